@@ -1,0 +1,130 @@
+"""Deterministic synthetic Tmall-shaped batches.
+
+Emits the 8-tuple GraphLoader yields (graph_loader.py:383) -- user_1hop
+[B,T,K,Fi], user_2hop [B,T,K,Fu], item_1hop [B,T,K,Fu], item_2hop [B,T,K,Fi],
+target_user [B,Fu], target_item [B,Fi], label [B], length [B] -- with the value
+distribution the loader produces: one shared id space (feateng_tmall.py:72-101:
+0 dummy, users, items, then categorical vocabularies), fixed per-entity side
+features, cyclic padding of short 1-hop lists (graph_loader.py:181-182), 2-hop
+draws with replacement (:192), all-zero dummy slices (:90-91), tail slices
+replicating the last real slice (:254-256), user-side tensors shared by a
+user's positive and negative candidate (:363-364).
+"""
+import numpy as np
+
+# categorical vocab sizes per config: item side then user side
+TMALL_ITEM_VOCABS = (1700, 5000, 8399)     # cat, seller, brand
+TMALL_USER_VOCABS = (9, 3)                 # age, gender
+
+
+def _zipf_cdf(n, s):
+    w = 1.0 / np.power(np.arange(1, n + 1, dtype=np.float64), s)
+    c = np.cumsum(w)
+    return c / c[-1]
+
+
+class SynthWorld(object):
+    def __init__(self, n_users, n_items, T, K, user_fnum=3, item_fnum=4,
+                 item_vocabs=TMALL_ITEM_VOCABS, user_vocabs=TMALL_USER_VOCABS, seed=1111):
+        assert len(item_vocabs) >= item_fnum - 1 and len(user_vocabs) >= user_fnum - 1
+        self.U, self.I, self.T, self.K = n_users, n_items, T, K
+        self.Fu, self.Fi = user_fnum, item_fnum
+        self.seed = seed
+        rng = np.random.Generator(np.random.PCG64(seed))
+        base = 1 + n_users + n_items
+        self.item_feat = np.zeros((n_items, item_fnum - 1), dtype=np.int32)
+        for j in range(item_fnum - 1):
+            v = item_vocabs[j]
+            self.item_feat[:, j] = base + np.searchsorted(_zipf_cdf(v, 1.0), rng.random(n_items))
+            base += v
+        self.user_feat = np.zeros((n_users, user_fnum - 1), dtype=np.int32)
+        for j in range(user_fnum - 1):
+            v = user_vocabs[j]
+            self.user_feat[:, j] = base + np.searchsorted(_zipf_cdf(v, 1.0), rng.random(n_users))
+            base += v
+        self.feature_size = base
+        self._ucdf = _zipf_cdf(n_users, 0.8)
+        self._icdf = _zipf_cdf(n_items, 0.8)
+
+    # entity index (0-based within type) -> feature row [id, side features...]
+    def _user_rows(self, u0):
+        u0 = np.asarray(u0)
+        return np.concatenate([(u0 + 1)[..., None].astype(np.int32), self.user_feat[u0]], axis=-1)
+
+    def _item_rows(self, i0):
+        i0 = np.asarray(i0)
+        return np.concatenate([(i0 + 1 + self.U)[..., None].astype(np.int32), self.item_feat[i0]], axis=-1)
+
+    def _history(self, rng, n_ent, hop1_is_item, length):
+        """[n_ent, T, K] 0-based neighbour picks for 1-hop and 2-hop, -1 = dummy."""
+        T, K = self.T, self.K
+        cdf1 = self._icdf if hop1_is_item else self._ucdf
+        cdf2 = self._ucdf if hop1_is_item else self._icdf
+        h1 = np.full((n_ent, T, K), -1, dtype=np.int64)
+        h2 = np.full((n_ent, T, K), -1, dtype=np.int64)
+        empty = rng.random((n_ent, length)) < 0.3
+        deg = np.minimum(K, rng.geometric(0.15, (n_ent, length)))
+        pool = rng.integers(1, 101, (n_ent, length))
+        for e in range(n_ent):
+            for t in range(length):
+                if empty[e, t]:
+                    continue
+                d = int(deg[e, t])
+                nb = np.unique(np.searchsorted(cdf1, rng.random(d)))
+                rng.shuffle(nb)
+                h1[e, t] = nb[np.arange(K) % len(nb)]            # cyclic pad
+                cand = np.searchsorted(cdf2, rng.random(int(pool[e, t])))
+                h2[e, t] = cand[rng.integers(0, len(cand), K)]   # with replacement
+        if length > 0:
+            h1[:, length:] = h1[:, length - 1:length]
+            h2[:, length:] = h2[:, length - 1:length]
+        return h1, h2
+
+    def _expand(self, picks, as_item):
+        """[.., K] 0-based picks (-1 dummy) -> [.., K, F] feature ids (0 for dummy)."""
+        safe = np.maximum(picks, 0)
+        rows = self._item_rows(safe) if as_item else self._user_rows(safe)
+        rows = rows.copy()
+        rows[picks < 0] = 0
+        return rows.astype(np.int32)
+
+    def batch(self, B, batch_idx=0, length=None, as_lists=False):
+        assert B % 2 == 0, "train batches hold one positive + one negative per user"
+        rng = np.random.Generator(np.random.PCG64([self.seed, 7919, batch_idx]))
+        T = self.T
+        length = max(T - 2, 1) if length is None else length
+        nu = B // 2
+        users = rng.integers(0, self.U, nu)
+        items = rng.integers(0, self.I, B)
+        u1, u2 = self._history(rng, nu, True, length)
+        i1, i2 = self._history(rng, B, False, length)
+        user_1hop = np.repeat(self._expand(u1, True), 2, axis=0)
+        user_2hop = np.repeat(self._expand(u2, False), 2, axis=0)
+        item_1hop = self._expand(i1, False)
+        item_2hop = self._expand(i2, True)
+        target_user = np.repeat(self._user_rows(users), 2, axis=0).astype(np.int32)
+        target_item = self._item_rows(items).astype(np.int32)
+        label = (np.arange(B) % 2 == 0).astype(np.int32)
+        length_arr = np.full((B,), length, dtype=np.int32)
+        out = (user_1hop, user_2hop, item_1hop, item_2hop, target_user, target_item, label, length_arr)
+        if as_lists:
+            out = tuple(a.tolist() for a in out)
+        return out
+
+
+CONFIGS = {
+    # name: (U, I, T, K, D, H, B, Fu, Fi, item_vocabs, user_vocabs)
+    "tiny": (40, 60, 3, 2, 4, 8, 4, 3, 4, (5, 7, 6), (4, 3)),
+    "cfg2": (100000, 50000, 10, 5, 16, 32, 256, 3, 4, (1500, 5000, 5000), (9, 3)),
+    "tmall_default": (424170, 1090390, 11, 10, 16, 32, 200, 3, 4, TMALL_ITEM_VOCABS, TMALL_USER_VOCABS),
+    "cfg3": (424170, 1090390, 20, 10, 64, 128, 1024, 3, 4, TMALL_ITEM_VOCABS, TMALL_USER_VOCABS),
+    "cfg5_taobao": (984080, 4049268, 50, 20, 128, 256, 4096, 1, 2, (9405,), ()),
+    "cfg5_tmall": (984080, 4049268, 50, 20, 128, 256, 4096, 3, 4, (3000, 3000, 3396), (6, 3)),
+}
+
+
+def make_world(name, seed=1111):
+    U, I, T, K, D, H, B, Fu, Fi, iv, uv = CONFIGS[name]
+    w = SynthWorld(U, I, T, K, Fu, Fi, iv, uv, seed)
+    return w, dict(feature_size=w.feature_size, eb_dim=D, hidden_size=H, max_time_len=T,
+                   obj_per_time_slice=K, user_fnum=Fu, item_fnum=Fi, batch=B)
