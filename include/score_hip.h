@@ -1,0 +1,190 @@
+/*
+ * score_hip.h -- C-ABI of libscore_hip.so: the MI355X (gfx950) implementation of
+ * the SCoRe forward/backward hot path (reference: qinjr/SCoRe code/score/score.py).
+ *
+ * The reference is pure Python on TensorFlow 1.x and has no FFI of its own
+ * ("Native components: NONE"); what a reference maintainer
+ * binds instead of `sess.run(...)` is this header (INTEGRATION.md shows the
+ * ctypes stub).  Each entry point cites the reference lines it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch tensors in
+ *     this repo); the library never allocates, frees or retains device memory;
+ *   - sizes are int64_t / int32_t, `stream` is a hipStream_t passed as void*;
+ *   - return value: 0 = ok, >0 = hipError_t, <0 = SCORE_E_* argument error;
+ *   - no global state: re-entrant across streams;
+ *   - all arithmetic is fp32, all indices int32 (score.py:21-30 placeholders);
+ *   - table row 0 is the dummy node and must be all-zero in `table`
+ *     (score.py:44-47 emb_mtx * mask): kernels rely on it and never update it.
+ */
+#ifndef SCORE_HIP_H
+#define SCORE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SCORE_E_BADARG   (-1)  /* null pointer / non-positive size               */
+#define SCORE_E_SHAPE    (-2)  /* shape outside what the kernels are built for   */
+#define SCORE_E_WORKSPACE (-3) /* workspace too small                            */
+
+/* model_type values (train_score.py:170-179 selects the class by name) */
+enum { SCORE_MODEL_SCORE = 0, SCORE_MODEL_RIA = 1, SCORE_MODEL_RCA = 2,
+       SCORE_MODEL_SCORE_USER = 3, SCORE_MODEL_SCORE_ITEM = 4 };
+
+/* Constructor arguments of SCOREBASE.__init__ (score.py:12-13). */
+typedef struct {
+  int64_t feature_size;        /* N: rows of emb_mtx                              */
+  int32_t eb_dim;              /* D: multiple of 4, <= 256                        */
+  int32_t hidden_size;         /* H                                               */
+  int32_t max_time_len;        /* T                                               */
+  int32_t obj_per_time_slice;  /* K <= 32                                         */
+  int32_t user_fnum;           /* Fu                                              */
+  int32_t item_fnum;           /* Fi                                              */
+  int32_t model_type;          /* SCORE_MODEL_*                                   */
+} score_config_t;
+
+/* One dense variable inside the flat parameter buffer (TF variable names,
+ * score.py graph-construction order). */
+typedef struct {
+  char    name[64];
+  int64_t offset;              /* in floats, into the flat buffer                 */
+  int32_t rows, cols;          /* cols == 0 for vectors                           */
+  int32_t regularised;         /* build_l2norm name filter, score.py:91-94        */
+  int32_t init;                /* 0 zeros, 1 ones, 2 glorot-uniform               */
+} score_param_entry_t;
+
+/* Layout of the flat dense-parameter buffer: regularised tensors first
+ * ([0, n_reg) floats), then biases.  Returns the number of entries (or <0). */
+int score_param_layout(const score_config_t* cfg, score_param_entry_t* out, int32_t max_entries,
+                       int64_t* n_floats, int64_t* n_reg_floats);
+
+/* The batch handed to SCOREBASE.train/eval (score.py:101-133, graph_loader.py:383),
+ * already on the device as row-major int32. */
+typedef struct {
+  const int32_t* user_1hop;    /* [B,T,K,Fi] */
+  const int32_t* user_2hop;    /* [B,T,K,Fu] */
+  const int32_t* item_1hop;    /* [B,T,K,Fu] */
+  const int32_t* item_2hop;    /* [B,T,K,Fi] */
+  const int32_t* target_user;  /* [B,Fu]     */
+  const int32_t* target_item;  /* [B,Fi]     */
+  const int32_t* label;        /* [B]        */
+  const int32_t* length;       /* [B]        */
+  int32_t B;
+} score_batch_t;
+
+/* Named float offsets into the workspace (for tests / introspection). */
+typedef struct {
+  int64_t total_bytes;
+  int64_t xside;      /* [2][B*T][Di+Du]  user_side, item_side (score.py:200-201) */
+  int64_t atten_info; /* [B*T][4K]        [info_item | info_user] (score.py:198)          */
+  int64_t rsave;      /* [2][B*T][K]      relu'd relateness r_i per co-attention  */
+  int64_t query;      /* [B][Du+Di]       [target_user, target_item] (:210)       */
+  int64_t head_inp;   /* [B][Dhead]       (:217)                                  */
+  int64_t att_score;  /* [B][T]           (:213)                                  */
+  int64_t logit;      /* [B]                                                      */
+  int64_t y_pred;     /* [B]              (:76)                                   */
+  int64_t loss;       /* [4]: loss, log_loss, l2, unused                          */
+  int64_t gru_out;    /* [2][B*T][H]      user_side_rep_t, item_side_rep_t        */
+  int64_t gru_final;  /* [2][B][H]        final states (RIA, score.py:244-247)    */
+} score_workspace_t;
+
+int score_workspace_layout(const score_config_t* cfg, int32_t B, score_workspace_t* out);
+
+/* ---- per-op entry points (each is also a stage of score_forward/backward) ---- */
+
+/* tf.nn.embedding_lookup + reshape (score.py:51-66): out[r, :] = table[idx[r], :].
+ * Bit-exact copy. n_idx rows of D floats. */
+int score_gather_fwd(const float* table, int64_t n_rows, int32_t D, const int32_t* idx,
+                     int64_t n_idx, float* out, void* stream);
+
+/* Fused gather + co_attention (score.py:147-167 in its exact collapsed form,
+ * SURVEY.md 8a A4) for ONE call: seq1/seq2 index tensors [BT,K,F], target rows
+ * gathered to tgt [B, F*D].  Writes seq1_result to out1 (row stride ld1),
+ * seq2_result to out2 (ld2), atten_info [BT,2K] into info (ldi) and r [BT,K]
+ * into rsave.  W = dense kernel [3*F*D], bias = [1].  mode 0 = co-attention,
+ * mode 1 = RCA's reduce_sum over K (score.py:266-269; W/bias/info/rsave unused). */
+int score_coattn_fwd(const float* table, int64_t n_rows, int32_t D, int32_t F, int32_t K,
+                     int32_t B, int32_t T, const int32_t* idx1, const int32_t* idx2,
+                     const float* tgt, const float* W, const float* bias,
+                     float* out1, int32_t ld1, float* out2, int32_t ld2,
+                     float* info, int32_t ldi, float* rsave, int32_t mode, void* stream);
+
+/* Backward of the above.  g1/g2/ginfo are the gradients of out1/out2/info with
+ * the same strides.  Scatter-adds row gradients into grad_table [n_rows, D]
+ * (row 0 skipped: mask, score.py:47), writes dzsum [BT] (sum_i dz_i, feeds the
+ * target-row / w_t / bias gradients) and accumulates dW[Dx..3Dx) into
+ * partial slabs reduced by the library into dW (+=). */
+int score_coattn_bwd(const float* table, float* grad_table, int64_t n_rows, int32_t D, int32_t F,
+                     int32_t K, int32_t B, int32_t T, const int32_t* idx1, const int32_t* idx2,
+                     const float* W, const float* rsave,
+                     const float* g1, int32_t ld1, const float* g2, int32_t ld2,
+                     const float* ginfo, int32_t ldi, float* dzsum, float* dW,
+                     float* scratch, int64_t scratch_floats, int32_t mode, void* stream);
+
+/* C[M,N] = epi(op(A) . op(B)) in exact fp32 (v_mfma_f32_32x32x2_f32).
+ * trans: 0 = A[M,K] B[K,N];  1 = A[M,K] B[N,K]^T;  2 = A[K,M]^T B[K,N] (K is the
+ * reduced dim).  flags: 1 add bias[N], 2 relu, 4 accumulate into C,
+ * 8 dropout (tf.nn.dropout: x/keep * mask; mask from drop_mask bytes or, if null,
+ * from a counter hash of drop_seed). scratch is used for split-K (trans 2). */
+int score_gemm(int32_t trans, int32_t M, int32_t N, int32_t K,
+               const float* A, int32_t lda, const float* Bm, int32_t ldb,
+               float* C, int32_t ldc, const float* bias, int32_t flags,
+               float keep_prob, const uint8_t* drop_mask, uint64_t drop_seed,
+               float* scratch, int64_t scratch_floats, void* stream);
+
+/* tf.nn.dynamic_rnn(GRUCell(H), sequence_length) recurrence (score.py:205-208)
+ * given the hoisted input projection xproj [B*T,3H] = x.[Wx_gates|Wx_cand]+bias.
+ * Wg/Wc point at the h-rows of gates/kernel [H,2H] and candidate/kernel [H,H].
+ * out [B*T, ldo] gets h_t (0 for t>=len), gates_save [B*T,3H] gets (r,u,c),
+ * final [B,H] the carried state. */
+int score_gru_fwd(int32_t B, int32_t T, int32_t H, const float* xproj, const float* Wg, int32_t ldwg,
+                  const float* Wc, int32_t ldwc, const int32_t* length,
+                  float* out, int32_t ldo, float* gates_save, float* final_state, void* stream);
+
+/* Backward recurrence: dout [B*T, lddo] (+ dfinal [B,H] or null) ->
+ * dxproj [B*T,3H] (pre-activation grads dr,du,dc), rh [B*T,H] = r*h_{t-1} and
+ * hprev [B*T,H] = h_{t-1}; `hprev` must have room for B*T*H + 3*H*H floats (its tail
+ * is scratch for the transposed recurrent weights). */
+int score_gru_bwd(int32_t B, int32_t T, int32_t H, const float* Wg, int32_t ldwg, const float* Wc,
+                  int32_t ldwc, const int32_t* length, const float* out, int32_t ldo,
+                  const float* gates_save, const float* dout, int32_t lddo, const float* dfinal,
+                  float* dxproj, float* rh, float* hprev, void* stream);
+
+/* tf.train.AdamOptimizer ApplyAdam (score.py:96-99), dense over n floats:
+ * g' = g + l2*p (first n_reg floats); m += (g'-m)(1-b1); v += (g'^2-v)(1-b2);
+ * p -= m*alpha/(sqrt(v)+eps).  alpha = lr*sqrt(1-b2^t)/(1-b1^t) from the host. */
+int score_adam(float* p, float* m, float* v, const float* g, int64_t n, int64_t n_reg,
+               float l2, float alpha, float beta1, float beta2, float eps, void* stream);
+
+/* ---- whole-path entry points --------------------------------------------- */
+
+typedef struct {
+  const float* table;   /* [n_table_rows, D] effective table (row 0 == 0)         */
+  int64_t n_table_rows;
+  const float* w;       /* flat dense parameters                                  */
+  float* workspace;     /* score_workspace_layout(...).total_bytes                */
+  int64_t workspace_bytes;
+} score_state_t;
+
+/* Forward of SCORE / RIA / RCA / SCORE_USER / SCORE_ITEM (score.py:188-369) +
+ * build_fc_net / build_logloss / build_l2norm (:68-94).  keep_prob 1.0 = eval
+ * (score.py:129), 0.8 = train (:113).  Results land in the workspace
+ * (y_pred, loss, ...). drop_mask0/1: optional explicit [B,200]/[B,80] byte masks. */
+int score_forward(const score_config_t* cfg, const score_state_t* st, const score_batch_t* batch,
+                  float reg_lambda, float keep_prob, const uint8_t* drop_mask0,
+                  const uint8_t* drop_mask1, uint64_t drop_seed, void* stream);
+
+/* Backward of the same graph: grad_w [n_floats] (overwritten; WITHOUT the L2
+ * term, which score_adam adds) and grad_table [n_table_rows, D] (must be zeroed
+ * by the caller; accumulated into).  Must follow score_forward on the same
+ * workspace/batch. */
+int score_backward(const score_config_t* cfg, const score_state_t* st, const score_batch_t* batch,
+                   float keep_prob, float* grad_w, float* grad_table, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCORE_HIP_H */

@@ -1,0 +1,125 @@
+"""ctypes binding of libscore_hip.so (include/score_hip.h).
+
+The HIP library is the product path: there is NO CPU or PyTorch fallback.  If the
+shared object is missing it is built in-tree with hipcc; if that fails, importing
+this module raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libscore_hip.so")
+
+MODEL_TYPES = {"SCORE": 0, "RIA": 1, "RCA": 2, "SCORE_USER": 3, "SCORE_ITEM": 4}
+
+c_f = C.c_void_p   # device float*
+c_i = C.c_void_p   # device int32*
+
+
+class Config(C.Structure):
+    _fields_ = [("feature_size", C.c_int64), ("eb_dim", C.c_int32), ("hidden_size", C.c_int32),
+                ("max_time_len", C.c_int32), ("obj_per_time_slice", C.c_int32),
+                ("user_fnum", C.c_int32), ("item_fnum", C.c_int32), ("model_type", C.c_int32)]
+
+
+class ParamEntry(C.Structure):
+    _fields_ = [("name", C.c_char * 64), ("offset", C.c_int64), ("rows", C.c_int32), ("cols", C.c_int32),
+                ("regularised", C.c_int32), ("init", C.c_int32)]
+
+
+class Batch(C.Structure):
+    _fields_ = [("user_1hop", c_i), ("user_2hop", c_i), ("item_1hop", c_i), ("item_2hop", c_i),
+                ("target_user", c_i), ("target_item", c_i), ("label", c_i), ("length", c_i),
+                ("B", C.c_int32)]
+
+
+class Workspace(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in
+                ("total_bytes", "xside", "atten_info", "rsave", "query", "head_inp", "att_score",
+                 "logit", "y_pred", "loss", "gru_out", "gru_final")]
+
+
+class State(C.Structure):
+    _fields_ = [("table", c_f), ("n_table_rows", C.c_int64), ("w", c_f), ("workspace", c_f),
+                ("workspace_bytes", C.c_int64)]
+
+
+_SIGS = {
+    "score_param_layout": [C.POINTER(Config), C.POINTER(ParamEntry), C.c_int32, C.POINTER(C.c_int64),
+                           C.POINTER(C.c_int64)],
+    "score_workspace_layout": [C.POINTER(Config), C.c_int32, C.POINTER(Workspace)],
+    "score_gather_fwd": [c_f, C.c_int64, C.c_int32, c_i, C.c_int64, c_f, C.c_void_p],
+    "score_coattn_fwd": [c_f, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_i, c_i,
+                         c_f, c_f, c_f, c_f, C.c_int32, c_f, C.c_int32, c_f, C.c_int32, c_f, C.c_int32,
+                         C.c_void_p],
+    "score_coattn_bwd": [c_f, c_f, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_i, c_i,
+                         c_f, c_f, c_f, C.c_int32, c_f, C.c_int32, c_f, C.c_int32, c_f, c_f, c_f, C.c_int64,
+                         C.c_int32, C.c_void_p],
+    "score_gemm": [C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_f, C.c_int32, c_f, C.c_int32, c_f, C.c_int32,
+                   c_f, C.c_int32, C.c_float, C.c_void_p, C.c_uint64, c_f, C.c_int64, C.c_void_p],
+    "score_gru_fwd": [C.c_int32, C.c_int32, C.c_int32, c_f, c_f, C.c_int32, c_f, C.c_int32, c_i, c_f, C.c_int32,
+                      c_f, c_f, C.c_void_p],
+    "score_gru_bwd": [C.c_int32, C.c_int32, C.c_int32, c_f, C.c_int32, c_f, C.c_int32, c_i, c_f, C.c_int32, c_f,
+                      c_f, C.c_int32, c_f, c_f, c_f, c_f, C.c_void_p],
+    "score_adam": [c_f, c_f, c_f, c_f, C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,
+                   C.c_float, C.c_void_p],
+    "score_forward": [C.POINTER(Config), C.POINTER(State), C.POINTER(Batch), C.c_float, C.c_float, C.c_void_p,
+                      C.c_void_p, C.c_uint64, C.c_void_p],
+    "score_backward": [C.POINTER(Config), C.POINTER(State), C.POINTER(Batch), C.c_float, c_f, c_f, C.c_void_p],
+}
+
+EXPORTS = tuple(_SIGS)
+_lib = None
+
+
+class ScoreHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (building first if needed) libscore_hip.so; raises if unavailable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        from . import build as _build
+        _build.build()
+    lib = C.CDLL(LIB_PATH)
+    for name, args in _SIGS.items():
+        fn = getattr(lib, name)      # AttributeError if a declared symbol is missing
+        fn.argtypes = args
+        fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        kinds = {-1: "bad argument", -2: "unsupported shape", -3: "workspace too small"}
+        raise ScoreHipError("%s failed: %s" % (what, kinds.get(rc, "hipError_t %d" % rc)))
+
+
+def make_config(feature_size, eb_dim, hidden_size, max_time_len, obj_per_time_slice, user_fnum, item_fnum,
+                model_type="SCORE"):
+    return Config(int(feature_size), int(eb_dim), int(hidden_size), int(max_time_len),
+                  int(obj_per_time_slice), int(user_fnum), int(item_fnum), MODEL_TYPES[model_type])
+
+
+def param_layout(cfg):
+    """-> (entries [(name, offset, rows, cols, regularised, init)], n_floats, n_reg)"""
+    lib = load()
+    arr = (ParamEntry * 32)()
+    nf, nr = C.c_int64(0), C.c_int64(0)
+    n = lib.score_param_layout(C.byref(cfg), arr, 32, C.byref(nf), C.byref(nr))
+    if n < 0:
+        check(n, "score_param_layout")
+    out = [(arr[i].name.decode(), arr[i].offset, arr[i].rows, arr[i].cols, arr[i].regularised, arr[i].init)
+           for i in range(n)]
+    return out, nf.value, nr.value
+
+
+def workspace_layout(cfg, B):
+    lib = load()
+    ws = Workspace()
+    check(lib.score_workspace_layout(C.byref(cfg), int(B), C.byref(ws)), "score_workspace_layout")
+    return ws

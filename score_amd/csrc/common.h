@@ -1,0 +1,59 @@
+// Shared device/host helpers for libscore_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/score_hip.h"
+
+#define SCORE_WAVE 64
+
+#define SCORE_CHECK_LAUNCH()                      \
+  do {                                            \
+    hipError_t e__ = hipGetLastError();           \
+    if (e__ != hipSuccess) return (int)e__;       \
+  } while (0)
+
+#define SCORE_TRY(expr)                           \
+  do {                                            \
+    int rc__ = (expr);                            \
+    if (rc__ != 0) return rc__;                   \
+  } while (0)
+
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int64_t align_up64(int64_t a, int64_t b) { return cdiv64(a, b) * b; }
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float dot4(float4 a, float4 b) {
+  return fmaf(a.w, b.w, fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)));
+}
+__device__ __forceinline__ float4 fma4(float s, float4 a, float4 acc) {
+  acc.x = fmaf(s, a.x, acc.x); acc.y = fmaf(s, a.y, acc.y);
+  acc.z = fmaf(s, a.z, acc.z); acc.w = fmaf(s, a.w, acc.w);
+  return acc;
+}
+__device__ __forceinline__ float4 add4(float4 a, float4 b) {
+  return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// sum over the `gs` (power of two <= 64) consecutive lanes of a group; every lane gets the sum
+__device__ __forceinline__ float group_sum(float v, int gs) {
+  for (int off = gs >> 1; off > 0; off >>= 1) v += __shfl_xor(v, off, SCORE_WAVE);
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) { return group_sum(v, SCORE_WAVE); }
+__device__ __forceinline__ float wave_max(float v) {
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, SCORE_WAVE));
+  return v;
+}
+
+// counter-based uniform in [0,1): splitmix64 finaliser of (seed, idx); same value
+// wherever and whenever it is evaluated, so backward never needs a stored mask.
+__device__ __forceinline__ float hash_uniform(uint64_t seed, uint64_t idx) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+

@@ -1,0 +1,616 @@
+// Embedding-table kernels: row gather, fused gather + co-attention forward/backward,
+// target-row gather/backward.  HBM-bound: every lane moves 16 B per load, all K
+// neighbour rows of a unit are issued before the first use.
+//
+// Mapping ("slot" = one float4 of the F*D-wide concatenated feature vector of a
+// neighbour, score.py:51-66 reshape): a GROUP of GS lanes (power of two, <= 64)
+// owns one (b,t) unit; lane gl owns slots gl, gl+GS, ... (SPL of them) and walks
+// the K neighbours in registers, so sums over K are sequential per lane (bitwise
+// reproducible) and only the K relateness scores cross lanes.
+#include "common.h"
+#include "kernels.h"
+
+// ------------------------------------------------------------------ plain gather (score.py:51-66)
+__global__ void gather_rows_kernel(const float* __restrict__ table, int D4, const int32_t* __restrict__ idx,
+                                   int64_t n_chunks, float* __restrict__ out) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n_chunks; i += stride) {
+    int64_t r = i / D4;
+    int c = (int)(i - r * D4);
+    int64_t row = idx[r];
+    st4(out + i * 4, ld4(table + (row * D4 + c) * 4));
+  }
+}
+
+extern "C" int score_gather_fwd(const float* table, int64_t n_rows, int32_t D, const int32_t* idx,
+                                int64_t n_idx, float* out, void* stream) {
+  if (!table || !idx || !out || n_rows <= 0 || n_idx < 0) return SCORE_E_BADARG;
+  if (D <= 0 || (D & 3)) return SCORE_E_SHAPE;
+  if (n_idx == 0) return 0;
+  int64_t n_chunks = n_idx * (D / 4);
+  int blocks = (int)(cdiv64(n_chunks, 256) < 4096 ? cdiv64(n_chunks, 256) : 4096);
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, table, D / 4, idx,
+                     n_chunks, out);
+  SCORE_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------ fused gather + co-attention
+struct CoattnGeom {
+  int GS;      // lanes per unit
+  int SPL;     // slots per lane
+  int nslots;  // F*D/4
+};
+
+static inline CoattnGeom coattn_geom(int D, int F) {
+  CoattnGeom g;
+  g.nslots = F * (D / 4);
+  int gs = 1;
+  while (gs < g.nslots && gs < 64) gs <<= 1;
+  g.GS = gs;
+  g.SPL = (g.nslots + gs - 1) / gs;
+  return g;
+}
+
+template <int KMAX, int SPL>
+__global__ __launch_bounds__(256) void coattn_fwd_kernel(
+    const float* __restrict__ table, int D4, int F, int K, int T, int n_units, int GS, int nslots,
+    const int32_t* __restrict__ idx1, const int32_t* __restrict__ idx2,
+    const float* __restrict__ tgt, int ldt, const float* __restrict__ W, const float* __restrict__ bias,
+    float* __restrict__ out1, int ld1, float* __restrict__ out2, int ld2,
+    float* __restrict__ info, int ldi, float* __restrict__ rsave, int mode) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int upw = 64 / GS;
+  const int gl = lane & (GS - 1);
+  const int unit = wave * upw + lane / GS;
+  const bool unit_ok = unit < n_units;
+  const int u = unit_ok ? unit : 0;  // clamp: inactive groups still take part in shuffles
+  const int Dx = nslots * 4;
+  const int D = D4 * 4;
+
+  bool ok[SPL];
+  int f[SPL], coff[SPL];
+  float4 w1[SPL], w2[SPL];
+#pragma unroll
+  for (int j = 0; j < SPL; ++j) {
+    int s = gl + j * GS;
+    ok[j] = unit_ok && s < nslots;
+    int sc = s < nslots ? s : 0;
+    f[j] = sc / D4;
+    coff[j] = (sc - f[j] * D4) * 4;
+    if (mode == 0) {
+      w1[j] = ld4(W + Dx + sc * 4);
+      w2[j] = ld4(W + 2 * Dx + sc * 4);
+    } else {
+      w1[j] = w2[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+
+  const int32_t* i1 = idx1 + (int64_t)u * K * F;
+  const int32_t* i2 = idx2 + (int64_t)u * K * F;
+  float4 v1[SPL][KMAX];
+  float4 sum2[SPL];
+  float part[KMAX];
+#pragma unroll
+  for (int j = 0; j < SPL; ++j) sum2[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) {
+    part[k] = 0.f;
+    if (k < K) {
+#pragma unroll
+      for (int j = 0; j < SPL; ++j) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+        if (ok[j]) {
+          int64_t r1 = i1[k * F + f[j]];
+          int64_t r2 = i2[k * F + f[j]];
+          a = ld4(table + r1 * D + coff[j]);
+          b = ld4(table + r2 * D + coff[j]);
+        }
+        v1[j][k] = a;
+        sum2[j] = add4(sum2[j], b);
+        part[k] += dot4(a, w1[j]) + dot4(b, w2[j]);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < SPL; ++j) v1[j][k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+
+  if (mode == 1) {  // RCA: reduce_sum over K (score.py:266-269)
+#pragma unroll
+    for (int j = 0; j < SPL; ++j) {
+      if (!ok[j]) continue;
+      float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k)
+        if (k < K) o = add4(o, v1[j][k]);
+      st4(out1 + (int64_t)u * ld1 + (gl + j * GS) * 4, o);
+      st4(out2 + (int64_t)u * ld2 + (gl + j * GS) * 4, sum2[j]);
+    }
+    return;
+  }
+
+  // c = w_t . target + bias (constant over t and i), then r_i = relu(part_i + c)
+  const int b_idx = u / T;
+  float cpart = 0.f;
+#pragma unroll
+  for (int j = 0; j < SPL; ++j)
+    if (ok[j]) cpart += dot4(ld4(tgt + (int64_t)b_idx * ldt + (gl + j * GS) * 4), ld4(W + (gl + j * GS) * 4));
+  const float c = group_sum(cpart, GS) + bias[0];
+  float r[KMAX];
+  float rmax = 0.f, rsum = 0.f;  // relu output >= 0
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) {
+    r[k] = 0.f;
+    if (k < K) {
+      r[k] = fmaxf(group_sum(part[k], GS) + c, 0.f);
+      rmax = fmaxf(rmax, r[k]);
+      rsum += r[k];
+    }
+  }
+  float p[KMAX];
+  float den = 0.f;
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) {
+    p[k] = (k < K) ? expf(r[k] - rmax) : 0.f;
+    den += p[k];
+  }
+  const float inv_den = 1.0f / den;
+#pragma unroll
+  for (int j = 0; j < SPL; ++j) {
+    if (!ok[j]) continue;
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+      if (k < K) o = fma4(p[k] * inv_den, v1[j][k], o);
+    st4(out1 + (int64_t)u * ld1 + (gl + j * GS) * 4, o);
+    const float fk = (float)K;
+    st4(out2 + (int64_t)u * ld2 + (gl + j * GS) * 4,
+        make_float4(sum2[j].x / fk, sum2[j].y / fk, sum2[j].z / fk, sum2[j].w / fk));
+  }
+  // atten_info = [K*r_0..K*r_{K-1}, sum_i r_i (K times)]  (score.py:165-166)
+  if (unit_ok) {
+    for (int i = gl; i < 2 * K; i += GS) {
+      float val = rsum;
+      float rv = 0.f;
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k)
+        if (i == k) rv = r[k];
+      if (i < K) {
+        val = (float)K * rv;
+        rsave[(int64_t)u * K + i] = rv;
+      }
+      info[(int64_t)u * ldi + i] = val;
+    }
+  }
+}
+
+template <int KMAX, int SPL>
+static int launch_coattn_fwd(const CoattnGeom& g, const float* table, int D, int F, int K, int B, int T,
+                             const int32_t* idx1, const int32_t* idx2, const float* tgt, int ldt,
+                             const float* W, const float* bias, float* out1, int ld1, float* out2, int ld2,
+                             float* info, int ldi, float* rsave, int mode, hipStream_t s) {
+  int n_units = B * T;
+  int upw = 64 / g.GS;
+  int64_t waves = cdiv64(n_units, upw);
+  int blocks = (int)cdiv64(waves, 4);
+  hipLaunchKernelGGL((coattn_fwd_kernel<KMAX, SPL>), dim3(blocks), dim3(256), 0, s, table, D / 4, F, K, T,
+                     n_units, g.GS, g.nslots, idx1, idx2, tgt, ldt, W, bias, out1, ld1, out2, ld2, info, ldi,
+                     rsave, mode);
+  SCORE_CHECK_LAUNCH();
+  return 0;
+}
+
+#define COATTN_DISPATCH(FN, ...)                                                         \
+  do {                                                                                   \
+    if (g.SPL == 1) {                                                                    \
+      if (K <= 4) return FN<4, 1>(__VA_ARGS__);                                          \
+      if (K <= 10) return FN<10, 1>(__VA_ARGS__);                                        \
+      if (K <= 20) return FN<20, 1>(__VA_ARGS__);                                        \
+      return FN<32, 1>(__VA_ARGS__);                                                     \
+    } else if (g.SPL == 2) {                                                             \
+      if (K <= 4) return FN<4, 2>(__VA_ARGS__);                                          \
+      if (K <= 10) return FN<10, 2>(__VA_ARGS__);                                        \
+      if (K <= 20) return FN<20, 2>(__VA_ARGS__);                                        \
+      return FN<32, 2>(__VA_ARGS__);                                                     \
+    } else if (g.SPL <= 4) {                                                             \
+      if (K <= 10) return FN<10, 4>(__VA_ARGS__);                                        \
+      if (K <= 20) return FN<20, 4>(__VA_ARGS__);                                        \
+      return SCORE_E_SHAPE;                                                              \
+    }                                                                                    \
+    return SCORE_E_SHAPE;                                                                \
+  } while (0)
+
+static int coattn_fwd_impl(const float* table, int D, int F, int K, int B, int T, const int32_t* idx1,
+                           const int32_t* idx2, const float* tgt, int ldt, const float* W, const float* bias,
+                           float* out1, int ld1, float* out2, int ld2, float* info, int ldi, float* rsave,
+                           int mode, hipStream_t s) {
+  CoattnGeom g = coattn_geom(D, F);
+  COATTN_DISPATCH(launch_coattn_fwd, g, table, D, F, K, B, T, idx1, idx2, tgt, ldt, W, bias, out1, ld1, out2,
+                  ld2, info, ldi, rsave, mode, s);
+}
+
+static int coattn_check(const void* table, int64_t n_rows, int D, int F, int K, int B, int T) {
+  if (!table || n_rows <= 0 || B <= 0 || T <= 0) return SCORE_E_BADARG;
+  if (D <= 0 || (D & 3) || D > 256 || F <= 0 || K <= 0 || K > 32) return SCORE_E_SHAPE;
+  if (F * (D / 4) > 256) return SCORE_E_SHAPE;
+  return 0;
+}
+
+// ABI wrapper; `tgt` is [B, F*D] contiguous here (the engine passes strided views internally)
+extern "C" int score_coattn_fwd(const float* table, int64_t n_rows, int32_t D, int32_t F, int32_t K,
+                                int32_t B, int32_t T, const int32_t* idx1, const int32_t* idx2,
+                                const float* tgt, const float* W, const float* bias, float* out1,
+                                int32_t ld1, float* out2, int32_t ld2, float* info, int32_t ldi,
+                                float* rsave, int32_t mode, void* stream) {
+  SCORE_TRY(coattn_check(table, n_rows, D, F, K, B, T));
+  if (!idx1 || !idx2 || !out1 || !out2) return SCORE_E_BADARG;
+  if (mode == 0 && (!tgt || !W || !bias || !info || !rsave)) return SCORE_E_BADARG;
+  if ((ld1 & 3) || (ld2 & 3)) return SCORE_E_SHAPE;
+  return coattn_fwd_impl(table, D, F, K, B, T, idx1, idx2, tgt, F * D, W, bias, out1, ld1, out2, ld2, info,
+                         ldi, rsave, mode, (hipStream_t)stream);
+}
+
+int score_coattn_fwd_strided(const float* table, int D, int F, int K, int B, int T, const int32_t* idx1,
+                             const int32_t* idx2, const float* tgt, int ldt, const float* W,
+                             const float* bias, float* out1, int ld1, float* out2, int ld2, float* info,
+                             int ldi, float* rsave, int mode, hipStream_t s) {
+  return coattn_fwd_impl(table, D, F, K, B, T, idx1, idx2, tgt, ldt, W, bias, out1, ld1, out2, ld2, info, ldi,
+                         rsave, mode, s);
+}
+
+// ------------------------------------------------------------------ backward
+// Per unit (collapsed form):
+//   dr_i  = K*ga_i + sum_j ga_{K+j} + p_i (dp_i - sum_k p_k dp_k),  dp_i = g1 . seq1_i
+//   dz_i  = dr_i * [r_i > 0]
+//   dseq1_i = p_i g1 + dz_i w1,   dseq2_i = g2/K + dz_i w2
+//   dw1 += sum_i dz_i seq1_i,  dw2 += sum_i dz_i seq2_i,  dzsum = sum_i dz_i
+template <int KMAX, int SPL>
+__global__ __launch_bounds__(256) void coattn_bwd_kernel(
+    const float* __restrict__ table, float* __restrict__ gtable, int D4, int F, int K, int n_units, int GS,
+    int nslots, const int32_t* __restrict__ idx1, const int32_t* __restrict__ idx2,
+    const float* __restrict__ W, const float* __restrict__ rsave, const float* __restrict__ g1p, int ld1,
+    const float* __restrict__ g2p, int ld2, const float* __restrict__ ginfo, int ldi,
+    float* __restrict__ dzsum, float* __restrict__ slab, int mode) {
+  extern __shared__ float lds[];  // [4 waves][upw][2*Dx]
+  const int lane = threadIdx.x & 63;
+  const int wib = threadIdx.x >> 6;
+  const int upw = 64 / GS;
+  const int gl = lane & (GS - 1);
+  const int grp = lane / GS;
+  const int Dx = nslots * 4;
+  const int D = D4 * 4;
+  const int waves_total = (gridDim.x * blockDim.x) >> 6;
+  const int wave0 = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+
+  bool sok[SPL];
+  int f[SPL], coff[SPL];
+  float4 w1[SPL], w2[SPL], dw1[SPL], dw2[SPL];
+#pragma unroll
+  for (int j = 0; j < SPL; ++j) {
+    int s = gl + j * GS;
+    sok[j] = s < nslots;
+    int sc = sok[j] ? s : 0;
+    f[j] = sc / D4;
+    coff[j] = (sc - f[j] * D4) * 4;
+    w1[j] = w2[j] = dw1[j] = dw2[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (mode == 0) {
+      w1[j] = ld4(W + Dx + sc * 4);
+      w2[j] = ld4(W + 2 * Dx + sc * 4);
+    }
+  }
+
+  const int n_iter = (n_units + waves_total * upw - 1) / (waves_total * upw);
+  for (int it = 0; it < n_iter; ++it) {
+    const int unit = (it * waves_total + wave0) * upw + grp;
+    const bool unit_ok = unit < n_units;
+    const int u = unit_ok ? unit : 0;
+    const int32_t* i1 = idx1 + (int64_t)u * K * F;
+    const int32_t* i2 = idx2 + (int64_t)u * K * F;
+    float4 g1[SPL], g2[SPL];
+    bool ok[SPL];
+#pragma unroll
+    for (int j = 0; j < SPL; ++j) {
+      ok[j] = unit_ok && sok[j];
+      g1[j] = g2[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ok[j]) {
+        g1[j] = ld4(g1p + (int64_t)u * ld1 + (gl + j * GS) * 4);
+        g2[j] = ld4(g2p + (int64_t)u * ld2 + (gl + j * GS) * 4);
+      }
+    }
+    if (mode == 1) {  // RCA: d(sum_k row_k) = g for every k
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) {
+#pragma unroll
+        for (int j = 0; j < SPL; ++j) {
+          if (!ok[j] || k >= K) continue;
+          int64_t r1 = i1[k * F + f[j]], r2 = i2[k * F + f[j]];
+          if (r1 != 0) {
+            float* d = gtable + r1 * D + coff[j];
+            atomicAdd(d, g1[j].x); atomicAdd(d + 1, g1[j].y); atomicAdd(d + 2, g1[j].z); atomicAdd(d + 3, g1[j].w);
+          }
+          if (r2 != 0) {
+            float* d = gtable + r2 * D + coff[j];
+            atomicAdd(d, g2[j].x); atomicAdd(d + 1, g2[j].y); atomicAdd(d + 2, g2[j].z); atomicAdd(d + 3, g2[j].w);
+          }
+        }
+      }
+      continue;
+    }
+
+    int32_t r1[SPL][KMAX], r2[SPL][KMAX];
+    float4 v1[SPL][KMAX];
+    float dp[KMAX];
+    // sum_k dz_k seq2_k needs dz first: keep the seq2 rows too
+    float4 v2[SPL][KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      dp[k] = 0.f;
+#pragma unroll
+      for (int j = 0; j < SPL; ++j) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+        int32_t ra = 0, rb = 0;
+        if (k < K && ok[j]) {
+          ra = i1[k * F + f[j]];
+          rb = i2[k * F + f[j]];
+          a = ld4(table + (int64_t)ra * D + coff[j]);
+          b = ld4(table + (int64_t)rb * D + coff[j]);
+        }
+        r1[j][k] = ra; r2[j][k] = rb;
+        v1[j][k] = a; v2[j][k] = b;
+        dp[k] += dot4(a, g1[j]);
+      }
+    }
+    // softmax from the saved relu'd scores
+    float r[KMAX], p[KMAX];
+    float rmax = 0.f, gsum = 0.f;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      r[k] = (k < K) ? rsave[(int64_t)u * K + k] : 0.f;
+      rmax = fmaxf(rmax, r[k]);
+      if (k < K) gsum += ginfo[(int64_t)u * ldi + K + k];
+    }
+    float den = 0.f;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      p[k] = (k < K) ? expf(r[k] - rmax) : 0.f;
+      den += p[k];
+    }
+    const float inv_den = 1.0f / den;
+    float pdp = 0.f;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      p[k] *= inv_den;
+      dp[k] = (k < K) ? group_sum(dp[k], GS) : 0.f;
+      pdp += p[k] * dp[k];
+    }
+    float dz[KMAX];
+    float dzs = 0.f;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      dz[k] = 0.f;
+      if (k < K) {
+        float dr = (float)K * ginfo[(int64_t)u * ldi + k] + gsum + p[k] * (dp[k] - pdp);
+        dz[k] = r[k] > 0.f ? dr : 0.f;
+        dzs += dz[k];
+      }
+    }
+    if (unit_ok && gl == 0) dzsum[u] = dzs;
+    const float invK = 1.0f / (float)K;
+#pragma unroll
+    for (int j = 0; j < SPL; ++j) {
+      if (!ok[j]) continue;
+      float4 g2k = make_float4(g2[j].x * invK, g2[j].y * invK, g2[j].z * invK, g2[j].w * invK);
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) {
+        if (k >= K) continue;
+        dw1[j] = fma4(dz[k], v1[j][k], dw1[j]);
+        dw2[j] = fma4(dz[k], v2[j][k], dw2[j]);
+        if (r1[j][k] != 0) {
+          float4 d1 = fma4(dz[k], w1[j], make_float4(p[k] * g1[j].x, p[k] * g1[j].y, p[k] * g1[j].z, p[k] * g1[j].w));
+          float* d = gtable + (int64_t)r1[j][k] * D + coff[j];
+          atomicAdd(d, d1.x); atomicAdd(d + 1, d1.y); atomicAdd(d + 2, d1.z); atomicAdd(d + 3, d1.w);
+        }
+        if (r2[j][k] != 0) {
+          float4 d2 = fma4(dz[k], w2[j], g2k);
+          float* d = gtable + (int64_t)r2[j][k] * D + coff[j];
+          atomicAdd(d, d2.x); atomicAdd(d + 1, d2.y); atomicAdd(d + 2, d2.z); atomicAdd(d + 3, d2.w);
+        }
+      }
+    }
+  }
+  if (mode == 1) return;
+  // block-level reduction of (dw1, dw2) -> slab[block][2*Dx], fixed order
+  float* mine = lds + ((wib * upw + grp) * 2) * Dx;
+#pragma unroll
+  for (int j = 0; j < SPL; ++j) {
+    if (!sok[j]) continue;
+    st4(mine + (gl + j * GS) * 4, dw1[j]);
+    st4(mine + Dx + (gl + j * GS) * 4, dw2[j]);
+  }
+  __syncthreads();
+  const int nsrc = 4 * upw;
+  for (int e = threadIdx.x; e < 2 * Dx; e += blockDim.x) {
+    float s = 0.f;
+    for (int q = 0; q < nsrc; ++q) s += lds[q * 2 * Dx + e];
+    slab[(int64_t)blockIdx.x * 2 * Dx + e] = s;
+  }
+}
+
+// out[e] += sum_b slab[b][e]   (fixed order: deterministic)
+__global__ void slab_reduce_kernel(const float* __restrict__ slab, int nslabs, int width, float* __restrict__ out,
+                                   int accumulate) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= width) return;
+  float s = 0.f;
+  for (int b = 0; b < nslabs; ++b) s += slab[(int64_t)b * width + e];
+  out[e] = accumulate ? out[e] + s : s;
+}
+
+template <int KMAX, int SPL>
+static int launch_coattn_bwd(const CoattnGeom& g, const float* table, float* gtable, int D, int F, int K, int B,
+                             int T, const int32_t* idx1, const int32_t* idx2, const float* W, const float* rsave,
+                             const float* g1, int ld1, const float* g2, int ld2, const float* ginfo, int ldi,
+                             float* dzsum, float* dW, float* scratch, int64_t scratch_floats, int mode,
+                             hipStream_t s) {
+  int n_units = B * T;
+  int upw = 64 / g.GS;
+  int Dx = g.nslots * 4;
+  int64_t waves = cdiv64(n_units, upw);
+  int blocks = (int)cdiv64(waves, 4);
+  if (blocks > 1024) blocks = 1024;
+  if (mode == 0 && (int64_t)blocks * 2 * Dx > scratch_floats) return SCORE_E_WORKSPACE;
+  size_t lds_bytes = (size_t)4 * upw * 2 * Dx * sizeof(float);
+  hipLaunchKernelGGL((coattn_bwd_kernel<KMAX, SPL>), dim3(blocks), dim3(256), lds_bytes, s, table, gtable, D / 4,
+                     F, K, n_units, g.GS, g.nslots, idx1, idx2, W, rsave, g1, ld1, g2, ld2, ginfo, ldi, dzsum,
+                     scratch, mode);
+  SCORE_CHECK_LAUNCH();
+  if (mode == 0) {
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((2 * Dx + 255) / 256), dim3(256), 0, s, scratch, blocks, 2 * Dx,
+                       dW + Dx, 1);
+    SCORE_CHECK_LAUNCH();
+  }
+  return 0;
+}
+
+extern "C" int score_coattn_bwd(const float* table, float* grad_table, int64_t n_rows, int32_t D, int32_t F,
+                                int32_t K, int32_t B, int32_t T, const int32_t* idx1, const int32_t* idx2,
+                                const float* W, const float* rsave, const float* g1, int32_t ld1,
+                                const float* g2, int32_t ld2, const float* ginfo, int32_t ldi, float* dzsum,
+                                float* dW, float* scratch, int64_t scratch_floats, int32_t mode, void* stream) {
+  SCORE_TRY(coattn_check(table, n_rows, D, F, K, B, T));
+  if (!grad_table || !idx1 || !idx2 || !g1 || !g2) return SCORE_E_BADARG;
+  if (mode == 0 && (!W || !rsave || !ginfo || !dzsum || !dW || !scratch)) return SCORE_E_BADARG;
+  if ((ld1 & 3) || (ld2 & 3)) return SCORE_E_SHAPE;
+  CoattnGeom g = coattn_geom(D, F);
+  COATTN_DISPATCH(launch_coattn_bwd, g, table, grad_table, D, F, K, B, T, idx1, idx2, W, rsave, g1, ld1, g2, ld2,
+                  ginfo, ldi, dzsum, dW, scratch, scratch_floats, mode, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------ target rows (score.py:62-66, 210, 217)
+__global__ void target_fwd_kernel(const float* __restrict__ table, int D4, int Fu, int Fi, int B,
+                                  const int32_t* __restrict__ tu, const int32_t* __restrict__ ti,
+                                  float* __restrict__ query, int ldq, float* __restrict__ head, int ldh,
+                                  int off_ti, int off_tu) {
+  const int cu = Fu * D4, ci = Fi * D4;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)B * (cu + ci)) return;
+  int b = (int)(i / (cu + ci));
+  int s = (int)(i - (int64_t)b * (cu + ci));
+  if (s < cu) {  // target_user slot
+    int fidx = s / D4, c = s - fidx * D4;
+    float4 v = ld4(table + ((int64_t)tu[b * Fu + fidx] * D4 + c) * 4);
+    if (query) st4(query + (int64_t)b * ldq + s * 4, v);
+    st4(head + (int64_t)b * ldh + off_tu + s * 4, v);
+  } else {
+    int s2 = s - cu;
+    int fidx = s2 / D4, c = s2 - fidx * D4;
+    float4 v = ld4(table + ((int64_t)ti[b * Fi + fidx] * D4 + c) * 4);
+    if (query) st4(query + (int64_t)b * ldq + cu * 4 + s2 * 4, v);
+    st4(head + (int64_t)b * ldh + off_ti + s2 * 4, v);
+  }
+}
+
+int score_launch_target_fwd(const float* table, int D, int Fu, int Fi, int B, const int32_t* tu,
+                            const int32_t* ti, float* query, int ldq, float* head, int ldh, int off_ti,
+                            int off_tu, hipStream_t s) {
+  int64_t n = (int64_t)B * (Fu + Fi) * (D / 4);
+  hipLaunchKernelGGL(target_fwd_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, s, table, D / 4, Fu, Fi, B,
+                     tu, ti, query, ldq, head, ldh, off_ti, off_tu);
+  SCORE_CHECK_LAUNCH();
+  return 0;
+}
+
+// S[c][b] = sum_t dzsum_c[b*T+t]
+__global__ void dzsum_reduce_kernel(const float* __restrict__ dz1, const float* __restrict__ dz2, int B, int T,
+                                    float* __restrict__ S) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2 * B) return;
+  const float* src = i < B ? dz1 : dz2;
+  int b = i < B ? i : i - B;
+  float s = 0.f;
+  if (src)
+    for (int t = 0; t < T; ++t) s += src[(int64_t)b * T + t];
+  S[i] = s;
+}
+
+// d target rows = dquery + dhead + S * w_t ; scatter-add into the table gradient
+__global__ void target_bwd_kernel(float* __restrict__ gtable, int D4, int Fu, int Fi, int B,
+                                  const int32_t* __restrict__ tu, const int32_t* __restrict__ ti,
+                                  const float* __restrict__ dquery, int ldq, const float* __restrict__ dhead,
+                                  int ldh, int off_ti, int off_tu, const float* __restrict__ W1,
+                                  const float* __restrict__ W2, const float* __restrict__ S) {
+  const int cu = Fu * D4, ci = Fi * D4;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)B * (cu + ci)) return;
+  int b = (int)(i / (cu + ci));
+  int s = (int)(i - (int64_t)b * (cu + ci));
+  float4 g;
+  int64_t row;
+  int c;
+  if (s < cu) {
+    int fidx = s / D4;
+    c = s - fidx * D4;
+    row = tu[b * Fu + fidx];
+    g = ld4(dhead + (int64_t)b * ldh + off_tu + s * 4);
+    if (dquery) g = add4(g, ld4(dquery + (int64_t)b * ldq + s * 4));
+    if (W2) g = fma4(S[B + b], ld4(W2 + s * 4), g);  // co-attention 2 targets the user (score.py:197)
+  } else {
+    int s2 = s - cu;
+    int fidx = s2 / D4;
+    c = s2 - fidx * D4;
+    row = ti[b * Fi + fidx];
+    g = ld4(dhead + (int64_t)b * ldh + off_ti + s2 * 4);
+    if (dquery) g = add4(g, ld4(dquery + (int64_t)b * ldq + cu * 4 + s2 * 4));
+    if (W1) g = fma4(S[b], ld4(W1 + s2 * 4), g);     // co-attention 1 targets the item (score.py:196)
+  }
+  if (row != 0) {
+    float* d = gtable + (row * D4 + c) * 4;
+    atomicAdd(d, g.x); atomicAdd(d + 1, g.y); atomicAdd(d + 2, g.z); atomicAdd(d + 3, g.w);
+  }
+}
+
+// dW_t[e] = sum_b S[b] * tgt[b][e];  dbias = sum_b S[b]     (one block per co-attention)
+__global__ void wt_grad_kernel(const float* __restrict__ query, int ldq, int Du, int Di, int B,
+                               const float* __restrict__ S, float* dW1, float* dB1, float* dW2, float* dB2) {
+  const int call = blockIdx.x;  // 0: item target (cols Du..Du+Di of query), 1: user target (cols 0..Du)
+  const int Dx = call == 0 ? Di : Du;
+  const int off = call == 0 ? Du : 0;
+  const float* Sc = S + (call == 0 ? 0 : B);
+  float* dW = call == 0 ? dW1 : dW2;
+  float* dB = call == 0 ? dB1 : dB2;
+  for (int e = threadIdx.x; e < Dx; e += blockDim.x) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s = fmaf(Sc[b], query[(int64_t)b * ldq + off + e], s);
+    dW[e] = s;
+  }
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += Sc[b];
+    dB[0] = s;
+  }
+}
+
+int score_launch_target_bwd(float* grad_table, int D, int Fu, int Fi, int B, int T, const int32_t* tu,
+                            const int32_t* ti, const float* dquery, int ldq, const float* dhead, int ldh,
+                            int off_ti, int off_tu, const float* query, const float* W1, const float* W2,
+                            const float* dzsum1, const float* dzsum2, float* S, float* dW1, float* dB1,
+                            float* dW2, float* dB2, hipStream_t s) {
+  const bool coattn = W1 != nullptr;
+  if (coattn) {
+    hipLaunchKernelGGL(dzsum_reduce_kernel, dim3((2 * B + 255) / 256), dim3(256), 0, s, dzsum1, dzsum2, B, T, S);
+    SCORE_CHECK_LAUNCH();
+  }
+  int64_t n = (int64_t)B * (Fu + Fi) * (D / 4);
+  hipLaunchKernelGGL(target_bwd_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, s, grad_table, D / 4, Fu,
+                     Fi, B, tu, ti, dquery, ldq, dhead, ldh, off_ti, off_tu, W1, W2, S);
+  SCORE_CHECK_LAUNCH();
+  if (coattn) {
+    hipLaunchKernelGGL(wt_grad_kernel, dim3(2), dim3(256), 0, s, query, ldq, Fu * D, Fi * D, B, S, dW1, dB1, dW2,
+                       dB2);
+    SCORE_CHECK_LAUNCH();
+  }
+  return 0;
+}

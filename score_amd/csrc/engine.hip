@@ -1,0 +1,409 @@
+// Whole-path orchestration: parameter/workspace layout and the forward / backward
+// launch sequences of SCORE and its ablations (score.py:188-369) on one stream.
+// Host code only; every kernel lives in embed/gemm/gru/head.hip.
+#include <string.h>
+#include <stdio.h>
+#include <math.h>
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+enum { GF_BIAS = 1, GF_RELU = 2, GF_ACC = 4, GF_DROP = 8 };
+const int FC1 = 200, FC2 = 80, AT1 = 80, AT2 = 40;
+
+struct Dims {
+  int64_t N;
+  int D, H, T, K, Fu, Fi, mt;
+  int Du, Di, I, Dq, NI, Dk, Dhead, nstate;
+  bool coattn, attn;
+  int off_u, off_i, off_ti, off_tu;  // columns of head_inp
+};
+
+int make_dims(const score_config_t* c, Dims* d) {
+  if (!c) return SCORE_E_BADARG;
+  d->N = c->feature_size; d->D = c->eb_dim; d->H = c->hidden_size; d->T = c->max_time_len;
+  d->K = c->obj_per_time_slice; d->Fu = c->user_fnum; d->Fi = c->item_fnum; d->mt = c->model_type;
+  if (d->N <= 0 || d->D <= 0 || (d->D & 3) || d->D > 256 || d->H <= 0 || d->T <= 0 || d->K <= 0 || d->K > 32 ||
+      d->Fu <= 0 || d->Fi <= 0 || d->mt < 0 || d->mt > 4)
+    return SCORE_E_SHAPE;
+  d->Du = d->Fu * d->D; d->Di = d->Fi * d->D; d->I = d->Di + d->Du; d->Dq = d->Du + d->Di;
+  d->coattn = d->mt != SCORE_MODEL_RCA;
+  d->attn = d->mt != SCORE_MODEL_RIA;
+  d->NI = (d->mt == SCORE_MODEL_RCA || d->mt == SCORE_MODEL_RIA) ? 0 : 4 * d->K;
+  d->Dk = d->attn ? 2 * d->H + d->NI : 0;
+  d->nstate = (d->mt == SCORE_MODEL_SCORE_USER || d->mt == SCORE_MODEL_SCORE_ITEM) ? 1 : 2;
+  d->Dhead = d->nstate * d->H + d->Di + d->Du;
+  d->off_u = d->mt == SCORE_MODEL_SCORE_ITEM ? -1 : 0;
+  d->off_i = d->mt == SCORE_MODEL_SCORE_USER ? -1 : (d->mt == SCORE_MODEL_SCORE_ITEM ? 0 : d->H);
+  d->off_ti = d->nstate * d->H;       // [..., target_item, target_user]  (score.py:217)
+  d->off_tu = d->off_ti + d->Di;
+  return 0;
+}
+
+// ---------------------------------------------------------------- dense parameter layout
+struct PEntry { const char* name; int rows, cols, reg, init; };
+
+struct Params {  // float offsets into the flat buffer
+  int64_t ca_w[2], ca_b[2];
+  int64_t gk[2], gb[2], ck[2], cb[2];  // gates/candidate kernel/bias per GRU (0 user side, 1 item side)
+  int64_t at_w[4], at_b[4];
+  int64_t bn_g, bn_b, fc_w[3], fc_b[3];
+  int64_t n_floats, n_reg;
+};
+
+int build_layout(const Dims& d, score_param_entry_t* out, int max_entries, Params* P) {
+  // TF creation order (score.py:188-224): co_attention denses, GRU cells, attention denses, bn1, fc1-3
+  char names[32][64];
+  int rows[32], cols[32], reg[32], init[32];
+  int n = 0, nd = 0;
+  auto add = [&](const char* nm, int r, int c, int rg, int in) {
+    snprintf(names[n], 64, "%s", nm);
+    rows[n] = r; cols[n] = c; reg[n] = rg; init[n] = in; ++n;
+  };
+  auto dense = [&](int i, int o) {
+    char b[64];
+    if (nd == 0) snprintf(b, 64, "dense"); else snprintf(b, 64, "dense_%d", nd);
+    ++nd;
+    char k[64], bb[64];
+    snprintf(k, 64, "%s/kernel", b); snprintf(bb, 64, "%s/bias", b);
+    add(k, i, o, 1, 2); add(bb, o, 0, 0, 0);
+  };
+  if (d.coattn) { dense(3 * d.Di, 1); dense(3 * d.Du, 1); }
+  const char* sides[2] = {"gru_user_side", "gru_item_side"};
+  for (int s = 0; s < 2; ++s) {
+    char b[64];
+    snprintf(b, 64, "%s/gru_cell/gates/kernel", sides[s]); add(b, d.I + d.H, 2 * d.H, 1, 2);
+    snprintf(b, 64, "%s/gru_cell/gates/bias", sides[s]); add(b, 2 * d.H, 0, 0, 1);
+    snprintf(b, 64, "%s/gru_cell/candidate/kernel", sides[s]); add(b, d.I + d.H, d.H, 1, 2);
+    snprintf(b, 64, "%s/gru_cell/candidate/bias", sides[s]); add(b, d.H, 0, 0, 0);
+  }
+  if (d.attn) { dense(d.Dq, d.Dk); dense(4 * d.Dk, AT1); dense(AT1, AT2); dense(AT2, 1); }
+  add("bn1/gamma", d.Dhead, 0, 1, 1);
+  add("bn1/beta", d.Dhead, 0, 1, 0);
+  add("fc1/kernel", d.Dhead, FC1, 1, 2); add("fc1/bias", FC1, 0, 0, 0);
+  add("fc2/kernel", FC1, FC2, 1, 2); add("fc2/bias", FC2, 0, 0, 0);
+  add("fc3/kernel", FC2, 1, 1, 2); add("fc3/bias", 1, 0, 0, 0);
+  // offsets: regularised tensors first, then the rest; every tensor 16-B aligned.  The
+  // regularised region is padded with zeros that stay zero (zero grad, zero l2 term).
+  int64_t off[32];
+  int64_t cur = 0;
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int i = 0; i < n; ++i) {
+      if ((reg[i] != 0) != (pass == 0)) continue;
+      off[i] = cur;
+      int64_t sz = (int64_t)rows[i] * (cols[i] ? cols[i] : 1);
+      cur = align_up64(cur + sz, 4);
+    }
+    if (pass == 0) P->n_reg = cur;
+  }
+  P->n_floats = cur;
+  if (out) {
+    if (n > max_entries) return SCORE_E_BADARG;
+    for (int i = 0; i < n; ++i) {
+      memset(&out[i], 0, sizeof(out[i]));
+      snprintf(out[i].name, 64, "%s", names[i]);
+      out[i].offset = off[i]; out[i].rows = rows[i]; out[i].cols = cols[i];
+      out[i].regularised = reg[i]; out[i].init = init[i];
+    }
+  }
+  int i = 0;
+  if (d.coattn) { for (int c = 0; c < 2; ++c) { P->ca_w[c] = off[i++]; P->ca_b[c] = off[i++]; } }
+  for (int s = 0; s < 2; ++s) { P->gk[s] = off[i++]; P->gb[s] = off[i++]; P->ck[s] = off[i++]; P->cb[s] = off[i++]; }
+  if (d.attn) { for (int a = 0; a < 4; ++a) { P->at_w[a] = off[i++]; P->at_b[a] = off[i++]; } }
+  P->bn_g = off[i++]; P->bn_b = off[i++];
+  for (int f = 0; f < 3; ++f) { P->fc_w[f] = off[i++]; P->fc_b[f] = off[i++]; }
+  return n;
+}
+
+// ---------------------------------------------------------------- workspace layout (float offsets)
+struct WS {
+  int64_t xside[2], info, rsave[2], query, head_inp, att_score, logit, y_pred, loss;
+  int64_t gru_out[2], gru_final[2], xproj[2], gates[2];
+  int64_t q, ainp, a1, a2, bn, f1, f2, lossb, dlogit, part;
+  // backward
+  int64_t dz2, dz1, dbn, dhead, ds, da2, da1, dainp, dgru[2], dinfo, dq, dquery, dfinal[2];
+  int64_t dxproj, rh, hprev, dxside[2], dzsum[2], S, scratch;
+  int64_t scratch_floats, total;
+};
+
+void build_ws(const Dims& d, int B, WS* w) {
+  int64_t cur = 0;
+  auto take = [&](int64_t n) { int64_t o = cur; cur = align_up64(cur + (n > 0 ? n : 4), 4); return o; };
+  const int64_t BT = (int64_t)B * d.T;
+  for (int s = 0; s < 2; ++s) w->xside[s] = take(BT * d.I);
+  w->info = take(BT * 4 * d.K);
+  for (int c = 0; c < 2; ++c) w->rsave[c] = take(BT * d.K);
+  w->query = take((int64_t)B * d.Dq);
+  w->head_inp = take((int64_t)B * d.Dhead);
+  w->att_score = take(BT);
+  w->logit = take(B); w->y_pred = take(B); w->loss = take(4);
+  for (int s = 0; s < 2; ++s) w->gru_out[s] = take(BT * d.H);
+  for (int s = 0; s < 2; ++s) w->gru_final[s] = take((int64_t)B * d.H);
+  for (int s = 0; s < 2; ++s) w->xproj[s] = take(BT * 3 * d.H);
+  for (int s = 0; s < 2; ++s) w->gates[s] = take(BT * 3 * d.H);
+  w->q = take((int64_t)B * d.Dk);
+  w->ainp = take(BT * 4 * d.Dk);
+  w->a1 = take(BT * AT1); w->a2 = take(BT * AT2);
+  w->bn = take((int64_t)B * d.Dhead);
+  w->f1 = take((int64_t)B * FC1); w->f2 = take((int64_t)B * FC2);
+  w->lossb = take(B); w->dlogit = take(B); w->part = take(64);
+  w->dz2 = take((int64_t)B * FC2); w->dz1 = take((int64_t)B * FC1);
+  w->dbn = take((int64_t)B * d.Dhead); w->dhead = take((int64_t)B * d.Dhead);
+  w->ds = take(BT); w->da2 = take(BT * AT2); w->da1 = take(BT * AT1);
+  w->dainp = take(BT * 4 * d.Dk);
+  for (int s = 0; s < 2; ++s) w->dgru[s] = take(BT * d.H);
+  w->dinfo = take(BT * 4 * d.K);
+  w->dq = take((int64_t)B * d.Dk); w->dquery = take((int64_t)B * d.Dq);
+  for (int s = 0; s < 2; ++s) w->dfinal[s] = take((int64_t)B * d.H);
+  w->dxproj = take(BT * 3 * d.H);
+  w->rh = take(BT * d.H);
+  w->hprev = take(BT * d.H + 3 * (int64_t)d.H * d.H);
+  for (int s = 0; s < 2; ++s) w->dxside[s] = take(BT * d.I);
+  for (int c = 0; c < 2; ++c) w->dzsum[c] = take(BT);
+  w->S = take(2 * (int64_t)B);
+  w->scratch_floats = 4 << 20;
+  w->scratch = take(w->scratch_floats);
+  w->total = cur;
+}
+
+#define G(call) SCORE_TRY(call)
+
+}  // namespace
+
+extern "C" int score_param_layout(const score_config_t* cfg, score_param_entry_t* out, int32_t max_entries,
+                                  int64_t* n_floats, int64_t* n_reg_floats) {
+  Dims d;
+  SCORE_TRY(make_dims(cfg, &d));
+  Params P;
+  int n = build_layout(d, out, max_entries, &P);
+  if (n < 0) return n;
+  if (n_floats) *n_floats = P.n_floats;
+  if (n_reg_floats) *n_reg_floats = P.n_reg;
+  return n;
+}
+
+extern "C" int score_workspace_layout(const score_config_t* cfg, int32_t B, score_workspace_t* out) {
+  Dims d;
+  SCORE_TRY(make_dims(cfg, &d));
+  if (B <= 0 || !out) return SCORE_E_BADARG;
+  WS w;
+  build_ws(d, B, &w);
+  out->total_bytes = w.total * 4;
+  out->xside = w.xside[0]; out->atten_info = w.info; out->rsave = w.rsave[0]; out->query = w.query;
+  out->head_inp = w.head_inp; out->att_score = w.att_score; out->logit = w.logit; out->y_pred = w.y_pred;
+  out->loss = w.loss; out->gru_out = w.gru_out[0]; out->gru_final = w.gru_final[0];
+  return 0;
+}
+
+extern "C" int score_forward(const score_config_t* cfg, const score_state_t* st, const score_batch_t* bt,
+                             float reg_lambda, float keep_prob, const uint8_t* drop_mask0,
+                             const uint8_t* drop_mask1, uint64_t drop_seed, void* stream) {
+  Dims d;
+  SCORE_TRY(make_dims(cfg, &d));
+  if (!st || !bt || !st->table || !st->w || !st->workspace || bt->B <= 0) return SCORE_E_BADARG;
+  if (!bt->user_1hop || !bt->user_2hop || !bt->item_1hop || !bt->item_2hop || !bt->target_user ||
+      !bt->target_item || !bt->label || !bt->length)
+    return SCORE_E_BADARG;
+  if (!(keep_prob > 0.f) || keep_prob > 1.f) return SCORE_E_BADARG;
+  Params P;
+  build_layout(d, nullptr, 0, &P);
+  const int B = bt->B, T = d.T, H = d.H, BT = B * T;
+  WS w;
+  build_ws(d, B, &w);
+  if (w.total * 4 > st->workspace_bytes) return SCORE_E_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  float* ws = st->workspace;
+  const float* W = st->w;
+  float* scratch = ws + w.scratch;
+
+  // target rows -> query [tu | ti] and head_inp [.., ti, tu]      (score.py:62-66, 210, 217)
+  G(score_launch_target_fwd(st->table, d.D, d.Fu, d.Fi, B, bt->target_user, bt->target_item, ws + w.query, d.Dq,
+                            ws + w.head_inp, d.Dhead, d.off_ti, d.off_tu, s));
+  // co-attention 1: (user_1hop, item_2hop, target_item) ; 2: (user_2hop, item_1hop, target_user)  (:196-197)
+  // user_side = [user_1hop_seq | user_2hop_seq], item_side = [item_1hop_seq | item_2hop_seq]   (:200-201)
+  const int mode = d.coattn ? 0 : 1;
+  const int ldi = 4 * d.K;
+  G(score_coattn_fwd_strided(st->table, d.D, d.Fi, d.K, B, T, bt->user_1hop, bt->item_2hop, ws + w.query + d.Du,
+                             d.Dq, d.coattn ? W + P.ca_w[0] : nullptr, d.coattn ? W + P.ca_b[0] : nullptr,
+                             ws + w.xside[0], d.I, ws + w.xside[1] + d.Du, d.I, ws + w.info, ldi, ws + w.rsave[0],
+                             mode, s));
+  G(score_coattn_fwd_strided(st->table, d.D, d.Fu, d.K, B, T, bt->user_2hop, bt->item_1hop, ws + w.query, d.Dq,
+                             d.coattn ? W + P.ca_w[1] : nullptr, d.coattn ? W + P.ca_b[1] : nullptr,
+                             ws + w.xside[0] + d.Di, d.I, ws + w.xside[1], d.I, ws + w.info + 2 * d.K, ldi,
+                             ws + w.rsave[1], mode, s));
+  // GRUs (:205-208): hoisted x-projection, then the persistent recurrence
+  for (int sd = 0; sd < 2; ++sd) {
+    float* xp = ws + w.xproj[sd];
+    G(score_gemm(0, BT, 2 * H, d.I, ws + w.xside[sd], d.I, W + P.gk[sd], 2 * H, xp, 3 * H, W + P.gb[sd], GF_BIAS,
+                 1.f, nullptr, 0, scratch, w.scratch_floats, s));
+    G(score_gemm(0, BT, H, d.I, ws + w.xside[sd], d.I, W + P.ck[sd], H, xp + 2 * H, 3 * H, W + P.cb[sd], GF_BIAS,
+                 1.f, nullptr, 0, scratch, w.scratch_floats, s));
+    G(score_gru_fwd(B, T, H, xp, W + P.gk[sd] + (int64_t)d.I * 2 * H, 2 * H, W + P.ck[sd] + (int64_t)d.I * H, H,
+                    bt->length, ws + w.gru_out[sd], H, ws + w.gates[sd], ws + w.gru_final[sd], s));
+  }
+  if (d.attn) {
+    // temporal attention (:169-186, 210-215)
+    G(score_gemm(0, B, d.Dk, d.Dq, ws + w.query, d.Dq, W + P.at_w[0], d.Dk, ws + w.q, d.Dk, W + P.at_b[0], GF_BIAS,
+                 1.f, nullptr, 0, scratch, w.scratch_floats, s));
+    G(score_launch_attn_build_inp(B, T, H, d.NI, ws + w.q, ws + w.gru_out[0], ws + w.gru_out[1], ws + w.info,
+                                  ws + w.ainp, s));
+    G(score_gemm(0, BT, AT1, 4 * d.Dk, ws + w.ainp, 4 * d.Dk, W + P.at_w[1], AT1, ws + w.a1, AT1, W + P.at_b[1],
+                 GF_BIAS | GF_RELU, 1.f, nullptr, 0, scratch, w.scratch_floats, s));
+    G(score_gemm(0, BT, AT2, AT1, ws + w.a1, AT1, W + P.at_w[2], AT2, ws + w.a2, AT2, W + P.at_b[2],
+                 GF_BIAS | GF_RELU, 1.f, nullptr, 0, scratch, w.scratch_floats, s));
+    G(score_launch_attn_pool_fwd(B, T, H, AT2, ws + w.a2, W + P.at_w[3], W + P.at_b[3], bt->length,
+                                 ws + w.gru_out[0], ws + w.gru_out[1], ws + w.att_score, ws + w.head_inp, d.Dhead,
+                                 d.off_u, d.off_i, s));
+  } else {
+    // RIA: final GRU states feed the head (:244-249)
+    G(score_launch_copy2d(B, H, ws + w.gru_final[0], H, ws + w.head_inp, d.Dhead, s));
+    G(score_launch_copy2d(B, H, ws + w.gru_final[1], H, ws + w.head_inp + H, d.Dhead, s));
+  }
+  // build_fc_net (:68-76)
+  const float rs = (float)(1.0 / sqrt(1.0 + 1e-3));
+  G(score_launch_bn_fwd(B, d.Dhead, ws + w.head_inp, W + P.bn_g, W + P.bn_b, rs, ws + w.bn, s));
+  const int dflag = keep_prob < 1.f ? GF_DROP : 0;
+  G(score_gemm(0, B, FC1, d.Dhead, ws + w.bn, d.Dhead, W + P.fc_w[0], FC1, ws + w.f1, FC1, W + P.fc_b[0],
+               GF_BIAS | GF_RELU | dflag, keep_prob, drop_mask0, drop_seed, scratch, w.scratch_floats, s));
+  G(score_gemm(0, B, FC2, FC1, ws + w.f1, FC1, W + P.fc_w[1], FC2, ws + w.f2, FC2, W + P.fc_b[1],
+               GF_BIAS | GF_RELU | dflag, keep_prob, drop_mask1, drop_seed ^ 0x5DEECE66Dull, scratch,
+               w.scratch_floats, s));
+  // fc3, sigmoid, log-loss, l2 (:74-94)
+  G(score_launch_head_out(B, FC2, ws + w.f2, W + P.fc_w[2], W + P.fc_b[2], bt->label, ws + w.logit, ws + w.y_pred,
+                          ws + w.lossb, ws + w.dlogit, ws + w.loss, W, P.n_reg, reg_lambda, ws + w.part, s));
+  return 0;
+}
+
+extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st, const score_batch_t* bt,
+                              float keep_prob, float* gw, float* grad_table, void* stream) {
+  Dims d;
+  SCORE_TRY(make_dims(cfg, &d));
+  if (!st || !bt || !st->table || !st->w || !st->workspace || !gw || !grad_table || bt->B <= 0)
+    return SCORE_E_BADARG;
+  Params P;
+  build_layout(d, nullptr, 0, &P);
+  const int B = bt->B, T = d.T, H = d.H, BT = B * T;
+  WS w;
+  build_ws(d, B, &w);
+  if (w.total * 4 > st->workspace_bytes) return SCORE_E_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  float* ws = st->workspace;
+  const float* W = st->w;
+  float* scratch = ws + w.scratch;
+  const int64_t SF = w.scratch_floats;
+  hipError_t he = hipMemsetAsync(gw, 0, P.n_floats * sizeof(float), s);
+  if (he != hipSuccess) return (int)he;
+
+  // ---- head (score.py:68-81)
+  // fc3: dW = f2^T dlogit, db = sum dlogit, dz2 = [f2>0] dlogit w3 / keep
+  G(score_gemm(2, FC2, 1, B, ws + w.f2, FC2, ws + w.dlogit, 1, gw + P.fc_w[2], 1, nullptr, 0, 1.f, nullptr, 0,
+               scratch, SF, s));
+  G(score_launch_colsum(ws + w.dlogit, B, 1, 1, gw + P.fc_b[2], 0, scratch, SF, s));
+  G(score_launch_outer_relu_bwd(B, FC2, ws + w.dlogit, W + P.fc_w[2], ws + w.f2, keep_prob, ws + w.dz2, s));
+  // fc2
+  G(score_gemm(2, FC1, FC2, B, ws + w.f1, FC1, ws + w.dz2, FC2, gw + P.fc_w[1], FC2, nullptr, 0, 1.f, nullptr, 0,
+               scratch, SF, s));
+  G(score_launch_colsum(ws + w.dz2, B, FC2, FC2, gw + P.fc_b[1], 0, scratch, SF, s));
+  G(score_gemm(1, B, FC1, FC2, ws + w.dz2, FC2, W + P.fc_w[1], FC2, ws + w.dz1, FC1, nullptr, 0, 1.f, nullptr, 0,
+               scratch, SF, s));
+  G(score_launch_relu_bwd(ws + w.dz1, ws + w.f1, B, FC1, FC1, FC1, keep_prob, s));
+  // fc1 + bn1
+  G(score_gemm(2, d.Dhead, FC1, B, ws + w.bn, d.Dhead, ws + w.dz1, FC1, gw + P.fc_w[0], FC1, nullptr, 0, 1.f,
+               nullptr, 0, scratch, SF, s));
+  G(score_launch_colsum(ws + w.dz1, B, FC1, FC1, gw + P.fc_b[0], 0, scratch, SF, s));
+  G(score_gemm(1, B, d.Dhead, FC1, ws + w.dz1, FC1, W + P.fc_w[0], FC1, ws + w.dbn, d.Dhead, nullptr, 0, 1.f,
+               nullptr, 0, scratch, SF, s));
+  const float rs = (float)(1.0 / sqrt(1.0 + 1e-3));
+  G(score_launch_bn_bwd(B, d.Dhead, ws + w.head_inp, W + P.bn_g, rs, ws + w.dbn, ws + w.dhead, gw + P.bn_g,
+                        gw + P.bn_b, s));
+
+  const float* dfinal[2] = {nullptr, nullptr};
+  if (d.attn) {
+    // ---- temporal attention (score.py:169-186, 214-215)
+    G(score_launch_attn_pool_bwd(B, T, H, AT2, ws + w.a2, W + P.at_w[3], bt->length, ws + w.gru_out[0],
+                                 ws + w.gru_out[1], ws + w.att_score, ws + w.dhead, d.Dhead, d.off_u, d.off_i,
+                                 ws + w.ds, ws + w.da2, s));
+    // dense_5 (40 -> 1): dW = a2^T ds ; db = sum ds
+    G(score_gemm(2, AT2, 1, BT, ws + w.a2, AT2, ws + w.ds, 1, gw + P.at_w[3], 1, nullptr, 0, 1.f, nullptr, 0,
+                 scratch, SF, s));
+    G(score_launch_colsum(ws + w.ds, BT, 1, 1, gw + P.at_b[3], 0, scratch, SF, s));
+    // dense_4 (80 -> 40); da2 is already relu-masked
+    G(score_gemm(2, AT1, AT2, BT, ws + w.a1, AT1, ws + w.da2, AT2, gw + P.at_w[2], AT2, nullptr, 0, 1.f, nullptr,
+                 0, scratch, SF, s));
+    G(score_launch_colsum(ws + w.da2, BT, AT2, AT2, gw + P.at_b[2], 0, scratch, SF, s));
+    G(score_gemm(1, BT, AT1, AT2, ws + w.da2, AT2, W + P.at_w[2], AT2, ws + w.da1, AT1, nullptr, 0, 1.f, nullptr,
+                 0, scratch, SF, s));
+    G(score_launch_relu_bwd(ws + w.da1, ws + w.a1, BT, AT1, AT1, AT1, 1.f, s));
+    // dense_3 (4Dk -> 80)
+    G(score_gemm(2, 4 * d.Dk, AT1, BT, ws + w.ainp, 4 * d.Dk, ws + w.da1, AT1, gw + P.at_w[1], AT1, nullptr, 0,
+                 1.f, nullptr, 0, scratch, SF, s));
+    G(score_launch_colsum(ws + w.da1, BT, AT1, AT1, gw + P.at_b[1], 0, scratch, SF, s));
+    G(score_gemm(1, BT, 4 * d.Dk, AT1, ws + w.da1, AT1, W + P.at_w[1], AT1, ws + w.dainp, 4 * d.Dk, nullptr, 0,
+                 1.f, nullptr, 0, scratch, SF, s));
+    G(score_launch_attn_inp_bwd(B, T, H, d.NI, ws + w.dainp, ws + w.q, ws + w.gru_out[0], ws + w.gru_out[1],
+                                ws + w.info, ws + w.att_score, ws + w.dhead, d.Dhead, d.off_u, d.off_i,
+                                ws + w.dgru[0], ws + w.dgru[1], ws + w.dinfo, ws + w.dq, s));
+    // dense_2 (query projection)
+    G(score_gemm(2, d.Dq, d.Dk, B, ws + w.query, d.Dq, ws + w.dq, d.Dk, gw + P.at_w[0], d.Dk, nullptr, 0, 1.f,
+                 nullptr, 0, scratch, SF, s));
+    G(score_launch_colsum(ws + w.dq, B, d.Dk, d.Dk, gw + P.at_b[0], 0, scratch, SF, s));
+    G(score_gemm(1, B, d.Dq, d.Dk, ws + w.dq, d.Dk, W + P.at_w[0], d.Dk, ws + w.dquery, d.Dq, nullptr, 0, 1.f,
+                 nullptr, 0, scratch, SF, s));
+  } else {
+    // RIA: gradient enters through the final states only; atten_info is unused downstream
+    for (int sd = 0; sd < 2; ++sd) {
+      G(score_launch_copy2d(B, H, ws + w.dhead + sd * H, d.Dhead, ws + w.dfinal[sd], H, s));
+      dfinal[sd] = ws + w.dfinal[sd];
+      he = hipMemsetAsync(ws + w.dgru[sd], 0, (int64_t)BT * H * sizeof(float), s);
+      if (he != hipSuccess) return (int)he;
+    }
+    he = hipMemsetAsync(ws + w.dinfo, 0, (int64_t)BT * 4 * d.K * sizeof(float), s);
+    if (he != hipSuccess) return (int)he;
+  }
+
+  // ---- GRUs (score.py:205-208)
+  for (int sd = 0; sd < 2; ++sd) {
+    const float* Wg = W + P.gk[sd];
+    const float* Wc = W + P.ck[sd];
+    float* dxp = ws + w.dxproj;
+    G(score_gru_bwd(B, T, H, Wg + (int64_t)d.I * 2 * H, 2 * H, Wc + (int64_t)d.I * H, H, bt->length,
+                    ws + w.gru_out[sd], H, ws + w.gates[sd], ws + w.dgru[sd], H, dfinal[sd], dxp, ws + w.rh,
+                    ws + w.hprev, s));
+    // kernels are [x ; h] row blocks (TF GRUCell): x rows first
+    G(score_gemm(2, d.I, 2 * H, BT, ws + w.xside[sd], d.I, dxp, 3 * H, gw + P.gk[sd], 2 * H, nullptr, 0, 1.f,
+                 nullptr, 0, scratch, SF, s));
+    G(score_gemm(2, H, 2 * H, BT, ws + w.hprev, H, dxp, 3 * H, gw + P.gk[sd] + (int64_t)d.I * 2 * H, 2 * H,
+                 nullptr, 0, 1.f, nullptr, 0, scratch, SF, s));
+    G(score_gemm(2, d.I, H, BT, ws + w.xside[sd], d.I, dxp + 2 * H, 3 * H, gw + P.ck[sd], H, nullptr, 0, 1.f,
+                 nullptr, 0, scratch, SF, s));
+    G(score_gemm(2, H, H, BT, ws + w.rh, H, dxp + 2 * H, 3 * H, gw + P.ck[sd] + (int64_t)d.I * H, H, nullptr, 0,
+                 1.f, nullptr, 0, scratch, SF, s));
+    G(score_launch_colsum(dxp, BT, 2 * H, 3 * H, gw + P.gb[sd], 0, scratch, SF, s));
+    G(score_launch_colsum(dxp + 2 * H, BT, H, 3 * H, gw + P.cb[sd], 0, scratch, SF, s));
+    // d x = dgates . Wxg^T + dcand . Wxc^T
+    G(score_gemm(1, BT, d.I, 2 * H, dxp, 3 * H, Wg, 2 * H, ws + w.dxside[sd], d.I, nullptr, 0, 1.f, nullptr, 0,
+                 scratch, SF, s));
+    G(score_gemm(1, BT, d.I, H, dxp + 2 * H, 3 * H, Wc, H, ws + w.dxside[sd], d.I, nullptr, GF_ACC, 1.f, nullptr,
+                 0, scratch, SF, s));
+  }
+
+  // ---- co-attention + embedding rows (score.py:147-167, 196-201, 51-66)
+  const int mode = d.coattn ? 0 : 1;
+  const int ldi = 4 * d.K;
+  G(score_coattn_bwd(st->table, grad_table, st->n_table_rows, d.D, d.Fi, d.K, B, T, bt->user_1hop, bt->item_2hop,
+                     d.coattn ? W + P.ca_w[0] : nullptr, ws + w.rsave[0], ws + w.dxside[0], d.I,
+                     ws + w.dxside[1] + d.Du, d.I, ws + w.dinfo, ldi, ws + w.dzsum[0],
+                     d.coattn ? gw + P.ca_w[0] : nullptr, scratch, SF, mode, s));
+  G(score_coattn_bwd(st->table, grad_table, st->n_table_rows, d.D, d.Fu, d.K, B, T, bt->user_2hop, bt->item_1hop,
+                     d.coattn ? W + P.ca_w[1] : nullptr, ws + w.rsave[1], ws + w.dxside[0] + d.Di, d.I,
+                     ws + w.dxside[1], d.I, ws + w.dinfo + 2 * d.K, ldi, ws + w.dzsum[1],
+                     d.coattn ? gw + P.ca_w[1] : nullptr, scratch, SF, mode, s));
+  G(score_launch_target_bwd(grad_table, d.D, d.Fu, d.Fi, B, T, bt->target_user, bt->target_item,
+                            d.attn ? ws + w.dquery : nullptr, d.Dq, ws + w.dhead, d.Dhead, d.off_ti, d.off_tu,
+                            ws + w.query, d.coattn ? W + P.ca_w[0] : nullptr, d.coattn ? W + P.ca_w[1] : nullptr,
+                            ws + w.dzsum[0], ws + w.dzsum[1], ws + w.S, d.coattn ? gw + P.ca_w[0] : nullptr,
+                            d.coattn ? gw + P.ca_b[0] : nullptr, d.coattn ? gw + P.ca_w[1] : nullptr,
+                            d.coattn ? gw + P.ca_b[1] : nullptr, s));
+  return 0;
+}

@@ -1,0 +1,240 @@
+// Exact-fp32 GEMM on the matrix cores: v_mfma_f32_32x32x2_f32 (bitwise an fmaf
+// chain in k order; gfx950 has no xf32/TF32).  64x64 block tile, 4 waves in 2x2,
+// one 32x32 accumulator per wave, BK = 16 staged through LDS with a register
+// prefetch of the next tile.  Three operand layouts (see score_hip.h).
+#include "common.h"
+#include "kernels.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define BM 64
+#define BN 64
+#define BK 16
+#define AS_LD (BK + 1)  // As[i][k]: column reads by 32 lanes -> stride 17 words, conflict-free
+#define BS_LD (BN + 1)
+
+enum { F_BIAS = 1, F_RELU = 2, F_ACC = 4, F_DROP = 8 };
+
+__device__ __forceinline__ float epilogue(float v, int row, int col, int N, const float* bias, int flags,
+                                          float keep, const uint8_t* mask, uint64_t seed) {
+  if (flags & F_BIAS) v += bias[col];
+  if (flags & F_RELU) v = fmaxf(v, 0.f);
+  if (flags & F_DROP) {
+    uint64_t e = (uint64_t)row * (uint64_t)N + (uint64_t)col;
+    bool on = mask ? (mask[e] != 0) : (hash_uniform(seed, e) < keep);
+    v = on ? v / keep : 0.f;  // tf.nn.dropout: x / keep_prob * binary mask
+  }
+  return v;
+}
+
+// TRANS 0: A[M,K] (lda) , B[K,N] (ldb)
+// TRANS 1: A[M,K] (lda) , B[N,K] (ldb)  -> C = A . B^T
+// TRANS 2: A[K,M] (lda) , B[K,N] (ldb)  -> C = A^T . B
+template <int TRANS>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, const float* __restrict__ A, int lda,
+                                                       const float* __restrict__ Bm, int ldb,
+                                                       float* __restrict__ C, int ldc,
+                                                       const float* __restrict__ bias, int flags, float keep,
+                                                       const uint8_t* __restrict__ mask, uint64_t seed,
+                                                       int k_chunk, float* __restrict__ slab) {
+  __shared__ float As[BM * AS_LD];
+  __shared__ float Bs[BK * BS_LD];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int bm = blockIdx.y * BM, bn = blockIdx.x * BN;
+  const int kbeg = blockIdx.z * k_chunk;
+  const int kend = min(K, kbeg + k_chunk);
+
+  // staging coordinates: A tile 64x16, B tile 16x64, one float4 per thread each
+  float ra[4], rb[4];
+  const bool vecA = ((lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
+  const bool vecB = ((ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(Bm) & 15) == 0);
+  // one row-major quad: 16-B load when aligned and fully in range, guarded scalars otherwise
+  auto load_quad = [&](const float* base, int ld, bool vec, int r, int rlim, int c, int clim, float* dst) {
+    if (vec && r < rlim && c + 3 < clim) {
+      float4 v = ld4(base + (int64_t)r * ld + c);
+      dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) dst[q] = (r < rlim && c + q < clim) ? base[(int64_t)r * ld + c + q] : 0.f;
+    }
+  };
+  auto load_tiles = [&](int k0) {
+    if (TRANS == 2) load_quad(A, lda, vecA, k0 + (tid >> 4), kend, bm + (tid & 15) * 4, M, ra);   // A[k][m]
+    else            load_quad(A, lda, vecA, bm + (tid >> 2), M, k0 + (tid & 3) * 4, kend, ra);    // A[m][k]
+    if (TRANS == 1) load_quad(Bm, ldb, vecB, bn + (tid >> 2), N, k0 + (tid & 3) * 4, kend, rb);   // B[n][k]
+    else            load_quad(Bm, ldb, vecB, k0 + (tid >> 4), kend, bn + (tid & 15) * 4, N, rb);  // B[k][n]
+  };
+  auto store_tiles = [&]() {
+    if (TRANS == 2) {
+      int k = tid >> 4, m = (tid & 15) * 4;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) As[(m + q) * AS_LD + k] = ra[q];
+    } else {
+      int m = tid >> 2, k = (tid & 3) * 4;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) As[m * AS_LD + k + q] = ra[q];
+    }
+    if (TRANS == 1) {
+      int n = tid >> 2, k = (tid & 3) * 4;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) Bs[(k + q) * BS_LD + n] = rb[q];
+    } else {
+      int k = tid >> 4, n = (tid & 15) * 4;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) Bs[k * BS_LD + n + q] = rb[q];
+    }
+  };
+
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+  const int arow = wm * 32 + (lane & 31);
+  const int bcol = wn * 32 + (lane & 31);
+  const int khalf = lane >> 5;
+  if (kbeg < kend) load_tiles(kbeg);
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    store_tiles();
+    __syncthreads();
+    if (k0 + BK < kend) load_tiles(k0 + BK);
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      float a = As[arow * AS_LD + kk * 2 + khalf];
+      float b = Bs[(kk * 2 + khalf) * BS_LD + bcol];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // C/D layout of the 32x32 accumulator: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const int col = bn + bcol;
+  if (col >= N) return;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    int row = bm + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+    if (row >= M) continue;
+    if (slab) {
+      slab[((int64_t)blockIdx.z * M + row) * N + col] = acc[r];
+    } else {
+      float v = epilogue(acc[r], row, col, N, bias, flags, keep, mask, seed);
+      float* dst = C + (int64_t)row * ldc + col;
+      *dst = (flags & F_ACC) ? *dst + v : v;
+    }
+  }
+}
+
+__global__ void splitk_reduce_kernel(const float* __restrict__ slab, int nsplit, int M, int N,
+                                     float* __restrict__ C, int ldc, const float* __restrict__ bias, int flags,
+                                     float keep, const uint8_t* __restrict__ mask, uint64_t seed) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)M * N) return;
+  int row = (int)(i / N), col = (int)(i - (int64_t)row * N);
+  float s = 0.f;
+  for (int z = 0; z < nsplit; ++z) s += slab[(int64_t)z * M * N + i];
+  float v = epilogue(s, row, col, N, bias, flags, keep, mask, seed);
+  float* dst = C + (int64_t)row * ldc + col;
+  *dst = (flags & F_ACC) ? *dst + v : v;
+}
+
+extern "C" int score_gemm(int32_t trans, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda,
+                          const float* Bm, int32_t ldb, float* C, int32_t ldc, const float* bias,
+                          int32_t flags, float keep_prob, const uint8_t* drop_mask, uint64_t drop_seed,
+                          float* scratch, int64_t scratch_floats, void* stream) {
+  if (!A || !Bm || !C || M <= 0 || N <= 0 || K <= 0) return SCORE_E_BADARG;
+  if (trans < 0 || trans > 2) return SCORE_E_BADARG;
+  if ((flags & F_BIAS) && !bias) return SCORE_E_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, 1);
+  // split the reduced dimension when the output grid alone cannot fill 256 CUs
+  int nsplit = 1;
+  int64_t tiles = (int64_t)grid.x * grid.y;
+  if (tiles < 256 && K >= 512 && scratch) {
+    nsplit = (int)((512 + tiles - 1) / tiles);
+    int max_split = K / 128;
+    if (nsplit > max_split) nsplit = max_split;
+    while (nsplit > 1 && (int64_t)nsplit * M * N > scratch_floats) --nsplit;
+    if (nsplit < 1) nsplit = 1;
+  }
+  int k_chunk = K;
+  float* slab = nullptr;
+  if (nsplit > 1) {
+    k_chunk = (int)align_up64(cdiv64(K, nsplit), BK);
+    nsplit = (int)cdiv64(K, k_chunk);
+    grid.z = nsplit;
+    slab = nsplit > 1 ? scratch : nullptr;
+  }
+#define LAUNCH(TR)                                                                                           \
+  hipLaunchKernelGGL((gemm_f32_kernel<TR>), grid, dim3(256), 0, s, M, N, K, A, lda, Bm, ldb, C, ldc, bias,   \
+                     flags, keep_prob, drop_mask, drop_seed, k_chunk, slab)
+  if (trans == 0) LAUNCH(0);
+  else if (trans == 1) LAUNCH(1);
+  else LAUNCH(2);
+#undef LAUNCH
+  SCORE_CHECK_LAUNCH();
+  if (slab) {
+    int64_t n = (int64_t)M * N;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, s, slab, nsplit, M, N,
+                       C, ldc, bias, flags, keep_prob, drop_mask, drop_seed);
+    SCORE_CHECK_LAUNCH();
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------ small helpers used by the engine
+// out[n] (+)= sum_m X[m][n]   two-stage, fixed order
+__global__ void colsum_stage1(const float* __restrict__ X, int M, int N, int ld, int rows_per_block,
+                              float* __restrict__ part) {
+  int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  int m0 = blockIdx.y * rows_per_block, m1 = min(M, m0 + rows_per_block);
+  float s = 0.f;
+  for (int m = m0; m < m1; ++m) s += X[(int64_t)m * ld + n];
+  part[(int64_t)blockIdx.y * N + n] = s;
+}
+__global__ void colsum_stage2(const float* __restrict__ part, int nparts, int N, float* __restrict__ out,
+                              int accumulate) {
+  int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float s = 0.f;
+  for (int p = 0; p < nparts; ++p) s += part[(int64_t)p * N + n];
+  out[n] = accumulate ? out[n] + s : s;
+}
+
+int score_launch_colsum(const float* X, int M, int N, int ld, float* out, int accumulate, float* scratch,
+                        int64_t scratch_floats, hipStream_t s) {
+  int nparts = (M + 255) / 256;
+  if (nparts > 512) nparts = 512;
+  if ((int64_t)nparts * N > scratch_floats) return SCORE_E_WORKSPACE;
+  int rpb = (M + nparts - 1) / nparts;
+  nparts = (M + rpb - 1) / rpb;
+  int tx = N < 64 ? 64 : 256;
+  hipLaunchKernelGGL(colsum_stage1, dim3((N + tx - 1) / tx, nparts), dim3(tx), 0, s, X, M, N, ld, rpb, scratch);
+  SCORE_CHECK_LAUNCH();
+  hipLaunchKernelGGL(colsum_stage2, dim3((N + tx - 1) / tx), dim3(tx), 0, s, scratch, nparts, N, out, accumulate);
+  SCORE_CHECK_LAUNCH();
+  return 0;
+}
+
+// dY <- dY * [Y > 0] / divisor      (relu / relu+dropout backward)
+__global__ void relu_bwd_kernel(float* __restrict__ dY, const float* __restrict__ Y, int64_t rows, int cols,
+                                int ldd, int ldy, float divisor) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * cols) return;
+  int64_t r = i / cols;
+  int c = (int)(i - r * cols);
+  float y = Y[r * ldy + c];
+  float* d = dY + r * ldd + c;
+  *d = y > 0.f ? *d / divisor : 0.f;
+}
+
+int score_launch_relu_bwd(float* dY, const float* Y, int64_t rows, int cols, int ldd, int ldy, float divisor,
+                          hipStream_t s) {
+  int64_t n = rows * cols;
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, s, dY, Y, rows, cols, ldd,
+                     ldy, divisor);
+  SCORE_CHECK_LAUNCH();
+  return 0;
+}

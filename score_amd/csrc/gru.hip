@@ -1,0 +1,258 @@
+// tf.nn.dynamic_rnn(GRUCell(H), sequence_length) recurrence (score.py:205-208),
+// forward and backward, as ONE persistent launch per direction: a workgroup owns
+// 32 batch rows (samples are independent) and walks all T steps with the hidden
+// state in LDS; the two small products of a step (h.Wg[H,2H], (r*h).Wc[H,H]) run
+// on v_mfma_f32_32x32x2_f32 (exact fp32), weights stream from L2.
+//
+// GRUCell (TF 1.x): [r,u] = sigmoid([x,h].Wg + bg) (r first), c = tanh([x,r*h].Wc + bc),
+// h' = u*h + (1-u)*c.  The x-part (x.Wx + b) is hoisted into one big GEMM: `xproj`.
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define RB 32  // batch rows per workgroup
+
+// acc(32 x 32 cols starting at j0) = Ash[32][K] (LDS, row stride lds_ld) . Wm[K][ldw] (global)
+__device__ __forceinline__ f32x16 tile_matmul(const float* __restrict__ Ash, int lds_ld, int Kdim,
+                                              const float* __restrict__ Wm, int ldw, int j0, int ncols,
+                                              int lane) {
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  const int i = lane & 31, kh = lane >> 5;
+  const int j = j0 + i;
+  const bool jok = j < ncols;
+  const float* wp = Wm + (jok ? j : 0);
+  int k = 0;
+  for (; k + 8 <= Kdim; k += 8) {  // 4 MFMAs per trip, loads issued together
+    float a0 = Ash[i * lds_ld + k + kh], a1 = Ash[i * lds_ld + k + 2 + kh];
+    float a2 = Ash[i * lds_ld + k + 4 + kh], a3 = Ash[i * lds_ld + k + 6 + kh];
+    float b0 = jok ? wp[(int64_t)(k + kh) * ldw] : 0.f, b1 = jok ? wp[(int64_t)(k + 2 + kh) * ldw] : 0.f;
+    float b2 = jok ? wp[(int64_t)(k + 4 + kh) * ldw] : 0.f, b3 = jok ? wp[(int64_t)(k + 6 + kh) * ldw] : 0.f;
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, b3, acc, 0, 0, 0);
+  }
+  for (; k < Kdim; k += 2) {
+    int kk = k + kh;
+    float a = kk < Kdim ? Ash[i * lds_ld + kk] : 0.f;
+    float b = (jok && kk < Kdim) ? wp[(int64_t)kk * ldw] : 0.f;
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+  }
+  return acc;
+}
+// accumulator element r of lane -> (row, col) inside the 32x32 tile
+#define ACC_ROW(r, lane) (((r) & 3) + 8 * ((r) >> 2) + 4 * ((lane) >> 5))
+#define ACC_COL(lane) ((lane) & 31)
+
+__global__ __launch_bounds__(256) void gru_fwd_kernel(int B, int T, int H, const float* __restrict__ xproj,
+                                                      const float* __restrict__ Wg, int ldwg,
+                                                      const float* __restrict__ Wc, int ldwc,
+                                                      const int32_t* __restrict__ length,
+                                                      float* __restrict__ out, int ldo,
+                                                      float* __restrict__ gates, float* __restrict__ final_state) {
+  extern __shared__ float sm[];
+  const int ld = H + 1;
+  float* hs = sm;             // [RB][H+1] hidden state
+  float* rhs = hs + RB * ld;  // r * h
+  float* us = rhs + RB * ld;  // update gate
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b0 = blockIdx.x * RB;
+  for (int e = tid; e < RB * ld; e += blockDim.x) hs[e] = 0.f;
+  __syncthreads();
+  const int ntg = (2 * H + 31) / 32, ntc = (H + 31) / 32;
+  for (int t = 0; t < T; ++t) {
+    // gates = sigmoid(xproj[:, 0:2H] + h.Wg)
+    for (int tile = wave; tile < ntg; tile += 4) {
+      f32x16 acc = tile_matmul(hs, ld, H, Wg, ldwg, tile * 32, 2 * H, lane);
+      const int j = tile * 32 + ACC_COL(lane);
+      if (j < 2 * H) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int i = ACC_ROW(r, lane);
+          const int b = b0 + i;
+          if (b >= B) continue;
+          const int64_t row = (int64_t)b * T + t;
+          float g = sigmoidf_(acc[r] + xproj[row * 3 * H + j]);
+          gates[row * 3 * H + j] = g;
+          if (j < H) rhs[i * ld + j] = g * hs[i * ld + j];
+          else us[i * ld + (j - H)] = g;
+        }
+      }
+    }
+    __syncthreads();
+    // c = tanh(xproj[:, 2H:3H] + (r*h).Wc);  h' = u*h + (1-u)*c
+    for (int tile = wave; tile < ntc; tile += 4) {
+      f32x16 acc = tile_matmul(rhs, ld, H, Wc, ldwc, tile * 32, H, lane);
+      const int j = tile * 32 + ACC_COL(lane);
+      if (j < H) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int i = ACC_ROW(r, lane);
+          const int b = b0 + i;
+          if (b >= B) continue;
+          const int64_t row = (int64_t)b * T + t;
+          float c = tanhf(acc[r] + xproj[row * 3 * H + 2 * H + j]);
+          gates[row * 3 * H + 2 * H + j] = c;
+          float u = us[i * ld + j], h = hs[i * ld + j];
+          float hn = u * h + (1.0f - u) * c;
+          bool live = t < length[b];
+          out[row * ldo + j] = live ? hn : 0.f;   // dynamic_rnn: zero output past the length
+          hs[i * ld + j] = live ? hn : h;         // ... and the state is carried through
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (final_state)
+    for (int e = tid; e < RB * H; e += blockDim.x) {
+      int i = e / H, j = e - i * H;
+      if (b0 + i < B) final_state[(int64_t)(b0 + i) * H + j] = hs[i * ld + j];
+    }
+}
+
+extern "C" int score_gru_fwd(int32_t B, int32_t T, int32_t H, const float* xproj, const float* Wg,
+                             int32_t ldwg, const float* Wc, int32_t ldwc, const int32_t* length, float* out,
+                             int32_t ldo, float* gates_save, float* final_state, void* stream) {
+  if (!xproj || !Wg || !Wc || !length || !out || !gates_save || B <= 0 || T <= 0 || H <= 0) return SCORE_E_BADARG;
+  size_t lds = (size_t)3 * RB * (H + 1) * sizeof(float);
+  if (lds > 160 * 1024) return SCORE_E_SHAPE;
+  if (lds > 48 * 1024)
+    (void)hipFuncSetAttribute((const void*)gru_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(gru_fwd_kernel, dim3((B + RB - 1) / RB), dim3(256), lds, (hipStream_t)stream, B, T, H, xproj,
+                     Wg, ldwg, Wc, ldwc, length, out, ldo, gates_save, final_state);
+  SCORE_CHECK_LAUNCH();
+  return 0;
+}
+
+// Backward recurrence.  WgT [2H][H] and WcT [H][H] are transposed copies of the
+// recurrent weights (made by transpose_kernel below) so the MFMA B operand reads
+// stay row-contiguous.
+//   dh      = dout_t (live) + dh_next
+//   du = dh*(h_prev - c), dc = dh*(1-u), dh_prev = dh*u
+//   dpc = dc*(1-c^2);  d(rh) = dpc.Wc^T;  dr = d(rh)*h_prev;  dh_prev += d(rh)*r
+//   dpr = dr*r*(1-r);  dpu = du*u*(1-u);  dh_prev += [dpr,dpu].Wg^T
+__global__ __launch_bounds__(256) void gru_bwd_kernel(int B, int T, int H, const float* __restrict__ WgT,
+                                                      const float* __restrict__ WcT,
+                                                      const int32_t* __restrict__ length,
+                                                      const float* __restrict__ out, int ldo,
+                                                      const float* __restrict__ gates,
+                                                      const float* __restrict__ dout, int lddo,
+                                                      const float* __restrict__ dfinal,
+                                                      float* __restrict__ dxproj, float* __restrict__ rh_out,
+                                                      float* __restrict__ hprev_out) {
+  extern __shared__ float sm[];
+  const int ld = H + 1, ld2 = 2 * H + 1;
+  float* dh = sm;                 // [RB][H+1]   running dL/dh
+  float* dpc = dh + RB * ld;      // [RB][H+1]   candidate pre-activation grad
+  float* dpg = dpc + RB * ld;     // [RB][2H+1]  gate pre-activation grads [dpr | dpu]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b0 = blockIdx.x * RB;
+  for (int e = tid; e < RB * H; e += blockDim.x) {
+    int i = e / H, j = e - i * H;
+    dh[i * ld + j] = (dfinal && b0 + i < B) ? dfinal[(int64_t)(b0 + i) * H + j] : 0.f;
+  }
+  __syncthreads();
+  const int nth = (H + 31) / 32;
+  for (int t = T - 1; t >= 0; --t) {
+    // phase 1 (elementwise): dh_tot, du, dc -> dpu, dpc ; dh <- dh_tot*u
+    for (int e = tid; e < RB * H; e += blockDim.x) {
+      int i = e / H, j = e - i * H;
+      int b = b0 + i;
+      float v_dpc = 0.f, v_dpu = 0.f;
+      if (b < B) {
+        const int64_t row = (int64_t)b * T + t;
+        const bool live = t < length[b];
+        float hp = t > 0 ? out[(row - 1) * ldo + j] : 0.f;
+        hprev_out[row * H + j] = live ? hp : 0.f;
+        if (live) {
+          float u = gates[row * 3 * H + H + j], c = gates[row * 3 * H + 2 * H + j];
+          float d = dh[i * ld + j] + dout[row * lddo + j];
+          float du = d * (hp - c), dc = d * (1.0f - u);
+          v_dpu = du * u * (1.0f - u);
+          v_dpc = dc * (1.0f - c * c);
+          dh[i * ld + j] = d * u;
+        }
+        dxproj[row * 3 * H + H + j] = v_dpu;
+        dxproj[row * 3 * H + 2 * H + j] = v_dpc;
+      }
+      dpc[i * ld + j] = v_dpc;
+      dpg[i * ld2 + H + j] = v_dpu;
+    }
+    __syncthreads();
+    // phase 2: d(rh) = dpc . Wc^T ; dr, dpr ; dh += d(rh)*r
+    for (int tile = wave; tile < nth; tile += 4) {
+      f32x16 acc = tile_matmul(dpc, ld, H, WcT, H, tile * 32, H, lane);
+      const int j = tile * 32 + ACC_COL(lane);
+      if (j < H) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int i = ACC_ROW(r, lane);
+          const int b = b0 + i;
+          float v_dpr = 0.f;
+          if (b < B) {
+            const int64_t row = (int64_t)b * T + t;
+            const bool live = t < length[b];
+            float rr = 0.f, hp = 0.f;
+            if (live) {
+              rr = gates[row * 3 * H + j];
+              hp = t > 0 ? out[(row - 1) * ldo + j] : 0.f;
+              float drh = acc[r];
+              v_dpr = drh * hp * rr * (1.0f - rr);
+              dh[i * ld + j] += drh * rr;
+            }
+            dxproj[row * 3 * H + j] = v_dpr;
+            rh_out[row * H + j] = rr * hp;
+          }
+          dpg[i * ld2 + j] = v_dpr;
+        }
+      }
+    }
+    __syncthreads();
+    // phase 3: dh += [dpr,dpu] . Wg^T
+    for (int tile = wave; tile < nth; tile += 4) {
+      f32x16 acc = tile_matmul(dpg, ld2, 2 * H, WgT, H, tile * 32, H, lane);
+      const int j = tile * 32 + ACC_COL(lane);
+      if (j < H) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int i = ACC_ROW(r, lane);
+          dh[i * ld + j] += acc[r];
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+__global__ void transpose_kernel(const float* __restrict__ src, int rows, int cols, int lds_, float* __restrict__ dst) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * cols) return;
+  int r = i / cols, c = i - r * cols;
+  dst[(int64_t)c * rows + r] = src[(int64_t)r * lds_ + c];
+}
+
+// `hprev` must hold B*T*H + 3*H*H floats: the tail receives the transposed recurrent weights.
+extern "C" int score_gru_bwd(int32_t B, int32_t T, int32_t H, const float* Wg, int32_t ldwg, const float* Wc,
+                             int32_t ldwc, const int32_t* length, const float* out, int32_t ldo,
+                             const float* gates_save, const float* dout, int32_t lddo, const float* dfinal,
+                             float* dxproj, float* rh, float* hprev, void* stream) {
+  if (!Wg || !Wc || !length || !out || !gates_save || !dout || !dxproj || !rh || !hprev || B <= 0 || T <= 0 ||
+      H <= 0)
+    return SCORE_E_BADARG;
+  size_t lds = (size_t)RB * (2 * (H + 1) + (2 * H + 1)) * sizeof(float);
+  if (lds > 160 * 1024) return SCORE_E_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  float* WgT = hprev + (int64_t)B * T * H;  // [2H][H]
+  float* WcT = WgT + (int64_t)2 * H * H;    // [H][H]
+  hipLaunchKernelGGL(transpose_kernel, dim3((2 * H * H + 255) / 256), dim3(256), 0, s, Wg, H, 2 * H, ldwg, WgT);
+  SCORE_CHECK_LAUNCH();
+  hipLaunchKernelGGL(transpose_kernel, dim3((H * H + 255) / 256), dim3(256), 0, s, Wc, H, H, ldwc, WcT);
+  SCORE_CHECK_LAUNCH();
+  if (lds > 48 * 1024)
+    (void)hipFuncSetAttribute((const void*)gru_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(gru_bwd_kernel, dim3((B + RB - 1) / RB), dim3(256), lds, s, B, T, H, WgT, WcT, length, out,
+                     ldo, gates_save, dout, lddo, dfinal, dxproj, rh, hprev);
+  SCORE_CHECK_LAUNCH();
+  return 0;
+}

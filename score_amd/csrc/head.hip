@@ -1,0 +1,377 @@
+// Pointwise / small-reduction kernels of the temporal attention (score.py:169-186),
+// pooled states (:214-215), build_fc_net (:68-76), build_logloss / build_l2norm
+// (:78-94) and ApplyAdam (:96-99).  All HBM- or latency-bound; GEMMs live in gemm.hip.
+#include "common.h"
+#include "kernels.h"
+
+// inp = [q, k, q-k, q*k] with k = [user_rep | item_rep | atten_info]   (score.py:173-174)
+__global__ void attn_build_inp_kernel(int BT, int T, int H, int NI, const float* __restrict__ q,
+                                      const float* __restrict__ ur, const float* __restrict__ ir,
+                                      const float* __restrict__ info, float* __restrict__ inp) {
+  const int Dk = 2 * H + NI;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)BT * Dk) return;
+  int bt = (int)(i / Dk), j = (int)(i - (int64_t)bt * Dk);
+  int b = bt / T;
+  float k = j < H ? ur[(int64_t)bt * H + j]
+                  : (j < 2 * H ? ir[(int64_t)bt * H + (j - H)] : info[(int64_t)bt * NI + (j - 2 * H)]);
+  float qq = q[(int64_t)b * Dk + j];
+  float* o = inp + (int64_t)bt * 4 * Dk;
+  o[j] = qq;
+  o[Dk + j] = k;
+  o[2 * Dk + j] = qq - k;
+  o[3 * Dk + j] = qq * k;
+}
+
+int score_launch_attn_build_inp(int B, int T, int H, int NI, const float* q, const float* ur, const float* ir,
+                                const float* info, float* inp, hipStream_t s) {
+  int64_t n = (int64_t)B * T * (2 * H + NI);
+  hipLaunchKernelGGL(attn_build_inp_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, s, B * T, T, H, NI, q,
+                     ur, ir, info, inp);
+  SCORE_CHECK_LAUNCH();
+  return 0;
+}
+
+// one wave per sample: fc3 = a2.w5 + b5, where(mask, fc3, -2^32+1), softmax over T,
+// pooled states sum_t rep_t * score_t  (score.py:177-181, 214-215).  The T scores of a
+// sample live in the wave's LDS row.
+__global__ __launch_bounds__(256) void attn_pool_fwd_kernel(
+    int B, int T, int H, int NA, const float* __restrict__ a2, const float* __restrict__ w5,
+    const float* __restrict__ b5, const int32_t* __restrict__ length, const float* __restrict__ ur,
+    const float* __restrict__ ir, float* __restrict__ score, float* __restrict__ head, int ldh, int off_u,
+    int off_i) {
+  extern __shared__ float sh[];  // [4][T]
+  const int lane = threadIdx.x & 63;
+  const int b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const bool bok = b < B;
+  float* sc = sh + (threadIdx.x >> 6) * T;
+  const int len = bok ? length[b] : 0;
+  float mx = -INFINITY;
+  for (int t = lane; t < T; t += 64) {
+    float acc = 0.f;
+    if (bok)
+      for (int n = 0; n < NA; ++n) acc = fmaf(a2[((int64_t)b * T + t) * NA + n], w5[n], acc);
+    float sv = t < len ? acc + b5[0] : -4294967295.0f;
+    sc[t] = sv;
+    mx = fmaxf(mx, sv);
+  }
+  mx = wave_max(mx);
+  float den = 0.f;
+  for (int t = lane; t < T; t += 64) {
+    float e = expf(sc[t] - mx);
+    sc[t] = e;
+    den += e;
+  }
+  den = wave_sum(den);
+  for (int t = lane; t < T; t += 64) {
+    float v = sc[t] / den;
+    sc[t] = v;
+    if (bok) score[(int64_t)b * T + t] = v;
+  }
+  __syncthreads();
+  if (!bok) return;
+  for (int j = lane; j < H; j += 64) {
+    float su = 0.f, si = 0.f;
+    for (int t = 0; t < T; ++t) {
+      float w = sc[t];
+      su = fmaf(ur[((int64_t)b * T + t) * H + j], w, su);
+      si = fmaf(ir[((int64_t)b * T + t) * H + j], w, si);
+    }
+    if (off_u >= 0) head[(int64_t)b * ldh + off_u + j] = su;
+    if (off_i >= 0) head[(int64_t)b * ldh + off_i + j] = si;
+  }
+}
+
+int score_launch_attn_pool_fwd(int B, int T, int H, int NA, const float* a2, const float* w5, const float* b5,
+                               const int32_t* length, const float* ur, const float* ir, float* score, float* head,
+                               int ldh, int off_u, int off_i, hipStream_t s) {
+  hipLaunchKernelGGL(attn_pool_fwd_kernel, dim3((B + 3) / 4), dim3(256), 4 * T * sizeof(float), s, B, T, H, NA,
+                     a2, w5, b5, length, ur, ir, score, head, ldh, off_u, off_i);
+  SCORE_CHECK_LAUNCH();
+  return 0;
+}
+
+// backward of the pooling + masked softmax + fc3:  one wave per sample
+//   dscore_t = duf.ur_t + dif.ir_t ; ds_t = score_t (dscore_t - sum score*dscore) [t < len]
+//   da2[t][n] = ds_t * w5[n] * [a2 > 0]
+__global__ __launch_bounds__(256) void attn_pool_bwd_kernel(
+    int B, int T, int H, int NA, const float* __restrict__ a2, const float* __restrict__ w5,
+    const int32_t* __restrict__ length, const float* __restrict__ ur, const float* __restrict__ ir,
+    const float* __restrict__ score, const float* __restrict__ dhead, int ldh, int off_u, int off_i,
+    float* __restrict__ ds, float* __restrict__ da2) {
+  const int lane = threadIdx.x & 63;
+  const int b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (b >= B) return;
+  const int len = length[b];
+  // every lane ends up with every dscore_t (wave_sum broadcasts), so nothing crosses lanes via memory
+  float tot = 0.f;
+  for (int t = 0; t < T; ++t) {
+    float part = 0.f;
+    for (int j = lane; j < H; j += 64) {
+      if (off_u >= 0) part = fmaf(dhead[(int64_t)b * ldh + off_u + j], ur[((int64_t)b * T + t) * H + j], part);
+      if (off_i >= 0) part = fmaf(dhead[(int64_t)b * ldh + off_i + j], ir[((int64_t)b * T + t) * H + j], part);
+    }
+    tot = fmaf(score[(int64_t)b * T + t], wave_sum(part), tot);
+  }
+  for (int t = 0; t < T; ++t) {
+    float part = 0.f;
+    for (int j = lane; j < H; j += 64) {
+      if (off_u >= 0) part = fmaf(dhead[(int64_t)b * ldh + off_u + j], ur[((int64_t)b * T + t) * H + j], part);
+      if (off_i >= 0) part = fmaf(dhead[(int64_t)b * ldh + off_i + j], ir[((int64_t)b * T + t) * H + j], part);
+    }
+    float dsc = wave_sum(part);
+    float g = t < len ? score[(int64_t)b * T + t] * (dsc - tot) : 0.f;
+    for (int n = lane; n < NA; n += 64) {
+      float a = a2[((int64_t)b * T + t) * NA + n];
+      da2[((int64_t)b * T + t) * NA + n] = a > 0.f ? g * w5[n] : 0.f;
+    }
+    if (lane == 0) ds[(int64_t)b * T + t] = g;
+  }
+}
+
+int score_launch_attn_pool_bwd(int B, int T, int H, int NA, const float* a2, const float* w5,
+                               const int32_t* length, const float* ur, const float* ir, const float* score,
+                               const float* dhead, int ldh, int off_u, int off_i, float* ds, float* da2,
+                               hipStream_t s) {
+  hipLaunchKernelGGL(attn_pool_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, s, B, T, H, NA, a2, w5, length, ur, ir,
+                     score, dhead, ldh, off_u, off_i, ds, da2);
+  SCORE_CHECK_LAUNCH();
+  return 0;
+}
+
+// backward of inp = [q,k,q-k,q*k] plus the pooled-state path into the GRU outputs.
+// thread per (b, j); loops over t.
+__global__ void attn_inp_bwd_kernel(int B, int T, int H, int NI, const float* __restrict__ dinp,
+                                    const float* __restrict__ q, const float* __restrict__ ur,
+                                    const float* __restrict__ ir, const float* __restrict__ info,
+                                    const float* __restrict__ score, const float* __restrict__ dhead, int ldh,
+                                    int off_u, int off_i, float* __restrict__ dur, float* __restrict__ dir,
+                                    float* __restrict__ dinfo, float* __restrict__ dq) {
+  const int Dk = 2 * H + NI;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * Dk) return;
+  int b = i / Dk, j = i - b * Dk;
+  float qq = q[(int64_t)b * Dk + j];
+  float pooled = 0.f;
+  if (j < H && off_u >= 0) pooled = dhead[(int64_t)b * ldh + off_u + j];
+  if (j >= H && j < 2 * H && off_i >= 0) pooled = dhead[(int64_t)b * ldh + off_i + (j - H)];
+  float dqa = 0.f;
+  for (int t = 0; t < T; ++t) {
+    int64_t bt = (int64_t)b * T + t;
+    const float* d = dinp + bt * 4 * Dk;
+    float k = j < H ? ur[bt * H + j] : (j < 2 * H ? ir[bt * H + (j - H)] : info[bt * NI + (j - 2 * H)]);
+    float d0 = d[j], d1 = d[Dk + j], d2 = d[2 * Dk + j], d3 = d[3 * Dk + j];
+    dqa += d0 + d2 + d3 * k;
+    float dk = d1 - d2 + d3 * qq;
+    if (j < H) dur[bt * H + j] = dk + pooled * score[bt];
+    else if (j < 2 * H) dir[bt * H + (j - H)] = dk + pooled * score[bt];
+    else dinfo[bt * NI + (j - 2 * H)] = dk;
+  }
+  dq[(int64_t)b * Dk + j] = dqa;
+}
+
+int score_launch_attn_inp_bwd(int B, int T, int H, int NI, const float* dinp, const float* q, const float* ur,
+                              const float* ir, const float* info, const float* score, const float* dhead, int ldh,
+                              int off_u, int off_i, float* dur, float* dir, float* dinfo, float* dq,
+                              hipStream_t s) {
+  int n = B * (2 * H + NI);
+  hipLaunchKernelGGL(attn_inp_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, s, B, T, H, NI, dinp, q, ur, ir,
+                     info, score, dhead, ldh, off_u, off_i, dur, dir, dinfo, dq);
+  SCORE_CHECK_LAUNCH();
+  return 0;
+}
+
+// bn1 (inference-mode affine, score.py:69): y = x * (gamma * rs) + beta, rs = rsqrt(1 + 1e-3)
+__global__ void bn_fwd_kernel(int B, int Dh, const float* __restrict__ x, const float* __restrict__ gamma,
+                              const float* __restrict__ beta, float rs, float* __restrict__ y) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)B * Dh) return;
+  int j = (int)(i % Dh);
+  y[i] = x[i] * (gamma[j] * rs) + beta[j];
+}
+// dx = dy * gamma*rs ; dgamma[j] = sum_b dy*x*rs ; dbeta[j] = sum_b dy   (thread per column)
+__global__ void bn_bwd_kernel(int B, int Dh, const float* __restrict__ x, const float* __restrict__ gamma, float rs,
+                              const float* __restrict__ dy, float* __restrict__ dx, float* __restrict__ dgamma,
+                              float* __restrict__ dbeta) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= Dh) return;
+  float inv = gamma[j] * rs, sg = 0.f, sb = 0.f;
+  for (int b = 0; b < B; ++b) {
+    float d = dy[(int64_t)b * Dh + j];
+    dx[(int64_t)b * Dh + j] = d * inv;
+    sg = fmaf(d, x[(int64_t)b * Dh + j] * rs, sg);
+    sb += d;
+  }
+  dgamma[j] = sg;
+  dbeta[j] = sb;
+}
+
+int score_launch_bn_fwd(int B, int Dh, const float* x, const float* gamma, const float* beta, float rs, float* y,
+                        hipStream_t s) {
+  int64_t n = (int64_t)B * Dh;
+  hipLaunchKernelGGL(bn_fwd_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, s, B, Dh, x, gamma, beta, rs, y);
+  SCORE_CHECK_LAUNCH();
+  return 0;
+}
+int score_launch_bn_bwd(int B, int Dh, const float* x, const float* gamma, float rs, const float* dy, float* dx,
+                        float* dgamma, float* dbeta, hipStream_t s) {
+  hipLaunchKernelGGL(bn_bwd_kernel, dim3((Dh + 63) / 64), dim3(64), 0, s, B, Dh, x, gamma, rs, dy, dx, dgamma,
+                     dbeta);
+  SCORE_CHECK_LAUNCH();
+  return 0;
+}
+
+// fc3 + sigmoid + per-sample log-loss term and its gradient (score.py:74-81), thread per sample
+//   loss_b = -y log(p+eps) - (1-y) log(1-p+eps) ; dlogit = dloss/dp * p(1-p) / B
+__global__ void head_out_kernel(int B, int NF, const float* __restrict__ f2, const float* __restrict__ w3,
+                                const float* __restrict__ b3, const int32_t* __restrict__ label,
+                                float* __restrict__ logit, float* __restrict__ y, float* __restrict__ lossb,
+                                float* __restrict__ dlogit) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float acc = 0.f;
+  for (int n = 0; n < NF; ++n) acc = fmaf(f2[(int64_t)b * NF + n], w3[n], acc);
+  float z = acc + b3[0];
+  float p = sigmoidf_(z);
+  float lab = (float)label[b];
+  const float eps = 1e-7f;
+  logit[b] = z;
+  y[b] = p;
+  lossb[b] = -lab * logf(p + eps) - (1.0f - lab) * logf(1.0f - p + eps);
+  float dp = (-lab / (p + eps) + (1.0f - lab) / (1.0f - p + eps)) / (float)B;
+  dlogit[b] = dp * p * (1.0f - p);
+}
+
+// single-block deterministic sum of n floats: out = scale * sum
+__global__ void reduce_sum_kernel(const float* __restrict__ x, int64_t n, float scale, float* __restrict__ out) {
+  __shared__ float sh[256];
+  float s = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += 256) s += x[i];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = sh[0] * scale;
+}
+__global__ void sumsq_stage1(const float* __restrict__ x, int64_t n, float* __restrict__ part) {
+  __shared__ float sh[256];
+  float s = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s = fmaf(x[i], x[i], s);
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[blockIdx.x] = sh[0];
+}
+// loss[1] = mean log-loss (already there), loss[2] = 0.5*sumsq, loss[0] = loss[1] + lambda*loss[2]
+__global__ void loss_final_kernel(const float* __restrict__ part, int nparts, float lambda, float* __restrict__ loss) {
+  if (threadIdx.x != 0) return;
+  float s = 0.f;
+  for (int i = 0; i < nparts; ++i) s += part[i];
+  loss[2] = 0.5f * s;
+  loss[0] = loss[1] + lambda * loss[2];
+}
+
+int score_launch_head_out(int B, int NF, const float* f2, const float* w3, const float* b3, const int32_t* label,
+                          float* logit, float* y, float* lossb, float* dlogit, float* loss, const float* wreg,
+                          int64_t n_reg, float lambda, float* part /* >= 64 floats */, hipStream_t s) {
+  hipLaunchKernelGGL(head_out_kernel, dim3((B + 63) / 64), dim3(64), 0, s, B, NF, f2, w3, b3, label, logit, y,
+                     lossb, dlogit);
+  SCORE_CHECK_LAUNCH();
+  hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, s, lossb, (int64_t)B, 1.0f / (float)B, loss + 1);
+  SCORE_CHECK_LAUNCH();
+  hipLaunchKernelGGL(sumsq_stage1, dim3(64), dim3(256), 0, s, wreg, n_reg, part);
+  SCORE_CHECK_LAUNCH();
+  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, s, part, 64, lambda, loss);
+  SCORE_CHECK_LAUNCH();
+  return 0;
+}
+
+// dz[b][n] = [f[b][n] > 0] * dlogit[b] * w[n] / keep      (fc3 backward into relu+dropout of fc2)
+__global__ void outer_relu_bwd_kernel(int B, int NF, const float* __restrict__ dlogit, const float* __restrict__ w,
+                                      const float* __restrict__ f, float keep, float* __restrict__ dz) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * NF) return;
+  int b = i / NF, n = i - b * NF;
+  dz[i] = f[i] > 0.f ? dlogit[b] * w[n] / keep : 0.f;
+}
+int score_launch_outer_relu_bwd(int B, int NF, const float* dlogit, const float* w, const float* f, float keep,
+                                float* dz, hipStream_t s) {
+  hipLaunchKernelGGL(outer_relu_bwd_kernel, dim3((B * NF + 255) / 256), dim3(256), 0, s, B, NF, dlogit, w, f, keep,
+                     dz);
+  SCORE_CHECK_LAUNCH();
+  return 0;
+}
+
+// dst[r][c] = src[r][c]  with independent row strides
+__global__ void copy2d_kernel(int64_t rows, int cols, const float* __restrict__ src, int lds_, float* __restrict__ dst,
+                              int ldd) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * cols) return;
+  int64_t r = i / cols;
+  int c = (int)(i - r * cols);
+  dst[r * ldd + c] = src[r * lds_ + c];
+}
+int score_launch_copy2d(int64_t rows, int cols, const float* src, int lds_, float* dst, int ldd, hipStream_t s) {
+  hipLaunchKernelGGL(copy2d_kernel, dim3((unsigned)cdiv64(rows * cols, 256)), dim3(256), 0, s, rows, cols, src,
+                     lds_, dst, ldd);
+  SCORE_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------ ApplyAdam (score.py:96-99)
+// TF training_ops: m += (g - m)(1-b1); v += (g*g - v)(1-b2); var -= m*alpha / (sqrt(v) + eps)
+__device__ __forceinline__ void adam1(float& p, float& m, float& v, float g, float omb1, float omb2, float alpha,
+                                      float eps) {
+  m += (g - m) * omb1;
+  v += (g * g - v) * omb2;
+  p -= (m * alpha) / (sqrtf(v) + eps);
+}
+__global__ void adam_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
+                            const float* __restrict__ g, int64_t n4, int64_t n, int64_t n_reg, float l2, float alpha,
+                            float omb1, float omb2, float eps) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n4; i += stride) {
+    float4 pp = ld4(p + i * 4), mm = ld4(m + i * 4), vv = ld4(v + i * 4), gg = ld4(g + i * 4);
+    int64_t e = i * 4;
+    if (e < n_reg) {  // d/dw of lambda * sum(w^2)/2   (build_l2norm, score.py:91-94)
+      gg.x = e + 0 < n_reg ? fmaf(l2, pp.x, gg.x) : gg.x;
+      gg.y = e + 1 < n_reg ? fmaf(l2, pp.y, gg.y) : gg.y;
+      gg.z = e + 2 < n_reg ? fmaf(l2, pp.z, gg.z) : gg.z;
+      gg.w = e + 3 < n_reg ? fmaf(l2, pp.w, gg.w) : gg.w;
+    }
+    adam1(pp.x, mm.x, vv.x, gg.x, omb1, omb2, alpha, eps);
+    adam1(pp.y, mm.y, vv.y, gg.y, omb1, omb2, alpha, eps);
+    adam1(pp.z, mm.z, vv.z, gg.z, omb1, omb2, alpha, eps);
+    adam1(pp.w, mm.w, vv.w, gg.w, omb1, omb2, alpha, eps);
+    st4(p + i * 4, pp); st4(m + i * 4, mm); st4(v + i * 4, vv);
+  }
+  // tail (n not a multiple of 4)
+  if (blockIdx.x == 0 && threadIdx.x < (unsigned)(n - n4 * 4)) {
+    int64_t e = n4 * 4 + threadIdx.x;
+    float pp = p[e], mm = m[e], vv = v[e], gg = g[e];
+    if (e < n_reg) gg = fmaf(l2, pp, gg);
+    adam1(pp, mm, vv, gg, omb1, omb2, alpha, eps);
+    p[e] = pp; m[e] = mm; v[e] = vv;
+  }
+}
+
+extern "C" int score_adam(float* p, float* m, float* v, const float* g, int64_t n, int64_t n_reg, float l2,
+                          float alpha, float beta1, float beta2, float eps, void* stream) {
+  if (!p || !m || !v || !g || n <= 0) return SCORE_E_BADARG;
+  if ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v) |
+       reinterpret_cast<uintptr_t>(g)) & 15)
+    return SCORE_E_SHAPE;
+  int64_t n4 = n / 4;
+  int64_t want = cdiv64(n4 > 0 ? n4 : 1, 256);
+  int blocks = (int)(want < 8192 ? want : 8192);
+  hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, m, v, g, n4, n, n_reg, l2,
+                     alpha, 1.0f - beta1, 1.0f - beta2, eps);
+  SCORE_CHECK_LAUNCH();
+  return 0;
+}

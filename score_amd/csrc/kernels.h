@@ -1,0 +1,46 @@
+// Internal (non-ABI) launchers shared between the translation units of libscore_hip.
+#pragma once
+#include "common.h"
+
+// embed.hip
+int score_coattn_fwd_strided(const float* table, int D, int F, int K, int B, int T, const int32_t* idx1,
+                             const int32_t* idx2, const float* tgt, int ldt, const float* W,
+                             const float* bias, float* out1, int ld1, float* out2, int ld2, float* info,
+                             int ldi, float* rsave, int mode, hipStream_t s);
+int score_launch_target_fwd(const float* table, int D, int Fu, int Fi, int B, const int32_t* tu,
+                            const int32_t* ti, float* query, int ldq, float* head, int ldh,
+                            int off_ti, int off_tu, hipStream_t s);
+int score_launch_target_bwd(float* grad_table, int D, int Fu, int Fi, int B, int T, const int32_t* tu,
+                            const int32_t* ti, const float* dquery, int ldq, const float* dhead, int ldh,
+                            int off_ti, int off_tu, const float* query, const float* W1, const float* W2,
+                            const float* dzsum1, const float* dzsum2, float* S /*[2][B]*/,
+                            float* dW1, float* dB1, float* dW2, float* dB2, hipStream_t s);
+// gemm.hip
+int score_launch_colsum(const float* X, int M, int N, int ld, float* out, int accumulate,
+                        float* scratch, int64_t scratch_floats, hipStream_t s);
+int score_launch_relu_bwd(float* dY, const float* Y, int64_t rows, int cols, int ldd, int ldy,
+                          float divisor, hipStream_t s);
+// head.hip
+int score_launch_attn_build_inp(int B, int T, int H, int NI, const float* q, const float* ur, const float* ir,
+                                const float* info, float* inp, hipStream_t s);
+int score_launch_attn_pool_fwd(int B, int T, int H, int NA, const float* a2, const float* w5, const float* b5,
+                               const int32_t* length, const float* ur, const float* ir, float* score, float* head,
+                               int ldh, int off_u, int off_i, hipStream_t s);
+int score_launch_attn_pool_bwd(int B, int T, int H, int NA, const float* a2, const float* w5,
+                               const int32_t* length, const float* ur, const float* ir, const float* score,
+                               const float* dhead, int ldh, int off_u, int off_i, float* ds, float* da2,
+                               hipStream_t s);
+int score_launch_attn_inp_bwd(int B, int T, int H, int NI, const float* dinp, const float* q, const float* ur,
+                              const float* ir, const float* info, const float* score, const float* dhead, int ldh,
+                              int off_u, int off_i, float* dur, float* dir, float* dinfo, float* dq,
+                              hipStream_t s);
+int score_launch_bn_fwd(int B, int Dh, const float* x, const float* gamma, const float* beta, float rs, float* y,
+                        hipStream_t s);
+int score_launch_bn_bwd(int B, int Dh, const float* x, const float* gamma, float rs, const float* dy, float* dx,
+                        float* dgamma, float* dbeta, hipStream_t s);
+int score_launch_head_out(int B, int NF, const float* f2, const float* w3, const float* b3, const int32_t* label,
+                          float* logit, float* y, float* lossb, float* dlogit, float* loss, const float* wreg,
+                          int64_t n_reg, float lambda, float* part, hipStream_t s);
+int score_launch_outer_relu_bwd(int B, int NF, const float* dlogit, const float* w, const float* f, float keep,
+                                float* dz, hipStream_t s);
+int score_launch_copy2d(int64_t rows, int cols, const float* src, int lds_, float* dst, int ldd, hipStream_t s);

@@ -1,0 +1,300 @@
+"""Drop-in host side of the SCoRe hot path on MI355X.
+
+Mirrors the reference's model interface (code/score/score.py):
+    SCORE(feature_size, eb_dim, hidden_size, max_time_len, obj_per_time_slice, user_fnum, item_fnum)
+    loss = model.train(sess, batch_data, lr, reg_lambda)            # score.py:101-116
+    pred, label, loss = model.eval(sess, batch_data, reg_lambda)    # score.py:118-133
+    model.save(sess, path) / model.restore(sess, path)              # score.py:135-142
+plus the ablations RIA, RCA, SCORE_USER, SCORE_ITEM (score.py:227-369).  ``sess`` is
+accepted and ignored (there is no TF session).  ``batch_data`` is the 8-tuple the
+reference's GraphLoader yields (graph_loader.py:383): nested lists, ndarrays or
+tensors, indexed positionally.
+
+All compute runs in libscore_hip.so (hand-written HIP for gfx950) through the C-ABI of
+include/score_hip.h; PyTorch only owns device memory and streams.  There is no CPU path.
+"""
+import ctypes as C
+import math
+import os
+
+import numpy as np
+import torch
+
+from . import _lib
+
+ADAM_B1, ADAM_B2, ADAM_EPS = 0.9, 0.999, 1e-8      # tf.train.AdamOptimizer defaults
+BATCH_FIELDS = ("user_1hop", "user_2hop", "item_1hop", "item_2hop",
+                "target_user", "target_item", "label", "length")
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class DeviceBatch(object):
+    """int32 device tensors of one batch + the C struct pointing at them."""
+
+    def __init__(self, model, batch_data):
+        if isinstance(batch_data, DeviceBatch):
+            raise TypeError("already a DeviceBatch")
+        if len(batch_data) != 8:
+            raise ValueError("batch_data must be the 8-tuple of graph_loader.py:383")
+        c = model.cfg
+        T, K, Fu, Fi = c.max_time_len, c.obj_per_time_slice, c.user_fnum, c.item_fnum
+        self.tensors = []
+        B = None
+        shapes = ((T, K, Fi), (T, K, Fu), (T, K, Fu), (T, K, Fi), (Fu,), (Fi,), (), ())
+        for i, x in enumerate(batch_data):
+            if torch.is_tensor(x):
+                t = x.to(device=model.device, dtype=torch.int32).contiguous()
+            else:
+                # nested lists hold ints, with float 0.0 in dummy slices (graph_loader.py:90-91)
+                a = np.asarray(x)
+                if a.dtype != np.int32:
+                    a = a.astype(np.int32)
+                t = torch.from_numpy(np.ascontiguousarray(a)).to(model.device, non_blocking=True)
+            if B is None:
+                B = t.shape[0]
+            if tuple(t.shape) != (B,) + shapes[i]:
+                raise ValueError("batch_data[%d] (%s) has shape %s, expected %s" %
+                                 (i, BATCH_FIELDS[i], tuple(t.shape), (B,) + shapes[i]))
+            self.tensors.append(t)
+        if B == 0:
+            raise ValueError("empty batch")
+        self.B = B
+        self.struct = _lib.Batch(*[_ptr(t) for t in self.tensors], B)
+
+
+class SCOREBASE(object):
+    model_type = None
+
+    def __init__(self, feature_size, eb_dim, hidden_size, max_time_len, obj_per_time_slice,
+                 user_fnum, item_fnum, seed=1111, device=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("score_amd needs an AMD GPU (HIP); there is no CPU fallback")
+        self.lib = _lib.load()
+        self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+        self.cfg = _lib.make_config(feature_size, eb_dim, hidden_size, max_time_len, obj_per_time_slice,
+                                    user_fnum, item_fnum, self.model_type)
+        self.obj_per_time_slice = obj_per_time_slice
+        self.entries, self.n_w, self.n_reg = _lib.param_layout(self.cfg)
+        N, D = int(feature_size), int(eb_dim)
+        f32 = dict(dtype=torch.float32, device=self.device)
+        self.table = torch.empty((N, D), **f32)
+        self.w = torch.zeros((self.n_w,), **f32)
+        self._alloc_optimizer()
+        self._ws = {}
+        self.step = 0
+        self.beta1_power = np.float32(ADAM_B1)
+        self.beta2_power = np.float32(ADAM_B2)
+        self.row0 = np.zeros((D,), dtype=np.float32)   # value of the masked variable row (score.py:44-47)
+        self._drop_seed = int(seed)
+        self._init_params(seed)
+
+    # ------------------------------------------------------------------ parameters
+    def _alloc_optimizer(self):
+        f32 = dict(dtype=torch.float32, device=self.device)
+        self.table_m = torch.zeros_like(self.table)
+        self.table_v = torch.zeros_like(self.table)
+        self.table_g = torch.zeros_like(self.table)
+        self.w_m = torch.zeros((self.n_w,), **f32)
+        self.w_v = torch.zeros((self.n_w,), **f32)
+        self.w_g = torch.zeros((self.n_w,), **f32)
+
+    def _view(self, flat, entry):
+        name, off, rows, cols, _, _ = entry
+        n = rows * (cols if cols else 1)
+        v = flat[off:off + n]
+        return v.view(rows, cols) if cols else v
+
+    def _init_params(self, seed):
+        """TF initialiser families: truncated normal(0,1) table (score.py:44), glorot-uniform
+        dense/GRU kernels, GRU gate bias 1, zeros elsewhere."""
+        gen = torch.Generator(device=self.device)
+        gen.manual_seed(int(seed))
+        torch.nn.init.trunc_normal_(self.table, mean=0.0, std=1.0, a=-2.0, b=2.0, generator=gen)
+        self.row0 = self.table[0].cpu().numpy().copy()
+        self.table[0].zero_()
+        for e in self.entries:
+            v = self._view(self.w, e)
+            if e[5] == 2:
+                lim = math.sqrt(6.0 / (e[2] + e[3]))
+                v.uniform_(-lim, lim, generator=gen)
+            elif e[5] == 1:
+                v.fill_(1.0)
+            else:
+                v.zero_()
+
+    def get_params(self):
+        """dict TF variable name -> ndarray (emb_mtx carries its masked row 0 value)."""
+        out = {"emb_mtx": self.table.cpu().numpy()}
+        out["emb_mtx"][0] = self.row0
+        for e in self.entries:
+            out[e[0]] = self._view(self.w, e).cpu().numpy().copy()
+        return out
+
+    def set_params(self, params):
+        emb = np.asarray(params["emb_mtx"], dtype=np.float32)
+        if emb.shape != tuple(self.table.shape):
+            raise ValueError("emb_mtx shape %s != %s" % (emb.shape, tuple(self.table.shape)))
+        self.row0 = emb[0].copy()
+        self.table.copy_(torch.from_numpy(emb))
+        self.table[0].zero_()
+        for e in self.entries:
+            v = self._view(self.w, e)
+            a = np.asarray(params[e[0]], dtype=np.float32).reshape(tuple(v.shape))
+            v.copy_(torch.from_numpy(a))
+
+    def get_grads(self):
+        out = {"emb_mtx": self.table_g.cpu().numpy()}
+        for e in self.entries:
+            out[e[0]] = self._view(self.w_g, e).cpu().numpy().copy()
+        return out
+
+    # ------------------------------------------------------------------ device plumbing
+    def _workspace(self, B):
+        ent = self._ws.get(B)
+        if ent is None:
+            lay = _lib.workspace_layout(self.cfg, B)
+            buf = torch.empty((lay.total_bytes // 4,), dtype=torch.float32, device=self.device)
+            if len(self._ws) > 4:
+                self._ws.clear()
+            ent = self._ws[B] = (lay, buf)
+        return ent
+
+    def _state(self, ws):
+        return _lib.State(_ptr(self.table), self.table.shape[0], _ptr(self.w), _ptr(ws), ws.numel() * 4)
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def device_batch(self, batch_data):
+        return batch_data if isinstance(batch_data, DeviceBatch) else DeviceBatch(self, batch_data)
+
+    def ws_tensor(self, B, field, shape):
+        """View of a named workspace region (tests / introspection)."""
+        lay, buf = self._workspace(B)
+        off = getattr(lay, field)
+        n = int(np.prod(shape))
+        return buf[off:off + n].view(*shape)
+
+    # ------------------------------------------------------------------ forward / backward / update
+    def _forward(self, db, reg_lambda, keep_prob, masks):
+        lay, ws = self._workspace(db.B)
+        st = self._state(ws)
+        m0 = m1 = None
+        if masks is not None:
+            m0 = torch.as_tensor(np.asarray(masks[0]), dtype=torch.uint8).to(self.device).contiguous()
+            m1 = torch.as_tensor(np.asarray(masks[1]), dtype=torch.uint8).to(self.device).contiguous()
+            if tuple(m0.shape) != (db.B, 200) or tuple(m1.shape) != (db.B, 80):
+                raise ValueError("dropout masks must be [B,200] and [B,80]")
+        seed = (self._drop_seed * 0x9E3779B1 + self.step * 0x85EBCA77) & 0xFFFFFFFFFFFFFFFF
+        rc = self.lib.score_forward(C.byref(self.cfg), C.byref(st), C.byref(db.struct), float(reg_lambda),
+                                    float(keep_prob), _ptr(m0), _ptr(m1), C.c_uint64(seed), self._stream())
+        _lib.check(rc, "score_forward")
+        self._keep = (m0, m1)
+        return lay, ws, st
+
+    def forward_backward(self, batch_data, reg_lambda, keep_prob=1.0, dropout_masks=None):
+        """Forward + backward; gradients land in self.w_g (without the L2 term) and
+        self.table_g (dense [N,D]).  Returns the device workspace layout/buffer."""
+        db = self.device_batch(batch_data)
+        lay, ws, st = self._forward(db, reg_lambda, keep_prob, dropout_masks)
+        self.table_g.zero_()
+        rc = self.lib.score_backward(C.byref(self.cfg), C.byref(st), C.byref(db.struct), float(keep_prob),
+                                     _ptr(self.w_g), _ptr(self.table_g), self._stream())
+        _lib.check(rc, "score_backward")
+        return lay, ws
+
+    def _alpha(self, lr):
+        f = np.float32
+        return float(f(f(lr) * np.sqrt(f(1) - self.beta2_power) / (f(1) - self.beta1_power)))
+
+    def apply_adam(self, lr, reg_lambda):
+        """tf.train.AdamOptimizer(lr).minimize(loss) update (score.py:96-99): dense over the
+        whole table (the emb_mtx*mask gradient is dense) and over every dense variable."""
+        a = self._alpha(lr)
+        s = self._stream()
+        rc = self.lib.score_adam(_ptr(self.table), _ptr(self.table_m), _ptr(self.table_v), _ptr(self.table_g),
+                                 self.table.numel(), 0, 0.0, a, ADAM_B1, ADAM_B2, ADAM_EPS, s)
+        _lib.check(rc, "score_adam(table)")
+        rc = self.lib.score_adam(_ptr(self.w), _ptr(self.w_m), _ptr(self.w_v), _ptr(self.w_g), self.n_w,
+                                 self.n_reg, float(reg_lambda), a, ADAM_B1, ADAM_B2, ADAM_EPS, s)
+        _lib.check(rc, "score_adam(dense)")
+        self.beta1_power = np.float32(self.beta1_power * np.float32(ADAM_B1))
+        self.beta2_power = np.float32(self.beta2_power * np.float32(ADAM_B2))
+        self.step += 1
+
+    def train_async(self, batch_data, lr, reg_lambda, keep_prob=0.8, dropout_masks=None):
+        """One training step; returns the loss as a 0-d device tensor (no host sync)."""
+        lay, ws = self.forward_backward(batch_data, reg_lambda, keep_prob, dropout_masks)
+        self.apply_adam(lr, reg_lambda)
+        return ws[lay.loss]
+
+    # ------------------------------------------------------------------ reference interface
+    def train(self, sess, batch_data, lr, reg_lambda, keep_prob=0.8, dropout_masks=None):
+        return float(self.train_async(batch_data, lr, reg_lambda, keep_prob, dropout_masks).item())
+
+    def eval(self, sess, batch_data, reg_lambda):
+        db = self.device_batch(batch_data)
+        lay, ws, _ = self._forward(db, reg_lambda, 1.0, None)
+        B = db.B
+        pred = ws[lay.y_pred:lay.y_pred + B].cpu().numpy()
+        label = db.tensors[6].cpu().numpy()
+        loss = float(ws[lay.loss].item())
+        return pred.reshape([-1, ]).tolist(), label.reshape([-1, ]).tolist(), loss
+
+    def save(self, sess, path):
+        """All global variables incl. the Adam slots, under the TF variable names."""
+        blob = {}
+        for k, v in self.get_params().items():
+            blob[k] = v
+        tm, tv = self.table_m.cpu().numpy(), self.table_v.cpu().numpy()
+        blob["emb_mtx/Adam"], blob["emb_mtx/Adam_1"] = tm, tv
+        for e in self.entries:
+            blob[e[0] + "/Adam"] = self._view(self.w_m, e).cpu().numpy()
+            blob[e[0] + "/Adam_1"] = self._view(self.w_v, e).cpu().numpy()
+        blob["beta1_power"] = self.beta1_power
+        blob["beta2_power"] = self.beta2_power
+        blob["global_step"] = np.int64(self.step)
+        d = os.path.dirname(path)
+        if d:
+            os.makedirs(d, exist_ok=True)
+        with open(path + ".npz", "wb") as f:
+            np.savez(f, **blob)
+
+    def restore(self, sess, path):
+        z = np.load(path + ".npz")
+        self.set_params({k: z[k] for k in ["emb_mtx"] + [e[0] for e in self.entries]})
+        self.table_m.copy_(torch.from_numpy(z["emb_mtx/Adam"]))
+        self.table_v.copy_(torch.from_numpy(z["emb_mtx/Adam_1"]))
+        for e in self.entries:
+            self._view(self.w_m, e).copy_(torch.from_numpy(z[e[0] + "/Adam"]).view_as(self._view(self.w_m, e)))
+            self._view(self.w_v, e).copy_(torch.from_numpy(z[e[0] + "/Adam_1"]).view_as(self._view(self.w_v, e)))
+        self.beta1_power = np.float32(z["beta1_power"])
+        self.beta2_power = np.float32(z["beta2_power"])
+        self.step = int(z["global_step"])
+        print('model restored from {}'.format(path))
+
+
+class SCORE(SCOREBASE):
+    model_type = "SCORE"
+
+
+class RIA(SCOREBASE):
+    model_type = "RIA"
+
+
+class RCA(SCOREBASE):
+    model_type = "RCA"
+
+
+class SCORE_USER(SCOREBASE):
+    model_type = "SCORE_USER"
+
+
+class SCORE_ITEM(SCOREBASE):
+    model_type = "SCORE_ITEM"
+
+
+MODELS = {"SCORE": SCORE, "RIA": RIA, "RCA": RCA, "SCORE_USER": SCORE_USER, "SCORE_ITEM": SCORE_ITEM}

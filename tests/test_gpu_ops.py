@@ -1,0 +1,264 @@
+"""GPU parity of the individual C-ABI ops against the oracle / a torch fp32 reference."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import score_oracle as so
+from score_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+
+def P(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def dev(a, dtype=None):
+    t = torch.as_tensor(np.asarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda().contiguous()
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def test_gather_bit_exact():
+    # tf.nn.embedding_lookup (score.py:51-66): pure row copy -> bit-exact
+    lib = _lib.load()
+    rng = np.random.default_rng(0)
+    for N, D, n in ((1000, 16, 5000), (50000, 64, 70001), (300, 4, 17), (4096, 128, 999)):
+        table = rng.standard_normal((N, D)).astype(np.float32)
+        idx = rng.integers(0, N, n).astype(np.int32)
+        idx[:3] = [0, N - 1, 0]
+        t, i = dev(table), dev(idx)
+        out = torch.empty((n, D), dtype=torch.float32, device="cuda")
+        _lib.check(lib.score_gather_fwd(P(t), N, D, P(i), n, P(out), stream()), "gather")
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy(), table[idx])
+    # empty input is a no-op
+    assert lib.score_gather_fwd(P(t), N, D, P(i), 0, P(out), stream()) == 0
+    # error behaviour: bad D, null pointer
+    assert lib.score_gather_fwd(P(t), N, 6, P(i), 4, P(out), stream()) == -2
+    assert lib.score_gather_fwd(C.c_void_p(0), N, 4, P(i), 4, P(out), stream()) == -1
+
+
+@pytest.mark.parametrize("trans", [0, 1, 2])
+@pytest.mark.parametrize("shape", [(64, 64, 16), (130, 70, 37), (2048, 384, 448), (5, 1, 80), (200, 80, 1000),
+                                   (1184, 80, 4096)])
+def test_gemm_fp32(trans, shape):
+    lib = _lib.load()
+    M, N, K = shape
+    g = torch.Generator(device="cuda").manual_seed(M * 7 + N * 3 + K + trans)
+    a = torch.randn((M, K), device="cuda", generator=g)
+    b = torch.randn((K, N), device="cuda", generator=g)
+    bias = torch.randn((N,), device="cuda", generator=g)
+    A = a if trans != 2 else a.t().contiguous()          # stored [K,M]
+    Bm = b if trans != 1 else b.t().contiguous()         # stored [N,K]
+    lda = A.shape[1]
+    ldb = Bm.shape[1]
+    scratch = torch.empty((1 << 22,), device="cuda")
+    ref = (a.double() @ b.double())
+    tol = 2e-6 * (a.abs().double() @ b.abs().double()) + 1e-6
+    for flags in (0, 1 | 2, 4):
+        c0 = torch.randn((M, N + 3), device="cuda", generator=g)
+        c = c0.clone()
+        _lib.check(lib.score_gemm(trans, M, N, K, P(A), lda, P(Bm), ldb, P(c), N + 3, P(bias), flags, 1.0,
+                                  C.c_void_p(0), 0, P(scratch), scratch.numel(), stream()), "gemm")
+        torch.cuda.synchronize()
+        want = ref.clone()
+        if flags & 1:
+            want = want + bias.double()
+        if flags & 2:
+            want = want.clamp_min(0)
+        if flags & 4:
+            want = want + c0[:, :N].double()
+        assert torch.equal(c[:, N:], c0[:, N:]), "wrote outside the N columns"
+        err = (c[:, :N].double() - want).abs()
+        assert bool((err <= tol).all()), float((err / tol).max())
+
+
+def test_gemm_dropout_epilogue():
+    lib = _lib.load()
+    M, N, K = 128, 200, 64
+    g = torch.Generator(device="cuda").manual_seed(3)
+    a, b = torch.randn((M, K), device="cuda", generator=g), torch.randn((K, N), device="cuda", generator=g)
+    bias = torch.zeros((N,), device="cuda")
+    mask = (torch.rand((M, N), device="cuda", generator=g) < 0.8).to(torch.uint8)
+    c = torch.empty((M, N), device="cuda")
+    _lib.check(lib.score_gemm(0, M, N, K, P(a), K, P(b), N, P(c), N, P(bias), 1 | 2 | 8, 0.8, P(mask), 0,
+                              C.c_void_p(0), 0, stream()), "gemm")
+    want = torch.relu(a @ b) / 0.8 * mask
+    assert torch.allclose(c, want, rtol=1e-5, atol=1e-5)
+    # hashed mask: keep fraction ~ keep_prob, kept values scaled by 1/keep
+    c2 = torch.empty((M, N), device="cuda")
+    _lib.check(lib.score_gemm(0, M, N, K, P(a), K, P(b), N, P(c2), N, P(bias), 1 | 8, 0.8, C.c_void_p(0), 1234,
+                              C.c_void_p(0), 0, stream()), "gemm")
+    full = a @ b
+    kept = c2 != 0
+    assert abs(float(kept.float().mean()) - 0.8) < 0.02
+    assert torch.allclose(c2[kept], full[kept] / 0.8, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("D,F,K,B,T", [(4, 3, 2, 5, 3), (16, 4, 10, 9, 11), (16, 3, 10, 9, 11), (64, 4, 10, 6, 5),
+                                       (64, 3, 5, 7, 4), (8, 1, 4, 6, 5), (128, 2, 20, 3, 4), (32, 5, 7, 4, 3)])
+def test_coattn_fwd_bwd(D, F, K, B, T):
+    # fused gather + co_attention (score.py:147-167) vs Oracle B's collapsed form + autograd
+    lib = _lib.load()
+    rng = np.random.default_rng(D + F + K)
+    N = 500
+    Dx = F * D
+    table = rng.standard_normal((N, D)).astype(np.float32)
+    table[0] = 0
+    idx1 = rng.integers(0, N, (B, T, K, F)).astype(np.int32)
+    idx2 = rng.integers(0, N, (B, T, K, F)).astype(np.int32)
+    idx1[0, 0] = 0
+    idx2[0, 0] = 0
+    idx1[1, :, 2:] = idx1[1, :, :1]
+    tgt_idx = rng.integers(1, N, (B, F))
+    W = (rng.standard_normal((3 * Dx, 1)) * 0.2).astype(np.float32)
+    bias = np.asarray([0.1], dtype=np.float32)
+    tt = torch.tensor(table, requires_grad=True)
+    Wt, bt = torch.tensor(W, requires_grad=True), torch.tensor(bias, requires_grad=True)
+    s1 = tt[torch.as_tensor(idx1).long()].reshape(B, T, K, Dx)
+    s2 = tt[torch.as_tensor(idx2).long()].reshape(B, T, K, Dx)
+    tg = tt[torch.as_tensor(tgt_idx).long()].reshape(B, Dx).detach().requires_grad_(True)
+    o1, o2, info = so._co_attention_collapsed(s1, s2, tg, Wt, bt)
+    g1 = torch.tensor(rng.standard_normal((B, T, Dx)).astype(np.float32))
+    g2 = torch.tensor(rng.standard_normal((B, T, Dx)).astype(np.float32))
+    gi = torch.tensor(rng.standard_normal((B, T, 2 * K)).astype(np.float32))
+    ((o1 * g1).sum() + (o2 * g2).sum() + (info * gi).sum()).backward()
+
+    dt, di1, di2 = dev(table), dev(idx1), dev(idx2)
+    dtg, dW, db = dev(tg.detach().numpy()), dev(W.reshape(-1)), dev(bias)
+    out1 = torch.zeros((B * T, Dx + 4), device="cuda")
+    out2 = torch.zeros((B * T, Dx), device="cuda")
+    oinfo = torch.zeros((B * T, 2 * K + 1), device="cuda")
+    rs = torch.zeros((B * T, K), device="cuda")
+    _lib.check(lib.score_coattn_fwd(P(dt), N, D, F, K, B, T, P(di1), P(di2), P(dtg), P(dW), P(db), P(out1), Dx + 4,
+                                    P(out2), Dx, P(oinfo), 2 * K + 1, P(rs), 0, stream()), "coattn_fwd")
+    torch.cuda.synchronize()
+    assert np.allclose(out1[:, :Dx].cpu().numpy(), o1.detach().numpy().reshape(B * T, Dx), rtol=1e-5, atol=2e-6)
+    assert np.allclose(out2.cpu().numpy(), o2.detach().numpy().reshape(B * T, Dx), rtol=1e-5, atol=2e-6)
+    assert np.allclose(oinfo[:, :2 * K].cpu().numpy(), info.detach().numpy().reshape(B * T, 2 * K), rtol=1e-5, atol=1e-5)
+    assert float(out1[:, Dx:].abs().max()) == 0 and float(oinfo[:, 2 * K:].abs().max()) == 0
+
+    gt = torch.zeros((N, D), device="cuda")
+    dzs = torch.zeros((B * T,), device="cuda")
+    gW = torch.zeros((3 * Dx,), device="cuda")
+    scratch = torch.empty((1 << 21,), device="cuda")
+    _lib.check(lib.score_coattn_bwd(P(dt), P(gt), N, D, F, K, B, T, P(di1), P(di2), P(dW), P(rs), P(dev(g1)), Dx,
+                                    P(dev(g2)), Dx, P(dev(gi)), 2 * K, P(dzs), P(gW), P(scratch), scratch.numel(),
+                                    0, stream()), "coattn_bwd")
+    torch.cuda.synchronize()
+    # row gradients: autograd on `tt` also holds the target-row path, which this op does not own,
+    # but tg was detached so tt.grad is exactly the neighbour-row scatter; row 0 is masked out.
+    want = tt.grad.numpy().copy()
+    want[0] = 0
+    got = gt.cpu().numpy()
+    assert np.abs(got[0]).max() == 0
+    assert np.allclose(got, want, rtol=2e-4, atol=2e-5), np.abs(got - want).max()
+    wg = Wt.grad.numpy().reshape(-1)
+    assert np.allclose(gW[Dx:].cpu().numpy(), wg[Dx:], rtol=2e-4, atol=2e-5)
+    # dzsum feeds w_t / bias / target grads: sum_bt dzsum == dbias
+    assert abs(float(dzs.sum()) - float(bt.grad)) < 1e-4 * max(1.0, abs(float(bt.grad)))
+
+
+def test_coattn_rca_sum_mode():
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+    N, D, F, K, B, T = 200, 16, 3, 10, 4, 3
+    table = rng.standard_normal((N, D)).astype(np.float32)
+    table[0] = 0
+    idx1 = rng.integers(0, N, (B, T, K, F)).astype(np.int32)
+    idx2 = rng.integers(0, N, (B, T, K, F)).astype(np.int32)
+    o1 = torch.zeros((B * T, F * D), device="cuda")
+    o2 = torch.zeros((B * T, F * D), device="cuda")
+    z = C.c_void_p(0)
+    _lib.check(lib.score_coattn_fwd(P(dev(table)), N, D, F, K, B, T, P(dev(idx1)), P(dev(idx2)), z, z, z, P(o1),
+                                    F * D, P(o2), F * D, z, 0, z, 1, stream()), "rca")
+    w1 = table[idx1].reshape(B * T, K, F * D).sum(1)
+    w2 = table[idx2].reshape(B * T, K, F * D).sum(1)
+    assert np.allclose(o1.cpu().numpy(), w1, rtol=1e-5, atol=1e-5)
+    assert np.allclose(o2.cpu().numpy(), w2, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("B,T,H", [(5, 3, 8), (70, 11, 32), (33, 6, 128), (9, 4, 20)])
+def test_gru_fwd_bwd(B, T, H):
+    # dynamic_rnn(GRUCell) recurrence (score.py:205-208) vs the oracle's _gru + autograd
+    lib = _lib.load()
+    rng = np.random.default_rng(B + T + H)
+    I = 12
+    x = torch.tensor(rng.standard_normal((B, T, I)).astype(np.float32), requires_grad=True)
+    Wg = torch.tensor((rng.standard_normal((I + H, 2 * H)) * 0.3).astype(np.float32), requires_grad=True)
+    bg = torch.tensor(np.ones(2 * H, dtype=np.float32), requires_grad=True)
+    Wc = torch.tensor((rng.standard_normal((I + H, H)) * 0.3).astype(np.float32), requires_grad=True)
+    bc = torch.tensor((rng.standard_normal(H) * 0.1).astype(np.float32), requires_grad=True)
+    length = rng.integers(1, T + 1, B)
+    length[0] = T
+    outs, hfin = so._gru(x, torch.as_tensor(length), Wg, bg, Wc, bc, H)
+    go = torch.tensor(rng.standard_normal((B, T, H)).astype(np.float32))
+    gf = torch.tensor(rng.standard_normal((B, H)).astype(np.float32))
+    ((outs * go).sum() + (hfin * gf).sum()).backward()
+
+    with torch.no_grad():
+        xp = torch.cat([x.reshape(B * T, I) @ Wg[:I] + bg, x.reshape(B * T, I) @ Wc[:I] + bc], 1)
+    dxp = dev(xp.numpy())
+    dWg, dWc = dev(Wg.detach().numpy()), dev(Wc.detach().numpy())
+    dl = dev(length.astype(np.int32))
+    out = torch.zeros((B * T, H), device="cuda")
+    gates = torch.zeros((B * T, 3 * H), device="cuda")
+    fin = torch.zeros((B, H), device="cuda")
+    wg_h = C.c_void_p(dWg.data_ptr() + I * 2 * H * 4)
+    wc_h = C.c_void_p(dWc.data_ptr() + I * H * 4)
+    _lib.check(lib.score_gru_fwd(B, T, H, P(dxp), wg_h, 2 * H, wc_h, H, P(dl), P(out), H, P(gates), P(fin),
+                                 stream()), "gru_fwd")
+    torch.cuda.synchronize()
+    assert np.allclose(out.cpu().numpy(), outs.detach().numpy().reshape(B * T, H), rtol=1e-5, atol=2e-6)
+    assert np.allclose(fin.cpu().numpy(), hfin.detach().numpy(), rtol=1e-5, atol=2e-6)
+
+    dxproj = torch.zeros((B * T, 3 * H), device="cuda")
+    rh = torch.zeros((B * T, H), device="cuda")
+    hprev = torch.zeros((B * T * H + 3 * H * H,), device="cuda")
+    _lib.check(lib.score_gru_bwd(B, T, H, wg_h, 2 * H, wc_h, H, P(dl), P(out), H, P(gates), P(dev(go)), H,
+                                 P(dev(gf)), P(dxproj), P(rh), P(hprev), stream()), "gru_bwd")
+    torch.cuda.synchronize()
+    d = dxproj.cpu()
+    # dx = dxproj . Wx^T ; dWx = x^T dxproj ; dWh = [hprev ; rh]^T dxproj ; db = colsum
+    xf = x.detach().reshape(B * T, I)
+    dx = d[:, :2 * H] @ Wg.detach()[:I].t() + d[:, 2 * H:] @ Wc.detach()[:I].t()
+    assert np.allclose(dx.numpy(), x.grad.reshape(B * T, I).numpy(), rtol=2e-4, atol=2e-5)
+    hp = hprev[:B * T * H].view(B * T, H).cpu()
+    gWg = torch.cat([xf.t() @ d[:, :2 * H], hp.t() @ d[:, :2 * H]], 0)
+    gWc = torch.cat([xf.t() @ d[:, 2 * H:], rh.cpu().t() @ d[:, 2 * H:]], 0)
+    assert np.allclose(gWg.numpy(), Wg.grad.numpy(), rtol=2e-4, atol=5e-5)
+    assert np.allclose(gWc.numpy(), Wc.grad.numpy(), rtol=2e-4, atol=5e-5)
+    assert np.allclose(d[:, :2 * H].sum(0).numpy(), bg.grad.numpy(), rtol=2e-4, atol=5e-5)
+
+
+def test_adam_matches_tf_form():
+    lib = _lib.load()
+    rng = np.random.default_rng(1)
+    n, n_reg = 10007, 5000
+    p = rng.standard_normal(n).astype(np.float32)
+    pad = (-n) % 4
+    params = {"p": p.copy()}
+    opt = so.TFAdam(params)
+    dp = dev(np.concatenate([p, np.zeros(pad, np.float32)]))
+    dm, dv = torch.zeros_like(dp), torch.zeros_like(dp)
+    lam = 1e-3
+    for step in range(3):
+        g = rng.standard_normal(n).astype(np.float32)
+        g[::7] = 0
+        geff = g.copy()
+        geff[:n_reg] += np.float32(lam) * params["p"][:n_reg]
+        a = float(opt.alpha(1e-3))
+        opt.step(params, {"p": geff}, 1e-3)
+        dg = dev(np.concatenate([g, np.zeros(pad, np.float32)]))
+        _lib.check(lib.score_adam(P(dp), P(dm), P(dv), P(dg), n, n_reg, lam, a, 0.9, 0.999, 1e-8, stream()), "adam")
+        torch.cuda.synchronize()
+        assert np.allclose(dp.cpu().numpy()[:n], params["p"], rtol=1e-6, atol=1e-7)
+        assert np.allclose(dm.cpu().numpy()[:n], opt.m["p"], rtol=1e-6, atol=1e-9)
