@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""bench.py -- train samples/sec of the SCoRe hot path on MI355X.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg3]
+  (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+
+A "step" is one full training step of SCORE (score.py:101-116: forward, backward,
+dense TF-Adam over the whole table and all dense variables) on one synthetic
+Tmall-shaped batch whose int32 index tensors are already resident in HBM.
+Prints ONE JSON line (rank 0).  `roofline` describes the fused gather + co-attention
+forward kernel (the embedding-gather kernel BASELINE.json's north_star targets):
+algorithmic bytes per launch / its average duration measured with HIP
+events recorded on the launch stream inside the timed region.  `cpu_baseline` times
+the CPU restatement of the TF graph (oracle/, "port") on the host cores for a bounded
+number of steps of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def alg_bytes_per_sample(T, K, D, Fu, Fi):
+    """fused gather forward = idx + row reads + reduced outputs."""
+    R = 2 * T * K * (Fu + Fi) + (Fu + Fi)
+    Du, Di = Fu * D, Fi * D
+    out = 4 * (T * 2 * (Du + Di) + (Du + Di) + T * 4 * K)
+    return R * 4 + R * 4 * D + out, R
+
+
+def cpu_baseline(kw, world, B, params, budget_s=20.0, max_steps=6):
+    """CPU restatement of the TF1 graph (Oracle B + dense TF-Adam), full train step."""
+    from oracle import score_oracle as so
+    torch.set_num_threads(os.cpu_count())
+    m = so.OracleModel(kw["feature_size"], kw["eb_dim"], kw["hidden_size"], kw["max_time_len"],
+                       kw["obj_per_time_slice"], kw["user_fnum"], kw["item_fnum"], "SCORE", params=params)
+    batch = world.batch(B, 1000)
+    m.train(None, batch, 1e-3, 1e-4, keep_prob=1.0)            # warm-up
+    times = []
+    t_all = time.time()
+    while len(times) < max_steps and (time.time() - t_all) < budget_s:
+        t0 = time.time()
+        m.train(None, batch, 1e-3, 1e-4, keep_prob=1.0)
+        times.append(time.time() - t0)
+    med = float(np.median(times))
+    return {"value": B / med, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d full train steps (fwd+bwd+dense TF-Adam) of the same workload, B=%d, median %.3f s/step; "
+                      "CPU restatement of the TF1 graph (TensorFlow unavailable), torch-CPU fp32, os.cpu_count()=%d"
+                      % (len(times), B, med, os.cpu_count())}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="cfg3")
+    ap.add_argument("--batches", type=int, default=4, help="distinct pre-staged batches cycled through")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lr", type=float, default=1e-3)
+    ap.add_argument("--reg-lambda", type=float, default=1e-4)
+    args = ap.parse_args()
+
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world_size != args.gpus:
+        if world_size == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world_size > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world_size,
+                                device_id=torch.device("cuda", local_rank))
+
+    from score_amd.synth import make_world
+    from score_amd.model import SCORE
+    world, kw = make_world(args.config)
+    B = kw.pop("batch")
+    T, K, D = kw["max_time_len"], kw["obj_per_time_slice"], kw["eb_dim"]
+    Fu, Fi = kw["user_fnum"], kw["item_fnum"]
+
+    if world_size > 1:
+        from score_amd.dist import ShardedSCORE
+        model = ShardedSCORE(seed=1111, **kw)
+    else:
+        model = SCORE(seed=1111, **kw)
+    # weak scaling: every rank trains on its own B-sample batches (global batch = B * N)
+    batches = [model.device_batch(world.batch(B, rank * 1000 + i)) for i in range(args.batches)]
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        model.train_async(batches[i % len(batches)], args.lr, args.reg_lambda)
+    # per-step stage events for the live kernel timing
+    ev_sets = []
+    for _ in range(args.steps):
+        model.enable_stage_events(True)
+        ev_sets.append((model.fwd_events, model.bwd_events, torch.cuda.Event(enable_timing=True),
+                        torch.cuda.Event(enable_timing=True)))
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        model.fwd_events, model.bwd_events, e_a0, e_a1 = ev_sets[i]
+        lay, ws = model.forward_backward(batches[i % len(batches)], args.reg_lambda, 0.8)
+        e_a0.record()
+        model.apply_adam(args.lr, args.reg_lambda)
+        e_a1.record()
+    barrier()
+    dt = time.perf_counter() - t0
+    model.enable_stage_events(False)
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    loss = float(ws[lay.loss].item())
+
+    # live stage timings (ms), averaged over the timed steps
+    def avg(fn):
+        return float(np.mean([fn(s) for s in ev_sets]))
+    stages = {
+        "fwd_gather_coattn": avg(lambda s: s[0][0].elapsed_time(s[0][1])),
+        "fwd_gru": avg(lambda s: s[0][1].elapsed_time(s[0][2])),
+        "fwd_attention": avg(lambda s: s[0][2].elapsed_time(s[0][3])),
+        "fwd_head_loss": avg(lambda s: s[0][3].elapsed_time(s[0][4])),
+        "bwd_head": avg(lambda s: s[1][0].elapsed_time(s[1][1])),
+        "bwd_attention": avg(lambda s: s[1][1].elapsed_time(s[1][2])),
+        "bwd_gru": avg(lambda s: s[1][2].elapsed_time(s[1][3])),
+        "bwd_coattn_scatter": avg(lambda s: s[1][3].elapsed_time(s[1][4])),
+        "adam_table_and_dense": avg(lambda s: s[2].elapsed_time(s[3])),
+    }
+    ab, R = alg_bytes_per_sample(T, K, D, Fu, Fi)
+    gather_s = stages["fwd_gather_coattn"] * 1e-3
+    achieved = ab * B / gather_s / 1e9
+    N = kw["feature_size"]
+    n_w = model.n_w
+    adam_bytes = 7 * 4 * (N * D / max(world_size, 1) + n_w)
+    scat_bytes = R * (4 + 4 * D) * B
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+    out = {
+        "metric": "train samples/sec @ batch=1024",
+        "value": B * world_size * args.steps / dt,
+        "unit": "samples/s",
+        "n_gpus": world_size,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "%s: SCORE full train step (fwd + bwd + dense TF-Adam), N=%d rows, T=%d, K=%d, "
+                               "D=%d, H=%d, Fu=%d, Fi=%d, per-GPU batch %d (global %d), keep_prob 0.8, "
+                               "%d distinct pre-staged batches" % (args.config, N, T, K, D, kw["hidden_size"], Fu, Fi,
+                                                                   B, B * world_size, len(batches)),
+                   "table": "row-sharded row%%G over %d GPU(s)" % world_size if world_size > 1 else "single GPU",
+                   "final_loss": loss},
+        "roofline": {"kernel": "coattn_fwd_kernel (fused embedding gather + co-attention, both calls, one launch)",
+                     "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_launch": ab * B, "avg_launch_ms": stages["fwd_gather_coattn"]},
+        "roofline_other": {
+            "adam_dense (7 fp32 streams over table shard + dense vars)": {
+                "bound": "hbm", "achieved": adam_bytes / (stages["adam_table_and_dense"] * 1e-3) / 1e9,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": adam_bytes / (stages["adam_table_and_dense"] * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "coattn_bwd + scatter (R*(4+4D) per sample)": {
+                "bound": "hbm", "achieved": scat_bytes / (stages["bwd_coattn_scatter"] * 1e-3) / 1e9,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": scat_bytes / (stages["bwd_coattn_scatter"] * 1e-3) / 1e9 / HBM_PEAK_GBS}},
+        "stages_ms": stages,
+    }
+    if world_size == 1 and not args.no_cpu_baseline:
+        params = model.get_params()
+        del model, batches
+        torch.cuda.empty_cache()
+        out["cpu_baseline"] = cpu_baseline(kw, world, B, params)
+    else:
+        out["cpu_baseline"] = None
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

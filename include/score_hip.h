@@ -172,17 +172,23 @@ typedef struct {
 /* Forward of SCORE / RIA / RCA / SCORE_USER / SCORE_ITEM (score.py:188-369) +
  * build_fc_net / build_logloss / build_l2norm (:68-94).  keep_prob 1.0 = eval
  * (score.py:129), 0.8 = train (:113).  Results land in the workspace
- * (y_pred, loss, ...). drop_mask0/1: optional explicit [B,200]/[B,80] byte masks. */
+ * (y_pred, loss, ...). drop_mask0/1: optional explicit [B,200]/[B,80] byte masks.
+ * stage_events: null, or 5 hipEvent_t handles (each may be null) recorded on `stream`
+ * at the stage boundaries: [0] before the fused gather+co-attention launch, [1] after
+ * it, [2] after the GRUs, [3] after the temporal attention, [4] after head + loss. */
 int score_forward(const score_config_t* cfg, const score_state_t* st, const score_batch_t* batch,
                   float reg_lambda, float keep_prob, const uint8_t* drop_mask0,
-                  const uint8_t* drop_mask1, uint64_t drop_seed, void* stream);
+                  const uint8_t* drop_mask1, uint64_t drop_seed, void* const* stage_events,
+                  void* stream);
 
 /* Backward of the same graph: grad_w [n_floats] (overwritten; WITHOUT the L2
  * term, which score_adam adds) and grad_table [n_table_rows, D] (must be zeroed
  * by the caller; accumulated into).  Must follow score_forward on the same
- * workspace/batch. */
+ * workspace/batch.  stage_events as above: [0] start, [1] after the head, [2] after the
+ * temporal attention, [3] after the GRUs, [4] after the co-attention/embedding scatter. */
 int score_backward(const score_config_t* cfg, const score_state_t* st, const score_batch_t* batch,
-                   float keep_prob, float* grad_w, float* grad_table, void* stream);
+                   float keep_prob, float* grad_w, float* grad_table, void* const* stage_events,
+                   void* stream);
 
 #ifdef __cplusplus
 }

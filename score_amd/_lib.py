@@ -64,8 +64,9 @@ _SIGS = {
     "score_adam": [c_f, c_f, c_f, c_f, C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,
                    C.c_float, C.c_void_p],
     "score_forward": [C.POINTER(Config), C.POINTER(State), C.POINTER(Batch), C.c_float, C.c_float, C.c_void_p,
-                      C.c_void_p, C.c_uint64, C.c_void_p],
-    "score_backward": [C.POINTER(Config), C.POINTER(State), C.POINTER(Batch), C.c_float, c_f, c_f, C.c_void_p],
+                      C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p), C.c_void_p],
+    "score_backward": [C.POINTER(Config), C.POINTER(State), C.POINTER(Batch), C.c_float, c_f, c_f,
+                       C.POINTER(C.c_void_p), C.c_void_p],
 }
 
 EXPORTS = tuple(_SIGS)

@@ -7,6 +7,7 @@
 // owns one (b,t) unit; lane gl owns slots gl, gl+GS, ... (SPL of them) and walks
 // the K neighbours in registers, so sums over K are sequential per lane (bitwise
 // reproducible) and only the K relateness scores cross lanes.
+#include <string.h>
 #include "common.h"
 #include "kernels.h"
 
@@ -37,38 +38,33 @@ extern "C" int score_gather_fwd(const float* table, int64_t n_rows, int32_t D, c
 }
 
 // ------------------------------------------------------------------ fused gather + co-attention
-struct CoattnGeom {
-  int GS;      // lanes per unit
-  int SPL;     // slots per lane
-  int nslots;  // F*D/4
-};
-
-static inline CoattnGeom coattn_geom(int D, int F) {
-  CoattnGeom g;
-  g.nslots = F * (D / 4);
+// One launch serves both co_attention calls of the model (score.py:196-197): blocks
+// [0, first_block[1]) work on call 0, the rest on call 1, each with its own geometry.
+static inline void coattn_geom(int D, int F, int* GS, int* SPL, int* nslots) {
+  *nslots = F * (D / 4);
   int gs = 1;
-  while (gs < g.nslots && gs < 64) gs <<= 1;
-  g.GS = gs;
-  g.SPL = (g.nslots + gs - 1) / gs;
-  return g;
+  while (gs < *nslots && gs < 64) gs <<= 1;
+  *GS = gs;
+  *SPL = (*nslots + gs - 1) / gs;
 }
 
 template <int KMAX, int SPL>
-__global__ __launch_bounds__(256) void coattn_fwd_kernel(
-    const float* __restrict__ table, int D4, int F, int K, int T, int n_units, int GS, int nslots,
-    const int32_t* __restrict__ idx1, const int32_t* __restrict__ idx2,
-    const float* __restrict__ tgt, int ldt, const float* __restrict__ W, const float* __restrict__ bias,
-    float* __restrict__ out1, int ld1, float* __restrict__ out2, int ld2,
-    float* __restrict__ info, int ldi, float* __restrict__ rsave, int mode) {
+__global__ __launch_bounds__(256) void coattn_fwd_kernel(const CoattnArgs a) {
+  const int ci = (int)blockIdx.x >= a.c[1].first_block ? 1 : 0;
+  const CoattnCall& cc = a.c[ci];
+  const int GS = cc.GS, nslots = cc.nslots, F = cc.F, K = a.K, D4 = a.D4;
   const int lane = threadIdx.x & 63;
-  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int wave = (((int)blockIdx.x - cc.first_block) * (int)blockDim.x + (int)threadIdx.x) >> 6;
   const int upw = 64 / GS;
   const int gl = lane & (GS - 1);
   const int unit = wave * upw + lane / GS;
-  const bool unit_ok = unit < n_units;
+  const bool unit_ok = unit < a.n_units;
   const int u = unit_ok ? unit : 0;  // clamp: inactive groups still take part in shuffles
   const int Dx = nslots * 4;
   const int D = D4 * 4;
+  const float* __restrict__ table = a.table;
+  const float* __restrict__ W = cc.W;
+  const int mode = a.mode;
 
   bool ok[SPL];
   int f[SPL], coff[SPL];
@@ -88,8 +84,8 @@ __global__ __launch_bounds__(256) void coattn_fwd_kernel(
     }
   }
 
-  const int32_t* i1 = idx1 + (int64_t)u * K * F;
-  const int32_t* i2 = idx2 + (int64_t)u * K * F;
+  const int32_t* __restrict__ i1 = cc.idx1 + (int64_t)u * K * F;
+  const int32_t* __restrict__ i2 = cc.idx2 + (int64_t)u * K * F;
   float4 v1[SPL][KMAX];
   float4 sum2[SPL];
   float part[KMAX];
@@ -101,16 +97,16 @@ __global__ __launch_bounds__(256) void coattn_fwd_kernel(
     if (k < K) {
 #pragma unroll
       for (int j = 0; j < SPL; ++j) {
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f), y = x;
         if (ok[j]) {
           int64_t r1 = i1[k * F + f[j]];
           int64_t r2 = i2[k * F + f[j]];
-          a = ld4(table + r1 * D + coff[j]);
-          b = ld4(table + r2 * D + coff[j]);
+          x = ld4(table + r1 * D + coff[j]);
+          y = ld4(table + r2 * D + coff[j]);
         }
-        v1[j][k] = a;
-        sum2[j] = add4(sum2[j], b);
-        part[k] += dot4(a, w1[j]) + dot4(b, w2[j]);
+        v1[j][k] = x;
+        sum2[j] = add4(sum2[j], y);
+        part[k] += dot4(x, w1[j]) + dot4(y, w2[j]);
       }
     } else {
 #pragma unroll
@@ -126,19 +122,19 @@ __global__ __launch_bounds__(256) void coattn_fwd_kernel(
 #pragma unroll
       for (int k = 0; k < KMAX; ++k)
         if (k < K) o = add4(o, v1[j][k]);
-      st4(out1 + (int64_t)u * ld1 + (gl + j * GS) * 4, o);
-      st4(out2 + (int64_t)u * ld2 + (gl + j * GS) * 4, sum2[j]);
+      st4(cc.out1 + (int64_t)u * cc.ld1 + (gl + j * GS) * 4, o);
+      st4(cc.out2 + (int64_t)u * cc.ld2 + (gl + j * GS) * 4, sum2[j]);
     }
     return;
   }
 
   // c = w_t . target + bias (constant over t and i), then r_i = relu(part_i + c)
-  const int b_idx = u / T;
+  const int b_idx = u / a.T;
   float cpart = 0.f;
 #pragma unroll
   for (int j = 0; j < SPL; ++j)
-    if (ok[j]) cpart += dot4(ld4(tgt + (int64_t)b_idx * ldt + (gl + j * GS) * 4), ld4(W + (gl + j * GS) * 4));
-  const float c = group_sum(cpart, GS) + bias[0];
+    if (ok[j]) cpart += dot4(ld4(cc.tgt + (int64_t)b_idx * cc.ldt + (gl + j * GS) * 4), ld4(W + (gl + j * GS) * 4));
+  const float c = group_sum(cpart, GS) + cc.bias[0];
   float r[KMAX];
   float rmax = 0.f, rsum = 0.f;  // relu output >= 0
 #pragma unroll
@@ -165,9 +161,9 @@ __global__ __launch_bounds__(256) void coattn_fwd_kernel(
 #pragma unroll
     for (int k = 0; k < KMAX; ++k)
       if (k < K) o = fma4(p[k] * inv_den, v1[j][k], o);
-    st4(out1 + (int64_t)u * ld1 + (gl + j * GS) * 4, o);
+    st4(cc.out1 + (int64_t)u * cc.ld1 + (gl + j * GS) * 4, o);
     const float fk = (float)K;
-    st4(out2 + (int64_t)u * ld2 + (gl + j * GS) * 4,
+    st4(cc.out2 + (int64_t)u * cc.ld2 + (gl + j * GS) * 4,
         make_float4(sum2[j].x / fk, sum2[j].y / fk, sum2[j].z / fk, sum2[j].w / fk));
   }
   // atten_info = [K*r_0..K*r_{K-1}, sum_i r_i (K times)]  (score.py:165-166)
@@ -180,85 +176,11 @@ __global__ __launch_bounds__(256) void coattn_fwd_kernel(
         if (i == k) rv = r[k];
       if (i < K) {
         val = (float)K * rv;
-        rsave[(int64_t)u * K + i] = rv;
+        cc.rsave[(int64_t)u * K + i] = rv;
       }
-      info[(int64_t)u * ldi + i] = val;
+      cc.info[(int64_t)u * cc.ldi + i] = val;
     }
   }
-}
-
-template <int KMAX, int SPL>
-static int launch_coattn_fwd(const CoattnGeom& g, const float* table, int D, int F, int K, int B, int T,
-                             const int32_t* idx1, const int32_t* idx2, const float* tgt, int ldt,
-                             const float* W, const float* bias, float* out1, int ld1, float* out2, int ld2,
-                             float* info, int ldi, float* rsave, int mode, hipStream_t s) {
-  int n_units = B * T;
-  int upw = 64 / g.GS;
-  int64_t waves = cdiv64(n_units, upw);
-  int blocks = (int)cdiv64(waves, 4);
-  hipLaunchKernelGGL((coattn_fwd_kernel<KMAX, SPL>), dim3(blocks), dim3(256), 0, s, table, D / 4, F, K, T,
-                     n_units, g.GS, g.nslots, idx1, idx2, tgt, ldt, W, bias, out1, ld1, out2, ld2, info, ldi,
-                     rsave, mode);
-  SCORE_CHECK_LAUNCH();
-  return 0;
-}
-
-#define COATTN_DISPATCH(FN, ...)                                                         \
-  do {                                                                                   \
-    if (g.SPL == 1) {                                                                    \
-      if (K <= 4) return FN<4, 1>(__VA_ARGS__);                                          \
-      if (K <= 10) return FN<10, 1>(__VA_ARGS__);                                        \
-      if (K <= 20) return FN<20, 1>(__VA_ARGS__);                                        \
-      return FN<32, 1>(__VA_ARGS__);                                                     \
-    } else if (g.SPL == 2) {                                                             \
-      if (K <= 4) return FN<4, 2>(__VA_ARGS__);                                          \
-      if (K <= 10) return FN<10, 2>(__VA_ARGS__);                                        \
-      if (K <= 20) return FN<20, 2>(__VA_ARGS__);                                        \
-      return FN<32, 2>(__VA_ARGS__);                                                     \
-    } else if (g.SPL <= 4) {                                                             \
-      if (K <= 10) return FN<10, 4>(__VA_ARGS__);                                        \
-      if (K <= 20) return FN<20, 4>(__VA_ARGS__);                                        \
-      return SCORE_E_SHAPE;                                                              \
-    }                                                                                    \
-    return SCORE_E_SHAPE;                                                                \
-  } while (0)
-
-static int coattn_fwd_impl(const float* table, int D, int F, int K, int B, int T, const int32_t* idx1,
-                           const int32_t* idx2, const float* tgt, int ldt, const float* W, const float* bias,
-                           float* out1, int ld1, float* out2, int ld2, float* info, int ldi, float* rsave,
-                           int mode, hipStream_t s) {
-  CoattnGeom g = coattn_geom(D, F);
-  COATTN_DISPATCH(launch_coattn_fwd, g, table, D, F, K, B, T, idx1, idx2, tgt, ldt, W, bias, out1, ld1, out2,
-                  ld2, info, ldi, rsave, mode, s);
-}
-
-static int coattn_check(const void* table, int64_t n_rows, int D, int F, int K, int B, int T) {
-  if (!table || n_rows <= 0 || B <= 0 || T <= 0) return SCORE_E_BADARG;
-  if (D <= 0 || (D & 3) || D > 256 || F <= 0 || K <= 0 || K > 32) return SCORE_E_SHAPE;
-  if (F * (D / 4) > 256) return SCORE_E_SHAPE;
-  return 0;
-}
-
-// ABI wrapper; `tgt` is [B, F*D] contiguous here (the engine passes strided views internally)
-extern "C" int score_coattn_fwd(const float* table, int64_t n_rows, int32_t D, int32_t F, int32_t K,
-                                int32_t B, int32_t T, const int32_t* idx1, const int32_t* idx2,
-                                const float* tgt, const float* W, const float* bias, float* out1,
-                                int32_t ld1, float* out2, int32_t ld2, float* info, int32_t ldi,
-                                float* rsave, int32_t mode, void* stream) {
-  SCORE_TRY(coattn_check(table, n_rows, D, F, K, B, T));
-  if (!idx1 || !idx2 || !out1 || !out2) return SCORE_E_BADARG;
-  if (mode == 0 && (!tgt || !W || !bias || !info || !rsave)) return SCORE_E_BADARG;
-  if ((ld1 & 3) || (ld2 & 3)) return SCORE_E_SHAPE;
-  return coattn_fwd_impl(table, D, F, K, B, T, idx1, idx2, tgt, F * D, W, bias, out1, ld1, out2, ld2, info,
-                         ldi, rsave, mode, (hipStream_t)stream);
-}
-
-int score_coattn_fwd_strided(const float* table, int D, int F, int K, int B, int T, const int32_t* idx1,
-                             const int32_t* idx2, const float* tgt, int ldt, const float* W,
-                             const float* bias, float* out1, int ld1, float* out2, int ld2, float* info,
-                             int ldi, float* rsave, int mode, hipStream_t s) {
-  return coattn_fwd_impl(table, D, F, K, B, T, idx1, idx2, tgt, ldt, W, bias, out1, ld1, out2, ld2, info, ldi,
-                         rsave, mode, s);
 }
 
 // ------------------------------------------------------------------ backward
@@ -267,14 +189,17 @@ int score_coattn_fwd_strided(const float* table, int D, int F, int K, int B, int
 //   dz_i  = dr_i * [r_i > 0]
 //   dseq1_i = p_i g1 + dz_i w1,   dseq2_i = g2/K + dz_i w2
 //   dw1 += sum_i dz_i seq1_i,  dw2 += sum_i dz_i seq2_i,  dzsum = sum_i dz_i
+__device__ __forceinline__ void atomic_add4(float* d, float4 v) {
+  atomicAdd(d, v.x); atomicAdd(d + 1, v.y); atomicAdd(d + 2, v.z); atomicAdd(d + 3, v.w);
+}
+
 template <int KMAX, int SPL>
-__global__ __launch_bounds__(256) void coattn_bwd_kernel(
-    const float* __restrict__ table, float* __restrict__ gtable, int D4, int F, int K, int n_units, int GS,
-    int nslots, const int32_t* __restrict__ idx1, const int32_t* __restrict__ idx2,
-    const float* __restrict__ W, const float* __restrict__ rsave, const float* __restrict__ g1p, int ld1,
-    const float* __restrict__ g2p, int ld2, const float* __restrict__ ginfo, int ldi,
-    float* __restrict__ dzsum, float* __restrict__ slab, int mode) {
+__global__ __launch_bounds__(256) void coattn_bwd_kernel(const CoattnArgs a) {
   extern __shared__ float lds[];  // [4 waves][upw][2*Dx]
+  const int ci = (int)blockIdx.x >= a.c[1].first_block ? 1 : 0;
+  const CoattnCall& cc = a.c[ci];
+  const int GS = cc.GS, nslots = cc.nslots, F = cc.F, K = a.K, D4 = a.D4, n_units = a.n_units;
+  const int mode = a.mode;
   const int lane = threadIdx.x & 63;
   const int wib = threadIdx.x >> 6;
   const int upw = 64 / GS;
@@ -282,8 +207,13 @@ __global__ __launch_bounds__(256) void coattn_bwd_kernel(
   const int grp = lane / GS;
   const int Dx = nslots * 4;
   const int D = D4 * 4;
-  const int waves_total = (gridDim.x * blockDim.x) >> 6;
-  const int wave0 = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int my_blocks = (ci == 0 ? a.c[1].first_block : (int)gridDim.x) - cc.first_block;
+  const int waves_total = my_blocks * 4;
+  const int blk = (int)blockIdx.x - cc.first_block;
+  const int wave0 = blk * 4 + wib;
+  const float* __restrict__ table = a.table;
+  float* __restrict__ gtable = a.gtable;
+  const float* __restrict__ W = cc.W;
 
   bool sok[SPL];
   int f[SPL], coff[SPL];
@@ -307,8 +237,8 @@ __global__ __launch_bounds__(256) void coattn_bwd_kernel(
     const int unit = (it * waves_total + wave0) * upw + grp;
     const bool unit_ok = unit < n_units;
     const int u = unit_ok ? unit : 0;
-    const int32_t* i1 = idx1 + (int64_t)u * K * F;
-    const int32_t* i2 = idx2 + (int64_t)u * K * F;
+    const int32_t* __restrict__ i1 = cc.idx1 + (int64_t)u * K * F;
+    const int32_t* __restrict__ i2 = cc.idx2 + (int64_t)u * K * F;
     float4 g1[SPL], g2[SPL];
     bool ok[SPL];
 #pragma unroll
@@ -316,8 +246,8 @@ __global__ __launch_bounds__(256) void coattn_bwd_kernel(
       ok[j] = unit_ok && sok[j];
       g1[j] = g2[j] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (ok[j]) {
-        g1[j] = ld4(g1p + (int64_t)u * ld1 + (gl + j * GS) * 4);
-        g2[j] = ld4(g2p + (int64_t)u * ld2 + (gl + j * GS) * 4);
+        g1[j] = ld4(cc.g1 + (int64_t)u * cc.ld1 + (gl + j * GS) * 4);
+        g2[j] = ld4(cc.g2 + (int64_t)u * cc.ld2 + (gl + j * GS) * 4);
       }
     }
     if (mode == 1) {  // RCA: d(sum_k row_k) = g for every k
@@ -327,40 +257,32 @@ __global__ __launch_bounds__(256) void coattn_bwd_kernel(
         for (int j = 0; j < SPL; ++j) {
           if (!ok[j] || k >= K) continue;
           int64_t r1 = i1[k * F + f[j]], r2 = i2[k * F + f[j]];
-          if (r1 != 0) {
-            float* d = gtable + r1 * D + coff[j];
-            atomicAdd(d, g1[j].x); atomicAdd(d + 1, g1[j].y); atomicAdd(d + 2, g1[j].z); atomicAdd(d + 3, g1[j].w);
-          }
-          if (r2 != 0) {
-            float* d = gtable + r2 * D + coff[j];
-            atomicAdd(d, g2[j].x); atomicAdd(d + 1, g2[j].y); atomicAdd(d + 2, g2[j].z); atomicAdd(d + 3, g2[j].w);
-          }
+          if (r1 != 0) atomic_add4(gtable + r1 * D + coff[j], g1[j]);
+          if (r2 != 0) atomic_add4(gtable + r2 * D + coff[j], g2[j]);
         }
       }
       continue;
     }
 
     int32_t r1[SPL][KMAX], r2[SPL][KMAX];
-    float4 v1[SPL][KMAX];
+    float4 v1[SPL][KMAX], v2[SPL][KMAX];
     float dp[KMAX];
-    // sum_k dz_k seq2_k needs dz first: keep the seq2 rows too
-    float4 v2[SPL][KMAX];
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) {
       dp[k] = 0.f;
 #pragma unroll
       for (int j = 0; j < SPL; ++j) {
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f), y = x;
         int32_t ra = 0, rb = 0;
         if (k < K && ok[j]) {
           ra = i1[k * F + f[j]];
           rb = i2[k * F + f[j]];
-          a = ld4(table + (int64_t)ra * D + coff[j]);
-          b = ld4(table + (int64_t)rb * D + coff[j]);
+          x = ld4(table + (int64_t)ra * D + coff[j]);
+          y = ld4(table + (int64_t)rb * D + coff[j]);
         }
         r1[j][k] = ra; r2[j][k] = rb;
-        v1[j][k] = a; v2[j][k] = b;
-        dp[k] += dot4(a, g1[j]);
+        v1[j][k] = x; v2[j][k] = y;
+        dp[k] += dot4(x, g1[j]);
       }
     }
     // softmax from the saved relu'd scores
@@ -368,9 +290,9 @@ __global__ __launch_bounds__(256) void coattn_bwd_kernel(
     float rmax = 0.f, gsum = 0.f;
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) {
-      r[k] = (k < K) ? rsave[(int64_t)u * K + k] : 0.f;
+      r[k] = (k < K) ? cc.rsave[(int64_t)u * K + k] : 0.f;
       rmax = fmaxf(rmax, r[k]);
-      if (k < K) gsum += ginfo[(int64_t)u * ldi + K + k];
+      if (k < K) gsum += cc.ginfo[(int64_t)u * cc.ldi + K + k];
     }
     float den = 0.f;
 #pragma unroll
@@ -392,12 +314,12 @@ __global__ __launch_bounds__(256) void coattn_bwd_kernel(
     for (int k = 0; k < KMAX; ++k) {
       dz[k] = 0.f;
       if (k < K) {
-        float dr = (float)K * ginfo[(int64_t)u * ldi + k] + gsum + p[k] * (dp[k] - pdp);
+        float dr = (float)K * cc.ginfo[(int64_t)u * cc.ldi + k] + gsum + p[k] * (dp[k] - pdp);
         dz[k] = r[k] > 0.f ? dr : 0.f;
         dzs += dz[k];
       }
     }
-    if (unit_ok && gl == 0) dzsum[u] = dzs;
+    if (unit_ok && gl == 0) cc.dzsum[u] = dzs;
     const float invK = 1.0f / (float)K;
 #pragma unroll
     for (int j = 0; j < SPL; ++j) {
@@ -409,15 +331,11 @@ __global__ __launch_bounds__(256) void coattn_bwd_kernel(
         dw1[j] = fma4(dz[k], v1[j][k], dw1[j]);
         dw2[j] = fma4(dz[k], v2[j][k], dw2[j]);
         if (r1[j][k] != 0) {
-          float4 d1 = fma4(dz[k], w1[j], make_float4(p[k] * g1[j].x, p[k] * g1[j].y, p[k] * g1[j].z, p[k] * g1[j].w));
-          float* d = gtable + (int64_t)r1[j][k] * D + coff[j];
-          atomicAdd(d, d1.x); atomicAdd(d + 1, d1.y); atomicAdd(d + 2, d1.z); atomicAdd(d + 3, d1.w);
+          float4 d1 = fma4(dz[k], w1[j],
+                           make_float4(p[k] * g1[j].x, p[k] * g1[j].y, p[k] * g1[j].z, p[k] * g1[j].w));
+          atomic_add4(gtable + (int64_t)r1[j][k] * D + coff[j], d1);
         }
-        if (r2[j][k] != 0) {
-          float4 d2 = fma4(dz[k], w2[j], g2k);
-          float* d = gtable + (int64_t)r2[j][k] * D + coff[j];
-          atomicAdd(d, d2.x); atomicAdd(d + 1, d2.y); atomicAdd(d + 2, d2.z); atomicAdd(d + 3, d2.w);
-        }
+        if (r2[j][k] != 0) atomic_add4(gtable + (int64_t)r2[j][k] * D + coff[j], fma4(dz[k], w2[j], g2k));
       }
     }
   }
@@ -435,11 +353,11 @@ __global__ __launch_bounds__(256) void coattn_bwd_kernel(
   for (int e = threadIdx.x; e < 2 * Dx; e += blockDim.x) {
     float s = 0.f;
     for (int q = 0; q < nsrc; ++q) s += lds[q * 2 * Dx + e];
-    slab[(int64_t)blockIdx.x * 2 * Dx + e] = s;
+    cc.slab[(int64_t)blk * 2 * Dx + e] = s;
   }
 }
 
-// out[e] += sum_b slab[b][e]   (fixed order: deterministic)
+// out[e] (+)= sum_b slab[b][e]   (fixed order: deterministic)
 __global__ void slab_reduce_kernel(const float* __restrict__ slab, int nslabs, int width, float* __restrict__ out,
                                    int accumulate) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -449,30 +367,107 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slab, int nslabs, i
   out[e] = accumulate ? out[e] + s : s;
 }
 
-template <int KMAX, int SPL>
-static int launch_coattn_bwd(const CoattnGeom& g, const float* table, float* gtable, int D, int F, int K, int B,
-                             int T, const int32_t* idx1, const int32_t* idx2, const float* W, const float* rsave,
-                             const float* g1, int ld1, const float* g2, int ld2, const float* ginfo, int ldi,
-                             float* dzsum, float* dW, float* scratch, int64_t scratch_floats, int mode,
-                             hipStream_t s) {
-  int n_units = B * T;
-  int upw = 64 / g.GS;
-  int Dx = g.nslots * 4;
-  int64_t waves = cdiv64(n_units, upw);
-  int blocks = (int)cdiv64(waves, 4);
-  if (blocks > 1024) blocks = 1024;
-  if (mode == 0 && (int64_t)blocks * 2 * Dx > scratch_floats) return SCORE_E_WORKSPACE;
-  size_t lds_bytes = (size_t)4 * upw * 2 * Dx * sizeof(float);
-  hipLaunchKernelGGL((coattn_bwd_kernel<KMAX, SPL>), dim3(blocks), dim3(256), lds_bytes, s, table, gtable, D / 4,
-                     F, K, n_units, g.GS, g.nslots, idx1, idx2, W, rsave, g1, ld1, g2, ld2, ginfo, ldi, dzsum,
-                     scratch, mode);
+#define COATTN_DISPATCH(KERNEL, SPLV, KV, ...)                                          \
+  do {                                                                                  \
+    if (SPLV == 1) {                                                                    \
+      if (KV <= 4) { hipLaunchKernelGGL((KERNEL<4, 1>), __VA_ARGS__); }                 \
+      else if (KV <= 10) { hipLaunchKernelGGL((KERNEL<10, 1>), __VA_ARGS__); }          \
+      else if (KV <= 20) { hipLaunchKernelGGL((KERNEL<20, 1>), __VA_ARGS__); }          \
+      else { hipLaunchKernelGGL((KERNEL<32, 1>), __VA_ARGS__); }                        \
+    } else if (SPLV == 2) {                                                             \
+      if (KV <= 4) { hipLaunchKernelGGL((KERNEL<4, 2>), __VA_ARGS__); }                 \
+      else if (KV <= 10) { hipLaunchKernelGGL((KERNEL<10, 2>), __VA_ARGS__); }          \
+      else if (KV <= 20) { hipLaunchKernelGGL((KERNEL<20, 2>), __VA_ARGS__); }          \
+      else { hipLaunchKernelGGL((KERNEL<32, 2>), __VA_ARGS__); }                        \
+    } else {                                                                            \
+      if (KV <= 10) { hipLaunchKernelGGL((KERNEL<10, 4>), __VA_ARGS__); }               \
+      else { hipLaunchKernelGGL((KERNEL<20, 4>), __VA_ARGS__); }                        \
+    }                                                                                   \
+  } while (0)
+
+static int coattn_check(const void* table, int64_t n_rows, int D, int F, int K, int B, int T) {
+  if (!table || n_rows <= 0 || B <= 0 || T <= 0) return SCORE_E_BADARG;
+  if (D <= 0 || (D & 3) || D > 256 || F <= 0 || K <= 0 || K > 32) return SCORE_E_SHAPE;
+  if (F * (D / 4) > 256) return SCORE_E_SHAPE;
+  if (F * (D / 4) > 128 && K > 20) return SCORE_E_SHAPE;
+  return 0;
+}
+
+// Launch 1 or 2 calls (ncalls) of the forward in a single grid.
+int score_coattn_fwd_multi(CoattnArgs& a, int ncalls, int D, int B, hipStream_t s) {
+  int spl = 1, total = 0;
+  a.D4 = D / 4;
+  a.n_units = B * a.T;
+  for (int c = 0; c < 2; ++c) {
+    if (c >= ncalls) { a.c[c] = a.c[0]; a.c[c].first_block = 0x7fffffff; continue; }
+    int SPLc;
+    coattn_geom(D, a.c[c].F, &a.c[c].GS, &SPLc, &a.c[c].nslots);
+    if (SPLc > spl) spl = SPLc;
+    a.c[c].first_block = total;
+    total += (int)cdiv64(cdiv64(a.n_units, 64 / a.c[c].GS), 4);
+  }
+  if (spl == 3) spl = 4;
+  COATTN_DISPATCH(coattn_fwd_kernel, spl, a.K, dim3(total), dim3(256), 0, s, a);
   SCORE_CHECK_LAUNCH();
-  if (mode == 0) {
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((2 * Dx + 255) / 256), dim3(256), 0, s, scratch, blocks, 2 * Dx,
-                       dW + Dx, 1);
-    SCORE_CHECK_LAUNCH();
+  return 0;
+}
+
+// Backward of 1 or 2 calls in a single grid + the per-call slab reductions into dW[c] (+=).
+int score_coattn_bwd_multi(CoattnArgs& a, int ncalls, int D, int B, float* const dW[2], float* scratch,
+                           int64_t scratch_floats, hipStream_t s) {
+  int spl = 1, total = 0, nblk[2] = {0, 0};
+  size_t lds_bytes = 0;
+  int64_t used = 0;
+  a.D4 = D / 4;
+  a.n_units = B * a.T;
+  for (int c = 0; c < 2; ++c) {
+    if (c >= ncalls) { a.c[c] = a.c[0]; a.c[c].first_block = 0x7fffffff; continue; }
+    int SPLc;
+    coattn_geom(D, a.c[c].F, &a.c[c].GS, &SPLc, &a.c[c].nslots);
+    if (SPLc > spl) spl = SPLc;
+    int upw = 64 / a.c[c].GS, Dx = a.c[c].nslots * 4;
+    int blocks = (int)cdiv64(cdiv64(a.n_units, upw), 4);
+    if (blocks > 1024) blocks = 1024;
+    nblk[c] = blocks;
+    a.c[c].first_block = total;
+    total += blocks;
+    a.c[c].slab = scratch + used;
+    used += (int64_t)blocks * 2 * Dx;
+    size_t l = (size_t)4 * upw * 2 * Dx * sizeof(float);
+    if (l > lds_bytes) lds_bytes = l;
+  }
+  if (a.mode == 0 && used > scratch_floats) return SCORE_E_WORKSPACE;
+  if (spl == 3) spl = 4;
+  COATTN_DISPATCH(coattn_bwd_kernel, spl, a.K, dim3(total), dim3(256), lds_bytes, s, a);
+  SCORE_CHECK_LAUNCH();
+  if (a.mode == 0) {
+    for (int c = 0; c < ncalls; ++c) {
+      int Dx = a.c[c].nslots * 4;
+      hipLaunchKernelGGL(slab_reduce_kernel, dim3((2 * Dx + 255) / 256), dim3(256), 0, s, a.c[c].slab, nblk[c],
+                         2 * Dx, dW[c] + Dx, 1);
+      SCORE_CHECK_LAUNCH();
+    }
   }
   return 0;
+}
+
+// ABI wrappers: one call; `tgt` is [B, F*D] contiguous
+extern "C" int score_coattn_fwd(const float* table, int64_t n_rows, int32_t D, int32_t F, int32_t K,
+                                int32_t B, int32_t T, const int32_t* idx1, const int32_t* idx2,
+                                const float* tgt, const float* W, const float* bias, float* out1,
+                                int32_t ld1, float* out2, int32_t ld2, float* info, int32_t ldi,
+                                float* rsave, int32_t mode, void* stream) {
+  SCORE_TRY(coattn_check(table, n_rows, D, F, K, B, T));
+  if (!idx1 || !idx2 || !out1 || !out2) return SCORE_E_BADARG;
+  if (mode == 0 && (!tgt || !W || !bias || !info || !rsave)) return SCORE_E_BADARG;
+  if ((ld1 & 3) || (ld2 & 3)) return SCORE_E_SHAPE;
+  CoattnArgs a;
+  memset(&a, 0, sizeof(a));
+  a.table = table; a.K = K; a.T = T; a.mode = mode;
+  CoattnCall& c = a.c[0];
+  c.idx1 = idx1; c.idx2 = idx2; c.tgt = tgt; c.ldt = F * D; c.W = W; c.bias = bias;
+  c.out1 = out1; c.ld1 = ld1; c.out2 = out2; c.ld2 = ld2; c.info = info; c.ldi = ldi; c.rsave = rsave; c.F = F;
+  return score_coattn_fwd_multi(a, 1, D, B, (hipStream_t)stream);
 }
 
 extern "C" int score_coattn_bwd(const float* table, float* grad_table, int64_t n_rows, int32_t D, int32_t F,
@@ -484,9 +479,14 @@ extern "C" int score_coattn_bwd(const float* table, float* grad_table, int64_t n
   if (!grad_table || !idx1 || !idx2 || !g1 || !g2) return SCORE_E_BADARG;
   if (mode == 0 && (!W || !rsave || !ginfo || !dzsum || !dW || !scratch)) return SCORE_E_BADARG;
   if ((ld1 & 3) || (ld2 & 3)) return SCORE_E_SHAPE;
-  CoattnGeom g = coattn_geom(D, F);
-  COATTN_DISPATCH(launch_coattn_bwd, g, table, grad_table, D, F, K, B, T, idx1, idx2, W, rsave, g1, ld1, g2, ld2,
-                  ginfo, ldi, dzsum, dW, scratch, scratch_floats, mode, (hipStream_t)stream);
+  CoattnArgs a;
+  memset(&a, 0, sizeof(a));
+  a.table = table; a.gtable = grad_table; a.K = K; a.T = T; a.mode = mode;
+  CoattnCall& c = a.c[0];
+  c.idx1 = idx1; c.idx2 = idx2; c.W = W; c.rsave = const_cast<float*>(rsave); c.g1 = g1; c.ld1 = ld1; c.g2 = g2; c.ld2 = ld2;
+  c.ginfo = ginfo; c.ldi = ldi; c.dzsum = dzsum; c.F = F;
+  float* dWs[2] = {dW, nullptr};
+  return score_coattn_bwd_multi(a, 1, D, B, dWs, scratch, scratch_floats, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------ target rows (score.py:62-66, 210, 217)

@@ -168,6 +168,14 @@ void build_ws(const Dims& d, int B, WS* w) {
 }
 
 #define G(call) SCORE_TRY(call)
+// optional stage boundary events (hipEvent_t handles) recorded on the launch stream
+#define EV(i)                                                                \
+  do {                                                                       \
+    if (stage_events && stage_events[i]) {                                   \
+      hipError_t ee__ = hipEventRecord((hipEvent_t)stage_events[i], s);      \
+      if (ee__ != hipSuccess) return (int)ee__;                              \
+    }                                                                        \
+  } while (0)
 
 }  // namespace
 
@@ -198,7 +206,8 @@ extern "C" int score_workspace_layout(const score_config_t* cfg, int32_t B, scor
 
 extern "C" int score_forward(const score_config_t* cfg, const score_state_t* st, const score_batch_t* bt,
                              float reg_lambda, float keep_prob, const uint8_t* drop_mask0,
-                             const uint8_t* drop_mask1, uint64_t drop_seed, void* stream) {
+                             const uint8_t* drop_mask1, uint64_t drop_seed, void* const* stage_events,
+                             void* stream) {
   Dims d;
   SCORE_TRY(make_dims(cfg, &d));
   if (!st || !bt || !st->table || !st->w || !st->workspace || bt->B <= 0) return SCORE_E_BADARG;
@@ -222,16 +231,25 @@ extern "C" int score_forward(const score_config_t* cfg, const score_state_t* st,
                             ws + w.head_inp, d.Dhead, d.off_ti, d.off_tu, s));
   // co-attention 1: (user_1hop, item_2hop, target_item) ; 2: (user_2hop, item_1hop, target_user)  (:196-197)
   // user_side = [user_1hop_seq | user_2hop_seq], item_side = [item_1hop_seq | item_2hop_seq]   (:200-201)
-  const int mode = d.coattn ? 0 : 1;
-  const int ldi = 4 * d.K;
-  G(score_coattn_fwd_strided(st->table, d.D, d.Fi, d.K, B, T, bt->user_1hop, bt->item_2hop, ws + w.query + d.Du,
-                             d.Dq, d.coattn ? W + P.ca_w[0] : nullptr, d.coattn ? W + P.ca_b[0] : nullptr,
-                             ws + w.xside[0], d.I, ws + w.xside[1] + d.Du, d.I, ws + w.info, ldi, ws + w.rsave[0],
-                             mode, s));
-  G(score_coattn_fwd_strided(st->table, d.D, d.Fu, d.K, B, T, bt->user_2hop, bt->item_1hop, ws + w.query, d.Dq,
-                             d.coattn ? W + P.ca_w[1] : nullptr, d.coattn ? W + P.ca_b[1] : nullptr,
-                             ws + w.xside[0] + d.Di, d.I, ws + w.xside[1], d.I, ws + w.info + 2 * d.K, ldi,
-                             ws + w.rsave[1], mode, s));
+  EV(0);
+  {
+    CoattnArgs ca;
+    memset(&ca, 0, sizeof(ca));
+    ca.table = st->table; ca.K = d.K; ca.T = T; ca.mode = d.coattn ? 0 : 1;
+    const int ldi = 4 * d.K;
+    CoattnCall& c0 = ca.c[0];
+    c0.idx1 = bt->user_1hop; c0.idx2 = bt->item_2hop; c0.tgt = ws + w.query + d.Du; c0.ldt = d.Dq;
+    c0.W = d.coattn ? W + P.ca_w[0] : nullptr; c0.bias = d.coattn ? W + P.ca_b[0] : nullptr;
+    c0.out1 = ws + w.xside[0]; c0.ld1 = d.I; c0.out2 = ws + w.xside[1] + d.Du; c0.ld2 = d.I;
+    c0.info = ws + w.info; c0.ldi = ldi; c0.rsave = ws + w.rsave[0]; c0.F = d.Fi;
+    CoattnCall& c1 = ca.c[1];
+    c1.idx1 = bt->user_2hop; c1.idx2 = bt->item_1hop; c1.tgt = ws + w.query; c1.ldt = d.Dq;
+    c1.W = d.coattn ? W + P.ca_w[1] : nullptr; c1.bias = d.coattn ? W + P.ca_b[1] : nullptr;
+    c1.out1 = ws + w.xside[0] + d.Di; c1.ld1 = d.I; c1.out2 = ws + w.xside[1]; c1.ld2 = d.I;
+    c1.info = ws + w.info + 2 * d.K; c1.ldi = ldi; c1.rsave = ws + w.rsave[1]; c1.F = d.Fu;
+    G(score_coattn_fwd_multi(ca, 2, d.D, B, s));
+  }
+  EV(1);
   // GRUs (:205-208): hoisted x-projection, then the persistent recurrence
   for (int sd = 0; sd < 2; ++sd) {
     float* xp = ws + w.xproj[sd];
@@ -242,6 +260,7 @@ extern "C" int score_forward(const score_config_t* cfg, const score_state_t* st,
     G(score_gru_fwd(B, T, H, xp, W + P.gk[sd] + (int64_t)d.I * 2 * H, 2 * H, W + P.ck[sd] + (int64_t)d.I * H, H,
                     bt->length, ws + w.gru_out[sd], H, ws + w.gates[sd], ws + w.gru_final[sd], s));
   }
+  EV(2);
   if (d.attn) {
     // temporal attention (:169-186, 210-215)
     G(score_gemm(0, B, d.Dk, d.Dq, ws + w.query, d.Dq, W + P.at_w[0], d.Dk, ws + w.q, d.Dk, W + P.at_b[0], GF_BIAS,
@@ -260,6 +279,7 @@ extern "C" int score_forward(const score_config_t* cfg, const score_state_t* st,
     G(score_launch_copy2d(B, H, ws + w.gru_final[0], H, ws + w.head_inp, d.Dhead, s));
     G(score_launch_copy2d(B, H, ws + w.gru_final[1], H, ws + w.head_inp + H, d.Dhead, s));
   }
+  EV(3);
   // build_fc_net (:68-76)
   const float rs = (float)(1.0 / sqrt(1.0 + 1e-3));
   G(score_launch_bn_fwd(B, d.Dhead, ws + w.head_inp, W + P.bn_g, W + P.bn_b, rs, ws + w.bn, s));
@@ -272,11 +292,13 @@ extern "C" int score_forward(const score_config_t* cfg, const score_state_t* st,
   // fc3, sigmoid, log-loss, l2 (:74-94)
   G(score_launch_head_out(B, FC2, ws + w.f2, W + P.fc_w[2], W + P.fc_b[2], bt->label, ws + w.logit, ws + w.y_pred,
                           ws + w.lossb, ws + w.dlogit, ws + w.loss, W, P.n_reg, reg_lambda, ws + w.part, s));
+  EV(4);
   return 0;
 }
 
 extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st, const score_batch_t* bt,
-                              float keep_prob, float* gw, float* grad_table, void* stream) {
+                              float keep_prob, float* gw, float* grad_table, void* const* stage_events,
+                              void* stream) {
   Dims d;
   SCORE_TRY(make_dims(cfg, &d));
   if (!st || !bt || !st->table || !st->w || !st->workspace || !gw || !grad_table || bt->B <= 0)
@@ -295,6 +317,7 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
   hipError_t he = hipMemsetAsync(gw, 0, P.n_floats * sizeof(float), s);
   if (he != hipSuccess) return (int)he;
 
+  EV(0);
   // ---- head (score.py:68-81)
   // fc3: dW = f2^T dlogit, db = sum dlogit, dz2 = [f2>0] dlogit w3 / keep
   G(score_gemm(2, FC2, 1, B, ws + w.f2, FC2, ws + w.dlogit, 1, gw + P.fc_w[2], 1, nullptr, 0, 1.f, nullptr, 0,
@@ -318,6 +341,7 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
   G(score_launch_bn_bwd(B, d.Dhead, ws + w.head_inp, W + P.bn_g, rs, ws + w.dbn, ws + w.dhead, gw + P.bn_g,
                         gw + P.bn_b, s));
 
+  EV(1);
   const float* dfinal[2] = {nullptr, nullptr};
   if (d.attn) {
     // ---- temporal attention (score.py:169-186, 214-215)
@@ -362,6 +386,7 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
     if (he != hipSuccess) return (int)he;
   }
 
+  EV(2);
   // ---- GRUs (score.py:205-208)
   for (int sd = 0; sd < 2; ++sd) {
     const float* Wg = W + P.gk[sd];
@@ -389,21 +414,29 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
   }
 
   // ---- co-attention + embedding rows (score.py:147-167, 196-201, 51-66)
-  const int mode = d.coattn ? 0 : 1;
-  const int ldi = 4 * d.K;
-  G(score_coattn_bwd(st->table, grad_table, st->n_table_rows, d.D, d.Fi, d.K, B, T, bt->user_1hop, bt->item_2hop,
-                     d.coattn ? W + P.ca_w[0] : nullptr, ws + w.rsave[0], ws + w.dxside[0], d.I,
-                     ws + w.dxside[1] + d.Du, d.I, ws + w.dinfo, ldi, ws + w.dzsum[0],
-                     d.coattn ? gw + P.ca_w[0] : nullptr, scratch, SF, mode, s));
-  G(score_coattn_bwd(st->table, grad_table, st->n_table_rows, d.D, d.Fu, d.K, B, T, bt->user_2hop, bt->item_1hop,
-                     d.coattn ? W + P.ca_w[1] : nullptr, ws + w.rsave[1], ws + w.dxside[0] + d.Di, d.I,
-                     ws + w.dxside[1], d.I, ws + w.dinfo + 2 * d.K, ldi, ws + w.dzsum[1],
-                     d.coattn ? gw + P.ca_w[1] : nullptr, scratch, SF, mode, s));
+  EV(3);
+  {
+    CoattnArgs ca;
+    memset(&ca, 0, sizeof(ca));
+    ca.table = st->table; ca.gtable = grad_table; ca.K = d.K; ca.T = T; ca.mode = d.coattn ? 0 : 1;
+    const int ldi = 4 * d.K;
+    CoattnCall& c0 = ca.c[0];
+    c0.idx1 = bt->user_1hop; c0.idx2 = bt->item_2hop; c0.W = d.coattn ? W + P.ca_w[0] : nullptr;
+    c0.rsave = ws + w.rsave[0]; c0.g1 = ws + w.dxside[0]; c0.ld1 = d.I; c0.g2 = ws + w.dxside[1] + d.Du;
+    c0.ld2 = d.I; c0.ginfo = ws + w.dinfo; c0.ldi = ldi; c0.dzsum = ws + w.dzsum[0]; c0.F = d.Fi;
+    CoattnCall& c1 = ca.c[1];
+    c1.idx1 = bt->user_2hop; c1.idx2 = bt->item_1hop; c1.W = d.coattn ? W + P.ca_w[1] : nullptr;
+    c1.rsave = ws + w.rsave[1]; c1.g1 = ws + w.dxside[0] + d.Di; c1.ld1 = d.I; c1.g2 = ws + w.dxside[1];
+    c1.ld2 = d.I; c1.ginfo = ws + w.dinfo + 2 * d.K; c1.ldi = ldi; c1.dzsum = ws + w.dzsum[1]; c1.F = d.Fu;
+    float* dWs[2] = {d.coattn ? gw + P.ca_w[0] : nullptr, d.coattn ? gw + P.ca_w[1] : nullptr};
+    G(score_coattn_bwd_multi(ca, 2, d.D, B, dWs, scratch, SF, s));
+  }
   G(score_launch_target_bwd(grad_table, d.D, d.Fu, d.Fi, B, T, bt->target_user, bt->target_item,
                             d.attn ? ws + w.dquery : nullptr, d.Dq, ws + w.dhead, d.Dhead, d.off_ti, d.off_tu,
                             ws + w.query, d.coattn ? W + P.ca_w[0] : nullptr, d.coattn ? W + P.ca_w[1] : nullptr,
                             ws + w.dzsum[0], ws + w.dzsum[1], ws + w.S, d.coattn ? gw + P.ca_w[0] : nullptr,
                             d.coattn ? gw + P.ca_b[0] : nullptr, d.coattn ? gw + P.ca_w[1] : nullptr,
                             d.coattn ? gw + P.ca_b[1] : nullptr, s));
+  EV(4);
   return 0;
 }

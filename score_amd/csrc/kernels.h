@@ -3,10 +3,24 @@
 #include "common.h"
 
 // embed.hip
-int score_coattn_fwd_strided(const float* table, int D, int F, int K, int B, int T, const int32_t* idx1,
-                             const int32_t* idx2, const float* tgt, int ldt, const float* W,
-                             const float* bias, float* out1, int ld1, float* out2, int ld2, float* info,
-                             int ldi, float* rsave, int mode, hipStream_t s);
+struct CoattnCall {
+  const int32_t* idx1; const int32_t* idx2;
+  const float* tgt; int ldt;
+  const float* W; const float* bias;
+  float* out1; int ld1; float* out2; int ld2;
+  float* info; int ldi; float* rsave;
+  const float* g1; const float* g2; const float* ginfo;
+  float* dzsum; float* slab;
+  int F, GS, nslots, first_block;
+};
+struct CoattnArgs {
+  CoattnCall c[2];
+  const float* table; float* gtable;
+  int D4, K, T, n_units, mode;
+};
+int score_coattn_fwd_multi(CoattnArgs& a, int ncalls, int D, int B, hipStream_t s);
+int score_coattn_bwd_multi(CoattnArgs& a, int ncalls, int D, int B, float* const dW[2], float* scratch,
+                           int64_t scratch_floats, hipStream_t s);
 int score_launch_target_fwd(const float* table, int D, int Fu, int Fi, int B, const int32_t* tu,
                             const int32_t* ti, float* query, int ldq, float* head, int ldh,
                             int off_ti, int off_tu, hipStream_t s);

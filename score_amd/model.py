@@ -89,6 +89,7 @@ class SCOREBASE(object):
         self.beta2_power = np.float32(ADAM_B2)
         self.row0 = np.zeros((D,), dtype=np.float32)   # value of the masked variable row (score.py:44-47)
         self._drop_seed = int(seed)
+        self.fwd_events = self.bwd_events = None
         self._init_params(seed)
 
     # ------------------------------------------------------------------ parameters
@@ -165,6 +166,24 @@ class SCOREBASE(object):
     def _state(self, ws):
         return _lib.State(_ptr(self.table), self.table.shape[0], _ptr(self.w), _ptr(ws), ws.numel() * 4)
 
+    @staticmethod
+    def _event_array(events):
+        """5 torch.cuda.Event (timing enabled, already recorded once) -> hipEvent_t[5], or NULL."""
+        if not events:
+            return None
+        return (C.c_void_p * 5)(*[C.c_void_p(e.cuda_event) for e in events])
+
+    def enable_stage_events(self, on=True):
+        """Record stage-boundary events inside score_forward/backward (bench.py's live
+        per-kernel timing).  See include/score_hip.h for what each boundary brackets."""
+        if not on:
+            self.fwd_events = self.bwd_events = None
+            return
+        mk = lambda: [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+        self.fwd_events, self.bwd_events = mk(), mk()
+        for e in self.fwd_events + self.bwd_events:
+            e.record()          # forces creation of the underlying hipEvent_t
+
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
@@ -190,7 +209,8 @@ class SCOREBASE(object):
                 raise ValueError("dropout masks must be [B,200] and [B,80]")
         seed = (self._drop_seed * 0x9E3779B1 + self.step * 0x85EBCA77) & 0xFFFFFFFFFFFFFFFF
         rc = self.lib.score_forward(C.byref(self.cfg), C.byref(st), C.byref(db.struct), float(reg_lambda),
-                                    float(keep_prob), _ptr(m0), _ptr(m1), C.c_uint64(seed), self._stream())
+                                    float(keep_prob), _ptr(m0), _ptr(m1), C.c_uint64(seed),
+                                    self._event_array(self.fwd_events), self._stream())
         _lib.check(rc, "score_forward")
         self._keep = (m0, m1)
         return lay, ws, st
@@ -202,7 +222,8 @@ class SCOREBASE(object):
         lay, ws, st = self._forward(db, reg_lambda, keep_prob, dropout_masks)
         self.table_g.zero_()
         rc = self.lib.score_backward(C.byref(self.cfg), C.byref(st), C.byref(db.struct), float(keep_prob),
-                                     _ptr(self.w_g), _ptr(self.table_g), self._stream())
+                                     _ptr(self.w_g), _ptr(self.table_g), self._event_array(self.bwd_events),
+                                     self._stream())
         _lib.check(rc, "score_backward")
         return lay, ws
 

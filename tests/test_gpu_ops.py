@@ -150,8 +150,9 @@ def test_coattn_fwd_bwd(D, F, K, B, T):
     dzs = torch.zeros((B * T,), device="cuda")
     gW = torch.zeros((3 * Dx,), device="cuda")
     scratch = torch.empty((1 << 21,), device="cuda")
-    _lib.check(lib.score_coattn_bwd(P(dt), P(gt), N, D, F, K, B, T, P(di1), P(di2), P(dW), P(rs), P(dev(g1)), Dx,
-                                    P(dev(g2)), Dx, P(dev(gi)), 2 * K, P(dzs), P(gW), P(scratch), scratch.numel(),
+    dg1, dg2, dgi = dev(g1), dev(g2), dev(gi)      # keep the device tensors alive across the call
+    _lib.check(lib.score_coattn_bwd(P(dt), P(gt), N, D, F, K, B, T, P(di1), P(di2), P(dW), P(rs), P(dg1), Dx,
+                                    P(dg2), Dx, P(dgi), 2 * K, P(dzs), P(gW), P(scratch), scratch.numel(),
                                     0, stream()), "coattn_bwd")
     torch.cuda.synchronize()
     # row gradients: autograd on `tt` also holds the target-row path, which this op does not own,
@@ -178,7 +179,8 @@ def test_coattn_rca_sum_mode():
     o1 = torch.zeros((B * T, F * D), device="cuda")
     o2 = torch.zeros((B * T, F * D), device="cuda")
     z = C.c_void_p(0)
-    _lib.check(lib.score_coattn_fwd(P(dev(table)), N, D, F, K, B, T, P(dev(idx1)), P(dev(idx2)), z, z, z, P(o1),
+    dt, d1, d2 = dev(table), dev(idx1), dev(idx2)
+    _lib.check(lib.score_coattn_fwd(P(dt), N, D, F, K, B, T, P(d1), P(d2), z, z, z, P(o1),
                                     F * D, P(o2), F * D, z, 0, z, 1, stream()), "rca")
     w1 = table[idx1].reshape(B * T, K, F * D).sum(1)
     w2 = table[idx2].reshape(B * T, K, F * D).sum(1)
@@ -223,8 +225,9 @@ def test_gru_fwd_bwd(B, T, H):
     dxproj = torch.zeros((B * T, 3 * H), device="cuda")
     rh = torch.zeros((B * T, H), device="cuda")
     hprev = torch.zeros((B * T * H + 3 * H * H,), device="cuda")
-    _lib.check(lib.score_gru_bwd(B, T, H, wg_h, 2 * H, wc_h, H, P(dl), P(out), H, P(gates), P(dev(go)), H,
-                                 P(dev(gf)), P(dxproj), P(rh), P(hprev), stream()), "gru_bwd")
+    dgo, dgf = dev(go), dev(gf)
+    _lib.check(lib.score_gru_bwd(B, T, H, wg_h, 2 * H, wc_h, H, P(dl), P(out), H, P(gates), P(dgo), H,
+                                 P(dgf), P(dxproj), P(rh), P(hprev), stream()), "gru_bwd")
     torch.cuda.synchronize()
     d = dxproj.cpu()
     # dx = dxproj . Wx^T ; dWx = x^T dxproj ; dWh = [hprev ; rh]^T dxproj ; db = colsum
