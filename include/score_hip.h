@@ -167,6 +167,10 @@ typedef struct {
   const float* w;       /* flat dense parameters                                  */
   float* workspace;     /* score_workspace_layout(...).total_bytes                */
   int64_t workspace_bytes;
+  int32_t scatter_mode; /* embedding-gradient scatter: 0 = radix-sort occurrences by row +
+                           per-row pull (no float atomics, bitwise reproducible; default),
+                           1 = global_atomic_add_f32 into grad_table                    */
+  int32_t reserved;
 } score_state_t;
 
 /* Forward of SCORE / RIA / RCA / SCORE_USER / SCORE_ITEM (score.py:188-369) +

@@ -41,7 +41,7 @@ class Workspace(C.Structure):
 
 class State(C.Structure):
     _fields_ = [("table", c_f), ("n_table_rows", C.c_int64), ("w", c_f), ("workspace", c_f),
-                ("workspace_bytes", C.c_int64)]
+                ("workspace_bytes", C.c_int64), ("scatter_mode", C.c_int32), ("reserved", C.c_int32)]
 
 
 _SIGS = {

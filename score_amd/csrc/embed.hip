@@ -193,8 +193,8 @@ __device__ __forceinline__ void atomic_add4(float* d, float4 v) {
   atomicAdd(d, v.x); atomicAdd(d + 1, v.y); atomicAdd(d + 2, v.z); atomicAdd(d + 3, v.w);
 }
 
-template <int KMAX, int SPL>
-__global__ __launch_bounds__(256) void coattn_bwd_kernel(const CoattnArgs a) {
+template <int KMAX, int SPL, bool ATOMIC>
+__global__ __launch_bounds__(256) void coattn_bwd_kernel_t(const CoattnArgs a) {
   extern __shared__ float lds[];  // [4 waves][upw][2*Dx]
   const int ci = (int)blockIdx.x >= a.c[1].first_block ? 1 : 0;
   const CoattnCall& cc = a.c[ci];
@@ -256,6 +256,7 @@ __global__ __launch_bounds__(256) void coattn_bwd_kernel(const CoattnArgs a) {
 #pragma unroll
         for (int j = 0; j < SPL; ++j) {
           if (!ok[j] || k >= K) continue;
+          if (!ATOMIC) continue;  // pull mode: every row gradient is g itself, nothing to prepare
           int64_t r1 = i1[k * F + f[j]], r2 = i2[k * F + f[j]];
           if (r1 != 0) atomic_add4(gtable + r1 * D + coff[j], g1[j]);
           if (r2 != 0) atomic_add4(gtable + r2 * D + coff[j], g2[j]);
@@ -320,6 +321,16 @@ __global__ __launch_bounds__(256) void coattn_bwd_kernel(const CoattnArgs a) {
       }
     }
     if (unit_ok && gl == 0) cc.dzsum[u] = dzs;
+    if (!ATOMIC && unit_ok) {  // the scalars the pull-form scatter multiplies G and w with
+      for (int i = gl; i < K; i += GS) {
+        float pv = 0.f, dv = 0.f;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+          if (i == k) { pv = p[k]; dv = dz[k]; }
+        cc.pcoef[(int64_t)u * K + i] = pv;
+        cc.dzcoef[(int64_t)u * K + i] = dv;
+      }
+    }
     const float invK = 1.0f / (float)K;
 #pragma unroll
     for (int j = 0; j < SPL; ++j) {
@@ -330,12 +341,14 @@ __global__ __launch_bounds__(256) void coattn_bwd_kernel(const CoattnArgs a) {
         if (k >= K) continue;
         dw1[j] = fma4(dz[k], v1[j][k], dw1[j]);
         dw2[j] = fma4(dz[k], v2[j][k], dw2[j]);
-        if (r1[j][k] != 0) {
-          float4 d1 = fma4(dz[k], w1[j],
-                           make_float4(p[k] * g1[j].x, p[k] * g1[j].y, p[k] * g1[j].z, p[k] * g1[j].w));
-          atomic_add4(gtable + (int64_t)r1[j][k] * D + coff[j], d1);
+        if (ATOMIC) {
+          if (r1[j][k] != 0) {
+            float4 d1 = fma4(dz[k], w1[j],
+                             make_float4(p[k] * g1[j].x, p[k] * g1[j].y, p[k] * g1[j].z, p[k] * g1[j].w));
+            atomic_add4(gtable + (int64_t)r1[j][k] * D + coff[j], d1);
+          }
+          if (r2[j][k] != 0) atomic_add4(gtable + (int64_t)r2[j][k] * D + coff[j], fma4(dz[k], w2[j], g2k));
         }
-        if (r2[j][k] != 0) atomic_add4(gtable + (int64_t)r2[j][k] * D + coff[j], fma4(dz[k], w2[j], g2k));
       }
     }
   }
@@ -367,23 +380,25 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slab, int nslabs, i
   out[e] = accumulate ? out[e] + s : s;
 }
 
-#define COATTN_DISPATCH(KERNEL, SPLV, KV, ...)                                          \
-  do {                                                                                  \
-    if (SPLV == 1) {                                                                    \
-      if (KV <= 4) { hipLaunchKernelGGL((KERNEL<4, 1>), __VA_ARGS__); }                 \
-      else if (KV <= 10) { hipLaunchKernelGGL((KERNEL<10, 1>), __VA_ARGS__); }          \
-      else if (KV <= 20) { hipLaunchKernelGGL((KERNEL<20, 1>), __VA_ARGS__); }          \
-      else { hipLaunchKernelGGL((KERNEL<32, 1>), __VA_ARGS__); }                        \
-    } else if (SPLV == 2) {                                                             \
-      if (KV <= 4) { hipLaunchKernelGGL((KERNEL<4, 2>), __VA_ARGS__); }                 \
-      else if (KV <= 10) { hipLaunchKernelGGL((KERNEL<10, 2>), __VA_ARGS__); }          \
-      else if (KV <= 20) { hipLaunchKernelGGL((KERNEL<20, 2>), __VA_ARGS__); }          \
-      else { hipLaunchKernelGGL((KERNEL<32, 2>), __VA_ARGS__); }                        \
-    } else {                                                                            \
-      if (KV <= 10) { hipLaunchKernelGGL((KERNEL<10, 4>), __VA_ARGS__); }               \
-      else { hipLaunchKernelGGL((KERNEL<20, 4>), __VA_ARGS__); }                        \
-    }                                                                                   \
+#define COATTN_DISPATCH(KERNEL, EXTRA, SPLV, KV, ...)                                     \
+  do {                                                                                    \
+    if (SPLV == 1) {                                                                      \
+      if (KV <= 4) { hipLaunchKernelGGL((KERNEL<4, 1 EXTRA>), __VA_ARGS__); }             \
+      else if (KV <= 10) { hipLaunchKernelGGL((KERNEL<10, 1 EXTRA>), __VA_ARGS__); }      \
+      else if (KV <= 20) { hipLaunchKernelGGL((KERNEL<20, 1 EXTRA>), __VA_ARGS__); }      \
+      else { hipLaunchKernelGGL((KERNEL<32, 1 EXTRA>), __VA_ARGS__); }                    \
+    } else if (SPLV == 2) {                                                               \
+      if (KV <= 4) { hipLaunchKernelGGL((KERNEL<4, 2 EXTRA>), __VA_ARGS__); }             \
+      else if (KV <= 10) { hipLaunchKernelGGL((KERNEL<10, 2 EXTRA>), __VA_ARGS__); }      \
+      else if (KV <= 20) { hipLaunchKernelGGL((KERNEL<20, 2 EXTRA>), __VA_ARGS__); }      \
+      else { hipLaunchKernelGGL((KERNEL<32, 2 EXTRA>), __VA_ARGS__); }                    \
+    } else {                                                                              \
+      if (KV <= 10) { hipLaunchKernelGGL((KERNEL<10, 4 EXTRA>), __VA_ARGS__); }           \
+      else { hipLaunchKernelGGL((KERNEL<20, 4 EXTRA>), __VA_ARGS__); }                    \
+    }                                                                                     \
   } while (0)
+#define COMMA_TRUE , true
+#define COMMA_FALSE , false
 
 static int coattn_check(const void* table, int64_t n_rows, int D, int F, int K, int B, int T) {
   if (!table || n_rows <= 0 || B <= 0 || T <= 0) return SCORE_E_BADARG;
@@ -407,14 +422,14 @@ int score_coattn_fwd_multi(CoattnArgs& a, int ncalls, int D, int B, hipStream_t 
     total += (int)cdiv64(cdiv64(a.n_units, 64 / a.c[c].GS), 4);
   }
   if (spl == 3) spl = 4;
-  COATTN_DISPATCH(coattn_fwd_kernel, spl, a.K, dim3(total), dim3(256), 0, s, a);
+  COATTN_DISPATCH(coattn_fwd_kernel, , spl, a.K, dim3(total), dim3(256), 0, s, a);
   SCORE_CHECK_LAUNCH();
   return 0;
 }
 
 // Backward of 1 or 2 calls in a single grid + the per-call slab reductions into dW[c] (+=).
 int score_coattn_bwd_multi(CoattnArgs& a, int ncalls, int D, int B, float* const dW[2], float* scratch,
-                           int64_t scratch_floats, hipStream_t s) {
+                           int64_t scratch_floats, int atomic_scatter, hipStream_t s) {
   int spl = 1, total = 0, nblk[2] = {0, 0};
   size_t lds_bytes = 0;
   int64_t used = 0;
@@ -438,7 +453,8 @@ int score_coattn_bwd_multi(CoattnArgs& a, int ncalls, int D, int B, float* const
   }
   if (a.mode == 0 && used > scratch_floats) return SCORE_E_WORKSPACE;
   if (spl == 3) spl = 4;
-  COATTN_DISPATCH(coattn_bwd_kernel, spl, a.K, dim3(total), dim3(256), lds_bytes, s, a);
+  if (atomic_scatter) COATTN_DISPATCH(coattn_bwd_kernel_t, COMMA_TRUE, spl, a.K, dim3(total), dim3(256), lds_bytes, s, a);
+  else COATTN_DISPATCH(coattn_bwd_kernel_t, COMMA_FALSE, spl, a.K, dim3(total), dim3(256), lds_bytes, s, a);
   SCORE_CHECK_LAUNCH();
   if (a.mode == 0) {
     for (int c = 0; c < ncalls; ++c) {
@@ -486,7 +502,7 @@ extern "C" int score_coattn_bwd(const float* table, float* grad_table, int64_t n
   c.idx1 = idx1; c.idx2 = idx2; c.W = W; c.rsave = const_cast<float*>(rsave); c.g1 = g1; c.ld1 = ld1; c.g2 = g2; c.ld2 = ld2;
   c.ginfo = ginfo; c.ldi = ldi; c.dzsum = dzsum; c.F = F;
   float* dWs[2] = {dW, nullptr};
-  return score_coattn_bwd_multi(a, 1, D, B, dWs, scratch, scratch_floats, (hipStream_t)stream);
+  return score_coattn_bwd_multi(a, 1, D, B, dWs, scratch, scratch_floats, 1, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------ target rows (score.py:62-66, 210, 217)
@@ -541,7 +557,8 @@ __global__ void target_bwd_kernel(float* __restrict__ gtable, int D4, int Fu, in
                                   const int32_t* __restrict__ tu, const int32_t* __restrict__ ti,
                                   const float* __restrict__ dquery, int ldq, const float* __restrict__ dhead,
                                   int ldh, int off_ti, int off_tu, const float* __restrict__ W1,
-                                  const float* __restrict__ W2, const float* __restrict__ S) {
+                                  const float* __restrict__ W2, const float* __restrict__ S,
+                                  float* __restrict__ dtgt) {
   const int cu = Fu * D4, ci = Fi * D4;
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (int64_t)B * (cu + ci)) return;
@@ -566,9 +583,10 @@ __global__ void target_bwd_kernel(float* __restrict__ gtable, int D4, int Fu, in
     if (dquery) g = add4(g, ld4(dquery + (int64_t)b * ldq + cu * 4 + s2 * 4));
     if (W1) g = fma4(S[b], ld4(W1 + s2 * 4), g);     // co-attention 1 targets the item (score.py:196)
   }
-  if (row != 0) {
-    float* d = gtable + (row * D4 + c) * 4;
-    atomicAdd(d, g.x); atomicAdd(d + 1, g.y); atomicAdd(d + 2, g.z); atomicAdd(d + 3, g.w);
+  if (dtgt) {  // pull mode: hand the [B, Du+Di] row gradients to the sorted scatter
+    st4(dtgt + (int64_t)b * (cu + ci) * 4 + s * 4, g);
+  } else if (row != 0) {
+    atomic_add4(gtable + (row * D4 + c) * 4, g);
   }
 }
 
@@ -597,7 +615,7 @@ int score_launch_target_bwd(float* grad_table, int D, int Fu, int Fi, int B, int
                             const int32_t* ti, const float* dquery, int ldq, const float* dhead, int ldh,
                             int off_ti, int off_tu, const float* query, const float* W1, const float* W2,
                             const float* dzsum1, const float* dzsum2, float* S, float* dW1, float* dB1,
-                            float* dW2, float* dB2, hipStream_t s) {
+                            float* dW2, float* dB2, float* dtgt_out, hipStream_t s) {
   const bool coattn = W1 != nullptr;
   if (coattn) {
     hipLaunchKernelGGL(dzsum_reduce_kernel, dim3((2 * B + 255) / 256), dim3(256), 0, s, dzsum1, dzsum2, B, T, S);
@@ -605,7 +623,7 @@ int score_launch_target_bwd(float* grad_table, int D, int Fu, int Fi, int B, int
   }
   int64_t n = (int64_t)B * (Fu + Fi) * (D / 4);
   hipLaunchKernelGGL(target_bwd_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, s, grad_table, D / 4, Fu,
-                     Fi, B, tu, ti, dquery, ldq, dhead, ldh, off_ti, off_tu, W1, W2, S);
+                     Fi, B, tu, ti, dquery, ldq, dhead, ldh, off_ti, off_tu, W1, W2, S, dtgt_out);
   SCORE_CHECK_LAUNCH();
   if (coattn) {
     hipLaunchKernelGGL(wt_grad_kernel, dim3(2), dim3(256), 0, s, query, ldq, Fu * D, Fi * D, B, S, dW1, dB1, dW2,

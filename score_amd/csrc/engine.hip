@@ -124,6 +124,8 @@ struct WS {
   // backward
   int64_t dz2, dz1, dbn, dhead, ds, da2, da1, dainp, dgru[2], dinfo, dq, dquery, dfinal[2];
   int64_t dxproj, rh, hprev, dxside[2], dzsum[2], S, scratch;
+  int64_t pcoef[2], dzcoef[2], dtgt, keys_in, keys_out, vals_in, vals_out, sort_temp, partials;
+  int64_t n_occ, sort_temp_bytes, partial_floats;
   int64_t scratch_floats, total;
 };
 
@@ -164,6 +166,18 @@ void build_ws(const Dims& d, int B, WS* w) {
   w->S = take(2 * (int64_t)B);
   w->scratch_floats = 4 << 20;
   w->scratch = take(w->scratch_floats);
+  // sorted pull-form scatter (scatter.hip)
+  for (int c = 0; c < 2; ++c) { w->pcoef[c] = take(BT * d.K); w->dzcoef[c] = take(BT * d.K); }
+  w->dtgt = take((int64_t)B * d.Dq);
+  w->n_occ = (int64_t)B * (2 * (int64_t)d.T * d.K * (d.Fu + d.Fi) + d.Fu + d.Fi);
+  w->keys_in = take(w->n_occ); w->keys_out = take(w->n_occ);
+  w->vals_in = take(w->n_occ); w->vals_out = take(w->n_occ);
+  size_t tb = 0;
+  score_plan_temp_bytes(w->n_occ, 32, &tb);
+  w->sort_temp_bytes = (int64_t)tb;
+  w->sort_temp = take((int64_t)(tb + 3) / 4 + 4);
+  w->partial_floats = 2 * cdiv64(w->n_occ, 64) * d.D;
+  w->partials = take(w->partial_floats);
   w->total = cur;
 }
 
@@ -415,6 +429,29 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
 
   // ---- co-attention + embedding rows (score.py:147-167, 196-201, 51-66)
   EV(3);
+  const bool atomic = st->scatter_mode == 1;
+  uint32_t* keys_out = reinterpret_cast<uint32_t*>(ws + w.keys_out);
+  uint32_t* vals_out = reinterpret_cast<uint32_t*>(ws + w.vals_out);
+  if (!atomic) {
+    // occurrence sort by row id: depends on the indices only
+    PlanFillArgs pf;
+    memset(&pf, 0, sizeof(pf));
+    const int32_t* idx[6] = {bt->user_1hop, bt->item_2hop, bt->user_2hop, bt->item_1hop, bt->target_user,
+                             bt->target_item};
+    const int Fs[6] = {d.Fi, d.Fi, d.Fu, d.Fu, d.Fu, d.Fi};
+    int64_t off = 0;
+    for (int g = 0; g < 6; ++g) {
+      pf.idx[g] = idx[g]; pf.F[g] = Fs[g]; pf.off[g] = off;
+      off += (g < 4 ? (int64_t)BT * d.K : (int64_t)B) * Fs[g];
+    }
+    pf.off[6] = off; pf.K = d.K; pf.G = 1; pf.shift = 0;
+    if (BT > (1 << 21) || d.Fu > 8 || d.Fi > 8) return SCORE_E_SHAPE;
+    int key_bits = 1;
+    while (key_bits < 32 && ((int64_t)1 << key_bits) < st->n_table_rows) ++key_bits;
+    G(score_launch_plan(pf, key_bits, reinterpret_cast<uint32_t*>(ws + w.keys_in),
+                        reinterpret_cast<uint32_t*>(ws + w.vals_in), keys_out, vals_out, ws + w.sort_temp,
+                        (size_t)w.sort_temp_bytes, s));
+  }
   {
     CoattnArgs ca;
     memset(&ca, 0, sizeof(ca));
@@ -424,19 +461,41 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
     c0.idx1 = bt->user_1hop; c0.idx2 = bt->item_2hop; c0.W = d.coattn ? W + P.ca_w[0] : nullptr;
     c0.rsave = ws + w.rsave[0]; c0.g1 = ws + w.dxside[0]; c0.ld1 = d.I; c0.g2 = ws + w.dxside[1] + d.Du;
     c0.ld2 = d.I; c0.ginfo = ws + w.dinfo; c0.ldi = ldi; c0.dzsum = ws + w.dzsum[0]; c0.F = d.Fi;
+    c0.pcoef = ws + w.pcoef[0]; c0.dzcoef = ws + w.dzcoef[0];
     CoattnCall& c1 = ca.c[1];
     c1.idx1 = bt->user_2hop; c1.idx2 = bt->item_1hop; c1.W = d.coattn ? W + P.ca_w[1] : nullptr;
     c1.rsave = ws + w.rsave[1]; c1.g1 = ws + w.dxside[0] + d.Di; c1.ld1 = d.I; c1.g2 = ws + w.dxside[1];
     c1.ld2 = d.I; c1.ginfo = ws + w.dinfo + 2 * d.K; c1.ldi = ldi; c1.dzsum = ws + w.dzsum[1]; c1.F = d.Fu;
+    c1.pcoef = ws + w.pcoef[1]; c1.dzcoef = ws + w.dzcoef[1];
     float* dWs[2] = {d.coattn ? gw + P.ca_w[0] : nullptr, d.coattn ? gw + P.ca_w[1] : nullptr};
-    G(score_coattn_bwd_multi(ca, 2, d.D, B, dWs, scratch, SF, s));
+    if (atomic || d.coattn)   // RCA in pull mode has nothing to prepare: every row gradient is G itself
+      G(score_coattn_bwd_multi(ca, 2, d.D, B, dWs, scratch, SF, atomic ? 1 : 0, s));
   }
   G(score_launch_target_bwd(grad_table, d.D, d.Fu, d.Fi, B, T, bt->target_user, bt->target_item,
                             d.attn ? ws + w.dquery : nullptr, d.Dq, ws + w.dhead, d.Dhead, d.off_ti, d.off_tu,
                             ws + w.query, d.coattn ? W + P.ca_w[0] : nullptr, d.coattn ? W + P.ca_w[1] : nullptr,
                             ws + w.dzsum[0], ws + w.dzsum[1], ws + w.S, d.coattn ? gw + P.ca_w[0] : nullptr,
                             d.coattn ? gw + P.ca_b[0] : nullptr, d.coattn ? gw + P.ca_w[1] : nullptr,
-                            d.coattn ? gw + P.ca_b[1] : nullptr, s));
+                            d.coattn ? gw + P.ca_b[1] : nullptr, atomic ? nullptr : ws + w.dtgt, s));
+  if (!atomic) {
+    PullArgs pa;
+    memset(&pa, 0, sizeof(pa));
+    pa.D = d.D; pa.K = d.K; pa.Gsh = 1; pa.shift = 0;
+    const float invK = 1.0f / (float)d.K;
+    const float* Gm[6] = {ws + w.dxside[0], ws + w.dxside[1], ws + w.dxside[0], ws + w.dxside[1], ws + w.dtgt,
+                          ws + w.dtgt};
+    const int ldg[6] = {d.I, d.I, d.I, d.I, d.Dq, d.Dq};
+    const int gcol[6] = {0, d.Du, d.Di, 0, 0, d.Du};
+    for (int g = 0; g < 6; ++g) { pa.G[g] = Gm[g]; pa.ldg[g] = ldg[g]; pa.gcol[g] = gcol[g]; pa.constA[g] = 1.0f; }
+    if (d.coattn) {
+      pa.cA[0] = ws + w.pcoef[0]; pa.cA[2] = ws + w.pcoef[1];
+      pa.constA[1] = invK; pa.constA[3] = invK;
+      pa.cB[0] = pa.cB[1] = ws + w.dzcoef[0]; pa.cB[2] = pa.cB[3] = ws + w.dzcoef[1];
+      pa.Wv[0] = W + P.ca_w[0] + d.Di; pa.Wv[1] = W + P.ca_w[0] + 2 * d.Di;
+      pa.Wv[2] = W + P.ca_w[1] + d.Du; pa.Wv[3] = W + P.ca_w[1] + 2 * d.Du;
+    }
+    G(score_launch_pull(pa, keys_out, vals_out, w.n_occ, grad_table, ws + w.partials, w.partial_floats, s));
+  }
   EV(4);
   return 0;
 }

@@ -11,6 +11,7 @@ struct CoattnCall {
   float* info; int ldi; float* rsave;
   const float* g1; const float* g2; const float* ginfo;
   float* dzsum; float* slab;
+  float* pcoef; float* dzcoef;                // backward, pull mode: softmax p_i and dz_i per (unit, i)
   int F, GS, nslots, first_block;
 };
 struct CoattnArgs {
@@ -20,7 +21,7 @@ struct CoattnArgs {
 };
 int score_coattn_fwd_multi(CoattnArgs& a, int ncalls, int D, int B, hipStream_t s);
 int score_coattn_bwd_multi(CoattnArgs& a, int ncalls, int D, int B, float* const dW[2], float* scratch,
-                           int64_t scratch_floats, hipStream_t s);
+                           int64_t scratch_floats, int atomic_scatter, hipStream_t s);
 int score_launch_target_fwd(const float* table, int D, int Fu, int Fi, int B, const int32_t* tu,
                             const int32_t* ti, float* query, int ldq, float* head, int ldh,
                             int off_ti, int off_tu, hipStream_t s);
@@ -28,7 +29,7 @@ int score_launch_target_bwd(float* grad_table, int D, int Fu, int Fi, int B, int
                             const int32_t* ti, const float* dquery, int ldq, const float* dhead, int ldh,
                             int off_ti, int off_tu, const float* query, const float* W1, const float* W2,
                             const float* dzsum1, const float* dzsum2, float* S /*[2][B]*/,
-                            float* dW1, float* dB1, float* dW2, float* dB2, hipStream_t s);
+                            float* dW1, float* dB1, float* dW2, float* dB2, float* dtgt_out, hipStream_t s);
 // gemm.hip
 int score_launch_colsum(const float* X, int M, int N, int ld, float* out, int accumulate,
                         float* scratch, int64_t scratch_floats, hipStream_t s);
@@ -58,3 +59,23 @@ int score_launch_head_out(int B, int NF, const float* f2, const float* w3, const
 int score_launch_outer_relu_bwd(int B, int NF, const float* dlogit, const float* w, const float* f, float keep,
                                 float* dz, hipStream_t s);
 int score_launch_copy2d(int64_t rows, int cols, const float* src, int lds_, float* dst, int ldd, hipStream_t s);
+
+// scatter.hip: occurrence sort ("index plan") and the pull-form gradient scatter
+struct PlanFillArgs {
+  const int32_t* idx[6];   // user_1hop, item_2hop, user_2hop, item_1hop, target_user, target_item
+  int64_t off[7];          // prefix offsets of the six tensors in the occurrence space
+  int F[6];
+  int K, G, shift;         // G > 1: key = (row % G) << shift | row / G
+};
+struct PullArgs {
+  const float* G[6]; int ldg[6]; int gcol[6];     // activation-gradient matrix per segment
+  const float* cA[6]; const float* cB[6];         // per-(unit,k) scalars (null: constA / none)
+  const float* Wv[6];                             // co-attention weight slice multiplied by cB
+  float constA[6];
+  int D, K, Gsh, shift, LPRp;
+};
+int score_plan_temp_bytes(int64_t n, int end_bit, size_t* bytes);
+int score_launch_plan(const PlanFillArgs& a, int key_bits, uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys_out,
+                      uint32_t* vals_out, void* temp, size_t temp_bytes, hipStream_t s);
+int score_launch_pull(PullArgs& a, const uint32_t* keys, const uint32_t* vals, int64_t n, float* out,
+                      float* partials, int64_t partial_floats, hipStream_t s);

@@ -90,6 +90,7 @@ class SCOREBASE(object):
         self.row0 = np.zeros((D,), dtype=np.float32)   # value of the masked variable row (score.py:44-47)
         self._drop_seed = int(seed)
         self.fwd_events = self.bwd_events = None
+        self.scatter_mode = 0      # 0: sorted pull-form scatter, 1: float atomics (score_hip.h)
         self._init_params(seed)
 
     # ------------------------------------------------------------------ parameters
@@ -164,7 +165,8 @@ class SCOREBASE(object):
         return ent
 
     def _state(self, ws):
-        return _lib.State(_ptr(self.table), self.table.shape[0], _ptr(self.w), _ptr(ws), ws.numel() * 4)
+        return _lib.State(_ptr(self.table), self.table.shape[0], _ptr(self.w), _ptr(ws), ws.numel() * 4,
+                          int(self.scatter_mode), 0)
 
     @staticmethod
     def _event_array(events):

@@ -31,7 +31,7 @@ def adam_close(got, want, grad, max_move, atol):
     gradient is at rounding-noise level the update is ill-conditioned: there only the step
     bound is asserted; everywhere else the golden value must be met to `atol`."""
     got, want, grad = np.asarray(got), np.asarray(want), np.asarray(grad)
-    well = np.abs(grad) > 1e-3 * max(np.abs(grad).max(), 1e-30)
+    well = np.abs(grad) > max(1e-3 * np.abs(grad).max(), 1e-6)
     ok_well = np.abs(got - want)[well] <= atol
     ok_rest = np.abs(got - want)[~well] <= 2.2 * max_move
     return bool(ok_well.all() and ok_rest.all())
@@ -202,3 +202,27 @@ def test_nested_list_feed_and_errors():
         m.eval(None, arr[:7], 1e-4)
     with pytest.raises(ValueError):
         m.eval(None, (arr[0][:, :2],) + arr[1:], 1e-4)
+
+
+def test_scatter_modes_agree_and_pull_is_deterministic():
+    # sorted pull-form scatter (default) vs float atomics: same gradients; the pull form is
+    # bitwise reproducible run to run (SURVEY 7 "hard parts": determinism of the scatter)
+    from score_amd.synth import make_world
+    from score_amd.model import SCORE
+    w, kw = make_world("cfg2")
+    kw.pop("batch")
+    m = SCORE(**kw)
+    batch = m.device_batch(w.batch(256, 3))
+    m.scatter_mode = 0
+    m.forward_backward(batch, 1e-4, 1.0)
+    g0 = m.table_g.clone()
+    w0 = m.w_g.clone()
+    m.forward_backward(batch, 1e-4, 1.0)
+    assert torch.equal(g0, m.table_g) and torch.equal(w0, m.w_g)
+    m.scatter_mode = 1
+    m.forward_backward(batch, 1e-4, 1.0)
+    g1 = m.table_g
+    scale = float(g0.abs().max())
+    assert float((g0 - g1).abs().max()) <= 2e-5 * scale
+    assert torch.equal((g0 != 0).any(dim=1), (g1 != 0).any(dim=1))
+    assert float(g0[0].abs().max()) == 0.0
