@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void coattn_bwd_kernel_t(const CoattnArgs a) {
   const int grp = lane / GS;
   const int Dx = nslots * 4;
   const int D = D4 * 4;
-  const int my_blocks = (ci == 0 ? a.c[1].first_block : (int)gridDim.x) - cc.first_block;
+  const int my_blocks = (ci == 0 ? min(a.c[1].first_block, (int)gridDim.x) : (int)gridDim.x) - cc.first_block;
   const int waves_total = my_blocks * 4;
   const int blk = (int)blockIdx.x - cc.first_block;
   const int wave0 = blk * 4 + wib;
@@ -442,7 +442,7 @@ int score_coattn_bwd_multi(CoattnArgs& a, int ncalls, int D, int B, float* const
     if (SPLc > spl) spl = SPLc;
     int upw = 64 / a.c[c].GS, Dx = a.c[c].nslots * 4;
     int blocks = (int)cdiv64(cdiv64(a.n_units, upw), 4);
-    if (blocks > 1024) blocks = 1024;
+    if (blocks > 512) blocks = 512;
     nblk[c] = blocks;
     a.c[c].first_block = total;
     total += blocks;
@@ -459,9 +459,8 @@ int score_coattn_bwd_multi(CoattnArgs& a, int ncalls, int D, int B, float* const
   if (a.mode == 0) {
     for (int c = 0; c < ncalls; ++c) {
       int Dx = a.c[c].nslots * 4;
-      hipLaunchKernelGGL(slab_reduce_kernel, dim3((2 * Dx + 255) / 256), dim3(256), 0, s, a.c[c].slab, nblk[c],
-                         2 * Dx, dW[c] + Dx, 1);
-      SCORE_CHECK_LAUNCH();
+      SCORE_TRY(score_launch_colsum(a.c[c].slab, nblk[c], 2 * Dx, 2 * Dx, dW[c] + Dx, 1, scratch + used,
+                                    scratch_floats - used, s));
     }
   }
   return 0;
@@ -590,32 +589,12 @@ __global__ void target_bwd_kernel(float* __restrict__ gtable, int D4, int Fu, in
   }
 }
 
-// dW_t[e] = sum_b S[b] * tgt[b][e];  dbias = sum_b S[b]     (one block per co-attention)
-__global__ void wt_grad_kernel(const float* __restrict__ query, int ldq, int Du, int Di, int B,
-                               const float* __restrict__ S, float* dW1, float* dB1, float* dW2, float* dB2) {
-  const int call = blockIdx.x;  // 0: item target (cols Du..Du+Di of query), 1: user target (cols 0..Du)
-  const int Dx = call == 0 ? Di : Du;
-  const int off = call == 0 ? Du : 0;
-  const float* Sc = S + (call == 0 ? 0 : B);
-  float* dW = call == 0 ? dW1 : dW2;
-  float* dB = call == 0 ? dB1 : dB2;
-  for (int e = threadIdx.x; e < Dx; e += blockDim.x) {
-    float s = 0.f;
-    for (int b = 0; b < B; ++b) s = fmaf(Sc[b], query[(int64_t)b * ldq + off + e], s);
-    dW[e] = s;
-  }
-  if (threadIdx.x == 0) {
-    float s = 0.f;
-    for (int b = 0; b < B; ++b) s += Sc[b];
-    dB[0] = s;
-  }
-}
-
 int score_launch_target_bwd(float* grad_table, int D, int Fu, int Fi, int B, int T, const int32_t* tu,
                             const int32_t* ti, const float* dquery, int ldq, const float* dhead, int ldh,
                             int off_ti, int off_tu, const float* query, const float* W1, const float* W2,
                             const float* dzsum1, const float* dzsum2, float* S, float* dW1, float* dB1,
-                            float* dW2, float* dB2, float* dtgt_out, hipStream_t s) {
+                            float* dW2, float* dB2, float* dtgt_out, float* scratch, int64_t scratch_floats,
+                            hipStream_t s) {
   const bool coattn = W1 != nullptr;
   if (coattn) {
     hipLaunchKernelGGL(dzsum_reduce_kernel, dim3((2 * B + 255) / 256), dim3(256), 0, s, dzsum1, dzsum2, B, T, S);
@@ -626,9 +605,14 @@ int score_launch_target_bwd(float* grad_table, int D, int Fu, int Fi, int B, int
                      Fi, B, tu, ti, dquery, ldq, dhead, ldh, off_ti, off_tu, W1, W2, S, dtgt_out);
   SCORE_CHECK_LAUNCH();
   if (coattn) {
-    hipLaunchKernelGGL(wt_grad_kernel, dim3(2), dim3(256), 0, s, query, ldq, Fu * D, Fi * D, B, S, dW1, dB1, dW2,
-                       dB2);
-    SCORE_CHECK_LAUNCH();
+    // dW_t = tgt^T S (call 0 targets the item: query cols Du.., call 1 the user: cols 0..), dbias = sum_b S
+    const int Du = Fu * D, Di = Fi * D;
+    SCORE_TRY(score_gemm(2, Di, 1, B, query + Du, ldq, S, 1, dW1, 1, nullptr, 0, 1.f, nullptr, 0, scratch,
+                         scratch_floats, s));
+    SCORE_TRY(score_gemm(2, Du, 1, B, query, ldq, S + B, 1, dW2, 1, nullptr, 0, 1.f, nullptr, 0, scratch,
+                         scratch_floats, s));
+    SCORE_TRY(score_launch_colsum(S, B, 1, 1, dB1, 0, scratch, scratch_floats, s));
+    SCORE_TRY(score_launch_colsum(S + B, B, 1, 1, dB2, 0, scratch, scratch_floats, s));
   }
   return 0;
 }

@@ -123,7 +123,7 @@ struct WS {
   int64_t q, ainp, a1, a2, bn, f1, f2, lossb, dlogit, part;
   // backward
   int64_t dz2, dz1, dbn, dhead, ds, da2, da1, dainp, dgru[2], dinfo, dq, dquery, dfinal[2];
-  int64_t dxproj, rh, hprev, dxside[2], dzsum[2], S, scratch;
+  int64_t dxproj[2], rh[2], hprev[2], dxside[2], dzsum[2], S, scratch;
   int64_t pcoef[2], dzcoef[2], dtgt, keys_in, keys_out, vals_in, vals_out, sort_temp, partials;
   int64_t n_occ, sort_temp_bytes, partial_floats;
   int64_t scratch_floats, total;
@@ -158,9 +158,11 @@ void build_ws(const Dims& d, int B, WS* w) {
   w->dinfo = take(BT * 4 * d.K);
   w->dq = take((int64_t)B * d.Dk); w->dquery = take((int64_t)B * d.Dq);
   for (int s = 0; s < 2; ++s) w->dfinal[s] = take((int64_t)B * d.H);
-  w->dxproj = take(BT * 3 * d.H);
-  w->rh = take(BT * d.H);
-  w->hprev = take(BT * d.H + 3 * (int64_t)d.H * d.H);
+  for (int s = 0; s < 2; ++s) {
+    w->dxproj[s] = take(BT * 3 * d.H);
+    w->rh[s] = take(BT * d.H);
+    w->hprev[s] = take(BT * d.H + 3 * (int64_t)d.H * d.H);
+  }
   for (int s = 0; s < 2; ++s) w->dxside[s] = take(BT * d.I);
   for (int c = 0; c < 2; ++c) w->dzsum[c] = take(BT);
   w->S = take(2 * (int64_t)B);
@@ -176,7 +178,7 @@ void build_ws(const Dims& d, int B, WS* w) {
   score_plan_temp_bytes(w->n_occ, 32, &tb);
   w->sort_temp_bytes = (int64_t)tb;
   w->sort_temp = take((int64_t)(tb + 3) / 4 + 4);
-  w->partial_floats = 2 * cdiv64(w->n_occ, 64) * d.D;
+  w->partial_floats = 2 * cdiv64(w->n_occ, 64) * d.D + 8 + 2 * cdiv64(w->n_occ, 64);
   w->partials = take(w->partial_floats);
   w->total = cur;
 }
@@ -265,14 +267,22 @@ extern "C" int score_forward(const score_config_t* cfg, const score_state_t* st,
   }
   EV(1);
   // GRUs (:205-208): hoisted x-projection, then the persistent recurrence
-  for (int sd = 0; sd < 2; ++sd) {
-    float* xp = ws + w.xproj[sd];
-    G(score_gemm(0, BT, 2 * H, d.I, ws + w.xside[sd], d.I, W + P.gk[sd], 2 * H, xp, 3 * H, W + P.gb[sd], GF_BIAS,
-                 1.f, nullptr, 0, scratch, w.scratch_floats, s));
-    G(score_gemm(0, BT, H, d.I, ws + w.xside[sd], d.I, W + P.ck[sd], H, xp + 2 * H, 3 * H, W + P.cb[sd], GF_BIAS,
-                 1.f, nullptr, 0, scratch, w.scratch_floats, s));
-    G(score_gru_fwd(B, T, H, xp, W + P.gk[sd] + (int64_t)d.I * 2 * H, 2 * H, W + P.ck[sd] + (int64_t)d.I * H, H,
-                    bt->length, ws + w.gru_out[sd], H, ws + w.gates[sd], ws + w.gru_final[sd], s));
+  {
+    GruArgs ga;
+    memset(&ga, 0, sizeof(ga));
+    ga.B = B; ga.T = T; ga.H = H; ga.length = bt->length;
+    for (int sd = 0; sd < 2; ++sd) {
+      float* xp = ws + w.xproj[sd];
+      G(score_gemm(0, BT, 2 * H, d.I, ws + w.xside[sd], d.I, W + P.gk[sd], 2 * H, xp, 3 * H, W + P.gb[sd],
+                   GF_BIAS, 1.f, nullptr, 0, scratch, w.scratch_floats, s));
+      G(score_gemm(0, BT, H, d.I, ws + w.xside[sd], d.I, W + P.ck[sd], H, xp + 2 * H, 3 * H, W + P.cb[sd], GF_BIAS,
+                   1.f, nullptr, 0, scratch, w.scratch_floats, s));
+      GruSide& g = ga.s[sd];
+      g.xproj = xp; g.Wg = W + P.gk[sd] + (int64_t)d.I * 2 * H; g.ldwg = 2 * H;
+      g.Wc = W + P.ck[sd] + (int64_t)d.I * H; g.ldwc = H;
+      g.out = ws + w.gru_out[sd]; g.ldo = H; g.gates = ws + w.gates[sd]; g.final_state = ws + w.gru_final[sd];
+    }
+    G(score_gru_fwd_multi(ga, 2, s));
   }
   EV(2);
   if (d.attn) {
@@ -352,8 +362,9 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
   G(score_gemm(1, B, d.Dhead, FC1, ws + w.dz1, FC1, W + P.fc_w[0], FC1, ws + w.dbn, d.Dhead, nullptr, 0, 1.f,
                nullptr, 0, scratch, SF, s));
   const float rs = (float)(1.0 / sqrt(1.0 + 1e-3));
+  // (w.bn is dead after the fc1 weight-gradient GEMM above: reuse it as the dgamma staging buffer)
   G(score_launch_bn_bwd(B, d.Dhead, ws + w.head_inp, W + P.bn_g, rs, ws + w.dbn, ws + w.dhead, gw + P.bn_g,
-                        gw + P.bn_b, s));
+                        gw + P.bn_b, ws + w.bn, scratch, SF, s));
 
   EV(1);
   const float* dfinal[2] = {nullptr, nullptr};
@@ -402,21 +413,32 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
 
   EV(2);
   // ---- GRUs (score.py:205-208)
+  {
+    GruArgs ga;
+    memset(&ga, 0, sizeof(ga));
+    ga.B = B; ga.T = T; ga.H = H; ga.length = bt->length;
+    for (int sd = 0; sd < 2; ++sd) {
+      GruSide& g = ga.s[sd];
+      g.Wg = W + P.gk[sd] + (int64_t)d.I * 2 * H; g.ldwg = 2 * H;
+      g.Wc = W + P.ck[sd] + (int64_t)d.I * H; g.ldwc = H;
+      g.out = ws + w.gru_out[sd]; g.ldo = H; g.gates = ws + w.gates[sd];
+      g.dout = ws + w.dgru[sd]; g.lddo = H; g.dfinal = dfinal[sd];
+      g.dxproj = ws + w.dxproj[sd]; g.rh = ws + w.rh[sd]; g.hprev = ws + w.hprev[sd];
+    }
+    G(score_gru_bwd_multi(ga, 2, s));
+  }
   for (int sd = 0; sd < 2; ++sd) {
     const float* Wg = W + P.gk[sd];
     const float* Wc = W + P.ck[sd];
-    float* dxp = ws + w.dxproj;
-    G(score_gru_bwd(B, T, H, Wg + (int64_t)d.I * 2 * H, 2 * H, Wc + (int64_t)d.I * H, H, bt->length,
-                    ws + w.gru_out[sd], H, ws + w.gates[sd], ws + w.dgru[sd], H, dfinal[sd], dxp, ws + w.rh,
-                    ws + w.hprev, s));
+    float* dxp = ws + w.dxproj[sd];
     // kernels are [x ; h] row blocks (TF GRUCell): x rows first
     G(score_gemm(2, d.I, 2 * H, BT, ws + w.xside[sd], d.I, dxp, 3 * H, gw + P.gk[sd], 2 * H, nullptr, 0, 1.f,
                  nullptr, 0, scratch, SF, s));
-    G(score_gemm(2, H, 2 * H, BT, ws + w.hprev, H, dxp, 3 * H, gw + P.gk[sd] + (int64_t)d.I * 2 * H, 2 * H,
+    G(score_gemm(2, H, 2 * H, BT, ws + w.hprev[sd], H, dxp, 3 * H, gw + P.gk[sd] + (int64_t)d.I * 2 * H, 2 * H,
                  nullptr, 0, 1.f, nullptr, 0, scratch, SF, s));
     G(score_gemm(2, d.I, H, BT, ws + w.xside[sd], d.I, dxp + 2 * H, 3 * H, gw + P.ck[sd], H, nullptr, 0, 1.f,
                  nullptr, 0, scratch, SF, s));
-    G(score_gemm(2, H, H, BT, ws + w.rh, H, dxp + 2 * H, 3 * H, gw + P.ck[sd] + (int64_t)d.I * H, H, nullptr, 0,
+    G(score_gemm(2, H, H, BT, ws + w.rh[sd], H, dxp + 2 * H, 3 * H, gw + P.ck[sd] + (int64_t)d.I * H, H, nullptr, 0,
                  1.f, nullptr, 0, scratch, SF, s));
     G(score_launch_colsum(dxp, BT, 2 * H, 3 * H, gw + P.gb[sd], 0, scratch, SF, s));
     G(score_launch_colsum(dxp + 2 * H, BT, H, 3 * H, gw + P.cb[sd], 0, scratch, SF, s));
@@ -476,7 +498,7 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
                             ws + w.query, d.coattn ? W + P.ca_w[0] : nullptr, d.coattn ? W + P.ca_w[1] : nullptr,
                             ws + w.dzsum[0], ws + w.dzsum[1], ws + w.S, d.coattn ? gw + P.ca_w[0] : nullptr,
                             d.coattn ? gw + P.ca_b[0] : nullptr, d.coattn ? gw + P.ca_w[1] : nullptr,
-                            d.coattn ? gw + P.ca_b[1] : nullptr, atomic ? nullptr : ws + w.dtgt, s));
+                            d.coattn ? gw + P.ca_b[1] : nullptr, atomic ? nullptr : ws + w.dtgt, scratch, SF, s));
   if (!atomic) {
     PullArgs pa;
     memset(&pa, 0, sizeof(pa));

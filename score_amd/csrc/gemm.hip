@@ -184,15 +184,24 @@ extern "C" int score_gemm(int32_t trans, int32_t M, int32_t N, int32_t K, const 
 }
 
 // ------------------------------------------------------------------ small helpers used by the engine
-// out[n] (+)= sum_m X[m][n]   two-stage, fixed order
-__global__ void colsum_stage1(const float* __restrict__ X, int M, int N, int ld, int rows_per_block,
-                              float* __restrict__ part) {
-  int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N) return;
-  int m0 = blockIdx.y * rows_per_block, m1 = min(M, m0 + rows_per_block);
+// out[n] (+)= sum_m X[m][n]   two-stage, fixed order.  A block is (cols x rows) threads;
+// each thread strides down its column, the row dimension is combined through LDS.
+__global__ __launch_bounds__(256) void colsum_stage1(const float* __restrict__ X, int M, int N, int ld, int cols,
+                                                     int rows_per_block, float* __restrict__ part) {
+  __shared__ float sh[256];
+  const int tx = threadIdx.x % cols, ty = threadIdx.x / cols, nty = 256 / cols;
+  const int n = blockIdx.x * cols + tx;
+  const int m0 = blockIdx.y * rows_per_block, m1 = min(M, m0 + rows_per_block);
   float s = 0.f;
-  for (int m = m0; m < m1; ++m) s += X[(int64_t)m * ld + n];
-  part[(int64_t)blockIdx.y * N + n] = s;
+  if (n < N)
+    for (int m = m0 + ty; m < m1; m += nty) s += X[(int64_t)m * ld + n];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  if (ty == 0 && n < N) {
+    float t = 0.f;
+    for (int r = 0; r < nty; ++r) t += sh[r * cols + tx];
+    part[(int64_t)blockIdx.y * N + n] = t;
+  }
 }
 __global__ void colsum_stage2(const float* __restrict__ part, int nparts, int N, float* __restrict__ out,
                               int accumulate) {
@@ -205,15 +214,16 @@ __global__ void colsum_stage2(const float* __restrict__ part, int nparts, int N,
 
 int score_launch_colsum(const float* X, int M, int N, int ld, float* out, int accumulate, float* scratch,
                         int64_t scratch_floats, hipStream_t s) {
-  int nparts = (M + 255) / 256;
-  if (nparts > 512) nparts = 512;
+  int cols = 1;
+  while (cols < N && cols < 64) cols <<= 1;
+  int rpb = 128;
+  int nparts = (M + rpb - 1) / rpb;
+  if (nparts > 256) { nparts = 256; rpb = (M + nparts - 1) / nparts; nparts = (M + rpb - 1) / rpb; }
   if ((int64_t)nparts * N > scratch_floats) return SCORE_E_WORKSPACE;
-  int rpb = (M + nparts - 1) / nparts;
-  nparts = (M + rpb - 1) / rpb;
-  int tx = N < 64 ? 64 : 256;
-  hipLaunchKernelGGL(colsum_stage1, dim3((N + tx - 1) / tx, nparts), dim3(tx), 0, s, X, M, N, ld, rpb, scratch);
+  hipLaunchKernelGGL(colsum_stage1, dim3((N + cols - 1) / cols, nparts), dim3(256), 0, s, X, M, N, ld, cols, rpb,
+                     scratch);
   SCORE_CHECK_LAUNCH();
-  hipLaunchKernelGGL(colsum_stage2, dim3((N + tx - 1) / tx), dim3(tx), 0, s, scratch, nparts, N, out, accumulate);
+  hipLaunchKernelGGL(colsum_stage2, dim3((N + 63) / 64), dim3(64), 0, s, scratch, nparts, N, out, accumulate);
   SCORE_CHECK_LAUNCH();
   return 0;
 }

@@ -7,9 +7,14 @@
 // GRUCell (TF 1.x): [r,u] = sigmoid([x,h].Wg + bg) (r first), c = tanh([x,r*h].Wc + bc),
 // h' = u*h + (1-u)*c.  The x-part (x.Wx + b) is hoisted into one big GEMM: `xproj`.
 #include "common.h"
+#include "kernels.h"
 
+#include <string.h>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-#define RB 32  // batch rows per workgroup
+#define RB 32
+static bool gru_reg_ok(int H);
+int score_gru_fwd_multi(GruArgs& a, int nsides, hipStream_t s);
+int score_gru_bwd_multi(GruArgs& a, int nsides, hipStream_t s);  // batch rows per workgroup
 
 // acc(32 x 32 cols starting at j0) = Ash[32][K] (LDS, row stride lds_ld) . Wm[K][ldw] (global)
 __device__ __forceinline__ f32x16 tile_matmul(const float* __restrict__ Ash, int lds_ld, int Kdim,
@@ -115,6 +120,14 @@ extern "C" int score_gru_fwd(int32_t B, int32_t T, int32_t H, const float* xproj
                              int32_t ldwg, const float* Wc, int32_t ldwc, const int32_t* length, float* out,
                              int32_t ldo, float* gates_save, float* final_state, void* stream) {
   if (!xproj || !Wg || !Wc || !length || !out || !gates_save || B <= 0 || T <= 0 || H <= 0) return SCORE_E_BADARG;
+  if (gru_reg_ok(H)) {
+    GruArgs a;
+    memset(&a, 0, sizeof(a));
+    a.B = B; a.T = T; a.H = H; a.length = length;
+    a.s[0].xproj = xproj; a.s[0].Wg = Wg; a.s[0].ldwg = ldwg; a.s[0].Wc = Wc; a.s[0].ldwc = ldwc;
+    a.s[0].out = out; a.s[0].ldo = ldo; a.s[0].gates = gates_save; a.s[0].final_state = final_state;
+    return score_gru_fwd_multi(a, 1, (hipStream_t)stream);
+  }
   size_t lds = (size_t)3 * RB * (H + 1) * sizeof(float);
   if (lds > 160 * 1024) return SCORE_E_SHAPE;
   if (lds > 48 * 1024)
@@ -240,6 +253,16 @@ extern "C" int score_gru_bwd(int32_t B, int32_t T, int32_t H, const float* Wg, i
   if (!Wg || !Wc || !length || !out || !gates_save || !dout || !dxproj || !rh || !hprev || B <= 0 || T <= 0 ||
       H <= 0)
     return SCORE_E_BADARG;
+  if (gru_reg_ok(H)) {
+    GruArgs a;
+    memset(&a, 0, sizeof(a));
+    a.B = B; a.T = T; a.H = H; a.length = length;
+    GruSide& g = a.s[0];
+    g.Wg = Wg; g.ldwg = ldwg; g.Wc = Wc; g.ldwc = ldwc; g.out = const_cast<float*>(out); g.ldo = ldo;
+    g.gates = const_cast<float*>(gates_save); g.dout = dout; g.lddo = lddo; g.dfinal = dfinal;
+    g.dxproj = dxproj; g.rh = rh; g.hprev = hprev;
+    return score_gru_bwd_multi(a, 1, (hipStream_t)stream);
+  }
   size_t lds = (size_t)RB * (2 * (H + 1) + (2 * H + 1)) * sizeof(float);
   if (lds > 160 * 1024) return SCORE_E_SHAPE;
   hipStream_t s = (hipStream_t)stream;
@@ -254,5 +277,309 @@ extern "C" int score_gru_bwd(int32_t B, int32_t T, int32_t H, const float* Wg, i
   hipLaunchKernelGGL(gru_bwd_kernel, dim3((B + RB - 1) / RB), dim3(256), lds, s, B, T, H, WgT, WcT, length, out,
                      ldo, gates_save, dout, lddo, dfinal, dxproj, rh, hprev);
   SCORE_CHECK_LAUNCH();
+  return 0;
+}
+
+// ======================================================================================
+// Register-resident recurrence (H in {16,32,64,128}): the recurrent weights never leave
+// the VGPRs.  A workgroup = 4 waves owns 16 batch rows; every wave owns a fixed set of
+// 16-column output tiles and keeps their B operands for v_mfma_f32_16x16x4_f32 in registers
+// for all T steps (H=128: 6 tiles x 32 k-steps = 192 VGPRs), so a step is LDS reads of the
+// 16xH state, MFMAs and the fused pointwise epilogue -- no weight traffic at all.  Both GRUs
+// of the model (user side / item side) share one launch.
+// ======================================================================================
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define RRB 16
+
+template <int H>
+__global__ __launch_bounds__(256) void gru_fwd_reg_kernel(const GruArgs a) {
+  constexpr int KS = H / 4;                 // k-steps of 4
+  constexpr int NTG = 2 * H / 16, NTC = H / 16;
+  constexpr int TGW = (NTG + 3) / 4, TCW = (NTC + 3) / 4;
+  constexpr int LD = H + 2;                 // (16 rows x 2 k) of a lane group land on 32 distinct banks
+  __shared__ float hs[RRB * LD], rhs[RRB * LD], us[RRB * LD];
+  const int tiles_b = (a.B + RRB - 1) / RRB;
+  const int side = blockIdx.x / tiles_b;
+  const GruSide& sd = a.s[side];
+  const int b0 = (blockIdx.x - side * tiles_b) * RRB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lc = lane & 15, lq = lane >> 4;  // column inside a tile / k-quarter == output row group
+  const int T = a.T;
+
+  float wg[TGW][KS], wc[TCW][KS];
+#pragma unroll
+  for (int tt = 0; tt < TGW; ++tt) {
+    const int tile = wave + 4 * tt;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+      wg[tt][ks] = tile < NTG ? sd.Wg[(int64_t)(ks * 4 + lq) * sd.ldwg + tile * 16 + lc] : 0.f;
+  }
+#pragma unroll
+  for (int tt = 0; tt < TCW; ++tt) {
+    const int tile = wave + 4 * tt;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+      wc[tt][ks] = tile < NTC ? sd.Wc[(int64_t)(ks * 4 + lq) * sd.ldwc + tile * 16 + lc] : 0.f;
+  }
+  int len[4];
+  bool rok[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int b = b0 + lq * 4 + r;
+    rok[r] = b < a.B;
+    len[r] = rok[r] ? a.length[b] : 0;
+  }
+  for (int e = tid; e < RRB * LD; e += 256) hs[e] = 0.f;
+  __syncthreads();
+
+  for (int t = 0; t < T; ++t) {
+    // issue this step's x-projection reads first: they are consumed after the MFMA chains
+    float xg[TGW][4], xc[TCW][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t row = (int64_t)(b0 + lq * 4 + r) * T + t;
+#pragma unroll
+      for (int tt = 0; tt < TGW; ++tt) {
+        const int tile = wave + 4 * tt;
+        xg[tt][r] = (rok[r] && tile < NTG) ? sd.xproj[row * 3 * H + tile * 16 + lc] : 0.f;
+      }
+#pragma unroll
+      for (int tt = 0; tt < TCW; ++tt) {
+        const int tile = wave + 4 * tt;
+        xc[tt][r] = (rok[r] && tile < NTC) ? sd.xproj[row * 3 * H + 2 * H + tile * 16 + lc] : 0.f;
+      }
+    }
+    // gates = sigmoid(xproj[:, :2H] + h . Wg)
+    f32x4 acc[TGW];
+#pragma unroll
+    for (int tt = 0; tt < TGW; ++tt) acc[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const float av = hs[lc * LD + ks * 4 + lq];
+#pragma unroll
+      for (int tt = 0; tt < TGW; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wg[tt][ks], acc[tt], 0, 0, 0);
+    }
+#pragma unroll
+    for (int tt = 0; tt < TGW; ++tt) {
+      const int tile = wave + 4 * tt;
+      if (tile >= NTG) continue;
+      const int j = tile * 16 + lc;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = lq * 4 + r;
+        const float g = sigmoidf_(acc[tt][r] + xg[tt][r]);
+        if (rok[r]) sd.gates[((int64_t)(b0 + i) * T + t) * 3 * H + j] = g;
+        if (j < H) rhs[i * LD + j] = g * hs[i * LD + j];
+        else us[i * LD + (j - H)] = g;
+      }
+    }
+    __syncthreads();
+    // c = tanh(xproj[:, 2H:] + (r*h) . Wc) ; h' = u*h + (1-u)*c
+    f32x4 acc2[TCW];
+#pragma unroll
+    for (int tt = 0; tt < TCW; ++tt) acc2[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const float av = rhs[lc * LD + ks * 4 + lq];
+#pragma unroll
+      for (int tt = 0; tt < TCW; ++tt)
+        acc2[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wc[tt][ks], acc2[tt], 0, 0, 0);
+    }
+#pragma unroll
+    for (int tt = 0; tt < TCW; ++tt) {
+      const int tile = wave + 4 * tt;
+      if (tile >= NTC) continue;
+      const int j = tile * 16 + lc;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = lq * 4 + r;
+        const float c = tanhf(acc2[tt][r] + xc[tt][r]);
+        const float u = us[i * LD + j], h = hs[i * LD + j];
+        const float hn = u * h + (1.0f - u) * c;
+        const bool live = t < len[r];
+        if (rok[r]) {
+          const int64_t row = (int64_t)(b0 + i) * T + t;
+          sd.gates[row * 3 * H + 2 * H + j] = c;
+          sd.out[row * sd.ldo + j] = live ? hn : 0.f;
+        }
+        hs[i * LD + j] = live ? hn : h;
+      }
+    }
+    __syncthreads();
+  }
+  if (sd.final_state)
+    for (int e = tid; e < RRB * H; e += 256) {
+      const int i = e / H, j = e - i * H;
+      if (b0 + i < a.B) sd.final_state[(int64_t)(b0 + i) * H + j] = hs[i * LD + j];
+    }
+}
+
+template <int H>
+__global__ __launch_bounds__(256) void gru_bwd_reg_kernel(const GruArgs a) {
+  constexpr int KS = H / 4;
+  constexpr int NT = H / 16;
+  constexpr int TW = (NT + 3) / 4;
+  constexpr int LD = H + 2, LD2 = 2 * H + 2;
+  __shared__ float dh[RRB * LD], dpc[RRB * LD], dpg[RRB * LD2];
+  const int tiles_b = (a.B + RRB - 1) / RRB;
+  const int side = blockIdx.x / tiles_b;
+  const GruSide& sd = a.s[side];
+  const int b0 = (blockIdx.x - side * tiles_b) * RRB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lc = lane & 15, lq = lane >> 4;
+  const int T = a.T;
+
+  // B operands of the two transposed products: B[k][j] = Wc[j][k] (k < H), Wg[j][k] (k < 2H)
+  float wct[TW][KS], wgt[TW][2 * KS];
+#pragma unroll
+  for (int tt = 0; tt < TW; ++tt) {
+    const int tile = wave + 4 * tt;
+    const int j = tile * 16 + lc;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) wct[tt][ks] = tile < NT ? sd.Wc[(int64_t)j * sd.ldwc + ks * 4 + lq] : 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 2 * KS; ++ks) wgt[tt][ks] = tile < NT ? sd.Wg[(int64_t)j * sd.ldwg + ks * 4 + lq] : 0.f;
+  }
+  int len[4];
+  bool rok[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int b = b0 + lq * 4 + r;
+    rok[r] = b < a.B;
+    len[r] = rok[r] ? a.length[b] : 0;
+  }
+  for (int e = tid; e < RRB * H; e += 256) {
+    const int i = e / H, j = e - i * H;
+    dh[i * LD + j] = (sd.dfinal && b0 + i < a.B) ? sd.dfinal[(int64_t)(b0 + i) * H + j] : 0.f;
+  }
+  __syncthreads();
+
+  for (int t = T - 1; t >= 0; --t) {
+    // phase 1 (elementwise): dpu, dpc ; dh <- dh_tot * u
+    for (int e = tid; e < RRB * H; e += 256) {
+      const int i = e / H, j = e - i * H;
+      const int b = b0 + i;
+      float v_dpc = 0.f, v_dpu = 0.f;
+      if (b < a.B) {
+        const int64_t row = (int64_t)b * T + t;
+        const bool live = t < a.length[b];
+        const float hp = t > 0 ? sd.out[(row - 1) * sd.ldo + j] : 0.f;
+        sd.hprev[row * H + j] = live ? hp : 0.f;
+        if (live) {
+          const float u = sd.gates[row * 3 * H + H + j], c = sd.gates[row * 3 * H + 2 * H + j];
+          const float d = dh[i * LD + j] + sd.dout[row * sd.lddo + j];
+          const float du = d * (hp - c), dc = d * (1.0f - u);
+          v_dpu = du * u * (1.0f - u);
+          v_dpc = dc * (1.0f - c * c);
+          dh[i * LD + j] = d * u;
+        }
+        sd.dxproj[row * 3 * H + H + j] = v_dpu;
+        sd.dxproj[row * 3 * H + 2 * H + j] = v_dpc;
+      }
+      dpc[i * LD + j] = v_dpc;
+      dpg[i * LD2 + H + j] = v_dpu;
+    }
+    __syncthreads();
+    // phase 2: d(rh) = dpc . Wc^T ; dpr = d(rh)*h_prev*r(1-r) ; dh += d(rh)*r
+    {
+      f32x4 acc[TW];
+#pragma unroll
+      for (int tt = 0; tt < TW; ++tt) acc[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const float av = dpc[lc * LD + ks * 4 + lq];
+#pragma unroll
+        for (int tt = 0; tt < TW; ++tt)
+          acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wct[tt][ks], acc[tt], 0, 0, 0);
+      }
+#pragma unroll
+      for (int tt = 0; tt < TW; ++tt) {
+        const int tile = wave + 4 * tt;
+        if (tile >= NT) continue;
+        const int j = tile * 16 + lc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = lq * 4 + r;
+          float v_dpr = 0.f;
+          if (rok[r]) {
+            const int64_t row = (int64_t)(b0 + i) * T + t;
+            float rr = 0.f, hp = 0.f;
+            if (t < len[r]) {
+              rr = sd.gates[row * 3 * H + j];
+              hp = t > 0 ? sd.out[(row - 1) * sd.ldo + j] : 0.f;
+              const float drh = acc[tt][r];
+              v_dpr = drh * hp * rr * (1.0f - rr);
+              dh[i * LD + j] += drh * rr;
+            }
+            sd.dxproj[row * 3 * H + j] = v_dpr;
+            sd.rh[row * H + j] = rr * hp;
+          }
+          dpg[i * LD2 + j] = v_dpr;
+        }
+      }
+    }
+    __syncthreads();
+    // phase 3: dh += [dpr | dpu] . Wg^T
+    {
+      f32x4 acc[TW];
+#pragma unroll
+      for (int tt = 0; tt < TW; ++tt) acc[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2 * KS; ++ks) {
+        const float av = dpg[lc * LD2 + ks * 4 + lq];
+#pragma unroll
+        for (int tt = 0; tt < TW; ++tt)
+          acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wgt[tt][ks], acc[tt], 0, 0, 0);
+      }
+#pragma unroll
+      for (int tt = 0; tt < TW; ++tt) {
+        const int tile = wave + 4 * tt;
+        if (tile >= NT) continue;
+        const int j = tile * 16 + lc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dh[(lq * 4 + r) * LD + j] += acc[tt][r];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+static bool gru_reg_ok(int H) { return H == 16 || H == 32 || H == 64 || H == 128; }
+
+int score_gru_fwd_multi(GruArgs& a, int nsides, hipStream_t s) {
+  const int H = a.H;
+  if (gru_reg_ok(H)) {
+    dim3 grid(nsides * ((a.B + RRB - 1) / RRB));
+    if (H == 16) hipLaunchKernelGGL(gru_fwd_reg_kernel<16>, grid, dim3(256), 0, s, a);
+    else if (H == 32) hipLaunchKernelGGL(gru_fwd_reg_kernel<32>, grid, dim3(256), 0, s, a);
+    else if (H == 64) hipLaunchKernelGGL(gru_fwd_reg_kernel<64>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(gru_fwd_reg_kernel<128>, grid, dim3(256), 0, s, a);
+    SCORE_CHECK_LAUNCH();
+    return 0;
+  }
+  for (int i = 0; i < nsides; ++i) {
+    const GruSide& sd = a.s[i];
+    SCORE_TRY(score_gru_fwd(a.B, a.T, H, sd.xproj, sd.Wg, sd.ldwg, sd.Wc, sd.ldwc, a.length, sd.out, sd.ldo,
+                            sd.gates, sd.final_state, s));
+  }
+  return 0;
+}
+
+int score_gru_bwd_multi(GruArgs& a, int nsides, hipStream_t s) {
+  const int H = a.H;
+  if (gru_reg_ok(H)) {
+    dim3 grid(nsides * ((a.B + RRB - 1) / RRB));
+    if (H == 16) hipLaunchKernelGGL(gru_bwd_reg_kernel<16>, grid, dim3(256), 0, s, a);
+    else if (H == 32) hipLaunchKernelGGL(gru_bwd_reg_kernel<32>, grid, dim3(256), 0, s, a);
+    else if (H == 64) hipLaunchKernelGGL(gru_bwd_reg_kernel<64>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(gru_bwd_reg_kernel<128>, grid, dim3(256), 0, s, a);
+    SCORE_CHECK_LAUNCH();
+    return 0;
+  }
+  for (int i = 0; i < nsides; ++i) {
+    const GruSide& sd = a.s[i];
+    SCORE_TRY(score_gru_bwd(a.B, a.T, H, sd.Wg, sd.ldwg, sd.Wc, sd.ldwc, a.length, sd.out, sd.ldo, sd.gates,
+                            sd.dout, sd.lddo, sd.dfinal, sd.dxproj, sd.rh, sd.hprev, s));
+  }
   return 0;
 }

@@ -189,21 +189,15 @@ __global__ void bn_fwd_kernel(int B, int Dh, const float* __restrict__ x, const 
   int j = (int)(i % Dh);
   y[i] = x[i] * (gamma[j] * rs) + beta[j];
 }
-// dx = dy * gamma*rs ; dgamma[j] = sum_b dy*x*rs ; dbeta[j] = sum_b dy   (thread per column)
+// dx = dy * gamma*rs ; tmp = dy * x*rs  (dgamma = colsum(tmp), dbeta = colsum(dy))
 __global__ void bn_bwd_kernel(int B, int Dh, const float* __restrict__ x, const float* __restrict__ gamma, float rs,
-                              const float* __restrict__ dy, float* __restrict__ dx, float* __restrict__ dgamma,
-                              float* __restrict__ dbeta) {
-  int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= Dh) return;
-  float inv = gamma[j] * rs, sg = 0.f, sb = 0.f;
-  for (int b = 0; b < B; ++b) {
-    float d = dy[(int64_t)b * Dh + j];
-    dx[(int64_t)b * Dh + j] = d * inv;
-    sg = fmaf(d, x[(int64_t)b * Dh + j] * rs, sg);
-    sb += d;
-  }
-  dgamma[j] = sg;
-  dbeta[j] = sb;
+                              const float* __restrict__ dy, float* __restrict__ dx, float* __restrict__ tmp) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)B * Dh) return;
+  int j = (int)(i % Dh);
+  float d = dy[i];
+  dx[i] = d * (gamma[j] * rs);
+  tmp[i] = d * (x[i] * rs);
 }
 
 int score_launch_bn_fwd(int B, int Dh, const float* x, const float* gamma, const float* beta, float rs, float* y,
@@ -214,10 +208,14 @@ int score_launch_bn_fwd(int B, int Dh, const float* x, const float* gamma, const
   return 0;
 }
 int score_launch_bn_bwd(int B, int Dh, const float* x, const float* gamma, float rs, const float* dy, float* dx,
-                        float* dgamma, float* dbeta, hipStream_t s) {
-  hipLaunchKernelGGL(bn_bwd_kernel, dim3((Dh + 63) / 64), dim3(64), 0, s, B, Dh, x, gamma, rs, dy, dx, dgamma,
-                     dbeta);
+                        float* dgamma, float* dbeta, float* tmp, float* scratch, int64_t scratch_floats,
+                        hipStream_t s) {
+  int64_t n = (int64_t)B * Dh;
+  hipLaunchKernelGGL(bn_bwd_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, s, B, Dh, x, gamma, rs, dy, dx,
+                     tmp);
   SCORE_CHECK_LAUNCH();
+  SCORE_TRY(score_launch_colsum(tmp, B, Dh, Dh, dgamma, 0, scratch, scratch_floats, s));
+  SCORE_TRY(score_launch_colsum(dy, B, Dh, Dh, dbeta, 0, scratch, scratch_floats, s));
   return 0;
 }
 

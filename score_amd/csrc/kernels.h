@@ -29,7 +29,8 @@ int score_launch_target_bwd(float* grad_table, int D, int Fu, int Fi, int B, int
                             const int32_t* ti, const float* dquery, int ldq, const float* dhead, int ldh,
                             int off_ti, int off_tu, const float* query, const float* W1, const float* W2,
                             const float* dzsum1, const float* dzsum2, float* S /*[2][B]*/,
-                            float* dW1, float* dB1, float* dW2, float* dB2, float* dtgt_out, hipStream_t s);
+                            float* dW1, float* dB1, float* dW2, float* dB2, float* dtgt_out, float* scratch,
+                            int64_t scratch_floats, hipStream_t s);
 // gemm.hip
 int score_launch_colsum(const float* X, int M, int N, int ld, float* out, int accumulate,
                         float* scratch, int64_t scratch_floats, hipStream_t s);
@@ -52,7 +53,8 @@ int score_launch_attn_inp_bwd(int B, int T, int H, int NI, const float* dinp, co
 int score_launch_bn_fwd(int B, int Dh, const float* x, const float* gamma, const float* beta, float rs, float* y,
                         hipStream_t s);
 int score_launch_bn_bwd(int B, int Dh, const float* x, const float* gamma, float rs, const float* dy, float* dx,
-                        float* dgamma, float* dbeta, hipStream_t s);
+                        float* dgamma, float* dbeta, float* tmp, float* scratch, int64_t scratch_floats,
+                        hipStream_t s);
 int score_launch_head_out(int B, int NF, const float* f2, const float* w3, const float* b3, const int32_t* label,
                           float* logit, float* y, float* lossb, float* dlogit, float* loss, const float* wreg,
                           int64_t n_reg, float lambda, float* part, hipStream_t s);
@@ -79,3 +81,26 @@ int score_launch_plan(const PlanFillArgs& a, int key_bits, uint32_t* keys_in, ui
                       uint32_t* vals_out, void* temp, size_t temp_bytes, hipStream_t s);
 int score_launch_pull(PullArgs& a, const uint32_t* keys, const uint32_t* vals, int64_t n, float* out,
                       float* partials, int64_t partial_floats, hipStream_t s);
+
+// gru.hip: both GRUs of the model in one launch
+struct GruSide {
+  const float* xproj;            // [B*T, 3H]  hoisted x.Wx + b
+  const float* Wg; int ldwg;     // h-rows of gates/kernel     [H, 2H]
+  const float* Wc; int ldwc;     // h-rows of candidate/kernel [H, H]
+  float* out; int ldo;           // [B*T, H] h_t (0 past the length)
+  float* gates;                  // [B*T, 3H] saved (r, u, c)
+  float* final_state;            // [B, H] or null
+  // backward
+  const float* dout; int lddo;   // dL/d out
+  const float* dfinal;           // dL/d final state or null
+  float* dxproj;                 // [B*T, 3H] pre-activation grads
+  float* rh;                     // [B*T, H] r * h_{t-1}
+  float* hprev;                  // [B*T, H] h_{t-1}  (+ 3*H*H scratch floats at its end for the fallback)
+};
+struct GruArgs {
+  GruSide s[2];
+  const int32_t* length;
+  int B, T, H;
+};
+int score_gru_fwd_multi(GruArgs& a, int nsides, hipStream_t s);
+int score_gru_bwd_multi(GruArgs& a, int nsides, hipStream_t s);

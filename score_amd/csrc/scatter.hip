@@ -120,11 +120,25 @@ __global__ __launch_bounds__(256) void pull_kernel(const PullArgs a, const uint3
   }
 }
 
-// a run that starts in window w and continues to the right: total = plast[w] + pfirst[w+1] + ...
+// first index in [lo, n) whose key differs from `key` (keys ascending, keys[lo-1] == key)
+__device__ __forceinline__ int64_t run_end(const uint32_t* __restrict__ keys, int64_t lo, int64_t n, uint32_t key) {
+  int64_t hi = n;
+  while (lo < hi) {
+    int64_t mid = (lo + hi) >> 1;
+    if (keys[mid] == key) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+// A run that starts in window w and continues to the right: total = plast[w] + pfirst[w+1] + ...
+// (window order, so the sum is reproducible).  Chains longer than LONG_CHAIN windows (the hot
+// categorical rows: thousands of windows) are queued for pull_long_kernel.
+#define LONG_CHAIN 16
 __global__ __launch_bounds__(256) void pull_fixup_kernel(const PullArgs a, const uint32_t* __restrict__ keys,
                                                          int64_t n, int WS, float* __restrict__ out,
                                                          const float* __restrict__ pfirst,
-                                                         const float* __restrict__ plast) {
+                                                         const float* __restrict__ plast,
+                                                         int* __restrict__ long_count, int2* __restrict__ long_list) {
   const int LPR = a.LPRp;
   const int gpb = blockDim.x / LPR;
   const int64_t w = (int64_t)blockIdx.x * gpb + threadIdx.x / LPR;
@@ -135,9 +149,54 @@ __global__ __launch_bounds__(256) void pull_fixup_kernel(const PullArgs a, const
   const uint32_t lastkey = keys[end - 1];
   if (lastkey == 0 || end >= n || keys[end] != lastkey) return;          // not open to the right
   if (keys[start] == lastkey && start > 0 && keys[start - 1] == lastkey) return;  // did not start here
+  const int64_t re = run_end(keys, end, n, lastkey);
+  const int L = (int)((re - 1) / WS - w);                                 // windows w+1 .. w+L continue the run
+  if (L > LONG_CHAIN) {
+    if (ch4 == 0) {
+      int slot = atomicAdd(long_count, 1);
+      long_list[slot] = make_int2((int)w, L);
+    }
+    return;
+  }
   float4 tot = ld4(plast + w * a.D + ch4);
-  for (int64_t j = w + 1; j * WS < n && keys[j * WS] == lastkey; ++j) tot = add4(tot, ld4(pfirst + j * a.D + ch4));
+  for (int j = 1; j <= L; ++j) tot = add4(tot, ld4(pfirst + (w + j) * a.D + ch4));
   st4(out + key_to_row(lastkey, a.Gsh, a.shift) * a.D + ch4, tot);
+}
+
+// one block per long chain: its groups sum contiguous sub-ranges of the chain, then the partial
+// sums are added in group order (fixed partition => reproducible)
+__global__ __launch_bounds__(256) void pull_long_kernel(const PullArgs a, const uint32_t* __restrict__ keys,
+                                                        int WS, float* __restrict__ out,
+                                                        const float* __restrict__ pfirst,
+                                                        const float* __restrict__ plast,
+                                                        const int* __restrict__ long_count,
+                                                        const int2* __restrict__ long_list) {
+  extern __shared__ float sh[];  // [groups][D]
+  const int LPR = a.LPRp;
+  const int ng = blockDim.x / LPR;
+  const int g = threadIdx.x / LPR;
+  const int ch4 = (threadIdx.x % LPR) * 4;
+  const bool lane_ok = ch4 < a.D;
+  const int count = *long_count;
+  for (int c = blockIdx.x; c < count; c += gridDim.x) {
+    const int2 e = long_list[c];
+    const int64_t w = e.x;
+    const int L = e.y;
+    const int chunk = (L + ng - 1) / ng;
+    const int j0 = 1 + g * chunk, j1 = min(L, (g + 1) * chunk);
+    float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lane_ok)
+      for (int j = j0; j <= j1; ++j) tot = add4(tot, ld4(pfirst + (w + j) * a.D + ch4));
+    if (lane_ok) st4(sh + g * a.D + ch4, tot);
+    __syncthreads();
+    if (g == 0 && lane_ok) {
+      float4 t = ld4(plast + w * a.D + ch4);
+      for (int q = 0; q < ng; ++q) t = add4(t, ld4(sh + q * a.D + ch4));
+      const uint32_t key = keys[(w + 1) * (int64_t)WS - 1];
+      st4(out + key_to_row(key, a.Gsh, a.shift) * a.D + ch4, t);
+    }
+    __syncthreads();
+  }
 }
 
 int score_launch_pull(PullArgs& a, const uint32_t* keys, const uint32_t* vals, int64_t n, float* out,
@@ -148,14 +207,23 @@ int score_launch_pull(PullArgs& a, const uint32_t* keys, const uint32_t* vals, i
   if (LPR > 64) return SCORE_E_SHAPE;
   a.LPRp = LPR;
   int64_t nw = cdiv64(n, WS);
-  if (2 * nw * a.D > partial_floats) return SCORE_E_WORKSPACE;
+  // partials: pfirst [nw][D] | plast [nw][D] | long-chain counter (4 floats) | long list [nw] int2
+  if (2 * nw * a.D + 4 + 2 * nw > partial_floats) return SCORE_E_WORKSPACE;
   float* pfirst = partials;
   float* plast = partials + nw * a.D;
+  int* long_count = reinterpret_cast<int*>(plast + nw * a.D);
+  int2* long_list = reinterpret_cast<int2*>(long_count + 4);
+  hipError_t e = hipMemsetAsync(long_count, 0, 16, s);
+  if (e != hipSuccess) return (int)e;
   int gpb = 256 / LPR;
   unsigned blocks = (unsigned)cdiv64(nw, gpb);
   hipLaunchKernelGGL(pull_kernel, dim3(blocks), dim3(256), 0, s, a, keys, vals, n, WS, out, pfirst, plast);
   SCORE_CHECK_LAUNCH();
-  hipLaunchKernelGGL(pull_fixup_kernel, dim3(blocks), dim3(256), 0, s, a, keys, n, WS, out, pfirst, plast);
+  hipLaunchKernelGGL(pull_fixup_kernel, dim3(blocks), dim3(256), 0, s, a, keys, n, WS, out, pfirst, plast,
+                     long_count, long_list);
+  SCORE_CHECK_LAUNCH();
+  hipLaunchKernelGGL(pull_long_kernel, dim3(1024), dim3(256), (size_t)gpb * a.D * sizeof(float), s, a, keys, WS,
+                     out, pfirst, plast, long_count, long_list);
   SCORE_CHECK_LAUNCH();
   return 0;
 }

@@ -141,9 +141,12 @@ def test_coattn_fwd_bwd(D, F, K, B, T):
     _lib.check(lib.score_coattn_fwd(P(dt), N, D, F, K, B, T, P(di1), P(di2), P(dtg), P(dW), P(db), P(out1), Dx + 4,
                                     P(out2), Dx, P(oinfo), 2 * K + 1, P(rs), 0, stream()), "coattn_fwd")
     torch.cuda.synchronize()
-    assert np.allclose(out1[:, :Dx].cpu().numpy(), o1.detach().numpy().reshape(B * T, Dx), rtol=1e-5, atol=2e-6)
-    assert np.allclose(out2.cpu().numpy(), o2.detach().numpy().reshape(B * T, Dx), rtol=1e-5, atol=2e-6)
-    assert np.allclose(oinfo[:, :2 * K].cpu().numpy(), info.detach().numpy().reshape(B * T, 2 * K), rtol=1e-5, atol=1e-5)
+    def relerr(got, want):       # max abs error relative to the largest reference magnitude
+        want = want.detach().numpy().reshape(got.shape)
+        return float(np.abs(got.cpu().numpy() - want).max() / max(np.abs(want).max(), 1e-30))
+    assert relerr(out1[:, :Dx], o1) < 1e-5
+    assert relerr(out2, o2) < 1e-5
+    assert relerr(oinfo[:, :2 * K], info) < 1e-5
     assert float(out1[:, Dx:].abs().max()) == 0 and float(oinfo[:, 2 * K:].abs().max()) == 0
 
     gt = torch.zeros((N, D), device="cuda")
@@ -188,7 +191,7 @@ def test_coattn_rca_sum_mode():
     assert np.allclose(o2.cpu().numpy(), w2, rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize("B,T,H", [(5, 3, 8), (70, 11, 32), (33, 6, 128), (9, 4, 20)])
+@pytest.mark.parametrize("B,T,H", [(5, 3, 8), (70, 11, 32), (33, 6, 128), (9, 4, 20), (17, 5, 16), (40, 7, 64)])
 def test_gru_fwd_bwd(B, T, H):
     # dynamic_rnn(GRUCell) recurrence (score.py:205-208) vs the oracle's _gru + autograd
     lib = _lib.load()
@@ -264,4 +267,4 @@ def test_adam_matches_tf_form():
         _lib.check(lib.score_adam(P(dp), P(dm), P(dv), P(dg), n, n_reg, lam, a, 0.9, 0.999, 1e-8, stream()), "adam")
         torch.cuda.synchronize()
         assert np.allclose(dp.cpu().numpy()[:n], params["p"], rtol=1e-6, atol=1e-7)
-        assert np.allclose(dm.cpu().numpy()[:n], opt.m["p"], rtol=1e-6, atol=1e-9)
+        assert np.allclose(dm.cpu().numpy()[:n], opt.m["p"], rtol=1e-6, atol=1e-7)   # fma contraction: <= 1 ulp of the operands
