@@ -89,6 +89,14 @@ typedef struct {
   int64_t loss;       /* [4]: loss, log_loss, l2, unused                          */
   int64_t gru_out;    /* [2][B*T][H]      user_side_rep_t, item_side_rep_t        */
   int64_t gru_final;  /* [2][B][H]        final states (RIA, score.py:244-247)    */
+  /* index plan (score_index_plan) */
+  int64_t n_occurrences;    /* R*B row uses in the batch (SURVEY 8d's R per sample)          */
+  int64_t plan_meta;        /* int32 [2+G]: [0] = U unique rows (incl. row 0), [1+o] = first
+                               unique position owned by shard o (o = 0..G)                   */
+  int64_t plan_unique_rows; /* int32 [U]: local row index (row / G) of every unique row,
+                               grouped by owner shard (row % G), ascending                   */
+  int64_t plan_remap[6];    /* int32 copies of user_1hop, item_2hop, user_2hop, item_1hop,
+                               target_user, target_item holding unique positions            */
 } score_workspace_t;
 
 int score_workspace_layout(const score_config_t* cfg, int32_t B, score_workspace_t* out);
@@ -167,11 +175,30 @@ typedef struct {
   const float* w;       /* flat dense parameters                                  */
   float* workspace;     /* score_workspace_layout(...).total_bytes                */
   int64_t workspace_bytes;
-  int32_t scatter_mode; /* embedding-gradient scatter: 0 = radix-sort occurrences by row +
-                           per-row pull (no float atomics, bitwise reproducible; default),
-                           1 = global_atomic_add_f32 into grad_table                    */
-  int32_t reserved;
+  int32_t scatter_mode; /* embedding-gradient scatter: 0 = sorted occurrences + per-row pull
+                           (no float atomics, bitwise reproducible; needs score_index_plan
+                           with 1 shard), 1 = global_atomic_add_f32 into grad_table,
+                           2 = pull into the unique-row order of a sharded plan (grad_table
+                           is the [U, D] gradient of the gathered mini-table)            */
+  int32_t global_batch; /* samples the loss mean runs over (data parallel); 0 = batch->B  */
 } score_state_t;
+
+/* Index plan of a batch (depends on the indices only; run it before score_backward, on
+ * any stream ordered before it).  Radix-sorts all R*B row uses by (owner shard, row).
+ * n_shards > 1 (table row-sharded, owner = row % n_shards) additionally de-duplicates
+ * them: unique rows grouped by owner -> what to request from each shard -- and writes the
+ * six index tensors remapped to unique positions, so the same kernels run on the gathered
+ * [U, D] mini-table.  Replaces nothing in the reference (it has no multi-device code);
+ * it is the index-routing step BASELINE.json's north_star asks for. */
+int score_index_plan(const score_config_t* cfg, const score_state_t* st, const score_batch_t* batch,
+                     int32_t n_shards, void* stream);
+
+/* out[rows[j], :] = sum over slots j with equal rows[j] of src[j, :] (slot order; rows never
+ * named keep their value).  The shard owner uses it to combine the row gradients received
+ * from every rank.  scratch: score_segment_sum_scratch_bytes(n, D). */
+int score_segment_sum_rows(const int32_t* rows, const float* src, int64_t n, int32_t D, int64_t n_out_rows,
+                           float* out, void* scratch, int64_t scratch_bytes, void* stream);
+int64_t score_segment_sum_scratch_bytes(int64_t n, int32_t D);
 
 /* Forward of SCORE / RIA / RCA / SCORE_USER / SCORE_ITEM (score.py:188-369) +
  * build_fc_net / build_logloss / build_l2norm (:68-94).  keep_prob 1.0 = eval

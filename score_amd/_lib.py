@@ -36,12 +36,13 @@ class Batch(C.Structure):
 class Workspace(C.Structure):
     _fields_ = [(n, C.c_int64) for n in
                 ("total_bytes", "xside", "atten_info", "rsave", "query", "head_inp", "att_score",
-                 "logit", "y_pred", "loss", "gru_out", "gru_final")]
+                 "logit", "y_pred", "loss", "gru_out", "gru_final", "n_occurrences", "plan_meta",
+                 "plan_unique_rows")] + [("plan_remap", C.c_int64 * 6)]
 
 
 class State(C.Structure):
     _fields_ = [("table", c_f), ("n_table_rows", C.c_int64), ("w", c_f), ("workspace", c_f),
-                ("workspace_bytes", C.c_int64), ("scatter_mode", C.c_int32), ("reserved", C.c_int32)]
+                ("workspace_bytes", C.c_int64), ("scatter_mode", C.c_int32), ("global_batch", C.c_int32)]
 
 
 _SIGS = {
@@ -63,6 +64,9 @@ _SIGS = {
                       c_f, C.c_int32, c_f, c_f, c_f, c_f, C.c_void_p],
     "score_adam": [c_f, c_f, c_f, c_f, C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,
                    C.c_float, C.c_void_p],
+    "score_index_plan": [C.POINTER(Config), C.POINTER(State), C.POINTER(Batch), C.c_int32, C.c_void_p],
+    "score_segment_sum_rows": [c_i, c_f, C.c_int64, C.c_int32, C.c_int64, c_f, C.c_void_p, C.c_int64, C.c_void_p],
+    "score_segment_sum_scratch_bytes": [C.c_int64, C.c_int32],
     "score_forward": [C.POINTER(Config), C.POINTER(State), C.POINTER(Batch), C.c_float, C.c_float, C.c_void_p,
                       C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p), C.c_void_p],
     "score_backward": [C.POINTER(Config), C.POINTER(State), C.POINTER(Batch), C.c_float, c_f, c_f,
@@ -89,7 +93,7 @@ def load():
     for name, args in _SIGS.items():
         fn = getattr(lib, name)      # AttributeError if a declared symbol is missing
         fn.argtypes = args
-        fn.restype = C.c_int
+        fn.restype = C.c_int64 if name.endswith("_bytes") else C.c_int
     _lib = lib
     return lib
 

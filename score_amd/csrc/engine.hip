@@ -126,6 +126,7 @@ struct WS {
   int64_t dxproj[2], rh[2], hprev[2], dxside[2], dzsum[2], S, scratch;
   int64_t pcoef[2], dzcoef[2], dtgt, keys_in, keys_out, vals_in, vals_out, sort_temp, partials;
   int64_t n_occ, sort_temp_bytes, partial_floats;
+  int64_t uid, unique_rows, meta, remap[6];
   int64_t scratch_floats, total;
 };
 
@@ -172,13 +173,22 @@ void build_ws(const Dims& d, int B, WS* w) {
   for (int c = 0; c < 2; ++c) { w->pcoef[c] = take(BT * d.K); w->dzcoef[c] = take(BT * d.K); }
   w->dtgt = take((int64_t)B * d.Dq);
   w->n_occ = (int64_t)B * (2 * (int64_t)d.T * d.K * (d.Fu + d.Fi) + d.Fu + d.Fi);
-  w->keys_in = take(w->n_occ); w->keys_out = take(w->n_occ);
-  w->vals_in = take(w->n_occ); w->vals_out = take(w->n_occ);
-  size_t tb = 0;
-  score_plan_temp_bytes(w->n_occ, 32, &tb);
+  const int64_t np = w->n_occ + 1;   // + sentinel occurrence of row 0
+  w->keys_in = take(np); w->keys_out = take(np);
+  w->vals_in = take(np); w->vals_out = take(np);
+  w->uid = take(np); w->unique_rows = take(np); w->meta = take(80);
+  {
+    const int64_t nn[6] = {BT * d.K * d.Fi, BT * d.K * d.Fi, BT * d.K * d.Fu, BT * d.K * d.Fu, (int64_t)B * d.Fu,
+                           (int64_t)B * d.Fi};
+    for (int g = 0; g < 6; ++g) w->remap[g] = take(nn[g]);
+  }
+  size_t tb = 0, tb2 = 0;
+  score_plan_temp_bytes(np, 32, &tb);
+  score_scan_temp_bytes(np, &tb2);
+  if (tb2 > tb) tb = tb2;
   w->sort_temp_bytes = (int64_t)tb;
   w->sort_temp = take((int64_t)(tb + 3) / 4 + 4);
-  w->partial_floats = 2 * cdiv64(w->n_occ, 64) * d.D + 8 + 2 * cdiv64(w->n_occ, 64);
+  w->partial_floats = 2 * cdiv64(np, 64) * d.D + 8 + 2 * cdiv64(np, 64);
   w->partials = take(w->partial_floats);
   w->total = cur;
 }
@@ -217,6 +227,61 @@ extern "C" int score_workspace_layout(const score_config_t* cfg, int32_t B, scor
   out->xside = w.xside[0]; out->atten_info = w.info; out->rsave = w.rsave[0]; out->query = w.query;
   out->head_inp = w.head_inp; out->att_score = w.att_score; out->logit = w.logit; out->y_pred = w.y_pred;
   out->loss = w.loss; out->gru_out = w.gru_out[0]; out->gru_final = w.gru_final[0];
+  out->plan_meta = w.meta; out->plan_unique_rows = w.unique_rows; out->n_occurrences = w.n_occ;
+  for (int g = 0; g < 6; ++g) out->plan_remap[g] = w.remap[g];
+  return 0;
+}
+
+extern "C" int score_index_plan(const score_config_t* cfg, const score_state_t* st, const score_batch_t* bt,
+                                int32_t n_shards, void* stream) {
+  Dims d;
+  SCORE_TRY(make_dims(cfg, &d));
+  if (!st || !bt || !st->workspace || bt->B <= 0 || n_shards < 1 || n_shards > 64) return SCORE_E_BADARG;
+  const int B = bt->B, BT = B * d.T;
+  WS w;
+  build_ws(d, B, &w);
+  if (w.total * 4 > st->workspace_bytes) return SCORE_E_WORKSPACE;
+  if (BT > (1 << 21) || d.Fu > 8 || d.Fi > 8) return SCORE_E_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  float* ws = st->workspace;
+  PlanFillArgs pf;
+  memset(&pf, 0, sizeof(pf));
+  const int32_t* idx[6] = {bt->user_1hop, bt->item_2hop, bt->user_2hop, bt->item_1hop, bt->target_user,
+                           bt->target_item};
+  const int Fs[6] = {d.Fi, d.Fi, d.Fu, d.Fu, d.Fu, d.Fi};
+  int64_t off = 0;
+  for (int g = 0; g < 6; ++g) {
+    if (!idx[g]) return SCORE_E_BADARG;
+    pf.idx[g] = idx[g]; pf.F[g] = Fs[g]; pf.off[g] = off;
+    off += (g < 4 ? (int64_t)BT * d.K : (int64_t)B) * Fs[g];
+  }
+  pf.off[6] = off; pf.K = d.K; pf.G = n_shards;
+  // key = row (1 shard) or (owner = row % G) << shift | (row / G)
+  const int64_t rows_local = cdiv64(d.N, n_shards);
+  int shift = 1;
+  while (shift < 31 && ((int64_t)1 << shift) < rows_local) ++shift;
+  int obits = 0;
+  while ((1 << obits) < n_shards) ++obits;
+  if (shift + obits > 32) return SCORE_E_SHAPE;
+  pf.shift = n_shards > 1 ? shift : 0;
+  const int key_bits = n_shards > 1 ? shift + obits : shift;
+  uint32_t* keys_in = reinterpret_cast<uint32_t*>(ws + w.keys_in);
+  uint32_t* vals_in = reinterpret_cast<uint32_t*>(ws + w.vals_in);
+  uint32_t* keys_out = reinterpret_cast<uint32_t*>(ws + w.keys_out);
+  uint32_t* vals_out = reinterpret_cast<uint32_t*>(ws + w.vals_out);
+  G(score_launch_plan(pf, key_bits, keys_in, vals_in, keys_out, vals_out, ws + w.sort_temp,
+                      (size_t)w.sort_temp_bytes, s));
+  if (n_shards > 1) {
+    PlanRemapArgs ra;
+    memset(&ra, 0, sizeof(ra));
+    for (int g = 0; g < 6; ++g) { ra.out[g] = reinterpret_cast<int32_t*>(ws + w.remap[g]); ra.F[g] = Fs[g]; }
+    ra.K = d.K;
+    // keys_in / vals_in are dead after the sort: reuse them for the head flags and the unique keys
+    G(score_launch_plan_unique(ra, keys_out, vals_out, w.n_occ + 1, keys_in, reinterpret_cast<uint32_t*>(ws + w.uid),
+                               vals_in, reinterpret_cast<int32_t*>(ws + w.unique_rows),
+                               reinterpret_cast<int32_t*>(ws + w.meta), n_shards, shift, ws + w.sort_temp,
+                               (size_t)w.sort_temp_bytes, s));
+  }
   return 0;
 }
 
@@ -315,7 +380,8 @@ extern "C" int score_forward(const score_config_t* cfg, const score_state_t* st,
                w.scratch_floats, s));
   // fc3, sigmoid, log-loss, l2 (:74-94)
   G(score_launch_head_out(B, FC2, ws + w.f2, W + P.fc_w[2], W + P.fc_b[2], bt->label, ws + w.logit, ws + w.y_pred,
-                          ws + w.lossb, ws + w.dlogit, ws + w.loss, W, P.n_reg, reg_lambda, ws + w.part, s));
+                          ws + w.lossb, ws + w.dlogit, ws + w.loss, W, P.n_reg, reg_lambda, ws + w.part,
+                          st->global_batch > 0 ? st->global_batch : B, s));
   EV(4);
   return 0;
 }
@@ -454,26 +520,6 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
   const bool atomic = st->scatter_mode == 1;
   uint32_t* keys_out = reinterpret_cast<uint32_t*>(ws + w.keys_out);
   uint32_t* vals_out = reinterpret_cast<uint32_t*>(ws + w.vals_out);
-  if (!atomic) {
-    // occurrence sort by row id: depends on the indices only
-    PlanFillArgs pf;
-    memset(&pf, 0, sizeof(pf));
-    const int32_t* idx[6] = {bt->user_1hop, bt->item_2hop, bt->user_2hop, bt->item_1hop, bt->target_user,
-                             bt->target_item};
-    const int Fs[6] = {d.Fi, d.Fi, d.Fu, d.Fu, d.Fu, d.Fi};
-    int64_t off = 0;
-    for (int g = 0; g < 6; ++g) {
-      pf.idx[g] = idx[g]; pf.F[g] = Fs[g]; pf.off[g] = off;
-      off += (g < 4 ? (int64_t)BT * d.K : (int64_t)B) * Fs[g];
-    }
-    pf.off[6] = off; pf.K = d.K; pf.G = 1; pf.shift = 0;
-    if (BT > (1 << 21) || d.Fu > 8 || d.Fi > 8) return SCORE_E_SHAPE;
-    int key_bits = 1;
-    while (key_bits < 32 && ((int64_t)1 << key_bits) < st->n_table_rows) ++key_bits;
-    G(score_launch_plan(pf, key_bits, reinterpret_cast<uint32_t*>(ws + w.keys_in),
-                        reinterpret_cast<uint32_t*>(ws + w.vals_in), keys_out, vals_out, ws + w.sort_temp,
-                        (size_t)w.sort_temp_bytes, s));
-  }
   {
     CoattnArgs ca;
     memset(&ca, 0, sizeof(ca));
@@ -502,7 +548,8 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
   if (!atomic) {
     PullArgs pa;
     memset(&pa, 0, sizeof(pa));
-    pa.D = d.D; pa.K = d.K; pa.Gsh = 1; pa.shift = 0;
+    pa.D = d.D; pa.K = d.K;
+    pa.uid = st->scatter_mode == 2 ? reinterpret_cast<const uint32_t*>(ws + w.uid) : nullptr;
     const float invK = 1.0f / (float)d.K;
     const float* Gm[6] = {ws + w.dxside[0], ws + w.dxside[1], ws + w.dxside[0], ws + w.dxside[1], ws + w.dtgt,
                           ws + w.dtgt};
@@ -516,7 +563,7 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
       pa.Wv[0] = W + P.ca_w[0] + d.Di; pa.Wv[1] = W + P.ca_w[0] + 2 * d.Di;
       pa.Wv[2] = W + P.ca_w[1] + d.Du; pa.Wv[3] = W + P.ca_w[1] + 2 * d.Du;
     }
-    G(score_launch_pull(pa, keys_out, vals_out, w.n_occ, grad_table, ws + w.partials, w.partial_floats, s));
+    G(score_launch_pull(pa, keys_out, vals_out, w.n_occ + 1, grad_table, ws + w.partials, w.partial_floats, s));
   }
   EV(4);
   return 0;

@@ -216,9 +216,10 @@ int score_launch_colsum(const float* X, int M, int N, int ld, float* out, int ac
                         int64_t scratch_floats, hipStream_t s) {
   int cols = 1;
   while (cols < N && cols < 64) cols <<= 1;
+  // <= 32 partial rows so the fixed-order second stage stays a short dependent chain
   int rpb = 128;
   int nparts = (M + rpb - 1) / rpb;
-  if (nparts > 256) { nparts = 256; rpb = (M + nparts - 1) / nparts; nparts = (M + rpb - 1) / rpb; }
+  if (nparts > 32) { nparts = 32; rpb = (M + nparts - 1) / nparts; nparts = (M + rpb - 1) / rpb; }
   if ((int64_t)nparts * N > scratch_floats) return SCORE_E_WORKSPACE;
   hipLaunchKernelGGL(colsum_stage1, dim3((N + cols - 1) / cols, nparts), dim3(256), 0, s, X, M, N, ld, cols, rpb,
                      scratch);

@@ -224,7 +224,7 @@ int score_launch_bn_bwd(int B, int Dh, const float* x, const float* gamma, float
 __global__ void head_out_kernel(int B, int NF, const float* __restrict__ f2, const float* __restrict__ w3,
                                 const float* __restrict__ b3, const int32_t* __restrict__ label,
                                 float* __restrict__ logit, float* __restrict__ y, float* __restrict__ lossb,
-                                float* __restrict__ dlogit) {
+                                float* __restrict__ dlogit, int Bglobal) {
   int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   float acc = 0.f;
@@ -236,7 +236,7 @@ __global__ void head_out_kernel(int B, int NF, const float* __restrict__ f2, con
   logit[b] = z;
   y[b] = p;
   lossb[b] = -lab * logf(p + eps) - (1.0f - lab) * logf(1.0f - p + eps);
-  float dp = (-lab / (p + eps) + (1.0f - lab) / (1.0f - p + eps)) / (float)B;
+  float dp = (-lab / (p + eps) + (1.0f - lab) / (1.0f - p + eps)) / (float)Bglobal;
   dlogit[b] = dp * p * (1.0f - p);
 }
 
@@ -276,11 +276,13 @@ __global__ void loss_final_kernel(const float* __restrict__ part, int nparts, fl
 
 int score_launch_head_out(int B, int NF, const float* f2, const float* w3, const float* b3, const int32_t* label,
                           float* logit, float* y, float* lossb, float* dlogit, float* loss, const float* wreg,
-                          int64_t n_reg, float lambda, float* part /* >= 64 floats */, hipStream_t s) {
+                          int64_t n_reg, float lambda, float* part /* >= 64 floats */, int Bglobal,
+                          hipStream_t s) {
+  // Bglobal = samples the mean is taken over (the local batch, or the global batch when data-parallel)
   hipLaunchKernelGGL(head_out_kernel, dim3((B + 63) / 64), dim3(64), 0, s, B, NF, f2, w3, b3, label, logit, y,
-                     lossb, dlogit);
+                     lossb, dlogit, Bglobal);
   SCORE_CHECK_LAUNCH();
-  hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, s, lossb, (int64_t)B, 1.0f / (float)B, loss + 1);
+  hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, s, lossb, (int64_t)B, 1.0f / (float)Bglobal, loss + 1);
   SCORE_CHECK_LAUNCH();
   hipLaunchKernelGGL(sumsq_stage1, dim3(64), dim3(256), 0, s, wreg, n_reg, part);
   SCORE_CHECK_LAUNCH();

@@ -57,7 +57,7 @@ int score_launch_bn_bwd(int B, int Dh, const float* x, const float* gamma, float
                         hipStream_t s);
 int score_launch_head_out(int B, int NF, const float* f2, const float* w3, const float* b3, const int32_t* label,
                           float* logit, float* y, float* lossb, float* dlogit, float* loss, const float* wreg,
-                          int64_t n_reg, float lambda, float* part, hipStream_t s);
+                          int64_t n_reg, float lambda, float* part, int Bglobal, hipStream_t s);
 int score_launch_outer_relu_bwd(int B, int NF, const float* dlogit, const float* w, const float* f, float keep,
                                 float* dz, hipStream_t s);
 int score_launch_copy2d(int64_t rows, int cols, const float* src, int lds_, float* dst, int ldd, hipStream_t s);
@@ -74,8 +74,14 @@ struct PullArgs {
   const float* cA[6]; const float* cB[6];         // per-(unit,k) scalars (null: constA / none)
   const float* Wv[6];                             // co-attention weight slice multiplied by cB
   float constA[6];
-  int D, K, Gsh, shift, LPRp;
+  const uint32_t* uid;     // null: a run's destination is its row id; else the run's unique position
+  int D, K, LPRp;
 };
+struct PlanRemapArgs { int32_t* out[6]; int F[6]; int K; };
+int score_launch_plan_unique(const PlanRemapArgs& ra, const uint32_t* keys, const uint32_t* vals, int64_t n,
+                             uint32_t* flags_scratch, uint32_t* uid, uint32_t* unique_keys, int32_t* unique_rows,
+                             int32_t* meta, int G, int shift, void* temp, size_t temp_bytes, hipStream_t s);
+int score_scan_temp_bytes(int64_t n, size_t* bytes);
 int score_plan_temp_bytes(int64_t n, int end_bit, size_t* bytes);
 int score_launch_plan(const PlanFillArgs& a, int key_bits, uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys_out,
                       uint32_t* vals_out, void* temp, size_t temp_bytes, hipStream_t s);

@@ -14,6 +14,7 @@
 #include <cstring>
 #include <cstdlib>
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 #include "common.h"
 #include "kernels.h"
 
@@ -22,7 +23,12 @@
 
 __global__ void plan_fill_kernel(PlanFillArgs a, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= a.off[6]) return;
+  if (i > a.off[6]) return;
+  if (i == a.off[6]) {  // sentinel occurrence of the dummy row: unique position 0 is always row 0
+    keys[i] = 0;
+    vals[i] = DESC(7, 0, 0, 0);
+    return;
+  }
   int seg = 0;
 #pragma unroll
   for (int s = 1; s < 6; ++s) seg += (i >= a.off[s]) ? 1 : 0;
@@ -56,7 +62,7 @@ int score_plan_temp_bytes(int64_t n, int end_bit, size_t* bytes) {
 // keys_out/vals_out <- occurrences of the batch sorted by (owner, row)
 int score_launch_plan(const PlanFillArgs& a, int key_bits, uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys_out,
                       uint32_t* vals_out, void* temp, size_t temp_bytes, hipStream_t s) {
-  int64_t n = a.off[6];
+  int64_t n = a.off[6] + 1;   // + sentinel
   hipLaunchKernelGGL(plan_fill_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, s, a, keys_in, vals_in);
   SCORE_CHECK_LAUNCH();
   size_t need = 0;
@@ -67,9 +73,103 @@ int score_launch_plan(const PlanFillArgs& a, int key_bits, uint32_t* keys_in, ui
   return e == hipSuccess ? 0 : (int)e;
 }
 
+// ------------------------------------------------------------------ unique rows / owner offsets / remap
+__global__ void plan_flags_kernel(const uint32_t* __restrict__ keys, int64_t n, uint32_t* __restrict__ flags) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  flags[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
+}
+// uid[i] = (#run heads in [0, i]) - 1 ; unique_keys[uid] = key of the run ; meta[0] = U
+__global__ void plan_unique_kernel(const uint32_t* __restrict__ keys, int64_t n, uint32_t* __restrict__ uid,
+                                   uint32_t* __restrict__ unique_keys, int32_t* __restrict__ meta) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t u = uid[i] - 1;   // inclusive scan of the head flags
+  uid[i] = u;
+  if (i == 0 || keys[i] != keys[i - 1]) unique_keys[u] = keys[i];
+  if (i == n - 1) meta[0] = (int32_t)(u + 1);
+}
+// meta[1 + o] = first unique position whose owner >= o  (o = 0..G) ; unique_rows[u] = local row index
+__global__ void plan_offsets_kernel(uint32_t* __restrict__ unique_keys, int32_t* __restrict__ meta, int G, int shift) {
+  const int U = meta[0];
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t <= G) {
+    uint32_t bound = (t == G) ? 0xFFFFFFFFu : ((uint32_t)t << shift);
+    int lo = 0, hi = U;
+    if (t == G) lo = U;
+    while (lo < hi) {
+      int mid = (lo + hi) >> 1;
+      if (unique_keys[mid] < bound) lo = mid + 1; else hi = mid;
+    }
+    meta[1 + t] = lo;
+  }
+}
+__global__ void plan_localrow_kernel(const uint32_t* __restrict__ unique_keys, const int32_t* __restrict__ meta,
+                                     int shift, int32_t* __restrict__ unique_rows) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= meta[0]) return;
+  unique_rows[i] = (int32_t)(unique_keys[i] & ((1u << shift) - 1u));
+}
+// remapped index tensors: every occurrence -> position of its row in the unique list
+__global__ void plan_remap_kernel(PlanRemapArgs a, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ uid,
+                                  int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t desc = vals[i];
+  const int seg = desc >> 29;
+  if (seg > 5) return;
+  const int f = (desc >> 26) & 7, k = (desc >> 21) & 31;
+  const int64_t bt = desc & 0x1FFFFF;
+  const int64_t local = seg < 4 ? (bt * a.K + k) * a.F[seg] + f : bt * a.F[seg] + f;
+  a.out[seg][local] = (int32_t)uid[i];
+}
+
+int score_launch_plan_unique(const PlanRemapArgs& ra, const uint32_t* keys, const uint32_t* vals, int64_t n,
+                             uint32_t* flags_scratch, uint32_t* uid, uint32_t* unique_keys, int32_t* unique_rows,
+                             int32_t* meta, int G, int shift, void* temp, size_t temp_bytes, hipStream_t s) {
+  unsigned blocks = (unsigned)cdiv64(n, 256);
+  hipLaunchKernelGGL(plan_flags_kernel, dim3(blocks), dim3(256), 0, s, keys, n, flags_scratch);
+  SCORE_CHECK_LAUNCH();
+  size_t need = 0;
+  hipError_t e = rocprim::inclusive_scan(nullptr, need, flags_scratch, uid, (size_t)n, rocprim::plus<uint32_t>(), s);
+  if (e != hipSuccess) return (int)e;
+  if (need > temp_bytes) return SCORE_E_WORKSPACE;
+  e = rocprim::inclusive_scan(temp, need, flags_scratch, uid, (size_t)n, rocprim::plus<uint32_t>(), s);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(plan_unique_kernel, dim3(blocks), dim3(256), 0, s, keys, n, uid, unique_keys, meta);
+  SCORE_CHECK_LAUNCH();
+  hipLaunchKernelGGL(plan_offsets_kernel, dim3(1), dim3(128), 0, s, unique_keys, meta, G, shift);
+  SCORE_CHECK_LAUNCH();
+  hipLaunchKernelGGL(plan_localrow_kernel, dim3(blocks), dim3(256), 0, s, unique_keys, meta, shift, unique_rows);
+  SCORE_CHECK_LAUNCH();
+  hipLaunchKernelGGL(plan_remap_kernel, dim3(blocks), dim3(256), 0, s, ra, vals, uid, n);
+  SCORE_CHECK_LAUNCH();
+  return 0;
+}
+
+int score_scan_temp_bytes(int64_t n, size_t* bytes) {
+  uint32_t* nul = nullptr;
+  hipError_t e = rocprim::inclusive_scan(nullptr, *bytes, nul, nul, (size_t)n, rocprim::plus<uint32_t>(),
+                                         (hipStream_t)0);
+  return e == hipSuccess ? 0 : (int)e;
+}
+
+// ------------------------------------------------------------------ sum rows by destination (owner side)
+// out[rows[j]] = sum_j src[j]   over equal rows, in slot order (reproducible).  Used by the shard owner to
+// combine the row gradients every rank sent it.
+__global__ void rowsum_fill_kernel(const int32_t* __restrict__ rows, int64_t n, uint32_t* __restrict__ keys,
+                                   uint32_t* __restrict__ vals) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  keys[i] = (uint32_t)rows[i];
+  vals[i] = (6u << 29) | (uint32_t)i;
+}
+
 // ------------------------------------------------------------------ pull
 __device__ __forceinline__ float4 pull_contrib(const PullArgs& a, uint32_t desc, int ch4) {
   const int seg = desc >> 29, f = (desc >> 26) & 7, k = (desc >> 21) & 31;
+  if (seg == 6) return ld4(a.G[0] + (int64_t)(desc & 0x1FFFFFFF) * a.D + ch4);   // owner-side row sum
+  if (seg == 7) return make_float4(0.f, 0.f, 0.f, 0.f);                            // sentinel
   const int64_t bt = desc & 0x1FFFFF;
   const int col = f * a.D + ch4;
   float4 g = ld4(a.G[seg] + bt * a.ldg[seg] + a.gcol[seg] + col);
@@ -79,9 +179,9 @@ __device__ __forceinline__ float4 pull_contrib(const PullArgs& a, uint32_t desc,
   return r;
 }
 
-__device__ __forceinline__ int64_t key_to_row(uint32_t key, int G, int shift) {
-  if (G <= 1) return key;
-  return (int64_t)(key & ((1u << shift) - 1)) * G + (key >> shift);
+// destination row of a run: its unique position (sharded: grads of the mini-table) or the row id itself
+__device__ __forceinline__ int64_t out_row(const PullArgs& a, uint32_t key, int64_t idx_in_run) {
+  return a.uid ? (int64_t)a.uid[idx_in_run] : (int64_t)key;
 }
 
 __global__ __launch_bounds__(256) void pull_kernel(const PullArgs a, const uint32_t* __restrict__ keys,
@@ -104,7 +204,7 @@ __global__ __launch_bounds__(256) void pull_kernel(const PullArgs a, const uint3
     if (key != cur) {
       if (cur != 0) {
         if (is_first && first_open) st4(pfirst + w * a.D + ch4, acc);
-        else st4(out + key_to_row(cur, a.Gsh, a.shift) * a.D + ch4, acc);
+        else st4(out + out_row(a, cur, i - 1) * a.D + ch4, acc);
       }
       acc = make_float4(0.f, 0.f, 0.f, 0.f);
       cur = key;
@@ -116,7 +216,7 @@ __global__ __launch_bounds__(256) void pull_kernel(const PullArgs a, const uint3
     const bool open_right = end < n && keys[end] == cur;
     if (is_first && first_open) st4(pfirst + w * a.D + ch4, acc);
     else if (open_right) st4(plast + w * a.D + ch4, acc);
-    else st4(out + key_to_row(cur, a.Gsh, a.shift) * a.D + ch4, acc);
+    else st4(out + out_row(a, cur, end - 1) * a.D + ch4, acc);
   }
 }
 
@@ -160,7 +260,7 @@ __global__ __launch_bounds__(256) void pull_fixup_kernel(const PullArgs a, const
   }
   float4 tot = ld4(plast + w * a.D + ch4);
   for (int j = 1; j <= L; ++j) tot = add4(tot, ld4(pfirst + (w + j) * a.D + ch4));
-  st4(out + key_to_row(lastkey, a.Gsh, a.shift) * a.D + ch4, tot);
+  st4(out + out_row(a, lastkey, end - 1) * a.D + ch4, tot);
 }
 
 // one block per long chain: its groups sum contiguous sub-ranges of the chain, then the partial
@@ -193,7 +293,7 @@ __global__ __launch_bounds__(256) void pull_long_kernel(const PullArgs a, const 
       float4 t = ld4(plast + w * a.D + ch4);
       for (int q = 0; q < ng; ++q) t = add4(t, ld4(sh + q * a.D + ch4));
       const uint32_t key = keys[(w + 1) * (int64_t)WS - 1];
-      st4(out + key_to_row(key, a.Gsh, a.shift) * a.D + ch4, t);
+      st4(out + out_row(a, key, (w + 1) * (int64_t)WS - 1) * a.D + ch4, t);
     }
     __syncthreads();
   }
@@ -226,4 +326,46 @@ int score_launch_pull(PullArgs& a, const uint32_t* keys, const uint32_t* vals, i
                      out, pfirst, plast, long_count, long_list);
   SCORE_CHECK_LAUNCH();
   return 0;
+}
+
+int score_rowsum_temp_bytes(int64_t n, size_t* bytes) { return score_plan_temp_bytes(n, 32, bytes); }
+
+extern "C" int score_segment_sum_rows(const int32_t* rows, const float* src, int64_t n, int32_t D, int64_t n_out_rows,
+                                      float* out, void* scratch, int64_t scratch_bytes, void* stream) {
+  if (!rows || !src || !out || !scratch || n < 0 || D <= 0 || (D & 3) || n_out_rows <= 0) return SCORE_E_BADARG;
+  if (n == 0) return 0;
+  if (n >= (1 << 29)) return SCORE_E_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  size_t sort_bytes = 0;
+  SCORE_TRY(score_plan_temp_bytes(n, 32, &sort_bytes));
+  const int64_t nw = cdiv64(n, 64);
+  const int64_t partial_floats = 2 * nw * D + 8 + 2 * nw;
+  // scratch: keys_in | keys_out | vals_in | vals_out | partials | sort temp
+  const int64_t need = 4 * align_up64(n, 4) * 4 + align_up64(partial_floats, 4) * 4 + (int64_t)sort_bytes;
+  if (need > scratch_bytes) return SCORE_E_WORKSPACE;
+  uint32_t* keys_in = static_cast<uint32_t*>(scratch);
+  uint32_t* keys_out = keys_in + align_up64(n, 4);
+  uint32_t* vals_in = keys_out + align_up64(n, 4);
+  uint32_t* vals_out = vals_in + align_up64(n, 4);
+  float* partials = reinterpret_cast<float*>(vals_out + align_up64(n, 4));
+  void* temp = partials + align_up64(partial_floats, 4);
+  hipLaunchKernelGGL(rowsum_fill_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, s, rows, n, keys_in, vals_in);
+  SCORE_CHECK_LAUNCH();
+  int key_bits = 1;
+  while (key_bits < 32 && ((int64_t)1 << key_bits) < n_out_rows) ++key_bits;
+  hipError_t e = rocprim::radix_sort_pairs(temp, sort_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u,
+                                           (unsigned)key_bits, s);
+  if (e != hipSuccess) return (int)e;
+  PullArgs pa;
+  memset(&pa, 0, sizeof(pa));
+  pa.D = D; pa.K = 1; pa.G[0] = src;
+  return score_launch_pull(pa, keys_out, vals_out, n, out, partials, partial_floats, s);
+}
+
+extern "C" int64_t score_segment_sum_scratch_bytes(int64_t n, int32_t D) {
+  size_t sort_bytes = 0;
+  if (score_plan_temp_bytes(n > 0 ? n : 1, 32, &sort_bytes) != 0) return -1;
+  const int64_t nw = cdiv64(n, 64);
+  const int64_t partial_floats = 2 * nw * D + 8 + 2 * nw;
+  return 4 * align_up64(n, 4) * 4 + align_up64(partial_floats, 4) * 4 + (int64_t)sort_bytes + 64;
 }

@@ -1,0 +1,292 @@
+"""Data-parallel SCoRe with the embedding table row-sharded across the GPUs of a node.
+
+The reference is single-process, single-device (no NCCL/MPI anywhere), so
+this layer has no counterpart to mirror; it implements what BASELINE.json's north_star
+asks for: rows of emb_mtx live on shard ``row % G`` (range sharding would put every hot
+categorical row on the last GPU -- id layout of feateng_tmall.py:72-101), each rank trains
+on its own batch, and one training step exchanges
+
+  1. int32 row requests       all_to_all_v   (unique rows of the batch, grouped by owner)
+  2. fp32 rows                all_to_all_v   (owners gather from their shard)
+  3. fp32 row gradients       all_to_all_v   (back to the owners, which sum them per row)
+  4. dense-variable gradients all_reduce     (~0.5-11 MB)
+
+over RCCL (``backend="nccl"`` on ROCm): all-to-all uses every xGMI link of a GPU at once.
+Dense variables are replicated; Adam on the shard and on the replicas needs no further
+communication.  The loss is the mean over the GLOBAL batch (G * B samples), so G ranks
+with batch B reproduce one device with batch G*B (tests/test_dist_*.py).
+
+Compute goes through a backend object: ``HipBackend`` (libscore_hip.so, the product path).
+Tests inject a CPU backend to exercise this file's routing with gloo; nothing here falls
+back to it on its own.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .model import SCOREBASE, DeviceBatch, _ptr, ADAM_B1, ADAM_B2, ADAM_EPS
+
+
+class TorchDistComm(object):
+    """torch.distributed collectives (nccl == RCCL on ROCm; gloo for the CPU tests)."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self._gloo = dist.get_backend(group) == "gloo"
+
+    def exchange_counts(self, send_counts, device):
+        t = torch.tensor(send_counts, dtype=torch.int64, device=device)
+        out = torch.empty_like(t)
+        self.all_to_all(out, t, [1] * self.world, [1] * self.world)
+        return [int(x) for x in out.cpu().tolist()]
+
+    def all_to_all(self, out, inp, out_splits, in_splits):
+        if not self._gloo:
+            self.dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)
+            return
+        # gloo has no all_to_all_v for every dtype/shape: pairwise isend/irecv
+        outs = list(out.split(out_splits, 0))
+        ins = list(inp.split(in_splits, 0))
+        outs[self.rank].copy_(ins[self.rank])
+        reqs = []
+        for p in range(self.world):
+            if p == self.rank:
+                continue
+            if in_splits[p] > 0:
+                reqs.append(self.dist.isend(ins[p].contiguous(), p, group=self.group))
+        for p in range(self.world):
+            if p == self.rank or out_splits[p] == 0:
+                continue
+            buf = torch.empty_like(outs[p])
+            self.dist.recv(buf, p, group=self.group)
+            outs[p].copy_(buf)
+        for r in reqs:
+            r.wait()
+
+    def all_reduce_sum(self, t):
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+
+
+class _ShardModel(SCOREBASE):
+    """SCOREBASE whose `table` is one row shard: local row i holds global row i*G + rank."""
+    model_type = "SCORE"
+
+    def __init__(self, rank, world, model_type, feature_size, *args, **kw):
+        self.model_type = model_type
+        self.rank, self.world = rank, world
+        self.N_global = int(feature_size)
+        self._rows_local = (self.N_global + world - 1) // world
+        SCOREBASE.__init__(self, feature_size, *args, **kw)
+
+    def _alloc_optimizer(self):
+        if getattr(self, "_sharded", False):       # skip the base class's full-table slots
+            SCOREBASE._alloc_optimizer(self)
+
+    def _init_params(self, seed):
+        # same generator sequence as the single-device model: full table, then slice the shard
+        SCOREBASE._init_params(self, seed)
+        full = self.table
+        self.table = self._take_shard(full)
+        del full
+        self._sharded = True
+        self._alloc_optimizer()
+
+    def _take_shard(self, full):
+        shard = torch.zeros((self._rows_local, full.shape[1]), dtype=torch.float32, device=self.device)
+        part = full[self.rank::self.world]
+        shard[:part.shape[0]].copy_(part)
+        return shard
+
+    def set_params(self, params):
+        emb = np.asarray(params["emb_mtx"], dtype=np.float32)
+        self.row0 = emb[0].copy()
+        full = torch.from_numpy(emb).to(self.device)
+        full[0].zero_()
+        self.table.copy_(self._take_shard(full))
+        for e in self.entries:
+            v = self._view(self.w, e)
+            v.copy_(torch.from_numpy(np.asarray(params[e[0]], dtype=np.float32).reshape(tuple(v.shape))))
+
+
+class HipBackend(object):
+    """Per-rank compute of the sharded step on libscore_hip.so."""
+
+    def __init__(self, rank, world, model_type, cfg_args, seed=1111, device=None):
+        self.m = _ShardModel(rank, world, model_type, *cfg_args, seed=seed, device=device)
+        self.rank, self.world = rank, world
+        self.device = self.m.device
+        self.D = int(cfg_args[1])
+        self.lib = self.m.lib
+        self._scratch = None
+
+    # -- index plan ---------------------------------------------------------------------
+    def plan(self, batch_data):
+        m = self.m
+        db = m.device_batch(batch_data)
+        lay, ws = m._workspace(db.B)
+        st = m._state(ws)
+        _lib.check(self.lib.score_index_plan(C.byref(m.cfg), C.byref(st), C.byref(db.struct), self.world,
+                                             m._stream()), "score_index_plan")
+        meta = ws[lay.plan_meta:lay.plan_meta + 2 + self.world].view(torch.int32).cpu().tolist()   # sync
+        U, offs = meta[0], meta[1:2 + self.world]
+        uniq = ws[lay.plan_unique_rows:lay.plan_unique_rows + U].view(torch.int32)
+        # batch struct over the remapped (unique-position) index tensors
+        sizes = [t.numel() for t in (db.tensors[0], db.tensors[3], db.tensors[1], db.tensors[2], db.tensors[4],
+                                     db.tensors[5])]
+        rm = [ws[lay.plan_remap[g]:lay.plan_remap[g] + sizes[g]].view(torch.int32) for g in range(6)]
+        # plan order: user_1hop, item_2hop, user_2hop, item_1hop, target_user, target_item
+        remapped = _lib.Batch(_ptr(rm[0]), _ptr(rm[2]), _ptr(rm[3]), _ptr(rm[1]), _ptr(rm[4]), _ptr(rm[5]),
+                              _ptr(db.tensors[6]), _ptr(db.tensors[7]), db.B)
+        return dict(db=db, remapped=remapped, keep=rm, U=U, offsets=offs, unique_rows=uniq)
+
+    def gather(self, req_rows):
+        n = req_rows.numel()
+        out = torch.empty((n, self.D), dtype=torch.float32, device=self.device)
+        if n:
+            _lib.check(self.lib.score_gather_fwd(_ptr(self.m.table), self.m.table.shape[0], self.D, _ptr(req_rows),
+                                                 n, _ptr(out), self.m._stream()), "score_gather_fwd")
+        return out
+
+    def _state(self, plan, mini):
+        m = self.m
+        lay, ws = m._workspace(plan["db"].B)
+        return lay, ws, _lib.State(_ptr(mini), mini.shape[0], _ptr(m.w), _ptr(ws), ws.numel() * 4, 2,
+                                   int(m.global_batch))
+
+    def forward(self, plan, mini, reg_lambda, keep_prob, masks):
+        m = self.m
+        lay, ws, st = self._state(plan, mini)
+        m0 = m1 = None
+        if masks is not None:
+            m0 = torch.as_tensor(np.asarray(masks[0]), dtype=torch.uint8).to(self.device).contiguous()
+            m1 = torch.as_tensor(np.asarray(masks[1]), dtype=torch.uint8).to(self.device).contiguous()
+        seed = (m._drop_seed * 0x9E3779B1 + m.step * 0x85EBCA77 + self.rank * 0xC2B2AE35) & 0xFFFFFFFFFFFFFFFF
+        rc = self.lib.score_forward(C.byref(m.cfg), C.byref(st), C.byref(plan["remapped"]), float(reg_lambda),
+                                    float(keep_prob), _ptr(m0), _ptr(m1), C.c_uint64(seed),
+                                    m._event_array(m.fwd_events), m._stream())
+        _lib.check(rc, "score_forward")
+        self._keep = (m0, m1)
+        B = plan["db"].B
+        return dict(lay=lay, ws=ws, st=st, y_pred=ws[lay.y_pred:lay.y_pred + B], loss=ws[lay.loss:lay.loss + 3])
+
+    def backward(self, plan, mini, fw, keep_prob):
+        m = self.m
+        mini_g = torch.zeros_like(mini)
+        rc = self.lib.score_backward(C.byref(m.cfg), C.byref(fw["st"]), C.byref(plan["remapped"]), float(keep_prob),
+                                     _ptr(m.w_g), _ptr(mini_g), m._event_array(m.bwd_events), m._stream())
+        _lib.check(rc, "score_backward")
+        return mini_g
+
+    def accumulate(self, req_rows, grads_in):
+        m = self.m
+        m.table_g.zero_()
+        n = req_rows.numel()
+        if n:
+            need = int(self.lib.score_segment_sum_scratch_bytes(n, self.D))
+            if self._scratch is None or self._scratch.numel() < need:
+                self._scratch = torch.empty((need,), dtype=torch.uint8, device=self.device)
+            rc = self.lib.score_segment_sum_rows(_ptr(req_rows), _ptr(grads_in), n, self.D, m.table.shape[0],
+                                                 _ptr(m.table_g), _ptr(self._scratch), self._scratch.numel(),
+                                                 m._stream())
+            _lib.check(rc, "score_segment_sum_rows")
+
+    def dense_grad(self):
+        return self.m.w_g
+
+    def adam(self, lr, reg_lambda):
+        self.m.apply_adam(lr, reg_lambda)
+
+    def set_global_batch(self, n):
+        self.m.global_batch = int(n)
+
+    def labels(self, plan):
+        return plan["db"].tensors[6]
+
+
+class ShardedSCORE(object):
+    """SCORE(...) with the reference's train/eval signatures (score.py:101-133), table sharded
+    over the ranks of `comm`.  Every rank calls train()/eval() with its own batch_data."""
+
+    model_type = "SCORE"
+
+    def __init__(self, feature_size, eb_dim, hidden_size, max_time_len, obj_per_time_slice, user_fnum, item_fnum,
+                 seed=1111, comm=None, backend=None, model_type=None, device=None):
+        self.comm = comm if comm is not None else TorchDistComm()
+        self.rank, self.world = self.comm.rank, self.comm.world
+        if model_type is not None:
+            self.model_type = model_type
+        cfg_args = (feature_size, eb_dim, hidden_size, max_time_len, obj_per_time_slice, user_fnum, item_fnum)
+        self.backend = backend if backend is not None else HipBackend(self.rank, self.world, self.model_type,
+                                                                      cfg_args, seed, device)
+        self.device = self.backend.device
+        self.D = int(eb_dim)
+
+    # bench.py compatibility with the single-device model
+    @property
+    def n_w(self):
+        return self.backend.m.n_w
+
+    def device_batch(self, batch_data):
+        return self.backend.m.device_batch(batch_data) if hasattr(self.backend, "m") else batch_data
+
+    def enable_stage_events(self, on=True):
+        self.backend.m.enable_stage_events(on)
+        self.fwd_events, self.bwd_events = self.backend.m.fwd_events, self.backend.m.bwd_events
+
+    def _fetch(self, batch_data):
+        """plan -> request rows from their owners -> gathered [U, D] mini-table"""
+        be, cm = self.backend, self.comm
+        plan = be.plan(batch_data)
+        offs = plan["offsets"]
+        send = [offs[o + 1] - offs[o] for o in range(self.world)]      # unique rows I need from shard o
+        recv = cm.exchange_counts(send, self.device)                    # rows shard-me must serve to rank p
+        req = torch.empty((sum(recv),), dtype=torch.int32, device=self.device)
+        cm.all_to_all(req, plan["unique_rows"], recv, send)
+        rows = be.gather(req)
+        mini = torch.empty((plan["U"], self.D), dtype=torch.float32, device=self.device)
+        cm.all_to_all(mini, rows, send, recv)
+        plan.update(send=send, recv=recv, req=req)
+        return plan, mini
+
+    def forward_backward(self, batch_data, reg_lambda, keep_prob=1.0, dropout_masks=None):
+        be, cm = self.backend, self.comm
+        plan, mini = self._fetch(batch_data)
+        B = plan["B"] if "B" in plan else plan["db"].B
+        be.set_global_batch(B * self.world)
+        fw = be.forward(plan, mini, reg_lambda, keep_prob, dropout_masks)
+        mini_g = be.backward(plan, mini, fw, keep_prob)
+        grads_in = torch.empty((plan["req"].numel(), self.D), dtype=torch.float32, device=self.device)
+        cm.all_to_all(grads_in, mini_g, plan["recv"], plan["send"])
+        cm.all_reduce_sum(be.dense_grad())
+        be.accumulate(plan["req"], grads_in)
+        loss = fw["loss"].clone()          # [loss, log_loss (local share of the global mean), l2]
+        cm.all_reduce_sum(loss[1:2])
+        return loss, fw
+
+    def apply_adam(self, lr, reg_lambda):
+        self.backend.adam(lr, reg_lambda)
+
+    def train_async(self, batch_data, lr, reg_lambda, keep_prob=0.8, dropout_masks=None):
+        loss, _ = self.forward_backward(batch_data, reg_lambda, keep_prob, dropout_masks)
+        self.apply_adam(lr, reg_lambda)
+        return loss[1] + float(reg_lambda) * loss[2]
+
+    def train(self, sess, batch_data, lr, reg_lambda, keep_prob=0.8, dropout_masks=None):
+        return float(self.train_async(batch_data, lr, reg_lambda, keep_prob, dropout_masks).item())
+
+    def eval(self, sess, batch_data, reg_lambda):
+        be = self.backend
+        plan, mini = self._fetch(batch_data)
+        B = plan["B"] if "B" in plan else plan["db"].B
+        be.set_global_batch(B)             # eval reports the local batch's loss, as the reference does
+        fw = be.forward(plan, mini, reg_lambda, 1.0, None)
+        pred = fw["y_pred"].cpu().numpy().reshape([-1, ]).tolist()
+        label = be.labels(plan).cpu().numpy().reshape([-1, ]).tolist()
+        loss = fw["loss"]
+        return pred, label, float((loss[1] + float(reg_lambda) * loss[2]).item())

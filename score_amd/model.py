@@ -91,6 +91,7 @@ class SCOREBASE(object):
         self._drop_seed = int(seed)
         self.fwd_events = self.bwd_events = None
         self.scatter_mode = 0      # 0: sorted pull-form scatter, 1: float atomics (score_hip.h)
+        self.global_batch = 0      # >0: the loss mean runs over this many samples (data parallel)
         self._init_params(seed)
 
     # ------------------------------------------------------------------ parameters
@@ -166,7 +167,7 @@ class SCOREBASE(object):
 
     def _state(self, ws):
         return _lib.State(_ptr(self.table), self.table.shape[0], _ptr(self.w), _ptr(ws), ws.numel() * 4,
-                          int(self.scatter_mode), 0)
+                          int(self.scatter_mode), int(self.global_batch))
 
     @staticmethod
     def _event_array(events):
@@ -222,6 +223,9 @@ class SCOREBASE(object):
         self.table_g (dense [N,D]).  Returns the device workspace layout/buffer."""
         db = self.device_batch(batch_data)
         lay, ws, st = self._forward(db, reg_lambda, keep_prob, dropout_masks)
+        if self.scatter_mode == 0:     # occurrence sort for the pull-form scatter (indices only)
+            _lib.check(self.lib.score_index_plan(C.byref(self.cfg), C.byref(st), C.byref(db.struct), 1,
+                                                 self._stream()), "score_index_plan")
         self.table_g.zero_()
         rc = self.lib.score_backward(C.byref(self.cfg), C.byref(st), C.byref(db.struct), float(keep_prob),
                                      _ptr(self.w_g), _ptr(self.table_g), self._event_array(self.bwd_events),

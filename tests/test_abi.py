@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared():
     src = open(os.path.join(ROOT, "include", "score_hip.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\bint\s+(score_\w+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(?:int|int64_t)\s+(score_\w+)\s*\(", src)))
 
 
 def test_header_symbols_exported():

@@ -1,0 +1,153 @@
+"""The sharded (row % G) HIP path on ONE GPU: G virtual ranks run score_amd.dist.ShardedSCORE with
+HipBackend in G threads of this process, exchanging through an in-process communicator with the
+semantics of all_to_all_v / all_reduce.  Result must equal the single-device SCORE trained on
+the concatenated batch (G ranks x B == 1 device x G*B)."""
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import score_oracle as so
+from helpers import random_batch, batch_tuple, NAMES
+
+pytestmark = pytest.mark.gpu
+
+
+class ThreadGroup(object):
+    def __init__(self, world):
+        self.world = world
+        self.barrier = threading.Barrier(world)
+        self.slots = [None] * world
+
+
+class ThreadComm(object):
+    def __init__(self, group, rank):
+        self.g, self.rank, self.world = group, rank, group.world
+
+    def exchange_counts(self, send_counts, device):
+        self.g.slots[self.rank] = list(send_counts)
+        self.g.barrier.wait()
+        out = [self.g.slots[p][self.rank] for p in range(self.world)]
+        self.g.barrier.wait()
+        return out
+
+    def all_to_all(self, out, inp, out_splits, in_splits):
+        torch.cuda.synchronize()
+        self.g.slots[self.rank] = inp.split(in_splits, 0)
+        self.g.barrier.wait()
+        for p, o in enumerate(out.split(out_splits, 0)):
+            o.copy_(self.g.slots[p][self.rank])
+        torch.cuda.synchronize()
+        self.g.barrier.wait()
+
+    def all_reduce_sum(self, t):
+        torch.cuda.synchronize()
+        self.g.slots[self.rank] = t.clone()
+        self.g.barrier.wait()
+        tot = self.g.slots[0].clone()
+        for p in range(1, self.world):
+            tot += self.g.slots[p]
+        torch.cuda.synchronize()
+        self.g.barrier.wait()
+        t.copy_(tot)
+
+
+def run_ranks(world, fn):
+    grp = ThreadGroup(world)
+    res, errs = [None] * world, []
+
+    def body(r):
+        try:
+            torch.cuda.set_device(0)
+            res[r] = fn(r, ThreadComm(grp, r))
+        except BaseException as e:      # noqa
+            errs.append(e)
+            grp.barrier.abort()
+    th = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    if errs:
+        raise errs[0]
+    return res
+
+
+@pytest.mark.parametrize("world,model_type,cfg_args,B", [
+    (2, "SCORE", (203, 4, 8, 3, 3, 3, 4), 6),
+    (4, "SCORE", (5001, 16, 32, 5, 10, 3, 4), 16),
+    (3, "RCA", (1000, 16, 16, 4, 5, 1, 2), 8),
+    (2, "RIA", (777, 8, 16, 4, 4, 3, 4), 10),
+])
+def test_virtual_ranks_match_single_device(world, model_type, cfg_args, B):
+    from score_amd.dist import ShardedSCORE
+    from score_amd.model import MODELS
+    cfg = so.Cfg(*cfg_args, model_type=model_type)
+    params = so.init_params(cfg, 5)
+    steps = 2
+    batches = [[random_batch(np.random.default_rng(100 * r + s), cfg, B) for s in range(steps)] for r in range(world)]
+
+    def fn(rank, comm):
+        m = ShardedSCORE(*cfg_args, comm=comm, model_type=model_type)
+        m.backend.m.set_params(params)
+        losses = [m.train(None, batch_tuple(b), 1e-3, 1e-3, keep_prob=1.0) for b in batches[rank]]
+        pred, _, _ = m.eval(None, batch_tuple(batches[rank][0]), 1e-3)
+        torch.cuda.synchronize()
+        return losses, m.backend.m.table.cpu().numpy(), m.backend.m.w.cpu().numpy(), pred
+
+    res = run_ranks(world, fn)
+    ref = MODELS[model_type](*cfg_args)
+    ref.set_params(params)
+    for s in range(steps):
+        cat = tuple(np.concatenate([batches[r][s][n] for r in range(world)]) for n in NAMES)
+        lref = ref.train(None, cat, 1e-3, 1e-3, keep_prob=1.0)
+        for r in range(world):
+            assert abs(res[r][0][s] - lref) < 2e-5 * max(1.0, abs(lref)), (s, r, res[r][0][s], lref)
+    # dense replicas identical across ranks (bitwise: same all-reduced gradient, same Adam)
+    for r in range(1, world):
+        assert np.array_equal(res[0][2], res[r][2])
+    wref = ref.w.cpu().numpy()
+    close = np.abs(res[0][2] - wref) <= 3e-6
+    assert close.mean() > 0.999 and np.abs(res[0][2] - wref).max() <= 2.2 * steps * 1e-3
+    # shards reassemble to the single device's table
+    N, D = cfg.N, cfg.D
+    full = np.zeros((N, D), dtype=np.float32)
+    for r in range(world):
+        n_r = len(range(r, N, world))
+        full[r::world] = res[r][1][:n_r]
+        assert not res[r][1][n_r:].any()
+    tref = ref.table.cpu().numpy()
+    d = np.abs(full - tref)
+    assert (d <= 3e-6).mean() > 0.999 and d.max() <= 2.2 * steps * 1e-3
+    assert not full[0].any()
+    # eval of rank r's batch on the sharded model == single device
+    for r in range(world):
+        pref, _, _ = ref.eval(None, batch_tuple(batches[r][0]), 1e-3)
+        assert np.abs(np.asarray(res[r][3]) - np.asarray(pref)).max() < 1e-4
+
+
+def test_segment_sum_rows_op():
+    import ctypes as C
+    from score_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(3)
+    n, D, R = 70000, 16, 5000
+    rows = rng.integers(0, R, n).astype(np.int32)
+    rows[:30000] = 7                      # one very hot row: exercises the long-chain path
+    src = rng.standard_normal((n, D)).astype(np.float32)
+    drows, dsrc = torch.from_numpy(rows).cuda(), torch.from_numpy(src).cuda()
+    out = torch.full((R, D), 3.0, device="cuda")
+    need = int(lib.score_segment_sum_scratch_bytes(n, D))
+    scratch = torch.empty((need,), dtype=torch.uint8, device="cuda")
+    p = lambda t: C.c_void_p(t.data_ptr())
+    for _ in range(2):
+        rc = lib.score_segment_sum_rows(p(drows), p(dsrc), n, D, R, p(out), p(scratch), need,
+                                        C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc == 0
+    want = np.full((R, D), 3.0, dtype=np.float64)
+    touched = np.unique(rows)
+    touched = touched[touched != 0]       # row 0 is the dummy: never written
+    acc = np.zeros((R, D))
+    np.add.at(acc, rows, src.astype(np.float64))
+    want[touched] = acc[touched]
+    got = out.cpu().numpy()
+    assert np.allclose(got, want, rtol=1e-5, atol=1e-3 * 1e-2 * np.abs(acc).max())
