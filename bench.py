@@ -66,6 +66,8 @@ def main():
     ap.add_argument("--config", default="cfg3")
     ap.add_argument("--batches", type=int, default=4, help="distinct pre-staged batches cycled through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="use the row-sharded all-to-all path even with one rank (exercises RCCL plumbing)")
     ap.add_argument("--lr", type=float, default=1e-3)
     ap.add_argument("--reg-lambda", type=float, default=1e-4)
     args = ap.parse_args()
@@ -78,8 +80,12 @@ def main():
             raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
     torch.cuda.set_device(local_rank)
     dist = None
-    if world_size > 1:
+    sharded = world_size > 1 or args.force_sharded
+    if sharded:
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world_size,
                                 device_id=torch.device("cuda", local_rank))
@@ -91,7 +97,7 @@ def main():
     T, K, D = kw["max_time_len"], kw["obj_per_time_slice"], kw["eb_dim"]
     Fu, Fi = kw["user_fnum"], kw["item_fnum"]
 
-    if world_size > 1:
+    if sharded:
         from score_amd.dist import ShardedSCORE
         model = ShardedSCORE(seed=1111, **kw)
     else:
@@ -116,7 +122,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         model.fwd_events, model.bwd_events, e_a0, e_a1 = ev_sets[i]
-        lay, ws = model.forward_backward(batches[i % len(batches)], args.reg_lambda, 0.8)
+        fb = model.forward_backward(batches[i % len(batches)], args.reg_lambda, 0.8)
         e_a0.record()
         model.apply_adam(args.lr, args.reg_lambda)
         e_a1.record()
@@ -127,7 +133,10 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    loss = float(ws[lay.loss].item())
+    if sharded:
+        loss = float((fb[0][1] + args.reg_lambda * fb[0][2]).item())
+    else:
+        loss = float(fb[1][fb[0].loss].item())
 
     # live stage timings (ms), averaged over the timed steps
     def avg(fn):

@@ -185,13 +185,13 @@ typedef struct {
 
 /* Index plan of a batch (depends on the indices only; run it before score_backward, on
  * any stream ordered before it).  Radix-sorts all R*B row uses by (owner shard, row).
- * n_shards > 1 (table row-sharded, owner = row % n_shards) additionally de-duplicates
- * them: unique rows grouped by owner -> what to request from each shard -- and writes the
- * six index tensors remapped to unique positions, so the same kernels run on the gathered
- * [U, D] mini-table.  Replaces nothing in the reference (it has no multi-device code);
+ * n_shards > 1 (table row-sharded, owner = row % n_shards) or dedup != 0 additionally
+ * de-duplicates them: unique rows grouped by owner -> what to request from each shard --
+ * and writes the six index tensors remapped to unique positions, so the same kernels run
+ * on the gathered [U, D] mini-table.  Replaces nothing in the reference (it has no multi-device code);
  * it is the index-routing step BASELINE.json's north_star asks for. */
 int score_index_plan(const score_config_t* cfg, const score_state_t* st, const score_batch_t* batch,
-                     int32_t n_shards, void* stream);
+                     int32_t n_shards, int32_t dedup, void* stream);
 
 /* out[rows[j], :] = sum over slots j with equal rows[j] of src[j, :] (slot order; rows never
  * named keep their value).  The shard owner uses it to combine the row gradients received

@@ -64,7 +64,7 @@ _SIGS = {
                       c_f, C.c_int32, c_f, c_f, c_f, c_f, C.c_void_p],
     "score_adam": [c_f, c_f, c_f, c_f, C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,
                    C.c_float, C.c_void_p],
-    "score_index_plan": [C.POINTER(Config), C.POINTER(State), C.POINTER(Batch), C.c_int32, C.c_void_p],
+    "score_index_plan": [C.POINTER(Config), C.POINTER(State), C.POINTER(Batch), C.c_int32, C.c_int32, C.c_void_p],
     "score_segment_sum_rows": [c_i, c_f, C.c_int64, C.c_int32, C.c_int64, c_f, C.c_void_p, C.c_int64, C.c_void_p],
     "score_segment_sum_scratch_bytes": [C.c_int64, C.c_int32],
     "score_forward": [C.POINTER(Config), C.POINTER(State), C.POINTER(Batch), C.c_float, C.c_float, C.c_void_p,

@@ -233,7 +233,7 @@ extern "C" int score_workspace_layout(const score_config_t* cfg, int32_t B, scor
 }
 
 extern "C" int score_index_plan(const score_config_t* cfg, const score_state_t* st, const score_batch_t* bt,
-                                int32_t n_shards, void* stream) {
+                                int32_t n_shards, int32_t dedup, void* stream) {
   Dims d;
   SCORE_TRY(make_dims(cfg, &d));
   if (!st || !bt || !st->workspace || bt->B <= 0 || n_shards < 1 || n_shards > 64) return SCORE_E_BADARG;
@@ -271,7 +271,7 @@ extern "C" int score_index_plan(const score_config_t* cfg, const score_state_t* 
   uint32_t* vals_out = reinterpret_cast<uint32_t*>(ws + w.vals_out);
   G(score_launch_plan(pf, key_bits, keys_in, vals_in, keys_out, vals_out, ws + w.sort_temp,
                       (size_t)w.sort_temp_bytes, s));
-  if (n_shards > 1) {
+  if (n_shards > 1 || dedup) {
     PlanRemapArgs ra;
     memset(&ra, 0, sizeof(ra));
     for (int g = 0; g < 6; ++g) { ra.out[g] = reinterpret_cast<int32_t*>(ws + w.remap[g]); ra.F[g] = Fs[g]; }
@@ -548,7 +548,7 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
   if (!atomic) {
     PullArgs pa;
     memset(&pa, 0, sizeof(pa));
-    pa.D = d.D; pa.K = d.K;
+    pa.D = d.D; pa.K = d.K; pa.zero_is_dummy = 1;
     pa.uid = st->scatter_mode == 2 ? reinterpret_cast<const uint32_t*>(ws + w.uid) : nullptr;
     const float invK = 1.0f / (float)d.K;
     const float* Gm[6] = {ws + w.dxside[0], ws + w.dxside[1], ws + w.dxside[0], ws + w.dxside[1], ws + w.dtgt,

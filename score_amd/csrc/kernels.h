@@ -76,6 +76,7 @@ struct PullArgs {
   float constA[6];
   const uint32_t* uid;     // null: a run's destination is its row id; else the run's unique position
   int D, K, LPRp;
+  int zero_is_dummy;       // key 0 is the masked dummy row (score.py:44-47): no gradient
 };
 struct PlanRemapArgs { int32_t* out[6]; int F[6]; int K; };
 int score_launch_plan_unique(const PlanRemapArgs& ra, const uint32_t* keys, const uint32_t* vals, int64_t n,

@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) void pull_kernel(const PullArgs a, const uint3
   for (int64_t i = start; i < end; ++i) {
     uint32_t key = keys[i];
     if (key != cur) {
-      if (cur != 0) {
+      if (cur != 0 || !a.zero_is_dummy) {
         if (is_first && first_open) st4(pfirst + w * a.D + ch4, acc);
         else st4(out + out_row(a, cur, i - 1) * a.D + ch4, acc);
       }
@@ -210,9 +210,9 @@ __global__ __launch_bounds__(256) void pull_kernel(const PullArgs a, const uint3
       cur = key;
       is_first = false;
     }
-    if (key != 0) acc = add4(acc, pull_contrib(a, vals[i], ch4));
+    if (key != 0 || !a.zero_is_dummy) acc = add4(acc, pull_contrib(a, vals[i], ch4));
   }
-  if (cur != 0) {
+  if (cur != 0 || !a.zero_is_dummy) {
     const bool open_right = end < n && keys[end] == cur;
     if (is_first && first_open) st4(pfirst + w * a.D + ch4, acc);
     else if (open_right) st4(plast + w * a.D + ch4, acc);
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void pull_fixup_kernel(const PullArgs a, const
   if (start >= n || ch4 >= a.D) return;
   const int64_t end = start + WS < n ? start + WS : n;
   const uint32_t lastkey = keys[end - 1];
-  if (lastkey == 0 || end >= n || keys[end] != lastkey) return;          // not open to the right
+  if ((lastkey == 0 && a.zero_is_dummy) || end >= n || keys[end] != lastkey) return;  // not open to the right
   if (keys[start] == lastkey && start > 0 && keys[start - 1] == lastkey) return;  // did not start here
   const int64_t re = run_end(keys, end, n, lastkey);
   const int L = (int)((re - 1) / WS - w);                                 // windows w+1 .. w+L continue the run
@@ -358,7 +358,7 @@ extern "C" int score_segment_sum_rows(const int32_t* rows, const float* src, int
   if (e != hipSuccess) return (int)e;
   PullArgs pa;
   memset(&pa, 0, sizeof(pa));
-  pa.D = D; pa.K = 1; pa.G[0] = src;
+  pa.D = D; pa.K = 1; pa.G[0] = src; pa.zero_is_dummy = 0;   // local row 0 is a real row on shards > 0
   return score_launch_pull(pa, keys_out, vals_out, n, out, partials, partial_floats, s);
 }
 

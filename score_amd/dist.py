@@ -131,7 +131,7 @@ class HipBackend(object):
         db = m.device_batch(batch_data)
         lay, ws = m._workspace(db.B)
         st = m._state(ws)
-        _lib.check(self.lib.score_index_plan(C.byref(m.cfg), C.byref(st), C.byref(db.struct), self.world,
+        _lib.check(self.lib.score_index_plan(C.byref(m.cfg), C.byref(st), C.byref(db.struct), self.world, 1,
                                              m._stream()), "score_index_plan")
         meta = ws[lay.plan_meta:lay.plan_meta + 2 + self.world].view(torch.int32).cpu().tolist()   # sync
         U, offs = meta[0], meta[1:2 + self.world]
@@ -237,7 +237,11 @@ class ShardedSCORE(object):
 
     def enable_stage_events(self, on=True):
         self.backend.m.enable_stage_events(on)
-        self.fwd_events, self.bwd_events = self.backend.m.fwd_events, self.backend.m.bwd_events
+
+    fwd_events = property(lambda self: self.backend.m.fwd_events,
+                          lambda self, v: setattr(self.backend.m, "fwd_events", v))
+    bwd_events = property(lambda self: self.backend.m.bwd_events,
+                          lambda self, v: setattr(self.backend.m, "bwd_events", v))
 
     def _fetch(self, batch_data):
         """plan -> request rows from their owners -> gathered [U, D] mini-table"""

@@ -224,7 +224,7 @@ class SCOREBASE(object):
         db = self.device_batch(batch_data)
         lay, ws, st = self._forward(db, reg_lambda, keep_prob, dropout_masks)
         if self.scatter_mode == 0:     # occurrence sort for the pull-form scatter (indices only)
-            _lib.check(self.lib.score_index_plan(C.byref(self.cfg), C.byref(st), C.byref(db.struct), 1,
+            _lib.check(self.lib.score_index_plan(C.byref(self.cfg), C.byref(st), C.byref(db.struct), 1, 0,
                                                  self._stream()), "score_index_plan")
         self.table_g.zero_()
         rc = self.lib.score_backward(C.byref(self.cfg), C.byref(st), C.byref(db.struct), float(keep_prob),

@@ -133,6 +133,7 @@ def test_segment_sum_rows_op():
     n, D, R = 70000, 16, 5000
     rows = rng.integers(0, R, n).astype(np.int32)
     rows[:30000] = 7                      # one very hot row: exercises the long-chain path
+    rows[-5:] = 0                         # local row 0 is a real row on shards > 0: summed like any other
     src = rng.standard_normal((n, D)).astype(np.float32)
     drows, dsrc = torch.from_numpy(rows).cuda(), torch.from_numpy(src).cuda()
     out = torch.full((R, D), 3.0, device="cuda")
@@ -143,9 +144,9 @@ def test_segment_sum_rows_op():
         rc = lib.score_segment_sum_rows(p(drows), p(dsrc), n, D, R, p(out), p(scratch), need,
                                         C.c_void_p(torch.cuda.current_stream().cuda_stream))
         assert rc == 0
-    want = np.full((R, D), 3.0, dtype=np.float64)
+    want = np.full((R, D), 3.0, dtype=np.float64)                         # local row 0 is a real row on shards > 0: summed like any other
+    drows = torch.from_numpy(rows).cuda()
     touched = np.unique(rows)
-    touched = touched[touched != 0]       # row 0 is the dummy: never written
     acc = np.zeros((R, D))
     np.add.at(acc, rows, src.astype(np.float64))
     want[touched] = acc[touched]
