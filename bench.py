@@ -205,9 +205,16 @@ def main():
         out["cpu_baseline"] = cpu_baseline(kw, world, B, params)
     else:
         out["cpu_baseline"] = None
-    print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+    # RCCL prints its version banner through C stdio: flush it first so the JSON is the LAST line
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
