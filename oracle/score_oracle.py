@@ -339,7 +339,8 @@ def forward(cfg, P, batch, keep_prob=1.0, dropout_masks=None, reg_lambda=0.0):
     emb_mask = torch.ones((c.N, 1), dtype=dt)
     emb_mask[0] = 0
     emb = P["emb_mtx"] * emb_mask                             # score.py:44-47
-    g = lambda idx, F: emb[idx.long()].reshape(tuple(idx.shape[:-1]) + (F * c.D,))
+    # tf.nn.embedding_lookup (score.py:51-66); F.embedding is torch's row gather with a dense backward
+    g = lambda idx, F: torch.nn.functional.embedding(idx.long(), emb).reshape(tuple(idx.shape[:-1]) + (F * c.D,))
     user_1hop, user_2hop = g(batch["user_1hop"], c.Fi), g(batch["user_2hop"], c.Fu)
     item_1hop, item_2hop = g(batch["item_1hop"], c.Fu), g(batch["item_2hop"], c.Fi)
     target_item, target_user = g(batch["target_item"], c.Fi), g(batch["target_user"], c.Fu)
@@ -455,12 +456,26 @@ class TFAdam(object):
         f = np.float32
         a = self.alpha(lr)
         omb1, omb2 = f(1) - f(ADAM_B1), f(1) - f(ADAM_B2)
+        # same fp32 operation sequence as the NumPy expressions
+        #   m += (g-m)*omb1 ; v += (g*g-v)*omb2 ; p = p - (m*a)/(sqrt(v)+eps)
+        # done in place through torch (multi-threaded) on the arrays' own memory
         for k in params:
-            g = grads[k].astype(np.float32)
-            m, v = self.m[k], self.v[k]
-            m += (g - m) * omb1
-            v += (g * g - v) * omb2
-            params[k] = (params[k] - (m * a) / (np.sqrt(v) + f(ADAM_EPS))).astype(np.float32)
+            g = torch.from_numpy(np.ascontiguousarray(grads[k], dtype=np.float32))
+            if not params[k].flags.writeable or not params[k].flags.c_contiguous:
+                params[k] = np.array(params[k], dtype=np.float32)
+            m, v, p = torch.from_numpy(self.m[k]), torch.from_numpy(self.v[k]), torch.from_numpy(params[k])
+            t = g - m
+            t.mul_(float(omb1))
+            m.add_(t)
+            torch.mul(g, g, out=t)
+            t.sub_(v)
+            t.mul_(float(omb2))
+            v.add_(t)
+            torch.mul(m, float(a), out=t)
+            den = torch.sqrt(v)
+            den.add_(float(f(ADAM_EPS)))
+            t.div_(den)
+            p.sub_(t)
         self.b1p = f(self.b1p * f(ADAM_B1))
         self.b2p = f(self.b2p * f(ADAM_B2))
 
