@@ -37,25 +37,54 @@ def alg_bytes_per_sample(T, K, D, Fu, Fi):
     return R * 4 + R * 4 * D + out, R
 
 
-def cpu_baseline(kw, world, B, params, budget_s=20.0, max_steps=6):
-    """CPU restatement of the TF1 graph (Oracle B + dense TF-Adam), full train step."""
+def usable_cpus():
+    """Host cores this process may actually use: affinity mask and cgroup quota, not os.cpu_count()."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return max(1, n)
+
+
+def cpu_baseline(kw, world, B, params, budget_s=25.0, max_steps=4, max_threads=32):
+    """CPU restatement of the TF1 graph (Oracle B + dense TF-Adam), full train step, on a bounded
+    sample: the first step is timed too and is the whole sample if it alone exceeds the budget."""
     from oracle import score_oracle as so
-    torch.set_num_threads(os.cpu_count())
+    threads = min(usable_cpus(), max_threads)
+    torch.set_num_threads(threads)
     m = so.OracleModel(kw["feature_size"], kw["eb_dim"], kw["hidden_size"], kw["max_time_len"],
                        kw["obj_per_time_slice"], kw["user_fnum"], kw["item_fnum"], "SCORE", params=params)
     batch = world.batch(B, 1000)
-    m.train(None, batch, 1e-3, 1e-4, keep_prob=1.0)            # warm-up
+    t0 = time.time()
+    m.train(None, batch, 1e-3, 1e-4, keep_prob=1.0)
+    first = time.time() - t0
     times = []
     t_all = time.time()
-    while len(times) < max_steps and (time.time() - t_all) < budget_s:
+    while first < budget_s and len(times) < max_steps and (time.time() - t_all) < budget_s:
         t0 = time.time()
         m.train(None, batch, 1e-3, 1e-4, keep_prob=1.0)
         times.append(time.time() - t0)
-    med = float(np.median(times))
-    return {"value": B / med, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d full train steps (fwd+bwd+dense TF-Adam) of the same workload, B=%d, median %.3f s/step; "
-                      "CPU restatement of the TF1 graph (TensorFlow unavailable), torch-CPU fp32, os.cpu_count()=%d"
-                      % (len(times), B, med, os.cpu_count())}
+    med = float(np.median(times)) if times else first
+    return {"value": B / med, "unit": "samples/s", "cores": threads, "kind": "port",
+            "sample": "%d full train step(s) (fwd+bwd+dense TF-Adam) of the same workload after one %s step, B=%d, "
+                      "median %.3f s/step; CPU restatement of the TF1 graph (TensorFlow unavailable), torch-CPU "
+                      "fp32, %d threads (os.cpu_count()=%d, usable=%d)"
+                      % (max(len(times), 1), "untimed warm-up" if times else "(timed, no warm-up)", B, med, threads,
+                         os.cpu_count(), usable_cpus())}
 
 
 def main():

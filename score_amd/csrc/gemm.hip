@@ -7,11 +7,8 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-#define BM 64
-#define BN 64
 #define BK 16
 #define AS_LD (BK + 1)  // As[i][k]: column reads by 32 lanes -> stride 17 words, conflict-free
-#define BS_LD (BN + 1)
 
 enum { F_BIAS = 1, F_RELU = 2, F_ACC = 4, F_DROP = 8 };
 
@@ -30,13 +27,15 @@ __device__ __forceinline__ float epilogue(float v, int row, int col, int N, cons
 // TRANS 0: A[M,K] (lda) , B[K,N] (ldb)
 // TRANS 1: A[M,K] (lda) , B[N,K] (ldb)  -> C = A . B^T
 // TRANS 2: A[K,M] (lda) , B[K,N] (ldb)  -> C = A^T . B
-template <int TRANS>
+// Block = 2x2 waves, each wave a (32*WM) x (32*WN) tile => block tile (64*WM) x (64*WN).
+template <int TRANS, int WM, int WN>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, const float* __restrict__ A, int lda,
                                                        const float* __restrict__ Bm, int ldb,
                                                        float* __restrict__ C, int ldc,
                                                        const float* __restrict__ bias, int flags, float keep,
                                                        const uint8_t* __restrict__ mask, uint64_t seed,
                                                        int k_chunk, float* __restrict__ slab) {
+  constexpr int BM = 64 * WM, BN = 64 * WN, BS_LD = BN + 1;
   __shared__ float As[BM * AS_LD];
   __shared__ float Bs[BK * BS_LD];
   const int tid = threadIdx.x;
@@ -47,8 +46,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, cons
   const int kbeg = blockIdx.z * k_chunk;
   const int kend = min(K, kbeg + k_chunk);
 
-  // staging coordinates: A tile 64x16, B tile 16x64, one float4 per thread each
-  float ra[4], rb[4];
+  float ra[WM][4], rb[WN][4];
   const bool vecA = ((lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
   const bool vecB = ((ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(Bm) & 15) == 0);
   // one row-major quad: 16-B load when aligned and fully in range, guarded scalars otherwise
@@ -62,38 +60,58 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, cons
     }
   };
   auto load_tiles = [&](int k0) {
-    if (TRANS == 2) load_quad(A, lda, vecA, k0 + (tid >> 4), kend, bm + (tid & 15) * 4, M, ra);   // A[k][m]
-    else            load_quad(A, lda, vecA, bm + (tid >> 2), M, k0 + (tid & 3) * 4, kend, ra);    // A[m][k]
-    if (TRANS == 1) load_quad(Bm, ldb, vecB, bn + (tid >> 2), N, k0 + (tid & 3) * 4, kend, rb);   // B[n][k]
-    else            load_quad(Bm, ldb, vecB, k0 + (tid >> 4), kend, bn + (tid & 15) * 4, N, rb);  // B[k][n]
+#pragma unroll
+    for (int rep = 0; rep < WM; ++rep) {
+      const int q = tid + 256 * rep;
+      if (TRANS == 2) load_quad(A, lda, vecA, k0 + q / (BM / 4), kend, bm + (q % (BM / 4)) * 4, M, ra[rep]);  // A[k][m]
+      else            load_quad(A, lda, vecA, bm + (q >> 2), M, k0 + (q & 3) * 4, kend, ra[rep]);              // A[m][k]
+    }
+#pragma unroll
+    for (int rep = 0; rep < WN; ++rep) {
+      const int q = tid + 256 * rep;
+      if (TRANS == 1) load_quad(Bm, ldb, vecB, bn + (q >> 2), N, k0 + (q & 3) * 4, kend, rb[rep]);             // B[n][k]
+      else            load_quad(Bm, ldb, vecB, k0 + q / (BN / 4), kend, bn + (q % (BN / 4)) * 4, N, rb[rep]);  // B[k][n]
+    }
   };
   auto store_tiles = [&]() {
-    if (TRANS == 2) {
-      int k = tid >> 4, m = (tid & 15) * 4;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) As[(m + q) * AS_LD + k] = ra[q];
-    } else {
-      int m = tid >> 2, k = (tid & 3) * 4;
+    for (int rep = 0; rep < WM; ++rep) {
+      const int q = tid + 256 * rep;
+      if (TRANS == 2) {
+        const int k = q / (BM / 4), m = (q % (BM / 4)) * 4;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) As[m * AS_LD + k + q] = ra[q];
+        for (int e = 0; e < 4; ++e) As[(m + e) * AS_LD + k] = ra[rep][e];
+      } else {
+        const int m = q >> 2, k = (q & 3) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) As[m * AS_LD + k + e] = ra[rep][e];
+      }
     }
-    if (TRANS == 1) {
-      int n = tid >> 2, k = (tid & 3) * 4;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) Bs[(k + q) * BS_LD + n] = rb[q];
-    } else {
-      int k = tid >> 4, n = (tid & 15) * 4;
+    for (int rep = 0; rep < WN; ++rep) {
+      const int q = tid + 256 * rep;
+      if (TRANS == 1) {
+        const int n = q >> 2, k = (q & 3) * 4;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) Bs[k * BS_LD + n + q] = rb[q];
+        for (int e = 0; e < 4; ++e) Bs[(k + e) * BS_LD + n] = rb[rep][e];
+      } else {
+        const int k = q / (BN / 4), n = (q % (BN / 4)) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) Bs[k * BS_LD + n + e] = rb[rep][e];
+      }
     }
   };
 
-  f32x16 acc;
+  f32x16 acc[WM][WN];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  const int arow = wm * 32 + (lane & 31);
-  const int bcol = wn * 32 + (lane & 31);
+  const int arow = wm * 32 * WM + (lane & 31);
+  const int bcol = wn * 32 * WN + (lane & 31);
   const int khalf = lane >> 5;
   if (kbeg < kend) load_tiles(kbeg);
   for (int k0 = kbeg; k0 < kend; k0 += BK) {
@@ -102,28 +120,39 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, cons
     if (k0 + BK < kend) load_tiles(k0 + BK);
 #pragma unroll
     for (int kk = 0; kk < BK / 2; ++kk) {
-      float a = As[arow * AS_LD + kk * 2 + khalf];
-      float b = Bs[(kk * 2 + khalf) * BS_LD + bcol];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+      float av[WM], bv[WN];
+#pragma unroll
+      for (int i = 0; i < WM; ++i) av[i] = As[(arow + 32 * i) * AS_LD + kk * 2 + khalf];
+#pragma unroll
+      for (int j = 0; j < WN; ++j) bv[j] = Bs[(kk * 2 + khalf) * BS_LD + bcol + 32 * j];
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
     }
     __syncthreads();
   }
 
-  // C/D layout of the 32x32 accumulator: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-  const int col = bn + bcol;
-  if (col >= N) return;
+  // C/D layout of a 32x32 accumulator: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    int row = bm + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-    if (row >= M) continue;
-    if (slab) {
-      slab[((int64_t)blockIdx.z * M + row) * N + col] = acc[r];
-    } else {
-      float v = epilogue(acc[r], row, col, N, bias, flags, keep, mask, seed);
-      float* dst = C + (int64_t)row * ldc + col;
-      *dst = (flags & F_ACC) ? *dst + v : v;
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      const int col = bn + bcol + 32 * j;
+      if (col >= N) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = bm + wm * 32 * WM + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+        if (row >= M) continue;
+        if (slab) {
+          slab[((int64_t)blockIdx.z * M + row) * N + col] = acc[i][j][r];
+        } else {
+          float v = epilogue(acc[i][j][r], row, col, N, bias, flags, keep, mask, seed);
+          float* dst = C + (int64_t)row * ldc + col;
+          *dst = (flags & F_ACC) ? *dst + v : v;
+        }
+      }
     }
-  }
 }
 
 __global__ void splitk_reduce_kernel(const float* __restrict__ slab, int nsplit, int M, int N,
@@ -147,7 +176,15 @@ extern "C" int score_gemm(int32_t trans, int32_t M, int32_t N, int32_t K, const 
   if (trans < 0 || trans > 2) return SCORE_E_BADARG;
   if ((flags & F_BIAS) && !bias) return SCORE_E_BADARG;
   hipStream_t s = (hipStream_t)stream;
-  dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, 1);
+  // tile choice: the largest wave tile that still gives the chip >= ~1.5 blocks per CU
+  int WMs = 1, WNs = 1;
+  auto nblocks = [&](int wm_, int wn_) { return (int64_t)((N + 64 * wn_ - 1) / (64 * wn_)) * ((M + 64 * wm_ - 1) / (64 * wm_)); };
+  const int64_t want = 384;
+  const int64_t ksplit_cap = (K >= 512 && scratch) ? K / 128 : 1;
+  if (N > 64 && nblocks(1, 2) * ksplit_cap >= want) WNs = 2;
+  if (M > 64 && nblocks(2, WNs) * ksplit_cap >= want) WMs = 2;
+  const int BMh = 64 * WMs, BNh = 64 * WNs;
+  dim3 grid((N + BNh - 1) / BNh, (M + BMh - 1) / BMh, 1);
   // split the reduced dimension when the output grid alone cannot fill 256 CUs
   int nsplit = 1;
   int64_t tiles = (int64_t)grid.x * grid.y;
@@ -166,12 +203,20 @@ extern "C" int score_gemm(int32_t trans, int32_t M, int32_t N, int32_t K, const 
     grid.z = nsplit;
     slab = nsplit > 1 ? scratch : nullptr;
   }
-#define LAUNCH(TR)                                                                                           \
-  hipLaunchKernelGGL((gemm_f32_kernel<TR>), grid, dim3(256), 0, s, M, N, K, A, lda, Bm, ldb, C, ldc, bias,   \
-                     flags, keep_prob, drop_mask, drop_seed, k_chunk, slab)
-  if (trans == 0) LAUNCH(0);
-  else if (trans == 1) LAUNCH(1);
-  else LAUNCH(2);
+#define LAUNCH(TR, WMv, WNv)                                                                                  \
+  hipLaunchKernelGGL((gemm_f32_kernel<TR, WMv, WNv>), grid, dim3(256), 0, s, M, N, K, A, lda, Bm, ldb, C, ldc, \
+                     bias, flags, keep_prob, drop_mask, drop_seed, k_chunk, slab)
+#define LAUNCH_T(TR)                                      \
+  do {                                                    \
+    if (WMs == 2 && WNs == 2) LAUNCH(TR, 2, 2);           \
+    else if (WMs == 2) LAUNCH(TR, 2, 1);                  \
+    else if (WNs == 2) LAUNCH(TR, 1, 2);                  \
+    else LAUNCH(TR, 1, 1);                                \
+  } while (0)
+  if (trans == 0) LAUNCH_T(0);
+  else if (trans == 1) LAUNCH_T(1);
+  else LAUNCH_T(2);
+#undef LAUNCH_T
 #undef LAUNCH
   SCORE_CHECK_LAUNCH();
   if (slab) {

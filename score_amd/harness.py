@@ -1,0 +1,71 @@
+"""Host-side harness around the hot path: the evaluation loop and ranking metrics the reference's
+driver wraps around model.eval (code/score/train_score.py:94-163).  Pure NumPy/Python, no TF."""
+import math
+import time
+
+import numpy as np
+
+TEST_NEG_SAMPLE_NUM = 99          # train_score.py:19: one positive + 99 negatives per target line
+
+
+def getNDCG_at_K(ranklist, target_item, k):
+    """log 2 / log(rank + 2) if the positive is ranked in the top k, else 0 (train_score.py:104-108)."""
+    for i in range(min(k, len(ranklist))):
+        if ranklist[i] == target_item:
+            return math.log(2) / math.log(i + 2)
+    return 0
+
+
+def getHR_at_K(ranklist, target_item, k):
+    return 1 if target_item in ranklist[:k] else 0
+
+
+def getMRR(ranklist, target_item):
+    for i, it in enumerate(ranklist):
+        if it == target_item:
+            return 1. / (i + 1)
+    return 0
+
+
+def _ranked(preds, target_iids, per_line):
+    p = np.asarray(preds, dtype=np.float64).reshape(-1, per_line)
+    ids = np.asarray(target_iids).reshape(-1, per_line)
+    order = np.argsort(p, axis=1)[:, ::-1]            # descending score, ties as the reference breaks them
+    ranked = np.take_along_axis(ids, order, axis=1)
+    # 0-based rank of the first entry equal to the positive's id (column 0 of every line)
+    hit = ranked == ids[:, :1]
+    return hit.argmax(axis=1)
+
+
+def get_ranking_quality(preds, target_iids, neg_sample_num=TEST_NEG_SAMPLE_NUM):
+    """(NDCG@5, NDCG@10, HR@1, HR@5, HR@10, MRR) over lines of 1 + neg_sample_num candidates
+    (train_score.py:122-142)."""
+    r = _ranked(preds, target_iids, neg_sample_num + 1).astype(np.float64)
+    gain = math.log(2) / np.log(r + 2)
+    return (float(np.mean(np.where(r < 5, gain, 0.0))), float(np.mean(np.where(r < 10, gain, 0.0))),
+            float(np.mean(r < 1)), float(np.mean(r < 5)), float(np.mean(r < 10)), float(np.mean(1.0 / (r + 1))))
+
+
+def get_ndcg(preds, target_iids, neg_sample_num=TEST_NEG_SAMPLE_NUM):
+    return get_ranking_quality(preds, target_iids, neg_sample_num)[0]
+
+
+def evaluate(model, batches, reg_lambda, sess=None, neg_sample_num=TEST_NEG_SAMPLE_NUM, verbose=False):
+    """train_score.py:144-163: run model.eval over the batches of a target file and return
+    (logloss, auc, ndcg_5, ndcg_10, hr_1, hr_5, hr_10, mrr, mean batch loss)."""
+    from sklearn.metrics import log_loss, roc_auc_score
+    preds, labels, target_iids, losses = [], [], [], []
+    t = time.time()
+    for batch_data in batches:
+        pred, label, loss = model.eval(sess, batch_data, reg_lambda)
+        preds += pred
+        labels += label
+        losses.append(loss)
+        target_iids += np.array(batch_data[5])[:, 0].tolist()
+    logloss = log_loss(labels, preds)
+    auc = roc_auc_score(labels, preds)
+    loss = sum(losses) / len(losses)
+    ndcg_5, ndcg_10, hr_1, hr_5, hr_10, mrr = get_ranking_quality(preds, target_iids, neg_sample_num)
+    if verbose:
+        print("EVAL TIME: %.4fs" % (time.time() - t))
+    return logloss, auc, ndcg_5, ndcg_10, hr_1, hr_5, hr_10, mrr, loss
