@@ -30,7 +30,7 @@ def test_scalar_helpers_match_reference_outputs():
 def test_hand_computed():
     # one line of 100: positive scored 3rd best -> rank index 2
     preds = np.linspace(0, 0.5, 100)
-    preds[0] = 0.495
+    preds[0] = 0.4925
     ids = np.arange(100) + 10
     q = h.get_ranking_quality(preds, ids)
     assert abs(q[0] - math.log(2) / math.log(4)) < 1e-12 and q[2] == 0 and q[3] == 1 and abs(q[5] - 1 / 3) < 1e-12
