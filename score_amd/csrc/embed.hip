@@ -429,7 +429,7 @@ int score_coattn_fwd_multi(CoattnArgs& a, int ncalls, int D, int B, hipStream_t 
 
 // Backward of 1 or 2 calls in a single grid + the per-call slab reductions into dW[c] (+=).
 int score_coattn_bwd_multi(CoattnArgs& a, int ncalls, int D, int B, float* const dW[2], float* scratch,
-                           int64_t scratch_floats, int atomic_scatter, hipStream_t s) {
+                           int64_t scratch_floats, int atomic_scatter, ColsumJobs* cq, hipStream_t s) {
   int spl = 1, total = 0, nblk[2] = {0, 0};
   size_t lds_bytes = 0;
   int64_t used = 0;
@@ -459,8 +459,9 @@ int score_coattn_bwd_multi(CoattnArgs& a, int ncalls, int D, int B, float* const
   if (a.mode == 0) {
     for (int c = 0; c < ncalls; ++c) {
       int Dx = a.c[c].nslots * 4;
-      SCORE_TRY(score_launch_colsum(a.c[c].slab, nblk[c], 2 * Dx, 2 * Dx, dW[c] + Dx, 1, scratch + used,
-                                    scratch_floats - used, s));
+      if (cq) SCORE_TRY(colsum_queue_add(cq, a.c[c].slab, nblk[c], 2 * Dx, 2 * Dx, dW[c] + Dx, 1));
+      else SCORE_TRY(score_launch_colsum(a.c[c].slab, nblk[c], 2 * Dx, 2 * Dx, dW[c] + Dx, 1, scratch + used,
+                                         scratch_floats - used, s));
     }
   }
   return 0;
@@ -501,7 +502,7 @@ extern "C" int score_coattn_bwd(const float* table, float* grad_table, int64_t n
   c.idx1 = idx1; c.idx2 = idx2; c.W = W; c.rsave = const_cast<float*>(rsave); c.g1 = g1; c.ld1 = ld1; c.g2 = g2; c.ld2 = ld2;
   c.ginfo = ginfo; c.ldi = ldi; c.dzsum = dzsum; c.F = F;
   float* dWs[2] = {dW, nullptr};
-  return score_coattn_bwd_multi(a, 1, D, B, dWs, scratch, scratch_floats, 1, (hipStream_t)stream);
+  return score_coattn_bwd_multi(a, 1, D, B, dWs, scratch, scratch_floats, 1, nullptr, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------ target rows (score.py:62-66, 210, 217)
@@ -594,7 +595,7 @@ int score_launch_target_bwd(float* grad_table, int D, int Fu, int Fi, int B, int
                             int off_ti, int off_tu, const float* query, const float* W1, const float* W2,
                             const float* dzsum1, const float* dzsum2, float* S, float* dW1, float* dB1,
                             float* dW2, float* dB2, float* dtgt_out, float* scratch, int64_t scratch_floats,
-                            hipStream_t s) {
+                            ColsumJobs* cq, hipStream_t s) {
   const bool coattn = W1 != nullptr;
   if (coattn) {
     hipLaunchKernelGGL(dzsum_reduce_kernel, dim3((2 * B + 255) / 256), dim3(256), 0, s, dzsum1, dzsum2, B, T, S);
@@ -611,8 +612,13 @@ int score_launch_target_bwd(float* grad_table, int D, int Fu, int Fi, int B, int
                          scratch_floats, s));
     SCORE_TRY(score_gemm(2, Du, 1, B, query, ldq, S + B, 1, dW2, 1, nullptr, 0, 1.f, nullptr, 0, scratch,
                          scratch_floats, s));
-    SCORE_TRY(score_launch_colsum(S, B, 1, 1, dB1, 0, scratch, scratch_floats, s));
-    SCORE_TRY(score_launch_colsum(S + B, B, 1, 1, dB2, 0, scratch, scratch_floats, s));
+    if (cq) {
+      SCORE_TRY(colsum_queue_add(cq, S, B, 1, 1, dB1, 0));
+      SCORE_TRY(colsum_queue_add(cq, S + B, B, 1, 1, dB2, 0));
+    } else {
+      SCORE_TRY(score_launch_colsum(S, B, 1, 1, dB1, 0, scratch, scratch_floats, s));
+      SCORE_TRY(score_launch_colsum(S + B, B, 1, 1, dB2, 0, scratch, scratch_floats, s));
+    }
   }
   return 0;
 }

@@ -127,6 +127,7 @@ struct WS {
   int64_t pcoef[2], dzcoef[2], dtgt, keys_in, keys_out, vals_in, vals_out, sort_temp, partials;
   int64_t n_occ, sort_temp_bytes, partial_floats;
   int64_t uid, unique_rows, meta, remap[6];
+  int64_t ca_slab, ca_slab_floats, cs_part, cs_part_floats;
   int64_t scratch_floats, total;
 };
 
@@ -169,6 +170,10 @@ void build_ws(const Dims& d, int B, WS* w) {
   w->S = take(2 * (int64_t)B);
   w->scratch_floats = 4 << 20;
   w->scratch = take(w->scratch_floats);
+  w->ca_slab_floats = 2 * 512 * 2 * (int64_t)(d.Di > d.Du ? d.Di : d.Du);
+  w->ca_slab = take(w->ca_slab_floats);
+  w->cs_part_floats = 1 << 20;
+  w->cs_part = take(w->cs_part_floats);
   // sorted pull-form scatter (scatter.hip)
   for (int c = 0; c < 2; ++c) { w->pcoef[c] = take(BT * d.K); w->dzcoef[c] = take(BT * d.K); }
   w->dtgt = take((int64_t)B * d.Dq);
@@ -404,6 +409,8 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
   const float* W = st->w;
   float* scratch = ws + w.scratch;
   const int64_t SF = w.scratch_floats;
+  ColsumJobs cq;
+  cq.n = 0; cq.part_used = 0;
   hipError_t he = hipMemsetAsync(gw, 0, P.n_floats * sizeof(float), s);
   if (he != hipSuccess) return (int)he;
 
@@ -412,25 +419,25 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
   // fc3: dW = f2^T dlogit, db = sum dlogit, dz2 = [f2>0] dlogit w3 / keep
   G(score_gemm(2, FC2, 1, B, ws + w.f2, FC2, ws + w.dlogit, 1, gw + P.fc_w[2], 1, nullptr, 0, 1.f, nullptr, 0,
                scratch, SF, s));
-  G(score_launch_colsum(ws + w.dlogit, B, 1, 1, gw + P.fc_b[2], 0, scratch, SF, s));
+  G(colsum_queue_add(&cq, ws + w.dlogit, B, 1, 1, gw + P.fc_b[2], 0));
   G(score_launch_outer_relu_bwd(B, FC2, ws + w.dlogit, W + P.fc_w[2], ws + w.f2, keep_prob, ws + w.dz2, s));
   // fc2
   G(score_gemm(2, FC1, FC2, B, ws + w.f1, FC1, ws + w.dz2, FC2, gw + P.fc_w[1], FC2, nullptr, 0, 1.f, nullptr, 0,
                scratch, SF, s));
-  G(score_launch_colsum(ws + w.dz2, B, FC2, FC2, gw + P.fc_b[1], 0, scratch, SF, s));
+  G(colsum_queue_add(&cq, ws + w.dz2, B, FC2, FC2, gw + P.fc_b[1], 0));
   G(score_gemm(1, B, FC1, FC2, ws + w.dz2, FC2, W + P.fc_w[1], FC2, ws + w.dz1, FC1, nullptr, 0, 1.f, nullptr, 0,
                scratch, SF, s));
   G(score_launch_relu_bwd(ws + w.dz1, ws + w.f1, B, FC1, FC1, FC1, keep_prob, s));
   // fc1 + bn1
   G(score_gemm(2, d.Dhead, FC1, B, ws + w.bn, d.Dhead, ws + w.dz1, FC1, gw + P.fc_w[0], FC1, nullptr, 0, 1.f,
                nullptr, 0, scratch, SF, s));
-  G(score_launch_colsum(ws + w.dz1, B, FC1, FC1, gw + P.fc_b[0], 0, scratch, SF, s));
+  G(colsum_queue_add(&cq, ws + w.dz1, B, FC1, FC1, gw + P.fc_b[0], 0));
   G(score_gemm(1, B, d.Dhead, FC1, ws + w.dz1, FC1, W + P.fc_w[0], FC1, ws + w.dbn, d.Dhead, nullptr, 0, 1.f,
                nullptr, 0, scratch, SF, s));
   const float rs = (float)(1.0 / sqrt(1.0 + 1e-3));
   // (w.bn is dead after the fc1 weight-gradient GEMM above: reuse it as the dgamma staging buffer)
   G(score_launch_bn_bwd(B, d.Dhead, ws + w.head_inp, W + P.bn_g, rs, ws + w.dbn, ws + w.dhead, gw + P.bn_g,
-                        gw + P.bn_b, ws + w.bn, scratch, SF, s));
+                        gw + P.bn_b, ws + w.bn, scratch, SF, &cq, s));
 
   EV(1);
   const float* dfinal[2] = {nullptr, nullptr};
@@ -442,18 +449,18 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
     // dense_5 (40 -> 1): dW = a2^T ds ; db = sum ds
     G(score_gemm(2, AT2, 1, BT, ws + w.a2, AT2, ws + w.ds, 1, gw + P.at_w[3], 1, nullptr, 0, 1.f, nullptr, 0,
                  scratch, SF, s));
-    G(score_launch_colsum(ws + w.ds, BT, 1, 1, gw + P.at_b[3], 0, scratch, SF, s));
+    G(colsum_queue_add(&cq, ws + w.ds, BT, 1, 1, gw + P.at_b[3], 0));
     // dense_4 (80 -> 40); da2 is already relu-masked
     G(score_gemm(2, AT1, AT2, BT, ws + w.a1, AT1, ws + w.da2, AT2, gw + P.at_w[2], AT2, nullptr, 0, 1.f, nullptr,
                  0, scratch, SF, s));
-    G(score_launch_colsum(ws + w.da2, BT, AT2, AT2, gw + P.at_b[2], 0, scratch, SF, s));
+    G(colsum_queue_add(&cq, ws + w.da2, BT, AT2, AT2, gw + P.at_b[2], 0));
     G(score_gemm(1, BT, AT1, AT2, ws + w.da2, AT2, W + P.at_w[2], AT2, ws + w.da1, AT1, nullptr, 0, 1.f, nullptr,
                  0, scratch, SF, s));
     G(score_launch_relu_bwd(ws + w.da1, ws + w.a1, BT, AT1, AT1, AT1, 1.f, s));
     // dense_3 (4Dk -> 80)
     G(score_gemm(2, 4 * d.Dk, AT1, BT, ws + w.ainp, 4 * d.Dk, ws + w.da1, AT1, gw + P.at_w[1], AT1, nullptr, 0,
                  1.f, nullptr, 0, scratch, SF, s));
-    G(score_launch_colsum(ws + w.da1, BT, AT1, AT1, gw + P.at_b[1], 0, scratch, SF, s));
+    G(colsum_queue_add(&cq, ws + w.da1, BT, AT1, AT1, gw + P.at_b[1], 0));
     G(score_gemm(1, BT, 4 * d.Dk, AT1, ws + w.da1, AT1, W + P.at_w[1], AT1, ws + w.dainp, 4 * d.Dk, nullptr, 0,
                  1.f, nullptr, 0, scratch, SF, s));
     G(score_launch_attn_inp_bwd(B, T, H, d.NI, ws + w.dainp, ws + w.q, ws + w.gru_out[0], ws + w.gru_out[1],
@@ -462,7 +469,7 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
     // dense_2 (query projection)
     G(score_gemm(2, d.Dq, d.Dk, B, ws + w.query, d.Dq, ws + w.dq, d.Dk, gw + P.at_w[0], d.Dk, nullptr, 0, 1.f,
                  nullptr, 0, scratch, SF, s));
-    G(score_launch_colsum(ws + w.dq, B, d.Dk, d.Dk, gw + P.at_b[0], 0, scratch, SF, s));
+    G(colsum_queue_add(&cq, ws + w.dq, B, d.Dk, d.Dk, gw + P.at_b[0], 0));
     G(score_gemm(1, B, d.Dq, d.Dk, ws + w.dq, d.Dk, W + P.at_w[0], d.Dk, ws + w.dquery, d.Dq, nullptr, 0, 1.f,
                  nullptr, 0, scratch, SF, s));
   } else {
@@ -506,8 +513,8 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
                  nullptr, 0, scratch, SF, s));
     G(score_gemm(2, H, H, BT, ws + w.rh[sd], H, dxp + 2 * H, 3 * H, gw + P.ck[sd] + (int64_t)d.I * H, H, nullptr, 0,
                  1.f, nullptr, 0, scratch, SF, s));
-    G(score_launch_colsum(dxp, BT, 2 * H, 3 * H, gw + P.gb[sd], 0, scratch, SF, s));
-    G(score_launch_colsum(dxp + 2 * H, BT, H, 3 * H, gw + P.cb[sd], 0, scratch, SF, s));
+    G(colsum_queue_add(&cq, dxp, BT, 2 * H, 3 * H, gw + P.gb[sd], 0));
+    G(colsum_queue_add(&cq, dxp + 2 * H, BT, H, 3 * H, gw + P.cb[sd], 0));
     // d x = dgates . Wxg^T + dcand . Wxc^T
     G(score_gemm(1, BT, d.I, 2 * H, dxp, 3 * H, Wg, 2 * H, ws + w.dxside[sd], d.I, nullptr, 0, 1.f, nullptr, 0,
                  scratch, SF, s));
@@ -537,14 +544,14 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
     c1.pcoef = ws + w.pcoef[1]; c1.dzcoef = ws + w.dzcoef[1];
     float* dWs[2] = {d.coattn ? gw + P.ca_w[0] : nullptr, d.coattn ? gw + P.ca_w[1] : nullptr};
     if (atomic || d.coattn)   // RCA in pull mode has nothing to prepare: every row gradient is G itself
-      G(score_coattn_bwd_multi(ca, 2, d.D, B, dWs, scratch, SF, atomic ? 1 : 0, s));
+      G(score_coattn_bwd_multi(ca, 2, d.D, B, dWs, ws + w.ca_slab, w.ca_slab_floats, atomic ? 1 : 0, &cq, s));
   }
   G(score_launch_target_bwd(grad_table, d.D, d.Fu, d.Fi, B, T, bt->target_user, bt->target_item,
                             d.attn ? ws + w.dquery : nullptr, d.Dq, ws + w.dhead, d.Dhead, d.off_ti, d.off_tu,
                             ws + w.query, d.coattn ? W + P.ca_w[0] : nullptr, d.coattn ? W + P.ca_w[1] : nullptr,
                             ws + w.dzsum[0], ws + w.dzsum[1], ws + w.S, d.coattn ? gw + P.ca_w[0] : nullptr,
                             d.coattn ? gw + P.ca_b[0] : nullptr, d.coattn ? gw + P.ca_w[1] : nullptr,
-                            d.coattn ? gw + P.ca_b[1] : nullptr, atomic ? nullptr : ws + w.dtgt, scratch, SF, s));
+                            d.coattn ? gw + P.ca_b[1] : nullptr, atomic ? nullptr : ws + w.dtgt, scratch, SF, &cq, s));
   if (!atomic) {
     PullArgs pa;
     memset(&pa, 0, sizeof(pa));
@@ -565,6 +572,7 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
     }
     G(score_launch_pull(pa, keys_out, vals_out, w.n_occ + 1, grad_table, ws + w.partials, w.partial_floats, s));
   }
+  G(colsum_queue_flush(&cq, ws + w.cs_part, w.cs_part_floats, s));
   EV(4);
   return 0;
 }

@@ -274,6 +274,67 @@ int score_launch_colsum(const float* X, int M, int N, int ld, float* out, int ac
   return 0;
 }
 
+// ---- many column sums in two launches (bias gradients and slab reductions of one backward pass)
+__global__ __launch_bounds__(256) void colsum_multi_stage1(const ColsumJobs jobs, float* __restrict__ part) {
+  __shared__ float sh[256];
+  const ColsumJob& j = jobs.job[blockIdx.z];
+  const int cols = j.cols, nty = 256 / cols;
+  if ((int)blockIdx.y >= j.nparts || (int)blockIdx.x * cols >= j.N) return;
+  const int tx = threadIdx.x % cols, ty = threadIdx.x / cols;
+  const int n = blockIdx.x * cols + tx;
+  const int m0 = blockIdx.y * j.rpb, m1 = min(j.M, m0 + j.rpb);
+  float s = 0.f;
+  if (n < j.N)
+    for (int m = m0 + ty; m < m1; m += nty) s += j.X[(int64_t)m * j.ld + n];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  if (ty == 0 && n < j.N) {
+    float t = 0.f;
+    for (int r = 0; r < nty; ++r) t += sh[r * cols + tx];
+    part[j.part_off + (int64_t)blockIdx.y * j.N + n] = t;
+  }
+}
+__global__ void colsum_multi_stage2(const ColsumJobs jobs, const float* __restrict__ part) {
+  const ColsumJob& j = jobs.job[blockIdx.y];
+  int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= j.N) return;
+  float s = 0.f;
+  for (int p = 0; p < j.nparts; ++p) s += part[j.part_off + (int64_t)p * j.N + n];
+  j.out[n] = j.acc ? j.out[n] + s : s;
+}
+
+int colsum_queue_add(ColsumJobs* q, const float* X, int M, int N, int ld, float* out, int acc) {
+  if (q->n >= COLSUM_MAX_JOBS) return SCORE_E_WORKSPACE;
+  ColsumJob& j = q->job[q->n++];
+  j.X = X; j.M = M; j.N = N; j.ld = ld; j.out = out; j.acc = acc;
+  int cols = 1;
+  while (cols < N && cols < 64) cols <<= 1;
+  j.cols = cols;
+  int rpb = 128, nparts = (M + rpb - 1) / rpb;
+  if (nparts > 32) { nparts = 32; rpb = (M + nparts - 1) / nparts; nparts = (M + rpb - 1) / rpb; }
+  j.rpb = rpb; j.nparts = nparts;
+  j.part_off = q->part_used;
+  q->part_used += (int64_t)nparts * N;
+  return 0;
+}
+
+int colsum_queue_flush(ColsumJobs* q, float* part, int64_t part_floats, hipStream_t s) {
+  if (q->n == 0) return 0;
+  if (q->part_used > part_floats) return SCORE_E_WORKSPACE;
+  int gx = 1, gx2 = 1;
+  for (int i = 0; i < q->n; ++i) {
+    gx = max(gx, (q->job[i].N + q->job[i].cols - 1) / q->job[i].cols);
+    gx2 = max(gx2, (q->job[i].N + 63) / 64);
+  }
+  hipLaunchKernelGGL(colsum_multi_stage1, dim3(gx, 32, q->n), dim3(256), 0, s, *q, part);
+  SCORE_CHECK_LAUNCH();
+  hipLaunchKernelGGL(colsum_multi_stage2, dim3(gx2, q->n), dim3(64), 0, s, *q, part);
+  SCORE_CHECK_LAUNCH();
+  q->n = 0;
+  q->part_used = 0;
+  return 0;
+}
+
 // dY <- dY * [Y > 0] / divisor      (relu / relu+dropout backward)
 __global__ void relu_bwd_kernel(float* __restrict__ dY, const float* __restrict__ Y, int64_t rows, int cols,
                                 int ldd, int ldy, float divisor) {

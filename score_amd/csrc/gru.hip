@@ -290,6 +290,10 @@ extern "C" int score_gru_bwd(int32_t B, int32_t T, int32_t H, const float* Wg, i
 // ======================================================================================
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define RRB 16
+// fast transcendental forms for the recurrence epilogues (v_exp_f32 / v_rcp_f32; abs error ~1e-7)
+__device__ __forceinline__ float sigmoid_fast(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanh_fast(float x) { return 1.0f - 2.0f * __frcp_rn(__expf(2.0f * x) + 1.0f); }
+
 
 template <int H>
 __global__ __launch_bounds__(256) void gru_fwd_reg_kernel(const GruArgs a) {
@@ -367,7 +371,7 @@ __global__ __launch_bounds__(256) void gru_fwd_reg_kernel(const GruArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = lq * 4 + r;
-        const float g = sigmoidf_(acc[tt][r] + xg[tt][r]);
+        const float g = sigmoid_fast(acc[tt][r] + xg[tt][r]);
         if (rok[r]) sd.gates[((int64_t)(b0 + i) * T + t) * 3 * H + j] = g;
         if (j < H) rhs[i * LD + j] = g * hs[i * LD + j];
         else us[i * LD + (j - H)] = g;
@@ -393,7 +397,7 @@ __global__ __launch_bounds__(256) void gru_fwd_reg_kernel(const GruArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = lq * 4 + r;
-        const float c = tanhf(acc2[tt][r] + xc[tt][r]);
+        const float c = tanh_fast(acc2[tt][r] + xc[tt][r]);
         const float u = us[i * LD + j], h = hs[i * LD + j];
         const float hn = u * h + (1.0f - u) * c;
         const bool live = t < len[r];
@@ -440,6 +444,8 @@ __global__ __launch_bounds__(256) void gru_bwd_reg_kernel(const GruArgs a) {
 #pragma unroll
     for (int ks = 0; ks < 2 * KS; ++ks) wgt[tt][ks] = tile < NT ? sd.Wg[(int64_t)j * sd.ldwg + ks * 4 + lq] : 0.f;
   }
+  // every thread owns the elements (row i = lq*4 + r, column j = (wave + 4*tt)*16 + lc) in all three
+  // phases, so the saved activations of a step are read once, one step ahead of their use
   int len[4];
   bool rok[4];
 #pragma unroll
@@ -448,36 +454,74 @@ __global__ __launch_bounds__(256) void gru_bwd_reg_kernel(const GruArgs a) {
     rok[r] = b < a.B;
     len[r] = rok[r] ? a.length[b] : 0;
   }
-  for (int e = tid; e < RRB * H; e += 256) {
-    const int i = e / H, j = e - i * H;
-    dh[i * LD + j] = (sd.dfinal && b0 + i < a.B) ? sd.dfinal[(int64_t)(b0 + i) * H + j] : 0.f;
+#pragma unroll
+  for (int tt = 0; tt < TW; ++tt) {
+    const int tile = wave + 4 * tt;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = lq * 4 + r, j = tile * 16 + lc;
+      if (tile < NT) dh[i * LD + j] = (sd.dfinal && rok[r]) ? sd.dfinal[(int64_t)(b0 + i) * H + j] : 0.f;
+    }
   }
+  float n_u[TW][4], n_c[TW][4], n_r[TW][4], n_hp[TW][4], n_do[TW][4];
+  auto prefetch = [&](int t) {
+#pragma unroll
+    for (int tt = 0; tt < TW; ++tt) {
+      const int tile = wave + 4 * tt;
+      const int j = tile * 16 + lc;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool ok = rok[r] && tile < NT && t >= 0 && t < len[r];
+        const int64_t row = (int64_t)(b0 + lq * 4 + r) * T + t;
+        n_r[tt][r] = ok ? sd.gates[row * 3 * H + j] : 0.f;
+        n_u[tt][r] = ok ? sd.gates[row * 3 * H + H + j] : 0.f;
+        n_c[tt][r] = ok ? sd.gates[row * 3 * H + 2 * H + j] : 0.f;
+        n_hp[tt][r] = (ok && t > 0) ? sd.out[(row - 1) * sd.ldo + j] : 0.f;
+        n_do[tt][r] = ok ? sd.dout[row * sd.lddo + j] : 0.f;
+      }
+    }
+  };
+  prefetch(T - 1);
   __syncthreads();
 
   for (int t = T - 1; t >= 0; --t) {
-    // phase 1 (elementwise): dpu, dpc ; dh <- dh_tot * u
-    for (int e = tid; e < RRB * H; e += 256) {
-      const int i = e / H, j = e - i * H;
-      const int b = b0 + i;
-      float v_dpc = 0.f, v_dpu = 0.f;
-      if (b < a.B) {
-        const int64_t row = (int64_t)b * T + t;
-        const bool live = t < a.length[b];
-        const float hp = t > 0 ? sd.out[(row - 1) * sd.ldo + j] : 0.f;
-        sd.hprev[row * H + j] = live ? hp : 0.f;
-        if (live) {
-          const float u = sd.gates[row * 3 * H + H + j], c = sd.gates[row * 3 * H + 2 * H + j];
-          const float d = dh[i * LD + j] + sd.dout[row * sd.lddo + j];
-          const float du = d * (hp - c), dc = d * (1.0f - u);
-          v_dpu = du * u * (1.0f - u);
-          v_dpc = dc * (1.0f - c * c);
-          dh[i * LD + j] = d * u;
-        }
-        sd.dxproj[row * 3 * H + H + j] = v_dpu;
-        sd.dxproj[row * 3 * H + 2 * H + j] = v_dpc;
+    float c_u[TW][4], c_c[TW][4], c_r[TW][4], c_hp[TW][4], c_do[TW][4];
+#pragma unroll
+    for (int tt = 0; tt < TW; ++tt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        c_u[tt][r] = n_u[tt][r]; c_c[tt][r] = n_c[tt][r]; c_r[tt][r] = n_r[tt][r];
+        c_hp[tt][r] = n_hp[tt][r]; c_do[tt][r] = n_do[tt][r];
       }
-      dpc[i * LD + j] = v_dpc;
-      dpg[i * LD2 + H + j] = v_dpu;
+    prefetch(t - 1);
+    // phase 1 (elementwise): dpu, dpc ; dh <- dh_tot * u
+#pragma unroll
+    for (int tt = 0; tt < TW; ++tt) {
+      const int tile = wave + 4 * tt;
+      if (tile >= NT) continue;
+      const int j = tile * 16 + lc;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = lq * 4 + r;
+        float v_dpc = 0.f, v_dpu = 0.f;
+        if (rok[r]) {
+          const int64_t row = (int64_t)(b0 + i) * T + t;
+          const bool live = t < len[r];
+          sd.hprev[row * H + j] = c_hp[tt][r];
+          if (live) {
+            const float u = c_u[tt][r], c = c_c[tt][r];
+            const float d = dh[i * LD + j] + c_do[tt][r];
+            const float du = d * (c_hp[tt][r] - c), dc = d * (1.0f - u);
+            v_dpu = du * u * (1.0f - u);
+            v_dpc = dc * (1.0f - c * c);
+            dh[i * LD + j] = d * u;
+          }
+          sd.dxproj[row * 3 * H + H + j] = v_dpu;
+          sd.dxproj[row * 3 * H + 2 * H + j] = v_dpc;
+        }
+        dpc[i * LD + j] = v_dpc;
+        dpg[i * LD2 + H + j] = v_dpu;
+      }
     }
     __syncthreads();
     // phase 2: d(rh) = dpc . Wc^T ; dpr = d(rh)*h_prev*r(1-r) ; dh += d(rh)*r
@@ -503,10 +547,8 @@ __global__ __launch_bounds__(256) void gru_bwd_reg_kernel(const GruArgs a) {
           float v_dpr = 0.f;
           if (rok[r]) {
             const int64_t row = (int64_t)(b0 + i) * T + t;
-            float rr = 0.f, hp = 0.f;
+            const float rr = c_r[tt][r], hp = c_hp[tt][r];   // both 0 past the length
             if (t < len[r]) {
-              rr = sd.gates[row * 3 * H + j];
-              hp = t > 0 ? sd.out[(row - 1) * sd.ldo + j] : 0.f;
               const float drh = acc[tt][r];
               v_dpr = drh * hp * rr * (1.0f - rr);
               dh[i * LD + j] += drh * rr;

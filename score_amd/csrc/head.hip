@@ -209,13 +209,18 @@ int score_launch_bn_fwd(int B, int Dh, const float* x, const float* gamma, const
 }
 int score_launch_bn_bwd(int B, int Dh, const float* x, const float* gamma, float rs, const float* dy, float* dx,
                         float* dgamma, float* dbeta, float* tmp, float* scratch, int64_t scratch_floats,
-                        hipStream_t s) {
+                        ColsumJobs* cq, hipStream_t s) {
   int64_t n = (int64_t)B * Dh;
   hipLaunchKernelGGL(bn_bwd_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, s, B, Dh, x, gamma, rs, dy, dx,
                      tmp);
   SCORE_CHECK_LAUNCH();
-  SCORE_TRY(score_launch_colsum(tmp, B, Dh, Dh, dgamma, 0, scratch, scratch_floats, s));
-  SCORE_TRY(score_launch_colsum(dy, B, Dh, Dh, dbeta, 0, scratch, scratch_floats, s));
+  if (cq) {
+    SCORE_TRY(colsum_queue_add(cq, tmp, B, Dh, Dh, dgamma, 0));
+    SCORE_TRY(colsum_queue_add(cq, dy, B, Dh, Dh, dbeta, 0));
+  } else {
+    SCORE_TRY(score_launch_colsum(tmp, B, Dh, Dh, dgamma, 0, scratch, scratch_floats, s));
+    SCORE_TRY(score_launch_colsum(dy, B, Dh, Dh, dbeta, 0, scratch, scratch_floats, s));
+  }
   return 0;
 }
 

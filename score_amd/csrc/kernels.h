@@ -2,6 +2,18 @@
 #pragma once
 #include "common.h"
 
+// gemm.hip
+#define COLSUM_MAX_JOBS 24
+struct ColsumJob { const float* X; float* out; int M, N, ld, acc, cols, rpb, nparts; int64_t part_off; };
+struct ColsumJobs { ColsumJob job[COLSUM_MAX_JOBS]; int n; int64_t part_used; };
+// deferred column sums: queue jobs during a pass, run them all in two launches at its end.
+// The queued X matrices must stay untouched until the flush.
+int colsum_queue_add(ColsumJobs* q, const float* X, int M, int N, int ld, float* out, int acc);
+int colsum_queue_flush(ColsumJobs* q, float* part, int64_t part_floats, hipStream_t s);
+int score_launch_colsum(const float* X, int M, int N, int ld, float* out, int accumulate,
+                        float* scratch, int64_t scratch_floats, hipStream_t s);
+int score_launch_relu_bwd(float* dY, const float* Y, int64_t rows, int cols, int ldd, int ldy,
+                          float divisor, hipStream_t s);
 // embed.hip
 struct CoattnCall {
   const int32_t* idx1; const int32_t* idx2;
@@ -21,7 +33,7 @@ struct CoattnArgs {
 };
 int score_coattn_fwd_multi(CoattnArgs& a, int ncalls, int D, int B, hipStream_t s);
 int score_coattn_bwd_multi(CoattnArgs& a, int ncalls, int D, int B, float* const dW[2], float* scratch,
-                           int64_t scratch_floats, int atomic_scatter, hipStream_t s);
+                           int64_t scratch_floats, int atomic_scatter, ColsumJobs* cq, hipStream_t s);
 int score_launch_target_fwd(const float* table, int D, int Fu, int Fi, int B, const int32_t* tu,
                             const int32_t* ti, float* query, int ldq, float* head, int ldh,
                             int off_ti, int off_tu, hipStream_t s);
@@ -30,12 +42,7 @@ int score_launch_target_bwd(float* grad_table, int D, int Fu, int Fi, int B, int
                             int off_ti, int off_tu, const float* query, const float* W1, const float* W2,
                             const float* dzsum1, const float* dzsum2, float* S /*[2][B]*/,
                             float* dW1, float* dB1, float* dW2, float* dB2, float* dtgt_out, float* scratch,
-                            int64_t scratch_floats, hipStream_t s);
-// gemm.hip
-int score_launch_colsum(const float* X, int M, int N, int ld, float* out, int accumulate,
-                        float* scratch, int64_t scratch_floats, hipStream_t s);
-int score_launch_relu_bwd(float* dY, const float* Y, int64_t rows, int cols, int ldd, int ldy,
-                          float divisor, hipStream_t s);
+                            int64_t scratch_floats, ColsumJobs* cq, hipStream_t s);
 // head.hip
 int score_launch_attn_build_inp(int B, int T, int H, int NI, const float* q, const float* ur, const float* ir,
                                 const float* info, float* inp, hipStream_t s);
@@ -54,7 +61,7 @@ int score_launch_bn_fwd(int B, int Dh, const float* x, const float* gamma, const
                         hipStream_t s);
 int score_launch_bn_bwd(int B, int Dh, const float* x, const float* gamma, float rs, const float* dy, float* dx,
                         float* dgamma, float* dbeta, float* tmp, float* scratch, int64_t scratch_floats,
-                        hipStream_t s);
+                        ColsumJobs* cq, hipStream_t s);
 int score_launch_head_out(int B, int NF, const float* f2, const float* w3, const float* b3, const int32_t* label,
                           float* logit, float* y, float* lossb, float* dlogit, float* loss, const float* wreg,
                           int64_t n_reg, float lambda, float* part, int Bglobal, hipStream_t s);

@@ -92,6 +92,7 @@ class SCOREBASE(object):
         self.fwd_events = self.bwd_events = None
         self.scatter_mode = 0      # 0: sorted pull-form scatter, 1: float atomics (score_hip.h)
         self.global_batch = 0      # >0: the loss mean runs over this many samples (data parallel)
+        self._side = None
         self._init_params(seed)
 
     # ------------------------------------------------------------------ parameters
@@ -222,10 +223,23 @@ class SCOREBASE(object):
         """Forward + backward; gradients land in self.w_g (without the L2 term) and
         self.table_g (dense [N,D]).  Returns the device workspace layout/buffer."""
         db = self.device_batch(batch_data)
+        plan_done = None
+        if self.scatter_mode == 0:
+            # occurrence sort for the pull-form scatter: depends on the indices only, so it runs on a
+            # side stream underneath the forward pass (its workspace regions are its own)
+            lay, ws = self._workspace(db.B)
+            st0 = self._state(ws)
+            cur = torch.cuda.current_stream(self.device)
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=self.device)
+            self._side.wait_stream(cur)
+            with torch.cuda.stream(self._side):
+                _lib.check(self.lib.score_index_plan(C.byref(self.cfg), C.byref(st0), C.byref(db.struct), 1, 0,
+                                                     self._stream()), "score_index_plan")
+                plan_done = self._side.record_event()
         lay, ws, st = self._forward(db, reg_lambda, keep_prob, dropout_masks)
-        if self.scatter_mode == 0:     # occurrence sort for the pull-form scatter (indices only)
-            _lib.check(self.lib.score_index_plan(C.byref(self.cfg), C.byref(st), C.byref(db.struct), 1, 0,
-                                                 self._stream()), "score_index_plan")
+        if plan_done is not None:
+            torch.cuda.current_stream(self.device).wait_event(plan_done)
         self.table_g.zero_()
         rc = self.lib.score_backward(C.byref(self.cfg), C.byref(st), C.byref(db.struct), float(keep_prob),
                                      _ptr(self.w_g), _ptr(self.table_g), self._event_array(self.bwd_events),
