@@ -193,6 +193,14 @@ def main():
         if dist is not None:
             dist.destroy_process_group()
         return
+    # HBM bytes per launch of the gather kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
+    # --pmc WRITE_SIZE, separate runs, gfx950 FETCH_SIZE x2 correction; tools/summarize_profile.py)
+    traffic = None
+    try:
+        pj = json.load(open(os.path.join(ROOT, "profiles", "r01_%s_pmc_traffic.json" % args.config)))
+        traffic = [v["hbm_bytes"] for k, v in pj["kernels"].items() if "coattn_fwd_kernel" in k][0]
+    except Exception:
+        traffic = None
     out = {
         "metric": "train samples/sec @ batch=1024",
         "value": B * world_size * args.steps / dt,
@@ -214,7 +222,7 @@ def main():
                    "final_loss": loss},
         "roofline": {"kernel": "coattn_fwd_kernel (fused embedding gather + co-attention, both calls, one launch)",
                      "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": ab * B, "avg_launch_ms": stages["fwd_gather_coattn"]},
         "roofline_other": {
             "adam_dense (7 fp32 streams over table shard + dense vars)": {

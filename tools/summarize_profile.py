@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 output directories (gpurun_out/...) into the small CSV/JSON summaries
+committed under profiles/.
+
+  python tools/summarize_profile.py stats  <rocprof_dir> <out.csv>          # --kernel-trace --stats
+  python tools/summarize_profile.py pmc    <fetch_dir> <write_dir> <out.json> [tag]   # --pmc passes
+
+PMC traffic follows /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE and WRITE_SIZE
+are in KiB, collected in separate passes; on gfx950 FETCH_SIZE reports half the bytes of a 16-B/lane
+coalesced read stream, so hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (calibrated here on
+adam_kernel: 4 read + 3 write streams of N*D*4 bytes reproduce to within 1 %).
+"""
+import collections
+import csv
+import glob
+import json
+import sys
+
+
+def stats(src, out):
+    f = glob.glob(src + "/*/*_kernel_stats.csv")[0]
+    rows = list(csv.DictReader(open(f)))
+    with open(out, "w") as o:
+        w = csv.writer(o)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+        for r in rows:
+            w.writerow([r["Name"], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"],
+                        r["MaxNs"]])
+
+
+def _per_kernel(d, counter):
+    f = glob.glob(d + "/*/*_counter_collection.csv")[0]
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] == counter:
+            acc[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+    return acc
+
+
+def pmc(fetch_dir, write_dir, out, tag=""):
+    f, w = _per_kernel(fetch_dir, "FETCH_SIZE"), _per_kernel(write_dir, "WRITE_SIZE")
+    res = {"tag": tag, "note": "per-dispatch averages; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 "
+                               "(gfx950 FETCH_SIZE correction, MI355X_MICROARCH.md HBM section)", "kernels": {}}
+    for k in sorted(f, key=lambda k: -sum(f[k])):
+        fa = sum(f[k]) / len(f[k])
+        wa = sum(w.get(k, [0])) / max(len(w.get(k, [0])), 1)
+        res["kernels"][k] = {"dispatches": len(f[k]), "FETCH_SIZE_KiB": fa, "WRITE_SIZE_KiB": wa,
+                             "hbm_bytes": (2 * fa + wa) * 1024}
+    json.dump(res, open(out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "stats":
+        stats(sys.argv[2], sys.argv[3])
+    else:
+        pmc(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5] if len(sys.argv) > 5 else "")
