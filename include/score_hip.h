@@ -221,6 +221,35 @@ int score_backward(const score_config_t* cfg, const score_state_t* st, const sco
                    float keep_prob, float* grad_w, float* grad_table, void* const* stage_events,
                    void* stream);
 
+/* ---- "next" row f1: batch assembly on the device -------------------------------------- */
+
+/* In-memory temporal bipartite graph (replaces the MongoDB documents {uid|iid,'1hop','2hop'} of
+ * graph_storage.py:78-246).  CSR over (entity, time slice): the neighbours of 0-based entity e in
+ * slice t are nbr[off[e*S + t] .. off[e*S + t + 1]).  Ids follow feateng_tmall.py:72-101: users
+ * 1..U, items U+1..U+I.  user_rows [U, Fu] / item_rows [I, Fi] hold [id, side features...]. */
+typedef struct {
+  const int64_t* user_off1; const int32_t* user_nbr1;   /* user -> items it interacted with   */
+  const int64_t* user_off2; const int32_t* user_nbr2;   /* user -> co-interacting users        */
+  const int64_t* item_off1; const int32_t* item_nbr1;   /* item -> users                       */
+  const int64_t* item_off2; const int32_t* item_nbr2;   /* item -> co-interacted items         */
+  const int32_t* user_rows; const int32_t* item_rows;
+  int32_t n_users, n_items, time_slice_num, user_fnum, item_fnum;
+} score_graph_t;
+
+typedef struct {   /* the 8-tuple of graph_loader.py:383, device int32, B = n_lines * (1 + neg) */
+  int32_t* user_1hop; int32_t* user_2hop; int32_t* item_1hop; int32_t* item_2hop;
+  int32_t* target_user; int32_t* target_item; int32_t* label; int32_t* length;
+} score_batch_out_t;
+
+/* GraphHandler.gen_{user,item}_history + GraphLoader.worker (graph_loader.py:169-277, 340-383, mode
+ * 'rs'): uids [n_lines], iids [n_lines*(1+neg)] (positive first).  1-hop lists are truncated /
+ * cyclically padded exactly as the reference does; 2-hop lists are sampled K times with replacement
+ * from a counter-based generator (`seed`), so draws differ from NumPy's but have its distribution. */
+int score_batch_assemble(const score_graph_t* g, const int32_t* uids, const int32_t* iids,
+                         int32_t n_lines, int32_t neg_sample_num, int32_t T, int32_t K,
+                         int32_t start_time, int32_t pred_time, uint64_t seed,
+                         const score_batch_out_t* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -45,7 +45,20 @@ class State(C.Structure):
                 ("workspace_bytes", C.c_int64), ("scatter_mode", C.c_int32), ("global_batch", C.c_int32)]
 
 
+class Graph(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("user_off1", "user_nbr1", "user_off2", "user_nbr2", "item_off1", "item_nbr1",
+                                           "item_off2", "item_nbr2", "user_rows", "item_rows")] + \
+               [(n, C.c_int32) for n in ("n_users", "n_items", "time_slice_num", "user_fnum", "item_fnum")]
+
+
+class BatchOut(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("user_1hop", "user_2hop", "item_1hop", "item_2hop", "target_user",
+                                           "target_item", "label", "length")]
+
+
 _SIGS = {
+    "score_batch_assemble": [C.POINTER(Graph), c_i, c_i, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                             C.c_int32, C.c_uint64, C.POINTER(BatchOut), C.c_void_p],
     "score_param_layout": [C.POINTER(Config), C.POINTER(ParamEntry), C.c_int32, C.POINTER(C.c_int64),
                            C.POINTER(C.c_int64)],
     "score_workspace_layout": [C.POINTER(Config), C.c_int32, C.POINTER(Workspace)],

@@ -1,0 +1,181 @@
+"""In-memory temporal graph store + device-side batch loader.
+
+Replaces, for the training loop, the reference's MongoDB documents (code/graph_storage.py:78-246:
+per entity and time slice a 1-hop list, a sampled 2-hop list) and its loader processes
+(code/score/graph_loader.py:279-402).  The graph is built once on the host (it is preprocessing in the
+reference too), lives in HBM as CSR, and every batch is assembled by one HIP launch
+(score_batch_assemble, include/score_hip.h) into the int32 tensors score.py:21-30 feeds on.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .model import DeviceBatch, _ptr
+
+
+def _csr(lists_per_cell):
+    lens = np.fromiter((len(l) for l in lists_per_cell), dtype=np.int64, count=len(lists_per_cell))
+    off = np.zeros(len(lists_per_cell) + 1, dtype=np.int64)
+    np.cumsum(lens, out=off[1:])
+    nbr = np.fromiter((x for l in lists_per_cell for x in l), dtype=np.int32, count=int(off[-1]))
+    return off, nbr
+
+
+class TemporalGraph(object):
+    """CSR over (entity, slice) for both sides + feature rows.  Ids: users 1..U, items U+1..U+I
+    (feateng_tmall.py:72-101)."""
+
+    def __init__(self, n_users, n_items, time_slice_num, user_csr, item_csr, user_rows, item_rows):
+        self.U, self.I, self.S = int(n_users), int(n_items), int(time_slice_num)
+        self.user_csr, self.item_csr = user_csr, item_csr          # dicts: off1, nbr1, off2, nbr2
+        self.user_rows = np.ascontiguousarray(user_rows, dtype=np.int32)
+        self.item_rows = np.ascontiguousarray(item_rows, dtype=np.int32)
+        assert self.user_rows.shape[0] == self.U and self.item_rows.shape[0] == self.I
+        self.Fu, self.Fi = self.user_rows.shape[1], self.item_rows.shape[1]
+        self._dev = None
+
+    # ---- construction -----------------------------------------------------------------
+    @classmethod
+    def from_padded(cls, n_users, n_items, S, u1, u1len, u2, u2len, i1, i1len, i2, i2len, user_rows, item_rows):
+        """From padded per-(entity, slice) lists: x[e, t, :xlen[e, t]]."""
+        def side(a1, l1, a2, l2):
+            c1 = [a1[e, t, :l1[e, t]].tolist() for e in range(a1.shape[0]) for t in range(S)]
+            c2 = [a2[e, t, :l2[e, t]].tolist() for e in range(a2.shape[0]) for t in range(S)]
+            o1, n1 = _csr(c1)
+            o2, n2 = _csr(c2)
+            return dict(off1=o1, nbr1=n1, off2=o2, nbr2=n2)
+        return cls(n_users, n_items, S, side(u1, u1len, u2, u2len), side(i1, i1len, i2, i2len), user_rows, item_rows)
+
+    @classmethod
+    def from_log(cls, uid, iid, t_idx, n_users, n_items, time_slice_num, user_rows, item_rows,
+                 max_1hop=10, max_2hop=100, seed=11):
+        """From a remapped behaviour log (graph_storage.py:93-128 construct_coll_1hop, :130-246
+        construct_coll_2hop): 1-hop = neighbours in log order; 2-hop of a node in slice t = the slice-t
+        1-hop lists of (at most max_1hop of) its neighbours whose slice degree is > 1, each cut to
+        max_1hop, the union down-sampled to max_2hop."""
+        rng = np.random.Generator(np.random.PCG64(seed))
+        S, U, I = time_slice_num, n_users, n_items
+        u1 = [[] for _ in range(U * S)]
+        i1 = [[] for _ in range(I * S)]
+        for u, i, t in zip(np.asarray(uid).tolist(), np.asarray(iid).tolist(), np.asarray(t_idx).tolist()):
+            u1[(u - 1) * S + t].append(i)
+            i1[(i - U - 1) * S + t].append(u)
+
+        def two_hop(own, other, other_base, n):
+            out = []
+            for e in range(n):
+                for t in range(S):
+                    nb = own[e * S + t]
+                    if len(nb) > max_1hop:
+                        nb = [nb[j] for j in rng.permutation(len(nb))[:max_1hop]]
+                    acc = []
+                    for x in nb:
+                        lst = other[(x - other_base) * S + t]
+                        if len(lst) > 1:
+                            acc += lst[:max_1hop]
+                    if len(acc) > max_2hop:
+                        acc = [acc[j] for j in rng.permutation(len(acc))[:max_2hop]]
+                    out.append(acc)
+            return out
+        u2 = two_hop(u1, i1, U + 1, U)
+        i2 = two_hop(i1, u1, 1, I)
+        uo1, un1 = _csr(u1)
+        uo2, un2 = _csr(u2)
+        io1, in1 = _csr(i1)
+        io2, in2 = _csr(i2)
+        return cls(U, I, S, dict(off1=uo1, nbr1=un1, off2=uo2, nbr2=un2),
+                   dict(off1=io1, nbr1=in1, off2=io2, nbr2=in2), user_rows, item_rows)
+
+    # ---- device residency -------------------------------------------------------------
+    def to_device(self, device=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("TemporalGraph.to_device needs an AMD GPU (HIP); batch assembly has no CPU path")
+        dev = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        d = {"u_" + k: t(v) for k, v in self.user_csr.items()}
+        d.update({"i_" + k: t(v) for k, v in self.item_csr.items()})
+        # an empty neighbour array still needs a valid pointer
+        for k in list(d):
+            if d[k].numel() == 0:
+                d[k] = torch.zeros((1,), dtype=d[k].dtype, device=dev)
+        d["user_rows"], d["item_rows"] = t(self.user_rows), t(self.item_rows)
+        self._dev = d
+        self.device = dev
+        self.struct = _lib.Graph(_ptr(d["u_off1"]), _ptr(d["u_nbr1"]), _ptr(d["u_off2"]), _ptr(d["u_nbr2"]),
+                                 _ptr(d["i_off1"]), _ptr(d["i_nbr1"]), _ptr(d["i_off2"]), _ptr(d["i_nbr2"]),
+                                 _ptr(d["user_rows"]), _ptr(d["item_rows"]), self.U, self.I, self.S, self.Fu, self.Fi)
+        return self
+
+
+class _AssembledBatch(DeviceBatch):
+    def __init__(self, tensors, B):      # bypass host conversion: tensors are already int32 on the device
+        self.tensors = tensors
+        self.B = B
+        self.struct = _lib.Batch(*[_ptr(t) for t in tensors], B)
+
+    def __len__(self):
+        return 8
+
+    def __getitem__(self, i):             # train_score.py:157 reads batch_data[5]
+        return self.tensors[i]
+
+
+class DeviceGraphLoader(object):
+    """Iterator with the constructor shape of GraphLoader (graph_loader.py:279-281); yields device
+    batches accepted by SCORE.train / SCORE.eval.  `target_lines`: iterable of 'uid,pos_iid,neg...'
+    strings or of (uid, [iids]) pairs (gen_target.py's target_<t>.txt format)."""
+
+    def __init__(self, graph, batch_size, target_lines, start_time, pred_time, neg_sample_num,
+                 max_time_len, obj_per_time_slice, seed=1111):
+        if batch_size % (1 + neg_sample_num) != 0:
+            raise ValueError("batch size should be time of {}".format(1 + neg_sample_num))    # :289-291
+        if graph._dev is None:
+            graph.to_device()
+        self.g, self.lib = graph, _lib.load()
+        self.lines_per_batch = batch_size // (1 + neg_sample_num)
+        self.neg, self.start_time, self.pred_time = neg_sample_num, start_time, pred_time
+        self.T, self.K, self.seed = max_time_len, obj_per_time_slice, seed
+        uids, iids = [], []
+        for line in target_lines:
+            if isinstance(line, str):
+                parts = line.strip().split(',')
+                u, its = int(parts[0]), [int(x) for x in parts[1:2 + neg_sample_num]]
+            else:
+                u, its = int(line[0]), [int(x) for x in line[1]][:1 + neg_sample_num]
+            uids.append(u)
+            iids += its
+        self.uids = torch.tensor(uids, dtype=torch.int32, device=graph.device)
+        self.iids = torch.tensor(iids, dtype=torch.int32, device=graph.device)
+        self.n_lines = len(uids)
+        self._pos = 0
+        self._batch_no = 0
+
+    def __iter__(self):
+        return self
+
+    def __len__(self):
+        return (self.n_lines + self.lines_per_batch - 1) // self.lines_per_batch
+
+    def __next__(self):
+        if self._pos >= self.n_lines:
+            raise StopIteration
+        n = min(self.lines_per_batch, self.n_lines - self._pos)      # the last batch is short (:321-324)
+        c = 1 + self.neg
+        B, g, T, K = n * c, self.g, self.T, self.K
+        i32 = dict(dtype=torch.int32, device=g.device)
+        tens = [torch.empty((B, T, K, g.Fi), **i32), torch.empty((B, T, K, g.Fu), **i32),
+                torch.empty((B, T, K, g.Fu), **i32), torch.empty((B, T, K, g.Fi), **i32),
+                torch.empty((B, g.Fu), **i32), torch.empty((B, g.Fi), **i32),
+                torch.empty((B,), **i32), torch.empty((B,), **i32)]
+        out = _lib.BatchOut(*[_ptr(t) for t in tens])
+        u = self.uids[self._pos:self._pos + n]
+        it = self.iids[self._pos * c:(self._pos + n) * c]
+        rc = self.lib.score_batch_assemble(C.byref(g.struct), _ptr(u), _ptr(it), n, self.neg, T, K, self.start_time,
+                                           self.pred_time, C.c_uint64(self.seed + 7919 * self._batch_no),
+                                           C.byref(out), C.c_void_p(torch.cuda.current_stream(g.device).cuda_stream))
+        _lib.check(rc, "score_batch_assemble")
+        self._pos += n
+        self._batch_no += 1
+        return _AssembledBatch(tens, B)

@@ -1,0 +1,113 @@
+"""Device-side batch assembly (row f1) against batches produced by the REFERENCE loader
+(graph_loader.py GraphHandler, tests/golden/g4_loader.npz)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+Z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g4_loader.npz"))
+
+
+def build(tag):
+    from score_amd.graph import TemporalGraph
+    U, I, S, K, Fu, Fi, st = [int(x) for x in Z[tag + "/dims"]]
+    g = TemporalGraph.from_padded(U, I, S, Z[tag + "/user_1hop"], Z[tag + "/user_1hop_len"], Z[tag + "/user_2hop"],
+                                  Z[tag + "/user_2hop_len"], Z[tag + "/item_1hop"], Z[tag + "/item_1hop_len"],
+                                  Z[tag + "/item_2hop"], Z[tag + "/item_2hop_len"], Z[tag + "/user_feat"],
+                                  Z[tag + "/item_feat"])
+    return g, (U, I, S, K, Fu, Fi, st)
+
+
+@pytest.mark.parametrize("tag", ["f34", "f12"])
+def test_assembled_batches_match_reference_loader(tag):
+    from score_amd.graph import DeviceGraphLoader
+    g, (U, I, S, K, Fu, Fi, st) = build(tag)
+    T = S - 1 - st
+    for pred_time in (S - 3, S - 1):
+        p = "%s_p%d/" % (tag, pred_time)
+        uids, iids = Z[p + "uids"].tolist(), Z[p + "iids"].tolist()
+        # neg_sample_num = 0: one (user, item) line each, exactly the golden calls
+        loader = DeviceGraphLoader(g, len(uids), [(u, [i]) for u, i in zip(uids, iids)], st, pred_time, 0, T, K)
+        b = next(loader)
+        got = [t.cpu().numpy() for t in b.tensors]
+        # 1-hop tensors: truncation, cyclic padding, dummy slices, tail replication, feature expansion -> exact
+        assert np.array_equal(got[0], Z[p + "user_1hop"])
+        assert np.array_equal(got[2], Z[p + "item_1hop"])
+        # 2-hop tensors: sampled; same dummy pattern, replicated tail, every draw inside the 2-hop list,
+        # feature rows consistent with the drawn id
+        for gi, name, ent, first, feat in ((1, "user_2hop", uids, 1, Z[tag + "/user_feat"]),
+                                           (3, "item_2hop", iids, U + 1, Z[tag + "/item_feat"])):
+            ref, mine = Z[p + name], got[gi]
+            assert mine.shape == ref.shape
+            assert np.array_equal(mine[..., 0] == 0, ref[..., 0] == 0)
+            length = pred_time - st
+            for t in range(length, T):
+                assert np.array_equal(mine[:, t], mine[:, length - 1])
+            lists, lens = Z["%s/%s" % (tag, name)], Z["%s/%s_len" % (tag, name)]
+            for s, e in enumerate(ent):
+                for t in range(length):
+                    allowed = set(lists[e - first, st + t, :lens[e - first, st + t]].tolist())
+                    drawn = mine[s, t, :, 0]
+                    assert all(int(x) in allowed for x in drawn if x != 0)
+            nz = mine[..., 0] != 0
+            assert np.array_equal(mine[nz], feat[mine[..., 0][nz] - first])
+        assert np.array_equal(got[4], Z[tag + "/user_feat"][np.asarray(uids) - 1])
+        assert np.array_equal(got[5], Z[tag + "/item_feat"][np.asarray(iids) - U - 1])
+        assert got[6].tolist() == [1] * len(uids) and got[7].tolist() == [pred_time - st] * len(uids)
+
+
+def test_loader_iteration_negatives_and_training():
+    # 1 positive + 1 negative per line (train_score.py:18), user tensors shared by both candidates,
+    # short last batch, and the assembled batches train the model
+    from score_amd.graph import DeviceGraphLoader
+    from score_amd.model import SCORE
+    g, (U, I, S, K, Fu, Fi, st) = build("f34")
+    T = S - 1 - st
+    rng = np.random.default_rng(0)
+    lines = ["%d,%d,%d\n" % (rng.integers(1, U + 1), rng.integers(U + 1, U + I + 1), rng.integers(U + 1, U + I + 1))
+             for _ in range(7)]
+    loader = DeviceGraphLoader(g, 4, lines, st, S - 2, 1, T, K)
+    assert len(loader) == 4
+    N = int(max(Z["f34/user_feat"].max(), Z["f34/item_feat"].max())) + 1
+    m = SCORE(N, 8, 16, T, K, Fu, Fi)
+    sizes, losses = [], []
+    for b in loader:
+        t = [x.cpu().numpy() for x in b.tensors]
+        sizes.append(b.B)
+        assert np.array_equal(t[0][0::2], t[0][1::2]) and np.array_equal(t[1][0::2], t[1][1::2])
+        assert np.array_equal(t[4][0::2], t[4][1::2]) and t[6].tolist() == [1, 0] * (b.B // 2)
+        losses.append(m.train(None, b, 1e-3, 1e-4))
+        pred, label, _ = m.eval(None, b, 1e-4)
+        assert len(pred) == b.B and label == t[6].tolist()
+        assert np.array_equal(np.asarray(b[5].cpu())[:, 0], t[5][:, 0])
+    assert sizes == [4, 4, 4, 2] and all(np.isfinite(losses))
+    # same seed -> same batches; the 2-hop draws are uniform over the list
+    l1 = DeviceGraphLoader(g, 4, lines, st, S - 2, 1, T, K, seed=5)
+    l2 = DeviceGraphLoader(g, 4, lines, st, S - 2, 1, T, K, seed=5)
+    for a, b in zip(l1, l2):
+        assert all(torch.equal(x, y) for x, y in zip(a.tensors, b.tensors))
+
+
+def test_two_hop_draws_are_uniform():
+    from score_amd.graph import TemporalGraph, DeviceGraphLoader
+    U, I, S, K = 1, 4, 2, 32
+    u2 = np.zeros((U, S, 4), np.int32)
+    u2[0, 0] = [1, 1, 1, 1]
+    i2 = np.zeros((I, S, 4), np.int32)
+    i2[:, 0] = [2, 3, 4, 5]
+    z1 = np.zeros((U, S, 1), np.int32)
+    zi = np.zeros((I, S, 1), np.int32)
+    zi[:, 0, 0] = 1
+    g = TemporalGraph.from_padded(U, I, S, z1, np.zeros((U, S), np.int32), u2, np.full((U, S), 4) * np.array([[1, 0]]),
+                                  zi, np.ones((I, S), np.int32) * np.array([[1, 0]]), i2,
+                                  np.full((I, S), 4) * np.array([[1, 0]]), np.array([[1]], np.int32),
+                                  np.arange(2, 6, dtype=np.int32)[:, None])
+    counts = np.zeros(6)
+    for seed in range(40):
+        b = next(DeviceGraphLoader(g, 4, [(1, [2]), (1, [3]), (1, [4]), (1, [5])], 0, 1, 0, 1, K, seed=seed))
+        d = b.tensors[3].cpu().numpy()[:, 0, :, 0]
+        counts += np.bincount(d.ravel(), minlength=6)
+    frac = counts[2:] / counts[2:].sum()
+    assert counts[:2].sum() == 0 and np.abs(frac - 0.25).max() < 0.03
