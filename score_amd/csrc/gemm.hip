@@ -161,8 +161,17 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slab, int nsplit,
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (int64_t)M * N) return;
   int row = (int)(i / N), col = (int)(i - (int64_t)row * N);
+  const int64_t stride = (int64_t)M * N;
   float s = 0.f;
-  for (int z = 0; z < nsplit; ++z) s += slab[(int64_t)z * M * N + i];
+  int z = 0;
+  for (; z + 8 <= nsplit; z += 8) {   // 8 independent loads in flight, summed in slab order
+    float v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = slab[(int64_t)(z + q) * stride + i];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s += v[q];
+  }
+  for (; z < nsplit; ++z) s += slab[(int64_t)z * stride + i];
   float v = epilogue(s, row, col, N, bias, flags, keep, mask, seed);
   float* dst = C + (int64_t)row * ldc + col;
   *dst = (flags & F_ACC) ? *dst + v : v;
@@ -189,7 +198,7 @@ extern "C" int score_gemm(int32_t trans, int32_t M, int32_t N, int32_t K, const 
   int nsplit = 1;
   int64_t tiles = (int64_t)grid.x * grid.y;
   if (tiles < 256 && K >= 512 && scratch) {
-    nsplit = (int)((512 + tiles - 1) / tiles);
+    nsplit = (int)((320 + tiles - 1) / tiles);   // ~1.25 blocks per CU: longer K chunks, smaller slabs
     int max_split = K / 128;
     if (nsplit > max_split) nsplit = max_split;
     while (nsplit > 1 && (int64_t)nsplit * M * N > scratch_floats) --nsplit;
