@@ -136,7 +136,9 @@ int score_coattn_bwd(const float* table, float* grad_table, int64_t n_rows, int3
  * trans: 0 = A[M,K] B[K,N];  1 = A[M,K] B[N,K]^T;  2 = A[K,M]^T B[K,N] (K is the
  * reduced dim).  flags: 1 add bias[N], 2 relu, 4 accumulate into C,
  * 8 dropout (tf.nn.dropout: x/keep * mask; mask from drop_mask bytes or, if null,
- * from a counter hash of drop_seed). scratch is used for split-K (trans 2). */
+ * from a counter hash of drop_seed), 16 use the bf16x3 matrix-core product (fp32-accurate,
+ * see score_state_t.gemm_mode) on the shapes where it measured faster, 32 use it whenever legal.
+ * scratch is used for split-K. */
 int score_gemm(int32_t trans, int32_t M, int32_t N, int32_t K,
                const float* A, int32_t lda, const float* Bm, int32_t ldb,
                float* C, int32_t ldc, const float* bias, int32_t flags,
@@ -181,6 +183,11 @@ typedef struct {
                            2 = pull into the unique-row order of a sharded plan (grad_table
                            is the [U, D] gradient of the gathered mini-table)            */
   int32_t global_batch; /* samples the loss mean runs over (data parallel); 0 = batch->B  */
+  int32_t gemm_mode;    /* dense layers: 0 = v_mfma_f32_32x32x2_f32 (bitwise an fp32 fmaf chain),
+                           1 = "bf16x3": every fp32 operand split exactly into three bf16 and
+                           six v_mfma_f32_32x32x16_bf16 per k-step -- fp32 accuracy (dropped
+                           terms < 2^-24 relative) at 2.7x the matrix-core rate              */
+  int32_t reserved;
 } score_state_t;
 
 /* Index plan of a batch (depends on the indices only; run it before score_backward, on

@@ -42,7 +42,8 @@ class Workspace(C.Structure):
 
 class State(C.Structure):
     _fields_ = [("table", c_f), ("n_table_rows", C.c_int64), ("w", c_f), ("workspace", c_f),
-                ("workspace_bytes", C.c_int64), ("scatter_mode", C.c_int32), ("global_batch", C.c_int32)]
+                ("workspace_bytes", C.c_int64), ("scatter_mode", C.c_int32), ("global_batch", C.c_int32),
+                ("gemm_mode", C.c_int32), ("reserved", C.c_int32)]
 
 
 class Graph(C.Structure):

@@ -9,7 +9,7 @@
 
 namespace {
 
-enum { GF_BIAS = 1, GF_RELU = 2, GF_ACC = 4, GF_DROP = 8 };
+enum { GF_BIAS = 1, GF_RELU = 2, GF_ACC = 4, GF_DROP = 8, GF_X3 = 16 };
 const int FC1 = 200, FC2 = 80, AT1 = 80, AT2 = 40;
 
 struct Dims {
@@ -199,6 +199,10 @@ void build_ws(const Dims& d, int B, WS* w) {
 }
 
 #define G(call) SCORE_TRY(call)
+// every GEMM launched from this file ORs in `x3`: GF_X3 when the caller's state asks for the
+// fp32-accurate bf16x3 matrix-core product (score_state_t.gemm_mode), else 0
+#define score_gemm(tr, M_, N_, K_, A_, lda_, B_, ldb_, C_, ldc_, bias_, fl_, ...) \
+  score_gemm(tr, M_, N_, K_, A_, lda_, B_, ldb_, C_, ldc_, bias_, (fl_) | x3, __VA_ARGS__)
 // optional stage boundary events (hipEvent_t handles) recorded on the launch stream
 #define EV(i)                                                                \
   do {                                                                       \
@@ -311,6 +315,7 @@ extern "C" int score_forward(const score_config_t* cfg, const score_state_t* st,
   float* ws = st->workspace;
   const float* W = st->w;
   float* scratch = ws + w.scratch;
+  const int x3 = st->gemm_mode == 1 ? GF_X3 : 0;
 
   // target rows -> query [tu | ti] and head_inp [.., ti, tu]      (score.py:62-66, 210, 217)
   G(score_launch_target_fwd(st->table, d.D, d.Fu, d.Fi, B, bt->target_user, bt->target_item, ws + w.query, d.Dq,
@@ -409,6 +414,7 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
   const float* W = st->w;
   float* scratch = ws + w.scratch;
   const int64_t SF = w.scratch_floats;
+  const int x3 = st->gemm_mode == 1 ? GF_X3 : 0;
   ColsumJobs cq;
   cq.n = 0; cq.part_used = 0;
   hipError_t he = hipMemsetAsync(gw, 0, P.n_floats * sizeof(float), s);

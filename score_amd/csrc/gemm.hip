@@ -10,7 +10,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define BK 16
 #define AS_LD (BK + 1)  // As[i][k]: column reads by 32 lanes -> stride 17 words, conflict-free
 
-enum { F_BIAS = 1, F_RELU = 2, F_ACC = 4, F_DROP = 8 };
+enum { F_BIAS = 1, F_RELU = 2, F_ACC = 4, F_DROP = 8, F_X3 = 16 };
 
 __device__ __forceinline__ float epilogue(float v, int row, int col, int N, const float* bias, int flags,
                                           float keep, const uint8_t* mask, uint64_t seed) {
@@ -185,6 +185,47 @@ extern "C" int score_gemm(int32_t trans, int32_t M, int32_t N, int32_t K, const 
   if (trans < 0 || trans > 2) return SCORE_E_BADARG;
   if ((flags & F_BIAS) && !bias) return SCORE_E_BADARG;
   hipStream_t s = (hipStream_t)stream;
+  // k-contiguous operands are staged with 16-B loads: need K % 4 == 0, ld % 4 == 0, 16-B aligned base
+  const bool a_kc = trans != 2, b_kc = trans == 1;
+  // (k-strided operands are staged as 4x4 blocks: their column count must be a multiple of 4 instead)
+  const bool al_a = (lda & 3) == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0;
+  const bool al_b = (ldb & 3) == 0 && (reinterpret_cast<uintptr_t>(Bm) & 15) == 0;
+  const bool x3_ok = al_a && al_b && (a_kc ? (K & 3) == 0 : (M & 3) == 0) && (b_kc ? (K & 3) == 0 : (N & 3) == 0);
+  // measured on MI355X (scratch/gemm_ab.py, interleaved A/B in one process): the split pays where the
+  // tile is wide and the K loop long; NT and small products stay on the f32 MFMA kernel
+  const bool x3_shape = (trans == 0 && M >= 4096 && (N >= 256 || (K >= 1024 && N >= 64))) ||
+                        (trans == 2 && (int64_t)M * N >= 32768 && K >= 4096);
+  const bool x3_force = (flags & 32) != 0;     // tests: take the bf16x3 kernel whenever it is legal
+  if ((flags & (F_X3 | 32)) && x3_ok && M >= 64 && N >= 32 && K >= 32 && (x3_shape || x3_force)) {
+    // fp32-accurate product on the bf16 matrix cores (gemm_bf16x3.hip): 128x128x32 tiles
+    dim3 g3((N + 127) / 128, (M + 127) / 128, 1);
+    int ns = 1;
+    int64_t t3 = (int64_t)g3.x * g3.y;
+    if (t3 < 256 && K >= 512 && scratch) {
+      ns = (int)((320 + t3 - 1) / t3);
+      if (ns > K / 128) ns = K / 128;
+      while (ns > 1 && (int64_t)ns * M * N > scratch_floats) --ns;
+      if (ns < 1) ns = 1;
+    }
+    int kc = K;
+    float* sl = nullptr;
+    if (ns > 1) {
+      kc = (int)align_up64(cdiv64(K, ns), 32);
+      ns = (int)cdiv64(K, kc);
+      g3.z = ns;
+      sl = ns > 1 ? scratch : nullptr;
+    }
+    SCORE_TRY(score_launch_gemm_bf16x3(trans, g3, M, N, K, A, lda, Bm, ldb, C, ldc, bias, flags & 15, keep_prob,
+                                       drop_mask, drop_seed, kc, sl, s));
+    if (sl) {
+      int64_t n = (int64_t)M * N;
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, s, sl, ns, M, N, C, ldc,
+                         bias, flags & 15, keep_prob, drop_mask, drop_seed);
+      SCORE_CHECK_LAUNCH();
+    }
+    return 0;
+  }
+  flags &= 15;
   // tile choice: the largest wave tile that still gives the chip >= ~1.5 blocks per CU
   int WMs = 1, WNs = 1;
   auto nblocks = [&](int wm_, int wn_) { return (int64_t)((N + 64 * wn_ - 1) / (64 * wn_)) * ((M + 64 * wm_ - 1) / (64 * wm_)); };

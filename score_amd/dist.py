@@ -157,7 +157,7 @@ class HipBackend(object):
         m = self.m
         lay, ws = m._workspace(plan["db"].B)
         return lay, ws, _lib.State(_ptr(mini), mini.shape[0], _ptr(m.w), _ptr(ws), ws.numel() * 4, 2,
-                                   int(m.global_batch))
+                                   int(m.global_batch), int(m.gemm_mode), 0)
 
     def forward(self, plan, mini, reg_lambda, keep_prob, masks):
         m = self.m

@@ -93,6 +93,7 @@ class SCOREBASE(object):
         self.scatter_mode = 0      # 0: sorted pull-form scatter, 1: float atomics (score_hip.h)
         self.global_batch = 0      # >0: the loss mean runs over this many samples (data parallel)
         self._side = None
+        self.gemm_mode = 0         # 0: f32 MFMA (default), 1: bf16x3 split (fp32-accurate) where it measured faster
         self._init_params(seed)
 
     # ------------------------------------------------------------------ parameters
@@ -168,7 +169,7 @@ class SCOREBASE(object):
 
     def _state(self, ws):
         return _lib.State(_ptr(self.table), self.table.shape[0], _ptr(self.w), _ptr(ws), ws.numel() * 4,
-                          int(self.scatter_mode), int(self.global_batch))
+                          int(self.scatter_mode), int(self.global_batch), int(self.gemm_mode), 0)
 
     @staticmethod
     def _event_array(events):

@@ -81,6 +81,41 @@ def test_gemm_fp32(trans, shape):
         assert bool((err <= tol).all()), float((err / tol).max())
 
 
+@pytest.mark.parametrize("trans", [0, 1, 2])
+@pytest.mark.parametrize("shape", [(128, 128, 32), (200, 76, 100), (2048, 384, 448), (4096, 80, 1184), (448, 256, 4096),
+                                   (64, 32, 36)])
+def test_gemm_bf16x3_is_fp32_accurate(trans, shape):
+    # "bf16x3": operands split exactly into three bf16, six bf16 MFMAs per k-step; must meet the SAME
+    # error bound as the f32-MFMA kernel (relative to sum |a||b|)
+    lib = _lib.load()
+    M, N, K = shape
+    g = torch.Generator(device="cuda").manual_seed(M + N + K + trans)
+    a = torch.randn((M, K), device="cuda", generator=g) * torch.logspace(-3, 3, K, device="cuda")   # wide dynamic range
+    b = torch.randn((K, N), device="cuda", generator=g)
+    bias = torch.randn((N,), device="cuda", generator=g)
+    A = a if trans != 2 else a.t().contiguous()
+    Bm = b if trans != 1 else b.t().contiguous()
+    scratch = torch.empty((1 << 22,), device="cuda")
+    ref = a.double() @ b.double()
+    tol = 2e-6 * (a.abs().double() @ b.abs().double()) + 1e-6
+    for flags in (32, 32 | 1 | 2, 32 | 4):
+        c0 = torch.randn((M, N + 4), device="cuda", generator=g)
+        c = c0.clone()
+        _lib.check(lib.score_gemm(trans, M, N, K, P(A), A.shape[1], P(Bm), Bm.shape[1], P(c), N + 4, P(bias), flags,
+                                  1.0, C.c_void_p(0), 0, P(scratch), scratch.numel(), stream()), "gemm")
+        torch.cuda.synchronize()
+        want = ref.clone()
+        if flags & 1:
+            want = want + bias.double()
+        if flags & 2:
+            want = want.clamp_min(0)
+        if flags & 4:
+            want = want + c0[:, :N].double()
+        assert torch.equal(c[:, N:], c0[:, N:])
+        err = (c[:, :N].double() - want).abs()
+        assert bool((err <= tol).all()), float((err / tol).max())
+
+
 def test_gemm_dropout_epilogue():
     lib = _lib.load()
     M, N, K = 128, 200, 64
