@@ -1,14 +1,13 @@
 // Exact-fp32 GEMM on the matrix cores: v_mfma_f32_32x32x2_f32 (bitwise an fmaf
 // chain in k order; gfx950 has no xf32/TF32).  64x64 block tile, 4 waves in 2x2,
-// one 32x32 accumulator per wave, BK = 16 staged through LDS with a register
+// (BK = 16: a 32-deep tile measured 6 % slower on this model's shapes) staged through LDS with a register
 // prefetch of the next tile.  Three operand layouts (see score_hip.h).
 #include "common.h"
 #include "kernels.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-#define BK 16
-#define AS_LD (BK + 1)  // As[i][k]: column reads by 32 lanes -> stride 17 words, conflict-free
+#define BK_ALIGN 32   // split-K chunks are multiples of this
 
 enum { F_BIAS = 1, F_RELU = 2, F_ACC = 4, F_DROP = 8, F_X3 = 16 };
 
@@ -28,7 +27,7 @@ __device__ __forceinline__ float epilogue(float v, int row, int col, int N, cons
 // TRANS 1: A[M,K] (lda) , B[N,K] (ldb)  -> C = A . B^T
 // TRANS 2: A[K,M] (lda) , B[K,N] (ldb)  -> C = A^T . B
 // Block = 2x2 waves, each wave a (32*WM) x (32*WN) tile => block tile (64*WM) x (64*WN).
-template <int TRANS, int WM, int WN>
+template <int TRANS, int WM, int WN, int BK>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, const float* __restrict__ A, int lda,
                                                        const float* __restrict__ Bm, int ldb,
                                                        float* __restrict__ C, int ldc,
@@ -36,6 +35,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, cons
                                                        const uint8_t* __restrict__ mask, uint64_t seed,
                                                        int k_chunk, float* __restrict__ slab) {
   constexpr int BM = 64 * WM, BN = 64 * WN, BS_LD = BN + 1;
+  constexpr int AS_LD = BK + 1;   // As[i][k]: column reads by 32 lanes -> odd word stride, conflict-free
+  constexpr int RA = WM * BK / 16, RB = WN * BK / 16, QK = BK / 4;   // staging quads per thread / per k-row
   __shared__ float As[BM * AS_LD];
   __shared__ float Bs[BK * BS_LD];
   const int tid = threadIdx.x;
@@ -46,7 +47,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, cons
   const int kbeg = blockIdx.z * k_chunk;
   const int kend = min(K, kbeg + k_chunk);
 
-  float ra[WM][4], rb[WN][4];
+  float ra[RA][4], rb[RB][4];
   const bool vecA = ((lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
   const bool vecB = ((ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(Bm) & 15) == 0);
   // one row-major quad: 16-B load when aligned and fully in range, guarded scalars otherwise
@@ -61,37 +62,37 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, cons
   };
   auto load_tiles = [&](int k0) {
 #pragma unroll
-    for (int rep = 0; rep < WM; ++rep) {
+    for (int rep = 0; rep < RA; ++rep) {
       const int q = tid + 256 * rep;
       if (TRANS == 2) load_quad(A, lda, vecA, k0 + q / (BM / 4), kend, bm + (q % (BM / 4)) * 4, M, ra[rep]);  // A[k][m]
-      else            load_quad(A, lda, vecA, bm + (q >> 2), M, k0 + (q & 3) * 4, kend, ra[rep]);              // A[m][k]
+      else            load_quad(A, lda, vecA, bm + q / QK, M, k0 + (q % QK) * 4, kend, ra[rep]);               // A[m][k]
     }
 #pragma unroll
-    for (int rep = 0; rep < WN; ++rep) {
+    for (int rep = 0; rep < RB; ++rep) {
       const int q = tid + 256 * rep;
-      if (TRANS == 1) load_quad(Bm, ldb, vecB, bn + (q >> 2), N, k0 + (q & 3) * 4, kend, rb[rep]);             // B[n][k]
+      if (TRANS == 1) load_quad(Bm, ldb, vecB, bn + q / QK, N, k0 + (q % QK) * 4, kend, rb[rep]);              // B[n][k]
       else            load_quad(Bm, ldb, vecB, k0 + q / (BN / 4), kend, bn + (q % (BN / 4)) * 4, N, rb[rep]);  // B[k][n]
     }
   };
   auto store_tiles = [&]() {
 #pragma unroll
-    for (int rep = 0; rep < WM; ++rep) {
+    for (int rep = 0; rep < RA; ++rep) {
       const int q = tid + 256 * rep;
       if (TRANS == 2) {
         const int k = q / (BM / 4), m = (q % (BM / 4)) * 4;
 #pragma unroll
         for (int e = 0; e < 4; ++e) As[(m + e) * AS_LD + k] = ra[rep][e];
       } else {
-        const int m = q >> 2, k = (q & 3) * 4;
+        const int m = q / QK, k = (q % QK) * 4;
 #pragma unroll
         for (int e = 0; e < 4; ++e) As[m * AS_LD + k + e] = ra[rep][e];
       }
     }
 #pragma unroll
-    for (int rep = 0; rep < WN; ++rep) {
+    for (int rep = 0; rep < RB; ++rep) {
       const int q = tid + 256 * rep;
       if (TRANS == 1) {
-        const int n = q >> 2, k = (q & 3) * 4;
+        const int n = q / QK, k = (q % QK) * 4;
 #pragma unroll
         for (int e = 0; e < 4; ++e) Bs[(k + e) * BS_LD + n] = rb[rep][e];
       } else {
@@ -248,13 +249,13 @@ extern "C" int score_gemm(int32_t trans, int32_t M, int32_t N, int32_t K, const 
   int k_chunk = K;
   float* slab = nullptr;
   if (nsplit > 1) {
-    k_chunk = (int)align_up64(cdiv64(K, nsplit), BK);
+    k_chunk = (int)align_up64(cdiv64(K, nsplit), BK_ALIGN);
     nsplit = (int)cdiv64(K, k_chunk);
     grid.z = nsplit;
     slab = nsplit > 1 ? scratch : nullptr;
   }
-#define LAUNCH(TR, WMv, WNv)                                                                                  \
-  hipLaunchKernelGGL((gemm_f32_kernel<TR, WMv, WNv>), grid, dim3(256), 0, s, M, N, K, A, lda, Bm, ldb, C, ldc, \
+#define LAUNCH(TR, WMv, WNv)                                                                                       \
+  hipLaunchKernelGGL((gemm_f32_kernel<TR, WMv, WNv, 16>), grid, dim3(256), 0, s, M, N, K, A, lda, Bm, ldb, C, ldc, \
                      bias, flags, keep_prob, drop_mask, drop_seed, k_chunk, slab)
 #define LAUNCH_T(TR)                                      \
   do {                                                    \
