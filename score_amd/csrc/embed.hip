@@ -265,24 +265,23 @@ __global__ __launch_bounds__(256) void coattn_bwd_kernel_t(const CoattnArgs a) {
       continue;
     }
 
-    int32_t r1[SPL][KMAX], r2[SPL][KMAX];
-    float4 v1[SPL][KMAX], v2[SPL][KMAX];
+    // pass 1: seq1 rows -> dp_k = g1 . seq1_k (seq1 stays in registers for dw1)
+    int32_t r1[SPL][KMAX];
+    float4 v1[SPL][KMAX];
     float dp[KMAX];
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) {
       dp[k] = 0.f;
 #pragma unroll
       for (int j = 0; j < SPL; ++j) {
-        float4 x = make_float4(0.f, 0.f, 0.f, 0.f), y = x;
-        int32_t ra = 0, rb = 0;
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+        int32_t ra = 0;
         if (k < K && ok[j]) {
           ra = i1[k * F + f[j]];
-          rb = i2[k * F + f[j]];
           x = ld4(table + (int64_t)ra * D + coff[j]);
-          y = ld4(table + (int64_t)rb * D + coff[j]);
         }
-        r1[j][k] = ra; r2[j][k] = rb;
-        v1[j][k] = x; v2[j][k] = y;
+        r1[j][k] = ra;
+        v1[j][k] = x;
         dp[k] += dot4(x, g1[j]);
       }
     }
@@ -332,23 +331,41 @@ __global__ __launch_bounds__(256) void coattn_bwd_kernel_t(const CoattnArgs a) {
       }
     }
     const float invK = 1.0f / (float)K;
+    // dw1 first (frees the seq1 registers), then the seq2 rows stream through: dw2 += dz_k seq2_k
 #pragma unroll
     for (int j = 0; j < SPL; ++j) {
       if (!ok[j]) continue;
-      float4 g2k = make_float4(g2[j].x * invK, g2[j].y * invK, g2[j].z * invK, g2[j].w * invK);
 #pragma unroll
       for (int k = 0; k < KMAX; ++k) {
         if (k >= K) continue;
         dw1[j] = fma4(dz[k], v1[j][k], dw1[j]);
-        dw2[j] = fma4(dz[k], v2[j][k], dw2[j]);
-        if (ATOMIC) {
-          if (r1[j][k] != 0) {
-            float4 d1 = fma4(dz[k], w1[j],
-                             make_float4(p[k] * g1[j].x, p[k] * g1[j].y, p[k] * g1[j].z, p[k] * g1[j].w));
-            atomic_add4(gtable + (int64_t)r1[j][k] * D + coff[j], d1);
-          }
-          if (r2[j][k] != 0) atomic_add4(gtable + (int64_t)r2[j][k] * D + coff[j], fma4(dz[k], w2[j], g2k));
+        if (ATOMIC && r1[j][k] != 0) {
+          float4 d1 = fma4(dz[k], w1[j],
+                           make_float4(p[k] * g1[j].x, p[k] * g1[j].y, p[k] * g1[j].z, p[k] * g1[j].w));
+          atomic_add4(gtable + (int64_t)r1[j][k] * D + coff[j], d1);
         }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < SPL; ++j) {
+      if (!ok[j]) continue;
+      float4 g2k = make_float4(g2[j].x * invK, g2[j].y * invK, g2[j].z * invK, g2[j].w * invK);
+      float4 y[KMAX];
+      int32_t rb[KMAX];
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) {
+        rb[k] = 0;
+        y[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < K) {
+          rb[k] = i2[k * F + f[j]];
+          y[k] = ld4(table + (int64_t)rb[k] * D + coff[j]);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) {
+        if (k >= K) continue;
+        dw2[j] = fma4(dz[k], y[k], dw2[j]);
+        if (ATOMIC && rb[k] != 0) atomic_add4(gtable + (int64_t)rb[k] * D + coff[j], fma4(dz[k], w2[j], g2k));
       }
     }
   }

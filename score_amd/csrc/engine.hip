@@ -199,10 +199,14 @@ void build_ws(const Dims& d, int B, WS* w) {
 }
 
 #define G(call) SCORE_TRY(call)
-// every GEMM launched from this file ORs in `x3`: GF_X3 when the caller's state asks for the
-// fp32-accurate bf16x3 matrix-core product (score_state_t.gemm_mode), else 0
-#define score_gemm(tr, M_, N_, K_, A_, lda_, B_, ldb_, C_, ldc_, bias_, fl_, ...) \
-  score_gemm(tr, M_, N_, K_, A_, lda_, B_, ldb_, C_, ldc_, bias_, (fl_) | x3, __VA_ARGS__)
+// every GEMM of the path goes through here: ORs in the caller's product mode (score_state_t.gemm_mode)
+static inline int gemm_mode_call(int x3, int tr, int M, int N, int K, const float* A, int lda, const float* B,
+                                 int ldb, float* C, int ldc, const float* bias, int flags, float keep,
+                                 const uint8_t* mask, uint64_t seed, float* scratch, int64_t scratch_floats,
+                                 void* s) {
+  return score_gemm(tr, M, N, K, A, lda, B, ldb, C, ldc, bias, flags | x3, keep, mask, seed, scratch, scratch_floats,
+                    s);
+}
 // optional stage boundary events (hipEvent_t handles) recorded on the launch stream
 #define EV(i)                                                                \
   do {                                                                       \
@@ -348,9 +352,9 @@ extern "C" int score_forward(const score_config_t* cfg, const score_state_t* st,
     ga.B = B; ga.T = T; ga.H = H; ga.length = bt->length;
     for (int sd = 0; sd < 2; ++sd) {
       float* xp = ws + w.xproj[sd];
-      G(score_gemm(0, BT, 2 * H, d.I, ws + w.xside[sd], d.I, W + P.gk[sd], 2 * H, xp, 3 * H, W + P.gb[sd],
+      G(gemm_mode_call(x3, 0, BT, 2 * H, d.I, ws + w.xside[sd], d.I, W + P.gk[sd], 2 * H, xp, 3 * H, W + P.gb[sd],
                    GF_BIAS, 1.f, nullptr, 0, scratch, w.scratch_floats, s));
-      G(score_gemm(0, BT, H, d.I, ws + w.xside[sd], d.I, W + P.ck[sd], H, xp + 2 * H, 3 * H, W + P.cb[sd], GF_BIAS,
+      G(gemm_mode_call(x3, 0, BT, H, d.I, ws + w.xside[sd], d.I, W + P.ck[sd], H, xp + 2 * H, 3 * H, W + P.cb[sd], GF_BIAS,
                    1.f, nullptr, 0, scratch, w.scratch_floats, s));
       GruSide& g = ga.s[sd];
       g.xproj = xp; g.Wg = W + P.gk[sd] + (int64_t)d.I * 2 * H; g.ldwg = 2 * H;
@@ -362,13 +366,13 @@ extern "C" int score_forward(const score_config_t* cfg, const score_state_t* st,
   EV(2);
   if (d.attn) {
     // temporal attention (:169-186, 210-215)
-    G(score_gemm(0, B, d.Dk, d.Dq, ws + w.query, d.Dq, W + P.at_w[0], d.Dk, ws + w.q, d.Dk, W + P.at_b[0], GF_BIAS,
+    G(gemm_mode_call(x3, 0, B, d.Dk, d.Dq, ws + w.query, d.Dq, W + P.at_w[0], d.Dk, ws + w.q, d.Dk, W + P.at_b[0], GF_BIAS,
                  1.f, nullptr, 0, scratch, w.scratch_floats, s));
     G(score_launch_attn_build_inp(B, T, H, d.NI, ws + w.q, ws + w.gru_out[0], ws + w.gru_out[1], ws + w.info,
                                   ws + w.ainp, s));
-    G(score_gemm(0, BT, AT1, 4 * d.Dk, ws + w.ainp, 4 * d.Dk, W + P.at_w[1], AT1, ws + w.a1, AT1, W + P.at_b[1],
+    G(gemm_mode_call(x3, 0, BT, AT1, 4 * d.Dk, ws + w.ainp, 4 * d.Dk, W + P.at_w[1], AT1, ws + w.a1, AT1, W + P.at_b[1],
                  GF_BIAS | GF_RELU, 1.f, nullptr, 0, scratch, w.scratch_floats, s));
-    G(score_gemm(0, BT, AT2, AT1, ws + w.a1, AT1, W + P.at_w[2], AT2, ws + w.a2, AT2, W + P.at_b[2],
+    G(gemm_mode_call(x3, 0, BT, AT2, AT1, ws + w.a1, AT1, W + P.at_w[2], AT2, ws + w.a2, AT2, W + P.at_b[2],
                  GF_BIAS | GF_RELU, 1.f, nullptr, 0, scratch, w.scratch_floats, s));
     G(score_launch_attn_pool_fwd(B, T, H, AT2, ws + w.a2, W + P.at_w[3], W + P.at_b[3], bt->length,
                                  ws + w.gru_out[0], ws + w.gru_out[1], ws + w.att_score, ws + w.head_inp, d.Dhead,
@@ -383,9 +387,9 @@ extern "C" int score_forward(const score_config_t* cfg, const score_state_t* st,
   const float rs = (float)(1.0 / sqrt(1.0 + 1e-3));
   G(score_launch_bn_fwd(B, d.Dhead, ws + w.head_inp, W + P.bn_g, W + P.bn_b, rs, ws + w.bn, s));
   const int dflag = keep_prob < 1.f ? GF_DROP : 0;
-  G(score_gemm(0, B, FC1, d.Dhead, ws + w.bn, d.Dhead, W + P.fc_w[0], FC1, ws + w.f1, FC1, W + P.fc_b[0],
+  G(gemm_mode_call(x3, 0, B, FC1, d.Dhead, ws + w.bn, d.Dhead, W + P.fc_w[0], FC1, ws + w.f1, FC1, W + P.fc_b[0],
                GF_BIAS | GF_RELU | dflag, keep_prob, drop_mask0, drop_seed, scratch, w.scratch_floats, s));
-  G(score_gemm(0, B, FC2, FC1, ws + w.f1, FC1, W + P.fc_w[1], FC2, ws + w.f2, FC2, W + P.fc_b[1],
+  G(gemm_mode_call(x3, 0, B, FC2, FC1, ws + w.f1, FC1, W + P.fc_w[1], FC2, ws + w.f2, FC2, W + P.fc_b[1],
                GF_BIAS | GF_RELU | dflag, keep_prob, drop_mask1, drop_seed ^ 0x5DEECE66Dull, scratch,
                w.scratch_floats, s));
   // fc3, sigmoid, log-loss, l2 (:74-94)
@@ -423,22 +427,22 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
   EV(0);
   // ---- head (score.py:68-81)
   // fc3: dW = f2^T dlogit, db = sum dlogit, dz2 = [f2>0] dlogit w3 / keep
-  G(score_gemm(2, FC2, 1, B, ws + w.f2, FC2, ws + w.dlogit, 1, gw + P.fc_w[2], 1, nullptr, 0, 1.f, nullptr, 0,
+  G(gemm_mode_call(x3, 2, FC2, 1, B, ws + w.f2, FC2, ws + w.dlogit, 1, gw + P.fc_w[2], 1, nullptr, 0, 1.f, nullptr, 0,
                scratch, SF, s));
   G(colsum_queue_add(&cq, ws + w.dlogit, B, 1, 1, gw + P.fc_b[2], 0));
   G(score_launch_outer_relu_bwd(B, FC2, ws + w.dlogit, W + P.fc_w[2], ws + w.f2, keep_prob, ws + w.dz2, s));
   // fc2
-  G(score_gemm(2, FC1, FC2, B, ws + w.f1, FC1, ws + w.dz2, FC2, gw + P.fc_w[1], FC2, nullptr, 0, 1.f, nullptr, 0,
+  G(gemm_mode_call(x3, 2, FC1, FC2, B, ws + w.f1, FC1, ws + w.dz2, FC2, gw + P.fc_w[1], FC2, nullptr, 0, 1.f, nullptr, 0,
                scratch, SF, s));
   G(colsum_queue_add(&cq, ws + w.dz2, B, FC2, FC2, gw + P.fc_b[1], 0));
-  G(score_gemm(1, B, FC1, FC2, ws + w.dz2, FC2, W + P.fc_w[1], FC2, ws + w.dz1, FC1, nullptr, 0, 1.f, nullptr, 0,
+  G(gemm_mode_call(x3, 1, B, FC1, FC2, ws + w.dz2, FC2, W + P.fc_w[1], FC2, ws + w.dz1, FC1, nullptr, 0, 1.f, nullptr, 0,
                scratch, SF, s));
   G(score_launch_relu_bwd(ws + w.dz1, ws + w.f1, B, FC1, FC1, FC1, keep_prob, s));
   // fc1 + bn1
-  G(score_gemm(2, d.Dhead, FC1, B, ws + w.bn, d.Dhead, ws + w.dz1, FC1, gw + P.fc_w[0], FC1, nullptr, 0, 1.f,
+  G(gemm_mode_call(x3, 2, d.Dhead, FC1, B, ws + w.bn, d.Dhead, ws + w.dz1, FC1, gw + P.fc_w[0], FC1, nullptr, 0, 1.f,
                nullptr, 0, scratch, SF, s));
   G(colsum_queue_add(&cq, ws + w.dz1, B, FC1, FC1, gw + P.fc_b[0], 0));
-  G(score_gemm(1, B, d.Dhead, FC1, ws + w.dz1, FC1, W + P.fc_w[0], FC1, ws + w.dbn, d.Dhead, nullptr, 0, 1.f,
+  G(gemm_mode_call(x3, 1, B, d.Dhead, FC1, ws + w.dz1, FC1, W + P.fc_w[0], FC1, ws + w.dbn, d.Dhead, nullptr, 0, 1.f,
                nullptr, 0, scratch, SF, s));
   const float rs = (float)(1.0 / sqrt(1.0 + 1e-3));
   // (w.bn is dead after the fc1 weight-gradient GEMM above: reuse it as the dgamma staging buffer)
@@ -453,30 +457,30 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
                                  ws + w.gru_out[1], ws + w.att_score, ws + w.dhead, d.Dhead, d.off_u, d.off_i,
                                  ws + w.ds, ws + w.da2, s));
     // dense_5 (40 -> 1): dW = a2^T ds ; db = sum ds
-    G(score_gemm(2, AT2, 1, BT, ws + w.a2, AT2, ws + w.ds, 1, gw + P.at_w[3], 1, nullptr, 0, 1.f, nullptr, 0,
+    G(gemm_mode_call(x3, 2, AT2, 1, BT, ws + w.a2, AT2, ws + w.ds, 1, gw + P.at_w[3], 1, nullptr, 0, 1.f, nullptr, 0,
                  scratch, SF, s));
     G(colsum_queue_add(&cq, ws + w.ds, BT, 1, 1, gw + P.at_b[3], 0));
     // dense_4 (80 -> 40); da2 is already relu-masked
-    G(score_gemm(2, AT1, AT2, BT, ws + w.a1, AT1, ws + w.da2, AT2, gw + P.at_w[2], AT2, nullptr, 0, 1.f, nullptr,
+    G(gemm_mode_call(x3, 2, AT1, AT2, BT, ws + w.a1, AT1, ws + w.da2, AT2, gw + P.at_w[2], AT2, nullptr, 0, 1.f, nullptr,
                  0, scratch, SF, s));
     G(colsum_queue_add(&cq, ws + w.da2, BT, AT2, AT2, gw + P.at_b[2], 0));
-    G(score_gemm(1, BT, AT1, AT2, ws + w.da2, AT2, W + P.at_w[2], AT2, ws + w.da1, AT1, nullptr, 0, 1.f, nullptr,
+    G(gemm_mode_call(x3, 1, BT, AT1, AT2, ws + w.da2, AT2, W + P.at_w[2], AT2, ws + w.da1, AT1, nullptr, 0, 1.f, nullptr,
                  0, scratch, SF, s));
     G(score_launch_relu_bwd(ws + w.da1, ws + w.a1, BT, AT1, AT1, AT1, 1.f, s));
     // dense_3 (4Dk -> 80)
-    G(score_gemm(2, 4 * d.Dk, AT1, BT, ws + w.ainp, 4 * d.Dk, ws + w.da1, AT1, gw + P.at_w[1], AT1, nullptr, 0,
+    G(gemm_mode_call(x3, 2, 4 * d.Dk, AT1, BT, ws + w.ainp, 4 * d.Dk, ws + w.da1, AT1, gw + P.at_w[1], AT1, nullptr, 0,
                  1.f, nullptr, 0, scratch, SF, s));
     G(colsum_queue_add(&cq, ws + w.da1, BT, AT1, AT1, gw + P.at_b[1], 0));
-    G(score_gemm(1, BT, 4 * d.Dk, AT1, ws + w.da1, AT1, W + P.at_w[1], AT1, ws + w.dainp, 4 * d.Dk, nullptr, 0,
+    G(gemm_mode_call(x3, 1, BT, 4 * d.Dk, AT1, ws + w.da1, AT1, W + P.at_w[1], AT1, ws + w.dainp, 4 * d.Dk, nullptr, 0,
                  1.f, nullptr, 0, scratch, SF, s));
     G(score_launch_attn_inp_bwd(B, T, H, d.NI, ws + w.dainp, ws + w.q, ws + w.gru_out[0], ws + w.gru_out[1],
                                 ws + w.info, ws + w.att_score, ws + w.dhead, d.Dhead, d.off_u, d.off_i,
                                 ws + w.dgru[0], ws + w.dgru[1], ws + w.dinfo, ws + w.dq, s));
     // dense_2 (query projection)
-    G(score_gemm(2, d.Dq, d.Dk, B, ws + w.query, d.Dq, ws + w.dq, d.Dk, gw + P.at_w[0], d.Dk, nullptr, 0, 1.f,
+    G(gemm_mode_call(x3, 2, d.Dq, d.Dk, B, ws + w.query, d.Dq, ws + w.dq, d.Dk, gw + P.at_w[0], d.Dk, nullptr, 0, 1.f,
                  nullptr, 0, scratch, SF, s));
     G(colsum_queue_add(&cq, ws + w.dq, B, d.Dk, d.Dk, gw + P.at_b[0], 0));
-    G(score_gemm(1, B, d.Dq, d.Dk, ws + w.dq, d.Dk, W + P.at_w[0], d.Dk, ws + w.dquery, d.Dq, nullptr, 0, 1.f,
+    G(gemm_mode_call(x3, 1, B, d.Dq, d.Dk, ws + w.dq, d.Dk, W + P.at_w[0], d.Dk, ws + w.dquery, d.Dq, nullptr, 0, 1.f,
                  nullptr, 0, scratch, SF, s));
   } else {
     // RIA: gradient enters through the final states only; atten_info is unused downstream
@@ -511,20 +515,20 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
     const float* Wc = W + P.ck[sd];
     float* dxp = ws + w.dxproj[sd];
     // kernels are [x ; h] row blocks (TF GRUCell): x rows first
-    G(score_gemm(2, d.I, 2 * H, BT, ws + w.xside[sd], d.I, dxp, 3 * H, gw + P.gk[sd], 2 * H, nullptr, 0, 1.f,
+    G(gemm_mode_call(x3, 2, d.I, 2 * H, BT, ws + w.xside[sd], d.I, dxp, 3 * H, gw + P.gk[sd], 2 * H, nullptr, 0, 1.f,
                  nullptr, 0, scratch, SF, s));
-    G(score_gemm(2, H, 2 * H, BT, ws + w.hprev[sd], H, dxp, 3 * H, gw + P.gk[sd] + (int64_t)d.I * 2 * H, 2 * H,
+    G(gemm_mode_call(x3, 2, H, 2 * H, BT, ws + w.hprev[sd], H, dxp, 3 * H, gw + P.gk[sd] + (int64_t)d.I * 2 * H, 2 * H,
                  nullptr, 0, 1.f, nullptr, 0, scratch, SF, s));
-    G(score_gemm(2, d.I, H, BT, ws + w.xside[sd], d.I, dxp + 2 * H, 3 * H, gw + P.ck[sd], H, nullptr, 0, 1.f,
+    G(gemm_mode_call(x3, 2, d.I, H, BT, ws + w.xside[sd], d.I, dxp + 2 * H, 3 * H, gw + P.ck[sd], H, nullptr, 0, 1.f,
                  nullptr, 0, scratch, SF, s));
-    G(score_gemm(2, H, H, BT, ws + w.rh[sd], H, dxp + 2 * H, 3 * H, gw + P.ck[sd] + (int64_t)d.I * H, H, nullptr, 0,
+    G(gemm_mode_call(x3, 2, H, H, BT, ws + w.rh[sd], H, dxp + 2 * H, 3 * H, gw + P.ck[sd] + (int64_t)d.I * H, H, nullptr, 0,
                  1.f, nullptr, 0, scratch, SF, s));
     G(colsum_queue_add(&cq, dxp, BT, 2 * H, 3 * H, gw + P.gb[sd], 0));
     G(colsum_queue_add(&cq, dxp + 2 * H, BT, H, 3 * H, gw + P.cb[sd], 0));
     // d x = dgates . Wxg^T + dcand . Wxc^T
-    G(score_gemm(1, BT, d.I, 2 * H, dxp, 3 * H, Wg, 2 * H, ws + w.dxside[sd], d.I, nullptr, 0, 1.f, nullptr, 0,
+    G(gemm_mode_call(x3, 1, BT, d.I, 2 * H, dxp, 3 * H, Wg, 2 * H, ws + w.dxside[sd], d.I, nullptr, 0, 1.f, nullptr, 0,
                  scratch, SF, s));
-    G(score_gemm(1, BT, d.I, H, dxp + 2 * H, 3 * H, Wc, H, ws + w.dxside[sd], d.I, nullptr, GF_ACC, 1.f, nullptr,
+    G(gemm_mode_call(x3, 1, BT, d.I, H, dxp + 2 * H, 3 * H, Wc, H, ws + w.dxside[sd], d.I, nullptr, GF_ACC, 1.f, nullptr,
                  0, scratch, SF, s));
   }
 

@@ -192,7 +192,7 @@ extern "C" int score_gemm(int32_t trans, int32_t M, int32_t N, int32_t K, const 
   const bool al_a = (lda & 3) == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0;
   const bool al_b = (ldb & 3) == 0 && (reinterpret_cast<uintptr_t>(Bm) & 15) == 0;
   const bool x3_ok = al_a && al_b && (a_kc ? (K & 3) == 0 : (M & 3) == 0) && (b_kc ? (K & 3) == 0 : (N & 3) == 0);
-  // measured on MI355X (scratch/gemm_ab.py, interleaved A/B in one process): the split pays where the
+  // measured on MI355X (tools/gemm_ab.py, interleaved A/B in one process): the split pays where the
   // tile is wide and the K loop long; NT and small products stay on the f32 MFMA kernel
   const bool x3_shape = (trans == 0 && M >= 4096 && (N >= 256 || (K >= 1024 && N >= 64))) ||
                         (trans == 2 && (int64_t)M * N >= 32768 && K >= 4096);

@@ -342,8 +342,14 @@ __global__ void adam_kernel(float* __restrict__ p, float* __restrict__ m, float*
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (; i < n4; i += stride) {
-    float4 pp = ld4(p + i * 4), mm = ld4(m + i * 4), vv = ld4(v + i * 4), gg = ld4(g + i * 4);
+    float4 mm = ld4(m + i * 4), vv = ld4(v + i * 4), gg = ld4(g + i * 4);
     int64_t e = i * 4;
+    // exact shortcut: with g = m = v = 0 (a row no batch has touched yet, no L2 term on it) ApplyAdam
+    // leaves m, v and the variable bit-identical -- skip the variable's read and all three writes
+    if (e >= n_reg && gg.x == 0.f && gg.y == 0.f && gg.z == 0.f && gg.w == 0.f && mm.x == 0.f && mm.y == 0.f &&
+        mm.z == 0.f && mm.w == 0.f && vv.x == 0.f && vv.y == 0.f && vv.z == 0.f && vv.w == 0.f)
+      continue;
+    float4 pp = ld4(p + i * 4);
     if (e < n_reg) {  // d/dw of lambda * sum(w^2)/2   (build_l2norm, score.py:91-94)
       gg.x = e + 0 < n_reg ? fmaf(l2, pp.x, gg.x) : gg.x;
       gg.y = e + 1 < n_reg ? fmaf(l2, pp.y, gg.y) : gg.y;

@@ -113,6 +113,13 @@ def test_one_step_vs_oracle_full_size(cfg3):
     l_g = m.train(None, b, 1e-3, 1e-4, keep_prob=1.0)
     l_o = om.train(None, b, 1e-3, 1e-4, keep_prob=1.0)
     assert abs(l_g - l_o) < 1e-5 * max(1.0, abs(l_o))
-    pg2, _, _ = m.eval(None, b, 1e-4)
-    po2, _, _ = om.eval(None, b, 1e-4)
-    assert np.abs(np.asarray(pg2) - np.asarray(po2)).max() < 1e-4
+    # After an update the two fp32 implementations are no longer on IDENTICAL parameters: forward sums are
+    # rounded in different orders (~1e-5), so a few of the 1.7 M relu units sit on opposite sides of zero,
+    # their weights' gradients differ discretely, and Adam's first step moves every element by ~lr*sign(g).
+    # The predictions must still agree closely in bulk, and within the reach of those +-lr moves at worst.
+    pg2, _, lg2 = m.eval(None, b, 1e-4)
+    po2, _, lo2 = om.eval(None, b, 1e-4)
+    d = np.abs(np.asarray(pg2) - np.asarray(po2))
+    assert np.median(d) < 1e-4 and d.max() < 2e-3, (np.median(d), d.max())
+    assert abs(lg2 - lo2) < 1e-4 * max(1.0, abs(lo2))
+    assert round(roc_auc_score(lab, pg2), 3) == round(roc_auc_score(lab, po2), 3)
