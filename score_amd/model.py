@@ -93,7 +93,7 @@ class SCOREBASE(object):
         self.scatter_mode = 0      # 0: sorted pull-form scatter, 1: float atomics (score_hip.h)
         self.global_batch = 0      # >0: the loss mean runs over this many samples (data parallel)
         self._side = None
-        self.gemm_mode = 0         # 0: f32 MFMA (default), 1: bf16x3 split (fp32-accurate) where it measured faster
+        self.gemm_mode = 1         # 1: bf16x3 split (fp32-accurate) on the shapes where it measured faster, 0: f32 MFMA only
         self._init_params(seed)
 
     # ------------------------------------------------------------------ parameters
