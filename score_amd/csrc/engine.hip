@@ -127,7 +127,7 @@ struct WS {
   int64_t pcoef[2], dzcoef[2], dtgt, keys_in, keys_out, vals_in, vals_out, sort_temp, partials;
   int64_t n_occ, sort_temp_bytes, partial_floats;
   int64_t uid, unique_rows, meta, remap[6];
-  int64_t ca_slab, ca_slab_floats, cs_part, cs_part_floats;
+  int64_t ca_slab, ca_slab_floats, cs_part, cs_part_floats, wxcat, dwxcat;
   int64_t scratch_floats, total;
 };
 
@@ -174,6 +174,8 @@ void build_ws(const Dims& d, int B, WS* w) {
   w->ca_slab = take(w->ca_slab_floats);
   w->cs_part_floats = 1 << 20;
   w->cs_part = take(w->cs_part_floats);
+  w->wxcat = take(2 * (int64_t)(d.I + 1) * 3 * d.H);
+  w->dwxcat = take((int64_t)d.I * 3 * d.H);
   // sorted pull-form scatter (scatter.hip)
   for (int c = 0; c < 2; ++c) { w->pcoef[c] = take(BT * d.K); w->dzcoef[c] = take(BT * d.K); }
   w->dtgt = take((int64_t)B * d.Dq);
@@ -350,12 +352,14 @@ extern "C" int score_forward(const score_config_t* cfg, const score_state_t* st,
     GruArgs ga;
     memset(&ga, 0, sizeof(ga));
     ga.B = B; ga.T = T; ga.H = H; ga.length = bt->length;
+    G(score_launch_gru_wxcat(W + P.gk[0], W + P.ck[0], W + P.gb[0], W + P.cb[0], W + P.gk[1], W + P.ck[1], W + P.gb[1],
+                             W + P.cb[1], d.I, H, ws + w.wxcat, s));
     for (int sd = 0; sd < 2; ++sd) {
       float* xp = ws + w.xproj[sd];
-      G(gemm_mode_call(x3, 0, BT, 2 * H, d.I, ws + w.xside[sd], d.I, W + P.gk[sd], 2 * H, xp, 3 * H, W + P.gb[sd],
-                   GF_BIAS, 1.f, nullptr, 0, scratch, w.scratch_floats, s));
-      G(gemm_mode_call(x3, 0, BT, H, d.I, ws + w.xside[sd], d.I, W + P.ck[sd], H, xp + 2 * H, 3 * H, W + P.cb[sd], GF_BIAS,
-                   1.f, nullptr, 0, scratch, w.scratch_floats, s));
+      // x . [Wx_gates | Wx_cand] + [b_gates | b_cand]: one GEMM per side on the concatenated copy
+      const float* cat = ws + w.wxcat + (int64_t)sd * (d.I + 1) * 3 * H;
+      G(gemm_mode_call(x3, 0, BT, 3 * H, d.I, ws + w.xside[sd], d.I, cat, 3 * H, xp, 3 * H, cat + (int64_t)d.I * 3 * H,
+                       GF_BIAS, 1.f, nullptr, 0, scratch, w.scratch_floats, s));
       GruSide& g = ga.s[sd];
       g.xproj = xp; g.Wg = W + P.gk[sd] + (int64_t)d.I * 2 * H; g.ldwg = 2 * H;
       g.Wc = W + P.ck[sd] + (int64_t)d.I * H; g.ldwc = H;
@@ -511,25 +515,22 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
     G(score_gru_bwd_multi(ga, 2, s));
   }
   for (int sd = 0; sd < 2; ++sd) {
-    const float* Wg = W + P.gk[sd];
-    const float* Wc = W + P.ck[sd];
     float* dxp = ws + w.dxproj[sd];
-    // kernels are [x ; h] row blocks (TF GRUCell): x rows first
-    G(gemm_mode_call(x3, 2, d.I, 2 * H, BT, ws + w.xside[sd], d.I, dxp, 3 * H, gw + P.gk[sd], 2 * H, nullptr, 0, 1.f,
-                 nullptr, 0, scratch, SF, s));
+    // kernels are [x ; h] row blocks (TF GRUCell): x rows first.  x part of both kernels in one product
+    // on the concatenated layout, then split into the two variables' gradients
+    const float* cat = ws + w.wxcat + (int64_t)sd * (d.I + 1) * 3 * H;
+    G(gemm_mode_call(x3, 2, d.I, 3 * H, BT, ws + w.xside[sd], d.I, dxp, 3 * H, ws + w.dwxcat, 3 * H, nullptr, 0, 1.f,
+                     nullptr, 0, scratch, SF, s));
+    G(score_launch_gru_wxsplit(ws + w.dwxcat, d.I, H, gw + P.gk[sd], gw + P.ck[sd], s));
     G(gemm_mode_call(x3, 2, H, 2 * H, BT, ws + w.hprev[sd], H, dxp, 3 * H, gw + P.gk[sd] + (int64_t)d.I * 2 * H, 2 * H,
                  nullptr, 0, 1.f, nullptr, 0, scratch, SF, s));
-    G(gemm_mode_call(x3, 2, d.I, H, BT, ws + w.xside[sd], d.I, dxp + 2 * H, 3 * H, gw + P.ck[sd], H, nullptr, 0, 1.f,
-                 nullptr, 0, scratch, SF, s));
     G(gemm_mode_call(x3, 2, H, H, BT, ws + w.rh[sd], H, dxp + 2 * H, 3 * H, gw + P.ck[sd] + (int64_t)d.I * H, H, nullptr, 0,
                  1.f, nullptr, 0, scratch, SF, s));
     G(colsum_queue_add(&cq, dxp, BT, 2 * H, 3 * H, gw + P.gb[sd], 0));
     G(colsum_queue_add(&cq, dxp + 2 * H, BT, H, 3 * H, gw + P.cb[sd], 0));
-    // d x = dgates . Wxg^T + dcand . Wxc^T
-    G(gemm_mode_call(x3, 1, BT, d.I, 2 * H, dxp, 3 * H, Wg, 2 * H, ws + w.dxside[sd], d.I, nullptr, 0, 1.f, nullptr, 0,
-                 scratch, SF, s));
-    G(gemm_mode_call(x3, 1, BT, d.I, H, dxp + 2 * H, 3 * H, Wc, H, ws + w.dxside[sd], d.I, nullptr, GF_ACC, 1.f, nullptr,
-                 0, scratch, SF, s));
+    // d x = [dgates | dcand] . [Wx_gates | Wx_cand]^T
+    G(gemm_mode_call(x3, 1, BT, d.I, 3 * H, dxp, 3 * H, cat, 3 * H, ws + w.dxside[sd], d.I, nullptr, 0, 1.f, nullptr, 0,
+                     scratch, SF, s));
   }
 
   // ---- co-attention + embedding rows (score.py:147-167, 196-201, 51-66)

@@ -328,6 +328,51 @@ int score_launch_copy2d(int64_t rows, int cols, const float* src, int lds_, floa
   return 0;
 }
 
+// [Wx_gates | Wx_cand] and [b_gates | b_cand] of both GRUs side by side, so the hoisted input projection
+// (and its two backward products) is ONE GEMM per side.  cat: [2][I+1][3H] (row I holds the bias).
+__global__ void gru_wxcat_kernel(const float* __restrict__ gk0, const float* __restrict__ ck0,
+                                 const float* __restrict__ gb0, const float* __restrict__ cb0,
+                                 const float* __restrict__ gk1, const float* __restrict__ ck1,
+                                 const float* __restrict__ gb1, const float* __restrict__ cb1, int I, int H,
+                                 float* __restrict__ cat) {
+  const int64_t per = (int64_t)(I + 1) * 3 * H;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2 * per) return;
+  const int sd = i >= per;
+  const int64_t l = i - sd * per;
+  const int r = (int)(l / (3 * H)), j = (int)(l - (int64_t)r * 3 * H);
+  const float* gk = sd ? gk1 : gk0; const float* ck = sd ? ck1 : ck0;
+  const float* gb = sd ? gb1 : gb0; const float* cb = sd ? cb1 : cb0;
+  float v;
+  if (r < I) v = j < 2 * H ? gk[(int64_t)r * 2 * H + j] : ck[(int64_t)r * H + (j - 2 * H)];
+  else v = j < 2 * H ? gb[j] : cb[j - 2 * H];
+  cat[i] = v;
+}
+int score_launch_gru_wxcat(const float* gk0, const float* ck0, const float* gb0, const float* cb0, const float* gk1,
+                           const float* ck1, const float* gb1, const float* cb1, int I, int H, float* cat,
+                           hipStream_t s) {
+  int64_t n = 2 * (int64_t)(I + 1) * 3 * H;
+  hipLaunchKernelGGL(gru_wxcat_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, s, gk0, ck0, gb0, cb0, gk1, ck1,
+                     gb1, cb1, I, H, cat);
+  SCORE_CHECK_LAUNCH();
+  return 0;
+}
+// dcat [I][3H] -> d gates/kernel rows [0,I) (ld 2H) and d candidate/kernel rows [0,I) (ld H)
+__global__ void gru_wxsplit_kernel(const float* __restrict__ dcat, int I, int H, float* __restrict__ dgk,
+                                   float* __restrict__ dck) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)I * 3 * H) return;
+  const int r = (int)(i / (3 * H)), j = (int)(i - (int64_t)r * 3 * H);
+  if (j < 2 * H) dgk[(int64_t)r * 2 * H + j] = dcat[i];
+  else dck[(int64_t)r * H + (j - 2 * H)] = dcat[i];
+}
+int score_launch_gru_wxsplit(const float* dcat, int I, int H, float* dgk, float* dck, hipStream_t s) {
+  int64_t n = (int64_t)I * 3 * H;
+  hipLaunchKernelGGL(gru_wxsplit_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, s, dcat, I, H, dgk, dck);
+  SCORE_CHECK_LAUNCH();
+  return 0;
+}
+
 // ------------------------------------------------------------------ ApplyAdam (score.py:96-99)
 // TF training_ops: m += (g - m)(1-b1); v += (g*g - v)(1-b2); var -= m*alpha / (sqrt(v) + eps)
 __device__ __forceinline__ void adam1(float& p, float& m, float& v, float g, float omb1, float omb2, float alpha,
