@@ -2,6 +2,7 @@
 // launch sequences of SCORE and its ablations (score.py:188-369) on one stream.
 // Host code only; every kernel lives in embed/gemm/gru/head.hip.
 #include <string.h>
+#include <stdlib.h>
 #include <stdio.h>
 #include <math.h>
 #include "common.h"
@@ -351,7 +352,7 @@ extern "C" int score_forward(const score_config_t* cfg, const score_state_t* st,
   {
     GruArgs ga;
     memset(&ga, 0, sizeof(ga));
-    ga.B = B; ga.T = T; ga.H = H; ga.length = bt->length;
+    ga.B = B; ga.T = T; ga.H = H; ga.length = bt->length; ga.nw8 = 1;   // H = 128: two waves per SIMD hide the LDS/epilogue latency (measured -0.08 ms/step)
     G(score_launch_gru_wxcat(W + P.gk[0], W + P.ck[0], W + P.gb[0], W + P.cb[0], W + P.gk[1], W + P.ck[1], W + P.gb[1],
                              W + P.cb[1], d.I, H, ws + w.wxcat, s));
     for (int sd = 0; sd < 2; ++sd) {
@@ -503,7 +504,7 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
   {
     GruArgs ga;
     memset(&ga, 0, sizeof(ga));
-    ga.B = B; ga.T = T; ga.H = H; ga.length = bt->length;
+    ga.B = B; ga.T = T; ga.H = H; ga.length = bt->length; ga.nw8 = 1;   // H = 128: two waves per SIMD hide the LDS/epilogue latency (measured -0.08 ms/step)
     for (int sd = 0; sd < 2; ++sd) {
       GruSide& g = ga.s[sd];
       g.Wg = W + P.gk[sd] + (int64_t)d.I * 2 * H; g.ldwg = 2 * H;

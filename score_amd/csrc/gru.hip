@@ -123,7 +123,7 @@ extern "C" int score_gru_fwd(int32_t B, int32_t T, int32_t H, const float* xproj
   if (gru_reg_ok(H)) {
     GruArgs a;
     memset(&a, 0, sizeof(a));
-    a.B = B; a.T = T; a.H = H; a.length = length;
+    a.B = B; a.T = T; a.H = H; a.length = length; a.nw8 = 1;
     a.s[0].xproj = xproj; a.s[0].Wg = Wg; a.s[0].ldwg = ldwg; a.s[0].Wc = Wc; a.s[0].ldwc = ldwc;
     a.s[0].out = out; a.s[0].ldo = ldo; a.s[0].gates = gates_save; a.s[0].final_state = final_state;
     return score_gru_fwd_multi(a, 1, (hipStream_t)stream);
@@ -256,7 +256,7 @@ extern "C" int score_gru_bwd(int32_t B, int32_t T, int32_t H, const float* Wg, i
   if (gru_reg_ok(H)) {
     GruArgs a;
     memset(&a, 0, sizeof(a));
-    a.B = B; a.T = T; a.H = H; a.length = length;
+    a.B = B; a.T = T; a.H = H; a.length = length; a.nw8 = 1;
     GruSide& g = a.s[0];
     g.Wg = Wg; g.ldwg = ldwg; g.Wc = Wc; g.ldwc = ldwc; g.out = const_cast<float*>(out); g.ldo = ldo;
     g.gates = const_cast<float*>(gates_save); g.dout = dout; g.lddo = lddo; g.dfinal = dfinal;
@@ -295,11 +295,11 @@ __device__ __forceinline__ float sigmoid_fast(float x) { return __frcp_rn(1.0f +
 __device__ __forceinline__ float tanh_fast(float x) { return 1.0f - 2.0f * __frcp_rn(__expf(2.0f * x) + 1.0f); }
 
 
-template <int H>
-__global__ __launch_bounds__(256) void gru_fwd_reg_kernel(const GruArgs a) {
+template <int H, int NW>
+__global__ __launch_bounds__(64 * NW) void gru_fwd_reg_kernel(const GruArgs a) {
   constexpr int KS = H / 4;                 // k-steps of 4
   constexpr int NTG = 2 * H / 16, NTC = H / 16;
-  constexpr int TGW = (NTG + 3) / 4, TCW = (NTC + 3) / 4;
+  constexpr int TGW = (NTG + NW - 1) / NW, TCW = (NTC + NW - 1) / NW;
   constexpr int LD = H + 2;                 // (16 rows x 2 k) of a lane group land on 32 distinct banks
   __shared__ float hs[RRB * LD], rhs[RRB * LD], us[RRB * LD];
   const int tiles_b = (a.B + RRB - 1) / RRB;
@@ -313,14 +313,14 @@ __global__ __launch_bounds__(256) void gru_fwd_reg_kernel(const GruArgs a) {
   float wg[TGW][KS], wc[TCW][KS];
 #pragma unroll
   for (int tt = 0; tt < TGW; ++tt) {
-    const int tile = wave + 4 * tt;
+    const int tile = wave + NW * tt;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
       wg[tt][ks] = tile < NTG ? sd.Wg[(int64_t)(ks * 4 + lq) * sd.ldwg + tile * 16 + lc] : 0.f;
   }
 #pragma unroll
   for (int tt = 0; tt < TCW; ++tt) {
-    const int tile = wave + 4 * tt;
+    const int tile = wave + NW * tt;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
       wc[tt][ks] = tile < NTC ? sd.Wc[(int64_t)(ks * 4 + lq) * sd.ldwc + tile * 16 + lc] : 0.f;
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256) void gru_fwd_reg_kernel(const GruArgs a) {
     rok[r] = b < a.B;
     len[r] = rok[r] ? a.length[b] : 0;
   }
-  for (int e = tid; e < RRB * LD; e += 256) hs[e] = 0.f;
+  for (int e = tid; e < RRB * LD; e += 64 * NW) hs[e] = 0.f;
   __syncthreads();
 
   for (int t = 0; t < T; ++t) {
@@ -344,12 +344,12 @@ __global__ __launch_bounds__(256) void gru_fwd_reg_kernel(const GruArgs a) {
       const int64_t row = (int64_t)(b0 + lq * 4 + r) * T + t;
 #pragma unroll
       for (int tt = 0; tt < TGW; ++tt) {
-        const int tile = wave + 4 * tt;
+        const int tile = wave + NW * tt;
         xg[tt][r] = (rok[r] && tile < NTG) ? sd.xproj[row * 3 * H + tile * 16 + lc] : 0.f;
       }
 #pragma unroll
       for (int tt = 0; tt < TCW; ++tt) {
-        const int tile = wave + 4 * tt;
+        const int tile = wave + NW * tt;
         xc[tt][r] = (rok[r] && tile < NTC) ? sd.xproj[row * 3 * H + 2 * H + tile * 16 + lc] : 0.f;
       }
     }
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(256) void gru_fwd_reg_kernel(const GruArgs a) {
     }
 #pragma unroll
     for (int tt = 0; tt < TGW; ++tt) {
-      const int tile = wave + 4 * tt;
+      const int tile = wave + NW * tt;
       if (tile >= NTG) continue;
       const int j = tile * 16 + lc;
 #pragma unroll
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(256) void gru_fwd_reg_kernel(const GruArgs a) {
     }
 #pragma unroll
     for (int tt = 0; tt < TCW; ++tt) {
-      const int tile = wave + 4 * tt;
+      const int tile = wave + NW * tt;
       if (tile >= NTC) continue;
       const int j = tile * 16 + lc;
 #pragma unroll
@@ -412,17 +412,17 @@ __global__ __launch_bounds__(256) void gru_fwd_reg_kernel(const GruArgs a) {
     __syncthreads();
   }
   if (sd.final_state)
-    for (int e = tid; e < RRB * H; e += 256) {
+    for (int e = tid; e < RRB * H; e += 64 * NW) {
       const int i = e / H, j = e - i * H;
       if (b0 + i < a.B) sd.final_state[(int64_t)(b0 + i) * H + j] = hs[i * LD + j];
     }
 }
 
-template <int H>
-__global__ __launch_bounds__(256) void gru_bwd_reg_kernel(const GruArgs a) {
+template <int H, int NW>
+__global__ __launch_bounds__(64 * NW) void gru_bwd_reg_kernel(const GruArgs a) {
   constexpr int KS = H / 4;
   constexpr int NT = H / 16;
-  constexpr int TW = (NT + 3) / 4;
+  constexpr int TW = (NT + NW - 1) / NW;
   constexpr int LD = H + 2, LD2 = 2 * H + 2;
   __shared__ float dh[RRB * LD], dpc[RRB * LD], dpg[RRB * LD2];
   const int tiles_b = (a.B + RRB - 1) / RRB;
@@ -437,7 +437,7 @@ __global__ __launch_bounds__(256) void gru_bwd_reg_kernel(const GruArgs a) {
   float wct[TW][KS], wgt[TW][2 * KS];
 #pragma unroll
   for (int tt = 0; tt < TW; ++tt) {
-    const int tile = wave + 4 * tt;
+    const int tile = wave + NW * tt;
     const int j = tile * 16 + lc;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) wct[tt][ks] = tile < NT ? sd.Wc[(int64_t)j * sd.ldwc + ks * 4 + lq] : 0.f;
@@ -456,7 +456,7 @@ __global__ __launch_bounds__(256) void gru_bwd_reg_kernel(const GruArgs a) {
   }
 #pragma unroll
   for (int tt = 0; tt < TW; ++tt) {
-    const int tile = wave + 4 * tt;
+    const int tile = wave + NW * tt;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int i = lq * 4 + r, j = tile * 16 + lc;
@@ -467,7 +467,7 @@ __global__ __launch_bounds__(256) void gru_bwd_reg_kernel(const GruArgs a) {
   auto prefetch = [&](int t) {
 #pragma unroll
     for (int tt = 0; tt < TW; ++tt) {
-      const int tile = wave + 4 * tt;
+      const int tile = wave + NW * tt;
       const int j = tile * 16 + lc;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -497,7 +497,7 @@ __global__ __launch_bounds__(256) void gru_bwd_reg_kernel(const GruArgs a) {
     // phase 1 (elementwise): dpu, dpc ; dh <- dh_tot * u
 #pragma unroll
     for (int tt = 0; tt < TW; ++tt) {
-      const int tile = wave + 4 * tt;
+      const int tile = wave + NW * tt;
       if (tile >= NT) continue;
       const int j = tile * 16 + lc;
 #pragma unroll
@@ -538,7 +538,7 @@ __global__ __launch_bounds__(256) void gru_bwd_reg_kernel(const GruArgs a) {
       }
 #pragma unroll
       for (int tt = 0; tt < TW; ++tt) {
-        const int tile = wave + 4 * tt;
+        const int tile = wave + NW * tt;
         if (tile >= NT) continue;
         const int j = tile * 16 + lc;
 #pragma unroll
@@ -575,7 +575,7 @@ __global__ __launch_bounds__(256) void gru_bwd_reg_kernel(const GruArgs a) {
       }
 #pragma unroll
       for (int tt = 0; tt < TW; ++tt) {
-        const int tile = wave + 4 * tt;
+        const int tile = wave + NW * tt;
         if (tile >= NT) continue;
         const int j = tile * 16 + lc;
 #pragma unroll
@@ -592,10 +592,11 @@ int score_gru_fwd_multi(GruArgs& a, int nsides, hipStream_t s) {
   const int H = a.H;
   if (gru_reg_ok(H)) {
     dim3 grid(nsides * ((a.B + RRB - 1) / RRB));
-    if (H == 16) hipLaunchKernelGGL(gru_fwd_reg_kernel<16>, grid, dim3(256), 0, s, a);
-    else if (H == 32) hipLaunchKernelGGL(gru_fwd_reg_kernel<32>, grid, dim3(256), 0, s, a);
-    else if (H == 64) hipLaunchKernelGGL(gru_fwd_reg_kernel<64>, grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(gru_fwd_reg_kernel<128>, grid, dim3(256), 0, s, a);
+    if (H == 16) hipLaunchKernelGGL((gru_fwd_reg_kernel<16, 4>), grid, dim3(256), 0, s, a);
+    else if (H == 32) hipLaunchKernelGGL((gru_fwd_reg_kernel<32, 4>), grid, dim3(256), 0, s, a);
+    else if (H == 64) hipLaunchKernelGGL((gru_fwd_reg_kernel<64, 4>), grid, dim3(256), 0, s, a);
+    else if (a.nw8) hipLaunchKernelGGL((gru_fwd_reg_kernel<128, 8>), grid, dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((gru_fwd_reg_kernel<128, 4>), grid, dim3(256), 0, s, a);
     SCORE_CHECK_LAUNCH();
     return 0;
   }
@@ -611,10 +612,11 @@ int score_gru_bwd_multi(GruArgs& a, int nsides, hipStream_t s) {
   const int H = a.H;
   if (gru_reg_ok(H)) {
     dim3 grid(nsides * ((a.B + RRB - 1) / RRB));
-    if (H == 16) hipLaunchKernelGGL(gru_bwd_reg_kernel<16>, grid, dim3(256), 0, s, a);
-    else if (H == 32) hipLaunchKernelGGL(gru_bwd_reg_kernel<32>, grid, dim3(256), 0, s, a);
-    else if (H == 64) hipLaunchKernelGGL(gru_bwd_reg_kernel<64>, grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(gru_bwd_reg_kernel<128>, grid, dim3(256), 0, s, a);
+    if (H == 16) hipLaunchKernelGGL((gru_bwd_reg_kernel<16, 4>), grid, dim3(256), 0, s, a);
+    else if (H == 32) hipLaunchKernelGGL((gru_bwd_reg_kernel<32, 4>), grid, dim3(256), 0, s, a);
+    else if (H == 64) hipLaunchKernelGGL((gru_bwd_reg_kernel<64, 4>), grid, dim3(256), 0, s, a);
+    else if (a.nw8) hipLaunchKernelGGL((gru_bwd_reg_kernel<128, 8>), grid, dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((gru_bwd_reg_kernel<128, 4>), grid, dim3(256), 0, s, a);
     SCORE_CHECK_LAUNCH();
     return 0;
   }

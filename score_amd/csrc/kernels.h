@@ -122,6 +122,7 @@ struct GruArgs {
   GruSide s[2];
   const int32_t* length;
   int B, T, H;
+  int nw8;      // H = 128: 8 waves per workgroup (2 per SIMD) instead of 4
 };
 int score_gru_fwd_multi(GruArgs& a, int nsides, hipStream_t s);
 int score_gru_bwd_multi(GruArgs& a, int nsides, hipStream_t s);
