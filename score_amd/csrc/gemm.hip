@@ -193,13 +193,22 @@ extern "C" int score_gemm(int32_t trans, int32_t M, int32_t N, int32_t K, const 
   const bool al_b = (ldb & 3) == 0 && (reinterpret_cast<uintptr_t>(Bm) & 15) == 0;
   const bool x3_ok = al_a && al_b && (a_kc ? (K & 3) == 0 : (M & 3) == 0) && (b_kc ? (K & 3) == 0 : (N & 3) == 0);
   // measured on MI355X (tools/gemm_ab.py, interleaved A/B in one process): the split pays where the
-  // tile is wide and the K loop long; NT and small products stay on the f32 MFMA kernel
+  // tile is wide and the K loop long; small products stay on the f32 MFMA kernel
   const bool x3_shape = (trans == 0 && M >= 4096 && (N >= 256 || (K >= 1024 && N >= 64))) ||
+                        (trans == 1 && M >= 4096 && N >= 256) ||
                         (trans == 2 && (int64_t)M * N >= 32768 && K >= 4096);
   const bool x3_force = (flags & 32) != 0;     // tests: take the bf16x3 kernel whenever it is legal
   if ((flags & (F_X3 | 32)) && x3_ok && M >= 64 && N >= 32 && K >= 32 && (x3_shape || x3_force)) {
-    // fp32-accurate product on the bf16 matrix cores (gemm_bf16x3.hip): 128x128x32 tiles
-    dim3 g3((N + 127) / 128, (M + 127) / 128, 1);
+    // fp32-accurate product on the bf16 matrix cores (gemm_bf16x3.hip): (64*wm) x 128 x 32 tiles.
+    // Pick the tile height by how many tiles the busiest CU gets (co-resident blocks share its matrix
+    // pipe, so what counts is tiles per CU, not per residency slot); a 64-row tile costs ~57 % of a
+    // 128-row one (same B tile, half the MFMAs).
+    auto rounds = [&](int wm_) {
+      int64_t blocks = (int64_t)((N + 127) / 128) * ((M + 64 * wm_ - 1) / (64 * wm_));
+      return (double)((blocks + 255) / 256) * (wm_ == 2 ? 1.0 : 0.57);
+    };
+    const int wm3 = rounds(1) < rounds(2) ? 1 : 2;
+    dim3 g3((N + 127) / 128, (M + 64 * wm3 - 1) / (64 * wm3), 1);
     int ns = 1;
     int64_t t3 = (int64_t)g3.x * g3.y;
     if (t3 < 256 && K >= 512 && scratch) {
@@ -216,7 +225,7 @@ extern "C" int score_gemm(int32_t trans, int32_t M, int32_t N, int32_t K, const 
       g3.z = ns;
       sl = ns > 1 ? scratch : nullptr;
     }
-    SCORE_TRY(score_launch_gemm_bf16x3(trans, g3, M, N, K, A, lda, Bm, ldb, C, ldc, bias, flags & 15, keep_prob,
+    SCORE_TRY(score_launch_gemm_bf16x3(trans, wm3, g3, M, N, K, A, lda, Bm, ldb, C, ldc, bias, flags & 15, keep_prob,
                                        drop_mask, drop_seed, kc, sl, s));
     if (sl) {
       int64_t n = (int64_t)M * N;

@@ -10,13 +10,13 @@
 // Tile: 128x128x32 per 256-thread block, 2x2 waves of 64x64 (2x2 MFMA tiles each), LDS holds the
 // three bf16 planes of A as [m][k] and of B as [n][k] (k contiguous, 16-B fragments, row stride 40
 // bf16 = 80 B: conflict-free ds_read_b128).  Same operand layouts / epilogue / split-K as gemm.hip.
+#include <type_traits>
 #include "common.h"
 #include "kernels.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-#define TBM 128
 #define TBN 128
 #define TBK 32
 #define TLD 40   // bf16 per LDS row (32 + 8 pad)
@@ -48,13 +48,16 @@ __device__ __forceinline__ void split3(float x, uint32_t& h, uint32_t& m, uint32
 // pack two bf16 (given as fp32-word upper halves) into one dword: lo element first
 __device__ __forceinline__ uint32_t pack2(uint32_t a, uint32_t b) { return (a >> 16) | b; }
 
-template <int TRANS>
+// WM = 32-row MFMA tiles per wave along M: block tile (64*WM) x 128
+template <int TRANS, int WM>
 __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(int M, int N, int K, const float* __restrict__ A, int lda,
                                                           const float* __restrict__ Bm, int ldb,
                                                           float* __restrict__ C, int ldc,
                                                           const float* __restrict__ bias, int flags, float keep,
                                                           const uint8_t* __restrict__ mask, uint64_t seed,
                                                           int k_chunk, float* __restrict__ slab) {
+  constexpr int TBM = 64 * WM;
+  constexpr int EA = TBM * TBK / 256;      // A elements staged per thread (16 or 8)
   __shared__ __attribute__((aligned(16))) unsigned short Ap[3][TBM * TLD];
   __shared__ __attribute__((aligned(16))) unsigned short Bp[3][TBN * TLD];
   const int tid = threadIdx.x;
@@ -70,12 +73,13 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(int M, int N, int K, c
   // Register pipeline: tile t is in LDS, tile t+1 is being split (VALU, interleaved with the MFMAs of
   // tile t), tile t+2 goes in flight from global memory as soon as the split has consumed the registers.  All staging is branch-free: addresses are
   // clamped into range and out-of-range elements are zeroed by a select.
-  float xa[16], xb[16];                    // staging registers (tile t+1, then t+2)
-  uint32_t pa[24], pb[24];
+  constexpr int XA = A_KCONTIG ? EA : 16;  // a k-strided operand is staged as 4x4 blocks: 16 per active thread
+  float xa[XA], xb[16];                    // staging registers (tile t+1, then t+2)
+  uint32_t pa[3 * XA / 2], pb[24];
   // k-contiguous operand X[r][k] (r = m or n): thread -> 4 quads, quad q: row q>>3, k (q&7)*4
-  auto load_kc = [&](const float* X, int ld, int r0, int rlim, int k0, float* dst) {
+  auto load_kc = [&](const float* X, int ld, int r0, int rlim, int k0, float* dst, auto nrep) {
 #pragma unroll
-    for (int rep = 0; rep < 4; ++rep) {
+    for (int rep = 0; rep < decltype(nrep)::value; ++rep) {
       const int q = tid + 256 * rep;
       const int r = r0 + (q >> 3), k = k0 + (q & 7) * 4;
       const bool ok = r < rlim && k < kend;
@@ -86,35 +90,40 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(int M, int N, int K, c
   };
   // k-strided operand X[k][c] (c = m or n): thread -> a 4(k) x 4(c) block: k-group tid&7, column-group
   // tid>>3; four 16-B loads along c (one per k), transposed in registers on the way to LDS
-  auto load_ks = [&](const float* X, int ld, int c0, int clim, int k0, float* dst) {
+  auto load_ks = [&](const float* X, int ld, int c0, int clim, int k0, float* dst, int ncols) {
     const int c = c0 + (tid >> 3) * 4;
     const int kb = k0 + (tid & 7) * 4;
+    const bool mine = (tid >> 3) * 4 < ncols;      // a 64-wide tile has only 128 blocks of 4x4
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const bool ok = c < clim && kb + i < kend;
+      const bool ok = mine && c < clim && kb + i < kend;
       const float4 v = ld4(X + (int64_t)(ok ? kb + i : 0) * ld + (ok ? c : 0));
       dst[i * 4 + 0] = ok ? v.x : 0.f; dst[i * 4 + 1] = ok ? v.y : 0.f;
       dst[i * 4 + 2] = ok ? v.z : 0.f; dst[i * 4 + 3] = ok ? v.w : 0.f;
     }
   };
   // split 16 staged floats into packed bf16 planes: dst[p*8 + d], d = dword index inside the plane
-  auto split16 = [&](const float* src, uint32_t* dst) {
+  // n floats -> planes dst[p*(n/2) + d]
+  auto split16 = [&](const float* src, uint32_t* dst, auto nn) {
+    constexpr int NH = decltype(nn)::value / 2;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < NH; ++j) {
       uint32_t h0, m0, l0, h1, m1, l1;
       split3(src[2 * j], h0, m0, l0);
       split3(src[2 * j + 1], h1, m1, l1);
-      dst[j] = pack2(h0, h1); dst[8 + j] = pack2(m0, m1); dst[16 + j] = pack2(l0, l1);
+      dst[j] = pack2(h0, h1); dst[NH + j] = pack2(m0, m1); dst[2 * NH + j] = pack2(l0, l1);
     }
   };
-  auto write_kc = [&](unsigned short (*P)[TBM * TLD], const uint32_t* src) {
+  auto write_kc = [&](unsigned short* P, int plane_stride, const uint32_t* src, auto nrep) {
+    constexpr int NR = decltype(nrep)::value;
 #pragma unroll
-    for (int rep = 0; rep < 4; ++rep) {
+    for (int rep = 0; rep < NR; ++rep) {
       const int q = tid + 256 * rep;
       const int r = q >> 3, k = (q & 7) * 4;
 #pragma unroll
       for (int p = 0; p < 3; ++p)
-        *reinterpret_cast<uint2*>(&P[p][r * TLD + k]) = make_uint2(src[p * 8 + rep * 2], src[p * 8 + rep * 2 + 1]);
+        *reinterpret_cast<uint2*>(&P[p * plane_stride + r * TLD + k]) =
+            make_uint2(src[p * 2 * NR + rep * 2], src[p * 2 * NR + rep * 2 + 1]);
     }
   };
   // (ks) the 4x4 block transposed: for column e the four k values are src[0*4+e] .. src[3*4+e]
@@ -129,30 +138,33 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(int M, int N, int K, c
       dst[16 + e * 2] = pack2(l[0], l[1]); dst[16 + e * 2 + 1] = pack2(l[2], l[3]);
     }
   };
-  auto write_ks = [&](unsigned short (*P)[TBM * TLD], const uint32_t* src) {
+  auto write_ks = [&](unsigned short* P, int plane_stride, const uint32_t* src, int ncols) {
     const int c = (tid >> 3) * 4, kb = (tid & 7) * 4;
+    if (c >= ncols) return;
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll
       for (int p = 0; p < 3; ++p)
-        *reinterpret_cast<uint2*>(&P[p][(c + e) * TLD + kb]) = make_uint2(src[p * 8 + e * 2], src[p * 8 + e * 2 + 1]);
+        *reinterpret_cast<uint2*>(&P[p * plane_stride + (c + e) * TLD + kb]) =
+            make_uint2(src[p * 8 + e * 2], src[p * 8 + e * 2 + 1]);
   };
+  // (the k-strided A of a 64-row tile still stages 16 floats per ACTIVE thread: EA counts kc quads only)
   auto split_tiles = [&](const float* ra, const float* rb) {
-    if (A_KCONTIG) split16(ra, pa); else split16t(ra, pa);
-    if (B_KCONTIG) split16(rb, pb); else split16t(rb, pb);
+    if (A_KCONTIG) split16(ra, pa, std::integral_constant<int, EA>()); else split16t(ra, pa);
+    if (B_KCONTIG) split16(rb, pb, std::integral_constant<int, 16>()); else split16t(rb, pb);
   };
   auto load_tiles = [&](int k0, float* ra, float* rb) {
-    if (A_KCONTIG) load_kc(A, lda, bm, M, k0, ra); else load_ks(A, lda, bm, M, k0, ra);
-    if (B_KCONTIG) load_kc(Bm, ldb, bn, N, k0, rb); else load_ks(Bm, ldb, bn, N, k0, rb);
+    if (A_KCONTIG) load_kc(A, lda, bm, M, k0, ra, std::integral_constant<int, EA / 4>()); else load_ks(A, lda, bm, M, k0, ra, TBM);
+    if (B_KCONTIG) load_kc(Bm, ldb, bn, N, k0, rb, std::integral_constant<int, 4>()); else load_ks(Bm, ldb, bn, N, k0, rb, TBN);
   };
   auto write_tiles = [&]() {
-    if (A_KCONTIG) write_kc(Ap, pa); else write_ks(Ap, pa);
-    if (B_KCONTIG) write_kc(Bp, pb); else write_ks(Bp, pb);
+    if (A_KCONTIG) write_kc(&Ap[0][0], TBM * TLD, pa, std::integral_constant<int, EA / 4>()); else write_ks(&Ap[0][0], TBM * TLD, pa, TBM);
+    if (B_KCONTIG) write_kc(&Bp[0][0], TBN * TLD, pb, std::integral_constant<int, 4>()); else write_ks(&Bp[0][0], TBN * TLD, pb, TBN);
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[WM][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < WM; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -164,18 +176,22 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(int M, int N, int K, c
   auto mfma_phase = [&]() {
 #pragma unroll
     for (int ks = 0; ks < TBK / 16; ++ks) {
-      bf16x8 af[2][3], bf[2][3];
+      bf16x8 af[WM][3], bf[2][3];
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int p = 0; p < 3; ++p) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
-          const uint4 va = *reinterpret_cast<const uint4*>(&Ap[p][(wm * 64 + i * 32 + r31) * TLD + ks * 16 + kh * 8]);
-          const uint4 vb = *reinterpret_cast<const uint4*>(&Bp[p][(wn * 64 + i * 32 + r31) * TLD + ks * 16 + kh * 8]);
+        for (int i = 0; i < WM; ++i) {
+          const uint4 va = *reinterpret_cast<const uint4*>(&Ap[p][(wm * 32 * WM + i * 32 + r31) * TLD + ks * 16 + kh * 8]);
           af[i][p] = __builtin_bit_cast(bf16x8, va);
-          bf[i][p] = __builtin_bit_cast(bf16x8, vb);
         }
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i) {
+          const uint4 vb = *reinterpret_cast<const uint4*>(&Bp[p][(wn * 64 + i * 32 + r31) * TLD + ks * 16 + kh * 8]);
+          bf[i][p] = __builtin_bit_cast(bf16x8, vb);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           f32x16 c = acc[i][j];
@@ -190,9 +206,9 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(int M, int N, int K, c
         }
     }
 #pragma unroll
-    for (int g = 0; g < 48; ++g) {
+    for (int g = 0; g < 24 * WM; ++g) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA  (32 cycles of matrix pipe, 8 of issue)
-      __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);   // 5 VALU  of the next tile's split
+      __builtin_amdgcn_sched_group_barrier(0x002, WM == 2 ? 5 : 8, 0);   // VALU of the next tile's split
     }
   };
   load_tiles(kbeg, xa, xb);
@@ -208,14 +224,14 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(int M, int N, int K, c
   }
 
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < WM; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int col = bn + wn * 64 + j * 32 + r31;
       if (col >= N) continue;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = bm + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        const int row = bm + wm * 32 * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
         if (row >= M) continue;
         if (slab) {
           slab[((int64_t)blockIdx.z * M + row) * N + col] = acc[i][j][r];
@@ -228,15 +244,21 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(int M, int N, int K, c
     }
 }
 
-int score_launch_gemm_bf16x3(int trans, dim3 grid, int M, int N, int K, const float* A, int lda, const float* Bm,
-                             int ldb, float* C, int ldc, const float* bias, int flags, float keep,
+int score_launch_gemm_bf16x3(int trans, int wm, dim3 grid, int M, int N, int K, const float* A, int lda,
+                             const float* Bm, int ldb, float* C, int ldc, const float* bias, int flags, float keep,
                              const uint8_t* mask, uint64_t seed, int k_chunk, float* slab, hipStream_t s) {
-#define LX(TR)                                                                                               \
-  hipLaunchKernelGGL((gemm_bf16x3_kernel<TR>), grid, dim3(256), 0, s, M, N, K, A, lda, Bm, ldb, C, ldc, bias, \
+#define LX(TR, WMv)                                                                                               \
+  hipLaunchKernelGGL((gemm_bf16x3_kernel<TR, WMv>), grid, dim3(256), 0, s, M, N, K, A, lda, Bm, ldb, C, ldc, bias, \
                      flags, keep, mask, seed, k_chunk, slab)
-  if (trans == 0) LX(0);
-  else if (trans == 1) LX(1);
-  else LX(2);
+  if (wm == 2) {
+    if (trans == 0) LX(0, 2);
+    else if (trans == 1) LX(1, 2);
+    else LX(2, 2);
+  } else {
+    if (trans == 0) LX(0, 1);
+    else if (trans == 1) LX(1, 1);
+    else LX(2, 1);
+  }
 #undef LX
   SCORE_CHECK_LAUNCH();
   return 0;

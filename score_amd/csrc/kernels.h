@@ -3,8 +3,8 @@
 #include "common.h"
 
 // gemm.hip / gemm_bf16x3.hip
-int score_launch_gemm_bf16x3(int trans, dim3 grid, int M, int N, int K, const float* A, int lda, const float* Bm,
-                             int ldb, float* C, int ldc, const float* bias, int flags, float keep,
+int score_launch_gemm_bf16x3(int trans, int wm, dim3 grid, int M, int N, int K, const float* A, int lda,
+                             const float* Bm, int ldb, float* C, int ldc, const float* bias, int flags, float keep,
                              const uint8_t* mask, uint64_t seed, int k_chunk, float* slab, hipStream_t s);
 #define COLSUM_MAX_JOBS 24
 struct ColsumJob { const float* X; float* out; int M, N, ld, acc, cols, rpb, nparts; int64_t part_off; };

@@ -82,7 +82,7 @@ def test_gemm_fp32(trans, shape):
 
 
 @pytest.mark.parametrize("trans", [0, 1, 2])
-@pytest.mark.parametrize("shape", [(128, 128, 32), (200, 76, 100), (2048, 384, 448), (4096, 80, 1184), (448, 256, 4096),
+@pytest.mark.parametrize("shape", [(128, 128, 32), (200, 76, 100), (2048, 384, 448), (4096, 80, 1184), (448, 256, 4096), (20480, 384, 64),
                                    (64, 32, 36)])
 def test_gemm_bf16x3_is_fp32_accurate(trans, shape):
     # "bf16x3": operands split exactly into three bf16, six bf16 MFMAs per k-step; must meet the SAME
