@@ -155,6 +155,8 @@ def main():
         e_a0.record()
         model.apply_adam(args.lr, args.reg_lambda)
         e_a1.record()
+        if sharded and i + 1 < args.steps:      # index-only phase of the next batch under this step's compute
+            model.prefetch(batches[(i + 1) % len(batches)])
     barrier()
     dt = time.perf_counter() - t0
     model.enable_stage_events(False)

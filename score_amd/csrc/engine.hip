@@ -196,7 +196,10 @@ void build_ws(const Dims& d, int B, WS* w) {
   if (tb2 > tb) tb = tb2;
   w->sort_temp_bytes = (int64_t)tb;
   w->sort_temp = take((int64_t)(tb + 3) / 4 + 4);
-  w->partial_floats = 2 * cdiv64(np, 64) * d.D + 8 + 2 * cdiv64(np, 64);
+  {
+    const int64_t nw = cdiv64(np, score_pull_window(np));
+    w->partial_floats = 2 * nw * d.D + 8 + 2 * nw;
+  }
   w->partials = take(w->partial_floats);
   w->total = cur;
 }

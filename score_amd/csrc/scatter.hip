@@ -299,9 +299,13 @@ __global__ __launch_bounds__(256) void pull_long_kernel(const PullArgs a, const 
   }
 }
 
+// occurrences per window: 64 for a whole batch (millions of occurrences), fewer for short lists so the
+// chip still gets >= ~16k independent groups
+int score_pull_window(int64_t n) { return n >= (1 << 20) ? 64 : n >= (1 << 19) ? 32 : n >= (1 << 18) ? 16 : 8; }
+
 int score_launch_pull(PullArgs& a, const uint32_t* keys, const uint32_t* vals, int64_t n, float* out,
                       float* partials, int64_t partial_floats, hipStream_t s) {
-  const int WS = 64;
+  const int WS = score_pull_window(n);
   int LPR = 1;
   while (LPR < a.D / 4) LPR <<= 1;
   if (LPR > 64) return SCORE_E_SHAPE;
@@ -338,7 +342,7 @@ extern "C" int score_segment_sum_rows(const int32_t* rows, const float* src, int
   hipStream_t s = (hipStream_t)stream;
   size_t sort_bytes = 0;
   SCORE_TRY(score_plan_temp_bytes(n, 32, &sort_bytes));
-  const int64_t nw = cdiv64(n, 64);
+  const int64_t nw = cdiv64(n, score_pull_window(n));
   const int64_t partial_floats = 2 * nw * D + 8 + 2 * nw;
   // scratch: keys_in | keys_out | vals_in | vals_out | partials | sort temp
   const int64_t need = 4 * align_up64(n, 4) * 4 + align_up64(partial_floats, 4) * 4 + (int64_t)sort_bytes;
@@ -365,7 +369,7 @@ extern "C" int score_segment_sum_rows(const int32_t* rows, const float* src, int
 extern "C" int64_t score_segment_sum_scratch_bytes(int64_t n, int32_t D) {
   size_t sort_bytes = 0;
   if (score_plan_temp_bytes(n > 0 ? n : 1, 32, &sort_bytes) != 0) return -1;
-  const int64_t nw = cdiv64(n, 64);
+  const int64_t nw = cdiv64(n, score_pull_window(n));
   const int64_t partial_floats = 2 * nw * D + 8 + 2 * nw;
   return 4 * align_up64(n, 4) * 4 + align_up64(partial_floats, 4) * 4 + (int64_t)sort_bytes + 64;
 }

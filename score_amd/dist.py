@@ -126,10 +126,10 @@ class HipBackend(object):
         self._scratch = None
 
     # -- index plan ---------------------------------------------------------------------
-    def plan(self, batch_data):
+    def plan(self, batch_data, slot=0):
         m = self.m
         db = m.device_batch(batch_data)
-        lay, ws = m._workspace(db.B)
+        lay, ws = m._workspace(db.B, slot)
         st = m._state(ws)
         _lib.check(self.lib.score_index_plan(C.byref(m.cfg), C.byref(st), C.byref(db.struct), self.world, 1,
                                              m._stream()), "score_index_plan")
@@ -143,7 +143,7 @@ class HipBackend(object):
         # plan order: user_1hop, item_2hop, user_2hop, item_1hop, target_user, target_item
         remapped = _lib.Batch(_ptr(rm[0]), _ptr(rm[2]), _ptr(rm[3]), _ptr(rm[1]), _ptr(rm[4]), _ptr(rm[5]),
                               _ptr(db.tensors[6]), _ptr(db.tensors[7]), db.B)
-        return dict(db=db, remapped=remapped, keep=rm, U=U, offsets=offs, unique_rows=uniq)
+        return dict(db=db, remapped=remapped, keep=rm, U=U, offsets=offs, unique_rows=uniq, slot=slot)
 
     def gather(self, req_rows):
         n = req_rows.numel()
@@ -155,7 +155,7 @@ class HipBackend(object):
 
     def _state(self, plan, mini):
         m = self.m
-        lay, ws = m._workspace(plan["db"].B)
+        lay, ws = m._workspace(plan["db"].B, plan.get("slot", 0))
         return lay, ws, _lib.State(_ptr(mini), mini.shape[0], _ptr(m.w), _ptr(ws), ws.numel() * 4, 2,
                                    int(m.global_batch), int(m.gemm_mode), 0)
 
@@ -226,6 +226,7 @@ class ShardedSCORE(object):
                                                                       cfg_args, seed, device)
         self.device = self.backend.device
         self.D = int(eb_dim)
+        self._side, self._slot, self._slot_done, self._prefetched = None, 0, [None, None], None
 
     # bench.py compatibility with the single-device model
     @property
@@ -243,20 +244,62 @@ class ShardedSCORE(object):
     bwd_events = property(lambda self: self.backend.m.bwd_events,
                           lambda self, v: setattr(self.backend.m, "bwd_events", v))
 
-    def _fetch(self, batch_data):
-        """plan -> request rows from their owners -> gathered [U, D] mini-table"""
+    # -- step phases -----------------------------------------------------------------------
+    def _plan_and_request(self, batch_data, slot=0):
+        """Index-only phase (needs no parameters): plan the batch, tell every owner which of its
+        rows this rank needs."""
         be, cm = self.backend, self.comm
-        plan = be.plan(batch_data)
+        plan = be.plan(batch_data, slot) if slot else be.plan(batch_data)
         offs = plan["offsets"]
         send = [offs[o + 1] - offs[o] for o in range(self.world)]      # unique rows I need from shard o
         recv = cm.exchange_counts(send, self.device)                    # rows shard-me must serve to rank p
         req = torch.empty((sum(recv),), dtype=torch.int32, device=self.device)
         cm.all_to_all(req, plan["unique_rows"], recv, send)
-        rows = be.gather(req)
-        mini = torch.empty((plan["U"], self.D), dtype=torch.float32, device=self.device)
-        cm.all_to_all(mini, rows, send, recv)
         plan.update(send=send, recv=recv, req=req)
-        return plan, mini
+        return plan
+
+    def _rows(self, plan):
+        """Parameter phase: owners gather the requested rows from their (up-to-date) shard."""
+        be, cm = self.backend, self.comm
+        rows = be.gather(plan["req"])
+        mini = torch.empty((plan["U"], self.D), dtype=torch.float32, device=self.device)
+        cm.all_to_all(mini, rows, plan["send"], plan["recv"])
+        return mini
+
+    def prefetch(self, batch_data):
+        """Run the index-only phase of the NEXT batch now, on a side stream, underneath the compute
+        of the step just enqueued (its result is picked up by the next forward_backward/eval on the
+        same batch object).  Every rank must call it with its own next batch."""
+        if self.device.type != "cuda":
+            self._prefetched = (batch_data, self._plan_and_request(batch_data, 0), None)
+            return
+        main = torch.cuda.current_stream(self.device)
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        slot = 1 - self._slot
+        if self._slot_done[slot] is not None:                # last user of that workspace slot
+            self._side.wait_event(self._slot_done[slot])
+        with torch.cuda.stream(self._side):
+            plan = self._plan_and_request(batch_data, slot)
+            ev = self._side.record_event()
+        self._prefetched = (batch_data, plan, ev)
+
+    def _fetch(self, batch_data):
+        """plan -> request rows from their owners -> gathered [U, D] mini-table"""
+        pf = getattr(self, "_prefetched", None)
+        if pf is not None and pf[0] is batch_data:
+            plan = pf[1]
+            if pf[2] is not None:
+                torch.cuda.current_stream(self.device).wait_event(pf[2])
+            self._slot = plan.get("slot", 0)
+        else:
+            plan = self._plan_and_request(batch_data, self._slot if self.device.type == "cuda" else 0)
+        self._prefetched = None
+        return plan, self._rows(plan)
+
+    def _mark_step_end(self):
+        if self.device.type == "cuda":
+            self._slot_done[self._slot] = torch.cuda.current_stream(self.device).record_event()
 
     def forward_backward(self, batch_data, reg_lambda, keep_prob=1.0, dropout_masks=None):
         be, cm = self.backend, self.comm
@@ -275,6 +318,7 @@ class ShardedSCORE(object):
 
     def apply_adam(self, lr, reg_lambda):
         self.backend.adam(lr, reg_lambda)
+        self._mark_step_end()
 
     def train_async(self, batch_data, lr, reg_lambda, keep_prob=0.8, dropout_masks=None):
         loss, _ = self.forward_backward(batch_data, reg_lambda, keep_prob, dropout_masks)
@@ -290,6 +334,7 @@ class ShardedSCORE(object):
         B = plan["B"] if "B" in plan else plan["db"].B
         be.set_global_batch(B)             # eval reports the local batch's loss, as the reference does
         fw = be.forward(plan, mini, reg_lambda, 1.0, None)
+        self._mark_step_end()
         pred = fw["y_pred"].cpu().numpy().reshape([-1, ]).tolist()
         label = be.labels(plan).cpu().numpy().reshape([-1, ]).tolist()
         loss = fw["loss"]

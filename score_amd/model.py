@@ -157,14 +157,16 @@ class SCOREBASE(object):
         return out
 
     # ------------------------------------------------------------------ device plumbing
-    def _workspace(self, B):
-        ent = self._ws.get(B)
+    def _workspace(self, B, slot=0):
+        """One workspace per (batch size, slot); slots let the sharded path plan batch t+1 while
+        batch t is still computing."""
+        ent = self._ws.get((B, slot))
         if ent is None:
             lay = _lib.workspace_layout(self.cfg, B)
             buf = torch.empty((lay.total_bytes // 4,), dtype=torch.float32, device=self.device)
-            if len(self._ws) > 4:
+            if len(self._ws) > 6:
                 self._ws.clear()
-            ent = self._ws[B] = (lay, buf)
+            ent = self._ws[(B, slot)] = (lay, buf)
         return ent
 
     def _state(self, ws):

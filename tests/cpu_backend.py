@@ -30,7 +30,7 @@ class CpuBackend(object):
         self.global_batch = 0
         self._wg = None
 
-    def plan(self, batch_data):
+    def plan(self, batch_data, slot=0):
         b = so.batch_to_arrays(batch_data)
         G = self.world
         rows_local = (self.cfg.N + G - 1) // G

@@ -41,7 +41,10 @@ def _worker(rank, world, port, model_type, out_dir):
     batches = [random_batch(rng, cfg, 6) for _ in range(2)]
     be = CpuBackend(rank, world, model_type, cfg_args, params)
     model = ShardedSCORE(*cfg_args, comm=TorchDistComm(), backend=be, model_type=model_type)
-    losses = [model.train(None, batch_tuple(b), 1e-3, 1e-3, keep_prob=1.0) for b in batches]
+    bts = [batch_tuple(b) for b in batches]
+    losses = [model.train(None, bts[0], 1e-3, 1e-3, keep_prob=1.0)]
+    model.prefetch(bts[1])                          # index-only phase of the next batch ahead of time
+    losses.append(model.train(None, bts[1], 1e-3, 1e-3, keep_prob=1.0))
     pred, label, eloss = model.eval(None, batch_tuple(batches[0]), 1e-3)
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), losses=np.asarray(losses), shard=be.full_table_part(),
              pred=np.asarray(pred), eloss=eloss, **{"dense/" + k: v for k, v in be.dense.items()},

@@ -89,7 +89,12 @@ def test_virtual_ranks_match_single_device(world, model_type, cfg_args, B):
     def fn(rank, comm):
         m = ShardedSCORE(*cfg_args, comm=comm, model_type=model_type)
         m.backend.m.set_params(params)
-        losses = [m.train(None, batch_tuple(b), 1e-3, 1e-3, keep_prob=1.0) for b in batches[rank]]
+        bts = [batch_tuple(b) for b in batches[rank]]
+        losses = []
+        for i, bt in enumerate(bts):            # with the next batch's index phase prefetched on a side stream
+            losses.append(m.train(None, bt, 1e-3, 1e-3, keep_prob=1.0))
+            if i + 1 < len(bts):
+                m.prefetch(bts[i + 1])
         pred, _, _ = m.eval(None, batch_tuple(batches[rank][0]), 1e-3)
         torch.cuda.synchronize()
         return losses, m.backend.m.table.cpu().numpy(), m.backend.m.w.cpu().numpy(), pred
