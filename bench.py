@@ -97,6 +97,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-sharded", action="store_true",
                     help="use the row-sharded all-to-all path even with one rank (exercises RCCL plumbing)")
+    ap.add_argument("--prefetch", action="store_true",
+                    help="sharded path: plan + request the next batch's rows on a side stream (measured neutral "
+                         "with one rank: the two host read-backs of the split sizes still bubble the pipeline)")
     ap.add_argument("--lr", type=float, default=1e-3)
     ap.add_argument("--reg-lambda", type=float, default=1e-4)
     args = ap.parse_args()
@@ -151,12 +154,14 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         model.fwd_events, model.bwd_events, e_a0, e_a1 = ev_sets[i]
-        fb = model.forward_backward(batches[i % len(batches)], args.reg_lambda, 0.8)
+        if sharded:   # optionally run the next batch's index-only phase (plan + row requests) inside this step
+            nxt = batches[(i + 1) % len(batches)] if (args.prefetch and i + 1 < args.steps) else None
+            fb = model.forward_backward(batches[i % len(batches)], args.reg_lambda, 0.8, None, nxt)
+        else:
+            fb = model.forward_backward(batches[i % len(batches)], args.reg_lambda, 0.8)
         e_a0.record()
         model.apply_adam(args.lr, args.reg_lambda)
         e_a1.record()
-        if sharded and i + 1 < args.steps:      # index-only phase of the next batch under this step's compute
-            model.prefetch(batches[(i + 1) % len(batches)])
     barrier()
     dt = time.perf_counter() - t0
     model.enable_stage_events(False)

@@ -29,6 +29,19 @@ from . import _lib
 from .model import SCOREBASE, DeviceBatch, _ptr, ADAM_B1, ADAM_B2, ADAM_EPS
 
 
+def _to_host(t):
+    """Device -> host copy that waits on the CURRENT stream only (pinned buffer + event), so a side
+    stream's read-back does not stall behind work queued on other streams."""
+    if t.device.type != "cuda":
+        return t
+    h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    h.copy_(t, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(t.device))
+    ev.synchronize()
+    return h
+
+
 class TorchDistComm(object):
     """torch.distributed collectives (nccl == RCCL on ROCm; gloo for the CPU tests)."""
 
@@ -44,7 +57,7 @@ class TorchDistComm(object):
         t = torch.tensor(send_counts, dtype=torch.int64, device=device)
         out = torch.empty_like(t)
         self.all_to_all(out, t, [1] * self.world, [1] * self.world)
-        return [int(x) for x in out.cpu().tolist()]
+        return [int(x) for x in _to_host(out).tolist()]
 
     def all_to_all(self, out, inp, out_splits, in_splits):
         if not self._gloo:
@@ -133,7 +146,7 @@ class HipBackend(object):
         st = m._state(ws)
         _lib.check(self.lib.score_index_plan(C.byref(m.cfg), C.byref(st), C.byref(db.struct), self.world, 1,
                                              m._stream()), "score_index_plan")
-        meta = ws[lay.plan_meta:lay.plan_meta + 2 + self.world].view(torch.int32).cpu().tolist()   # sync
+        meta = _to_host(ws[lay.plan_meta:lay.plan_meta + 2 + self.world].view(torch.int32)).tolist()   # sync
         U, offs = meta[0], meta[1:2 + self.world]
         uniq = ws[lay.plan_unique_rows:lay.plan_unique_rows + U].view(torch.int32)
         # batch struct over the remapped (unique-position) index tensors
@@ -226,7 +239,7 @@ class ShardedSCORE(object):
                                                                       cfg_args, seed, device)
         self.device = self.backend.device
         self.D = int(eb_dim)
-        self._side, self._slot, self._slot_done, self._prefetched = None, 0, [None, None], None
+        self._side, self._slot, self._slot_done, self._prefetched = None, 0, [None, None, None], None
 
     # bench.py compatibility with the single-device model
     @property
@@ -245,10 +258,11 @@ class ShardedSCORE(object):
                           lambda self, v: setattr(self.backend.m, "bwd_events", v))
 
     # -- step phases -----------------------------------------------------------------------
-    def _plan_and_request(self, batch_data, slot=0):
+    def _plan_and_request(self, batch_data, slot=0, cm=None):
         """Index-only phase (needs no parameters): plan the batch, tell every owner which of its
         rows this rank needs."""
-        be, cm = self.backend, self.comm
+        be = self.backend
+        cm = cm if cm is not None else self.comm
         plan = be.plan(batch_data, slot) if slot else be.plan(batch_data)
         offs = plan["offsets"]
         send = [offs[o + 1] - offs[o] for o in range(self.world)]      # unique rows I need from shard o
@@ -267,17 +281,19 @@ class ShardedSCORE(object):
         return mini
 
     def prefetch(self, batch_data):
-        """Run the index-only phase of the NEXT batch now, on a side stream, underneath the compute
-        of the step just enqueued (its result is picked up by the next forward_backward/eval on the
-        same batch object).  Every rank must call it with its own next batch."""
+        """Index-only phase of the NEXT batch, on a high-priority side stream.  Called right after this
+        step's row fetch has been enqueued and BEFORE its forward/backward are (forward_backward(...,
+        next_batch=) does that): on the communicator's stream the two small collectives then sit between
+        this step's row exchange and its gradient exchange, the host blocks on the side stream only while
+        the GPU still works on the previous step, and three workspace slots keep the plan buffers of the
+        steps in flight apart.  Every rank must call it, with its own next batch."""
         if self.device.type != "cuda":
             self._prefetched = (batch_data, self._plan_and_request(batch_data, 0), None)
             return
-        main = torch.cuda.current_stream(self.device)
         if self._side is None:
-            self._side = torch.cuda.Stream(device=self.device)
-        slot = 1 - self._slot
-        if self._slot_done[slot] is not None:                # last user of that workspace slot
+            self._side = torch.cuda.Stream(device=self.device, priority=-1)
+        slot = (self._slot + 1) % 3
+        if self._slot_done[slot] is not None:                # the step that last used this slot (t-2)
             self._side.wait_event(self._slot_done[slot])
         with torch.cuda.stream(self._side):
             plan = self._plan_and_request(batch_data, slot)
@@ -301,9 +317,11 @@ class ShardedSCORE(object):
         if self.device.type == "cuda":
             self._slot_done[self._slot] = torch.cuda.current_stream(self.device).record_event()
 
-    def forward_backward(self, batch_data, reg_lambda, keep_prob=1.0, dropout_masks=None):
+    def forward_backward(self, batch_data, reg_lambda, keep_prob=1.0, dropout_masks=None, next_batch=None):
         be, cm = self.backend, self.comm
         plan, mini = self._fetch(batch_data)
+        if next_batch is not None:
+            self.prefetch(next_batch)
         B = plan["B"] if "B" in plan else plan["db"].B
         be.set_global_batch(B * self.world)
         fw = be.forward(plan, mini, reg_lambda, keep_prob, dropout_masks)
@@ -320,13 +338,13 @@ class ShardedSCORE(object):
         self.backend.adam(lr, reg_lambda)
         self._mark_step_end()
 
-    def train_async(self, batch_data, lr, reg_lambda, keep_prob=0.8, dropout_masks=None):
-        loss, _ = self.forward_backward(batch_data, reg_lambda, keep_prob, dropout_masks)
+    def train_async(self, batch_data, lr, reg_lambda, keep_prob=0.8, dropout_masks=None, next_batch=None):
+        loss, _ = self.forward_backward(batch_data, reg_lambda, keep_prob, dropout_masks, next_batch)
         self.apply_adam(lr, reg_lambda)
         return loss[1] + float(reg_lambda) * loss[2]
 
-    def train(self, sess, batch_data, lr, reg_lambda, keep_prob=0.8, dropout_masks=None):
-        return float(self.train_async(batch_data, lr, reg_lambda, keep_prob, dropout_masks).item())
+    def train(self, sess, batch_data, lr, reg_lambda, keep_prob=0.8, dropout_masks=None, next_batch=None):
+        return float(self.train_async(batch_data, lr, reg_lambda, keep_prob, dropout_masks, next_batch).item())
 
     def eval(self, sess, batch_data, reg_lambda):
         be = self.backend

@@ -42,8 +42,8 @@ def _worker(rank, world, port, model_type, out_dir):
     be = CpuBackend(rank, world, model_type, cfg_args, params)
     model = ShardedSCORE(*cfg_args, comm=TorchDistComm(), backend=be, model_type=model_type)
     bts = [batch_tuple(b) for b in batches]
-    losses = [model.train(None, bts[0], 1e-3, 1e-3, keep_prob=1.0)]
-    model.prefetch(bts[1])                          # index-only phase of the next batch ahead of time
+    # the next batch's index-only phase is run ahead, inside the current step
+    losses = [model.train(None, bts[0], 1e-3, 1e-3, keep_prob=1.0, next_batch=bts[1])]
     losses.append(model.train(None, bts[1], 1e-3, 1e-3, keep_prob=1.0))
     pred, label, eloss = model.eval(None, batch_tuple(batches[0]), 1e-3)
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), losses=np.asarray(losses), shard=be.full_table_part(),

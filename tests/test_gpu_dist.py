@@ -83,7 +83,7 @@ def test_virtual_ranks_match_single_device(world, model_type, cfg_args, B):
     from score_amd.model import MODELS
     cfg = so.Cfg(*cfg_args, model_type=model_type)
     params = so.init_params(cfg, 5)
-    steps = 2
+    steps = 4
     batches = [[random_batch(np.random.default_rng(100 * r + s), cfg, B) for s in range(steps)] for r in range(world)]
 
     def fn(rank, comm):
@@ -92,9 +92,8 @@ def test_virtual_ranks_match_single_device(world, model_type, cfg_args, B):
         bts = [batch_tuple(b) for b in batches[rank]]
         losses = []
         for i, bt in enumerate(bts):            # with the next batch's index phase prefetched on a side stream
-            losses.append(m.train(None, bt, 1e-3, 1e-3, keep_prob=1.0))
-            if i + 1 < len(bts):
-                m.prefetch(bts[i + 1])
+            losses.append(m.train(None, bt, 1e-3, 1e-3, keep_prob=1.0,
+                                  next_batch=bts[i + 1] if i + 1 < len(bts) else None))
         pred, _, _ = m.eval(None, batch_tuple(batches[rank][0]), 1e-3)
         torch.cuda.synchronize()
         return losses, m.backend.m.table.cpu().numpy(), m.backend.m.w.cpu().numpy(), pred
