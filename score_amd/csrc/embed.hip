@@ -387,16 +387,6 @@ __global__ __launch_bounds__(256) void coattn_bwd_kernel_t(const CoattnArgs a) {
   }
 }
 
-// out[e] (+)= sum_b slab[b][e]   (fixed order: deterministic)
-__global__ void slab_reduce_kernel(const float* __restrict__ slab, int nslabs, int width, float* __restrict__ out,
-                                   int accumulate) {
-  int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= width) return;
-  float s = 0.f;
-  for (int b = 0; b < nslabs; ++b) s += slab[(int64_t)b * width + e];
-  out[e] = accumulate ? out[e] + s : s;
-}
-
 #define COATTN_DISPATCH(KERNEL, EXTRA, SPLV, KV, ...)                                     \
   do {                                                                                    \
     if (SPLV == 1) {                                                                      \

@@ -1,7 +1,9 @@
-// Exact-fp32 GEMM on the matrix cores: v_mfma_f32_32x32x2_f32 (bitwise an fmaf
-// chain in k order; gfx950 has no xf32/TF32).  64x64 block tile, 4 waves in 2x2,
-// (BK = 16: a 32-deep tile measured 6 % slower on this model's shapes) staged through LDS with a register
-// prefetch of the next tile.  Three operand layouts (see score_hip.h).
+// fp32 GEMM entry point (score_gemm) and the exact-fp32 kernel: v_mfma_f32_32x32x2_f32 (bitwise an
+// fmaf chain in k order; gfx950 has no xf32/TF32).  Block = 2x2 waves of (32*WM)x(32*WN) MFMA tiles,
+// BK = 16 (a 32-deep tile measured 6 % slower on this model's shapes) staged through LDS with a register
+// prefetch of the next tile; NN / NT / TN operand layouts (see score_hip.h); split-K with a fixed-order
+// slab reduce.  Large products are routed to gemm_bf16x3.hip when the caller allows it.  Also here: the
+// deferred multi-job column sum (bias gradients, slab reductions) and the relu mask kernel.
 #include "common.h"
 #include "kernels.h"
 
