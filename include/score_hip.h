@@ -138,6 +138,8 @@ int score_coattn_bwd(const float* table, float* grad_table, int64_t n_rows, int3
  * 8 dropout (tf.nn.dropout: x/keep * mask; mask from drop_mask bytes or, if null,
  * from a counter hash of drop_seed), 16 use the bf16x3 matrix-core product (fp32-accurate,
  * see score_state_t.gemm_mode) on the shapes where it measured faster, 32 use it whenever legal.
+ * Bits 16-30: bias row group g (0 = the usual single bias row): bias is [ceil(M/g), N] and
+ * output row r adds bias row r/g -- the per-sample term of the folded attention layer.
  * scratch is used for split-K. */
 int score_gemm(int32_t trans, int32_t M, int32_t N, int32_t K,
                const float* A, int32_t lda, const float* Bm, int32_t ldb,
@@ -169,6 +171,16 @@ int score_gru_bwd(int32_t B, int32_t T, int32_t H, const float* Wg, int32_t ldwg
 int score_adam(float* p, float* m, float* v, const float* g, int64_t n, int64_t n_reg,
                float l2, float alpha, float beta1, float beta2, float eps, void* stream);
 
+/* The same update over the [n_rows, D] embedding table, driven by a per-row state byte so the
+ * dense sweep only moves the rows dense ApplyAdam actually changes (bit-identical result):
+ *   0  m = v = 0 and no gradient this step  -> ApplyAdam is the identity: nothing is read
+ *   1  m or v nonzero, no gradient this step -> g = 0 (moments decay, p moves); g is not read
+ *   2  gradient written this step (score_backward / score_segment_sum_rows set it) -> full
+ *      update from g, then the state becomes 1
+ * g rows in state 0/1 are never read, so grad_table needs no zero fill between steps. */
+int score_adam_rows(float* p, float* m, float* v, const float* g, int64_t n_rows, int32_t D,
+                    uint8_t* row_flags, float alpha, float beta1, float beta2, float eps, void* stream);
+
 /* ---- whole-path entry points --------------------------------------------- */
 
 typedef struct {
@@ -188,6 +200,11 @@ typedef struct {
                            six v_mfma_f32_32x32x16_bf16 per k-step -- fp32 accuracy (dropped
                            terms < 2^-24 relative) at 2.7x the matrix-core rate              */
   int32_t reserved;
+  uint8_t* row_flags;   /* optional [n_table_rows] row state of the dense table optimizer (see
+                           score_adam_rows): score_backward (scatter_mode 0) marks every row it
+                           writes into grad_table with 2 and leaves all other rows of grad_table
+                           untouched, so grad_table needs no zero fill.  NULL = off: the caller
+                           zero-fills grad_table and uses score_adam.                            */
 } score_state_t;
 
 /* Index plan of a batch (depends on the indices only; run it before score_backward, on
@@ -202,9 +219,10 @@ int score_index_plan(const score_config_t* cfg, const score_state_t* st, const s
 
 /* out[rows[j], :] = sum over slots j with equal rows[j] of src[j, :] (slot order; rows never
  * named keep their value).  The shard owner uses it to combine the row gradients received
- * from every rank.  scratch: score_segment_sum_scratch_bytes(n, D). */
+ * from every rank.  row_flags (optional, [n_out_rows]): every row written is marked 2 for
+ * score_adam_rows.  scratch: score_segment_sum_scratch_bytes(n, D). */
 int score_segment_sum_rows(const int32_t* rows, const float* src, int64_t n, int32_t D, int64_t n_out_rows,
-                           float* out, void* scratch, int64_t scratch_bytes, void* stream);
+                           float* out, uint8_t* row_flags, void* scratch, int64_t scratch_bytes, void* stream);
 int64_t score_segment_sum_scratch_bytes(int64_t n, int32_t D);
 
 /* Forward of SCORE / RIA / RCA / SCORE_USER / SCORE_ITEM (score.py:188-369) +

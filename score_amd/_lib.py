@@ -43,7 +43,7 @@ class Workspace(C.Structure):
 class State(C.Structure):
     _fields_ = [("table", c_f), ("n_table_rows", C.c_int64), ("w", c_f), ("workspace", c_f),
                 ("workspace_bytes", C.c_int64), ("scatter_mode", C.c_int32), ("global_batch", C.c_int32),
-                ("gemm_mode", C.c_int32), ("reserved", C.c_int32)]
+                ("gemm_mode", C.c_int32), ("reserved", C.c_int32), ("row_flags", C.c_void_p)]
 
 
 class Graph(C.Structure):
@@ -78,8 +78,11 @@ _SIGS = {
                       c_f, C.c_int32, c_f, c_f, c_f, c_f, C.c_void_p],
     "score_adam": [c_f, c_f, c_f, c_f, C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,
                    C.c_float, C.c_void_p],
+    "score_adam_rows": [c_f, c_f, c_f, c_f, C.c_int64, C.c_int32, C.c_void_p, C.c_float, C.c_float, C.c_float,
+                        C.c_float, C.c_void_p],
     "score_index_plan": [C.POINTER(Config), C.POINTER(State), C.POINTER(Batch), C.c_int32, C.c_int32, C.c_void_p],
-    "score_segment_sum_rows": [c_i, c_f, C.c_int64, C.c_int32, C.c_int64, c_f, C.c_void_p, C.c_int64, C.c_void_p],
+    "score_segment_sum_rows": [c_i, c_f, C.c_int64, C.c_int32, C.c_int64, c_f, C.c_void_p, C.c_void_p, C.c_int64,
+                               C.c_void_p],
     "score_segment_sum_scratch_bytes": [C.c_int64, C.c_int32],
     "score_forward": [C.POINTER(Config), C.POINTER(State), C.POINTER(Batch), C.c_float, C.c_float, C.c_void_p,
                       C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p), C.c_void_p],

@@ -122,6 +122,7 @@ struct WS {
   int64_t xside[2], info, rsave[2], query, head_inp, att_score, logit, y_pred, loss;
   int64_t gru_out[2], gru_final[2], xproj[2], gates[2];
   int64_t q, ainp, a1, a2, bn, f1, f2, lossb, dlogit, part;
+  int64_t weff, wq, qz, adzsum, dweff, dwq, dqd;   // folded first attention layer (head.hip)
   // backward
   int64_t dz2, dz1, dbn, dhead, ds, da2, da1, dainp, dgru[2], dinfo, dq, dquery, dfinal[2];
   int64_t dxproj[2], rh[2], hprev[2], dxside[2], dzsum[2], S, scratch;
@@ -148,7 +149,8 @@ void build_ws(const Dims& d, int B, WS* w) {
   for (int s = 0; s < 2; ++s) w->xproj[s] = take(BT * 3 * d.H);
   for (int s = 0; s < 2; ++s) w->gates[s] = take(BT * 3 * d.H);
   w->q = take((int64_t)B * d.Dk);
-  w->ainp = take(BT * 4 * d.Dk);
+  w->ainp = take(BT * 2 * d.Dk);
+  w->weff = take(2 * (int64_t)d.Dk * AT1); w->wq = take((int64_t)d.Dk * AT1); w->qz = take((int64_t)B * AT1);
   w->a1 = take(BT * AT1); w->a2 = take(BT * AT2);
   w->bn = take((int64_t)B * d.Dhead);
   w->f1 = take((int64_t)B * FC1); w->f2 = take((int64_t)B * FC2);
@@ -156,7 +158,9 @@ void build_ws(const Dims& d, int B, WS* w) {
   w->dz2 = take((int64_t)B * FC2); w->dz1 = take((int64_t)B * FC1);
   w->dbn = take((int64_t)B * d.Dhead); w->dhead = take((int64_t)B * d.Dhead);
   w->ds = take(BT); w->da2 = take(BT * AT2); w->da1 = take(BT * AT1);
-  w->dainp = take(BT * 4 * d.Dk);
+  w->dainp = take(BT * 2 * d.Dk);
+  w->adzsum = take((int64_t)B * AT1); w->dweff = take(2 * (int64_t)d.Dk * AT1); w->dwq = take((int64_t)d.Dk * AT1);
+  w->dqd = take((int64_t)B * d.Dk);
   for (int s = 0; s < 2; ++s) w->dgru[s] = take(BT * d.H);
   w->dinfo = take(BT * 4 * d.K);
   w->dq = take((int64_t)B * d.Dk); w->dquery = take((int64_t)B * d.Dq);
@@ -376,10 +380,14 @@ extern "C" int score_forward(const score_config_t* cfg, const score_state_t* st,
     // temporal attention (:169-186, 210-215)
     G(gemm_mode_call(x3, 0, B, d.Dk, d.Dq, ws + w.query, d.Dq, W + P.at_w[0], d.Dk, ws + w.q, d.Dk, W + P.at_b[0], GF_BIAS,
                  1.f, nullptr, 0, scratch, w.scratch_floats, s));
+    // dense_3 on [q, k, q-k, q*k], folded (head.hip): a1 = relu([k, q*k] . Weff + (q . Wq + b)[sample])
+    G(score_launch_attn_fold_w1(d.Dk, AT1, W + P.at_w[1], ws + w.weff, ws + w.wq, s));
+    G(gemm_mode_call(x3, 0, B, AT1, d.Dk, ws + w.q, d.Dk, ws + w.wq, AT1, ws + w.qz, AT1, W + P.at_b[1], GF_BIAS, 1.f,
+                     nullptr, 0, scratch, w.scratch_floats, s));
     G(score_launch_attn_build_inp(B, T, H, d.NI, ws + w.q, ws + w.gru_out[0], ws + w.gru_out[1], ws + w.info,
                                   ws + w.ainp, s));
-    G(gemm_mode_call(x3, 0, BT, AT1, 4 * d.Dk, ws + w.ainp, 4 * d.Dk, W + P.at_w[1], AT1, ws + w.a1, AT1, W + P.at_b[1],
-                 GF_BIAS | GF_RELU, 1.f, nullptr, 0, scratch, w.scratch_floats, s));
+    G(gemm_mode_call(x3, 0, BT, AT1, 2 * d.Dk, ws + w.ainp, 2 * d.Dk, ws + w.weff, AT1, ws + w.a1, AT1, ws + w.qz,
+                     GF_BIAS | GF_RELU | (T << 16), 1.f, nullptr, 0, scratch, w.scratch_floats, s));
     G(gemm_mode_call(x3, 0, BT, AT2, AT1, ws + w.a1, AT1, W + P.at_w[2], AT2, ws + w.a2, AT2, W + P.at_b[2],
                  GF_BIAS | GF_RELU, 1.f, nullptr, 0, scratch, w.scratch_floats, s));
     G(score_launch_attn_pool_fwd(B, T, H, AT2, ws + w.a2, W + P.at_w[3], W + P.at_b[3], bt->length,
@@ -475,15 +483,21 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
     G(gemm_mode_call(x3, 1, BT, AT1, AT2, ws + w.da2, AT2, W + P.at_w[2], AT2, ws + w.da1, AT1, nullptr, 0, 1.f, nullptr,
                  0, scratch, SF, s));
     G(score_launch_relu_bwd(ws + w.da1, ws + w.a1, BT, AT1, AT1, AT1, 1.f, s));
-    // dense_3 (4Dk -> 80)
-    G(gemm_mode_call(x3, 2, 4 * d.Dk, AT1, BT, ws + w.ainp, 4 * d.Dk, ws + w.da1, AT1, gw + P.at_w[1], AT1, nullptr, 0,
+    // dense_3 (4Dk -> 80), folded: weight gradient from [k, q*k]^T da1 and q^T sum_t da1
+    G(gemm_mode_call(x3, 2, 2 * d.Dk, AT1, BT, ws + w.ainp, 2 * d.Dk, ws + w.da1, AT1, ws + w.dweff, AT1, nullptr, 0,
                  1.f, nullptr, 0, scratch, SF, s));
     G(colsum_queue_add(&cq, ws + w.da1, BT, AT1, AT1, gw + P.at_b[1], 0));
-    G(gemm_mode_call(x3, 1, BT, 4 * d.Dk, AT1, ws + w.da1, AT1, W + P.at_w[1], AT1, ws + w.dainp, 4 * d.Dk, nullptr, 0,
+    G(score_launch_attn_dzsum(B, T, AT1, ws + w.da1, ws + w.adzsum, s));
+    G(gemm_mode_call(x3, 2, d.Dk, AT1, B, ws + w.q, d.Dk, ws + w.adzsum, AT1, ws + w.dwq, AT1, nullptr, 0, 1.f, nullptr,
+                 0, scratch, SF, s));
+    G(score_launch_attn_w1_grad(d.Dk, AT1, ws + w.dweff, ws + w.dwq, gw + P.at_w[1], s));
+    G(gemm_mode_call(x3, 1, BT, 2 * d.Dk, AT1, ws + w.da1, AT1, ws + w.weff, AT1, ws + w.dainp, 2 * d.Dk, nullptr, 0,
                  1.f, nullptr, 0, scratch, SF, s));
+    G(gemm_mode_call(x3, 1, B, d.Dk, AT1, ws + w.adzsum, AT1, ws + w.wq, AT1, ws + w.dqd, d.Dk, nullptr, 0, 1.f, nullptr,
+                 0, scratch, SF, s));
     G(score_launch_attn_inp_bwd(B, T, H, d.NI, ws + w.dainp, ws + w.q, ws + w.gru_out[0], ws + w.gru_out[1],
                                 ws + w.info, ws + w.att_score, ws + w.dhead, d.Dhead, d.off_u, d.off_i,
-                                ws + w.dgru[0], ws + w.dgru[1], ws + w.dinfo, ws + w.dq, s));
+                                ws + w.dqd, ws + w.dgru[0], ws + w.dgru[1], ws + w.dinfo, ws + w.dq, s));
     // dense_2 (query projection)
     G(gemm_mode_call(x3, 2, d.Dq, d.Dk, B, ws + w.query, d.Dq, ws + w.dq, d.Dk, gw + P.at_w[0], d.Dk, nullptr, 0, 1.f,
                  nullptr, 0, scratch, SF, s));
@@ -571,6 +585,7 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
     PullArgs pa;
     memset(&pa, 0, sizeof(pa));
     pa.D = d.D; pa.K = d.K; pa.zero_is_dummy = 1;
+    pa.flags = st->scatter_mode == 0 ? st->row_flags : nullptr;
     pa.uid = st->scatter_mode == 2 ? reinterpret_cast<const uint32_t*>(ws + w.uid) : nullptr;
     const float invK = 1.0f / (float)d.K;
     const float* Gm[6] = {ws + w.dxside[0], ws + w.dxside[1], ws + w.dxside[0], ws + w.dxside[1], ws + w.dtgt,

@@ -12,10 +12,17 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define BK_ALIGN 32   // split-K chunks are multiples of this
 
 enum { F_BIAS = 1, F_RELU = 2, F_ACC = 4, F_DROP = 8, F_X3 = 16 };
+#define KF_MASK (15 | 0x7FFF0000)   // what the kernels see: epilogue bits + the bias row group
+
+// bias element of (row, col): one bias row, or one per group of g = flags >> 16 output rows
+__device__ __forceinline__ int64_t bias_index(int flags, int row, int col, int N) {
+  const int g = flags >> 16;
+  return g ? (int64_t)(row / g) * N + col : col;
+}
 
 __device__ __forceinline__ float epilogue(float v, int row, int col, int N, const float* bias, int flags,
                                           float keep, const uint8_t* mask, uint64_t seed) {
-  if (flags & F_BIAS) v += bias[col];
+  if (flags & F_BIAS) v += bias[bias_index(flags, row, col, N)];
   if (flags & F_RELU) v = fmaxf(v, 0.f);
   if (flags & F_DROP) {
     uint64_t e = (uint64_t)row * (uint64_t)N + (uint64_t)col;
@@ -187,6 +194,7 @@ extern "C" int score_gemm(int32_t trans, int32_t M, int32_t N, int32_t K, const 
   if (!A || !Bm || !C || M <= 0 || N <= 0 || K <= 0) return SCORE_E_BADARG;
   if (trans < 0 || trans > 2) return SCORE_E_BADARG;
   if ((flags & F_BIAS) && !bias) return SCORE_E_BADARG;
+  if (flags < 0) return SCORE_E_BADARG;
   hipStream_t s = (hipStream_t)stream;
   // k-contiguous operands are staged with 16-B loads: need K % 4 == 0, ld % 4 == 0, 16-B aligned base
   const bool a_kc = trans != 2, b_kc = trans == 1;
@@ -227,17 +235,17 @@ extern "C" int score_gemm(int32_t trans, int32_t M, int32_t N, int32_t K, const 
       g3.z = ns;
       sl = ns > 1 ? scratch : nullptr;
     }
-    SCORE_TRY(score_launch_gemm_bf16x3(trans, wm3, g3, M, N, K, A, lda, Bm, ldb, C, ldc, bias, flags & 15, keep_prob,
+    SCORE_TRY(score_launch_gemm_bf16x3(trans, wm3, g3, M, N, K, A, lda, Bm, ldb, C, ldc, bias, flags & KF_MASK, keep_prob,
                                        drop_mask, drop_seed, kc, sl, s));
     if (sl) {
       int64_t n = (int64_t)M * N;
       hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, s, sl, ns, M, N, C, ldc,
-                         bias, flags & 15, keep_prob, drop_mask, drop_seed);
+                         bias, flags & KF_MASK, keep_prob, drop_mask, drop_seed);
       SCORE_CHECK_LAUNCH();
     }
     return 0;
   }
-  flags &= 15;
+  flags &= KF_MASK;
   // tile choice: the largest wave tile that still gives the chip >= ~1.5 blocks per CU
   int WMs = 1, WNs = 1;
   auto nblocks = [&](int wm_, int wn_) { return (int64_t)((N + 64 * wn_ - 1) / (64 * wn_)) * ((M + 64 * wm_ - 1) / (64 * wm_)); };

@@ -25,7 +25,10 @@ enum { XF_BIAS = 1, XF_RELU = 2, XF_ACC = 4, XF_DROP = 8 };
 
 __device__ __forceinline__ float x3_epilogue(float v, int row, int col, int N, const float* bias, int flags,
                                              float keep, const uint8_t* mask, uint64_t seed) {
-  if (flags & XF_BIAS) v += bias[col];
+  if (flags & XF_BIAS) {
+    const int g = flags >> 16;   // bias row group (score_gemm)
+    v += bias[g ? (int64_t)(row / g) * N + col : col];
+  }
   if (flags & XF_RELU) v = fmaxf(v, 0.f);
   if (flags & XF_DROP) {
     uint64_t e = (uint64_t)row * (uint64_t)N + (uint64_t)col;

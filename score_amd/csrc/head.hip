@@ -4,7 +4,29 @@
 #include "common.h"
 #include "kernels.h"
 
-// inp = [q, k, q-k, q*k] with k = [user_rep | item_rep | atten_info]   (score.py:173-174)
+// The first attention layer acts on inp = [q, k, q-k, q*k] (score.py:173-174), k = [user_rep | item_rep |
+// atten_info], q broadcast over the T slices.  With W1 = [Wa; Wb; Wc; Wd] (Dk rows each)
+//   inp . W1 = q . (Wa + Wc)  +  k . (Wb - Wc)  +  (q*k) . Wd
+// so the [B*T]-row product only needs [k, q*k] (2 Dk columns, half the bytes and flops of the literal
+// form) against Weff = [Wb - Wc; Wd]; the q term is one [B, Dk] x [Dk, 80] product added per sample
+// (score_gemm's row-grouped bias).
+__global__ void attn_fold_w1_kernel(int Dk, int NA, const float* __restrict__ W1, float* __restrict__ weff,
+                                    float* __restrict__ wq) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Dk * NA) return;
+  const float wa = W1[i], wb = W1[Dk * NA + i], wc = W1[2 * Dk * NA + i], wd = W1[3 * Dk * NA + i];
+  weff[i] = wb - wc;
+  weff[Dk * NA + i] = wd;
+  wq[i] = wa + wc;
+}
+
+int score_launch_attn_fold_w1(int Dk, int NA, const float* W1, float* weff, float* wq, hipStream_t s) {
+  hipLaunchKernelGGL(attn_fold_w1_kernel, dim3((Dk * NA + 255) / 256), dim3(256), 0, s, Dk, NA, W1, weff, wq);
+  SCORE_CHECK_LAUNCH();
+  return 0;
+}
+
+// inp2 = [k, q*k]
 __global__ void attn_build_inp_kernel(int BT, int T, int H, int NI, const float* __restrict__ q,
                                       const float* __restrict__ ur, const float* __restrict__ ir,
                                       const float* __restrict__ info, float* __restrict__ inp) {
@@ -16,11 +38,9 @@ __global__ void attn_build_inp_kernel(int BT, int T, int H, int NI, const float*
   float k = j < H ? ur[(int64_t)bt * H + j]
                   : (j < 2 * H ? ir[(int64_t)bt * H + (j - H)] : info[(int64_t)bt * NI + (j - 2 * H)]);
   float qq = q[(int64_t)b * Dk + j];
-  float* o = inp + (int64_t)bt * 4 * Dk;
-  o[j] = qq;
-  o[Dk + j] = k;
-  o[2 * Dk + j] = qq - k;
-  o[3 * Dk + j] = qq * k;
+  float* o = inp + (int64_t)bt * 2 * Dk;
+  o[j] = k;
+  o[Dk + j] = qq * k;
 }
 
 int score_launch_attn_build_inp(int B, int T, int H, int NI, const float* q, const float* ur, const float* ir,
@@ -28,6 +48,40 @@ int score_launch_attn_build_inp(int B, int T, int H, int NI, const float* q, con
   int64_t n = (int64_t)B * T * (2 * H + NI);
   hipLaunchKernelGGL(attn_build_inp_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, s, B * T, T, H, NI, q,
                      ur, ir, info, inp);
+  SCORE_CHECK_LAUNCH();
+  return 0;
+}
+
+// dzsum[b][n] = sum_t dz[b*T + t][n]  (t order): the gradient reaching the per-sample q term
+__global__ void attn_dzsum_kernel(int B, int T, int NA, const float* __restrict__ dz, float* __restrict__ dzsum) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * NA) return;
+  const int b = i / NA, n = i - b * NA;
+  float acc = 0.f;
+  for (int t = 0; t < T; ++t) acc += dz[((int64_t)b * T + t) * NA + n];
+  dzsum[i] = acc;
+}
+
+int score_launch_attn_dzsum(int B, int T, int NA, const float* dz, float* dzsum, hipStream_t s) {
+  hipLaunchKernelGGL(attn_dzsum_kernel, dim3((B * NA + 255) / 256), dim3(256), 0, s, B, T, NA, dz, dzsum);
+  SCORE_CHECK_LAUNCH();
+  return 0;
+}
+
+// gradient of W1 from the folded pieces: dWa = dWq, dWb = dWeff_k, dWc = dWq - dWeff_k, dWd = dWeff_qk
+__global__ void attn_w1_grad_kernel(int Dk, int NA, const float* __restrict__ dweff, const float* __restrict__ dwq,
+                                    float* __restrict__ gW1) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Dk * NA) return;
+  const float dq = dwq[i], dk = dweff[i], dqk = dweff[Dk * NA + i];
+  gW1[i] = dq;
+  gW1[Dk * NA + i] = dk;
+  gW1[2 * Dk * NA + i] = dq - dk;
+  gW1[3 * Dk * NA + i] = dqk;
+}
+
+int score_launch_attn_w1_grad(int Dk, int NA, const float* dweff, const float* dwq, float* gW1, hipStream_t s) {
+  hipLaunchKernelGGL(attn_w1_grad_kernel, dim3((Dk * NA + 255) / 256), dim3(256), 0, s, Dk, NA, dweff, dwq, gW1);
   SCORE_CHECK_LAUNCH();
   return 0;
 }
@@ -139,14 +193,14 @@ int score_launch_attn_pool_bwd(int B, int T, int H, int NA, const float* a2, con
   return 0;
 }
 
-// backward of inp = [q,k,q-k,q*k] plus the pooled-state path into the GRU outputs.
-// thread per (b, j); loops over t.
+// backward of inp2 = [k, q*k] plus the pooled-state path into the GRU outputs; dq starts from the
+// per-sample q-term gradient dqd = dzsum . (Wa + Wc)^T.  thread per (b, j); loops over t.
 __global__ void attn_inp_bwd_kernel(int B, int T, int H, int NI, const float* __restrict__ dinp,
                                     const float* __restrict__ q, const float* __restrict__ ur,
                                     const float* __restrict__ ir, const float* __restrict__ info,
                                     const float* __restrict__ score, const float* __restrict__ dhead, int ldh,
-                                    int off_u, int off_i, float* __restrict__ dur, float* __restrict__ dir,
-                                    float* __restrict__ dinfo, float* __restrict__ dq) {
+                                    int off_u, int off_i, const float* __restrict__ dqd, float* __restrict__ dur,
+                                    float* __restrict__ dir, float* __restrict__ dinfo, float* __restrict__ dq) {
   const int Dk = 2 * H + NI;
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * Dk) return;
@@ -158,25 +212,25 @@ __global__ void attn_inp_bwd_kernel(int B, int T, int H, int NI, const float* __
   float dqa = 0.f;
   for (int t = 0; t < T; ++t) {
     int64_t bt = (int64_t)b * T + t;
-    const float* d = dinp + bt * 4 * Dk;
+    const float* d = dinp + bt * 2 * Dk;
     float k = j < H ? ur[bt * H + j] : (j < 2 * H ? ir[bt * H + (j - H)] : info[bt * NI + (j - 2 * H)]);
-    float d0 = d[j], d1 = d[Dk + j], d2 = d[2 * Dk + j], d3 = d[3 * Dk + j];
-    dqa += d0 + d2 + d3 * k;
-    float dk = d1 - d2 + d3 * qq;
+    float d1 = d[j], d3 = d[Dk + j];
+    dqa = fmaf(d3, k, dqa);
+    float dk = fmaf(d3, qq, d1);
     if (j < H) dur[bt * H + j] = dk + pooled * score[bt];
     else if (j < 2 * H) dir[bt * H + (j - H)] = dk + pooled * score[bt];
     else dinfo[bt * NI + (j - 2 * H)] = dk;
   }
-  dq[(int64_t)b * Dk + j] = dqa;
+  dq[(int64_t)b * Dk + j] = dqa + dqd[(int64_t)b * Dk + j];
 }
 
 int score_launch_attn_inp_bwd(int B, int T, int H, int NI, const float* dinp, const float* q, const float* ur,
                               const float* ir, const float* info, const float* score, const float* dhead, int ldh,
-                              int off_u, int off_i, float* dur, float* dir, float* dinfo, float* dq,
+                              int off_u, int off_i, const float* dqd, float* dur, float* dir, float* dinfo, float* dq,
                               hipStream_t s) {
   int n = B * (2 * H + NI);
   hipLaunchKernelGGL(attn_inp_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, s, B, T, H, NI, dinp, q, ur, ir,
-                     info, score, dhead, ldh, off_u, off_i, dur, dir, dinfo, dq);
+                     info, score, dhead, ldh, off_u, off_i, dqd, dur, dir, dinfo, dq);
   SCORE_CHECK_LAUNCH();
   return 0;
 }
@@ -415,6 +469,50 @@ __global__ void adam_kernel(float* __restrict__ p, float* __restrict__ m, float*
     adam1(pp, mm, vv, gg, omb1, omb2, alpha, eps);
     p[e] = pp; m[e] = mm; v[e] = vv;
   }
+}
+
+// One group of D/4 lanes per table row; the state byte decides what the row costs (see score_hip.h).
+__global__ __launch_bounds__(256) void adam_rows_kernel(float* __restrict__ p, float* __restrict__ m,
+                                                        float* __restrict__ v, const float* __restrict__ g,
+                                                        int64_t n_rows, int D, int LPR, uint8_t* __restrict__ flags,
+                                                        float alpha, float omb1, float omb2, float eps) {
+  const int gpb = blockDim.x / LPR;
+  const int ch4 = (threadIdx.x % LPR) * 4;
+  int64_t row = (int64_t)blockIdx.x * gpb + threadIdx.x / LPR;
+  const int64_t stride = (int64_t)gridDim.x * gpb;
+  for (; row < n_rows; row += stride) {
+    const uint8_t f = flags[row];
+    if (f == 0 || ch4 >= D) continue;
+    const int64_t e = row * D + ch4;
+    float4 pp = ld4(p + e), mm = ld4(m + e), vv = ld4(v + e);
+    float4 gg = f == 2 ? ld4(g + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+    adam1(pp.x, mm.x, vv.x, gg.x, omb1, omb2, alpha, eps);
+    adam1(pp.y, mm.y, vv.y, gg.y, omb1, omb2, alpha, eps);
+    adam1(pp.z, mm.z, vv.z, gg.z, omb1, omb2, alpha, eps);
+    adam1(pp.w, mm.w, vv.w, gg.w, omb1, omb2, alpha, eps);
+    st4(p + e, pp); st4(m + e, mm); st4(v + e, vv);
+    // (every lane of the group read the byte above; a group is inside one wave, so the store below
+    //  cannot overtake a sibling lane's load)
+    if (f == 2 && ch4 == 0) flags[row] = 1;
+  }
+}
+
+extern "C" int score_adam_rows(float* p, float* m, float* v, const float* g, int64_t n_rows, int32_t D,
+                               uint8_t* row_flags, float alpha, float beta1, float beta2, float eps, void* stream) {
+  if (!p || !m || !v || !g || !row_flags || n_rows <= 0 || D <= 0) return SCORE_E_BADARG;
+  if ((D & 3) || D > 256) return SCORE_E_SHAPE;
+  if ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v) |
+       reinterpret_cast<uintptr_t>(g)) & 15)
+    return SCORE_E_SHAPE;
+  int LPR = 1;
+  while (LPR < D / 4) LPR <<= 1;
+  const int gpb = 256 / LPR;
+  int64_t want = cdiv64(n_rows, gpb);
+  int blocks = (int)(want < 16384 ? want : 16384);
+  hipLaunchKernelGGL(adam_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, m, v, g, n_rows, D, LPR,
+                     row_flags, alpha, 1.0f - beta1, 1.0f - beta2, eps);
+  SCORE_CHECK_LAUNCH();
+  return 0;
 }
 
 extern "C" int score_adam(float* p, float* m, float* v, const float* g, int64_t n, int64_t n_reg, float l2,

@@ -58,8 +58,11 @@ int score_launch_attn_pool_bwd(int B, int T, int H, int NA, const float* a2, con
                                hipStream_t s);
 int score_launch_attn_inp_bwd(int B, int T, int H, int NI, const float* dinp, const float* q, const float* ur,
                               const float* ir, const float* info, const float* score, const float* dhead, int ldh,
-                              int off_u, int off_i, float* dur, float* dir, float* dinfo, float* dq,
+                              int off_u, int off_i, const float* dqd, float* dur, float* dir, float* dinfo, float* dq,
                               hipStream_t s);
+int score_launch_attn_fold_w1(int Dk, int NA, const float* W1, float* weff, float* wq, hipStream_t s);
+int score_launch_attn_dzsum(int B, int T, int NA, const float* dz, float* dzsum, hipStream_t s);
+int score_launch_attn_w1_grad(int Dk, int NA, const float* dweff, const float* dwq, float* gW1, hipStream_t s);
 int score_launch_bn_fwd(int B, int Dh, const float* x, const float* gamma, const float* beta, float rs, float* y,
                         hipStream_t s);
 int score_launch_bn_bwd(int B, int Dh, const float* x, const float* gamma, float rs, const float* dy, float* dx,
@@ -91,6 +94,7 @@ struct PullArgs {
   const uint32_t* uid;     // null: a run's destination is its row id; else the run's unique position
   int D, K, LPRp;
   int zero_is_dummy;       // key 0 is the masked dummy row (score.py:44-47): no gradient
+  uint8_t* flags;          // optional per-destination-row state byte: 2 = written this step
 };
 struct PlanRemapArgs { int32_t* out[6]; int F[6]; int K; };
 int score_launch_plan_unique(const PlanRemapArgs& ra, const uint32_t* keys, const uint32_t* vals, int64_t n,

@@ -184,6 +184,14 @@ __device__ __forceinline__ int64_t out_row(const PullArgs& a, uint32_t key, int6
   return a.uid ? (int64_t)a.uid[idx_in_run] : (int64_t)key;
 }
 
+// final value of a run's row (+ the "written this step" mark score_adam_rows consumes)
+__device__ __forceinline__ void store_row(const PullArgs& a, float* __restrict__ out, uint32_t key, int64_t idx_in_run,
+                                          int ch4, const float4& v) {
+  const int64_t r = out_row(a, key, idx_in_run);
+  st4(out + r * a.D + ch4, v);
+  if (a.flags && ch4 == 0) a.flags[r] = 2;
+}
+
 __global__ __launch_bounds__(256) void pull_kernel(const PullArgs a, const uint32_t* __restrict__ keys,
                                                    const uint32_t* __restrict__ vals, int64_t n, int WS,
                                                    float* __restrict__ out, float* __restrict__ pfirst,
@@ -204,7 +212,7 @@ __global__ __launch_bounds__(256) void pull_kernel(const PullArgs a, const uint3
     if (key != cur) {
       if (cur != 0 || !a.zero_is_dummy) {
         if (is_first && first_open) st4(pfirst + w * a.D + ch4, acc);
-        else st4(out + out_row(a, cur, i - 1) * a.D + ch4, acc);
+        else store_row(a, out, cur, i - 1, ch4, acc);
       }
       acc = make_float4(0.f, 0.f, 0.f, 0.f);
       cur = key;
@@ -216,7 +224,7 @@ __global__ __launch_bounds__(256) void pull_kernel(const PullArgs a, const uint3
     const bool open_right = end < n && keys[end] == cur;
     if (is_first && first_open) st4(pfirst + w * a.D + ch4, acc);
     else if (open_right) st4(plast + w * a.D + ch4, acc);
-    else st4(out + out_row(a, cur, end - 1) * a.D + ch4, acc);
+    else store_row(a, out, cur, end - 1, ch4, acc);
   }
 }
 
@@ -260,7 +268,7 @@ __global__ __launch_bounds__(256) void pull_fixup_kernel(const PullArgs a, const
   }
   float4 tot = ld4(plast + w * a.D + ch4);
   for (int j = 1; j <= L; ++j) tot = add4(tot, ld4(pfirst + (w + j) * a.D + ch4));
-  st4(out + out_row(a, lastkey, end - 1) * a.D + ch4, tot);
+  store_row(a, out, lastkey, end - 1, ch4, tot);
 }
 
 // one block per long chain: its groups sum contiguous sub-ranges of the chain, then the partial
@@ -293,7 +301,7 @@ __global__ __launch_bounds__(256) void pull_long_kernel(const PullArgs a, const 
       float4 t = ld4(plast + w * a.D + ch4);
       for (int q = 0; q < ng; ++q) t = add4(t, ld4(sh + q * a.D + ch4));
       const uint32_t key = keys[(w + 1) * (int64_t)WS - 1];
-      st4(out + out_row(a, key, (w + 1) * (int64_t)WS - 1) * a.D + ch4, t);
+      store_row(a, out, key, (w + 1) * (int64_t)WS - 1, ch4, t);
     }
     __syncthreads();
   }
@@ -335,7 +343,8 @@ int score_launch_pull(PullArgs& a, const uint32_t* keys, const uint32_t* vals, i
 int score_rowsum_temp_bytes(int64_t n, size_t* bytes) { return score_plan_temp_bytes(n, 32, bytes); }
 
 extern "C" int score_segment_sum_rows(const int32_t* rows, const float* src, int64_t n, int32_t D, int64_t n_out_rows,
-                                      float* out, void* scratch, int64_t scratch_bytes, void* stream) {
+                                      float* out, uint8_t* row_flags, void* scratch, int64_t scratch_bytes,
+                                      void* stream) {
   if (!rows || !src || !out || !scratch || n < 0 || D <= 0 || (D & 3) || n_out_rows <= 0) return SCORE_E_BADARG;
   if (n == 0) return 0;
   if (n >= (1 << 29)) return SCORE_E_SHAPE;
@@ -362,7 +371,7 @@ extern "C" int score_segment_sum_rows(const int32_t* rows, const float* src, int
   if (e != hipSuccess) return (int)e;
   PullArgs pa;
   memset(&pa, 0, sizeof(pa));
-  pa.D = D; pa.K = 1; pa.G[0] = src; pa.zero_is_dummy = 0;   // local row 0 is a real row on shards > 0
+  pa.D = D; pa.K = 1; pa.G[0] = src; pa.zero_is_dummy = 0; pa.flags = row_flags;   // local row 0 is a real row on shards > 0
   return score_launch_pull(pa, keys_out, vals_out, n, out, partials, partial_floats, s);
 }
 

@@ -198,15 +198,17 @@ class HipBackend(object):
 
     def accumulate(self, req_rows, grads_in):
         m = self.m
-        m.table_g.zero_()
+        # no zero fill: the segment sum marks the shard rows it writes (state 2) and score_adam_rows
+        # reads gradient rows in that state only
+        m._begin_row_grads()
         n = req_rows.numel()
         if n:
             need = int(self.lib.score_segment_sum_scratch_bytes(n, self.D))
             if self._scratch is None or self._scratch.numel() < need:
                 self._scratch = torch.empty((need,), dtype=torch.uint8, device=self.device)
             rc = self.lib.score_segment_sum_rows(_ptr(req_rows), _ptr(grads_in), n, self.D, m.table.shape[0],
-                                                 _ptr(m.table_g), _ptr(self._scratch), self._scratch.numel(),
-                                                 m._stream())
+                                                 _ptr(m.table_g), _ptr(m.table_flags), _ptr(self._scratch),
+                                                 self._scratch.numel(), m._stream())
             _lib.check(rc, "score_segment_sum_rows")
 
     def dense_grad(self):

@@ -102,6 +102,10 @@ class SCOREBASE(object):
         self.table_m = torch.zeros_like(self.table)
         self.table_v = torch.zeros_like(self.table)
         self.table_g = torch.zeros_like(self.table)
+        # per-row optimizer state byte (score_adam_rows): 0 = moments zero, 1 = live, 2 = gradient this step
+        self.table_flags = torch.zeros((self.table.shape[0],), dtype=torch.uint8, device=self.device)
+        self._row_grads = False      # table_g holds valid rows only where table_flags == 2
+        self._flags_marked = False   # table_flags may hold 2s
         self.w_m = torch.zeros((self.n_w,), **f32)
         self.w_v = torch.zeros((self.n_w,), **f32)
         self.w_g = torch.zeros((self.n_w,), **f32)
@@ -150,8 +154,33 @@ class SCOREBASE(object):
             a = np.asarray(params[e[0]], dtype=np.float32).reshape(tuple(v.shape))
             v.copy_(torch.from_numpy(a))
 
+    def dense_table_grad(self):
+        """[N, D] gradient of the last forward_backward (device tensor)."""
+        if self._row_grads:
+            return self.table_g * (self.table_flags == 2).unsqueeze(1)
+        return self.table_g
+
+    def _drop_row_marks(self):
+        # rows a previous backward marked (state 2) that no optimizer step consumed: back to "live"
+        if self._flags_marked:
+            self.table_flags.clamp_(max=1)
+        self._flags_marked = False
+        self._row_grads = False
+
+    def _begin_row_grads(self):
+        self._drop_row_marks()
+        self._row_grads = True
+        self._flags_marked = True
+
+    def refresh_row_flags(self):
+        """Recompute the row state bytes after the Adam slots were set from outside."""
+        live = (self.table_m != 0).any(dim=1) | (self.table_v != 0).any(dim=1)
+        self.table_flags.copy_(live.to(torch.uint8))
+        self._row_grads = False
+        self._flags_marked = False
+
     def get_grads(self):
-        out = {"emb_mtx": self.table_g.cpu().numpy()}
+        out = {"emb_mtx": self.dense_table_grad().cpu().numpy()}
         for e in self.entries:
             out[e[0]] = self._view(self.w_g, e).cpu().numpy().copy()
         return out
@@ -171,7 +200,8 @@ class SCOREBASE(object):
 
     def _state(self, ws):
         return _lib.State(_ptr(self.table), self.table.shape[0], _ptr(self.w), _ptr(ws), ws.numel() * 4,
-                          int(self.scatter_mode), int(self.global_batch), int(self.gemm_mode), 0)
+                          int(self.scatter_mode), int(self.global_batch), int(self.gemm_mode), 0,
+                          _ptr(self.table_flags) if self.scatter_mode == 0 else None)
 
     @staticmethod
     def _event_array(events):
@@ -243,7 +273,11 @@ class SCOREBASE(object):
         lay, ws, st = self._forward(db, reg_lambda, keep_prob, dropout_masks)
         if plan_done is not None:
             torch.cuda.current_stream(self.device).wait_event(plan_done)
-        self.table_g.zero_()
+        if self.scatter_mode == 0:
+            self._begin_row_grads()         # the pull kernels mark what they write; no zero fill
+        else:
+            self._drop_row_marks()
+            self.table_g.zero_()
         rc = self.lib.score_backward(C.byref(self.cfg), C.byref(st), C.byref(db.struct), float(keep_prob),
                                      _ptr(self.w_g), _ptr(self.table_g), self._event_array(self.bwd_events),
                                      self._stream())
@@ -259,8 +293,17 @@ class SCOREBASE(object):
         whole table (the emb_mtx*mask gradient is dense) and over every dense variable."""
         a = self._alpha(lr)
         s = self._stream()
-        rc = self.lib.score_adam(_ptr(self.table), _ptr(self.table_m), _ptr(self.table_v), _ptr(self.table_g),
-                                 self.table.numel(), 0, 0.0, a, ADAM_B1, ADAM_B2, ADAM_EPS, s)
+        if self._row_grads:
+            rc = self.lib.score_adam_rows(_ptr(self.table), _ptr(self.table_m), _ptr(self.table_v),
+                                          _ptr(self.table_g), self.table.shape[0], self.table.shape[1],
+                                          _ptr(self.table_flags), a, ADAM_B1, ADAM_B2, ADAM_EPS, s)
+            self._row_grads = False
+            self._flags_marked = False
+        else:
+            rc = self.lib.score_adam(_ptr(self.table), _ptr(self.table_m), _ptr(self.table_v), _ptr(self.table_g),
+                                     self.table.numel(), 0, 0.0, a, ADAM_B1, ADAM_B2, ADAM_EPS, s)
+            self.table_flags.fill_(1)       # dense sweep: any row may carry moments now
+            self._flags_marked = False
         _lib.check(rc, "score_adam(table)")
         rc = self.lib.score_adam(_ptr(self.w), _ptr(self.w_m), _ptr(self.w_v), _ptr(self.w_g), self.n_w,
                                  self.n_reg, float(reg_lambda), a, ADAM_B1, ADAM_B2, ADAM_EPS, s)
@@ -315,6 +358,7 @@ class SCOREBASE(object):
         for e in self.entries:
             self._view(self.w_m, e).copy_(torch.from_numpy(z[e[0] + "/Adam"]).view_as(self._view(self.w_m, e)))
             self._view(self.w_v, e).copy_(torch.from_numpy(z[e[0] + "/Adam_1"]).view_as(self._view(self.w_v, e)))
+        self.refresh_row_flags()
         self.beta1_power = np.float32(z["beta1_power"])
         self.beta2_power = np.float32(z["beta2_power"])
         self.step = int(z["global_step"])

@@ -144,10 +144,17 @@ def test_segment_sum_rows_op():
     need = int(lib.score_segment_sum_scratch_bytes(n, D))
     scratch = torch.empty((need,), dtype=torch.uint8, device="cuda")
     p = lambda t: C.c_void_p(t.data_ptr())
-    for _ in range(2):
-        rc = lib.score_segment_sum_rows(p(drows), p(dsrc), n, D, R, p(out), p(scratch), need,
-                                        C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    flags = torch.zeros((R,), dtype=torch.uint8, device="cuda")
+    flags[::3] = 1
+    for it in range(2):
+        rc = lib.score_segment_sum_rows(p(drows), p(dsrc), n, D, R, p(out), p(flags) if it else None, p(scratch),
+                                        need, C.c_void_p(torch.cuda.current_stream().cuda_stream))
         assert rc == 0
+    # every row written is marked 2; the others keep their state
+    wantf = np.zeros(R, np.uint8)
+    wantf[::3] = 1
+    wantf[np.unique(rows)] = 2
+    assert np.array_equal(flags.cpu().numpy(), wantf)
     want = np.full((R, D), 3.0, dtype=np.float64)                         # local row 0 is a real row on shards > 0: summed like any other
     drows = torch.from_numpy(rows).cuda()
     touched = np.unique(rows)

@@ -53,16 +53,16 @@ def test_gradient_linearity_and_scatter_agreement(cfg3):
     batch = m.device_batch(w.batch(B, 2))
     m.scatter_mode, m.global_batch = 0, 0
     m.forward_backward(batch, 1e-4, 1.0)
-    g0, w0 = m.table_g.clone(), m.w_g.clone()
+    g0, w0 = m.dense_table_grad().clone(), m.w_g.clone()
     m.forward_backward(batch, 1e-4, 1.0)
-    assert torch.equal(g0, m.table_g) and torch.equal(w0, m.w_g)
+    assert torch.equal(g0, m.dense_table_grad()) and torch.equal(w0, m.w_g)
     m.global_batch = 2 * B
     m.forward_backward(batch, 1e-4, 1.0)
-    assert torch.equal(m.table_g * 2, g0) and torch.equal(m.w_g * 2, w0)
+    assert torch.equal(m.dense_table_grad() * 2, g0) and torch.equal(m.w_g * 2, w0)
     m.global_batch = 0
     m.scatter_mode = 1
     m.forward_backward(batch, 1e-4, 1.0)
-    assert float((m.table_g - g0).abs().max()) <= 2e-5 * float(g0.abs().max())
+    assert float((m.dense_table_grad() - g0).abs().max()) <= 2e-5 * float(g0.abs().max())
     m.scatter_mode = 0
     # rows not in the batch get exactly zero gradient; row 0 (dummy) too
     used = torch.zeros(m.table.shape[0], dtype=torch.bool, device="cuda")

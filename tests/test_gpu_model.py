@@ -215,13 +215,13 @@ def test_scatter_modes_agree_and_pull_is_deterministic():
     batch = m.device_batch(w.batch(256, 3))
     m.scatter_mode = 0
     m.forward_backward(batch, 1e-4, 1.0)
-    g0 = m.table_g.clone()
+    g0 = m.dense_table_grad().clone()
     w0 = m.w_g.clone()
     m.forward_backward(batch, 1e-4, 1.0)
-    assert torch.equal(g0, m.table_g) and torch.equal(w0, m.w_g)
+    assert torch.equal(g0, m.dense_table_grad()) and torch.equal(w0, m.w_g)
     m.scatter_mode = 1
     m.forward_backward(batch, 1e-4, 1.0)
-    g1 = m.table_g
+    g1 = m.dense_table_grad()
     scale = float(g0.abs().max())
     assert float((g0 - g1).abs().max()) <= 2e-5 * scale
     assert torch.equal((g0 != 0).any(dim=1), (g1 != 0).any(dim=1))

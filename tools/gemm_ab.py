@@ -4,7 +4,7 @@ from score_amd import _lib
 lib=_lib.load()
 P=lambda t: C.c_void_p(t.data_ptr())
 st=lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
-shapes=[(0,20480,256,448),(0,20480,128,448),(0,20480,384,448),(0,20480,80,1184),
+shapes=[(0,20480,80,592),(1,20480,592,80),(2,592,80,20480),(0,20480,256,448),(0,20480,128,448),(0,20480,384,448),(0,20480,80,1184),
         (1,20480,448,256),(1,20480,448,128),(1,20480,448,384),(1,20480,1184,80),
         (2,448,256,20480),(2,448,128,20480),(2,448,384,20480),(2,128,256,20480),(2,1184,80,20480),(2,128,128,20480),(0,1024,200,704),(2,704,200,1024)]
 FLB=int(sys.argv[1]) if len(sys.argv)>1 else 16
