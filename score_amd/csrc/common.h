@@ -47,6 +47,21 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// Logical tile (bx, by, bz) of this workgroup in a 1-D launch of gx*gy*gz workgroups.  Workgroups are dealt
+// round-robin over the 8 XCDs (each with a private L2), so neighbours in launch order never share an L2;
+// this hands every XCD one contiguous run of logical tiles, x fastest, so the tiles that stream the same
+// operand panel (same by/bz) find it in one L2.  Bijective for any workgroup count; placement is a speed
+// assumption only.
+__device__ __forceinline__ void xcd_tile_coords(int gx, int gy, int& bx, int& by, int& bz) {
+  const int nwg = (int)gridDim.x, orig = (int)blockIdx.x;
+  const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+  const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+  bx = wg % gx;
+  const int t = wg / gx;
+  by = t % gy;
+  bz = t / gy;
+}
+
 // counter-based uniform in [0,1): splitmix64 finaliser of (seed, idx); same value
 // wherever and whenever it is evaluated, so backward never needs a stored mask.
 __device__ __forceinline__ float hash_uniform(uint64_t seed, uint64_t idx) {

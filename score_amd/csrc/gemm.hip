@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, cons
                                                        float* __restrict__ C, int ldc,
                                                        const float* __restrict__ bias, int flags, float keep,
                                                        const uint8_t* __restrict__ mask, uint64_t seed,
-                                                       int k_chunk, float* __restrict__ slab) {
+                                                       int k_chunk, float* __restrict__ slab, int gx, int gy) {
   constexpr int BM = 64 * WM, BN = 64 * WN, BS_LD = BN + 1;
   constexpr int AS_LD = BK + 1;   // As[i][k]: column reads by 32 lanes -> odd word stride, conflict-free
   constexpr int RA = WM * BK / 16, RB = WN * BK / 16, QK = BK / 4;   // staging quads per thread / per k-row
@@ -52,8 +52,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, cons
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int bm = blockIdx.y * BM, bn = blockIdx.x * BN;
-  const int kbeg = blockIdx.z * k_chunk;
+  int bx, by, bz;
+  xcd_tile_coords(gx, gy, bx, by, bz);
+  const int bm = by * BM, bn = bx * BN;
+  const int kbeg = bz * k_chunk;
   const int kend = min(K, kbeg + k_chunk);
 
   float ra[RA][4], rb[RB][4];
@@ -155,7 +157,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, cons
         const int row = bm + wm * 32 * WM + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * khalf;
         if (row >= M) continue;
         if (slab) {
-          slab[((int64_t)blockIdx.z * M + row) * N + col] = acc[i][j][r];
+          slab[((int64_t)bz * M + row) * N + col] = acc[i][j][r];
         } else {
           float v = epilogue(acc[i][j][r], row, col, N, bias, flags, keep, mask, seed);
           float* dst = C + (int64_t)row * ldc + col;
@@ -204,7 +206,7 @@ extern "C" int score_gemm(int32_t trans, int32_t M, int32_t N, int32_t K, const 
   const bool x3_ok = al_a && al_b && (a_kc ? (K & 3) == 0 : (M & 3) == 0) && (b_kc ? (K & 3) == 0 : (N & 3) == 0);
   // measured on MI355X (tools/gemm_ab.py, interleaved A/B in one process): the split pays where the
   // tile is wide and the K loop long; small products stay on the f32 MFMA kernel
-  const bool x3_shape = (trans == 0 && M >= 4096 && (N >= 256 || (K >= 1024 && N >= 64))) ||
+  const bool x3_shape = (trans == 0 && M >= 4096 && N >= 64) ||
                         (trans == 1 && M >= 4096 && N >= 256) ||
                         (trans == 2 && (int64_t)M * N >= 32768 && K >= 4096);
   const bool x3_force = (flags & 32) != 0;     // tests: take the bf16x3 kernel whenever it is legal
@@ -274,8 +276,9 @@ extern "C" int score_gemm(int32_t trans, int32_t M, int32_t N, int32_t K, const 
     slab = nsplit > 1 ? scratch : nullptr;
   }
 #define LAUNCH(TR, WMv, WNv)                                                                                       \
-  hipLaunchKernelGGL((gemm_f32_kernel<TR, WMv, WNv, 16>), grid, dim3(256), 0, s, M, N, K, A, lda, Bm, ldb, C, ldc, \
-                     bias, flags, keep_prob, drop_mask, drop_seed, k_chunk, slab)
+  hipLaunchKernelGGL((gemm_f32_kernel<TR, WMv, WNv, 16>), dim3(grid.x * grid.y * grid.z), dim3(256), 0, s, M, N, K, A, \
+                     lda, Bm, ldb, C, ldc, bias, flags, keep_prob, drop_mask, drop_seed, k_chunk, slab, (int)grid.x,  \
+                     (int)grid.y)
 #define LAUNCH_T(TR)                                      \
   do {                                                    \
     if (WMs == 2 && WNs == 2) LAUNCH(TR, 2, 2);           \

@@ -7,9 +7,14 @@
 // v_mfma_f32_32x32x16_bf16 per k-step reproduce an fp32 GEMM to fp32 accuracy at 16/6 = 2.7x the
 // f32-MFMA rate.  The split is done once per element while staging the tile into LDS.
 //
-// Tile: 128x128x32 per 256-thread block, 2x2 waves of 64x64 (2x2 MFMA tiles each), LDS holds the
+// Tile: (64*WM)x128x32 per 256-thread block, 2x2 waves of (32*WM)x64, two blocks per CU.  LDS holds the
 // three bf16 planes of A as [m][k] and of B as [n][k] (k contiguous, 16-B fragments, row stride 40
-// bf16 = 80 B: conflict-free ds_read_b128).  Same operand layouts / epilogue / split-K as gemm.hip.
+// bf16 = 80 B: conflict-free ds_read_b128).  The K loop is software-pipelined by hand: each of the
+// tile's MFMA slots carries its share of the NEXT tile's split (a few VALU ops, in the shadow of the
+// 32-cycle MFMA), of the tile-after-next's global loads (issued as soon as the split frees their
+// registers) and of the second k-step's fragment reads; sched_barrier pins the interleave.  Workgroups
+// take their tile through the XCD-aware order of common.h.  Same operand layouts / epilogue / split-K
+// as gemm.hip.  X3_PROBE_* macros strip one ingredient at a time for tools/x3_probe.py.
 #include <type_traits>
 #include "common.h"
 #include "kernels.h"
@@ -46,19 +51,20 @@ __device__ __forceinline__ void split3(float x, uint32_t& h, uint32_t& m, uint32
   uint32_t rb = __float_as_uint(r1);
   m = rb & 0xFFFF0000u;
   float r2 = r1 - __uint_as_float(m);
-  l = __float_as_uint(r2) & 0xFFFF0000u;
+  l = __float_as_uint(r2);       // (pack2 keeps the upper half only)
 }
-// pack two bf16 (given as fp32-word upper halves) into one dword: lo element first
-__device__ __forceinline__ uint32_t pack2(uint32_t a, uint32_t b) { return (a >> 16) | b; }
+// pack the upper halves of two fp32 words (= two bf16) into one dword, first element low: one v_perm_b32
+__device__ __forceinline__ uint32_t pack2(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
 
 // WM = 32-row MFMA tiles per wave along M: block tile (64*WM) x 128
 template <int TRANS, int WM>
-__global__ __launch_bounds__(256) void gemm_bf16x3_kernel(int M, int N, int K, const float* __restrict__ A, int lda,
-                                                          const float* __restrict__ Bm, int ldb,
-                                                          float* __restrict__ C, int ldc,
-                                                          const float* __restrict__ bias, int flags, float keep,
-                                                          const uint8_t* __restrict__ mask, uint64_t seed,
-                                                          int k_chunk, float* __restrict__ slab) {
+__global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(int M, int N, int K, const float* __restrict__ A, int lda,
+                                                             const float* __restrict__ Bm, int ldb,
+                                                             float* __restrict__ C, int ldc,
+                                                             const float* __restrict__ bias, int flags, float keep,
+                                                             const uint8_t* __restrict__ mask, uint64_t seed,
+                                                             int k_chunk, float* __restrict__ slab, int gx,
+                                                             int gy) {
   constexpr int TBM = 64 * WM;
   constexpr int EA = TBM * TBK / 256;      // A elements staged per thread (16 or 8)
   __shared__ __attribute__((aligned(16))) unsigned short Ap[3][TBM * TLD];
@@ -67,102 +73,164 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(int M, int N, int K, c
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int bm = blockIdx.y * TBM, bn = blockIdx.x * TBN;
-  const int kbeg = blockIdx.z * k_chunk;
+  int bx, by, bz;
+  xcd_tile_coords(gx, gy, bx, by, bz);
+  const int bm = by * TBM, bn = bx * TBN;
+  const int kbeg = bz * k_chunk;
   const int kend = min(K, kbeg + k_chunk);
   constexpr bool A_KCONTIG = (TRANS != 2);   // A[m][k]
   constexpr bool B_KCONTIG = (TRANS == 1);   // B[n][k]
 
   // Register pipeline: tile t is in LDS, tile t+1 is being split (VALU, interleaved with the MFMAs of
-  // tile t), tile t+2 goes in flight from global memory as soon as the split has consumed the registers.  All staging is branch-free: addresses are
-  // clamped into range and out-of-range elements are zeroed by a select.
+  // tile t), tile t+2 goes in flight from global memory as its staging registers are consumed.
+  // Per-thread element offsets are fixed for the whole K loop (computed once; rows/columns past the
+  // edge are clamped onto the last valid one -- their products land in C rows/columns that are never
+  // stored); only the K tail needs zero fill, and only the last tile(s) take that path.
   constexpr int XA = A_KCONTIG ? EA : 16;  // a k-strided operand is staged as 4x4 blocks: 16 per active thread
+  constexpr int NA4 = XA / 4;              // 16-B loads per thread and tile
   float xa[XA], xb[16];                    // staging registers (tile t+1, then t+2)
   uint32_t pa[3 * XA / 2], pb[24];
-  // k-contiguous operand X[r][k] (r = m or n): thread -> 4 quads, quad q: row q>>3, k (q&7)*4
-  auto load_kc = [&](const float* X, int ld, int r0, int rlim, int k0, float* dst, auto nrep) {
+  uint32_t offa[NA4], offb[4];             // element offsets of this thread's quads inside a k-tile
+  int ka[NA4], kb4[4];                     // k of each quad relative to the tile start
+  // k-contiguous operand X[r][k]: quad q = tid + 256*rep: row q>>3, k (q&7)*4
+  // k-strided operand X[k][c]: a 4(k) x 4(c) block: k-group tid&7, column-group tid>>3 (rep = k inside the block)
+  const bool a_mine = A_KCONTIG || (tid >> 3) * 4 < TBM;   // a 64-wide k-strided tile has only 128 blocks of 4x4
 #pragma unroll
-    for (int rep = 0; rep < decltype(nrep)::value; ++rep) {
+  for (int rep = 0; rep < NA4; ++rep) {
+    if (A_KCONTIG) {
       const int q = tid + 256 * rep;
-      const int r = r0 + (q >> 3), k = k0 + (q & 7) * 4;
-      const bool ok = r < rlim && k < kend;
-      const float4 v = ld4(X + (int64_t)(ok ? r : 0) * ld + (ok ? k : 0));
-      dst[rep * 4 + 0] = ok ? v.x : 0.f; dst[rep * 4 + 1] = ok ? v.y : 0.f;
-      dst[rep * 4 + 2] = ok ? v.z : 0.f; dst[rep * 4 + 3] = ok ? v.w : 0.f;
+      offa[rep] = (uint32_t)min(bm + (q >> 3), M - 1) * (uint32_t)lda + (uint32_t)((q & 7) * 4);
+      ka[rep] = (q & 7) * 4;
+    } else {
+      offa[rep] = (uint32_t)((tid & 7) * 4 + rep) * (uint32_t)lda + (uint32_t)min(bm + (tid >> 3) * 4, M - 4);
+      ka[rep] = (tid & 7) * 4 + rep;
     }
-  };
-  // k-strided operand X[k][c] (c = m or n): thread -> a 4(k) x 4(c) block: k-group tid&7, column-group
-  // tid>>3; four 16-B loads along c (one per k), transposed in registers on the way to LDS
-  auto load_ks = [&](const float* X, int ld, int c0, int clim, int k0, float* dst, int ncols) {
-    const int c = c0 + (tid >> 3) * 4;
-    const int kb = k0 + (tid & 7) * 4;
-    const bool mine = (tid >> 3) * 4 < ncols;      // a 64-wide tile has only 128 blocks of 4x4
+  }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const bool ok = mine && c < clim && kb + i < kend;
-      const float4 v = ld4(X + (int64_t)(ok ? kb + i : 0) * ld + (ok ? c : 0));
-      dst[i * 4 + 0] = ok ? v.x : 0.f; dst[i * 4 + 1] = ok ? v.y : 0.f;
-      dst[i * 4 + 2] = ok ? v.z : 0.f; dst[i * 4 + 3] = ok ? v.w : 0.f;
-    }
-  };
-  // split 16 staged floats into packed bf16 planes: dst[p*8 + d], d = dword index inside the plane
-  // n floats -> planes dst[p*(n/2) + d]
-  auto split16 = [&](const float* src, uint32_t* dst, auto nn) {
-    constexpr int NH = decltype(nn)::value / 2;
-#pragma unroll
-    for (int j = 0; j < NH; ++j) {
-      uint32_t h0, m0, l0, h1, m1, l1;
-      split3(src[2 * j], h0, m0, l0);
-      split3(src[2 * j + 1], h1, m1, l1);
-      dst[j] = pack2(h0, h1); dst[NH + j] = pack2(m0, m1); dst[2 * NH + j] = pack2(l0, l1);
-    }
-  };
-  auto write_kc = [&](unsigned short* P, int plane_stride, const uint32_t* src, auto nrep) {
-    constexpr int NR = decltype(nrep)::value;
-#pragma unroll
-    for (int rep = 0; rep < NR; ++rep) {
+  for (int rep = 0; rep < 4; ++rep) {
+    if (B_KCONTIG) {
       const int q = tid + 256 * rep;
-      const int r = q >> 3, k = (q & 7) * 4;
-#pragma unroll
-      for (int p = 0; p < 3; ++p)
-        *reinterpret_cast<uint2*>(&P[p * plane_stride + r * TLD + k]) =
-            make_uint2(src[p * 2 * NR + rep * 2], src[p * 2 * NR + rep * 2 + 1]);
+      offb[rep] = (uint32_t)min(bn + (q >> 3), N - 1) * (uint32_t)ldb + (uint32_t)((q & 7) * 4);
+      kb4[rep] = (q & 7) * 4;
+    } else {
+      offb[rep] = (uint32_t)((tid & 7) * 4 + rep) * (uint32_t)ldb + (uint32_t)min(bn + (tid >> 3) * 4, N - 4);
+      kb4[rep] = (tid & 7) * 4 + rep;
     }
+  }
+  // One quad = the four elements that become two packed dwords per plane:
+  //   k-contiguous operand: quad `rep` = one 16-B load (elements rep*4 .. rep*4+3);
+  //   k-strided operand:    quad `e`   = column e of the 4x4 block (elements i*4+e, i = k inside the block).
+  // The quads of A come first (NA4 of them), then the four of B.
+  constexpr int NQ = NA4 + 4;
+  auto quad_src = [&](int qd, int e) -> float& {
+    if (qd < NA4) return A_KCONTIG ? xa[qd * 4 + e] : xa[e * 4 + qd];
+    return B_KCONTIG ? xb[(qd - NA4) * 4 + e] : xb[e * 4 + (qd - NA4)];
   };
-  // (ks) the 4x4 block transposed: for column e the four k values are src[0*4+e] .. src[3*4+e]
-  auto split16t = [&](const float* src, uint32_t* dst) {
+  // k (relative to the tile start) of element e of quad qd
+  auto quad_k = [&](int qd, int e) -> int {
+    if (qd < NA4) return A_KCONTIG ? ka[qd] : ka[e];
+    return B_KCONTIG ? kb4[qd - NA4] : kb4[e];
+  };
+  auto quad_dst = [&](int qd, int p, int d) -> uint32_t& {   // d = 0/1: first / second dword of the quad in plane p
+    if (qd < NA4) return A_KCONTIG ? pa[p * 2 * NA4 + qd * 2 + d] : pa[p * 8 + qd * 2 + d];
+    return B_KCONTIG ? pb[p * 8 + (qd - NA4) * 2 + d] : pb[p * 8 + (qd - NA4) * 2 + d];
+  };
+  // issue the 16-B load `rep` of operand A (which = 0) / B (which = 1) for the tile starting at k0
+  auto load_one = [&](int which, int rep, int k0, auto kcheck) {
+    constexpr bool KCHECK = decltype(kcheck)::value;
+    const bool kc = which == 0 ? A_KCONTIG : B_KCONTIG;
+    const float* X = which == 0 ? A : Bm;
+    const int ld = which == 0 ? lda : ldb;
+    const uint32_t off = which == 0 ? offa[rep] : offb[rep];
+    const int krel = which == 0 ? ka[rep] : kb4[rep];
+    const float* src = X + (kc ? (int64_t)k0 : (int64_t)k0 * ld) + off;
+    if (KCHECK) src = (k0 + krel < kend) ? src : X;      // past the K end: any valid address (zeroed at split)
+#if defined(X3_PROBE_NOLOADA) || defined(X3_PROBE_NOLOADB)   // profiling aids: drop one operand's global loads
+#ifdef X3_PROBE_NOLOADA
+    if (which == 0) return;
+#endif
+#ifdef X3_PROBE_NOLOADB
+    if (which == 1) return;
+#endif
+#endif
+    const float4 v = ld4(src);
+    float* dst = which == 0 ? &xa[rep * 4] : &xb[rep * 4];
+    dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+  };
+  auto load_all = [&](int k0, auto kcheck) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      uint32_t h[4], m[4], l[4];
+    for (int rep = 0; rep < NA4; ++rep) load_one(0, rep, k0, kcheck);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) split3(src[i * 4 + e], h[i], m[i], l[i]);
-      dst[e * 2] = pack2(h[0], h[1]); dst[e * 2 + 1] = pack2(h[2], h[3]);
-      dst[8 + e * 2] = pack2(m[0], m[1]); dst[8 + e * 2 + 1] = pack2(m[2], m[3]);
-      dst[16 + e * 2] = pack2(l[0], l[1]); dst[16 + e * 2 + 1] = pack2(l[2], l[3]);
+    for (int rep = 0; rep < 4; ++rep) load_one(1, rep, k0, kcheck);
+  };
+  uint32_t sh[4], sm[4], sl[4];   // split pieces of the quad in progress
+  // micro-op m of the split of the tile starting at k1 (m = quad * 5 + step; steps 0-3 split one element,
+  // step 4 packs); after a quad's elements are split its staging registers are refilled from tile k2
+  auto split_micro = [&](int m, int k1, int k2, auto kcheck) {
+    constexpr bool KCHECK = decltype(kcheck)::value;
+    const int qd = m / 5, step = m % 5;
+    if (step < 4) {
+      float x = quad_src(qd, step);
+      if (KCHECK) x = (k1 + quad_k(qd, step) < kend) ? x : 0.f;
+#ifdef X3_PROBE_NOSPLIT          // profiling aid (tools/x3_probe.py): wrong numbers, same data movement
+      sh[step] = sm[step] = sl[step] = __float_as_uint(x);
+#else
+      split3(x, sh[step], sm[step], sl[step]);
+#endif
+      if (step == 3) {
+        const bool is_a = qd < NA4;
+        const bool kc = is_a ? A_KCONTIG : B_KCONTIG;
+        if (kc) {
+          load_one(is_a ? 0 : 1, is_a ? qd : qd - NA4, k2, kcheck);
+        } else if (qd == (is_a ? NA4 - 1 : NQ - 1)) {      // a 4x4 block is free once its last column is split
+#pragma unroll
+          for (int rep = 0; rep < 4; ++rep) load_one(is_a ? 0 : 1, rep, k2, kcheck);
+        }
+      }
+    } else {
+      quad_dst(qd, 0, 0) = pack2(sh[0], sh[1]); quad_dst(qd, 0, 1) = pack2(sh[2], sh[3]);
+      quad_dst(qd, 1, 0) = pack2(sm[0], sm[1]); quad_dst(qd, 1, 1) = pack2(sm[2], sm[3]);
+      quad_dst(qd, 2, 0) = pack2(sl[0], sl[1]); quad_dst(qd, 2, 1) = pack2(sl[2], sl[3]);
     }
-  };
-  auto write_ks = [&](unsigned short* P, int plane_stride, const uint32_t* src, int ncols) {
-    const int c = (tid >> 3) * 4, kb = (tid & 7) * 4;
-    if (c >= ncols) return;
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-#pragma unroll
-      for (int p = 0; p < 3; ++p)
-        *reinterpret_cast<uint2*>(&P[p * plane_stride + (c + e) * TLD + kb]) =
-            make_uint2(src[p * 8 + e * 2], src[p * 8 + e * 2 + 1]);
-  };
-  // (the k-strided A of a 64-row tile still stages 16 floats per ACTIVE thread: EA counts kc quads only)
-  auto split_tiles = [&](const float* ra, const float* rb) {
-    if (A_KCONTIG) split16(ra, pa, std::integral_constant<int, EA>()); else split16t(ra, pa);
-    if (B_KCONTIG) split16(rb, pb, std::integral_constant<int, 16>()); else split16t(rb, pb);
-  };
-  auto load_tiles = [&](int k0, float* ra, float* rb) {
-    if (A_KCONTIG) load_kc(A, lda, bm, M, k0, ra, std::integral_constant<int, EA / 4>()); else load_ks(A, lda, bm, M, k0, ra, TBM);
-    if (B_KCONTIG) load_kc(Bm, ldb, bn, N, k0, rb, std::integral_constant<int, 4>()); else load_ks(Bm, ldb, bn, N, k0, rb, TBN);
   };
   auto write_tiles = [&]() {
-    if (A_KCONTIG) write_kc(&Ap[0][0], TBM * TLD, pa, std::integral_constant<int, EA / 4>()); else write_ks(&Ap[0][0], TBM * TLD, pa, TBM);
-    if (B_KCONTIG) write_kc(&Bp[0][0], TBN * TLD, pb, std::integral_constant<int, 4>()); else write_ks(&Bp[0][0], TBN * TLD, pb, TBN);
+#ifdef X3_PROBE_NOLDSW           // profiling aid: no LDS writes (keeps the packed registers live)
+    if (pa[0] != 0x12345678u || pb[0] != 0x12345678u) return;
+#endif
+    if (A_KCONTIG) {
+#pragma unroll
+      for (int rep = 0; rep < NA4; ++rep) {
+        const int q = tid + 256 * rep;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          *reinterpret_cast<uint2*>(&Ap[p][(q >> 3) * TLD + (q & 7) * 4]) =
+              make_uint2(pa[p * 2 * NA4 + rep * 2], pa[p * 2 * NA4 + rep * 2 + 1]);
+      }
+    } else if (a_mine) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          *reinterpret_cast<uint2*>(&Ap[p][((tid >> 3) * 4 + e) * TLD + (tid & 7) * 4]) =
+              make_uint2(pa[p * 8 + e * 2], pa[p * 8 + e * 2 + 1]);
+    }
+    if (B_KCONTIG) {
+#pragma unroll
+      for (int rep = 0; rep < 4; ++rep) {
+        const int q = tid + 256 * rep;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          *reinterpret_cast<uint2*>(&Bp[p][(q >> 3) * TLD + (q & 7) * 4]) =
+              make_uint2(pb[p * 8 + rep * 2], pb[p * 8 + rep * 2 + 1]);
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          *reinterpret_cast<uint2*>(&Bp[p][((tid >> 3) * 4 + e) * TLD + (tid & 7) * 4]) =
+              make_uint2(pb[p * 8 + e * 2], pb[p * 8 + e * 2 + 1]);
+    }
   };
 
   f32x16 acc[WM][2];
@@ -174,55 +242,74 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(int M, int N, int K, c
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   const int r31 = lane & 31, kh = lane >> 5;
-  // MFMA phase on the tile resident in LDS, with the next tile's split (VALU) spread into the MFMA
-  // issue gaps and the loads of the tile after that issued first
-  auto mfma_phase = [&]() {
-#pragma unroll
-    for (int ks = 0; ks < TBK / 16; ++ks) {
-      bf16x8 af[WM][3], bf[2][3];
-#pragma unroll
-      for (int p = 0; p < 3; ++p) {
-#pragma unroll
-        for (int i = 0; i < WM; ++i) {
-          const uint4 va = *reinterpret_cast<const uint4*>(&Ap[p][(wm * 32 * WM + i * 32 + r31) * TLD + ks * 16 + kh * 8]);
-          af[i][p] = __builtin_bit_cast(bf16x8, va);
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const uint4 vb = *reinterpret_cast<const uint4*>(&Bp[p][(wn * 64 + i * 32 + r31) * TLD + ks * 16 + kh * 8]);
-          bf[i][p] = __builtin_bit_cast(bf16x8, vb);
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < WM; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          f32x16 c = acc[i][j];
-          // smallest terms first
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], c, 0, 0, 0);
-          acc[i][j] = c;
-        }
+  constexpr int KS = TBK / 16;                  // MFMA k-steps per tile
+  constexpr int NM1 = 6 * WM * 2;               // MFMAs per k-step (24 / 12)
+  constexpr int NM = KS * NM1;                  // per tile (48 / 24)
+  constexpr int NF1 = 3 * (WM + 2);             // fragment reads per k-step (12 / 9)
+  constexpr int MU = NQ * 5;                    // split micro-ops per tile
+  bf16x8 af[KS][WM][3], bf[KS][2][3];
+  auto read_frag = [&](int ks, int f) {         // f: p-major, A tiles then B tiles
+    const int p = f / (WM + 2), i = f % (WM + 2);
+#ifdef X3_PROBE_NOLDSR           // profiling aid: fragments from registers instead of LDS
+    {
+      uint4 z = make_uint4(pa[0], pa[1], pb[0], pb[1] + (uint32_t)f);
+      if (i < WM) af[ks][i][p] = __builtin_bit_cast(bf16x8, z); else bf[ks][i - WM][p] = __builtin_bit_cast(bf16x8, z);
+      return;
     }
-#pragma unroll
-    for (int g = 0; g < 24 * WM; ++g) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA  (32 cycles of matrix pipe, 8 of issue)
-      __builtin_amdgcn_sched_group_barrier(0x002, WM == 2 ? 5 : 8, 0);   // VALU of the next tile's split
+#endif
+    if (i < WM) {
+      const uint4 va = *reinterpret_cast<const uint4*>(&Ap[p][(wm * 32 * WM + i * 32 + r31) * TLD + ks * 16 + kh * 8]);
+      af[ks][i][p] = __builtin_bit_cast(bf16x8, va);
+    } else {
+      const uint4 vb = *reinterpret_cast<const uint4*>(&Bp[p][(wn * 64 + (i - WM) * 32 + r31) * TLD + ks * 16 + kh * 8]);
+      bf[ks][i - WM][p] = __builtin_bit_cast(bf16x8, vb);
     }
   };
-  load_tiles(kbeg, xa, xb);
-  split_tiles(xa, xb);
-  load_tiles(kbeg + TBK, xa, xb);         // (zero-filled past kend)
-  for (int k0 = kbeg; k0 < kend; k0 += TBK) {
-    write_tiles();                        // tile k0
+  // One tile: the MFMAs of the tile resident in LDS, in program order slot by slot; every slot also carries
+  // its share of the next tile's split (VALU in the shadow of the 32-cycle MFMA), of the tile-after-next's
+  // global loads and of the second k-step's fragment reads.  sched_barrier pins that interleave.
+  // Terms smallest first: (1,1) (0,2) (2,0) (0,1) (1,0) (0,0); term-major, so neighbouring MFMAs hit
+  // different accumulators.
+  auto phase = [&](int k0, auto kcheck) {
+    constexpr int TA[6] = {1, 0, 2, 0, 1, 0}, TB[6] = {1, 2, 0, 1, 0, 0};
+#pragma unroll
+    for (int f = 0; f < NF1; ++f) read_frag(0, f);
+#pragma unroll
+    for (int g = 0; g < NM; ++g) {
+      const int ks = g / NM1, t = (g % NM1) / (WM * 2), i = (g / 2) % WM, j = g % 2;
+      if (KS > 1 && g >= NM1 - NF1 - 2 && g < NM1 - 2) read_frag(1, g - (NM1 - NF1 - 2));   // lands before k-step 1
+#ifdef X3_PROBE_NOMFMA           // profiling aid: everything but the matrix instruction
+      acc[i][j][g % 16] += (float)af[ks][i][TA[t]][0] * (float)bf[ks][j][TB[t]][0];
+#else
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][i][TA[t]], bf[ks][j][TB[t]], acc[i][j], 0, 0, 0);
+#endif
+#pragma unroll
+      for (int m = g * MU / NM; m < (g + 1) * MU / NM; ++m) split_micro(m, k0 + TBK, k0 + 2 * TBK, kcheck);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  // tiles [0, nfull) are whole; the main loop only ever splits and loads whole tiles (no bounds work at
+  // all), the last iterations (which reach the K tail or run past kend) take the checked variant
+  const int nfull = (kend - kbeg) / TBK;
+  load_all(kbeg, std::true_type());
+#pragma unroll
+  for (int m = 0; m < MU; ++m) {               // split tile 0 (and fetch tile 1 behind it)
+    const int qd = m / 5, step = m % 5;
+    (void)qd; (void)step;
+    split_micro(m, kbeg, kbeg + TBK, std::true_type());
+  }
+  int k0 = kbeg;
+  for (int t = 0; t + 2 < nfull; ++t, k0 += TBK) {
+    write_tiles();                        // tile k0 (split during the previous phase)
     __syncthreads();
-    split_tiles(xa, xb);                  // tile k0+1 (its loads were issued one phase ago)
-    load_tiles(k0 + 2 * TBK, xa, xb);     // tile k0+2: issued as soon as the split has read xa/xb
-    mfma_phase();
+    phase(k0, std::false_type());
+    __syncthreads();
+  }
+  for (; k0 < kend; k0 += TBK) {
+    write_tiles();
+    __syncthreads();
+    phase(k0, std::true_type());
     __syncthreads();
   }
 
@@ -236,8 +323,11 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(int M, int N, int K, c
       for (int r = 0; r < 16; ++r) {
         const int row = bm + wm * 32 * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
         if (row >= M) continue;
+#ifdef X3_PROBE_NOSTORE          // profiling aid: keep the result live, store (almost) nothing
+        if (acc[i][j][r] != 12345.678f) continue;
+#endif
         if (slab) {
-          slab[((int64_t)blockIdx.z * M + row) * N + col] = acc[i][j][r];
+          slab[((int64_t)bz * M + row) * N + col] = acc[i][j][r];
         } else {
           float v = x3_epilogue(acc[i][j][r], row, col, N, bias, flags, keep, mask, seed);
           float* dst = C + (int64_t)row * ldc + col;
@@ -251,8 +341,8 @@ int score_launch_gemm_bf16x3(int trans, int wm, dim3 grid, int M, int N, int K, 
                              const float* Bm, int ldb, float* C, int ldc, const float* bias, int flags, float keep,
                              const uint8_t* mask, uint64_t seed, int k_chunk, float* slab, hipStream_t s) {
 #define LX(TR, WMv)                                                                                               \
-  hipLaunchKernelGGL((gemm_bf16x3_kernel<TR, WMv>), grid, dim3(256), 0, s, M, N, K, A, lda, Bm, ldb, C, ldc, bias, \
-                     flags, keep, mask, seed, k_chunk, slab)
+  hipLaunchKernelGGL((gemm_bf16x3_kernel<TR, WMv>), dim3(grid.x * grid.y * grid.z), dim3(256), 0, s, M, N, K, A, lda, \
+                     Bm, ldb, C, ldc, bias, flags, keep, mask, seed, k_chunk, slab, (int)grid.x, (int)grid.y)
   if (wm == 2) {
     if (trans == 0) LX(0, 2);
     else if (trans == 1) LX(1, 2);

@@ -116,6 +116,22 @@ def test_gemm_bf16x3_is_fp32_accurate(trans, shape):
         assert bool((err <= tol).all()), float((err / tol).max())
 
 
+@pytest.mark.parametrize("force", [0, 32])
+def test_gemm_row_grouped_bias(force):
+    # flags bits 16+: bias row group g -> output row r adds bias[r // g, :]  (folded attention layer)
+    lib = _lib.load()
+    M, N, K, grp = 20 * 37, 80, 72, 20
+    g = torch.Generator(device="cuda").manual_seed(11)
+    a, b = torch.randn((M, K), device="cuda", generator=g), torch.randn((K, N), device="cuda", generator=g)
+    bias = torch.randn((M // grp, N), device="cuda", generator=g)
+    c = torch.empty((M, N), device="cuda")
+    scratch = torch.empty((1 << 20,), device="cuda")
+    _lib.check(lib.score_gemm(0, M, N, K, P(a), K, P(b), N, P(c), N, P(bias), force | 1 | 2 | (grp << 16), 1.0,
+                              C.c_void_p(0), 0, P(scratch), scratch.numel(), stream()), "gemm")
+    want = torch.relu(a.double() @ b.double() + bias.double().repeat_interleave(grp, dim=0))
+    assert float((c.double() - want).abs().max()) < 1e-4
+
+
 def test_gemm_dropout_epilogue():
     lib = _lib.load()
     M, N, K = 128, 200, 64

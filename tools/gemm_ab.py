@@ -16,14 +16,14 @@ for tr,M,N,K in shapes:
     c=torch.empty((M,N),device='cuda')
     res=[]
     for rnd in range(3):
-        for FL in (0,FLB):
+        for FL in (0,FLB,32):
             e0=torch.cuda.Event(enable_timing=True); e1=torch.cuda.Event(enable_timing=True)
             lib.score_gemm(tr,M,N,K,P(A),A.shape[1],P(Bm),Bm.shape[1],P(c),N,None,FL,1.0,None,0,P(scratch),scratch.numel(),st())
             e0.record()
             for _ in range(10): lib.score_gemm(tr,M,N,K,P(A),A.shape[1],P(Bm),Bm.shape[1],P(c),N,None,FL,1.0,None,0,P(scratch),scratch.numel(),st())
             e1.record(); torch.cuda.synchronize()
             res.append((FL,e0.elapsed_time(e1)/10))
-    t0=min(t for f,t in res if f==0); t1=min(t for f,t in res if f==FLB)
+    t0=min(t for f,t in res if f==0); t1=min(t for f,t in res if f==FLB); t2=min(t for f,t in res if f==32)
     tot[0]+=t0; tot[1]+=t1
-    print("trans=%d M=%6d N=%5d K=%6d  fp32 %7.1f us (%5.1f TF)  x3 %7.1f us (%5.1f TF)  ratio %.2f"%(tr,M,N,K,t0*1e3,2*M*N*K/t0/1e9,t1*1e3,2*M*N*K/t1/1e9,t0/t1))
+    print("trans=%d M=%6d N=%5d K=%6d  fp32 %7.1f us (%5.1f TF)  x3 %7.1f us (%5.1f TF)  ratio %.2f  forced-x3 %7.1f us (%5.1f TF)"%(tr,M,N,K,t0*1e3,2*M*N*K/t0/1e9,t1*1e3,2*M*N*K/t1/1e9,t0/t1,t2*1e3,2*M*N*K/t2/1e9))
 print("sum fp32 %.1f us  x3 %.1f us"%(tot[0]*1e3,tot[1]*1e3))
