@@ -52,14 +52,16 @@ __device__ __forceinline__ float wave_max(float v) {
 // this hands every XCD one contiguous run of logical tiles, x fastest, so the tiles that stream the same
 // operand panel (same by/bz) find it in one L2.  Bijective for any workgroup count; placement is a speed
 // assumption only.
-__device__ __forceinline__ void xcd_tile_coords(int gx, int gy, int& bx, int& by, int& bz) {
-  const int nwg = (int)gridDim.x, orig = (int)blockIdx.x;
+__device__ __forceinline__ void xcd_tile_coords_n(int nwg, int orig, int gx, int gy, int& bx, int& by, int& bz) {
   const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
   const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
   bx = wg % gx;
   const int t = wg / gx;
   by = t % gy;
   bz = t / gy;
+}
+__device__ __forceinline__ void xcd_tile_coords(int gx, int gy, int& bx, int& by, int& bz) {
+  xcd_tile_coords_n((int)gridDim.x, (int)blockIdx.x, gx, gy, bx, by, bz);
 }
 
 // counter-based uniform in [0,1): splitmix64 finaliser of (seed, idx); same value

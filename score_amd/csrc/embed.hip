@@ -602,7 +602,7 @@ int score_launch_target_bwd(float* grad_table, int D, int Fu, int Fi, int B, int
                             int off_ti, int off_tu, const float* query, const float* W1, const float* W2,
                             const float* dzsum1, const float* dzsum2, float* S, float* dW1, float* dB1,
                             float* dW2, float* dB2, float* dtgt_out, float* scratch, int64_t scratch_floats,
-                            ColsumJobs* cq, hipStream_t s) {
+                            ColsumJobs* cq, GemmQueue* gq, hipStream_t s) {
   const bool coattn = W1 != nullptr;
   if (coattn) {
     hipLaunchKernelGGL(dzsum_reduce_kernel, dim3((2 * B + 255) / 256), dim3(256), 0, s, dzsum1, dzsum2, B, T, S);
@@ -615,10 +615,15 @@ int score_launch_target_bwd(float* grad_table, int D, int Fu, int Fi, int B, int
   if (coattn) {
     // dW_t = tgt^T S (call 0 targets the item: query cols Du.., call 1 the user: cols 0..), dbias = sum_b S
     const int Du = Fu * D, Di = Fi * D;
-    SCORE_TRY(score_gemm(2, Di, 1, B, query + Du, ldq, S, 1, dW1, 1, nullptr, 0, 1.f, nullptr, 0, scratch,
-                         scratch_floats, s));
-    SCORE_TRY(score_gemm(2, Du, 1, B, query, ldq, S + B, 1, dW2, 1, nullptr, 0, 1.f, nullptr, 0, scratch,
-                         scratch_floats, s));
+    if (gq) {   // with the backward pass's other weight-gradient products (query and S stay untouched)
+      SCORE_TRY(gemm_queue_add(gq, Di, 1, B, query + Du, ldq, S, 1, dW1, 1));
+      SCORE_TRY(gemm_queue_add(gq, Du, 1, B, query, ldq, S + B, 1, dW2, 1));
+    } else {
+      SCORE_TRY(score_gemm(2, Di, 1, B, query + Du, ldq, S, 1, dW1, 1, nullptr, 0, 1.f, nullptr, 0, scratch,
+                           scratch_floats, s));
+      SCORE_TRY(score_gemm(2, Du, 1, B, query, ldq, S + B, 1, dW2, 1, nullptr, 0, 1.f, nullptr, 0, scratch,
+                           scratch_floats, s));
+    }
     if (cq) {
       SCORE_TRY(colsum_queue_add(cq, S, B, 1, 1, dB1, 0));
       SCORE_TRY(colsum_queue_add(cq, S + B, B, 1, 1, dB2, 0));

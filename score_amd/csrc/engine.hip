@@ -123,6 +123,7 @@ struct WS {
   int64_t gru_out[2], gru_final[2], xproj[2], gates[2];
   int64_t q, ainp, a1, a2, bn, f1, f2, lossb, dlogit, part;
   int64_t weff, wq, qz, adzsum, dweff, dwq, dqd;   // folded first attention layer (head.hip)
+  int64_t dwslab, dwslab_floats, dgstage;          // deferred weight-gradient products (gemm.hip), bn1 dgamma staging
   // backward
   int64_t dz2, dz1, dbn, dhead, ds, da2, da1, dainp, dgru[2], dinfo, dq, dquery, dfinal[2];
   int64_t dxproj[2], rh[2], hprev[2], dxside[2], dzsum[2], S, scratch;
@@ -180,7 +181,15 @@ void build_ws(const Dims& d, int B, WS* w) {
   w->cs_part_floats = 1 << 20;
   w->cs_part = take(w->cs_part_floats);
   w->wxcat = take(2 * (int64_t)(d.I + 1) * 3 * d.H);
-  w->dwxcat = take((int64_t)d.I * 3 * d.H);
+  w->dwxcat = take(2 * (int64_t)d.I * 3 * d.H);
+  w->dgstage = take((int64_t)B * d.Dhead);
+  {
+    // split-K partials of every queued weight-gradient product: ~24 slabs of each dense variable
+    Params Pl;
+    build_layout(d, nullptr, 0, &Pl);
+    w->dwslab_floats = 24 * Pl.n_floats;
+    w->dwslab = take(w->dwslab_floats);
+  }
   // sorted pull-form scatter (scatter.hip)
   for (int c = 0; c < 2; ++c) { w->pcoef[c] = take(BT * d.K); w->dzcoef[c] = take(BT * d.K); }
   w->dtgt = take((int64_t)B * d.Dq);
@@ -437,33 +446,32 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
   const int x3 = st->gemm_mode == 1 ? GF_X3 : 0;
   ColsumJobs cq;
   cq.n = 0; cq.part_used = 0;
+  // weight gradients C = X^T dY have no consumer inside the pass: queued, issued together at its end
+  GemmQueue gq;
+  gq.n = 0;
   hipError_t he = hipMemsetAsync(gw, 0, P.n_floats * sizeof(float), s);
   if (he != hipSuccess) return (int)he;
 
   EV(0);
   // ---- head (score.py:68-81)
   // fc3: dW = f2^T dlogit, db = sum dlogit, dz2 = [f2>0] dlogit w3 / keep
-  G(gemm_mode_call(x3, 2, FC2, 1, B, ws + w.f2, FC2, ws + w.dlogit, 1, gw + P.fc_w[2], 1, nullptr, 0, 1.f, nullptr, 0,
-               scratch, SF, s));
+  G(gemm_queue_add(&gq, FC2, 1, B, ws + w.f2, FC2, ws + w.dlogit, 1, gw + P.fc_w[2], 1));
   G(colsum_queue_add(&cq, ws + w.dlogit, B, 1, 1, gw + P.fc_b[2], 0));
   G(score_launch_outer_relu_bwd(B, FC2, ws + w.dlogit, W + P.fc_w[2], ws + w.f2, keep_prob, ws + w.dz2, s));
   // fc2
-  G(gemm_mode_call(x3, 2, FC1, FC2, B, ws + w.f1, FC1, ws + w.dz2, FC2, gw + P.fc_w[1], FC2, nullptr, 0, 1.f, nullptr, 0,
-               scratch, SF, s));
+  G(gemm_queue_add(&gq, FC1, FC2, B, ws + w.f1, FC1, ws + w.dz2, FC2, gw + P.fc_w[1], FC2));
   G(colsum_queue_add(&cq, ws + w.dz2, B, FC2, FC2, gw + P.fc_b[1], 0));
   G(gemm_mode_call(x3, 1, B, FC1, FC2, ws + w.dz2, FC2, W + P.fc_w[1], FC2, ws + w.dz1, FC1, nullptr, 0, 1.f, nullptr, 0,
                scratch, SF, s));
   G(score_launch_relu_bwd(ws + w.dz1, ws + w.f1, B, FC1, FC1, FC1, keep_prob, s));
   // fc1 + bn1
-  G(gemm_mode_call(x3, 2, d.Dhead, FC1, B, ws + w.bn, d.Dhead, ws + w.dz1, FC1, gw + P.fc_w[0], FC1, nullptr, 0, 1.f,
-               nullptr, 0, scratch, SF, s));
+  G(gemm_queue_add(&gq, d.Dhead, FC1, B, ws + w.bn, d.Dhead, ws + w.dz1, FC1, gw + P.fc_w[0], FC1));
   G(colsum_queue_add(&cq, ws + w.dz1, B, FC1, FC1, gw + P.fc_b[0], 0));
   G(gemm_mode_call(x3, 1, B, d.Dhead, FC1, ws + w.dz1, FC1, W + P.fc_w[0], FC1, ws + w.dbn, d.Dhead, nullptr, 0, 1.f,
                nullptr, 0, scratch, SF, s));
   const float rs = (float)(1.0 / sqrt(1.0 + 1e-3));
-  // (w.bn is dead after the fc1 weight-gradient GEMM above: reuse it as the dgamma staging buffer)
   G(score_launch_bn_bwd(B, d.Dhead, ws + w.head_inp, W + P.bn_g, rs, ws + w.dbn, ws + w.dhead, gw + P.bn_g,
-                        gw + P.bn_b, ws + w.bn, scratch, SF, &cq, s));
+                        gw + P.bn_b, ws + w.dgstage, scratch, SF, &cq, s));
 
   EV(1);
   const float* dfinal[2] = {nullptr, nullptr};
@@ -473,24 +481,20 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
                                  ws + w.gru_out[1], ws + w.att_score, ws + w.dhead, d.Dhead, d.off_u, d.off_i,
                                  ws + w.ds, ws + w.da2, s));
     // dense_5 (40 -> 1): dW = a2^T ds ; db = sum ds
-    G(gemm_mode_call(x3, 2, AT2, 1, BT, ws + w.a2, AT2, ws + w.ds, 1, gw + P.at_w[3], 1, nullptr, 0, 1.f, nullptr, 0,
-                 scratch, SF, s));
+    G(gemm_queue_add(&gq, AT2, 1, BT, ws + w.a2, AT2, ws + w.ds, 1, gw + P.at_w[3], 1));
     G(colsum_queue_add(&cq, ws + w.ds, BT, 1, 1, gw + P.at_b[3], 0));
     // dense_4 (80 -> 40); da2 is already relu-masked
-    G(gemm_mode_call(x3, 2, AT1, AT2, BT, ws + w.a1, AT1, ws + w.da2, AT2, gw + P.at_w[2], AT2, nullptr, 0, 1.f, nullptr,
-                 0, scratch, SF, s));
+    G(gemm_queue_add(&gq, AT1, AT2, BT, ws + w.a1, AT1, ws + w.da2, AT2, gw + P.at_w[2], AT2));
     G(colsum_queue_add(&cq, ws + w.da2, BT, AT2, AT2, gw + P.at_b[2], 0));
     G(gemm_mode_call(x3, 1, BT, AT1, AT2, ws + w.da2, AT2, W + P.at_w[2], AT2, ws + w.da1, AT1, nullptr, 0, 1.f, nullptr,
                  0, scratch, SF, s));
     G(score_launch_relu_bwd(ws + w.da1, ws + w.a1, BT, AT1, AT1, AT1, 1.f, s));
     // dense_3 (4Dk -> 80), folded: weight gradient from [k, q*k]^T da1 and q^T sum_t da1
-    G(gemm_mode_call(x3, 2, 2 * d.Dk, AT1, BT, ws + w.ainp, 2 * d.Dk, ws + w.da1, AT1, ws + w.dweff, AT1, nullptr, 0,
-                 1.f, nullptr, 0, scratch, SF, s));
+    G(gemm_queue_add(&gq, 2 * d.Dk, AT1, BT, ws + w.ainp, 2 * d.Dk, ws + w.da1, AT1, ws + w.dweff, AT1));
     G(colsum_queue_add(&cq, ws + w.da1, BT, AT1, AT1, gw + P.at_b[1], 0));
     G(score_launch_attn_dzsum(B, T, AT1, ws + w.da1, ws + w.adzsum, s));
-    G(gemm_mode_call(x3, 2, d.Dk, AT1, B, ws + w.q, d.Dk, ws + w.adzsum, AT1, ws + w.dwq, AT1, nullptr, 0, 1.f, nullptr,
-                 0, scratch, SF, s));
-    G(score_launch_attn_w1_grad(d.Dk, AT1, ws + w.dweff, ws + w.dwq, gw + P.at_w[1], s));
+    G(gemm_queue_add(&gq, d.Dk, AT1, B, ws + w.q, d.Dk, ws + w.adzsum, AT1, ws + w.dwq, AT1));
+    // (gw + P.at_w[1] is assembled from dweff / dwq after the queue is flushed)
     G(gemm_mode_call(x3, 1, BT, 2 * d.Dk, AT1, ws + w.da1, AT1, ws + w.weff, AT1, ws + w.dainp, 2 * d.Dk, nullptr, 0,
                  1.f, nullptr, 0, scratch, SF, s));
     G(gemm_mode_call(x3, 1, B, d.Dk, AT1, ws + w.adzsum, AT1, ws + w.wq, AT1, ws + w.dqd, d.Dk, nullptr, 0, 1.f, nullptr,
@@ -499,8 +503,7 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
                                 ws + w.info, ws + w.att_score, ws + w.dhead, d.Dhead, d.off_u, d.off_i,
                                 ws + w.dqd, ws + w.dgru[0], ws + w.dgru[1], ws + w.dinfo, ws + w.dq, s));
     // dense_2 (query projection)
-    G(gemm_mode_call(x3, 2, d.Dq, d.Dk, B, ws + w.query, d.Dq, ws + w.dq, d.Dk, gw + P.at_w[0], d.Dk, nullptr, 0, 1.f,
-                 nullptr, 0, scratch, SF, s));
+    G(gemm_queue_add(&gq, d.Dq, d.Dk, B, ws + w.query, d.Dq, ws + w.dq, d.Dk, gw + P.at_w[0], d.Dk));
     G(colsum_queue_add(&cq, ws + w.dq, B, d.Dk, d.Dk, gw + P.at_b[0], 0));
     G(gemm_mode_call(x3, 1, B, d.Dq, d.Dk, ws + w.dq, d.Dk, W + P.at_w[0], d.Dk, ws + w.dquery, d.Dq, nullptr, 0, 1.f,
                  nullptr, 0, scratch, SF, s));
@@ -537,13 +540,10 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
     // kernels are [x ; h] row blocks (TF GRUCell): x rows first.  x part of both kernels in one product
     // on the concatenated layout, then split into the two variables' gradients
     const float* cat = ws + w.wxcat + (int64_t)sd * (d.I + 1) * 3 * H;
-    G(gemm_mode_call(x3, 2, d.I, 3 * H, BT, ws + w.xside[sd], d.I, dxp, 3 * H, ws + w.dwxcat, 3 * H, nullptr, 0, 1.f,
-                     nullptr, 0, scratch, SF, s));
-    G(score_launch_gru_wxsplit(ws + w.dwxcat, d.I, H, gw + P.gk[sd], gw + P.ck[sd], s));
-    G(gemm_mode_call(x3, 2, H, 2 * H, BT, ws + w.hprev[sd], H, dxp, 3 * H, gw + P.gk[sd] + (int64_t)d.I * 2 * H, 2 * H,
-                 nullptr, 0, 1.f, nullptr, 0, scratch, SF, s));
-    G(gemm_mode_call(x3, 2, H, H, BT, ws + w.rh[sd], H, dxp + 2 * H, 3 * H, gw + P.ck[sd] + (int64_t)d.I * H, H, nullptr, 0,
-                 1.f, nullptr, 0, scratch, SF, s));
+    G(gemm_queue_add(&gq, d.I, 3 * H, BT, ws + w.xside[sd], d.I, dxp, 3 * H, ws + w.dwxcat + (int64_t)sd * d.I * 3 * H,
+                     3 * H));                       // (split into the two variables' gradients after the flush)
+    G(gemm_queue_add(&gq, H, 2 * H, BT, ws + w.hprev[sd], H, dxp, 3 * H, gw + P.gk[sd] + (int64_t)d.I * 2 * H, 2 * H));
+    G(gemm_queue_add(&gq, H, H, BT, ws + w.rh[sd], H, dxp + 2 * H, 3 * H, gw + P.ck[sd] + (int64_t)d.I * H, H));
     G(colsum_queue_add(&cq, dxp, BT, 2 * H, 3 * H, gw + P.gb[sd], 0));
     G(colsum_queue_add(&cq, dxp + 2 * H, BT, H, 3 * H, gw + P.cb[sd], 0));
     // d x = [dgates | dcand] . [Wx_gates | Wx_cand]^T
@@ -580,7 +580,8 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
                             ws + w.query, d.coattn ? W + P.ca_w[0] : nullptr, d.coattn ? W + P.ca_w[1] : nullptr,
                             ws + w.dzsum[0], ws + w.dzsum[1], ws + w.S, d.coattn ? gw + P.ca_w[0] : nullptr,
                             d.coattn ? gw + P.ca_b[0] : nullptr, d.coattn ? gw + P.ca_w[1] : nullptr,
-                            d.coattn ? gw + P.ca_b[1] : nullptr, atomic ? nullptr : ws + w.dtgt, scratch, SF, &cq, s));
+                            d.coattn ? gw + P.ca_b[1] : nullptr, atomic ? nullptr : ws + w.dtgt, scratch, SF, &cq, &gq,
+                            s));
   if (!atomic) {
     PullArgs pa;
     memset(&pa, 0, sizeof(pa));
@@ -602,6 +603,11 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
     }
     G(score_launch_pull(pa, keys_out, vals_out, w.n_occ + 1, grad_table, ws + w.partials, w.partial_floats, s));
   }
+  // every weight-gradient product of the pass, then the gradients assembled from them
+  G(gemm_queue_flush(&gq, x3 != 0, ws + w.dwslab, w.dwslab_floats, s));
+  if (d.attn) G(score_launch_attn_w1_grad(d.Dk, AT1, ws + w.dweff, ws + w.dwq, gw + P.at_w[1], s));
+  for (int sd = 0; sd < 2; ++sd)
+    G(score_launch_gru_wxsplit(ws + w.dwxcat + (int64_t)sd * d.I * 3 * H, d.I, H, gw + P.gk[sd], gw + P.ck[sd], s));
   G(colsum_queue_flush(&cq, ws + w.cs_part, w.cs_part_floats, s));
   EV(4);
   return 0;

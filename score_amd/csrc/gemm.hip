@@ -37,12 +37,18 @@ __device__ __forceinline__ float epilogue(float v, int row, int col, int N, cons
 // TRANS 2: A[K,M] (lda) , B[K,N] (ldb)  -> C = A^T . B
 // Block = 2x2 waves, each wave a (32*WM) x (32*WN) tile => block tile (64*WM) x (64*WN).
 template <int TRANS, int WM, int WN, int BK>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, const float* __restrict__ A, int lda,
-                                                       const float* __restrict__ Bm, int ldb,
-                                                       float* __restrict__ C, int ldc,
-                                                       const float* __restrict__ bias, int flags, float keep,
-                                                       const uint8_t* __restrict__ mask, uint64_t seed,
-                                                       int k_chunk, float* __restrict__ slab, int gx, int gy) {
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmGroup grp, const float* __restrict__ bias, int flags,
+                                                       float keep, const uint8_t* __restrict__ mask, uint64_t seed) {
+  // this workgroup's problem and its index inside it (kernels.h: GemmGroup)
+  int pi = 0, local = (int)blockIdx.x;
+  while (pi + 1 < grp.n && local >= ((grp.p[pi].nblocks + 7) & ~7)) { local -= (grp.p[pi].nblocks + 7) & ~7; ++pi; }
+  const GemmProb& pr = grp.p[pi];
+  if (local >= pr.nblocks) return;
+  const int M = pr.M, N = pr.N, K = pr.K, lda = pr.lda, ldb = pr.ldb, ldc = pr.ldc, k_chunk = pr.k_chunk;
+  const float* __restrict__ A = pr.A;
+  const float* __restrict__ Bm = pr.B;
+  float* __restrict__ C = pr.C;
+  float* __restrict__ slab = pr.slab;
   constexpr int BM = 64 * WM, BN = 64 * WN, BS_LD = BN + 1;
   constexpr int AS_LD = BK + 1;   // As[i][k]: column reads by 32 lanes -> odd word stride, conflict-free
   constexpr int RA = WM * BK / 16, RB = WN * BK / 16, QK = BK / 4;   // staging quads per thread / per k-row
@@ -53,7 +59,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, cons
   const int wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   int bx, by, bz;
-  xcd_tile_coords(gx, gy, bx, by, bz);
+  xcd_tile_coords_n(pr.nblocks, local, pr.gx, pr.gy, bx, by, bz);
   const int bm = by * BM, bn = bx * BN;
   const int kbeg = bz * k_chunk;
   const int kend = min(K, kbeg + k_chunk);
@@ -189,6 +195,36 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slab, int nsplit,
   *dst = (flags & F_ACC) ? *dst + v : v;
 }
 
+// every split-K slab set of a flushed queue in one launch: C = sum_z slab[z]  (slab order)
+struct ReduceJob { const float* slab; float* C; int ns, M, N, ldc, first_block, pad; };
+struct ReduceGroup { int n; int pad; ReduceJob j[2 * GEMM_GROUP_MAX]; };
+__global__ void splitk_reduce_group_kernel(const ReduceGroup g) {
+  int ji = 0;
+  while (ji + 1 < g.n && (int)blockIdx.x >= g.j[ji + 1].first_block) ++ji;
+  const ReduceJob& job = g.j[ji];
+  const int64_t n = (int64_t)job.M * job.N;
+  const int64_t i = (int64_t)((int)blockIdx.x - job.first_block) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int row = (int)(i / job.N), col = (int)(i - (int64_t)row * job.N);
+  float s = 0.f;
+  int z = 0;
+  for (; z + 8 <= job.ns; z += 8) {
+    float v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = job.slab[(int64_t)(z + q) * n + i];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s += v[q];
+  }
+  for (; z < job.ns; ++z) s += job.slab[(int64_t)z * n + i];
+  job.C[(int64_t)row * job.ldc + col] = s;
+}
+
+static void fill_prob(GemmProb* p, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
+                      int ldc, int k_chunk, float* slab, int gx, int gy, int gz) {
+  p->A = A; p->B = B; p->C = C; p->slab = slab; p->M = M; p->N = N; p->K = K; p->lda = lda; p->ldb = ldb;
+  p->ldc = ldc; p->k_chunk = k_chunk; p->gx = gx; p->gy = gy; p->nblocks = gx * gy * gz;
+}
+
 extern "C" int score_gemm(int32_t trans, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda,
                           const float* Bm, int32_t ldb, float* C, int32_t ldc, const float* bias,
                           int32_t flags, float keep_prob, const uint8_t* drop_mask, uint64_t drop_seed,
@@ -237,8 +273,11 @@ extern "C" int score_gemm(int32_t trans, int32_t M, int32_t N, int32_t K, const 
       g3.z = ns;
       sl = ns > 1 ? scratch : nullptr;
     }
-    SCORE_TRY(score_launch_gemm_bf16x3(trans, wm3, g3, M, N, K, A, lda, Bm, ldb, C, ldc, bias, flags & KF_MASK, keep_prob,
-                                       drop_mask, drop_seed, kc, sl, s));
+    GemmGroup grp;
+    grp.n = 1;
+    fill_prob(&grp.p[0], M, N, K, A, lda, Bm, ldb, C, ldc, kc, sl, (int)g3.x, (int)g3.y, (int)g3.z);
+    grp.total_blocks = (grp.p[0].nblocks + 7) & ~7;
+    SCORE_TRY(score_launch_gemm_bf16x3(trans, wm3, grp, bias, flags & KF_MASK, keep_prob, drop_mask, drop_seed, s));
     if (sl) {
       int64_t n = (int64_t)M * N;
       hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, s, sl, ns, M, N, C, ldc,
@@ -275,10 +314,13 @@ extern "C" int score_gemm(int32_t trans, int32_t M, int32_t N, int32_t K, const 
     grid.z = nsplit;
     slab = nsplit > 1 ? scratch : nullptr;
   }
+  GemmGroup grp;
+  grp.n = 1;
+  fill_prob(&grp.p[0], M, N, K, A, lda, Bm, ldb, C, ldc, k_chunk, slab, (int)grid.x, (int)grid.y, (int)grid.z);
+  grp.total_blocks = (grp.p[0].nblocks + 7) & ~7;
 #define LAUNCH(TR, WMv, WNv)                                                                                       \
-  hipLaunchKernelGGL((gemm_f32_kernel<TR, WMv, WNv, 16>), dim3(grid.x * grid.y * grid.z), dim3(256), 0, s, M, N, K, A, \
-                     lda, Bm, ldb, C, ldc, bias, flags, keep_prob, drop_mask, drop_seed, k_chunk, slab, (int)grid.x,  \
-                     (int)grid.y)
+  hipLaunchKernelGGL((gemm_f32_kernel<TR, WMv, WNv, 16>), dim3(grp.total_blocks), dim3(256), 0, s, grp, bias, flags, \
+                     keep_prob, drop_mask, drop_seed)
 #define LAUNCH_T(TR)                                      \
   do {                                                    \
     if (WMs == 2 && WNs == 2) LAUNCH(TR, 2, 2);           \
@@ -298,6 +340,85 @@ extern "C" int score_gemm(int32_t trans, int32_t M, int32_t N, int32_t K, const 
                        C, ldc, bias, flags, keep_prob, drop_mask, drop_seed);
     SCORE_CHECK_LAUNCH();
   }
+  return 0;
+}
+
+// ------------------------------------------------------------------ deferred weight-gradient products
+int gemm_queue_add(GemmQueue* q, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
+                   int ldc) {
+  if (!q || !A || !B || !C || M <= 0 || N <= 0 || K <= 0) return SCORE_E_BADARG;
+  if (q->n >= 2 * GEMM_GROUP_MAX) return SCORE_E_WORKSPACE;
+  GemmQueueJob& j = q->j[q->n++];
+  j.A = A; j.B = B; j.C = C; j.M = M; j.N = N; j.K = K; j.lda = lda; j.ldb = ldb; j.ldc = ldc;
+  return 0;
+}
+
+// C_j = A_j^T . B_j for every queued job: the jobs that qualify for the bf16x3 kernel go out as one grouped
+// launch of 64x128 tiles, the rest as one grouped launch of the 64x64 f32 kernel, K split so that either
+// launch fills the chip a few times over; one more launch reduces all slabs (fixed order: reproducible).
+int gemm_queue_flush(GemmQueue* q, int x3, float* slab, int64_t slab_floats, hipStream_t s) {
+  if (!q || q->n == 0) return 0;
+  if (!slab) return SCORE_E_BADARG;
+  GemmGroup g3, gf;
+  g3.n = gf.n = 0; g3.total_blocks = gf.total_blocks = 0;
+  int fam[2 * GEMM_GROUP_MAX];
+  int64_t work[2] = {0, 0};          // sum over jobs of tiles * K, per family (0 = f32, 1 = bf16x3)
+  for (int i = 0; i < q->n; ++i) {
+    const GemmQueueJob& j = q->j[i];
+    const bool al = (j.lda & 3) == 0 && (j.ldb & 3) == 0 && (reinterpret_cast<uintptr_t>(j.A) & 15) == 0 &&
+                    (reinterpret_cast<uintptr_t>(j.B) & 15) == 0 && (j.M & 3) == 0 && (j.N & 3) == 0;
+    fam[i] = (x3 && al && j.M >= 64 && j.N >= 32 && (int64_t)j.M * j.N >= 32768 && j.K >= 4096) ? 1 : 0;
+    const int64_t tiles = fam[i] ? (int64_t)((j.M + 63) / 64) * ((j.N + 127) / 128)
+                                 : (int64_t)((j.M + 63) / 64) * ((j.N + 63) / 64);
+    work[fam[i]] += tiles * j.K;
+  }
+  // K chunk per family: ~768 (bf16x3, three 64x128 blocks per CU) / ~1024 (f32) blocks in flight
+  int kc[2];
+  kc[1] = (int)align_up64(cdiv64(work[1] > 0 ? work[1] : 1, 768), 32);
+  if (kc[1] < 256) kc[1] = 256;
+  kc[0] = (int)align_up64(cdiv64(work[0] > 0 ? work[0] : 1, 1024), BK_ALIGN);
+  if (kc[0] < 128) kc[0] = 128;
+  ReduceGroup rg;
+  rg.n = 0;
+  int rblocks = 0;
+  int64_t used = 0;
+  for (int i = 0; i < q->n; ++i) {
+    const GemmQueueJob& j = q->j[i];
+    GemmGroup& g = fam[i] ? g3 : gf;
+    if (g.n >= GEMM_GROUP_MAX) return SCORE_E_WORKSPACE;
+    const int gx = fam[i] ? (j.N + 127) / 128 : (j.N + 63) / 64, gy = (j.M + 63) / 64;
+    int chunk = kc[fam[i]];
+    int ns = (int)cdiv64(j.K, chunk);
+    const int64_t mn = (int64_t)j.M * j.N;
+    while (ns > 1 && used + (int64_t)ns * mn > slab_floats) {   // not enough slab room: longer chunks
+      chunk *= 2;
+      ns = (int)cdiv64(j.K, chunk);
+    }
+    float* sl = nullptr;
+    if (ns > 1) {
+      sl = slab + used;
+      used += align_up64((int64_t)ns * mn, 4);
+      ReduceJob& r = rg.j[rg.n++];
+      r.slab = sl; r.C = j.C; r.ns = ns; r.M = j.M; r.N = j.N; r.ldc = j.ldc; r.first_block = rblocks; r.pad = 0;
+      rblocks += (int)cdiv64(mn, 256);
+    } else {
+      chunk = j.K;
+    }
+    fill_prob(&g.p[g.n], j.M, j.N, j.K, j.A, j.lda, j.B, j.ldb, j.C, j.ldc, chunk, sl, gx, gy, ns);
+    g.total_blocks += (g.p[g.n].nblocks + 7) & ~7;
+    ++g.n;
+  }
+  if (g3.n) SCORE_TRY(score_launch_gemm_bf16x3(2, 1, g3, nullptr, 0, 1.f, nullptr, 0, s));
+  if (gf.n) {
+    hipLaunchKernelGGL((gemm_f32_kernel<2, 1, 1, 16>), dim3(gf.total_blocks), dim3(256), 0, s, gf, nullptr, 0, 1.f, nullptr,
+                       0);
+    SCORE_CHECK_LAUNCH();
+  }
+  if (rg.n) {
+    hipLaunchKernelGGL(splitk_reduce_group_kernel, dim3(rblocks), dim3(256), 0, s, rg);
+    SCORE_CHECK_LAUNCH();
+  }
+  q->n = 0;
   return 0;
 }
 

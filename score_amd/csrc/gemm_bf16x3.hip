@@ -58,13 +58,19 @@ __device__ __forceinline__ uint32_t pack2(uint32_t a, uint32_t b) { return __bui
 
 // WM = 32-row MFMA tiles per wave along M: block tile (64*WM) x 128
 template <int TRANS, int WM>
-__global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(int M, int N, int K, const float* __restrict__ A, int lda,
-                                                             const float* __restrict__ Bm, int ldb,
-                                                             float* __restrict__ C, int ldc,
-                                                             const float* __restrict__ bias, int flags, float keep,
-                                                             const uint8_t* __restrict__ mask, uint64_t seed,
-                                                             int k_chunk, float* __restrict__ slab, int gx,
-                                                             int gy) {
+__global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(const GemmGroup grp, const float* __restrict__ bias, int flags,
+                                                             float keep, const uint8_t* __restrict__ mask,
+                                                             uint64_t seed) {
+  // this workgroup's problem and its index inside it
+  int pi = 0, local = (int)blockIdx.x;
+  while (pi + 1 < grp.n && local >= ((grp.p[pi].nblocks + 7) & ~7)) { local -= (grp.p[pi].nblocks + 7) & ~7; ++pi; }
+  const GemmProb& pr = grp.p[pi];
+  if (local >= pr.nblocks) return;
+  const int M = pr.M, N = pr.N, K = pr.K, lda = pr.lda, ldb = pr.ldb, ldc = pr.ldc, k_chunk = pr.k_chunk;
+  const float* __restrict__ A = pr.A;
+  const float* __restrict__ Bm = pr.B;
+  float* __restrict__ C = pr.C;
+  float* __restrict__ slab = pr.slab;
   constexpr int TBM = 64 * WM;
   constexpr int EA = TBM * TBK / 256;      // A elements staged per thread (16 or 8)
   __shared__ __attribute__((aligned(16))) unsigned short Ap[3][TBM * TLD];
@@ -74,7 +80,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(int M, int N, int K
   const int wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   int bx, by, bz;
-  xcd_tile_coords(gx, gy, bx, by, bz);
+  xcd_tile_coords_n(pr.nblocks, local, pr.gx, pr.gy, bx, by, bz);
   const int bm = by * TBM, bn = bx * TBN;
   const int kbeg = bz * k_chunk;
   const int kend = min(K, kbeg + k_chunk);
@@ -337,12 +343,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(int M, int N, int K
     }
 }
 
-int score_launch_gemm_bf16x3(int trans, int wm, dim3 grid, int M, int N, int K, const float* A, int lda,
-                             const float* Bm, int ldb, float* C, int ldc, const float* bias, int flags, float keep,
-                             const uint8_t* mask, uint64_t seed, int k_chunk, float* slab, hipStream_t s) {
-#define LX(TR, WMv)                                                                                               \
-  hipLaunchKernelGGL((gemm_bf16x3_kernel<TR, WMv>), dim3(grid.x * grid.y * grid.z), dim3(256), 0, s, M, N, K, A, lda, \
-                     Bm, ldb, C, ldc, bias, flags, keep, mask, seed, k_chunk, slab, (int)grid.x, (int)grid.y)
+int score_launch_gemm_bf16x3(int trans, int wm, const GemmGroup& g, const float* bias, int flags, float keep,
+                             const uint8_t* mask, uint64_t seed, hipStream_t s) {
+#define LX(TR, WMv)                                                                                              \
+  hipLaunchKernelGGL((gemm_bf16x3_kernel<TR, WMv>), dim3(g.total_blocks), dim3(256), 0, s, g, bias, flags, keep, mask, \
+                     seed)
   if (wm == 2) {
     if (trans == 0) LX(0, 2);
     else if (trans == 1) LX(1, 2);

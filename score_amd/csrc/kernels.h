@@ -3,9 +3,26 @@
 #include "common.h"
 
 // gemm.hip / gemm_bf16x3.hip
-int score_launch_gemm_bf16x3(int trans, int wm, dim3 grid, int M, int N, int K, const float* A, int lda,
-                             const float* Bm, int ldb, float* C, int ldc, const float* bias, int flags, float keep,
-                             const uint8_t* mask, uint64_t seed, int k_chunk, float* slab, hipStream_t s);
+// One launch can carry several GEMM problems of the same operand layout and tile shape (the independent
+// weight-gradient products of a backward pass): a workgroup finds its problem from the running block count.
+// Every problem's block range starts at a multiple of 8, so (index inside the problem) % 8 still names the
+// XCD group of common.h's tile order; the padding blocks exit at once.
+#define GEMM_GROUP_MAX 16
+struct GemmProb {
+  const float* A; const float* B; float* C; float* slab;   // slab: split-K partials [gz][M][N] (null: write C)
+  int M, N, K, lda, ldb, ldc, k_chunk, gx, gy, nblocks;    // nblocks = gx*gy*gz; the launch gives it align8(nblocks)
+};
+struct GemmGroup { int n; int total_blocks; GemmProb p[GEMM_GROUP_MAX]; };
+int score_launch_gemm_bf16x3(int trans, int wm, const GemmGroup& g, const float* bias, int flags, float keep,
+                             const uint8_t* mask, uint64_t seed, hipStream_t s);
+// deferred weight-gradient products C = A^T . B (layout 2) of a backward pass: queued while the pass runs
+// (their operands must stay untouched until the flush), then issued as one grouped launch per kernel family
+// plus one launch that reduces every split-K slab.
+struct GemmQueueJob { const float* A; const float* B; float* C; int M, N, K, lda, ldb, ldc; };
+struct GemmQueue { int n; GemmQueueJob j[2 * GEMM_GROUP_MAX]; };
+int gemm_queue_add(GemmQueue* q, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
+                   int ldc);
+int gemm_queue_flush(GemmQueue* q, int x3, float* slab, int64_t slab_floats, hipStream_t s);
 #define COLSUM_MAX_JOBS 24
 struct ColsumJob { const float* X; float* out; int M, N, ld, acc, cols, rpb, nparts; int64_t part_off; };
 struct ColsumJobs { ColsumJob job[COLSUM_MAX_JOBS]; int n; int64_t part_used; };
@@ -45,7 +62,7 @@ int score_launch_target_bwd(float* grad_table, int D, int Fu, int Fi, int B, int
                             int off_ti, int off_tu, const float* query, const float* W1, const float* W2,
                             const float* dzsum1, const float* dzsum2, float* S /*[2][B]*/,
                             float* dW1, float* dB1, float* dW2, float* dB2, float* dtgt_out, float* scratch,
-                            int64_t scratch_floats, ColsumJobs* cq, hipStream_t s);
+                            int64_t scratch_floats, ColsumJobs* cq, struct GemmQueue* gq, hipStream_t s);
 // head.hip
 int score_launch_attn_build_inp(int B, int T, int H, int NI, const float* q, const float* ur, const float* ir,
                                 const float* info, float* inp, hipStream_t s);
