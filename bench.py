@@ -191,7 +191,8 @@ def main():
         "bwd_head": avg(lambda s: s[1][0].elapsed_time(s[1][1])),
         "bwd_attention": avg(lambda s: s[1][1].elapsed_time(s[1][2])),
         "bwd_gru": avg(lambda s: s[1][2].elapsed_time(s[1][3])),
-        "bwd_coattn_scatter_wgrads": avg(lambda s: s[1][3].elapsed_time(s[1][4])),
+        "bwd_coattn_scatter": avg(lambda s: s[1][3].elapsed_time(s[1][4])),
+        "bwd_weight_grads": avg(lambda s: s[1][4].elapsed_time(s[1][5])),
         "adam_table_and_dense": avg(lambda s: s[2].elapsed_time(s[3])),
     }
     ab, R = alg_bytes_per_sample(T, K, D, Fu, Fi)
@@ -253,9 +254,9 @@ def main():
                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": adam_bytes / (stages["adam_table_and_dense"] * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "coattn_bwd + scatter (R*(4+4D) per sample)": {
-                "bound": "hbm", "achieved": scat_bytes / (stages["bwd_coattn_scatter_wgrads"] * 1e-3) / 1e9,
+                "bound": "hbm", "achieved": scat_bytes / (stages["bwd_coattn_scatter"] * 1e-3) / 1e9,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": scat_bytes / (stages["bwd_coattn_scatter_wgrads"] * 1e-3) / 1e9 / HBM_PEAK_GBS}},
+                "frac": scat_bytes / (stages["bwd_coattn_scatter"] * 1e-3) / 1e9 / HBM_PEAK_GBS}},
         "stages_ms": stages,
     }
     if world_size == 1 and not args.no_cpu_baseline:

@@ -238,10 +238,12 @@ int score_forward(const score_config_t* cfg, const score_state_t* st, const scor
                   void* stream);
 
 /* Backward of the same graph: grad_w [n_floats] (overwritten; WITHOUT the L2
- * term, which score_adam adds) and grad_table [n_table_rows, D] (must be zeroed
- * by the caller; accumulated into).  Must follow score_forward on the same
- * workspace/batch.  stage_events as above: [0] start, [1] after the head, [2] after the
- * temporal attention, [3] after the GRUs, [4] after the co-attention/embedding scatter. */
+ * term, which score_adam adds) and grad_table [n_table_rows, D] (scatter_mode 1: zeroed by
+ * the caller, accumulated into; modes 0/2: the rows of the batch are overwritten, see
+ * score_state_t.row_flags).  Must follow score_forward on the same workspace/batch.
+ * stage_events: null, or SIX handles: [0] start, [1] after the head, [2] after the temporal
+ * attention, [3] after the GRUs, [4] after the co-attention/embedding scatter, [5] after the
+ * weight-gradient products (all X^T dY of the pass run here, as grouped launches). */
 int score_backward(const score_config_t* cfg, const score_state_t* st, const score_batch_t* batch,
                    float keep_prob, float* grad_w, float* grad_table, void* const* stage_events,
                    void* stream);

@@ -178,7 +178,7 @@ void build_ws(const Dims& d, int B, WS* w) {
   w->scratch = take(w->scratch_floats);
   w->ca_slab_floats = 2 * 512 * 2 * (int64_t)(d.Di > d.Du ? d.Di : d.Du);
   w->ca_slab = take(w->ca_slab_floats);
-  w->cs_part_floats = 1 << 20;
+  w->cs_part_floats = 1 << 21;
   w->cs_part = take(w->cs_part_floats);
   w->wxcat = take(2 * (int64_t)(d.I + 1) * 3 * d.H);
   w->dwxcat = take(2 * (int64_t)d.I * 3 * d.H);
@@ -603,12 +603,13 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
     }
     G(score_launch_pull(pa, keys_out, vals_out, w.n_occ + 1, grad_table, ws + w.partials, w.partial_floats, s));
   }
+  EV(4);
   // every weight-gradient product of the pass, then the gradients assembled from them
   G(gemm_queue_flush(&gq, x3 != 0, ws + w.dwslab, w.dwslab_floats, s));
   if (d.attn) G(score_launch_attn_w1_grad(d.Dk, AT1, ws + w.dweff, ws + w.dwq, gw + P.at_w[1], s));
   for (int sd = 0; sd < 2; ++sd)
     G(score_launch_gru_wxsplit(ws + w.dwxcat + (int64_t)sd * d.I * 3 * H, d.I, H, gw + P.gk[sd], gw + P.ck[sd], s));
   G(colsum_queue_flush(&cq, ws + w.cs_part, w.cs_part_floats, s));
-  EV(4);
+  EV(5);
   return 0;
 }

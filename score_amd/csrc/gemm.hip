@@ -10,6 +10,10 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define BK_ALIGN 32   // split-K chunks are multiples of this
+#ifndef GEMM_SPLITK_MIN_K
+#define GEMM_SPLITK_MIN_K 512       // f32 kernel: split the reduced dimension only from this K on ...
+#define GEMM_SPLITK_MIN_CHUNK 128   // ... and never into chunks shorter than this (tools/gemm_small_ab.py)
+#endif
 
 enum { F_BIAS = 1, F_RELU = 2, F_ACC = 4, F_DROP = 8, F_X3 = 16 };
 #define KF_MASK (15 | 0x7FFF0000)   // what the kernels see: epilogue bits + the bias row group
@@ -291,7 +295,7 @@ extern "C" int score_gemm(int32_t trans, int32_t M, int32_t N, int32_t K, const 
   int WMs = 1, WNs = 1;
   auto nblocks = [&](int wm_, int wn_) { return (int64_t)((N + 64 * wn_ - 1) / (64 * wn_)) * ((M + 64 * wm_ - 1) / (64 * wm_)); };
   const int64_t want = 384;
-  const int64_t ksplit_cap = (K >= 512 && scratch) ? K / 128 : 1;
+  const int64_t ksplit_cap = (K >= GEMM_SPLITK_MIN_K && scratch) ? K / GEMM_SPLITK_MIN_CHUNK : 1;
   if (N > 64 && nblocks(1, 2) * ksplit_cap >= want) WNs = 2;
   if (M > 64 && nblocks(2, WNs) * ksplit_cap >= want) WMs = 2;
   const int BMh = 64 * WMs, BNh = 64 * WNs;
@@ -299,9 +303,9 @@ extern "C" int score_gemm(int32_t trans, int32_t M, int32_t N, int32_t K, const 
   // split the reduced dimension when the output grid alone cannot fill 256 CUs
   int nsplit = 1;
   int64_t tiles = (int64_t)grid.x * grid.y;
-  if (tiles < 256 && K >= 512 && scratch) {
+  if (tiles < 256 && K >= GEMM_SPLITK_MIN_K && scratch) {
     nsplit = (int)((320 + tiles - 1) / tiles);   // ~1.25 blocks per CU: longer K chunks, smaller slabs
-    int max_split = K / 128;
+    int max_split = K / GEMM_SPLITK_MIN_CHUNK;
     if (nsplit > max_split) nsplit = max_split;
     while (nsplit > 1 && (int64_t)nsplit * M * N > scratch_floats) --nsplit;
     if (nsplit < 1) nsplit = 1;
@@ -478,8 +482,19 @@ __global__ __launch_bounds__(256) void colsum_multi_stage1(const ColsumJobs jobs
   const int n = blockIdx.x * cols + tx;
   const int m0 = blockIdx.y * j.rpb, m1 = min(j.M, m0 + j.rpb);
   float s = 0.f;
-  if (n < j.N)
-    for (int m = m0 + ty; m < m1; m += nty) s += j.X[(int64_t)m * j.ld + n];
+  if (n < j.N) {
+    // four rows in flight per thread; the order of the adds is fixed by (rpb, nty): reproducible
+    const float* x = j.X + n;
+    int m = m0 + ty;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (; m + 3 * nty < m1; m += 4 * nty) {
+      const float v0 = x[(int64_t)m * j.ld], v1 = x[(int64_t)(m + nty) * j.ld];
+      const float v2 = x[(int64_t)(m + 2 * nty) * j.ld], v3 = x[(int64_t)(m + 3 * nty) * j.ld];
+      s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+    }
+    for (; m < m1; m += nty) s0 += x[(int64_t)m * j.ld];
+    s = (s0 + s1) + (s2 + s3);
+  }
   sh[threadIdx.x] = s;
   __syncthreads();
   if (ty == 0 && n < j.N) {
@@ -492,8 +507,17 @@ __global__ void colsum_multi_stage2(const ColsumJobs jobs, const float* __restri
   const ColsumJob& j = jobs.job[blockIdx.y];
   int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= j.N) return;
+  const float* p0 = part + j.part_off + n;
   float s = 0.f;
-  for (int p = 0; p < j.nparts; ++p) s += part[j.part_off + (int64_t)p * j.N + n];
+  int p = 0;
+  for (; p + 8 <= j.nparts; p += 8) {   // 8 loads in flight, summed in part order
+    float v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = p0[(int64_t)(p + q) * j.N];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s += v[q];
+  }
+  for (; p < j.nparts; ++p) s += p0[(int64_t)p * j.N];
   j.out[n] = j.acc ? j.out[n] + s : s;
 }
 
@@ -504,8 +528,11 @@ int colsum_queue_add(ColsumJobs* q, const float* X, int M, int N, int ld, float*
   int cols = 1;
   while (cols < N && cols < 64) cols <<= 1;
   j.cols = cols;
-  int rpb = 128, nparts = (M + rpb - 1) / rpb;
-  if (nparts > 32) { nparts = 32; rpb = (M + nparts - 1) / nparts; nparts = (M + rpb - 1) / rpb; }
+  // up to COLSUM_MAX_PARTS row slices per job: a [B*T, 3H] bias gradient alone then fills the chip
+  int rpb = 64, nparts = (M + rpb - 1) / rpb;
+  if (nparts > COLSUM_MAX_PARTS) {
+    nparts = COLSUM_MAX_PARTS; rpb = (M + nparts - 1) / nparts; nparts = (M + rpb - 1) / rpb;
+  }
   j.rpb = rpb; j.nparts = nparts;
   j.part_off = q->part_used;
   q->part_used += (int64_t)nparts * N;
@@ -520,7 +547,7 @@ int colsum_queue_flush(ColsumJobs* q, float* part, int64_t part_floats, hipStrea
     gx = max(gx, (q->job[i].N + q->job[i].cols - 1) / q->job[i].cols);
     gx2 = max(gx2, (q->job[i].N + 63) / 64);
   }
-  hipLaunchKernelGGL(colsum_multi_stage1, dim3(gx, 32, q->n), dim3(256), 0, s, *q, part);
+  hipLaunchKernelGGL(colsum_multi_stage1, dim3(gx, COLSUM_MAX_PARTS, q->n), dim3(256), 0, s, *q, part);
   SCORE_CHECK_LAUNCH();
   hipLaunchKernelGGL(colsum_multi_stage2, dim3(gx2, q->n), dim3(64), 0, s, *q, part);
   SCORE_CHECK_LAUNCH();

@@ -145,41 +145,39 @@ int score_launch_attn_pool_fwd(int B, int T, int H, int NA, const float* a2, con
   return 0;
 }
 
-// backward of the pooling + masked softmax + fc3:  one wave per sample
+// backward of the pooling + masked softmax + fc3:  one block per sample, the T slices side by side
 //   dscore_t = duf.ur_t + dif.ir_t ; ds_t = score_t (dscore_t - sum score*dscore) [t < len]
 //   da2[t][n] = ds_t * w5[n] * [a2 > 0]
 __global__ __launch_bounds__(256) void attn_pool_bwd_kernel(
-    int B, int T, int H, int NA, const float* __restrict__ a2, const float* __restrict__ w5,
+    int B, int T, int H, int NA, int LPT, const float* __restrict__ a2, const float* __restrict__ w5,
     const int32_t* __restrict__ length, const float* __restrict__ ur, const float* __restrict__ ir,
     const float* __restrict__ score, const float* __restrict__ dhead, int ldh, int off_u, int off_i,
     float* __restrict__ ds, float* __restrict__ da2) {
-  const int lane = threadIdx.x & 63;
-  const int b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  if (b >= B) return;
+  extern __shared__ float sd[];   // [T] dscore
+  const int b = blockIdx.x;
   const int len = length[b];
-  // every lane ends up with every dscore_t (wave_sum broadcasts), so nothing crosses lanes via memory
-  float tot = 0.f;
-  for (int t = 0; t < T; ++t) {
+  const int gl = threadIdx.x % LPT;          // LPT lanes (a power of two <= 64) share one slice
+  const float* du = off_u >= 0 ? dhead + (int64_t)b * ldh + off_u : nullptr;
+  const float* di = off_i >= 0 ? dhead + (int64_t)b * ldh + off_i : nullptr;
+  for (int t = threadIdx.x / LPT; t < T; t += 256 / LPT) {
+    const int64_t bt = (int64_t)b * T + t;
     float part = 0.f;
-    for (int j = lane; j < H; j += 64) {
-      if (off_u >= 0) part = fmaf(dhead[(int64_t)b * ldh + off_u + j], ur[((int64_t)b * T + t) * H + j], part);
-      if (off_i >= 0) part = fmaf(dhead[(int64_t)b * ldh + off_i + j], ir[((int64_t)b * T + t) * H + j], part);
+    for (int j = gl; j < H; j += LPT) {
+      if (du) part = fmaf(du[j], ur[bt * H + j], part);
+      if (di) part = fmaf(di[j], ir[bt * H + j], part);
     }
-    tot = fmaf(score[(int64_t)b * T + t], wave_sum(part), tot);
+    part = group_sum(part, LPT);
+    if (gl == 0) sd[t] = part;
   }
-  for (int t = 0; t < T; ++t) {
-    float part = 0.f;
-    for (int j = lane; j < H; j += 64) {
-      if (off_u >= 0) part = fmaf(dhead[(int64_t)b * ldh + off_u + j], ur[((int64_t)b * T + t) * H + j], part);
-      if (off_i >= 0) part = fmaf(dhead[(int64_t)b * ldh + off_i + j], ir[((int64_t)b * T + t) * H + j], part);
-    }
-    float dsc = wave_sum(part);
-    float g = t < len ? score[(int64_t)b * T + t] * (dsc - tot) : 0.f;
-    for (int n = lane; n < NA; n += 64) {
-      float a = a2[((int64_t)b * T + t) * NA + n];
-      da2[((int64_t)b * T + t) * NA + n] = a > 0.f ? g * w5[n] : 0.f;
-    }
-    if (lane == 0) ds[(int64_t)b * T + t] = g;
+  __syncthreads();
+  float tot = 0.f;
+  for (int t = 0; t < T; ++t) tot = fmaf(score[(int64_t)b * T + t], sd[t], tot);
+  for (int i = threadIdx.x; i < T * NA; i += 256) {
+    const int t = i / NA, n = i - t * NA;
+    const int64_t bt = (int64_t)b * T + t;
+    const float g = t < len ? score[bt] * (sd[t] - tot) : 0.f;
+    da2[bt * NA + n] = a2[bt * NA + n] > 0.f ? g * w5[n] : 0.f;
+    if (n == 0) ds[bt] = g;
   }
 }
 
@@ -187,8 +185,10 @@ int score_launch_attn_pool_bwd(int B, int T, int H, int NA, const float* a2, con
                                const int32_t* length, const float* ur, const float* ir, const float* score,
                                const float* dhead, int ldh, int off_u, int off_i, float* ds, float* da2,
                                hipStream_t s) {
-  hipLaunchKernelGGL(attn_pool_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, s, B, T, H, NA, a2, w5, length, ur, ir,
-                     score, dhead, ldh, off_u, off_i, ds, da2);
+  int LPT = 64;
+  while (LPT > 1 && 256 / LPT < T) LPT >>= 1;      // as many slices side by side as the block holds
+  hipLaunchKernelGGL(attn_pool_bwd_kernel, dim3(B), dim3(256), (size_t)T * sizeof(float), s, B, T, H, NA, LPT, a2, w5,
+                     length, ur, ir, score, dhead, ldh, off_u, off_i, ds, da2);
   SCORE_CHECK_LAUNCH();
   return 0;
 }

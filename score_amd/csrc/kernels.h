@@ -24,6 +24,7 @@ int gemm_queue_add(GemmQueue* q, int M, int N, int K, const float* A, int lda, c
                    int ldc);
 int gemm_queue_flush(GemmQueue* q, int x3, float* slab, int64_t slab_floats, hipStream_t s);
 #define COLSUM_MAX_JOBS 24
+#define COLSUM_MAX_PARTS 128
 struct ColsumJob { const float* X; float* out; int M, N, ld, acc, cols, rpb, nparts; int64_t part_off; };
 struct ColsumJobs { ColsumJob job[COLSUM_MAX_JOBS]; int n; int64_t part_used; };
 // deferred column sums: queue jobs during a pass, run them all in two launches at its end.

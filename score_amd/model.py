@@ -205,10 +205,10 @@ class SCOREBASE(object):
 
     @staticmethod
     def _event_array(events):
-        """5 torch.cuda.Event (timing enabled, already recorded once) -> hipEvent_t[5], or NULL."""
+        """torch.cuda.Events (timing enabled, already recorded once) -> hipEvent_t[], or NULL."""
         if not events:
             return None
-        return (C.c_void_p * 5)(*[C.c_void_p(e.cuda_event) for e in events])
+        return (C.c_void_p * len(events))(*[C.c_void_p(e.cuda_event) for e in events])
 
     def enable_stage_events(self, on=True):
         """Record stage-boundary events inside score_forward/backward (bench.py's live
@@ -216,8 +216,8 @@ class SCOREBASE(object):
         if not on:
             self.fwd_events = self.bwd_events = None
             return
-        mk = lambda: [torch.cuda.Event(enable_timing=True) for _ in range(5)]
-        self.fwd_events, self.bwd_events = mk(), mk()
+        mk = lambda n: [torch.cuda.Event(enable_timing=True) for _ in range(n)]
+        self.fwd_events, self.bwd_events = mk(5), mk(6)
         for e in self.fwd_events + self.bwd_events:
             e.record()          # forces creation of the underlying hipEvent_t
 
