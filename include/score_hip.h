@@ -225,6 +225,14 @@ int score_segment_sum_rows(const int32_t* rows, const float* src, int64_t n, int
                            float* out, uint8_t* row_flags, void* scratch, int64_t scratch_bytes, void* stream);
 int64_t score_segment_sum_scratch_bytes(int64_t n, int32_t D);
 
+/* The owner's usual way to combine the row gradients it receives: one call per source rank, in rank
+ * order, each with that rank's rows (unique inside a call -- they come from score_index_plan's
+ * de-duplication) and gradients.  The first writer of a row this step stores, later ones add:
+ * out[rows[i], :] (+)= src[i, :], reproducible without a sort or an atomic.  row_flags (required):
+ * rows already in state 2 are added to, every row touched ends in state 2 (score_adam_rows). */
+int score_rows_accumulate(const int32_t* rows, const float* src, int64_t n, int32_t D, int64_t n_out_rows,
+                          float* out, uint8_t* row_flags, void* stream);
+
 /* Forward of SCORE / RIA / RCA / SCORE_USER / SCORE_ITEM (score.py:188-369) +
  * build_fc_net / build_logloss / build_l2norm (:68-94).  keep_prob 1.0 = eval
  * (score.py:129), 0.8 = train (:113).  Results land in the workspace

@@ -375,6 +375,39 @@ extern "C" int score_segment_sum_rows(const int32_t* rows, const float* src, int
   return score_launch_pull(pa, keys_out, vals_out, n, out, partials, partial_floats, s);
 }
 
+// out[rows[i]] (+)= src[i] for one source's row list (rows unique inside the call): the first writer of a
+// row this step stores, later ones add -- called once per source rank in rank order, the sum is reproducible
+// without a sort or an atomic.  Marks every row it touches (state 2, see score_adam_rows).
+__global__ __launch_bounds__(256) void rows_accumulate_kernel(const int32_t* __restrict__ rows,
+                                                              const float* __restrict__ src, int64_t n, int D,
+                                                              int LPR, float* __restrict__ out,
+                                                              uint8_t* __restrict__ flags) {
+  const int gpb = blockDim.x / LPR;
+  const int64_t i = (int64_t)blockIdx.x * gpb + threadIdx.x / LPR;
+  const int ch4 = (threadIdx.x % LPR) * 4;
+  if (i >= n || ch4 >= D) return;
+  const int64_t r = rows[i];
+  const uint8_t f = flags[r];
+  float4 v = ld4(src + i * D + ch4);
+  if (f == 2) v = add4(ld4(out + r * D + ch4), v);
+  st4(out + r * D + ch4, v);
+  if (ch4 == 0 && f != 2) flags[r] = 2;   // (the group's lanes sit in one wave: all of them read f above)
+}
+
+extern "C" int score_rows_accumulate(const int32_t* rows, const float* src, int64_t n, int32_t D, int64_t n_out_rows,
+                                     float* out, uint8_t* row_flags, void* stream) {
+  if (!rows || !src || !out || !row_flags || n < 0 || D <= 0 || (D & 3) || D > 256 || n_out_rows <= 0)
+    return SCORE_E_BADARG;
+  if (n == 0) return 0;
+  int LPR = 1;
+  while (LPR < D / 4) LPR <<= 1;
+  const int gpb = 256 / LPR;
+  hipLaunchKernelGGL(rows_accumulate_kernel, dim3((unsigned)cdiv64(n, gpb)), dim3(256), 0, (hipStream_t)stream, rows,
+                     src, n, D, LPR, out, row_flags);
+  SCORE_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int64_t score_segment_sum_scratch_bytes(int64_t n, int32_t D) {
   size_t sort_bytes = 0;
   if (score_plan_temp_bytes(n > 0 ? n : 1, 32, &sort_bytes) != 0) return -1;

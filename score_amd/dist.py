@@ -139,14 +139,26 @@ class HipBackend(object):
         self._scratch = None
 
     # -- index plan ---------------------------------------------------------------------
-    def plan(self, batch_data, slot=0):
+    def plan_launch(self, batch_data, slot=0):
+        """Enqueue the index plan on the current stream and start the read-back of its sizes; no host wait."""
         m = self.m
         db = m.device_batch(batch_data)
         lay, ws = m._workspace(db.B, slot)
         st = m._state(ws)
         _lib.check(self.lib.score_index_plan(C.byref(m.cfg), C.byref(st), C.byref(db.struct), self.world, 1,
                                              m._stream()), "score_index_plan")
-        meta = _to_host(ws[lay.plan_meta:lay.plan_meta + 2 + self.world].view(torch.int32)).tolist()   # sync
+        meta = ws[lay.plan_meta:lay.plan_meta + 2 + self.world].view(torch.int32)
+        host = torch.empty(meta.shape, dtype=meta.dtype, pin_memory=True)
+        host.copy_(meta, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        return dict(db=db, lay=lay, ws=ws, host=host, event=ev, slot=slot)
+
+    def plan_finish(self, h):
+        """Wait for the plan's sizes (that event only) and build the plan record."""
+        h["event"].synchronize()
+        db, lay, ws = h["db"], h["lay"], h["ws"]
+        meta = h["host"].tolist()
         U, offs = meta[0], meta[1:2 + self.world]
         uniq = ws[lay.plan_unique_rows:lay.plan_unique_rows + U].view(torch.int32)
         # batch struct over the remapped (unique-position) index tensors
@@ -156,7 +168,11 @@ class HipBackend(object):
         # plan order: user_1hop, item_2hop, user_2hop, item_1hop, target_user, target_item
         remapped = _lib.Batch(_ptr(rm[0]), _ptr(rm[2]), _ptr(rm[3]), _ptr(rm[1]), _ptr(rm[4]), _ptr(rm[5]),
                               _ptr(db.tensors[6]), _ptr(db.tensors[7]), db.B)
-        return dict(db=db, remapped=remapped, keep=rm, U=U, offsets=offs, unique_rows=uniq, slot=slot)
+        return dict(db=db, remapped=remapped, keep=rm, U=U, offsets=offs, unique_rows=uniq, slot=h["slot"],
+                    event=h["event"])
+
+    def plan(self, batch_data, slot=0):
+        return self.plan_finish(self.plan_launch(batch_data, slot))
 
     def gather(self, req_rows):
         n = req_rows.numel()
@@ -196,20 +212,25 @@ class HipBackend(object):
         _lib.check(rc, "score_backward")
         return mini_g
 
-    def accumulate(self, req_rows, grads_in):
+    def accumulate(self, req_rows, grads_in, counts=None):
+        """Combine the row gradients received from every rank into this shard's table gradient.
+        counts[p] = rows rank p asked for (its slice of req_rows, unique inside the slice): one
+        score_rows_accumulate per rank, in rank order -- no sort, no atomics, reproducible."""
         m = self.m
-        # no zero fill: the segment sum marks the shard rows it writes (state 2) and score_adam_rows
-        # reads gradient rows in that state only
+        # no zero fill: rows are marked (state 2) as they are written and score_adam_rows reads
+        # gradient rows in that state only
         m._begin_row_grads()
-        n = req_rows.numel()
-        if n:
-            need = int(self.lib.score_segment_sum_scratch_bytes(n, self.D))
-            if self._scratch is None or self._scratch.numel() < need:
-                self._scratch = torch.empty((need,), dtype=torch.uint8, device=self.device)
-            rc = self.lib.score_segment_sum_rows(_ptr(req_rows), _ptr(grads_in), n, self.D, m.table.shape[0],
-                                                 _ptr(m.table_g), _ptr(m.table_flags), _ptr(self._scratch),
-                                                 self._scratch.numel(), m._stream())
-            _lib.check(rc, "score_segment_sum_rows")
+        if counts is None:
+            counts = [req_rows.numel()]
+        off = 0
+        for c in counts:
+            c = int(c)
+            if c:
+                rc = self.lib.score_rows_accumulate(_ptr(req_rows[off:off + c]), _ptr(grads_in[off:off + c]), c,
+                                                    self.D, m.table.shape[0], _ptr(m.table_g), _ptr(m.table_flags),
+                                                    m._stream())
+                _lib.check(rc, "score_rows_accumulate")
+            off += c
 
     def dense_grad(self):
         return self.m.w_g
@@ -260,12 +281,9 @@ class ShardedSCORE(object):
                           lambda self, v: setattr(self.backend.m, "bwd_events", v))
 
     # -- step phases -----------------------------------------------------------------------
-    def _plan_and_request(self, batch_data, slot=0, cm=None):
-        """Index-only phase (needs no parameters): plan the batch, tell every owner which of its
-        rows this rank needs."""
-        be = self.backend
+    def _request(self, plan, cm=None):
+        """Tell every owner which of its rows this rank needs (two small collectives)."""
         cm = cm if cm is not None else self.comm
-        plan = be.plan(batch_data, slot) if slot else be.plan(batch_data)
         offs = plan["offsets"]
         send = [offs[o + 1] - offs[o] for o in range(self.world)]      # unique rows I need from shard o
         recv = cm.exchange_counts(send, self.device)                    # rows shard-me must serve to rank p
@@ -273,6 +291,12 @@ class ShardedSCORE(object):
         cm.all_to_all(req, plan["unique_rows"], recv, send)
         plan.update(send=send, recv=recv, req=req)
         return plan
+
+    def _plan_and_request(self, batch_data, slot=0, cm=None):
+        """Index-only phase (needs no parameters): plan the batch, then request its rows."""
+        be = self.backend
+        plan = be.plan(batch_data, slot) if slot else be.plan(batch_data)
+        return self._request(plan, cm)
 
     def _rows(self, plan):
         """Parameter phase: owners gather the requested rows from their (up-to-date) shard."""
@@ -283,14 +307,19 @@ class ShardedSCORE(object):
         return mini
 
     def prefetch(self, batch_data):
-        """Index-only phase of the NEXT batch, on a high-priority side stream.  Called right after this
-        step's row fetch has been enqueued and BEFORE its forward/backward are (forward_backward(...,
-        next_batch=) does that): on the communicator's stream the two small collectives then sit between
-        this step's row exchange and its gradient exchange, the host blocks on the side stream only while
-        the GPU still works on the previous step, and three workspace slots keep the plan buffers of the
-        steps in flight apart.  Every rank must call it, with its own next batch."""
-        if self.device.type != "cuda":
-            self._prefetched = (batch_data, self._plan_and_request(batch_data, 0), None)
+        """Index-only phase of the NEXT batch in one call (plan, then request its rows); see
+        _prefetch_launch / _prefetch_finish for how forward_backward(..., next_batch=) splits it around
+        this step's compute.  Every rank must call it, with its own next batch."""
+        self._prefetch_launch(batch_data)
+        self._prefetch_finish()
+
+    def _prefetch_launch(self, batch_data):
+        """Start the next batch's index plan on a high-priority side stream; returns at once.  Called
+        BEFORE this step's forward/backward are enqueued, so the plan's kernels run under them.  Three
+        workspace slots keep the plan buffers of the steps in flight apart."""
+        be = self.backend
+        if self.device.type != "cuda" or not hasattr(be, "plan_launch"):
+            self._prefetched = (batch_data, None, None, None)
             return
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.device, priority=-1)
@@ -298,17 +327,33 @@ class ShardedSCORE(object):
         if self._slot_done[slot] is not None:                # the step that last used this slot (t-2)
             self._side.wait_event(self._slot_done[slot])
         with torch.cuda.stream(self._side):
-            plan = self._plan_and_request(batch_data, slot)
+            handle = be.plan_launch(batch_data, slot)
+        self._prefetched = (batch_data, handle, None, None)
+
+    def _prefetch_finish(self):
+        """Read the plan's sizes and request the rows, from the side stream.  Called once this step's
+        forward/backward are enqueued and BEFORE its gradient exchange is: the plan has had the whole
+        enqueue time to run, the host wait is short and the GPU has a full queue behind it, and on the
+        communicator's stream the two small collectives sit between this step's row exchange and its
+        gradient exchange (they wait for the side stream only)."""
+        batch_data, handle, _, _ = self._prefetched
+        if handle is None:                                   # CPU test backend: nothing to overlap
+            self._prefetched = (batch_data, None, self._plan_and_request(batch_data, 0), None)
+            return
+        with torch.cuda.stream(self._side):
+            plan = self._request(self.backend.plan_finish(handle))
             ev = self._side.record_event()
-        self._prefetched = (batch_data, plan, ev)
+        self._prefetched = (batch_data, None, plan, ev)
 
     def _fetch(self, batch_data):
         """plan -> request rows from their owners -> gathered [U, D] mini-table"""
         pf = getattr(self, "_prefetched", None)
-        if pf is not None and pf[0] is batch_data:
-            plan = pf[1]
-            if pf[2] is not None:
-                torch.cuda.current_stream(self.device).wait_event(pf[2])
+        if pf is not None and pf[0] is batch_data and pf[2] is not None:
+            plan = pf[2]
+            if pf[3] is not None:
+                cur = torch.cuda.current_stream(self.device)
+                cur.wait_event(pf[3])
+                plan["req"].record_stream(cur)          # allocated on the side stream, consumed here
             self._slot = plan.get("slot", 0)
         else:
             plan = self._plan_and_request(batch_data, self._slot if self.device.type == "cuda" else 0)
@@ -323,15 +368,17 @@ class ShardedSCORE(object):
         be, cm = self.backend, self.comm
         plan, mini = self._fetch(batch_data)
         if next_batch is not None:
-            self.prefetch(next_batch)
+            self._prefetch_launch(next_batch)     # its kernels run under this step's forward
         B = plan["B"] if "B" in plan else plan["db"].B
         be.set_global_batch(B * self.world)
         fw = be.forward(plan, mini, reg_lambda, keep_prob, dropout_masks)
         mini_g = be.backward(plan, mini, fw, keep_prob)
+        if next_batch is not None:
+            self._prefetch_finish()               # sizes + row requests, ahead of this step's gradient exchange
         grads_in = torch.empty((plan["req"].numel(), self.D), dtype=torch.float32, device=self.device)
         cm.all_to_all(grads_in, mini_g, plan["recv"], plan["send"])
         cm.all_reduce_sum(be.dense_grad())
-        be.accumulate(plan["req"], grads_in)
+        be.accumulate(plan["req"], grads_in, plan["recv"])
         loss = fw["loss"].clone()          # [loss, log_loss (local share of the global mean), l2]
         cm.all_reduce_sum(loss[1:2])
         return loss, fw

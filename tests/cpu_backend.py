@@ -80,7 +80,7 @@ class CpuBackend(object):
     def dense_grad(self):
         return self._wg
 
-    def accumulate(self, req_rows, grads_in):
+    def accumulate(self, req_rows, grads_in, counts=None):
         g = torch.zeros(self.table["t"].shape, dtype=torch.float32)
         if req_rows.numel():
             g.index_add_(0, req_rows.long(), grads_in)

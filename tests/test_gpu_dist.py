@@ -129,6 +129,35 @@ def test_virtual_ranks_match_single_device(world, model_type, cfg_args, B):
         assert np.abs(np.asarray(res[r][3]) - np.asarray(pref)).max() < 1e-4
 
 
+def test_rows_accumulate_op():
+    # owner-side combine, one call per source rank in rank order: first writer stores, later ones add
+    import ctypes as C
+    from score_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(9)
+    D, R = 24, 4000
+    p = lambda t: C.c_void_p(t.data_ptr())
+    out = torch.full((R, D), 7.0, device="cuda")                     # stale contents: never read
+    flags = torch.zeros((R,), dtype=torch.uint8, device="cuda")
+    flags[::5] = 1
+    want = torch.zeros((R, D), device="cuda")
+    touched = np.zeros(R, bool)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for rank in range(3):
+        rows = rng.choice(R, 1500, replace=False).astype(np.int32)   # unique inside a rank's list
+        src = torch.from_numpy(rng.standard_normal((len(rows), D)).astype(np.float32)).cuda()
+        drows = torch.from_numpy(rows).cuda()
+        assert lib.score_rows_accumulate(p(drows), p(src), len(rows), D, R, p(out), p(flags), st) == 0
+        want[drows.long()] += src                                    # same order of adds: bitwise equal
+        touched[rows] = True
+    torch.cuda.synchronize()
+    t = torch.from_numpy(touched).cuda()
+    assert torch.equal(out[t], want[t]) and bool((out[~t] == 7.0).all())
+    wf = np.zeros(R, np.uint8); wf[::5] = 1; wf[touched] = 2
+    assert np.array_equal(flags.cpu().numpy(), wf)
+    assert lib.score_rows_accumulate(p(drows), p(src), 4, 6, R, p(out), p(flags), st) != 0   # D % 4
+
+
 def test_segment_sum_rows_op():
     import ctypes as C
     from score_amd import _lib
