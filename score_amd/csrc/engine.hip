@@ -123,7 +123,7 @@ struct WS {
   int64_t gru_out[2], gru_final[2], xproj[2], gates[2];
   int64_t q, ainp, a1, a2, bn, f1, f2, lossb, dlogit, part;
   int64_t weff, wq, qz, adzsum, dweff, dwq, dqd;   // folded first attention layer (head.hip)
-  int64_t dwslab, dwslab_floats, dgstage;          // deferred weight-gradient products (gemm.hip), bn1 dgamma staging
+  int64_t dwslab, dwslab_floats, dgstage, scratch2;          // deferred weight-gradient products (gemm.hip), bn1 dgamma staging
   // backward
   int64_t dz2, dz1, dbn, dhead, ds, da2, da1, dainp, dgru[2], dinfo, dq, dquery, dfinal[2];
   int64_t dxproj[2], rh[2], hprev[2], dxside[2], dzsum[2], S, scratch;
@@ -183,6 +183,7 @@ void build_ws(const Dims& d, int B, WS* w) {
   w->wxcat = take(2 * (int64_t)(d.I + 1) * 3 * d.H);
   w->dwxcat = take(2 * (int64_t)d.I * 3 * d.H);
   w->dgstage = take((int64_t)B * d.Dhead);
+  w->scratch2 = take(w->scratch_floats);           // split-K scratch of the side stream's products
   {
     // split-K partials of every queued weight-gradient product: ~24 slabs of each dense variable
     Params Pl;
@@ -216,6 +217,29 @@ void build_ws(const Dims& d, int B, WS* w) {
   w->partials = take(w->partial_floats);
   w->total = cur;
 }
+
+// A second stream for work that is independent of the long narrow kernels of the path: the GRU recurrences
+// occupy 128 workgroups (16 samples each at B = 1024), half the chip; the attention query branch (forward) and
+// the weight gradients already known (backward) run beside them.  One stream + two events per host thread
+// and device, created on first use; forked from / joined back into the caller's stream with events.
+struct SideStream { hipStream_t st; hipEvent_t fork, join; };
+static thread_local SideStream g_side[16];
+static int side_stream(SideStream** out) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return SCORE_E_BADARG;
+  SideStream& sd = g_side[dev];
+  if (!sd.st) {
+    hipStream_t st; hipEvent_t a, b;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return SCORE_E_BADARG;
+    if (hipEventCreateWithFlags(&a, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&b, hipEventDisableTiming) != hipSuccess)
+      return SCORE_E_BADARG;
+    sd.st = st; sd.fork = a; sd.join = b;
+  }
+  *out = &sd;
+  return 0;
+}
+#define HIPTRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return (int)e_; } while (0)
 
 #define G(call) SCORE_TRY(call)
 // every GEMM of the path goes through here: ORs in the caller's product mode (score_state_t.gemm_mode)
@@ -343,6 +367,21 @@ extern "C" int score_forward(const score_config_t* cfg, const score_state_t* st,
   // target rows -> query [tu | ti] and head_inp [.., ti, tu]      (score.py:62-66, 210, 217)
   G(score_launch_target_fwd(st->table, d.D, d.Fu, d.Fi, B, bt->target_user, bt->target_item, ws + w.query, d.Dq,
                             ws + w.head_inp, d.Dhead, d.off_ti, d.off_tu, s));
+  SideStream* sd = nullptr;
+  if (d.attn) {
+    // the attention's query branch needs the target rows and weights only: beside the gather and the GRUs
+    G(side_stream(&sd));
+    HIPTRY(hipEventRecord(sd->fork, s));
+    HIPTRY(hipStreamWaitEvent(sd->st, sd->fork, 0));
+    float* scratch2 = ws + w.scratch2;
+    G(gemm_mode_call(x3, 0, B, d.Dk, d.Dq, ws + w.query, d.Dq, W + P.at_w[0], d.Dk, ws + w.q, d.Dk, W + P.at_b[0], GF_BIAS,
+                     1.f, nullptr, 0, scratch2, w.scratch_floats, sd->st));
+    // dense_3 on [q, k, q-k, q*k], folded (head.hip): a1 = relu([k, q*k] . Weff + (q . Wq + b)[sample])
+    G(score_launch_attn_fold_w1(d.Dk, AT1, W + P.at_w[1], ws + w.weff, ws + w.wq, sd->st));
+    G(gemm_mode_call(x3, 0, B, AT1, d.Dk, ws + w.q, d.Dk, ws + w.wq, AT1, ws + w.qz, AT1, W + P.at_b[1], GF_BIAS, 1.f,
+                     nullptr, 0, scratch2, w.scratch_floats, sd->st));
+    HIPTRY(hipEventRecord(sd->join, sd->st));
+  }
   // co-attention 1: (user_1hop, item_2hop, target_item) ; 2: (user_2hop, item_1hop, target_user)  (:196-197)
   // user_side = [user_1hop_seq | user_2hop_seq], item_side = [item_1hop_seq | item_2hop_seq]   (:200-201)
   EV(0);
@@ -386,13 +425,8 @@ extern "C" int score_forward(const score_config_t* cfg, const score_state_t* st,
   }
   EV(2);
   if (d.attn) {
-    // temporal attention (:169-186, 210-215)
-    G(gemm_mode_call(x3, 0, B, d.Dk, d.Dq, ws + w.query, d.Dq, W + P.at_w[0], d.Dk, ws + w.q, d.Dk, W + P.at_b[0], GF_BIAS,
-                 1.f, nullptr, 0, scratch, w.scratch_floats, s));
-    // dense_3 on [q, k, q-k, q*k], folded (head.hip): a1 = relu([k, q*k] . Weff + (q . Wq + b)[sample])
-    G(score_launch_attn_fold_w1(d.Dk, AT1, W + P.at_w[1], ws + w.weff, ws + w.wq, s));
-    G(gemm_mode_call(x3, 0, B, AT1, d.Dk, ws + w.q, d.Dk, ws + w.wq, AT1, ws + w.qz, AT1, W + P.at_b[1], GF_BIAS, 1.f,
-                     nullptr, 0, scratch, w.scratch_floats, s));
+    // temporal attention (:169-186, 210-215); q, Weff/Wq and qz come from the side stream
+    HIPTRY(hipStreamWaitEvent(s, sd->join, 0));
     G(score_launch_attn_build_inp(B, T, H, d.NI, ws + w.q, ws + w.gru_out[0], ws + w.gru_out[1], ws + w.info,
                                   ws + w.ainp, s));
     G(gemm_mode_call(x3, 0, BT, AT1, 2 * d.Dk, ws + w.ainp, 2 * d.Dk, ws + w.weff, AT1, ws + w.a1, AT1, ws + w.qz,
@@ -521,6 +555,16 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
 
   EV(2);
   // ---- GRUs (score.py:205-208)
+  // the weight gradients queued so far (head, attention) have everything they need: beside the recurrence
+  SideStream* side = nullptr;
+  const int64_t slab_half = (w.dwslab_floats / 2) & ~(int64_t)3;
+  if (gq.n > 0) {
+    G(side_stream(&side));
+    HIPTRY(hipEventRecord(side->fork, s));
+    HIPTRY(hipStreamWaitEvent(side->st, side->fork, 0));
+    G(gemm_queue_flush(&gq, x3 != 0, ws + w.dwslab, slab_half, side->st));
+    HIPTRY(hipEventRecord(side->join, side->st));
+  }
   {
     GruArgs ga;
     memset(&ga, 0, sizeof(ga));
@@ -604,8 +648,9 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
     G(score_launch_pull(pa, keys_out, vals_out, w.n_occ + 1, grad_table, ws + w.partials, w.partial_floats, s));
   }
   EV(4);
-  // every weight-gradient product of the pass, then the gradients assembled from them
-  G(gemm_queue_flush(&gq, x3 != 0, ws + w.dwslab, w.dwslab_floats, s));
+  // the remaining weight-gradient products of the pass, then the gradients assembled from them
+  if (side) HIPTRY(hipStreamWaitEvent(s, side->join, 0));
+  G(gemm_queue_flush(&gq, x3 != 0, ws + w.dwslab + slab_half, w.dwslab_floats - slab_half, s));
   if (d.attn) G(score_launch_attn_w1_grad(d.Dk, AT1, ws + w.dweff, ws + w.dwq, gw + P.at_w[1], s));
   for (int sd = 0; sd < 2; ++sd)
     G(score_launch_gru_wxsplit(ws + w.dwxcat + (int64_t)sd * d.I * 3 * H, d.I, H, gw + P.gk[sd], gw + P.ck[sd], s));
