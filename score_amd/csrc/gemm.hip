@@ -358,7 +358,7 @@ int gemm_queue_add(GemmQueue* q, int M, int N, int K, const float* A, int lda, c
 }
 
 // C_j = A_j^T . B_j for every queued job: the jobs that qualify for the bf16x3 kernel go out as one grouped
-// launch of 64x128 tiles, the rest as one grouped launch of the 64x64 f32 kernel, K split so that either
+// launch of 128x128 tiles, the rest as one grouped launch of the 64x64 f32 kernel, K split so that either
 // launch fills the chip a few times over; one more launch reduces all slabs (fixed order: reproducible).
 int gemm_queue_flush(GemmQueue* q, int x3, float* slab, int64_t slab_floats, hipStream_t s) {
   if (!q || q->n == 0) return 0;
@@ -372,13 +372,14 @@ int gemm_queue_flush(GemmQueue* q, int x3, float* slab, int64_t slab_floats, hip
     const bool al = (j.lda & 3) == 0 && (j.ldb & 3) == 0 && (reinterpret_cast<uintptr_t>(j.A) & 15) == 0 &&
                     (reinterpret_cast<uintptr_t>(j.B) & 15) == 0 && (j.M & 3) == 0 && (j.N & 3) == 0;
     fam[i] = (x3 && al && j.M >= 64 && j.N >= 32 && (int64_t)j.M * j.N >= 32768 && j.K >= 4096) ? 1 : 0;
-    const int64_t tiles = fam[i] ? (int64_t)((j.M + 63) / 64) * ((j.N + 127) / 128)
+    const int64_t tiles = fam[i] ? (int64_t)((j.M + 127) / 128) * ((j.N + 127) / 128)
                                  : (int64_t)((j.M + 63) / 64) * ((j.N + 63) / 64);
     work[fam[i]] += tiles * j.K;
   }
-  // K chunk per family: ~768 (bf16x3, three 64x128 blocks per CU) / ~1024 (f32) blocks in flight
+  // K chunk per family: ~512 (bf16x3, two 128x128 blocks per CU: both operands stream, so the larger tile
+  // halves the bytes pulled through L2 per flop) / ~1024 (f32) blocks in flight
   int kc[2];
-  kc[1] = (int)align_up64(cdiv64(work[1] > 0 ? work[1] : 1, 768), 32);
+  kc[1] = (int)align_up64(cdiv64(work[1] > 0 ? work[1] : 1, 512), 32);
   if (kc[1] < 256) kc[1] = 256;
   kc[0] = (int)align_up64(cdiv64(work[0] > 0 ? work[0] : 1, 1024), BK_ALIGN);
   if (kc[0] < 128) kc[0] = 128;
@@ -390,7 +391,7 @@ int gemm_queue_flush(GemmQueue* q, int x3, float* slab, int64_t slab_floats, hip
     const GemmQueueJob& j = q->j[i];
     GemmGroup& g = fam[i] ? g3 : gf;
     if (g.n >= GEMM_GROUP_MAX) return SCORE_E_WORKSPACE;
-    const int gx = fam[i] ? (j.N + 127) / 128 : (j.N + 63) / 64, gy = (j.M + 63) / 64;
+    const int gx = fam[i] ? (j.N + 127) / 128 : (j.N + 63) / 64, gy = fam[i] ? (j.M + 127) / 128 : (j.M + 63) / 64;
     int chunk = kc[fam[i]];
     int ns = (int)cdiv64(j.K, chunk);
     const int64_t mn = (int64_t)j.M * j.N;
@@ -412,7 +413,7 @@ int gemm_queue_flush(GemmQueue* q, int x3, float* slab, int64_t slab_floats, hip
     g.total_blocks += (g.p[g.n].nblocks + 7) & ~7;
     ++g.n;
   }
-  if (g3.n) SCORE_TRY(score_launch_gemm_bf16x3(2, 1, g3, nullptr, 0, 1.f, nullptr, 0, s));
+  if (g3.n) SCORE_TRY(score_launch_gemm_bf16x3(2, 2, g3, nullptr, 0, 1.f, nullptr, 0, s));
   if (gf.n) {
     hipLaunchKernelGGL((gemm_f32_kernel<2, 1, 1, 16>), dim3(gf.total_blocks), dim3(256), 0, s, gf, nullptr, 0, 1.f, nullptr,
                        0);
