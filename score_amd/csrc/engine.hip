@@ -123,7 +123,7 @@ struct WS {
   int64_t gru_out[2], gru_final[2], xproj[2], gates[2];
   int64_t q, ainp, a1, a2, bn, f1, f2, lossb, dlogit, part;
   int64_t weff, wq, qz, adzsum, dweff, dwq, dqd;   // folded first attention layer (head.hip)
-  int64_t dwslab, dwslab_floats, dgstage, scratch2;          // deferred weight-gradient products (gemm.hip), bn1 dgamma staging
+  int64_t dwslab, dwslab_floats, dgstage, scratch2, gru_tmp;          // deferred weight-gradient products (gemm.hip), bn1 dgamma staging
   // backward
   int64_t dz2, dz1, dbn, dhead, ds, da2, da1, dainp, dgru[2], dinfo, dq, dquery, dfinal[2];
   int64_t dxproj[2], rh[2], hprev[2], dxside[2], dzsum[2], S, scratch;
@@ -184,6 +184,7 @@ void build_ws(const Dims& d, int B, WS* w) {
   w->dwxcat = take(2 * (int64_t)d.I * 3 * d.H);
   w->dgstage = take((int64_t)B * d.Dhead);
   w->scratch2 = take(w->scratch_floats);           // split-K scratch of the side stream's products
+  w->gru_tmp = take(10 * (int64_t)B * d.H);        // step-by-step recurrence (hidden sizes without a register kernel)
   {
     // split-K partials of every queued weight-gradient product: ~24 slabs of each dense variable
     Params Pl;
@@ -407,7 +408,8 @@ extern "C" int score_forward(const score_config_t* cfg, const score_state_t* st,
   {
     GruArgs ga;
     memset(&ga, 0, sizeof(ga));
-    ga.B = B; ga.T = T; ga.H = H; ga.length = bt->length; ga.nw8 = 1;   // H = 128: two waves per SIMD hide the LDS/epilogue latency (measured -0.08 ms/step)
+    ga.B = B; ga.T = T; ga.H = H; ga.length = bt->length; ga.nw8 = 1;
+    ga.tmp = ws + w.gru_tmp; ga.tmp_floats = 10 * (int64_t)B * H; ga.x3 = x3 != 0;   // H = 128: two waves per SIMD hide the LDS/epilogue latency (measured -0.08 ms/step)
     G(score_launch_gru_wxcat(W + P.gk[0], W + P.ck[0], W + P.gb[0], W + P.cb[0], W + P.gk[1], W + P.ck[1], W + P.gb[1],
                              W + P.cb[1], d.I, H, ws + w.wxcat, s));
     for (int sd = 0; sd < 2; ++sd) {
@@ -568,7 +570,8 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
   {
     GruArgs ga;
     memset(&ga, 0, sizeof(ga));
-    ga.B = B; ga.T = T; ga.H = H; ga.length = bt->length; ga.nw8 = 1;   // H = 128: two waves per SIMD hide the LDS/epilogue latency (measured -0.08 ms/step)
+    ga.B = B; ga.T = T; ga.H = H; ga.length = bt->length; ga.nw8 = 1;
+    ga.tmp = ws + w.gru_tmp; ga.tmp_floats = 10 * (int64_t)B * H; ga.x3 = x3 != 0;   // H = 128: two waves per SIMD hide the LDS/epilogue latency (measured -0.08 ms/step)
     for (int sd = 0; sd < 2; ++sd) {
       GruSide& g = ga.s[sd];
       g.Wg = W + P.gk[sd] + (int64_t)d.I * 2 * H; g.ldwg = 2 * H;

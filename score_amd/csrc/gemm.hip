@@ -347,6 +347,54 @@ extern "C" int score_gemm(int32_t trans, int32_t M, int32_t N, int32_t K, const 
   return 0;
 }
 
+// nprob same-shape problems in one grouped launch (no bias, no split-K: meant for per-time-slice products whose
+// tiles already fill the chip together); anything it cannot take goes through score_gemm one by one.
+int score_gemm_same_shape(int trans, int nprob, int M, int N, int K, const float* const* A, int lda,
+                          const float* const* B, int ldb, float* const* C, int ldc, int flags, int x3, float* scratch,
+                          int64_t scratch_floats, hipStream_t s) {
+  if (nprob <= 0 || nprob > GEMM_GROUP_MAX || trans < 0 || trans > 2 || (flags & ~F_ACC)) return SCORE_E_BADARG;
+  bool al = (lda & 3) == 0 && (ldb & 3) == 0;
+  for (int i = 0; i < nprob; ++i)
+    al = al && (reinterpret_cast<uintptr_t>(A[i]) & 15) == 0 && (reinterpret_cast<uintptr_t>(B[i]) & 15) == 0;
+  const bool a_kc = trans != 2, b_kc = trans == 1;
+  const bool x3_ok = al && (a_kc ? (K & 3) == 0 : (M & 3) == 0) && (b_kc ? (K & 3) == 0 : (N & 3) == 0) && M >= 64 &&
+                     N >= 32 && K >= 32;
+  const bool x3_shape = (trans == 0 && M >= 4096 && N >= 64) || (trans == 1 && M >= 4096 && N >= 256);
+  GemmGroup grp;
+  grp.n = nprob; grp.total_blocks = 0;
+  if (x3 && x3_ok && x3_shape) {
+    const int64_t t2 = (int64_t)nprob * ((N + 127) / 128) * ((M + 127) / 128);
+    const int64_t t1 = (int64_t)nprob * ((N + 127) / 128) * ((M + 63) / 64);
+    auto rounds = [](int64_t blocks, double w) { return (double)((blocks + 255) / 256) * w; };
+    const int wm = rounds(t1, 0.57) < rounds(t2, 1.0) ? 1 : 2;
+    if ((wm == 2 ? t2 : t1) >= 128) {
+      for (int i = 0; i < nprob; ++i) {
+        fill_prob(&grp.p[i], M, N, K, A[i], lda, B[i], ldb, C[i], ldc, K, nullptr, (N + 127) / 128,
+                  (M + 64 * wm - 1) / (64 * wm), 1);
+        grp.total_blocks += (grp.p[i].nblocks + 7) & ~7;
+      }
+      return score_launch_gemm_bf16x3(trans, wm, grp, nullptr, flags, 1.f, nullptr, 0, s);
+    }
+  }
+  const int64_t tiles = (int64_t)nprob * ((N + 63) / 64) * ((M + 63) / 64);
+  if (tiles < 128) {          // too few tiles even together: let score_gemm split K
+    for (int i = 0; i < nprob; ++i)
+      SCORE_TRY(score_gemm(trans, M, N, K, A[i], lda, B[i], ldb, C[i], ldc, nullptr, flags | (x3 ? F_X3 : 0), 1.f, nullptr, 0,
+                           scratch, scratch_floats, s));
+    return 0;
+  }
+  for (int i = 0; i < nprob; ++i) {
+    fill_prob(&grp.p[i], M, N, K, A[i], lda, B[i], ldb, C[i], ldc, K, nullptr, (N + 63) / 64, (M + 63) / 64, 1);
+    grp.total_blocks += (grp.p[i].nblocks + 7) & ~7;
+  }
+#define LS(TR) hipLaunchKernelGGL((gemm_f32_kernel<TR, 1, 1, 16>), dim3(grp.total_blocks), dim3(256), 0, s, grp, nullptr, \
+                                  flags, 1.f, nullptr, 0)
+  if (trans == 0) LS(0); else if (trans == 1) LS(1); else LS(2);
+#undef LS
+  SCORE_CHECK_LAUNCH();
+  return 0;
+}
+
 // ------------------------------------------------------------------ deferred weight-gradient products
 int gemm_queue_add(GemmQueue* q, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
                    int ldc) {

@@ -586,6 +586,165 @@ __global__ __launch_bounds__(64 * NW) void gru_bwd_reg_kernel(const GruArgs a) {
   }
 }
 
+// ------------------------------------------------------------------ step-by-step recurrence (any H)
+// Per time slice: gpre = h.Wg (grouped GEMM over the sides) -> gates, r*h -> cpre = (r*h).Wc -> candidate,
+// new state.  The same arithmetic as gru_fwd_kernel / gru_bwd_kernel, with the matrix products on the GEMM
+// kernels (bf16x3 where allowed) instead of one-float-per-lane operand loads.
+struct GruStepSide {
+  const float* xproj; float* out; int ldo; float* gates; float* hstate; const float* gpre; float* rh;
+  const float* cpre;
+  // backward
+  const float* dout; int lddo; float* dxproj; float* rh_out; float* hprev_out; float* dh; float* dpc;
+  const float* drh; float* dpg;
+};
+struct GruStepArgs { GruStepSide s[2]; const int32_t* length; int B, T, H, t; };
+
+__global__ void gru_step_gates_kernel(const GruStepArgs a, int first) {
+  const GruStepSide& sd = a.s[blockIdx.y];
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)a.B * 2 * a.H) return;
+  const int b = (int)(i / (2 * a.H)), j = (int)(i - (int64_t)b * 2 * a.H);
+  const int64_t row = (int64_t)b * a.T + a.t;
+  const float pre = first ? 0.f : sd.gpre[i];
+  const float g = sigmoidf_(pre + sd.xproj[row * 3 * a.H + j]);
+  sd.gates[row * 3 * a.H + j] = g;
+  if (j < a.H) sd.rh[(int64_t)b * a.H + j] = first ? 0.f : g * sd.hstate[(int64_t)b * a.H + j];
+}
+__global__ void gru_step_out_kernel(const GruStepArgs a, int first) {
+  const GruStepSide& sd = a.s[blockIdx.y];
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)a.B * a.H) return;
+  const int b = (int)(i / a.H), j = (int)(i - (int64_t)b * a.H);
+  const int64_t row = (int64_t)b * a.T + a.t;
+  const float pre = first ? 0.f : sd.cpre[i];
+  const float c = tanhf(pre + sd.xproj[row * 3 * a.H + 2 * a.H + j]);
+  sd.gates[row * 3 * a.H + 2 * a.H + j] = c;
+  const float u = sd.gates[row * 3 * a.H + a.H + j], h = first ? 0.f : sd.hstate[i];
+  const float hn = u * h + (1.0f - u) * c;
+  const bool live = a.t < a.length[b];
+  sd.out[row * sd.ldo + j] = live ? hn : 0.f;     // dynamic_rnn: zero output past the length
+  sd.hstate[i] = live ? hn : h;                   // ... and the state is carried through
+}
+// backward phase 1: dh_tot, du, dc -> dpu, dpc ; dh <- dh_tot*u
+__global__ void gru_bstep_a_kernel(const GruStepArgs a) {
+  const GruStepSide& sd = a.s[blockIdx.y];
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)a.B * a.H) return;
+  const int b = (int)(i / a.H), j = (int)(i - (int64_t)b * a.H), H = a.H, t = a.t;
+  const int64_t row = (int64_t)b * a.T + t;
+  const bool live = t < a.length[b];
+  const float hp = t > 0 ? sd.out[(row - 1) * sd.ldo + j] : 0.f;
+  sd.hprev_out[row * H + j] = live ? hp : 0.f;
+  float v_dpc = 0.f, v_dpu = 0.f;
+  if (live) {
+    const float u = sd.gates[row * 3 * H + H + j], c = sd.gates[row * 3 * H + 2 * H + j];
+    const float d = sd.dh[i] + sd.dout[row * sd.lddo + j];
+    const float du = d * (hp - c), dc = d * (1.0f - u);
+    v_dpu = du * u * (1.0f - u);
+    v_dpc = dc * (1.0f - c * c);
+    sd.dh[i] = d * u;
+  }
+  sd.dxproj[row * 3 * H + H + j] = v_dpu;
+  sd.dxproj[row * 3 * H + 2 * H + j] = v_dpc;
+  sd.dpc[i] = v_dpc;
+  sd.dpg[(int64_t)b * 2 * H + H + j] = v_dpu;
+}
+// backward phase 2 (after drh = dpc . Wc^T): dr, dpr ; dh += d(rh)*r
+__global__ void gru_bstep_b_kernel(const GruStepArgs a) {
+  const GruStepSide& sd = a.s[blockIdx.y];
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)a.B * a.H) return;
+  const int b = (int)(i / a.H), j = (int)(i - (int64_t)b * a.H), H = a.H, t = a.t;
+  const int64_t row = (int64_t)b * a.T + t;
+  const bool live = t < a.length[b];
+  float v_dpr = 0.f, rr = 0.f, hp = 0.f;
+  if (live) {
+    rr = sd.gates[row * 3 * H + j];
+    hp = t > 0 ? sd.out[(row - 1) * sd.ldo + j] : 0.f;
+    const float drh = sd.drh[i];
+    v_dpr = drh * hp * rr * (1.0f - rr);
+    sd.dh[i] += drh * rr;
+  }
+  sd.dxproj[row * 3 * H + j] = v_dpr;
+  sd.rh_out[row * H + j] = rr * hp;
+  sd.dpg[(int64_t)b * 2 * H + j] = v_dpr;
+}
+__global__ void gru_copy_or_zero_kernel(float* __restrict__ dst, const float* __restrict__ src, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src ? src[i] : 0.f;
+}
+
+static int gru_fwd_steps(GruArgs& a, int nsides, hipStream_t s) {
+  const int B = a.B, T = a.T, H = a.H;
+  const int64_t BH = (int64_t)B * H;
+  if (a.tmp_floats < 10 * BH) return SCORE_E_WORKSPACE;
+  GruStepArgs g;
+  memset(&g, 0, sizeof(g));
+  g.length = a.length; g.B = B; g.T = T; g.H = H;
+  const float *Ah[2], *Wg[2], *Arh[2], *Wc[2];
+  float *Cg[2], *Cc[2];
+  for (int i = 0; i < nsides; ++i) {
+    float* base = a.tmp + (int64_t)i * 5 * BH;
+    GruStepSide& sd = g.s[i];
+    sd.xproj = a.s[i].xproj; sd.out = a.s[i].out; sd.ldo = a.s[i].ldo; sd.gates = a.s[i].gates;
+    sd.hstate = base; sd.gpre = base + BH; sd.rh = base + 3 * BH; sd.cpre = base + 4 * BH;
+    Ah[i] = sd.hstate; Wg[i] = a.s[i].Wg; Cg[i] = base + BH; Arh[i] = sd.rh; Wc[i] = a.s[i].Wc; Cc[i] = base + 4 * BH;
+  }
+  const unsigned g2 = (unsigned)cdiv64(2 * BH, 256), g1 = (unsigned)cdiv64(BH, 256);
+  for (int t = 0; t < T; ++t) {
+    g.t = t;
+    const int first = t == 0;      // h_{-1} = 0: both products vanish
+    if (!first)
+      SCORE_TRY(score_gemm_same_shape(0, nsides, B, 2 * H, H, Ah, H, Wg, a.s[0].ldwg, Cg, 2 * H, 0, a.x3, nullptr, 0, s));
+    hipLaunchKernelGGL(gru_step_gates_kernel, dim3(g2, nsides), dim3(256), 0, s, g, first);
+    SCORE_CHECK_LAUNCH();
+    if (!first)
+      SCORE_TRY(score_gemm_same_shape(0, nsides, B, H, H, Arh, H, Wc, a.s[0].ldwc, Cc, H, 0, a.x3, nullptr, 0, s));
+    hipLaunchKernelGGL(gru_step_out_kernel, dim3(g1, nsides), dim3(256), 0, s, g, first);
+    SCORE_CHECK_LAUNCH();
+  }
+  for (int i = 0; i < nsides; ++i)
+    if (a.s[i].final_state) {
+      hipLaunchKernelGGL(gru_copy_or_zero_kernel, dim3(g1), dim3(256), 0, s, a.s[i].final_state, g.s[i].hstate, BH);
+      SCORE_CHECK_LAUNCH();
+    }
+  return 0;
+}
+
+static int gru_bwd_steps(GruArgs& a, int nsides, hipStream_t s) {
+  const int B = a.B, T = a.T, H = a.H;
+  const int64_t BH = (int64_t)B * H;
+  if (a.tmp_floats < 10 * BH) return SCORE_E_WORKSPACE;
+  GruStepArgs g;
+  memset(&g, 0, sizeof(g));
+  g.length = a.length; g.B = B; g.T = T; g.H = H;
+  const float *Adpc[2], *Wc[2], *Adpg[2], *Wg[2];
+  float *Cdrh[2], *Cdh[2];
+  const unsigned g1 = (unsigned)cdiv64(BH, 256);
+  for (int i = 0; i < nsides; ++i) {
+    float* base = a.tmp + (int64_t)i * 5 * BH;
+    GruStepSide& sd = g.s[i];
+    sd.out = a.s[i].out; sd.ldo = a.s[i].ldo; sd.gates = a.s[i].gates; sd.dout = a.s[i].dout; sd.lddo = a.s[i].lddo;
+    sd.dxproj = a.s[i].dxproj; sd.rh_out = a.s[i].rh; sd.hprev_out = a.s[i].hprev;
+    sd.dh = base; sd.dpc = base + BH; sd.drh = base + 2 * BH; sd.dpg = base + 3 * BH;
+    Adpc[i] = sd.dpc; Wc[i] = a.s[i].Wc; Cdrh[i] = base + 2 * BH; Adpg[i] = sd.dpg; Wg[i] = a.s[i].Wg; Cdh[i] = sd.dh;
+    hipLaunchKernelGGL(gru_copy_or_zero_kernel, dim3(g1), dim3(256), 0, s, sd.dh, a.s[i].dfinal, BH);
+    SCORE_CHECK_LAUNCH();
+  }
+  for (int t = T - 1; t >= 0; --t) {
+    g.t = t;
+    hipLaunchKernelGGL(gru_bstep_a_kernel, dim3(g1, nsides), dim3(256), 0, s, g);
+    SCORE_CHECK_LAUNCH();
+    // d(rh) = dpc . Wc^T   (Wc is [H_in, H_out]: the NT layout reads it as is)
+    SCORE_TRY(score_gemm_same_shape(1, nsides, B, H, H, Adpc, H, Wc, a.s[0].ldwc, Cdrh, H, 0, a.x3, nullptr, 0, s));
+    hipLaunchKernelGGL(gru_bstep_b_kernel, dim3(g1, nsides), dim3(256), 0, s, g);
+    SCORE_CHECK_LAUNCH();
+    // dh += [dpr | dpu] . Wg^T
+    SCORE_TRY(score_gemm_same_shape(1, nsides, B, H, 2 * H, Adpg, 2 * H, Wg, a.s[0].ldwg, Cdh, H, 4, a.x3, nullptr, 0, s));
+  }
+  return 0;
+}
+
 static bool gru_reg_ok(int H) { return H == 16 || H == 32 || H == 64 || H == 128; }
 
 int score_gru_fwd_multi(GruArgs& a, int nsides, hipStream_t s) {
@@ -600,6 +759,8 @@ int score_gru_fwd_multi(GruArgs& a, int nsides, hipStream_t s) {
     SCORE_CHECK_LAUNCH();
     return 0;
   }
+  if (a.tmp && (nsides == 1 || (a.s[0].ldwg == a.s[1].ldwg && a.s[0].ldwc == a.s[1].ldwc)))
+    return gru_fwd_steps(a, nsides, s);
   for (int i = 0; i < nsides; ++i) {
     const GruSide& sd = a.s[i];
     SCORE_TRY(score_gru_fwd(a.B, a.T, H, sd.xproj, sd.Wg, sd.ldwg, sd.Wc, sd.ldwc, a.length, sd.out, sd.ldo,
@@ -620,6 +781,8 @@ int score_gru_bwd_multi(GruArgs& a, int nsides, hipStream_t s) {
     SCORE_CHECK_LAUNCH();
     return 0;
   }
+  if (a.tmp && (nsides == 1 || (a.s[0].ldwg == a.s[1].ldwg && a.s[0].ldwc == a.s[1].ldwc)))
+    return gru_bwd_steps(a, nsides, s);
   for (int i = 0; i < nsides; ++i) {
     const GruSide& sd = a.s[i];
     SCORE_TRY(score_gru_bwd(a.B, a.T, H, sd.Wg, sd.ldwg, sd.Wc, sd.ldwc, a.length, sd.out, sd.ldo, sd.gates,

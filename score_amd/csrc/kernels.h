@@ -146,6 +146,13 @@ struct GruArgs {
   const int32_t* length;
   int B, T, H;
   int nw8;      // H = 128: 8 waves per workgroup (2 per SIMD) instead of 4
+  // hidden sizes without a register-resident kernel: the recurrence runs step by step (two grouped GEMMs +
+  // two pointwise launches per time slice) when this scratch is given (10 * B * H floats), x3 = bf16x3 allowed
+  float* tmp; int64_t tmp_floats; int x3;
 };
+// nprob same-shape GEMMs C_i = op(A_i) op(B_i) in one launch (the two sides of a recurrence step); flags: 4 = C += .
+int score_gemm_same_shape(int trans, int nprob, int M, int N, int K, const float* const* A, int lda,
+                          const float* const* B, int ldb, float* const* C, int ldc, int flags, int x3, float* scratch,
+                          int64_t scratch_floats, hipStream_t s);
 int score_gru_fwd_multi(GruArgs& a, int nsides, hipStream_t s);
 int score_gru_bwd_multi(GruArgs& a, int nsides, hipStream_t s);

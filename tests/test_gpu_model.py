@@ -167,6 +167,26 @@ def test_random_midsize_vs_oracle(mt):
     assert round(roc_auc_score(lab, pg), 4) == round(roc_auc_score(lab, po), 4)
 
 
+@pytest.mark.parametrize("H,B", [(48, 96), (256, 4096)])
+def test_stepwise_recurrence_hidden_sizes(H, B):
+    # hidden sizes without a register-resident GRU kernel run the recurrence step by step on grouped
+    # GEMMs (H = 256 is cfg-5's; B = 4096 puts its products on the bf16x3 kernel); ragged lengths
+    cfg = so.Cfg(3000, 8, H, 6, 4, 3, 4, "SCORE")
+    rng = np.random.default_rng(5)
+    P = so.init_params(cfg, 9)
+    b = random_batch(rng, cfg, B)
+    b["length"] = rng.integers(1, cfg.T + 1, B).astype(np.int32)
+    m = make_model(cfg, P)
+    om = so.OracleModel(cfg.N, cfg.D, cfg.H, cfg.T, cfg.K, cfg.Fu, cfg.Fi, "SCORE", params={k: v.copy() for k, v in P.items()})
+    for _ in range(2):
+        lg = m.train(None, batch_tuple(b), 1e-3, 1e-4, keep_prob=1.0)
+        lo = om.train(None, batch_tuple(b), 1e-3, 1e-4, keep_prob=1.0)
+        assert abs(lg - lo) < 2e-5 * max(1.0, abs(lo))
+    pg, _, _ = m.eval(None, batch_tuple(b), 1e-4)
+    po, _, _ = om.eval(None, batch_tuple(b), 1e-4)
+    assert np.abs(np.asarray(pg) - np.asarray(po)).max() < LOGIT_TOL
+
+
 def test_save_restore_roundtrip(tmp_path):
     cfg, P, b, z = load_golden("g1_tiny_score")
     m = make_model(cfg, P)
