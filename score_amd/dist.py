@@ -21,6 +21,7 @@ Tests inject a CPU backend to exercise this file's routing with gloo; nothing he
 back to it on its own.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -52,6 +53,20 @@ class TorchDistComm(object):
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self._gloo = dist.get_backend(group) == "gloo"
+        self._index = None
+
+    def index_comm(self):
+        """A second communicator over the same ranks for the index-only collectives (split sizes, row
+        requests).  They depend on the batch's plan alone; on their own communicator they are not queued
+        behind the previous step's gradient exchange, so reading the sizes never waits for (or drains) the
+        compute stream.  SCORE_SINGLE_COMM=1 keeps everything on one communicator."""
+        if os.environ.get("SCORE_SINGLE_COMM") or self.world == 1 and self._gloo:
+            return self
+        if self._index is None:
+            ranks = self.dist.get_process_group_ranks(self.group) if self.group is not None else None
+            self._index = TorchDistComm(self.dist.new_group(ranks=ranks))
+            self._index._index = self._index
+        return self._index
 
     def exchange_counts(self, send_counts, device):
         t = torch.tensor(send_counts, dtype=torch.int64, device=device)
@@ -263,6 +278,11 @@ class ShardedSCORE(object):
         self.device = self.backend.device
         self.D = int(eb_dim)
         self._side, self._slot, self._slot_done, self._prefetched = None, 0, [None, None, None], None
+        if self.device.type == "cuda" and hasattr(self.comm, "index_comm"):
+            # bring both communicators up now (every rank constructs the model): their lazy first-use
+            # initialisation costs tens of ms and would otherwise land inside a training step
+            for cm in (self.comm, self.comm.index_comm()):
+                cm.exchange_counts([0] * self.world, self.device)
 
     # bench.py compatibility with the single-device model
     @property
@@ -307,9 +327,9 @@ class ShardedSCORE(object):
         return mini
 
     def prefetch(self, batch_data):
-        """Index-only phase of the NEXT batch in one call (plan, then request its rows); see
-        _prefetch_launch / _prefetch_finish for how forward_backward(..., next_batch=) splits it around
-        this step's compute.  Every rank must call it, with its own next batch."""
+        """Index-only phase of the NEXT batch in one call (plan, then request its rows).
+        forward_backward(..., next_batch=) only LAUNCHES the plan (before this step's compute is enqueued)
+        and lets the next step pick it up.  Every rank must call it, with its own next batch."""
         self._prefetch_launch(batch_data)
         self._prefetch_finish()
 
@@ -331,24 +351,27 @@ class ShardedSCORE(object):
         self._prefetched = (batch_data, handle, None, None)
 
     def _prefetch_finish(self):
-        """Read the plan's sizes and request the rows, from the side stream.  Called once this step's
-        forward/backward are enqueued and BEFORE its gradient exchange is: the plan has had the whole
-        enqueue time to run, the host wait is short and the GPU has a full queue behind it, and on the
-        communicator's stream the two small collectives sit between this step's row exchange and its
-        gradient exchange (they wait for the side stream only)."""
+        """Read the prefetched plan's sizes and request its rows, from the side stream and on the index
+        communicator (TorchDistComm.index_comm: not queued behind the previous step's gradient exchange).
+        Runs at the start of the step that uses the plan: it was launched a whole step earlier, so the two
+        host reads return at once while the GPU still has that previous step's tail in its queue."""
         batch_data, handle, _, _ = self._prefetched
         if handle is None:                                   # CPU test backend: nothing to overlap
             self._prefetched = (batch_data, None, self._plan_and_request(batch_data, 0), None)
             return
+        icm = self.comm.index_comm() if hasattr(self.comm, "index_comm") else self.comm
         with torch.cuda.stream(self._side):
-            plan = self._request(self.backend.plan_finish(handle))
+            plan = self._request(self.backend.plan_finish(handle), icm)
             ev = self._side.record_event()
         self._prefetched = (batch_data, None, plan, ev)
 
     def _fetch(self, batch_data):
         """plan -> request rows from their owners -> gathered [U, D] mini-table"""
         pf = getattr(self, "_prefetched", None)
-        if pf is not None and pf[0] is batch_data and pf[2] is not None:
+        if pf is not None and pf[0] is batch_data:
+            if pf[2] is None:
+                self._prefetch_finish()
+                pf = self._prefetched
             plan = pf[2]
             if pf[3] is not None:
                 cur = torch.cuda.current_stream(self.device)
@@ -373,8 +396,6 @@ class ShardedSCORE(object):
         be.set_global_batch(B * self.world)
         fw = be.forward(plan, mini, reg_lambda, keep_prob, dropout_masks)
         mini_g = be.backward(plan, mini, fw, keep_prob)
-        if next_batch is not None:
-            self._prefetch_finish()               # sizes + row requests, ahead of this step's gradient exchange
         grads_in = torch.empty((plan["req"].numel(), self.D), dtype=torch.float32, device=self.device)
         cm.all_to_all(grads_in, mini_g, plan["recv"], plan["send"])
         cm.all_reduce_sum(be.dense_grad())
