@@ -295,12 +295,20 @@ __device__ __forceinline__ float sigmoid_fast(float x) { return __frcp_rn(1.0f +
 __device__ __forceinline__ float tanh_fast(float x) { return 1.0f - 2.0f * __frcp_rn(__expf(2.0f * x) + 1.0f); }
 
 
-template <int H, int NW>
+// FULL: the batch is a whole number of 16-row tiles and every wave owns whole column tiles -- the time loop
+// then has no predicated memory operation at all.  That matters beyond the saved compares: with loads and
+// stores under exec-mask branches the compiler's s_waitcnt placement falls back to vmcnt(0) in the loop,
+// so every step waited for the prefetch it had just issued (43 % of the kernel's wave time).
+template <int H, int NW, bool FULL>
 __global__ __launch_bounds__(64 * NW) void gru_fwd_reg_kernel(const GruArgs a) {
   constexpr int KS = H / 4;                 // k-steps of 4
   constexpr int NTG = 2 * H / 16, NTC = H / 16;
   constexpr int TGW = (NTG + NW - 1) / NW, TCW = (NTC + NW - 1) / NW;
-  constexpr int LD = H + 2;                 // (16 rows x 2 k) of a lane group land on 32 distinct banks
+  constexpr bool TEX = (NTG % NW == 0) && (NTC % NW == 0);   // every wave owns whole tiles
+  // K is dealt to the four lane quarters in contiguous runs (quarter lq owns k in [lq*KS, (lq+1)*KS)): a lane
+  // then reads its A operands of four consecutive MFMA steps with one ds_read_b128, all of a phase's reads
+  // go out before its MFMA chain starts.  Row stride H+4: 16-B aligned, the 16 rows of a read land on 64 banks.
+  constexpr int LD = H + 4;
   __shared__ float hs[RRB * LD], rhs[RRB * LD], us[RRB * LD];
   const int tiles_b = (a.B + RRB - 1) / RRB;
   const int side = blockIdx.x / tiles_b;
@@ -309,6 +317,7 @@ __global__ __launch_bounds__(64 * NW) void gru_fwd_reg_kernel(const GruArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lc = lane & 15, lq = lane >> 4;  // column inside a tile / k-quarter == output row group
   const int T = a.T;
+  auto tile_ok = [&](int tile, int nt) { return (FULL && TEX) ? true : tile < nt; };
 
   float wg[TGW][KS], wc[TCW][KS];
 #pragma unroll
@@ -316,63 +325,78 @@ __global__ __launch_bounds__(64 * NW) void gru_fwd_reg_kernel(const GruArgs a) {
     const int tile = wave + NW * tt;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
-      wg[tt][ks] = tile < NTG ? sd.Wg[(int64_t)(ks * 4 + lq) * sd.ldwg + tile * 16 + lc] : 0.f;
+      wg[tt][ks] = tile < NTG ? sd.Wg[(int64_t)(lq * KS + ks) * sd.ldwg + tile * 16 + lc] : 0.f;
   }
 #pragma unroll
   for (int tt = 0; tt < TCW; ++tt) {
     const int tile = wave + NW * tt;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
-      wc[tt][ks] = tile < NTC ? sd.Wc[(int64_t)(ks * 4 + lq) * sd.ldwc + tile * 16 + lc] : 0.f;
+      wc[tt][ks] = tile < NTC ? sd.Wc[(int64_t)(lq * KS + ks) * sd.ldwc + tile * 16 + lc] : 0.f;
   }
   int len[4];
   bool rok[4];
+  int64_t rowb[4];                // row of (sample, t = 0); samples past the batch read the last one's (never stored)
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int b = b0 + lq * 4 + r;
-    rok[r] = b < a.B;
-    len[r] = rok[r] ? a.length[b] : 0;
+    rok[r] = FULL ? true : b < a.B;
+    const int bc = FULL ? b : min(b, a.B - 1);
+    len[r] = rok[r] ? a.length[bc] : 0;
+    rowb[r] = (int64_t)bc * T;
   }
   for (int e = tid; e < RRB * LD; e += 64 * NW) hs[e] = 0.f;
   __syncthreads();
 
+  // x-projection values are read one step ahead, unconditionally (clamped addresses)
+  float nxg[TGW][4], nxc[TCW][4];
+  auto fetch_x = [&](int t) {
+    const int tc = min(t, T - 1);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float* xr = sd.xproj + (rowb[r] + tc) * 3 * H;
+#pragma unroll
+      for (int tt = 0; tt < TGW; ++tt) nxg[tt][r] = xr[min(wave + NW * tt, NTG - 1) * 16 + lc];
+#pragma unroll
+      for (int tt = 0; tt < TCW; ++tt) nxc[tt][r] = xr[2 * H + min(wave + NW * tt, NTC - 1) * 16 + lc];
+    }
+  };
+  fetch_x(0);
   for (int t = 0; t < T; ++t) {
-    // issue this step's x-projection reads first: they are consumed after the MFMA chains
     float xg[TGW][4], xc[TCW][4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int64_t row = (int64_t)(b0 + lq * 4 + r) * T + t;
 #pragma unroll
-      for (int tt = 0; tt < TGW; ++tt) {
-        const int tile = wave + NW * tt;
-        xg[tt][r] = (rok[r] && tile < NTG) ? sd.xproj[row * 3 * H + tile * 16 + lc] : 0.f;
-      }
+      for (int tt = 0; tt < TGW; ++tt) xg[tt][r] = nxg[tt][r];
 #pragma unroll
-      for (int tt = 0; tt < TCW; ++tt) {
-        const int tile = wave + NW * tt;
-        xc[tt][r] = (rok[r] && tile < NTC) ? sd.xproj[row * 3 * H + 2 * H + tile * 16 + lc] : 0.f;
-      }
+      for (int tt = 0; tt < TCW; ++tt) xc[tt][r] = nxc[tt][r];
     }
+    fetch_x(t + 1);
     // gates = sigmoid(xproj[:, :2H] + h . Wg)
     f32x4 acc[TGW];
 #pragma unroll
     for (int tt = 0; tt < TGW; ++tt) acc[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    {
+      float4 av4[KS / 4];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const float av = hs[lc * LD + ks * 4 + lq];
+      for (int q = 0; q < KS / 4; ++q) av4[q] = *reinterpret_cast<const float4*>(&hs[lc * LD + lq * KS + 4 * q]);
 #pragma unroll
-      for (int tt = 0; tt < TGW; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wg[tt][ks], acc[tt], 0, 0, 0);
+      for (int ks = 0; ks < KS; ++ks) {
+        const float av = (ks & 3) == 0 ? av4[ks >> 2].x : (ks & 3) == 1 ? av4[ks >> 2].y : (ks & 3) == 2 ? av4[ks >> 2].z : av4[ks >> 2].w;
+#pragma unroll
+        for (int tt = 0; tt < TGW; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wg[tt][ks], acc[tt], 0, 0, 0);
+      }
     }
 #pragma unroll
     for (int tt = 0; tt < TGW; ++tt) {
       const int tile = wave + NW * tt;
-      if (tile >= NTG) continue;
+      if (!tile_ok(tile, NTG)) continue;
       const int j = tile * 16 + lc;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = lq * 4 + r;
         const float g = sigmoid_fast(acc[tt][r] + xg[tt][r]);
-        if (rok[r]) sd.gates[((int64_t)(b0 + i) * T + t) * 3 * H + j] = g;
+        if (rok[r]) sd.gates[(rowb[r] + t) * 3 * H + j] = g;
         if (j < H) rhs[i * LD + j] = g * hs[i * LD + j];
         else us[i * LD + (j - H)] = g;
       }
@@ -382,17 +406,22 @@ __global__ __launch_bounds__(64 * NW) void gru_fwd_reg_kernel(const GruArgs a) {
     f32x4 acc2[TCW];
 #pragma unroll
     for (int tt = 0; tt < TCW; ++tt) acc2[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    {
+      float4 av4[KS / 4];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const float av = rhs[lc * LD + ks * 4 + lq];
+      for (int q = 0; q < KS / 4; ++q) av4[q] = *reinterpret_cast<const float4*>(&rhs[lc * LD + lq * KS + 4 * q]);
 #pragma unroll
-      for (int tt = 0; tt < TCW; ++tt)
-        acc2[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wc[tt][ks], acc2[tt], 0, 0, 0);
+      for (int ks = 0; ks < KS; ++ks) {
+        const float av = (ks & 3) == 0 ? av4[ks >> 2].x : (ks & 3) == 1 ? av4[ks >> 2].y : (ks & 3) == 2 ? av4[ks >> 2].z : av4[ks >> 2].w;
+#pragma unroll
+        for (int tt = 0; tt < TCW; ++tt)
+          acc2[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wc[tt][ks], acc2[tt], 0, 0, 0);
+      }
     }
 #pragma unroll
     for (int tt = 0; tt < TCW; ++tt) {
       const int tile = wave + NW * tt;
-      if (tile >= NTC) continue;
+      if (!tile_ok(tile, NTC)) continue;
       const int j = tile * 16 + lc;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -402,7 +431,7 @@ __global__ __launch_bounds__(64 * NW) void gru_fwd_reg_kernel(const GruArgs a) {
         const float hn = u * h + (1.0f - u) * c;
         const bool live = t < len[r];
         if (rok[r]) {
-          const int64_t row = (int64_t)(b0 + i) * T + t;
+          const int64_t row = rowb[r] + t;
           sd.gates[row * 3 * H + 2 * H + j] = c;
           sd.out[row * sd.ldo + j] = live ? hn : 0.f;
         }
@@ -418,12 +447,13 @@ __global__ __launch_bounds__(64 * NW) void gru_fwd_reg_kernel(const GruArgs a) {
     }
 }
 
-template <int H, int NW>
+template <int H, int NW, bool FULL>
 __global__ __launch_bounds__(64 * NW) void gru_bwd_reg_kernel(const GruArgs a) {
   constexpr int KS = H / 4;
   constexpr int NT = H / 16;
   constexpr int TW = (NT + NW - 1) / NW;
-  constexpr int LD = H + 2, LD2 = 2 * H + 2;
+  constexpr bool TEX = NT % NW == 0;
+  constexpr int LD = H + 4, LD2 = 2 * H + 4;     // K dealt to the lane quarters in contiguous runs, as in the forward
   __shared__ float dh[RRB * LD], dpc[RRB * LD], dpg[RRB * LD2];
   const int tiles_b = (a.B + RRB - 1) / RRB;
   const int side = blockIdx.x / tiles_b;
@@ -432,6 +462,7 @@ __global__ __launch_bounds__(64 * NW) void gru_bwd_reg_kernel(const GruArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lc = lane & 15, lq = lane >> 4;
   const int T = a.T;
+  auto tile_ok = [&](int tile) { return (FULL && TEX) ? true : tile < NT; };
 
   // B operands of the two transposed products: B[k][j] = Wc[j][k] (k < H), Wg[j][k] (k < 2H)
   float wct[TW][KS], wgt[TW][2 * KS];
@@ -440,19 +471,22 @@ __global__ __launch_bounds__(64 * NW) void gru_bwd_reg_kernel(const GruArgs a) {
     const int tile = wave + NW * tt;
     const int j = tile * 16 + lc;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) wct[tt][ks] = tile < NT ? sd.Wc[(int64_t)j * sd.ldwc + ks * 4 + lq] : 0.f;
+    for (int ks = 0; ks < KS; ++ks) wct[tt][ks] = tile < NT ? sd.Wc[(int64_t)j * sd.ldwc + lq * KS + ks] : 0.f;
 #pragma unroll
-    for (int ks = 0; ks < 2 * KS; ++ks) wgt[tt][ks] = tile < NT ? sd.Wg[(int64_t)j * sd.ldwg + ks * 4 + lq] : 0.f;
+    for (int ks = 0; ks < 2 * KS; ++ks) wgt[tt][ks] = tile < NT ? sd.Wg[(int64_t)j * sd.ldwg + lq * 2 * KS + ks] : 0.f;
   }
-  // every thread owns the elements (row i = lq*4 + r, column j = (wave + 4*tt)*16 + lc) in all three
+  // every thread owns the elements (row i = lq*4 + r, column j = (wave + NW*tt)*16 + lc) in all three
   // phases, so the saved activations of a step are read once, one step ahead of their use
   int len[4];
   bool rok[4];
+  int64_t rowb[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int b = b0 + lq * 4 + r;
-    rok[r] = b < a.B;
-    len[r] = rok[r] ? a.length[b] : 0;
+    rok[r] = FULL ? true : b < a.B;
+    const int bc = FULL ? b : min(b, a.B - 1);
+    len[r] = rok[r] ? a.length[bc] : 0;
+    rowb[r] = (int64_t)bc * T;
   }
 #pragma unroll
   for (int tt = 0; tt < TW; ++tt) {
@@ -463,21 +497,26 @@ __global__ __launch_bounds__(64 * NW) void gru_bwd_reg_kernel(const GruArgs a) {
       if (tile < NT) dh[i * LD + j] = (sd.dfinal && rok[r]) ? sd.dfinal[(int64_t)(b0 + i) * H + j] : 0.f;
     }
   }
+  // saved activations of step t, read unconditionally (clamped addresses), zeroed past the length by selects
   float n_u[TW][4], n_c[TW][4], n_r[TW][4], n_hp[TW][4], n_do[TW][4];
   auto prefetch = [&](int t) {
+    const int tc = max(t, 0);
 #pragma unroll
     for (int tt = 0; tt < TW; ++tt) {
-      const int tile = wave + NW * tt;
-      const int j = tile * 16 + lc;
+      const int j = min(wave + NW * tt, NT - 1) * 16 + lc;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const bool ok = rok[r] && tile < NT && t >= 0 && t < len[r];
-        const int64_t row = (int64_t)(b0 + lq * 4 + r) * T + t;
-        n_r[tt][r] = ok ? sd.gates[row * 3 * H + j] : 0.f;
-        n_u[tt][r] = ok ? sd.gates[row * 3 * H + H + j] : 0.f;
-        n_c[tt][r] = ok ? sd.gates[row * 3 * H + 2 * H + j] : 0.f;
-        n_hp[tt][r] = (ok && t > 0) ? sd.out[(row - 1) * sd.ldo + j] : 0.f;
-        n_do[tt][r] = ok ? sd.dout[row * sd.lddo + j] : 0.f;
+        const bool ok = t >= 0 && t < len[r];
+        const int64_t row = rowb[r] + tc;
+        const float gr = sd.gates[row * 3 * H + j], gu = sd.gates[row * 3 * H + H + j];
+        const float gc = sd.gates[row * 3 * H + 2 * H + j];
+        const float hp = sd.out[(row - (tc > 0 ? 1 : 0)) * sd.ldo + j];
+        const float dd = sd.dout[row * sd.lddo + j];
+        n_r[tt][r] = ok ? gr : 0.f;
+        n_u[tt][r] = ok ? gu : 0.f;
+        n_c[tt][r] = ok ? gc : 0.f;
+        n_hp[tt][r] = (ok && t > 0) ? hp : 0.f;
+        n_do[tt][r] = ok ? dd : 0.f;
       }
     }
   };
@@ -494,28 +533,26 @@ __global__ __launch_bounds__(64 * NW) void gru_bwd_reg_kernel(const GruArgs a) {
         c_hp[tt][r] = n_hp[tt][r]; c_do[tt][r] = n_do[tt][r];
       }
     prefetch(t - 1);
-    // phase 1 (elementwise): dpu, dpc ; dh <- dh_tot * u
+    // phase 1 (elementwise): dpu, dpc ; dh <- dh_tot * u      (selects, no branches: see FULL above)
 #pragma unroll
     for (int tt = 0; tt < TW; ++tt) {
       const int tile = wave + NW * tt;
-      if (tile >= NT) continue;
+      if (!tile_ok(tile)) continue;
       const int j = tile * 16 + lc;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = lq * 4 + r;
-        float v_dpc = 0.f, v_dpu = 0.f;
+        const bool live = t < len[r];
+        const float u = c_u[tt][r], c = c_c[tt][r];
+        const float dold = dh[i * LD + j];
+        const float d = dold + c_do[tt][r];
+        const float du = d * (c_hp[tt][r] - c), dc = d * (1.0f - u);
+        const float v_dpu = live ? du * u * (1.0f - u) : 0.f;
+        const float v_dpc = live ? dc * (1.0f - c * c) : 0.f;
+        dh[i * LD + j] = live ? d * u : dold;
         if (rok[r]) {
-          const int64_t row = (int64_t)(b0 + i) * T + t;
-          const bool live = t < len[r];
+          const int64_t row = rowb[r] + t;
           sd.hprev[row * H + j] = c_hp[tt][r];
-          if (live) {
-            const float u = c_u[tt][r], c = c_c[tt][r];
-            const float d = dh[i * LD + j] + c_do[tt][r];
-            const float du = d * (c_hp[tt][r] - c), dc = d * (1.0f - u);
-            v_dpu = du * u * (1.0f - u);
-            v_dpc = dc * (1.0f - c * c);
-            dh[i * LD + j] = d * u;
-          }
           sd.dxproj[row * 3 * H + H + j] = v_dpu;
           sd.dxproj[row * 3 * H + 2 * H + j] = v_dpc;
         }
@@ -529,9 +566,12 @@ __global__ __launch_bounds__(64 * NW) void gru_bwd_reg_kernel(const GruArgs a) {
       f32x4 acc[TW];
 #pragma unroll
       for (int tt = 0; tt < TW; ++tt) acc[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      float4 av4[KS / 4];
+#pragma unroll
+      for (int q = 0; q < KS / 4; ++q) av4[q] = *reinterpret_cast<const float4*>(&dpc[lc * LD + lq * KS + 4 * q]);
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        const float av = dpc[lc * LD + ks * 4 + lq];
+        const float av = (ks & 3) == 0 ? av4[ks >> 2].x : (ks & 3) == 1 ? av4[ks >> 2].y : (ks & 3) == 2 ? av4[ks >> 2].z : av4[ks >> 2].w;
 #pragma unroll
         for (int tt = 0; tt < TW; ++tt)
           acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wct[tt][ks], acc[tt], 0, 0, 0);
@@ -539,20 +579,18 @@ __global__ __launch_bounds__(64 * NW) void gru_bwd_reg_kernel(const GruArgs a) {
 #pragma unroll
       for (int tt = 0; tt < TW; ++tt) {
         const int tile = wave + NW * tt;
-        if (tile >= NT) continue;
+        if (!tile_ok(tile)) continue;
         const int j = tile * 16 + lc;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int i = lq * 4 + r;
-          float v_dpr = 0.f;
+          const float rr = c_r[tt][r], hp = c_hp[tt][r];   // both 0 past the length
+          const bool live = t < len[r];
+          const float drh = acc[tt][r];
+          const float v_dpr = live ? drh * hp * rr * (1.0f - rr) : 0.f;
+          dh[i * LD + j] += live ? drh * rr : 0.f;
           if (rok[r]) {
-            const int64_t row = (int64_t)(b0 + i) * T + t;
-            const float rr = c_r[tt][r], hp = c_hp[tt][r];   // both 0 past the length
-            if (t < len[r]) {
-              const float drh = acc[tt][r];
-              v_dpr = drh * hp * rr * (1.0f - rr);
-              dh[i * LD + j] += drh * rr;
-            }
+            const int64_t row = rowb[r] + t;
             sd.dxproj[row * 3 * H + j] = v_dpr;
             sd.rh[row * H + j] = rr * hp;
           }
@@ -566,9 +604,12 @@ __global__ __launch_bounds__(64 * NW) void gru_bwd_reg_kernel(const GruArgs a) {
       f32x4 acc[TW];
 #pragma unroll
       for (int tt = 0; tt < TW; ++tt) acc[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      float4 av4[KS / 2];
+#pragma unroll
+      for (int q = 0; q < KS / 2; ++q) av4[q] = *reinterpret_cast<const float4*>(&dpg[lc * LD2 + lq * 2 * KS + 4 * q]);
 #pragma unroll
       for (int ks = 0; ks < 2 * KS; ++ks) {
-        const float av = dpg[lc * LD2 + ks * 4 + lq];
+        const float av = (ks & 3) == 0 ? av4[ks >> 2].x : (ks & 3) == 1 ? av4[ks >> 2].y : (ks & 3) == 2 ? av4[ks >> 2].z : av4[ks >> 2].w;
 #pragma unroll
         for (int tt = 0; tt < TW; ++tt)
           acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wgt[tt][ks], acc[tt], 0, 0, 0);
@@ -576,7 +617,7 @@ __global__ __launch_bounds__(64 * NW) void gru_bwd_reg_kernel(const GruArgs a) {
 #pragma unroll
       for (int tt = 0; tt < TW; ++tt) {
         const int tile = wave + NW * tt;
-        if (tile >= NT) continue;
+        if (!tile_ok(tile)) continue;
         const int j = tile * 16 + lc;
 #pragma unroll
         for (int r = 0; r < 4; ++r) dh[(lq * 4 + r) * LD + j] += acc[tt][r];
@@ -751,11 +792,18 @@ int score_gru_fwd_multi(GruArgs& a, int nsides, hipStream_t s) {
   const int H = a.H;
   if (gru_reg_ok(H)) {
     dim3 grid(nsides * ((a.B + RRB - 1) / RRB));
-    if (H == 16) hipLaunchKernelGGL((gru_fwd_reg_kernel<16, 4>), grid, dim3(256), 0, s, a);
-    else if (H == 32) hipLaunchKernelGGL((gru_fwd_reg_kernel<32, 4>), grid, dim3(256), 0, s, a);
-    else if (H == 64) hipLaunchKernelGGL((gru_fwd_reg_kernel<64, 4>), grid, dim3(256), 0, s, a);
-    else if (a.nw8) hipLaunchKernelGGL((gru_fwd_reg_kernel<128, 8>), grid, dim3(512), 0, s, a);
-    else hipLaunchKernelGGL((gru_fwd_reg_kernel<128, 4>), grid, dim3(256), 0, s, a);
+    const bool full = a.B % RRB == 0;
+#define LF(Hv, NWv)                                                                                         \
+  do {                                                                                                      \
+    if (full) hipLaunchKernelGGL((gru_fwd_reg_kernel<Hv, NWv, true>), grid, dim3(64 * NWv), 0, s, a);       \
+    else hipLaunchKernelGGL((gru_fwd_reg_kernel<Hv, NWv, false>), grid, dim3(64 * NWv), 0, s, a);           \
+  } while (0)
+    if (H == 16) LF(16, 4);
+    else if (H == 32) LF(32, 4);
+    else if (H == 64) LF(64, 4);
+    else if (a.nw8) LF(128, 8);
+    else LF(128, 4);
+#undef LF
     SCORE_CHECK_LAUNCH();
     return 0;
   }
@@ -773,11 +821,18 @@ int score_gru_bwd_multi(GruArgs& a, int nsides, hipStream_t s) {
   const int H = a.H;
   if (gru_reg_ok(H)) {
     dim3 grid(nsides * ((a.B + RRB - 1) / RRB));
-    if (H == 16) hipLaunchKernelGGL((gru_bwd_reg_kernel<16, 4>), grid, dim3(256), 0, s, a);
-    else if (H == 32) hipLaunchKernelGGL((gru_bwd_reg_kernel<32, 4>), grid, dim3(256), 0, s, a);
-    else if (H == 64) hipLaunchKernelGGL((gru_bwd_reg_kernel<64, 4>), grid, dim3(256), 0, s, a);
-    else if (a.nw8) hipLaunchKernelGGL((gru_bwd_reg_kernel<128, 8>), grid, dim3(512), 0, s, a);
-    else hipLaunchKernelGGL((gru_bwd_reg_kernel<128, 4>), grid, dim3(256), 0, s, a);
+    const bool full = a.B % RRB == 0;
+#define LB(Hv, NWv)                                                                                         \
+  do {                                                                                                      \
+    if (full) hipLaunchKernelGGL((gru_bwd_reg_kernel<Hv, NWv, true>), grid, dim3(64 * NWv), 0, s, a);       \
+    else hipLaunchKernelGGL((gru_bwd_reg_kernel<Hv, NWv, false>), grid, dim3(64 * NWv), 0, s, a);           \
+  } while (0)
+    if (H == 16) LB(16, 4);
+    else if (H == 32) LB(32, 4);
+    else if (H == 64) LB(64, 4);
+    else if (a.nw8) LB(128, 8);
+    else LB(128, 4);
+#undef LB
     SCORE_CHECK_LAUNCH();
     return 0;
   }
