@@ -497,7 +497,9 @@ __global__ __launch_bounds__(64 * NW) void gru_bwd_reg_kernel(const GruArgs a) {
       if (tile < NT) dh[i * LD + j] = (sd.dfinal && rok[r]) ? sd.dfinal[(int64_t)(b0 + i) * H + j] : 0.f;
     }
   }
-  // saved activations of step t, read unconditionally (clamped addresses), zeroed past the length by selects
+  // saved activations of step t, read unconditionally (clamped addresses) one step ahead; the raw values are
+  // zeroed past the length only when the step that uses them starts (a select right after the load would
+  // make the wave wait for it on the spot)
   float n_u[TW][4], n_c[TW][4], n_r[TW][4], n_hp[TW][4], n_do[TW][4];
   auto prefetch = [&](int t) {
     const int tc = max(t, 0);
@@ -506,17 +508,12 @@ __global__ __launch_bounds__(64 * NW) void gru_bwd_reg_kernel(const GruArgs a) {
       const int j = min(wave + NW * tt, NT - 1) * 16 + lc;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const bool ok = t >= 0 && t < len[r];
         const int64_t row = rowb[r] + tc;
-        const float gr = sd.gates[row * 3 * H + j], gu = sd.gates[row * 3 * H + H + j];
-        const float gc = sd.gates[row * 3 * H + 2 * H + j];
-        const float hp = sd.out[(row - (tc > 0 ? 1 : 0)) * sd.ldo + j];
-        const float dd = sd.dout[row * sd.lddo + j];
-        n_r[tt][r] = ok ? gr : 0.f;
-        n_u[tt][r] = ok ? gu : 0.f;
-        n_c[tt][r] = ok ? gc : 0.f;
-        n_hp[tt][r] = (ok && t > 0) ? hp : 0.f;
-        n_do[tt][r] = ok ? dd : 0.f;
+        n_r[tt][r] = sd.gates[row * 3 * H + j];
+        n_u[tt][r] = sd.gates[row * 3 * H + H + j];
+        n_c[tt][r] = sd.gates[row * 3 * H + 2 * H + j];
+        n_hp[tt][r] = sd.out[(row - (tc > 0 ? 1 : 0)) * sd.ldo + j];
+        n_do[tt][r] = sd.dout[row * sd.lddo + j];
       }
     }
   };
@@ -529,8 +526,9 @@ __global__ __launch_bounds__(64 * NW) void gru_bwd_reg_kernel(const GruArgs a) {
     for (int tt = 0; tt < TW; ++tt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        c_u[tt][r] = n_u[tt][r]; c_c[tt][r] = n_c[tt][r]; c_r[tt][r] = n_r[tt][r];
-        c_hp[tt][r] = n_hp[tt][r]; c_do[tt][r] = n_do[tt][r];
+        const bool ok = t < len[r];
+        c_u[tt][r] = ok ? n_u[tt][r] : 0.f; c_c[tt][r] = ok ? n_c[tt][r] : 0.f; c_r[tt][r] = ok ? n_r[tt][r] : 0.f;
+        c_hp[tt][r] = (ok && t > 0) ? n_hp[tt][r] : 0.f; c_do[tt][r] = ok ? n_do[tt][r] : 0.f;
       }
     prefetch(t - 1);
     // phase 1 (elementwise): dpu, dpc ; dh <- dh_tot * u      (selects, no branches: see FULL above)
