@@ -32,7 +32,8 @@ extern "C" {
 
 /* model_type values (train_score.py:170-179 selects the class by name) */
 enum { SCORE_MODEL_SCORE = 0, SCORE_MODEL_RIA = 1, SCORE_MODEL_RCA = 2,
-       SCORE_MODEL_SCORE_USER = 3, SCORE_MODEL_SCORE_ITEM = 4 };
+       SCORE_MODEL_SCORE_USER = 3, SCORE_MODEL_SCORE_ITEM = 4,
+       SCORE_MODEL_RRN = 5 /* slice_models/slice_model.py:155-174: summed 1-hop sets -> GRUs -> head */ };
 
 /* Constructor arguments of SCOREBASE.__init__ (score.py:12-13). */
 typedef struct {

@@ -37,13 +37,16 @@ TF-1.x semantics assumed (reviewed, not checkable here):
  10. d(emb_mtx * mask) is dense, so Adam runs on every table row every step.
  11. tf.where(mask, fc3, -2**32+1) then softmax over T (score.py:179-181).
  12. softmax is max-subtracted.
+
+Model types: SCORE and its ablations (score.py:188-369) and RRN, the slice baseline that shares the feed
+tuple, table, GRUs, head, loss and optimizer (code/slice_models/slice_model.py:11-174).
 """
 import math
 
 import numpy as np
 import torch
 
-MODEL_TYPES = ("SCORE", "RIA", "RCA", "SCORE_USER", "SCORE_ITEM")
+MODEL_TYPES = ("SCORE", "RIA", "RCA", "SCORE_USER", "SCORE_ITEM", "RRN")
 BN_EPS = 1e-3
 LOGLOSS_EPS = 1e-7
 ADAM_B1, ADAM_B2, ADAM_EPS = 0.9, 0.999, 1e-8
@@ -64,7 +67,7 @@ class Cfg(object):
         # attention key width: score.py:211 (SCORE*), :285 (RCA: no atten_info)
         if model_type == "RCA":
             self.Dk = 2 * hidden_size
-        elif model_type == "RIA":
+        elif model_type in ("RIA", "RRN"):
             self.Dk = 0
         else:
             self.Dk = 2 * hidden_size + 4 * obj_per_time_slice
@@ -93,16 +96,18 @@ def param_spec(cfg):
         spec.append((base + "/kernel", (i, o), "glorot", True))
         spec.append((base + "/bias", (o,), "zeros", False))
 
-    if c.model_type != "RCA":
+    if c.model_type not in ("RCA", "RRN"):
         dense(3 * c.Di, 1)          # co_attention(user_1hop, item_2hop, target_item)
         dense(3 * c.Du, 1)          # co_attention(user_2hop, item_1hop, target_user)
     for side in ("gru_user_side", "gru_item_side"):
         i = c.Di + c.Du
+        if c.model_type == "RRN":   # slice_model.py:159-160: the summed 1-hop sets only
+            i = c.Di if side == "gru_user_side" else c.Du
         spec.append((side + "/gru_cell/gates/kernel", (i + c.H, 2 * c.H), "glorot", True))
         spec.append((side + "/gru_cell/gates/bias", (2 * c.H,), "ones", False))
         spec.append((side + "/gru_cell/candidate/kernel", (i + c.H, c.H), "glorot", True))
         spec.append((side + "/gru_cell/candidate/bias", (c.H,), "zeros", False))
-    if c.model_type != "RIA":
+    if c.model_type not in ("RIA", "RRN"):
         dense(c.Du + c.Di, c.Dk)    # query projection, score.py:172
         dense(4 * c.Dk, 80)
         dense(80, 40)
@@ -225,7 +230,9 @@ def forward_literal(cfg, params, batch, keep_prob=1.0, dropout_masks=None):
     out = {"user_1hop": user_1hop, "user_2hop": user_2hop, "item_1hop": item_1hop,
            "item_2hop": item_2hop, "target_item": target_item, "target_user": target_user}
 
-    if c.model_type == "RCA":                                # score.py:266-269
+    if c.model_type == "RRN":                                # slice_models/slice_model.py:159-160
+        user_side, item_side, atten_info = user_1hop.sum(2), item_1hop.sum(2), None
+    elif c.model_type == "RCA":                              # score.py:266-269
         u1s, u2s = user_1hop.sum(2), user_2hop.sum(2)
         i1s, i2s = item_1hop.sum(2), item_2hop.sum(2)
         atten_info = None
@@ -238,8 +245,9 @@ def forward_literal(cfg, params, batch, keep_prob=1.0, dropout_masks=None):
             atten_info = info_item + info_user               # score.py:237
         else:
             atten_info = np.concatenate([info_item, info_user], axis=2)
-    user_side = np.concatenate([u1s, u2s], axis=2)
-    item_side = np.concatenate([i1s, i2s], axis=2)
+    if c.model_type != "RRN":
+        user_side = np.concatenate([u1s, u2s], axis=2)
+        item_side = np.concatenate([i1s, i2s], axis=2)
     out.update(user_side=user_side, item_side=item_side, atten_info=atten_info)
 
     gp = lambda s, n: P[s + "/gru_cell/" + n]
@@ -251,7 +259,7 @@ def forward_literal(cfg, params, batch, keep_prob=1.0, dropout_masks=None):
                           gp("gru_item_side", "candidate/bias"), c.H)
     out.update(user_rep=ur, item_rep=ir)
 
-    if c.model_type == "RIA":                                # score.py:249
+    if c.model_type in ("RIA", "RRN"):                       # score.py:249 / slice_model.py:170
         inp = np.concatenate([uh, ih, target_item, target_user], axis=1)
     else:
         query = np.concatenate([target_user, target_item], axis=1)
@@ -348,7 +356,9 @@ def forward(cfg, P, batch, keep_prob=1.0, dropout_masks=None, reg_lambda=0.0):
     mask = torch.arange(c.T)[None, :] < length[:, None]       # [B,T] bool
     out = {"target_item": target_item, "target_user": target_user}
 
-    if c.model_type == "RCA":
+    if c.model_type == "RRN":
+        user_side, item_side, atten_info = user_1hop.sum(2), item_1hop.sum(2), None
+    elif c.model_type == "RCA":
         u1s, u2s = user_1hop.sum(2), user_2hop.sum(2)
         i1s, i2s = item_1hop.sum(2), item_2hop.sum(2)
         atten_info = None
@@ -359,8 +369,9 @@ def forward(cfg, P, batch, keep_prob=1.0, dropout_masks=None, reg_lambda=0.0):
             user_2hop, item_1hop, target_user, P["dense_1/kernel"], P["dense_1/bias"])
         atten_info = (info_item + info_user) if c.model_type == "RIA" \
             else torch.cat([info_item, info_user], 2)
-    user_side = torch.cat([u1s, u2s], 2)
-    item_side = torch.cat([i1s, i2s], 2)
+    if c.model_type != "RRN":
+        user_side = torch.cat([u1s, u2s], 2)
+        item_side = torch.cat([i1s, i2s], 2)
     out.update(user_side=user_side, item_side=item_side, atten_info=atten_info)
 
     gp = lambda s, n: P[s + "/gru_cell/" + n]
@@ -370,7 +381,7 @@ def forward(cfg, P, batch, keep_prob=1.0, dropout_masks=None, reg_lambda=0.0):
                   gp("gru_item_side", "candidate/kernel"), gp("gru_item_side", "candidate/bias"), c.H)
     out.update(user_rep=ur, item_rep=ir)
 
-    if c.model_type == "RIA":
+    if c.model_type in ("RIA", "RRN"):
         inp = torch.cat([uh, ih, target_item, target_user], 1)
     else:
         query = torch.cat([target_user, target_item], 1)

@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libscore_hip.so")
 
-MODEL_TYPES = {"SCORE": 0, "RIA": 1, "RCA": 2, "SCORE_USER": 3, "SCORE_ITEM": 4}
+MODEL_TYPES = {"SCORE": 0, "RIA": 1, "RCA": 2, "SCORE_USER": 3, "SCORE_ITEM": 4, "RRN": 5}
 
 c_f = C.c_void_p   # device float*
 c_i = C.c_void_p   # device int32*

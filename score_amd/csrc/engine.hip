@@ -17,6 +17,7 @@ struct Dims {
   int64_t N;
   int D, H, T, K, Fu, Fi, mt;
   int Du, Di, I, Dq, NI, Dk, Dhead, nstate;
+  int Is[2];       // GRU input width per side (user, item): I, except RRN (its 1-hop sums only)
   bool coattn, attn;
   int off_u, off_i, off_ti, off_tu;  // columns of head_inp
 };
@@ -26,12 +27,16 @@ int make_dims(const score_config_t* c, Dims* d) {
   d->N = c->feature_size; d->D = c->eb_dim; d->H = c->hidden_size; d->T = c->max_time_len;
   d->K = c->obj_per_time_slice; d->Fu = c->user_fnum; d->Fi = c->item_fnum; d->mt = c->model_type;
   if (d->N <= 0 || d->D <= 0 || (d->D & 3) || d->D > 256 || d->H <= 0 || d->T <= 0 || d->K <= 0 || d->K > 32 ||
-      d->Fu <= 0 || d->Fi <= 0 || d->mt < 0 || d->mt > 4)
+      d->Fu <= 0 || d->Fi <= 0 || d->mt < 0 || d->mt > SCORE_MODEL_RRN)
     return SCORE_E_SHAPE;
   d->Du = d->Fu * d->D; d->Di = d->Fi * d->D; d->I = d->Di + d->Du; d->Dq = d->Du + d->Di;
-  d->coattn = d->mt != SCORE_MODEL_RCA;
-  d->attn = d->mt != SCORE_MODEL_RIA;
-  d->NI = (d->mt == SCORE_MODEL_RCA || d->mt == SCORE_MODEL_RIA) ? 0 : 4 * d->K;
+  const bool rrn = d->mt == SCORE_MODEL_RRN;
+  d->coattn = d->mt != SCORE_MODEL_RCA && !rrn;
+  d->attn = d->mt != SCORE_MODEL_RIA && !rrn;
+  d->NI = (d->mt == SCORE_MODEL_RCA || d->mt == SCORE_MODEL_RIA || rrn) ? 0 : 4 * d->K;
+  // RRN (slice_model.py:159-160): user side = sum_k user_1hop (item features), item side = sum_k item_1hop
+  d->Is[0] = rrn ? d->Di : d->I;
+  d->Is[1] = rrn ? d->Du : d->I;
   d->Dk = d->attn ? 2 * d->H + d->NI : 0;
   d->nstate = (d->mt == SCORE_MODEL_SCORE_USER || d->mt == SCORE_MODEL_SCORE_ITEM) ? 1 : 2;
   d->Dhead = d->nstate * d->H + d->Di + d->Du;
@@ -74,9 +79,9 @@ int build_layout(const Dims& d, score_param_entry_t* out, int max_entries, Param
   const char* sides[2] = {"gru_user_side", "gru_item_side"};
   for (int s = 0; s < 2; ++s) {
     char b[64];
-    snprintf(b, 64, "%s/gru_cell/gates/kernel", sides[s]); add(b, d.I + d.H, 2 * d.H, 1, 2);
+    snprintf(b, 64, "%s/gru_cell/gates/kernel", sides[s]); add(b, d.Is[s] + d.H, 2 * d.H, 1, 2);
     snprintf(b, 64, "%s/gru_cell/gates/bias", sides[s]); add(b, 2 * d.H, 0, 0, 1);
-    snprintf(b, 64, "%s/gru_cell/candidate/kernel", sides[s]); add(b, d.I + d.H, d.H, 1, 2);
+    snprintf(b, 64, "%s/gru_cell/candidate/kernel", sides[s]); add(b, d.Is[s] + d.H, d.H, 1, 2);
     snprintf(b, 64, "%s/gru_cell/candidate/bias", sides[s]); add(b, d.H, 0, 0, 0);
   }
   if (d.attn) { dense(d.Dq, d.Dk); dense(4 * d.Dk, AT1); dense(AT1, AT2); dense(AT2, 1); }
@@ -411,16 +416,16 @@ extern "C" int score_forward(const score_config_t* cfg, const score_state_t* st,
     ga.B = B; ga.T = T; ga.H = H; ga.length = bt->length; ga.nw8 = 1;
     ga.tmp = ws + w.gru_tmp; ga.tmp_floats = 10 * (int64_t)B * H; ga.x3 = x3 != 0;   // H = 128: two waves per SIMD hide the LDS/epilogue latency (measured -0.08 ms/step)
     G(score_launch_gru_wxcat(W + P.gk[0], W + P.ck[0], W + P.gb[0], W + P.cb[0], W + P.gk[1], W + P.ck[1], W + P.gb[1],
-                             W + P.cb[1], d.I, H, ws + w.wxcat, s));
+                             W + P.cb[1], d.Is[0], d.Is[1], d.I, H, ws + w.wxcat, s));
     for (int sd = 0; sd < 2; ++sd) {
       float* xp = ws + w.xproj[sd];
       // x . [Wx_gates | Wx_cand] + [b_gates | b_cand]: one GEMM per side on the concatenated copy
       const float* cat = ws + w.wxcat + (int64_t)sd * (d.I + 1) * 3 * H;
-      G(gemm_mode_call(x3, 0, BT, 3 * H, d.I, ws + w.xside[sd], d.I, cat, 3 * H, xp, 3 * H, cat + (int64_t)d.I * 3 * H,
+      G(gemm_mode_call(x3, 0, BT, 3 * H, d.Is[sd], ws + w.xside[sd], d.I, cat, 3 * H, xp, 3 * H, cat + (int64_t)d.Is[sd] * 3 * H,
                        GF_BIAS, 1.f, nullptr, 0, scratch, w.scratch_floats, s));
       GruSide& g = ga.s[sd];
-      g.xproj = xp; g.Wg = W + P.gk[sd] + (int64_t)d.I * 2 * H; g.ldwg = 2 * H;
-      g.Wc = W + P.ck[sd] + (int64_t)d.I * H; g.ldwc = H;
+      g.xproj = xp; g.Wg = W + P.gk[sd] + (int64_t)d.Is[sd] * 2 * H; g.ldwg = 2 * H;
+      g.Wc = W + P.ck[sd] + (int64_t)d.Is[sd] * H; g.ldwc = H;
       g.out = ws + w.gru_out[sd]; g.ldo = H; g.gates = ws + w.gates[sd]; g.final_state = ws + w.gru_final[sd];
     }
     G(score_gru_fwd_multi(ga, 2, s));
@@ -574,8 +579,8 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
     ga.tmp = ws + w.gru_tmp; ga.tmp_floats = 10 * (int64_t)B * H; ga.x3 = x3 != 0;   // H = 128: two waves per SIMD hide the LDS/epilogue latency (measured -0.08 ms/step)
     for (int sd = 0; sd < 2; ++sd) {
       GruSide& g = ga.s[sd];
-      g.Wg = W + P.gk[sd] + (int64_t)d.I * 2 * H; g.ldwg = 2 * H;
-      g.Wc = W + P.ck[sd] + (int64_t)d.I * H; g.ldwc = H;
+      g.Wg = W + P.gk[sd] + (int64_t)d.Is[sd] * 2 * H; g.ldwg = 2 * H;
+      g.Wc = W + P.ck[sd] + (int64_t)d.Is[sd] * H; g.ldwc = H;
       g.out = ws + w.gru_out[sd]; g.ldo = H; g.gates = ws + w.gates[sd];
       g.dout = ws + w.dgru[sd]; g.lddo = H; g.dfinal = dfinal[sd];
       g.dxproj = ws + w.dxproj[sd]; g.rh = ws + w.rh[sd]; g.hprev = ws + w.hprev[sd];
@@ -587,14 +592,18 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
     // kernels are [x ; h] row blocks (TF GRUCell): x rows first.  x part of both kernels in one product
     // on the concatenated layout, then split into the two variables' gradients
     const float* cat = ws + w.wxcat + (int64_t)sd * (d.I + 1) * 3 * H;
-    G(gemm_queue_add(&gq, d.I, 3 * H, BT, ws + w.xside[sd], d.I, dxp, 3 * H, ws + w.dwxcat + (int64_t)sd * d.I * 3 * H,
+    G(gemm_queue_add(&gq, d.Is[sd], 3 * H, BT, ws + w.xside[sd], d.I, dxp, 3 * H, ws + w.dwxcat + (int64_t)sd * d.I * 3 * H,
                      3 * H));                       // (split into the two variables' gradients after the flush)
-    G(gemm_queue_add(&gq, H, 2 * H, BT, ws + w.hprev[sd], H, dxp, 3 * H, gw + P.gk[sd] + (int64_t)d.I * 2 * H, 2 * H));
-    G(gemm_queue_add(&gq, H, H, BT, ws + w.rh[sd], H, dxp + 2 * H, 3 * H, gw + P.ck[sd] + (int64_t)d.I * H, H));
+    G(gemm_queue_add(&gq, H, 2 * H, BT, ws + w.hprev[sd], H, dxp, 3 * H, gw + P.gk[sd] + (int64_t)d.Is[sd] * 2 * H, 2 * H));
+    G(gemm_queue_add(&gq, H, H, BT, ws + w.rh[sd], H, dxp + 2 * H, 3 * H, gw + P.ck[sd] + (int64_t)d.Is[sd] * H, H));
     G(colsum_queue_add(&cq, dxp, BT, 2 * H, 3 * H, gw + P.gb[sd], 0));
     G(colsum_queue_add(&cq, dxp + 2 * H, BT, H, 3 * H, gw + P.cb[sd], 0));
     // d x = [dgates | dcand] . [Wx_gates | Wx_cand]^T
-    G(gemm_mode_call(x3, 1, BT, d.I, 3 * H, dxp, 3 * H, cat, 3 * H, ws + w.dxside[sd], d.I, nullptr, 0, 1.f, nullptr, 0,
+    if (d.Is[sd] != d.I) {   // RRN: the 2-hop columns of this side carry no gradient
+      he = hipMemsetAsync(ws + w.dxside[sd], 0, (int64_t)BT * d.I * sizeof(float), s);
+      if (he != hipSuccess) return (int)he;
+    }
+    G(gemm_mode_call(x3, 1, BT, d.Is[sd], 3 * H, dxp, 3 * H, cat, 3 * H, ws + w.dxside[sd], d.I, nullptr, 0, 1.f, nullptr, 0,
                      scratch, SF, s));
   }
 
@@ -656,7 +665,7 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
   G(gemm_queue_flush(&gq, x3 != 0, ws + w.dwslab + slab_half, w.dwslab_floats - slab_half, s));
   if (d.attn) G(score_launch_attn_w1_grad(d.Dk, AT1, ws + w.dweff, ws + w.dwq, gw + P.at_w[1], s));
   for (int sd = 0; sd < 2; ++sd)
-    G(score_launch_gru_wxsplit(ws + w.dwxcat + (int64_t)sd * d.I * 3 * H, d.I, H, gw + P.gk[sd], gw + P.ck[sd], s));
+    G(score_launch_gru_wxsplit(ws + w.dwxcat + (int64_t)sd * d.I * 3 * H, d.Is[sd], H, gw + P.gk[sd], gw + P.ck[sd], s));
   G(colsum_queue_flush(&cq, ws + w.cs_part, w.cs_part_floats, s));
   EV(5);
   return 0;

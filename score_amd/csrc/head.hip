@@ -387,14 +387,17 @@ int score_launch_copy2d(int64_t rows, int cols, const float* src, int lds_, floa
 __global__ void gru_wxcat_kernel(const float* __restrict__ gk0, const float* __restrict__ ck0,
                                  const float* __restrict__ gb0, const float* __restrict__ cb0,
                                  const float* __restrict__ gk1, const float* __restrict__ ck1,
-                                 const float* __restrict__ gb1, const float* __restrict__ cb1, int I, int H,
-                                 float* __restrict__ cat) {
-  const int64_t per = (int64_t)(I + 1) * 3 * H;
+                                 const float* __restrict__ gb1, const float* __restrict__ cb1, int I0, int I1, int Imax,
+                                 int H, float* __restrict__ cat) {
+  // side sd's block is [(Imax+1)][3H]: rows [0, I_sd) the x rows of both kernels, row I_sd the biases
+  const int64_t per = (int64_t)(Imax + 1) * 3 * H;
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= 2 * per) return;
   const int sd = i >= per;
   const int64_t l = i - sd * per;
   const int r = (int)(l / (3 * H)), j = (int)(l - (int64_t)r * 3 * H);
+  const int I = sd ? I1 : I0;
+  if (r > I) return;
   const float* gk = sd ? gk1 : gk0; const float* ck = sd ? ck1 : ck0;
   const float* gb = sd ? gb1 : gb0; const float* cb = sd ? cb1 : cb0;
   float v;
@@ -403,11 +406,11 @@ __global__ void gru_wxcat_kernel(const float* __restrict__ gk0, const float* __r
   cat[i] = v;
 }
 int score_launch_gru_wxcat(const float* gk0, const float* ck0, const float* gb0, const float* cb0, const float* gk1,
-                           const float* ck1, const float* gb1, const float* cb1, int I, int H, float* cat,
-                           hipStream_t s) {
-  int64_t n = 2 * (int64_t)(I + 1) * 3 * H;
+                           const float* ck1, const float* gb1, const float* cb1, int I0, int I1, int Imax, int H,
+                           float* cat, hipStream_t s) {
+  int64_t n = 2 * (int64_t)(Imax + 1) * 3 * H;
   hipLaunchKernelGGL(gru_wxcat_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, s, gk0, ck0, gb0, cb0, gk1, ck1,
-                     gb1, cb1, I, H, cat);
+                     gb1, cb1, I0, I1, Imax, H, cat);
   SCORE_CHECK_LAUNCH();
   return 0;
 }

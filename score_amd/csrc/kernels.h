@@ -92,8 +92,8 @@ int score_launch_head_out(int B, int NF, const float* f2, const float* w3, const
 int score_launch_outer_relu_bwd(int B, int NF, const float* dlogit, const float* w, const float* f, float keep,
                                 float* dz, hipStream_t s);
 int score_launch_gru_wxcat(const float* gk0, const float* ck0, const float* gb0, const float* cb0, const float* gk1,
-                           const float* ck1, const float* gb1, const float* cb1, int I, int H, float* cat,
-                           hipStream_t s);
+                           const float* ck1, const float* gb1, const float* cb1, int I0, int I1, int Imax, int H,
+                           float* cat, hipStream_t s);
 int score_launch_gru_wxsplit(const float* dcat, int I, int H, float* dgk, float* dck, hipStream_t s);
 int score_launch_copy2d(int64_t rows, int cols, const float* src, int lds_, float* dst, int ldd, hipStream_t s);
 

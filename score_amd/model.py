@@ -385,4 +385,10 @@ class SCORE_ITEM(SCOREBASE):
     model_type = "SCORE_ITEM"
 
 
-MODELS = {"SCORE": SCORE, "RIA": RIA, "RCA": RCA, "SCORE_USER": SCORE_USER, "SCORE_ITEM": SCORE_ITEM}
+class RRN(SCOREBASE):
+    """slice_models/slice_model.py:155-174: the summed 1-hop sets feed the two GRUs, final states + targets
+    feed the same head; same constructor and train/eval/save/restore (SliceBaseModel, :11-152)."""
+    model_type = "RRN"
+
+
+MODELS = {"SCORE": SCORE, "RIA": RIA, "RCA": RCA, "SCORE_USER": SCORE_USER, "SCORE_ITEM": SCORE_ITEM, "RRN": RRN}

@@ -37,7 +37,7 @@ def adam_close(got, want, grad, max_move, atol):
     return bool(ok_well.all() and ok_rest.all())
 
 
-GOLD = ["g1_tiny_score", "g1_tiny_ria", "g1_tiny_rca", "g1_tiny_score_user", "g1_tiny_score_item",
+GOLD = ["g1_tiny_score", "g1_tiny_ria", "g1_tiny_rca", "g1_tiny_score_user", "g1_tiny_score_item", "g1_tiny_rrn",
         "g3_edge_f34_b3", "g3_edge_f11_b6", "g3_edge_f12_b2"]
 
 
@@ -59,7 +59,8 @@ def test_golden_forward_backward_adam(name):
     logit = ws[lay.logit:lay.logit + B].cpu().numpy()
     assert np.abs(logit - z["fwd/logit"]).max() < LOGIT_TOL
     xs = m.ws_tensor(B, "xside", (2, B, T, I)).cpu().numpy()
-    assert close(xs[0], z["fwd/user_side"])[0] and close(xs[1], z["fwd/item_side"])[0]
+    us, its = z["fwd/user_side"], z["fwd/item_side"]      # (RRN: the summed 1-hop sets only -- the leading columns)
+    assert close(xs[0][..., :us.shape[-1]], us)[0] and close(xs[1][..., :its.shape[-1]], its)[0]
     go = m.ws_tensor(B, "gru_out", (2, B, T, cfg.H)).cpu().numpy()
     assert close(go[0], z["fwd/user_rep"])[0] and close(go[1], z["fwd/item_rep"])[0]
     hi = m.ws_tensor(B, "head_inp", (B, cfg.Dhead)).cpu().numpy()

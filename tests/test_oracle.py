@@ -7,7 +7,7 @@ import torch
 from oracle import score_oracle as so
 from helpers import load_golden, random_batch
 
-GOLD = ["g1_tiny_score", "g1_tiny_ria", "g1_tiny_rca", "g1_tiny_score_user", "g1_tiny_score_item",
+GOLD = ["g1_tiny_score", "g1_tiny_ria", "g1_tiny_rca", "g1_tiny_score_user", "g1_tiny_score_item", "g1_tiny_rrn",
         "g3_edge_f34_b3", "g3_edge_f11_b6", "g3_edge_f12_b2"]
 
 
