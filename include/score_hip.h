@@ -138,7 +138,9 @@ int score_coattn_bwd(const float* table, float* grad_table, int64_t n_rows, int3
  * reduced dim).  flags: 1 add bias[N], 2 relu, 4 accumulate into C,
  * 8 dropout (tf.nn.dropout: x/keep * mask; mask from drop_mask bytes or, if null,
  * from a counter hash of drop_seed), 16 use the bf16x3 matrix-core product (fp32-accurate,
- * see score_state_t.gemm_mode) on the shapes where it measured faster, 32 use it whenever legal.
+ * see score_state_t.gemm_mode) on the shapes where it measured faster, 32 use it whenever legal,
+ * 64 relu backward fused: drop_mask then points at the layer's fp32 output Y [M,N] and the result is
+ * C = [Y > 0] * (A.B) / keep_prob (not together with 8).
  * Bits 16-30: bias row group g (0 = the usual single bias row): bias is [ceil(M/g), N] and
  * output row r adds bias row r/g -- the per-sample term of the folded attention layer.
  * scratch is used for split-K. */

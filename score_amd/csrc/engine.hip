@@ -10,7 +10,7 @@
 
 namespace {
 
-enum { GF_BIAS = 1, GF_RELU = 2, GF_ACC = 4, GF_DROP = 8, GF_X3 = 16 };
+enum { GF_BIAS = 1, GF_RELU = 2, GF_ACC = 4, GF_DROP = 8, GF_X3 = 16, GF_RELUGRAD = 64 };
 const int FC1 = 200, FC2 = 80, AT1 = 80, AT2 = 40;
 
 struct Dims {
@@ -135,7 +135,7 @@ struct WS {
   int64_t pcoef[2], dzcoef[2], dtgt, keys_in, keys_out, vals_in, vals_out, sort_temp, partials;
   int64_t n_occ, sort_temp_bytes, partial_floats;
   int64_t uid, unique_rows, meta, remap[6];
-  int64_t ca_slab, ca_slab_floats, cs_part, cs_part_floats, wxcat, dwxcat;
+  int64_t ca_slab, ca_slab_floats, cs_part, cs_part_floats, wxcat;
   int64_t scratch_floats, total;
 };
 
@@ -186,7 +186,6 @@ void build_ws(const Dims& d, int B, WS* w) {
   w->cs_part_floats = 1 << 21;
   w->cs_part = take(w->cs_part_floats);
   w->wxcat = take(2 * (int64_t)(d.I + 1) * 3 * d.H);
-  w->dwxcat = take(2 * (int64_t)d.I * 3 * d.H);
   w->dgstage = take((int64_t)B * d.Dhead);
   w->scratch2 = take(w->scratch_floats);           // split-K scratch of the side stream's products
   w->gru_tmp = take(10 * (int64_t)B * d.H);        // step-by-step recurrence (hidden sizes without a register kernel)
@@ -502,9 +501,8 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
   // fc2
   G(gemm_queue_add(&gq, FC1, FC2, B, ws + w.f1, FC1, ws + w.dz2, FC2, gw + P.fc_w[1], FC2));
   G(colsum_queue_add(&cq, ws + w.dz2, B, FC2, FC2, gw + P.fc_b[1], 0));
-  G(gemm_mode_call(x3, 1, B, FC1, FC2, ws + w.dz2, FC2, W + P.fc_w[1], FC2, ws + w.dz1, FC1, nullptr, 0, 1.f, nullptr, 0,
-               scratch, SF, s));
-  G(score_launch_relu_bwd(ws + w.dz1, ws + w.f1, B, FC1, FC1, FC1, keep_prob, s));
+  G(gemm_mode_call(x3, 1, B, FC1, FC2, ws + w.dz2, FC2, W + P.fc_w[1], FC2, ws + w.dz1, FC1, nullptr, GF_RELUGRAD, keep_prob,
+                   reinterpret_cast<const uint8_t*>(ws + w.f1), 0, scratch, SF, s));   // relu/dropout mask of fc1 in the epilogue
   // fc1 + bn1
   G(gemm_queue_add(&gq, d.Dhead, FC1, B, ws + w.bn, d.Dhead, ws + w.dz1, FC1, gw + P.fc_w[0], FC1));
   G(colsum_queue_add(&cq, ws + w.dz1, B, FC1, FC1, gw + P.fc_b[0], 0));
@@ -527,9 +525,8 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
     // dense_4 (80 -> 40); da2 is already relu-masked
     G(gemm_queue_add(&gq, AT1, AT2, BT, ws + w.a1, AT1, ws + w.da2, AT2, gw + P.at_w[2], AT2));
     G(colsum_queue_add(&cq, ws + w.da2, BT, AT2, AT2, gw + P.at_b[2], 0));
-    G(gemm_mode_call(x3, 1, BT, AT1, AT2, ws + w.da2, AT2, W + P.at_w[2], AT2, ws + w.da1, AT1, nullptr, 0, 1.f, nullptr,
-                 0, scratch, SF, s));
-    G(score_launch_relu_bwd(ws + w.da1, ws + w.a1, BT, AT1, AT1, AT1, 1.f, s));
+    G(gemm_mode_call(x3, 1, BT, AT1, AT2, ws + w.da2, AT2, W + P.at_w[2], AT2, ws + w.da1, AT1, nullptr, GF_RELUGRAD, 1.f,
+                     reinterpret_cast<const uint8_t*>(ws + w.a1), 0, scratch, SF, s));    // relu mask of dense_3 in the epilogue
     // dense_3 (4Dk -> 80), folded: weight gradient from [k, q*k]^T da1 and q^T sum_t da1
     G(gemm_queue_add(&gq, 2 * d.Dk, AT1, BT, ws + w.ainp, 2 * d.Dk, ws + w.da1, AT1, ws + w.dweff, AT1));
     G(colsum_queue_add(&cq, ws + w.da1, BT, AT1, AT1, gw + P.at_b[1], 0));
@@ -592,8 +589,9 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
     // kernels are [x ; h] row blocks (TF GRUCell): x rows first.  x part of both kernels in one product
     // on the concatenated layout, then split into the two variables' gradients
     const float* cat = ws + w.wxcat + (int64_t)sd * (d.I + 1) * 3 * H;
-    G(gemm_queue_add(&gq, d.Is[sd], 3 * H, BT, ws + w.xside[sd], d.I, dxp, 3 * H, ws + w.dwxcat + (int64_t)sd * d.I * 3 * H,
-                     3 * H));                       // (split into the two variables' gradients after the flush)
+    // x rows of the two kernels straight into their gradients (same A panel, the column tiles of [dgates | dcand])
+    G(gemm_queue_add(&gq, d.Is[sd], 2 * H, BT, ws + w.xside[sd], d.I, dxp, 3 * H, gw + P.gk[sd], 2 * H));
+    G(gemm_queue_add(&gq, d.Is[sd], H, BT, ws + w.xside[sd], d.I, dxp + 2 * H, 3 * H, gw + P.ck[sd], H));
     G(gemm_queue_add(&gq, H, 2 * H, BT, ws + w.hprev[sd], H, dxp, 3 * H, gw + P.gk[sd] + (int64_t)d.Is[sd] * 2 * H, 2 * H));
     G(gemm_queue_add(&gq, H, H, BT, ws + w.rh[sd], H, dxp + 2 * H, 3 * H, gw + P.ck[sd] + (int64_t)d.Is[sd] * H, H));
     G(colsum_queue_add(&cq, dxp, BT, 2 * H, 3 * H, gw + P.gb[sd], 0));
@@ -664,8 +662,6 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
   if (side) HIPTRY(hipStreamWaitEvent(s, side->join, 0));
   G(gemm_queue_flush(&gq, x3 != 0, ws + w.dwslab + slab_half, w.dwslab_floats - slab_half, s));
   if (d.attn) G(score_launch_attn_w1_grad(d.Dk, AT1, ws + w.dweff, ws + w.dwq, gw + P.at_w[1], s));
-  for (int sd = 0; sd < 2; ++sd)
-    G(score_launch_gru_wxsplit(ws + w.dwxcat + (int64_t)sd * d.I * 3 * H, d.Is[sd], H, gw + P.gk[sd], gw + P.ck[sd], s));
   G(colsum_queue_flush(&cq, ws + w.cs_part, w.cs_part_floats, s));
   EV(5);
   return 0;

@@ -3,7 +3,8 @@
 // BK = 16 (a 32-deep tile measured 6 % slower on this model's shapes) staged through LDS with a register
 // prefetch of the next tile; NN / NT / TN operand layouts (see score_hip.h); split-K with a fixed-order
 // slab reduce.  Large products are routed to gemm_bf16x3.hip when the caller allows it.  Also here: the
-// deferred multi-job column sum (bias gradients, slab reductions) and the relu mask kernel.
+// deferred multi-job column sum (bias gradients, slab reductions), the grouped launches and the deferred
+// weight-gradient queue.
 #include "common.h"
 #include "kernels.h"
 
@@ -15,8 +16,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define GEMM_SPLITK_MIN_CHUNK 128   // ... and never into chunks shorter than this (tools/gemm_small_ab.py)
 #endif
 
-enum { F_BIAS = 1, F_RELU = 2, F_ACC = 4, F_DROP = 8, F_X3 = 16 };
-#define KF_MASK (15 | 0x7FFF0000)   // what the kernels see: epilogue bits + the bias row group
+enum { F_BIAS = 1, F_RELU = 2, F_ACC = 4, F_DROP = 8, F_X3 = 16, F_X3F = 32, F_RELUGRAD = 64 };
+#define KF_MASK (15 | 64 | 0x7FFF0000)   // what the kernels see: epilogue bits + the bias row group
 
 // bias element of (row, col): one bias row, or one per group of g = flags >> 16 output rows
 __device__ __forceinline__ int64_t bias_index(int flags, int row, int col, int N) {
@@ -32,6 +33,10 @@ __device__ __forceinline__ float epilogue(float v, int row, int col, int N, cons
     uint64_t e = (uint64_t)row * (uint64_t)N + (uint64_t)col;
     bool on = mask ? (mask[e] != 0) : (hash_uniform(seed, e) < keep);
     v = on ? v / keep : 0.f;  // tf.nn.dropout: x / keep_prob * binary mask
+  }
+  if (flags & F_RELUGRAD) {   // backward of relu (+dropout): `mask` carries the layer's fp32 output Y [M,N]
+    const float y = reinterpret_cast<const float*>(mask)[(int64_t)row * N + col];
+    v = y > 0.f ? v / keep : 0.f;
   }
   return v;
 }
@@ -237,6 +242,7 @@ extern "C" int score_gemm(int32_t trans, int32_t M, int32_t N, int32_t K, const 
   if (trans < 0 || trans > 2) return SCORE_E_BADARG;
   if ((flags & F_BIAS) && !bias) return SCORE_E_BADARG;
   if (flags < 0) return SCORE_E_BADARG;
+  if ((flags & F_RELUGRAD) && (!drop_mask || (flags & F_DROP))) return SCORE_E_BADARG;
   hipStream_t s = (hipStream_t)stream;
   // k-contiguous operands are staged with 16-B loads: need K % 4 == 0, ld % 4 == 0, 16-B aligned base
   const bool a_kc = trans != 2, b_kc = trans == 1;
@@ -602,26 +608,5 @@ int colsum_queue_flush(ColsumJobs* q, float* part, int64_t part_floats, hipStrea
   SCORE_CHECK_LAUNCH();
   q->n = 0;
   q->part_used = 0;
-  return 0;
-}
-
-// dY <- dY * [Y > 0] / divisor      (relu / relu+dropout backward)
-__global__ void relu_bwd_kernel(float* __restrict__ dY, const float* __restrict__ Y, int64_t rows, int cols,
-                                int ldd, int ldy, float divisor) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= rows * cols) return;
-  int64_t r = i / cols;
-  int c = (int)(i - r * cols);
-  float y = Y[r * ldy + c];
-  float* d = dY + r * ldd + c;
-  *d = y > 0.f ? *d / divisor : 0.f;
-}
-
-int score_launch_relu_bwd(float* dY, const float* Y, int64_t rows, int cols, int ldd, int ldy, float divisor,
-                          hipStream_t s) {
-  int64_t n = rows * cols;
-  hipLaunchKernelGGL(relu_bwd_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, s, dY, Y, rows, cols, ldd,
-                     ldy, divisor);
-  SCORE_CHECK_LAUNCH();
   return 0;
 }

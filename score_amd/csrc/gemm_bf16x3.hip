@@ -26,7 +26,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define TBK 32
 #define TLD 40   // bf16 per LDS row (32 + 8 pad)
 
-enum { XF_BIAS = 1, XF_RELU = 2, XF_ACC = 4, XF_DROP = 8 };
+enum { XF_BIAS = 1, XF_RELU = 2, XF_ACC = 4, XF_DROP = 8, XF_RELUGRAD = 64 };
 
 __device__ __forceinline__ float x3_epilogue(float v, int row, int col, int N, const float* bias, int flags,
                                              float keep, const uint8_t* mask, uint64_t seed) {
@@ -39,6 +39,10 @@ __device__ __forceinline__ float x3_epilogue(float v, int row, int col, int N, c
     uint64_t e = (uint64_t)row * (uint64_t)N + (uint64_t)col;
     bool on = mask ? (mask[e] != 0) : (hash_uniform(seed, e) < keep);
     v = on ? v / keep : 0.f;
+  }
+  if (flags & XF_RELUGRAD) {   // backward of relu (+dropout): `mask` carries the layer's fp32 output Y [M,N]
+    const float y = reinterpret_cast<const float*>(mask)[(int64_t)row * N + col];
+    v = y > 0.f ? v / keep : 0.f;
   }
   return v;
 }

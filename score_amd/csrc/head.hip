@@ -414,22 +414,6 @@ int score_launch_gru_wxcat(const float* gk0, const float* ck0, const float* gb0,
   SCORE_CHECK_LAUNCH();
   return 0;
 }
-// dcat [I][3H] -> d gates/kernel rows [0,I) (ld 2H) and d candidate/kernel rows [0,I) (ld H)
-__global__ void gru_wxsplit_kernel(const float* __restrict__ dcat, int I, int H, float* __restrict__ dgk,
-                                   float* __restrict__ dck) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (int64_t)I * 3 * H) return;
-  const int r = (int)(i / (3 * H)), j = (int)(i - (int64_t)r * 3 * H);
-  if (j < 2 * H) dgk[(int64_t)r * 2 * H + j] = dcat[i];
-  else dck[(int64_t)r * H + (j - 2 * H)] = dcat[i];
-}
-int score_launch_gru_wxsplit(const float* dcat, int I, int H, float* dgk, float* dck, hipStream_t s) {
-  int64_t n = (int64_t)I * 3 * H;
-  hipLaunchKernelGGL(gru_wxsplit_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, s, dcat, I, H, dgk, dck);
-  SCORE_CHECK_LAUNCH();
-  return 0;
-}
-
 // ------------------------------------------------------------------ ApplyAdam (score.py:96-99)
 // TF training_ops: m += (g - m)(1-b1); v += (g*g - v)(1-b2); var -= m*alpha / (sqrt(v) + eps)
 __device__ __forceinline__ void adam1(float& p, float& m, float& v, float g, float omb1, float omb2, float alpha,

@@ -33,8 +33,6 @@ int colsum_queue_add(ColsumJobs* q, const float* X, int M, int N, int ld, float*
 int colsum_queue_flush(ColsumJobs* q, float* part, int64_t part_floats, hipStream_t s);
 int score_launch_colsum(const float* X, int M, int N, int ld, float* out, int accumulate,
                         float* scratch, int64_t scratch_floats, hipStream_t s);
-int score_launch_relu_bwd(float* dY, const float* Y, int64_t rows, int cols, int ldd, int ldy,
-                          float divisor, hipStream_t s);
 // embed.hip
 struct CoattnCall {
   const int32_t* idx1; const int32_t* idx2;
@@ -94,7 +92,6 @@ int score_launch_outer_relu_bwd(int B, int NF, const float* dlogit, const float*
 int score_launch_gru_wxcat(const float* gk0, const float* ck0, const float* gb0, const float* cb0, const float* gk1,
                            const float* ck1, const float* gb1, const float* cb1, int I0, int I1, int Imax, int H,
                            float* cat, hipStream_t s);
-int score_launch_gru_wxsplit(const float* dcat, int I, int H, float* dgk, float* dck, hipStream_t s);
 int score_launch_copy2d(int64_t rows, int cols, const float* src, int lds_, float* dst, int ldd, hipStream_t s);
 
 // scatter.hip: occurrence sort ("index plan") and the pull-form gradient scatter
