@@ -288,6 +288,17 @@ int score_batch_assemble(const score_graph_t* g, const int32_t* uids, const int3
                          int32_t start_time, int32_t pred_time, uint64_t seed,
                          const score_batch_out_t* out, void* stream);
 
+/* ---- "next" row f4: ranking metrics of an evaluation pass on the device ----------------------- */
+
+/* get_ranking_quality (train_score.py:104-142) without the host round trip of the predictions:
+ * pred / ids are [n_lines, per_line] (one positive in column 0 + the sampled negatives, the layout
+ * model.eval's outputs arrive in, train_score.py:153-157).  The rank of a line is the position, in
+ * descending-score order with np.argsort(...)[::-1]'s tie order, of the first entry whose id equals
+ * the positive's.  out6 (device) = means over the lines of NDCG@5, NDCG@10, HR@1, HR@5, HR@10, MRR;
+ * ranks (optional, device int32 [n_lines]) receives the 0-based ranks.  scratch: 6 * n_lines floats. */
+int score_ranking_quality(const float* pred, const int32_t* ids, int64_t n_lines, int32_t per_line,
+                          float* out6, int32_t* ranks, float* scratch, int64_t scratch_floats, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -106,3 +106,66 @@ extern "C" int score_batch_assemble(const score_graph_t* g, const int32_t* uids,
   SCORE_CHECK_LAUNCH();
   return 0;
 }
+
+// ------------------------------------------------------------------ ranking metrics (train_score.py:104-142)
+// one wave per line: the positive's id may also appear among the negatives, so every entry carrying it is ranked
+// and the best position wins.  Position of entry c in np.argsort(p)[::-1]: entries with a larger score, plus
+// equal scores with a larger index (the stable ascending sort, reversed).
+__global__ __launch_bounds__(256) void rank_lines_kernel(const float* __restrict__ pred, const int32_t* __restrict__ ids,
+                                                         int64_t n_lines, int per_line, int32_t* __restrict__ ranks,
+                                                         float* __restrict__ metrics) {
+  const int lane = threadIdx.x & 63;
+  const int64_t line = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (line >= n_lines) return;
+  const float* p = pred + line * per_line;
+  const int32_t* id = ids + line * per_line;
+  const int32_t pos_id = id[0];
+  int best = per_line;
+  for (int c = lane; c < per_line; c += 64) {
+    if (id[c] != pos_id) continue;
+    const float pc = p[c];
+    int before = 0;
+    for (int j = 0; j < per_line; ++j) before += (p[j] > pc) || (p[j] == pc && j > c);
+    best = min(best, before);
+  }
+  for (int off = 32; off > 0; off >>= 1) best = min(best, __shfl_xor(best, off, 64));
+  if (lane == 0) {
+    if (ranks) ranks[line] = best;
+    const float gain = logf(2.0f) / logf((float)best + 2.0f);
+    float* m = metrics + line * 6;
+    m[0] = best < 5 ? gain : 0.f; m[1] = best < 10 ? gain : 0.f;
+    m[2] = best < 1 ? 1.f : 0.f; m[3] = best < 5 ? 1.f : 0.f; m[4] = best < 10 ? 1.f : 0.f;
+    m[5] = 1.0f / (float)(best + 1);
+  }
+}
+// means of the six per-line metrics: one block, fixed order, double accumulation
+__global__ __launch_bounds__(256) void rank_mean_kernel(const float* __restrict__ metrics, int64_t n_lines,
+                                                        float* __restrict__ out6) {
+  __shared__ double sh[256];
+  for (int q = 0; q < 6; ++q) {
+    double acc = 0.0;
+    for (int64_t i = threadIdx.x; i < n_lines; i += 256) acc += (double)metrics[i * 6 + q];
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+      if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) out6[q] = (float)(sh[0] / (double)n_lines);
+    __syncthreads();
+  }
+}
+
+extern "C" int score_ranking_quality(const float* pred, const int32_t* ids, int64_t n_lines, int32_t per_line,
+                                     float* out6, int32_t* ranks, float* scratch, int64_t scratch_floats,
+                                     void* stream) {
+  if (!pred || !ids || !out6 || !scratch || n_lines <= 0 || per_line <= 0) return SCORE_E_BADARG;
+  if (scratch_floats < 6 * n_lines) return SCORE_E_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(rank_lines_kernel, dim3((unsigned)cdiv64(n_lines, 4)), dim3(256), 0, s, pred, ids, n_lines,
+                     per_line, ranks, scratch);
+  SCORE_CHECK_LAUNCH();
+  hipLaunchKernelGGL(rank_mean_kernel, dim3(1), dim3(256), 0, s, scratch, n_lines, out6);
+  SCORE_CHECK_LAUNCH();
+  return 0;
+}

@@ -30,7 +30,10 @@ def getMRR(ranklist, target_item):
 def _ranked(preds, target_iids, per_line):
     p = np.asarray(preds, dtype=np.float64).reshape(-1, per_line)
     ids = np.asarray(target_iids).reshape(-1, per_line)
-    order = np.argsort(p, axis=1)[:, ::-1]            # descending score, ties as the reference breaks them
+    # descending score.  The reference calls np.argsort with its default kind, whose order among EQUAL scores
+    # depends on NumPy's build (introsort / SIMD sort); a stable sort pins it (equal scores: larger index
+    # first after the reversal) -- the rule score_ranking_quality implements on the device
+    order = np.argsort(p, axis=1, kind="stable")[:, ::-1]
     ranked = np.take_along_axis(ids, order, axis=1)
     # 0-based rank of the first entry equal to the positive's id (column 0 of every line)
     hit = ranked == ids[:, :1]
@@ -69,3 +72,46 @@ def evaluate(model, batches, reg_lambda, sess=None, neg_sample_num=TEST_NEG_SAMP
     if verbose:
         print("EVAL TIME: %.4fs" % (time.time() - t))
     return logloss, auc, ndcg_5, ndcg_10, hr_1, hr_5, hr_10, mrr, loss
+
+
+def ranking_quality_device(preds, target_iids, neg_sample_num=TEST_NEG_SAMPLE_NUM, return_ranks=False):
+    """get_ranking_quality on the device (score_ranking_quality, include/score_hip.h): preds float32 and
+    target_iids int32 device tensors of n_lines * (1 + neg_sample_num) entries.  One 6-float read-back."""
+    import ctypes as C
+    import torch
+    from . import _lib
+    lib = _lib.load()
+    per = neg_sample_num + 1
+    preds = preds.reshape(-1).contiguous().float()
+    ids = target_iids.reshape(-1).contiguous().to(torch.int32)
+    n_lines = preds.numel() // per
+    if n_lines * per != preds.numel() or ids.numel() != preds.numel():
+        raise ValueError("preds / target_iids must hold n_lines * (1 + neg_sample_num) entries")
+    out = torch.empty((6,), dtype=torch.float32, device=preds.device)
+    ranks = torch.empty((n_lines,), dtype=torch.int32, device=preds.device)
+    scratch = torch.empty((6 * n_lines,), dtype=torch.float32, device=preds.device)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    _lib.check(lib.score_ranking_quality(p(preds), p(ids), n_lines, per, p(out), p(ranks), p(scratch), scratch.numel(),
+                                         C.c_void_p(torch.cuda.current_stream(preds.device).cuda_stream)),
+               "score_ranking_quality")
+    res = tuple(float(x) for x in out.cpu().tolist())
+    return (res, ranks) if return_ranks else res
+
+
+def evaluate_device(model, batches, reg_lambda, neg_sample_num=TEST_NEG_SAMPLE_NUM):
+    """evaluate() with predictions, ids and labels kept on the device: one forward per batch
+    (model.eval_async), ranking metrics by score_ranking_quality, log-loss / AUC from one read-back at the
+    end.  Returns the same 9-tuple as evaluate()."""
+    import torch
+    from sklearn.metrics import log_loss, roc_auc_score
+    preds, labels, iids, losses = [], [], [], []
+    for batch_data in batches:
+        db = model.device_batch(batch_data)
+        pred, label, loss = model.eval_async(db, reg_lambda)
+        preds.append(pred.clone()); labels.append(label); losses.append(loss.clone())
+        iids.append(db.tensors[5][:, 0])
+    preds, labels, iids = torch.cat(preds), torch.cat(labels), torch.cat(iids)
+    ndcg_5, ndcg_10, hr_1, hr_5, hr_10, mrr = ranking_quality_device(preds, iids, neg_sample_num)
+    p_host, l_host = preds.cpu().numpy().astype(np.float64), labels.cpu().numpy()
+    loss = float(torch.stack(losses).mean().item())
+    return (log_loss(l_host, p_host), roc_auc_score(l_host, p_host), ndcg_5, ndcg_10, hr_1, hr_5, hr_10, mrr, loss)

@@ -322,6 +322,13 @@ class SCOREBASE(object):
     def train(self, sess, batch_data, lr, reg_lambda, keep_prob=0.8, dropout_masks=None):
         return float(self.train_async(batch_data, lr, reg_lambda, keep_prob, dropout_masks).item())
 
+    def eval_async(self, batch_data, reg_lambda):
+        """eval without the host round trip: (y_pred [B] device view of the workspace -- copy it before the next
+        forward --, labels [B] device int32, loss 0-d device tensor)."""
+        db = self.device_batch(batch_data)
+        lay, ws, _ = self._forward(db, reg_lambda, 1.0, None)
+        return ws[lay.y_pred:lay.y_pred + db.B], db.tensors[6], ws[lay.loss]
+
     def eval(self, sess, batch_data, reg_lambda):
         db = self.device_batch(batch_data)
         lay, ws, _ = self._forward(db, reg_lambda, 1.0, None)
