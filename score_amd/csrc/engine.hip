@@ -160,7 +160,7 @@ void build_ws(const Dims& d, int B, WS* w) {
   w->a1 = take(BT * AT1); w->a2 = take(BT * AT2);
   w->bn = take((int64_t)B * d.Dhead);
   w->f1 = take((int64_t)B * FC1); w->f2 = take((int64_t)B * FC2);
-  w->lossb = take(B); w->dlogit = take(B); w->part = take(64);
+  w->lossb = take(B); w->dlogit = take(B); w->part = take(256);
   w->dz2 = take((int64_t)B * FC2); w->dz1 = take((int64_t)B * FC1);
   w->dbn = take((int64_t)B * d.Dhead); w->dhead = take((int64_t)B * d.Dhead);
   w->ds = take(BT); w->da2 = take(BT * AT2); w->da1 = take(BT * AT1);
@@ -372,12 +372,15 @@ extern "C" int score_forward(const score_config_t* cfg, const score_state_t* st,
   // target rows -> query [tu | ti] and head_inp [.., ti, tu]      (score.py:62-66, 210, 217)
   G(score_launch_target_fwd(st->table, d.D, d.Fu, d.Fi, B, bt->target_user, bt->target_item, ws + w.query, d.Dq,
                             ws + w.head_inp, d.Dhead, d.off_ti, d.off_tu, s));
+  // side stream: the L2 norm of the weights (needs no batch), then the attention's query branch (target rows and
+  // weights only) -- beside the gather and the GRUs
   SideStream* sd = nullptr;
+  G(side_stream(&sd));
+  HIPTRY(hipEventRecord(sd->fork, s));
+  HIPTRY(hipStreamWaitEvent(sd->st, sd->fork, 0));
+  G(score_launch_l2_partials(W, P.n_reg, ws + w.part, sd->st));
+  if (!d.attn) HIPTRY(hipEventRecord(sd->join, sd->st));
   if (d.attn) {
-    // the attention's query branch needs the target rows and weights only: beside the gather and the GRUs
-    G(side_stream(&sd));
-    HIPTRY(hipEventRecord(sd->fork, s));
-    HIPTRY(hipStreamWaitEvent(sd->st, sd->fork, 0));
     float* scratch2 = ws + w.scratch2;
     G(gemm_mode_call(x3, 0, B, d.Dk, d.Dq, ws + w.query, d.Dq, W + P.at_w[0], d.Dk, ws + w.q, d.Dk, W + P.at_b[0], GF_BIAS,
                      1.f, nullptr, 0, scratch2, w.scratch_floats, sd->st));
@@ -458,8 +461,9 @@ extern "C" int score_forward(const score_config_t* cfg, const score_state_t* st,
                GF_BIAS | GF_RELU | dflag, keep_prob, drop_mask1, drop_seed ^ 0x5DEECE66Dull, scratch,
                w.scratch_floats, s));
   // fc3, sigmoid, log-loss, l2 (:74-94)
+  if (!d.attn) HIPTRY(hipStreamWaitEvent(s, sd->join, 0));     // (with attention the join was waited for there)
   G(score_launch_head_out(B, FC2, ws + w.f2, W + P.fc_w[2], W + P.fc_b[2], bt->label, ws + w.logit, ws + w.y_pred,
-                          ws + w.lossb, ws + w.dlogit, ws + w.loss, W, P.n_reg, reg_lambda, ws + w.part,
+                          ws + w.lossb, ws + w.dlogit, ws + w.loss, reg_lambda, ws + w.part,
                           st->global_batch > 0 ? st->global_batch : B, s));
   EV(4);
   return 0;

@@ -299,23 +299,17 @@ __global__ void head_out_kernel(int B, int NF, const float* __restrict__ f2, con
   dlogit[b] = dp * p * (1.0f - p);
 }
 
-// single-block deterministic sum of n floats: out = scale * sum
-__global__ void reduce_sum_kernel(const float* __restrict__ x, int64_t n, float scale, float* __restrict__ out) {
+#define L2_PARTS 256
+// partial sums of squares of the regularised range (build_l2norm, score.py:91-94): 256 blocks, float4 loads
+__global__ __launch_bounds__(256) void sumsq_stage1(const float* __restrict__ x, int64_t n, float* __restrict__ part) {
   __shared__ float sh[256];
+  const int64_t n4 = n >> 2;
   float s = 0.f;
-  for (int64_t i = threadIdx.x; i < n; i += 256) s += x[i];
-  sh[threadIdx.x] = s;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
-    __syncthreads();
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const float4 v = ld4(x + i * 4);
+    s = fmaf(v.x, v.x, s); s = fmaf(v.y, v.y, s); s = fmaf(v.z, v.z, s); s = fmaf(v.w, v.w, s);
   }
-  if (threadIdx.x == 0) out[0] = sh[0] * scale;
-}
-__global__ void sumsq_stage1(const float* __restrict__ x, int64_t n, float* __restrict__ part) {
-  __shared__ float sh[256];
-  float s = 0.f;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s = fmaf(x[i], x[i], s);
+  if (blockIdx.x == 0 && threadIdx.x < (unsigned)(n - n4 * 4)) { const float v = x[n4 * 4 + threadIdx.x]; s = fmaf(v, v, s); }
   sh[threadIdx.x] = s;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
@@ -324,28 +318,43 @@ __global__ void sumsq_stage1(const float* __restrict__ x, int64_t n, float* __re
   }
   if (threadIdx.x == 0) part[blockIdx.x] = sh[0];
 }
-// loss[1] = mean log-loss (already there), loss[2] = 0.5*sumsq, loss[0] = loss[1] + lambda*loss[2]
-__global__ void loss_final_kernel(const float* __restrict__ part, int nparts, float lambda, float* __restrict__ loss) {
-  if (threadIdx.x != 0) return;
+int score_launch_l2_partials(const float* wreg, int64_t n_reg, float* part /* L2_PARTS floats */, hipStream_t s) {
+  hipLaunchKernelGGL(sumsq_stage1, dim3(L2_PARTS), dim3(256), 0, s, wreg, n_reg, part);
+  SCORE_CHECK_LAUNCH();
+  return 0;
+}
+// one block: loss[1] = sum_b lossb / Bglobal, loss[2] = 0.5 * sum(parts), loss[0] = loss[1] + lambda*loss[2]
+// (fixed-order tree sums: reproducible)
+__global__ __launch_bounds__(256) void loss_final_kernel(const float* __restrict__ lossb, int64_t B, float scale,
+                                                         const float* __restrict__ part, float lambda,
+                                                         float* __restrict__ loss) {
+  __shared__ float sh[256], sp[256];
   float s = 0.f;
-  for (int i = 0; i < nparts; ++i) s += part[i];
-  loss[2] = 0.5f * s;
-  loss[0] = loss[1] + lambda * loss[2];
+  for (int64_t i = threadIdx.x; i < B; i += 256) s += lossb[i];
+  sh[threadIdx.x] = s;
+  sp[threadIdx.x] = part[threadIdx.x];
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) { sh[threadIdx.x] += sh[threadIdx.x + o]; sp[threadIdx.x] += sp[threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    loss[1] = sh[0] * scale;
+    loss[2] = 0.5f * sp[0];
+    loss[0] = loss[1] + lambda * loss[2];
+  }
 }
 
 int score_launch_head_out(int B, int NF, const float* f2, const float* w3, const float* b3, const int32_t* label,
-                          float* logit, float* y, float* lossb, float* dlogit, float* loss, const float* wreg,
-                          int64_t n_reg, float lambda, float* part /* >= 64 floats */, int Bglobal,
+                          float* logit, float* y, float* lossb, float* dlogit, float* loss, float lambda,
+                          const float* part /* L2_PARTS sums of squares from score_launch_l2_partials */, int Bglobal,
                           hipStream_t s) {
   // Bglobal = samples the mean is taken over (the local batch, or the global batch when data-parallel)
   hipLaunchKernelGGL(head_out_kernel, dim3((B + 63) / 64), dim3(64), 0, s, B, NF, f2, w3, b3, label, logit, y,
                      lossb, dlogit, Bglobal);
   SCORE_CHECK_LAUNCH();
-  hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, s, lossb, (int64_t)B, 1.0f / (float)Bglobal, loss + 1);
-  SCORE_CHECK_LAUNCH();
-  hipLaunchKernelGGL(sumsq_stage1, dim3(64), dim3(256), 0, s, wreg, n_reg, part);
-  SCORE_CHECK_LAUNCH();
-  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, s, part, 64, lambda, loss);
+  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, s, lossb, (int64_t)B, 1.0f / (float)Bglobal, part, lambda,
+                     loss);
   SCORE_CHECK_LAUNCH();
   return 0;
 }

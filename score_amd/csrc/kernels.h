@@ -84,9 +84,10 @@ int score_launch_bn_fwd(int B, int Dh, const float* x, const float* gamma, const
 int score_launch_bn_bwd(int B, int Dh, const float* x, const float* gamma, float rs, const float* dy, float* dx,
                         float* dgamma, float* dbeta, float* tmp, float* scratch, int64_t scratch_floats,
                         ColsumJobs* cq, hipStream_t s);
+int score_launch_l2_partials(const float* wreg, int64_t n_reg, float* part /* 256 floats */, hipStream_t s);
 int score_launch_head_out(int B, int NF, const float* f2, const float* w3, const float* b3, const int32_t* label,
-                          float* logit, float* y, float* lossb, float* dlogit, float* loss, const float* wreg,
-                          int64_t n_reg, float lambda, float* part, int Bglobal, hipStream_t s);
+                          float* logit, float* y, float* lossb, float* dlogit, float* loss, float lambda,
+                          const float* part, int Bglobal, hipStream_t s);
 int score_launch_outer_relu_bwd(int B, int NF, const float* dlogit, const float* w, const float* f, float keep,
                                 float* dz, hipStream_t s);
 int score_launch_gru_wxcat(const float* gk0, const float* ck0, const float* gb0, const float* cb0, const float* gk1,
