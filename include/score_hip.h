@@ -299,6 +299,15 @@ int score_batch_assemble(const score_graph_t* g, const int32_t* uids, const int3
 int score_ranking_quality(const float* pred, const int32_t* ids, int64_t n_lines, int32_t per_line,
                           float* out6, int32_t* ranks, float* scratch, int64_t scratch_floats, void* stream);
 
+/* sklearn.metrics.roc_auc_score / log_loss of an evaluation pass (train_score.py:159-160) on the device:
+ * pred float32 [n] in (0,1), label int32 [n] in {0,1}.  AUC is the Mann-Whitney statistic with average
+ * ranks for tied scores (what the trapezoidal ROC area equals); log-loss clips to [eps, 1-eps] with
+ * eps = 2^-52 and accumulates in double.  out2 (device doubles) = {auc, logloss}; auc is NaN when only
+ * one class is present.  scratch: score_auc_scratch_bytes(n). */
+int score_auc_logloss(const float* pred, const int32_t* label, int64_t n, double* out2, void* scratch,
+                      int64_t scratch_bytes, void* stream);
+int64_t score_auc_scratch_bytes(int64_t n);
+
 #ifdef __cplusplus
 }
 #endif

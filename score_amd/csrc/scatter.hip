@@ -415,3 +415,87 @@ extern "C" int64_t score_segment_sum_scratch_bytes(int64_t n, int32_t D) {
   const int64_t partial_floats = 2 * nw * D + 8 + 2 * nw;
   return 4 * align_up64(n, 4) * 4 + align_up64(partial_floats, 4) * 4 + (int64_t)sort_bytes + 64;
 }
+
+// ------------------------------------------------------------------ AUC / log-loss of an evaluation pass
+__global__ void auc_keys_kernel(const float* __restrict__ pred, const int32_t* __restrict__ label, int64_t n,
+                                uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  keys[i] = __float_as_uint(pred[i]);     // scores are positive floats: their bit patterns sort like the values
+  vals[i] = label[i] != 0;
+}
+// per block: sum over its positives of the average rank of their tie group, the positives' count, and the
+// log-loss terms; groups are found by binary search in the sorted keys (robust to long runs of equal scores)
+__global__ __launch_bounds__(256) void auc_partials_kernel(const uint32_t* __restrict__ keys,
+                                                           const uint32_t* __restrict__ lab, int64_t n,
+                                                           double* __restrict__ part) {
+  __shared__ double sh[3][256];
+  double rk = 0.0, np = 0.0, ll = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const uint32_t k = keys[i];
+    const bool pos = lab[i] != 0;
+    if (pos) {
+      int64_t lo = 0, hi = i;                 // first index with key == k
+      while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (keys[mid] < k) lo = mid + 1; else hi = mid; }
+      const int64_t first = lo;
+      lo = i; hi = n;                         // first index with key > k
+      while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (keys[mid] <= k) lo = mid + 1; else hi = mid; }
+      rk += 0.5 * (double)(first + 1 + lo);   // average of the 1-based ranks first+1 .. lo
+      np += 1.0;
+    }
+    const double eps = 2.220446049250313e-16;
+    double p = (double)__uint_as_float(k);
+    p = p < eps ? eps : (p > 1.0 - eps ? 1.0 - eps : p);
+    ll -= pos ? log(p) : log(1.0 - p);
+  }
+  sh[0][threadIdx.x] = rk; sh[1][threadIdx.x] = np; sh[2][threadIdx.x] = ll;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o)
+      for (int q = 0; q < 3; ++q) sh[q][threadIdx.x] += sh[q][threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0)
+    for (int q = 0; q < 3; ++q) part[q * gridDim.x + blockIdx.x] = sh[q][0];
+}
+__global__ void auc_final_kernel(const double* __restrict__ part, int nparts, int64_t n, double* __restrict__ out2) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double rk = 0.0, np = 0.0, ll = 0.0;
+  for (int i = 0; i < nparts; ++i) { rk += part[i]; np += part[nparts + i]; ll += part[2 * nparts + i]; }
+  const double nn = (double)n - np;
+  out2[0] = (np > 0.0 && nn > 0.0) ? (rk - np * (np + 1.0) * 0.5) / (np * nn) : nan("");
+  out2[1] = ll / (double)n;
+}
+
+#define AUC_PARTS 256
+extern "C" int64_t score_auc_scratch_bytes(int64_t n) {
+  size_t sort_bytes = 0;
+  if (n <= 0 || score_plan_temp_bytes(n, 32, &sort_bytes) != 0) return -1;
+  return 4 * align_up64(n, 4) * 4 + 3 * AUC_PARTS * 8 + (int64_t)sort_bytes + 64;
+}
+
+extern "C" int score_auc_logloss(const float* pred, const int32_t* label, int64_t n, double* out2, void* scratch,
+                                 int64_t scratch_bytes, void* stream) {
+  if (!pred || !label || !out2 || !scratch || n <= 0) return SCORE_E_BADARG;
+  if (n >= (1ll << 31)) return SCORE_E_SHAPE;
+  if (scratch_bytes < score_auc_scratch_bytes(n)) return SCORE_E_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  size_t sort_bytes = 0;
+  SCORE_TRY(score_plan_temp_bytes(n, 32, &sort_bytes));
+  const int64_t n4 = align_up64(n, 4);
+  uint32_t* keys_in = static_cast<uint32_t*>(scratch);
+  uint32_t* keys_out = keys_in + n4;
+  uint32_t* vals_in = keys_out + n4;
+  uint32_t* vals_out = vals_in + n4;
+  double* part = reinterpret_cast<double*>(vals_out + n4);
+  void* temp = part + 3 * AUC_PARTS;
+  hipLaunchKernelGGL(auc_keys_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, s, pred, label, n, keys_in, vals_in);
+  SCORE_CHECK_LAUNCH();
+  hipError_t e = rocprim::radix_sort_pairs(temp, sort_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u, 32u, s);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(auc_partials_kernel, dim3(AUC_PARTS), dim3(256), 0, s, keys_out, vals_out, n, part);
+  SCORE_CHECK_LAUNCH();
+  hipLaunchKernelGGL(auc_final_kernel, dim3(1), dim3(64), 0, s, part, AUC_PARTS, n, out2);
+  SCORE_CHECK_LAUNCH();
+  return 0;
+}

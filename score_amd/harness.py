@@ -98,12 +98,32 @@ def ranking_quality_device(preds, target_iids, neg_sample_num=TEST_NEG_SAMPLE_NU
     return (res, ranks) if return_ranks else res
 
 
+def auc_logloss_device(preds, labels):
+    """(roc_auc_score, log_loss) of device tensors preds float32 [n], labels int32 [n] (score_auc_logloss)."""
+    import ctypes as C
+    import torch
+    from . import _lib
+    lib = _lib.load()
+    preds = preds.reshape(-1).contiguous().float()
+    labels = labels.reshape(-1).contiguous().to(torch.int32)
+    n = preds.numel()
+    if labels.numel() != n or n == 0:
+        raise ValueError("preds and labels must be non-empty and of equal length")
+    out = torch.empty((2,), dtype=torch.float64, device=preds.device)
+    scratch = torch.empty((int(lib.score_auc_scratch_bytes(n)),), dtype=torch.uint8, device=preds.device)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    _lib.check(lib.score_auc_logloss(p(preds), p(labels), n, p(out), p(scratch), scratch.numel(),
+                                     C.c_void_p(torch.cuda.current_stream(preds.device).cuda_stream)),
+               "score_auc_logloss")
+    auc, ll = out.cpu().tolist()
+    return auc, ll
+
+
 def evaluate_device(model, batches, reg_lambda, neg_sample_num=TEST_NEG_SAMPLE_NUM):
     """evaluate() with predictions, ids and labels kept on the device: one forward per batch
-    (model.eval_async), ranking metrics by score_ranking_quality, log-loss / AUC from one read-back at the
-    end.  Returns the same 9-tuple as evaluate()."""
+    (model.eval_async), ranking metrics by score_ranking_quality, AUC / log-loss by score_auc_logloss; two
+    small read-backs at the end.  Returns the same 9-tuple as evaluate()."""
     import torch
-    from sklearn.metrics import log_loss, roc_auc_score
     preds, labels, iids, losses = [], [], [], []
     for batch_data in batches:
         db = model.device_batch(batch_data)
@@ -112,6 +132,6 @@ def evaluate_device(model, batches, reg_lambda, neg_sample_num=TEST_NEG_SAMPLE_N
         iids.append(db.tensors[5][:, 0])
     preds, labels, iids = torch.cat(preds), torch.cat(labels), torch.cat(iids)
     ndcg_5, ndcg_10, hr_1, hr_5, hr_10, mrr = ranking_quality_device(preds, iids, neg_sample_num)
-    p_host, l_host = preds.cpu().numpy().astype(np.float64), labels.cpu().numpy()
+    auc, logloss = auc_logloss_device(preds, labels)
     loss = float(torch.stack(losses).mean().item())
-    return (log_loss(l_host, p_host), roc_auc_score(l_host, p_host), ndcg_5, ndcg_10, hr_1, hr_5, hr_10, mrr, loss)
+    return (logloss, auc, ndcg_5, ndcg_10, hr_1, hr_5, hr_10, mrr, loss)

@@ -41,6 +41,22 @@ def test_device_ranks_ties_and_repeated_positive_id():
         h.ranking_quality_device(torch.zeros(7).cuda(), torch.zeros(7, dtype=torch.int32).cuda(), 3)
 
 
+def test_device_auc_logloss_match_sklearn():
+    from sklearn.metrics import log_loss, roc_auc_score
+    rng = np.random.default_rng(8)
+    for n, ties in ((5000, False), (3001, True), (64, True)):
+        p = rng.random(n).astype(np.float32) * 0.98 + 0.01
+        if ties:
+            p = np.round(p, 1 if n < 100 else 2).astype(np.float32).clip(0.01, 0.99)   # long runs of equal scores
+        y = (rng.random(n) < p).astype(np.int32)
+        y[:2] = [0, 1]
+        auc, ll = h.auc_logloss_device(torch.from_numpy(p).cuda(), torch.from_numpy(y).cuda())
+        assert abs(auc - roc_auc_score(y, p.astype(np.float64))) < 1e-12
+        assert abs(ll - log_loss(y, p.astype(np.float64))) < 1e-12
+    auc, _ = h.auc_logloss_device(torch.full((8,), 0.3).cuda(), torch.ones(8, dtype=torch.int32).cuda())
+    assert np.isnan(auc)                                       # one class only
+
+
 def test_evaluate_device_equals_host_evaluate():
     from score_amd.synth import make_world
     from score_amd.model import SCORE
