@@ -166,19 +166,6 @@ __global__ void rowsum_fill_kernel(const int32_t* __restrict__ rows, int64_t n, 
 }
 
 // ------------------------------------------------------------------ pull
-__device__ __forceinline__ float4 pull_contrib(const PullArgs& a, uint32_t desc, int ch4) {
-  const int seg = desc >> 29, f = (desc >> 26) & 7, k = (desc >> 21) & 31;
-  if (seg == 6) return ld4(a.G[0] + (int64_t)(desc & 0x1FFFFFFF) * a.D + ch4);   // owner-side row sum
-  if (seg == 7) return make_float4(0.f, 0.f, 0.f, 0.f);                            // sentinel
-  const int64_t bt = desc & 0x1FFFFF;
-  const int col = f * a.D + ch4;
-  float4 g = ld4(a.G[seg] + bt * a.ldg[seg] + a.gcol[seg] + col);
-  float ca = a.cA[seg] ? a.cA[seg][bt * a.K + k] : a.constA[seg];
-  float4 r = make_float4(ca * g.x, ca * g.y, ca * g.z, ca * g.w);
-  if (a.cB[seg]) r = fma4(a.cB[seg][bt * a.K + k], ld4(a.Wv[seg] + col), r);
-  return r;
-}
-
 // destination row of a run: its unique position (sharded: grads of the mini-table) or the row id itself
 __device__ __forceinline__ int64_t out_row(const PullArgs& a, uint32_t key, int64_t idx_in_run) {
   return a.uid ? (int64_t)a.uid[idx_in_run] : (int64_t)key;
@@ -192,6 +179,47 @@ __device__ __forceinline__ void store_row(const PullArgs& a, float* __restrict__
   if (a.flags && ch4 == 0) a.flags[r] = 2;
 }
 
+// Contribution of one occurrence without data-dependent branches, so the loads of several occurrences can be
+// in flight together.  MODE 0: owner-side row sum (descriptor = source slot).  MODE 1: model segments with
+// constant coefficients (RCA / RRN).  MODE 2: with the co-attention's per-(unit,k) coefficients.  Segments the
+// model does not use and the sentinel are clamped onto segment 4/5's pointers; their value is discarded by the
+// caller (their key is the dummy row 0).
+struct PullSeg {          // per-segment fields of PullArgs, looked up from LDS by the descriptor's segment
+  const float* G; const float* cA; const float* cB; const float* Wv;
+  int ldg, gcol; float constA; int useA;
+};
+template <int MODE>
+__device__ __forceinline__ float4 pull_contrib_t(const PullArgs& a, const PullSeg* __restrict__ tab, uint32_t desc,
+                                                 int ch4) {
+  if (MODE == 0) return ld4(a.G[0] + (int64_t)(desc & 0x1FFFFFFF) * a.D + ch4);
+  int seg = desc >> 29;
+  seg = seg > 5 ? 5 : seg;
+  const int f = (desc >> 26) & 7, k = (desc >> 21) & 31;
+  const int64_t bt = desc & 0x1FFFFF;
+  const int col = f * a.D + ch4;
+  const PullSeg si = tab[seg];               // ds_read: no branch, so the loads below batch across occurrences
+  const float4 g = ld4(si.G + bt * si.ldg + si.gcol + col);
+  float ca = si.constA;
+  float4 r;
+  if (MODE == 2) {
+    // every segment has valid cA / cB / Wv pointers (the targets' point at the first call's arrays): the
+    // loads are unconditional, useA / constA decide what is used
+    const float pa = si.cA[bt * a.K + k];
+    const float cb = si.cB[bt * a.K + k];
+    const float4 wv = ld4(si.Wv + col);
+    ca = (si.useA & 1) ? pa : ca;
+    r = make_float4(ca * g.x, ca * g.y, ca * g.z, ca * g.w);
+    r = fma4((si.useA & 2) ? cb : 0.f, wv, r);
+  } else {
+    r = make_float4(ca * g.x, ca * g.y, ca * g.z, ca * g.w);
+  }
+  return r;
+}
+
+// U occurrences per trip: their keys, descriptors and contributions are loaded before the run logic consumes
+// them in order (the walk used to be one dependent global-memory latency per occurrence)
+#define PULL_U 4
+template <int MODE>
 __global__ __launch_bounds__(256) void pull_kernel(const PullArgs a, const uint32_t* __restrict__ keys,
                                                    const uint32_t* __restrict__ vals, int64_t n, int WS,
                                                    float* __restrict__ out, float* __restrict__ pfirst,
@@ -200,25 +228,57 @@ __global__ __launch_bounds__(256) void pull_kernel(const PullArgs a, const uint3
   const int gpb = blockDim.x / LPR;                      // groups per block
   const int64_t w = (int64_t)blockIdx.x * gpb + threadIdx.x / LPR;
   const int ch4 = (threadIdx.x % LPR) * 4;
+  __shared__ PullSeg tab[6];
+  if (MODE != 0) {
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int sg = 0; sg < 6; ++sg) {
+        PullSeg t;
+        t.G = a.G[sg] ? a.G[sg] : a.G[4];
+        t.ldg = a.ldg[sg]; t.gcol = a.gcol[sg]; t.constA = a.constA[sg];
+        const int c = (sg & 2) ? 2 : 0;                       // segments 0,1 -> call 0; 2,3 -> call 1; targets -> call 0
+        t.cA = a.cA[sg < 4 ? c : 0]; t.cB = a.cB[sg < 4 ? c : 0];
+        t.Wv = a.Wv[sg < 4 ? sg : sg - 4];
+        t.useA = (sg < 4 && a.cA[sg] ? 1 : 0) | (sg < 4 && a.cB[sg] ? 2 : 0);
+        tab[sg] = t;
+      }
+    }
+    __syncthreads();
+  }
   const int64_t start = w * WS;
   if (start >= n || ch4 >= a.D) return;
   const int64_t end = start + WS < n ? start + WS : n;
+  if (a.zero_is_dummy && keys[end - 1] == 0) return;    // keys ascend: a window of dummy-row uses only
   uint32_t cur = keys[start];
   const bool first_open = start > 0 && keys[start - 1] == cur;
   bool is_first = true;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int64_t i = start; i < end; ++i) {
-    uint32_t key = keys[i];
-    if (key != cur) {
-      if (cur != 0 || !a.zero_is_dummy) {
-        if (is_first && first_open) st4(pfirst + w * a.D + ch4, acc);
-        else store_row(a, out, cur, i - 1, ch4, acc);
-      }
-      acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      cur = key;
-      is_first = false;
+  for (int64_t i0 = start; i0 < end; i0 += PULL_U) {
+    uint32_t kk[PULL_U], vv[PULL_U];
+    float4 cc[PULL_U];
+#pragma unroll
+    for (int u = 0; u < PULL_U; ++u) {
+      const int64_t idx = i0 + u < end ? i0 + u : end - 1;
+      kk[u] = keys[idx];
+      vv[u] = vals[idx];
     }
-    if (key != 0 || !a.zero_is_dummy) acc = add4(acc, pull_contrib(a, vals[i], ch4));
+#pragma unroll
+    for (int u = 0; u < PULL_U; ++u) cc[u] = pull_contrib_t<MODE>(a, tab, vv[u], ch4);
+#pragma unroll
+    for (int u = 0; u < PULL_U; ++u) {
+      if (i0 + u >= end) break;
+      const uint32_t key = kk[u];
+      if (key != cur) {
+        if (cur != 0 || !a.zero_is_dummy) {
+          if (is_first && first_open) st4(pfirst + w * a.D + ch4, acc);
+          else store_row(a, out, cur, i0 + u - 1, ch4, acc);
+        }
+        acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        cur = key;
+        is_first = false;
+      }
+      if (key != 0 || !a.zero_is_dummy) acc = add4(acc, cc[u]);
+    }
   }
   if (cur != 0 || !a.zero_is_dummy) {
     const bool open_right = end < n && keys[end] == cur;
@@ -329,7 +389,12 @@ int score_launch_pull(PullArgs& a, const uint32_t* keys, const uint32_t* vals, i
   if (e != hipSuccess) return (int)e;
   int gpb = 256 / LPR;
   unsigned blocks = (unsigned)cdiv64(nw, gpb);
-  hipLaunchKernelGGL(pull_kernel, dim3(blocks), dim3(256), 0, s, a, keys, vals, n, WS, out, pfirst, plast);
+  // contribution form: owner-side row sum (descriptors are source slots), constant coefficients, or the
+  // co-attention's per-(unit, k) coefficients
+  const int mode = (a.G[1] == nullptr && a.ldg[0] == 0) ? 0 : (a.cA[0] ? 2 : 1);
+  if (mode == 0) hipLaunchKernelGGL(pull_kernel<0>, dim3(blocks), dim3(256), 0, s, a, keys, vals, n, WS, out, pfirst, plast);
+  else if (mode == 1) hipLaunchKernelGGL(pull_kernel<1>, dim3(blocks), dim3(256), 0, s, a, keys, vals, n, WS, out, pfirst, plast);
+  else hipLaunchKernelGGL(pull_kernel<2>, dim3(blocks), dim3(256), 0, s, a, keys, vals, n, WS, out, pfirst, plast);
   SCORE_CHECK_LAUNCH();
   hipLaunchKernelGGL(pull_fixup_kernel, dim3(blocks), dim3(256), 0, s, a, keys, n, WS, out, pfirst, plast,
                      long_count, long_list);
