@@ -218,7 +218,7 @@ __device__ __forceinline__ float4 pull_contrib_t(const PullArgs& a, const PullSe
 
 // U occurrences per trip: their keys, descriptors and contributions are loaded before the run logic consumes
 // them in order (the walk used to be one dependent global-memory latency per occurrence)
-#define PULL_U 4
+#define PULL_U 8
 template <int MODE>
 __global__ __launch_bounds__(256) void pull_kernel(const PullArgs a, const uint32_t* __restrict__ keys,
                                                    const uint32_t* __restrict__ vals, int64_t n, int WS,
