@@ -194,7 +194,7 @@ __device__ __forceinline__ void atomic_add4(float* d, float4 v) {
 }
 
 template <int KMAX, int SPL, bool ATOMIC>
-__global__ __launch_bounds__(256) void coattn_bwd_kernel_t(const CoattnArgs a) {
+__global__ __launch_bounds__(256, (KMAX <= 10 && SPL == 1) ? 4 : 1) void coattn_bwd_kernel_t(const CoattnArgs a) {
   extern __shared__ float lds[];  // [4 waves][upw][2*Dx]
   const int ci = (int)blockIdx.x >= a.c[1].first_block ? 1 : 0;
   const CoattnCall& cc = a.c[ci];
@@ -282,9 +282,18 @@ __global__ __launch_bounds__(256) void coattn_bwd_kernel_t(const CoattnArgs a) {
         }
         r1[j][k] = ra;
         v1[j][k] = x;
-        dp[k] += dot4(x, g1[j]);
       }
     }
+    // the seq2 row ids go in flight behind the seq1 rows (pass 2 then waits for its rows only)
+    int32_t rb2[SPL][KMAX];
+#pragma unroll
+    for (int j = 0; j < SPL; ++j)
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) rb2[j][k] = (k < K && ok[j]) ? i2[k * F + f[j]] : 0;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+#pragma unroll
+      for (int j = 0; j < SPL; ++j) dp[k] += dot4(v1[j][k], g1[j]);
     // softmax from the saved relu'd scores
     float r[KMAX], p[KMAX];
     float rmax = 0.f, gsum = 0.f;
@@ -357,7 +366,7 @@ __global__ __launch_bounds__(256) void coattn_bwd_kernel_t(const CoattnArgs a) {
         rb[k] = 0;
         y[k] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (k < K) {
-          rb[k] = i2[k * F + f[j]];
+          rb[k] = rb2[j][k];
           y[k] = ld4(table + (int64_t)rb[k] * D + coff[j]);
         }
       }
