@@ -353,8 +353,23 @@ __global__ __launch_bounds__(256) void pull_long_kernel(const PullArgs a, const 
     const int chunk = (L + ng - 1) / ng;
     const int j0 = 1 + g * chunk, j1 = min(L, (g + 1) * chunk);
     float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (lane_ok)
-      for (int j = j0; j <= j1; ++j) tot = add4(tot, ld4(pfirst + (w + j) * a.D + ch4));
+    if (lane_ok) {
+      // eight partial sums: eight loads in flight per trip (one dependent add chain made this kernel wait a
+      // full memory latency per window); fixed association, so still reproducible
+      float4 t8[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) t8[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      int j = j0;
+      for (; j + 7 <= j1; j += 8) {
+        float4 v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = ld4(pfirst + (w + j + q) * a.D + ch4);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t8[q] = add4(t8[q], v[q]);
+      }
+      for (; j <= j1; ++j) t8[0] = add4(t8[0], ld4(pfirst + (w + j) * a.D + ch4));
+      tot = add4(add4(add4(t8[0], t8[1]), add4(t8[2], t8[3])), add4(add4(t8[4], t8[5]), add4(t8[6], t8[7])));
+    }
     if (lane_ok) st4(sh + g * a.D + ch4, tot);
     __syncthreads();
     if (g == 0 && lane_ok) {
