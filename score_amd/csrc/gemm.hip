@@ -73,7 +73,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmGroup grp, cons
   const int kbeg = bz * k_chunk;
   const int kend = min(K, kbeg + k_chunk);
 
-  float ra[RA][4], rb[RB][4];
+  // two staged tiles in flight (register sets 0/1): a grid too small to fill the chip is paced by its K loop, one
+  // memory latency per staged tile with a single set
+  float ra0[RA][4], rb0[RB][4], ra1[RA][4], rb1[RB][4];
   const bool vecA = ((lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
   const bool vecB = ((ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(Bm) & 15) == 0);
   // one row-major quad: 16-B load when aligned and fully in range, guarded scalars otherwise
@@ -86,7 +88,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmGroup grp, cons
       for (int q = 0; q < 4; ++q) dst[q] = (r < rlim && c + q < clim) ? base[(int64_t)r * ld + c + q] : 0.f;
     }
   };
-  auto load_tiles = [&](int k0) {
+  auto load_tiles = [&](int k0, float (*ra)[4], float (*rb)[4]) {
 #pragma unroll
     for (int rep = 0; rep < RA; ++rep) {
       const int q = tid + 256 * rep;
@@ -100,7 +102,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmGroup grp, cons
       else            load_quad(Bm, ldb, vecB, k0 + q / (BN / 4), kend, bn + (q % (BN / 4)) * 4, N, rb[rep]);  // B[k][n]
     }
   };
-  auto store_tiles = [&]() {
+  auto store_tiles = [&](float (*ra)[4], float (*rb)[4]) {
 #pragma unroll
     for (int rep = 0; rep < RA; ++rep) {
       const int q = tid + 256 * rep;
@@ -140,11 +142,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmGroup grp, cons
   const int arow = wm * 32 * WM + (lane & 31);
   const int bcol = wn * 32 * WN + (lane & 31);
   const int khalf = lane >> 5;
-  if (kbeg < kend) load_tiles(kbeg);
-  for (int k0 = kbeg; k0 < kend; k0 += BK) {
-    store_tiles();
-    __syncthreads();
-    if (k0 + BK < kend) load_tiles(k0 + BK);
+  auto mfma_tile = [&]() {
 #pragma unroll
     for (int kk = 0; kk < BK / 2; ++kk) {
       float av[WM], bv[WN];
@@ -157,6 +155,20 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmGroup grp, cons
 #pragma unroll
         for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
     }
+  };
+  if (kbeg < kend) load_tiles(kbeg, ra0, rb0);
+  if (kbeg + BK < kend) load_tiles(kbeg + BK, ra1, rb1);
+  for (int k0 = kbeg; k0 < kend; k0 += 2 * BK) {
+    store_tiles(ra0, rb0);
+    __syncthreads();
+    if (k0 + 2 * BK < kend) load_tiles(k0 + 2 * BK, ra0, rb0);
+    mfma_tile();
+    __syncthreads();
+    if (k0 + BK >= kend) break;
+    store_tiles(ra1, rb1);
+    __syncthreads();
+    if (k0 + 3 * BK < kend) load_tiles(k0 + 3 * BK, ra1, rb1);
+    mfma_tile();
     __syncthreads();
   }
 
