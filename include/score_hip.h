@@ -208,6 +208,12 @@ typedef struct {
                            writes into grad_table with 2 and leaves all other rows of grad_table
                            untouched, so grad_table needs no zero fill.  NULL = off: the caller
                            zero-fills grad_table and uses score_adam.                            */
+  void* gather_done_event; /* optional hipEvent_t: score_forward records it right after the fused gather +
+                           co-attention launch, so a caller can start the index plan of the same batch on
+                           another stream behind the HBM-bound gather instead of beside it             */
+  void* plan_done_event;   /* optional hipEvent_t (recorded by the caller after score_index_plan on its own
+                           stream): score_backward waits for it just before the row scatter, the first
+                           consumer of the plan -- not at its start                                   */
 } score_state_t;
 
 /* Index plan of a batch (depends on the indices only; run it before score_backward, on

@@ -410,6 +410,7 @@ extern "C" int score_forward(const score_config_t* cfg, const score_state_t* st,
     c1.info = ws + w.info + 2 * d.K; c1.ldi = ldi; c1.rsave = ws + w.rsave[1]; c1.F = d.Fu;
     G(score_coattn_fwd_multi(ca, 2, d.D, B, s));
   }
+  if (st->gather_done_event) HIPTRY(hipEventRecord((hipEvent_t)st->gather_done_event, s));
   EV(1);
   // GRUs (:205-208): hoisted x-projection, then the persistent recurrence
   {
@@ -641,6 +642,7 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
                             d.coattn ? gw + P.ca_b[1] : nullptr, atomic ? nullptr : ws + w.dtgt, scratch, SF, &cq, &gq,
                             s));
   if (!atomic) {
+    if (st->plan_done_event) HIPTRY(hipStreamWaitEvent(s, (hipEvent_t)st->plan_done_event, 0));
     PullArgs pa;
     memset(&pa, 0, sizeof(pa));
     pa.D = d.D; pa.K = d.K; pa.zero_is_dummy = 1;

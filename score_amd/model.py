@@ -235,9 +235,11 @@ class SCOREBASE(object):
         return buf[off:off + n].view(*shape)
 
     # ------------------------------------------------------------------ forward / backward / update
-    def _forward(self, db, reg_lambda, keep_prob, masks):
+    def _forward(self, db, reg_lambda, keep_prob, masks, gather_event=None):
         lay, ws = self._workspace(db.B)
         st = self._state(ws)
+        if gather_event is not None:
+            st.gather_done_event = C.c_void_p(gather_event.cuda_event)
         m0 = m1 = None
         if masks is not None:
             m0 = torch.as_tensor(np.asarray(masks[0]), dtype=torch.uint8).to(self.device).contiguous()
@@ -257,22 +259,26 @@ class SCOREBASE(object):
         self.table_g (dense [N,D]).  Returns the device workspace layout/buffer."""
         db = self.device_batch(batch_data)
         plan_done = None
+        cur = torch.cuda.current_stream(self.device)
         if self.scatter_mode == 0:
-            # occurrence sort for the pull-form scatter: depends on the indices only, so it runs on a
-            # side stream underneath the forward pass (its workspace regions are its own)
-            lay, ws = self._workspace(db.B)
-            st0 = self._state(ws)
-            cur = torch.cuda.current_stream(self.device)
             if self._side is None:
                 self._side = torch.cuda.Stream(device=self.device)
-            self._side.wait_stream(cur)
+                self._ev_gather = torch.cuda.Event()
+                self._ev_gather.record(cur)          # materialise the hipEvent_t
+        lay, ws, st = self._forward(db, reg_lambda, keep_prob, dropout_masks,
+                                    gather_event=self._ev_gather if self.scatter_mode == 0 else None)
+        if self.scatter_mode == 0:
+            # occurrence sort for the pull-form scatter: depends on the indices only.  It starts on a side
+            # stream once the fused gather (HBM-bound, the whole chip) is through, runs under the GRUs /
+            # attention / head and the first half of the backward, and score_backward waits for it just
+            # before the row scatter (its workspace regions are its own)
+            self._side.wait_event(self._ev_gather)
             with torch.cuda.stream(self._side):
-                _lib.check(self.lib.score_index_plan(C.byref(self.cfg), C.byref(st0), C.byref(db.struct), 1, 0,
+                _lib.check(self.lib.score_index_plan(C.byref(self.cfg), C.byref(st), C.byref(db.struct), 1, 0,
                                                      self._stream()), "score_index_plan")
                 plan_done = self._side.record_event()
-        lay, ws, st = self._forward(db, reg_lambda, keep_prob, dropout_masks)
-        if plan_done is not None:
-            torch.cuda.current_stream(self.device).wait_event(plan_done)
+            st.plan_done_event = C.c_void_p(plan_done.cuda_event)
+            self._plan_done = plan_done                  # keep the event alive until the backward has run
         if self.scatter_mode == 0:
             self._begin_row_grads()         # the pull kernels mark what they write; no zero fill
         else:
