@@ -106,6 +106,9 @@ def main():
     ap.add_argument("--all-rows-live", action="store_true",
                     help="mark every table row as carrying Adam moments before the run: the long-run state of "
                          "dense Adam (its sweep then moves 6 fp32 streams over the whole table every step)")
+    ap.add_argument("--no-skip-masked", action="store_true",
+                    help="gather and compute all T time slices, also those past every sample's length (whose "
+                         "results the model masks): A/B for score_batch_t.active_slices")
     ap.add_argument("--lr", type=float, default=1e-3)
     ap.add_argument("--reg-lambda", type=float, default=1e-4)
     args = ap.parse_args()
@@ -140,6 +143,8 @@ def main():
         model = ShardedSCORE(seed=1111, **kw)
     else:
         model = SCORE(seed=1111, **kw)
+    if args.no_skip_masked:
+        (model.backend.m if sharded else model).skip_masked_slices = False
     # weak scaling: every rank trains on its own B-sample batches (global batch = B * N)
     batches = [model.device_batch(world.batch(B, rank * 1000 + i)) for i in range(args.batches)]
 
@@ -211,7 +216,12 @@ def main():
         "bwd_weight_grads": avg(lambda s: s[1][4].elapsed_time(s[1][5])),
         "adam_table_and_dense": avg(lambda s: s[2].elapsed_time(s[3])),
     }
-    ab, R = alg_bytes_per_sample(T, K, D, Fu, Fi)
+    # slices the gather really reads: synthetic batches have length = T-2 (the reference's train split has 9 of
+    # 11, graph_loader.py:382) and the slices past the longest sample, which the model masks out of every
+    # result, are skipped (score_batch_t.active_slices) -- the numerator counts only what is gathered
+    A = int(getattr(batches[0], "active_slices", 0)) or T
+    ab, R = alg_bytes_per_sample(A, K, D, Fu, Fi)
+    ab_full, _ = alg_bytes_per_sample(T, K, D, Fu, Fi)
     gather_s = stages["fwd_gather_coattn"] * 1e-3
     achieved = ab * B / gather_s / 1e9
     N = kw["feature_size"]
@@ -255,14 +265,17 @@ def main():
         "data": "synthetic",
         "config": {"workload": "%s: SCORE full train step (fwd + bwd + dense TF-Adam), N=%d rows, T=%d, K=%d, "
                                "D=%d, H=%d, Fu=%d, Fi=%d, per-GPU batch %d (global %d), keep_prob 0.8, "
-                               "%d distinct pre-staged batches" % (args.config, N, T, K, D, kw["hidden_size"], Fu, Fi,
-                                                                   B, B * world_size, len(batches)),
+                               "%d distinct pre-staged batches, length=%d for every sample (slices >= length are "
+                               "masked by the model and skipped)" % (args.config, N, T, K, D, kw["hidden_size"], Fu, Fi,
+                                                                   B, B * world_size, len(batches), A),
                    "table": "row-sharded row%%G over %d GPU(s)" % world_size if world_size > 1 else "single GPU",
                    "final_loss": loss},
         "roofline": {"kernel": "coattn_fwd_kernel (fused embedding gather + co-attention, both calls, one launch)",
                      "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "algorithmic_bytes_per_launch": ab * B, "avg_launch_ms": stages["fwd_gather_coattn"]},
+                     "algorithmic_bytes_per_launch": ab * B, "avg_launch_ms": stages["fwd_gather_coattn"],
+                     "time_slices_gathered": A, "time_slices_fed": T,
+                     "algorithmic_bytes_per_launch_if_all_fed_slices_were_gathered": ab_full * B},
         "roofline_other": {
             "adam_rows (6 fp32 streams over the live table rows, + g on touched rows, + dense vars)": {
                 "live_row_frac": live_rows / float(rows_local), "rows_with_gradient_per_step": touched,

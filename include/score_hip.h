@@ -74,6 +74,15 @@ typedef struct {
   const int32_t* label;        /* [B]        */
   const int32_t* length;       /* [B]        */
   int32_t B;
+  int32_t active_slices;       /* 0 (or >= T) = all T time slices.  0 < A < T: the caller promises
+                                  length[b] <= A for every sample, and only slices t < A are gathered,
+                                  planned and computed; every [B*T, .] activation of the pass is then
+                                  laid out [B*A, .].  Slices t >= length[b] reach nothing in the
+                                  reference either: dynamic_rnn(sequence_length) zeroes their outputs
+                                  (score.py:205-208) and the temporal attention masks them to an exact 0
+                                  weight (:182-185), so loss, predictions and every gradient are
+                                  unchanged; samples with length[b] > A are treated as length A.
+                                  The index tensors keep their [B,T,K,F] strides.                   */
 } score_batch_t;
 
 /* Named float offsets into the workspace (for tests / introspection). */

@@ -30,7 +30,7 @@ class ParamEntry(C.Structure):
 class Batch(C.Structure):
     _fields_ = [("user_1hop", c_i), ("user_2hop", c_i), ("item_1hop", c_i), ("item_2hop", c_i),
                 ("target_user", c_i), ("target_item", c_i), ("label", c_i), ("length", c_i),
-                ("B", C.c_int32)]
+                ("B", C.c_int32), ("active_slices", C.c_int32)]
 
 
 class Workspace(C.Structure):

@@ -84,8 +84,11 @@ __global__ __launch_bounds__(256) void coattn_fwd_kernel(const CoattnArgs a) {
     }
   }
 
-  const int32_t* __restrict__ i1 = cc.idx1 + (int64_t)u * K * F;
-  const int32_t* __restrict__ i2 = cc.idx2 + (int64_t)u * K * F;
+  // unit u = b * T + t over the ACTIVE time slices; the index tensors keep their [B, Tidx, K, F] strides
+  const int b_idx = u / a.T;
+  const int64_t ui = (int64_t)b_idx * a.Tidx + (u - b_idx * a.T);
+  const int32_t* __restrict__ i1 = cc.idx1 + ui * K * F;
+  const int32_t* __restrict__ i2 = cc.idx2 + ui * K * F;
   float4 v1[SPL][KMAX];
   float4 sum2[SPL];
   float part[KMAX];
@@ -129,7 +132,6 @@ __global__ __launch_bounds__(256) void coattn_fwd_kernel(const CoattnArgs a) {
   }
 
   // c = w_t . target + bias (constant over t and i), then r_i = relu(part_i + c)
-  const int b_idx = u / a.T;
   float cpart = 0.f;
 #pragma unroll
   for (int j = 0; j < SPL; ++j)
@@ -237,8 +239,10 @@ __global__ __launch_bounds__(256, (KMAX <= 10 && SPL == 1) ? 4 : 1) void coattn_
     const int unit = (it * waves_total + wave0) * upw + grp;
     const bool unit_ok = unit < n_units;
     const int u = unit_ok ? unit : 0;
-    const int32_t* __restrict__ i1 = cc.idx1 + (int64_t)u * K * F;
-    const int32_t* __restrict__ i2 = cc.idx2 + (int64_t)u * K * F;
+    const int ub = u / a.T;
+    const int64_t ui = (int64_t)ub * a.Tidx + (u - ub * a.T);   // [B, Tidx, K, F] strides of the index tensors
+    const int32_t* __restrict__ i1 = cc.idx1 + ui * K * F;
+    const int32_t* __restrict__ i2 = cc.idx2 + ui * K * F;
     float4 g1[SPL], g2[SPL];
     bool ok[SPL];
 #pragma unroll
@@ -429,6 +433,7 @@ int score_coattn_fwd_multi(CoattnArgs& a, int ncalls, int D, int B, hipStream_t 
   int spl = 1, total = 0;
   a.D4 = D / 4;
   a.n_units = B * a.T;
+  if (a.Tidx <= 0) a.Tidx = a.T;
   for (int c = 0; c < 2; ++c) {
     if (c >= ncalls) { a.c[c] = a.c[0]; a.c[c].first_block = 0x7fffffff; continue; }
     int SPLc;
@@ -451,6 +456,7 @@ int score_coattn_bwd_multi(CoattnArgs& a, int ncalls, int D, int B, float* const
   int64_t used = 0;
   a.D4 = D / 4;
   a.n_units = B * a.T;
+  if (a.Tidx <= 0) a.Tidx = a.T;
   for (int c = 0; c < 2; ++c) {
     if (c >= ncalls) { a.c[c] = a.c[0]; a.c[c].first_block = 0x7fffffff; continue; }
     int SPLc;

@@ -47,6 +47,13 @@ int make_dims(const score_config_t* c, Dims* d) {
   return 0;
 }
 
+// time slices actually computed for a batch (score_batch_t.active_slices): every [B*T, .] activation of the
+// pass is laid out [B * TA, .]; the workspace regions keep their full-T sizes and offsets
+static inline int active_T(const Dims& d, const score_batch_t* bt) {
+  const int a = bt->active_slices;
+  return (a > 0 && a < d.T) ? a : d.T;
+}
+
 // ---------------------------------------------------------------- dense parameter layout
 struct PEntry { const char* name; int rows, cols, reg, init; };
 
@@ -216,7 +223,10 @@ void build_ws(const Dims& d, int B, WS* w) {
   w->sort_temp_bytes = (int64_t)tb;
   w->sort_temp = take((int64_t)(tb + 3) / 4 + 4);
   {
-    const int64_t nw = cdiv64(np, score_pull_window(np));
+    // fewer active slices shrink the occurrence list, and a shorter list may use a narrower window:
+    // below 2^20 occurrences there are never more than 2^15 windows
+    int64_t nw = cdiv64(np, score_pull_window(np));
+    if (nw < (1 << 15) + 1) nw = (1 << 15) + 1;
     w->partial_floats = 2 * nw * d.D + 8 + 2 * nw;
   }
   w->partials = take(w->partial_floats);
@@ -298,7 +308,8 @@ extern "C" int score_index_plan(const score_config_t* cfg, const score_state_t* 
   Dims d;
   SCORE_TRY(make_dims(cfg, &d));
   if (!st || !bt || !st->workspace || bt->B <= 0 || n_shards < 1 || n_shards > 64) return SCORE_E_BADARG;
-  const int B = bt->B, BT = B * d.T;
+  const int TA = active_T(d, bt);
+  const int B = bt->B, BT = B * TA;
   WS w;
   build_ws(d, B, &w);
   if (w.total * 4 > st->workspace_bytes) return SCORE_E_WORKSPACE;
@@ -316,7 +327,7 @@ extern "C" int score_index_plan(const score_config_t* cfg, const score_state_t* 
     pf.idx[g] = idx[g]; pf.F[g] = Fs[g]; pf.off[g] = off;
     off += (g < 4 ? (int64_t)BT * d.K : (int64_t)B) * Fs[g];
   }
-  pf.off[6] = off; pf.K = d.K; pf.G = n_shards;
+  pf.off[6] = off; pf.K = d.K; pf.G = n_shards; pf.T = d.T; pf.TA = TA;
   // key = row (1 shard) or (owner = row % G) << shift | (row / G)
   const int64_t rows_local = cdiv64(d.N, n_shards);
   int shift = 1;
@@ -336,9 +347,9 @@ extern "C" int score_index_plan(const score_config_t* cfg, const score_state_t* 
     PlanRemapArgs ra;
     memset(&ra, 0, sizeof(ra));
     for (int g = 0; g < 6; ++g) { ra.out[g] = reinterpret_cast<int32_t*>(ws + w.remap[g]); ra.F[g] = Fs[g]; }
-    ra.K = d.K;
+    ra.K = d.K; ra.T = d.T; ra.TA = TA;
     // keys_in / vals_in are dead after the sort: reuse them for the head flags and the unique keys
-    G(score_launch_plan_unique(ra, keys_out, vals_out, w.n_occ + 1, keys_in, reinterpret_cast<uint32_t*>(ws + w.uid),
+    G(score_launch_plan_unique(ra, keys_out, vals_out, off + 1, keys_in, reinterpret_cast<uint32_t*>(ws + w.uid),
                                vals_in, reinterpret_cast<int32_t*>(ws + w.unique_rows),
                                reinterpret_cast<int32_t*>(ws + w.meta), n_shards, shift, ws + w.sort_temp,
                                (size_t)w.sort_temp_bytes, s));
@@ -359,7 +370,7 @@ extern "C" int score_forward(const score_config_t* cfg, const score_state_t* st,
   if (!(keep_prob > 0.f) || keep_prob > 1.f) return SCORE_E_BADARG;
   Params P;
   build_layout(d, nullptr, 0, &P);
-  const int B = bt->B, T = d.T, H = d.H, BT = B * T;
+  const int B = bt->B, T = active_T(d, bt), H = d.H, BT = B * T;   // T: the time slices computed
   WS w;
   build_ws(d, B, &w);
   if (w.total * 4 > st->workspace_bytes) return SCORE_E_WORKSPACE;
@@ -396,7 +407,7 @@ extern "C" int score_forward(const score_config_t* cfg, const score_state_t* st,
   {
     CoattnArgs ca;
     memset(&ca, 0, sizeof(ca));
-    ca.table = st->table; ca.K = d.K; ca.T = T; ca.mode = d.coattn ? 0 : 1;
+    ca.table = st->table; ca.K = d.K; ca.T = T; ca.Tidx = d.T; ca.mode = d.coattn ? 0 : 1;
     const int ldi = 4 * d.K;
     CoattnCall& c0 = ca.c[0];
     c0.idx1 = bt->user_1hop; c0.idx2 = bt->item_2hop; c0.tgt = ws + w.query + d.Du; c0.ldt = d.Dq;
@@ -479,7 +490,7 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
     return SCORE_E_BADARG;
   Params P;
   build_layout(d, nullptr, 0, &P);
-  const int B = bt->B, T = d.T, H = d.H, BT = B * T;
+  const int B = bt->B, T = active_T(d, bt), H = d.H, BT = B * T;   // T: the time slices computed
   WS w;
   build_ws(d, B, &w);
   if (w.total * 4 > st->workspace_bytes) return SCORE_E_WORKSPACE;
@@ -618,7 +629,7 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
   {
     CoattnArgs ca;
     memset(&ca, 0, sizeof(ca));
-    ca.table = st->table; ca.gtable = grad_table; ca.K = d.K; ca.T = T; ca.mode = d.coattn ? 0 : 1;
+    ca.table = st->table; ca.gtable = grad_table; ca.K = d.K; ca.T = T; ca.Tidx = d.T; ca.mode = d.coattn ? 0 : 1;
     const int ldi = 4 * d.K;
     CoattnCall& c0 = ca.c[0];
     c0.idx1 = bt->user_1hop; c0.idx2 = bt->item_2hop; c0.W = d.coattn ? W + P.ca_w[0] : nullptr;
@@ -661,7 +672,8 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
       pa.Wv[0] = W + P.ca_w[0] + d.Di; pa.Wv[1] = W + P.ca_w[0] + 2 * d.Di;
       pa.Wv[2] = W + P.ca_w[1] + d.Du; pa.Wv[3] = W + P.ca_w[1] + 2 * d.Du;
     }
-    G(score_launch_pull(pa, keys_out, vals_out, w.n_occ + 1, grad_table, ws + w.partials, w.partial_floats, s));
+    const int64_t n_occ = (int64_t)B * (2 * (int64_t)T * d.K * (d.Fu + d.Fi) + d.Fu + d.Fi);   // what score_index_plan enumerated
+    G(score_launch_pull(pa, keys_out, vals_out, n_occ + 1, grad_table, ws + w.partials, w.partial_floats, s));
   }
   EV(4);
   // the remaining weight-gradient products of the pass, then the gradients assembled from them

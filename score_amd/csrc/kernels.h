@@ -49,6 +49,7 @@ struct CoattnArgs {
   CoattnCall c[2];
   const float* table; float* gtable;
   int D4, K, T, n_units, mode;
+  int Tidx;                                   // time stride of the index tensors ([B, Tidx, K, F]); 0 = T.  T = slices computed
 };
 int score_coattn_fwd_multi(CoattnArgs& a, int ncalls, int D, int B, hipStream_t s);
 int score_coattn_bwd_multi(CoattnArgs& a, int ncalls, int D, int B, float* const dW[2], float* scratch,
@@ -101,6 +102,7 @@ struct PlanFillArgs {
   int64_t off[7];          // prefix offsets of the six tensors in the occurrence space
   int F[6];
   int K, G, shift;         // G > 1: key = (row % G) << shift | row / G
+  int T, TA;               // index tensors are [B, T, K, F]; only slices t < TA are enumerated (bt = b * TA + t)
 };
 struct PullArgs {
   const float* G[6]; int ldg[6]; int gcol[6];     // activation-gradient matrix per segment
@@ -112,7 +114,7 @@ struct PullArgs {
   int zero_is_dummy;       // key 0 is the masked dummy row (score.py:44-47): no gradient
   uint8_t* flags;          // optional per-destination-row state byte: 2 = written this step
 };
-struct PlanRemapArgs { int32_t* out[6]; int F[6]; int K; };
+struct PlanRemapArgs { int32_t* out[6]; int F[6]; int K; int T, TA; };
 int score_launch_plan_unique(const PlanRemapArgs& ra, const uint32_t* keys, const uint32_t* vals, int64_t n,
                              uint32_t* flags_scratch, uint32_t* uid, uint32_t* unique_keys, int32_t* unique_rows,
                              int32_t* meta, int G, int shift, void* temp, size_t temp_bytes, hipStream_t s);

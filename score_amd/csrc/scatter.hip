@@ -39,7 +39,11 @@ __global__ void plan_fill_kernel(PlanFillArgs a, uint32_t* __restrict__ keys, ui
     f = (uint32_t)(local % F);
     int64_t q = local / F;
     k = (uint32_t)(q % a.K);
-    bt = (uint32_t)(q / a.K);
+    bt = (uint32_t)(q / a.K);          // b * TA + t: the occurrence space holds the active slices only
+    if (a.TA != a.T) {                 // position inside the [B, T, K, F] index tensor
+      const uint32_t b = bt / (uint32_t)a.TA;
+      local = (((int64_t)b * a.T + (bt - b * (uint32_t)a.TA)) * a.K + k) * F + f;
+    }
   } else {
     f = (uint32_t)(local % F);
     k = 0;
@@ -119,7 +123,11 @@ __global__ void plan_remap_kernel(PlanRemapArgs a, const uint32_t* __restrict__ 
   const int seg = desc >> 29;
   if (seg > 5) return;
   const int f = (desc >> 26) & 7, k = (desc >> 21) & 31;
-  const int64_t bt = desc & 0x1FFFFF;
+  int64_t bt = desc & 0x1FFFFF;
+  if (seg < 4 && a.TA != a.T) {   // b * TA + t -> b * T + t
+    const int64_t b = bt / a.TA;
+    bt = b * a.T + (bt - b * a.TA);
+  }
   const int64_t local = seg < 4 ? (bt * a.K + k) * a.F[seg] + f : bt * a.F[seg] + f;
   a.out[seg][local] = (int32_t)uid[i];
 }

@@ -182,7 +182,7 @@ class HipBackend(object):
         rm = [ws[lay.plan_remap[g]:lay.plan_remap[g] + sizes[g]].view(torch.int32) for g in range(6)]
         # plan order: user_1hop, item_2hop, user_2hop, item_1hop, target_user, target_item
         remapped = _lib.Batch(_ptr(rm[0]), _ptr(rm[2]), _ptr(rm[3]), _ptr(rm[1]), _ptr(rm[4]), _ptr(rm[5]),
-                              _ptr(db.tensors[6]), _ptr(db.tensors[7]), db.B)
+                              _ptr(db.tensors[6]), _ptr(db.tensors[7]), db.B, getattr(db, "active_slices", 0))
         return dict(db=db, remapped=remapped, keep=rm, U=U, offsets=offs, unique_rows=uniq, slot=h["slot"],
                     event=h["event"])
 

@@ -110,10 +110,11 @@ class TemporalGraph(object):
 
 
 class _AssembledBatch(DeviceBatch):
-    def __init__(self, tensors, B):      # bypass host conversion: tensors are already int32 on the device
+    def __init__(self, tensors, B, active=0):   # bypass host conversion: tensors are already int32 on the device
         self.tensors = tensors
         self.B = B
-        self.struct = _lib.Batch(*[_ptr(t) for t in tensors], B)
+        self.active_slices = int(active)  # every sample has length pred_time - start_time (graph_loader.py:382)
+        self.struct = _lib.Batch(*[_ptr(t) for t in tensors], B, self.active_slices)
 
     def __len__(self):
         return 8
@@ -178,4 +179,5 @@ class DeviceGraphLoader(object):
         _lib.check(rc, "score_batch_assemble")
         self._pos += n
         self._batch_no += 1
-        return _AssembledBatch(tens, B)
+        length = self.pred_time - self.start_time
+        return _AssembledBatch(tens, B, length if 0 < length < T else 0)

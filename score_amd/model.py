@@ -43,6 +43,7 @@ class DeviceBatch(object):
         T, K, Fu, Fi = c.max_time_len, c.obj_per_time_slice, c.user_fnum, c.item_fnum
         self.tensors = []
         B = None
+        max_len = None
         shapes = ((T, K, Fi), (T, K, Fu), (T, K, Fu), (T, K, Fi), (Fu,), (Fi,), (), ())
         for i, x in enumerate(batch_data):
             if torch.is_tensor(x):
@@ -53,6 +54,8 @@ class DeviceBatch(object):
                 if a.dtype != np.int32:
                     a = a.astype(np.int32)
                 t = torch.from_numpy(np.ascontiguousarray(a)).to(model.device, non_blocking=True)
+                if i == 7 and a.size:
+                    max_len = int(a.max())
             if B is None:
                 B = t.shape[0]
             if tuple(t.shape) != (B,) + shapes[i]:
@@ -62,7 +65,21 @@ class DeviceBatch(object):
         if B == 0:
             raise ValueError("empty batch")
         self.B = B
-        self.struct = _lib.Batch(*[_ptr(t) for t in self.tensors], B)
+        if max_len is None:                  # `length` arrived as a device tensor: one read-back per batch object
+            max_len = int(self.tensors[7].max().item())
+        self.active_slices = active_slices(model, max_len)
+        self.struct = _lib.Batch(*[_ptr(t) for t in self.tensors], B, self.active_slices)
+
+
+def active_slices(model, max_len):
+    """score_batch_t.active_slices for a batch whose longest sample has `max_len` slices: the slices past every
+    sample's length are masked out of the result by the model itself (dynamic_rnn's sequence_length,
+    score.py:205-208; the attention mask, :182-185) and are not gathered or computed.  0 = all T."""
+    T = int(model.cfg.max_time_len)
+    if not getattr(model, "skip_masked_slices", True):
+        return 0
+    a = min(max(int(max_len), 1), T)
+    return 0 if a >= T else a
 
 
 class SCOREBASE(object):
@@ -93,6 +110,7 @@ class SCOREBASE(object):
         self.scatter_mode = 0      # 0: sorted pull-form scatter, 1: float atomics (score_hip.h)
         self.global_batch = 0      # >0: the loss mean runs over this many samples (data parallel)
         self._side = None
+        self.skip_masked_slices = True   # batches carry active_slices = max(length): slices every sample masks are skipped
         self.gemm_mode = 1         # 1: bf16x3 split (fp32-accurate) on the shapes where it measured faster, 0: f32 MFMA only
         self._init_params(seed)
 
@@ -228,7 +246,8 @@ class SCOREBASE(object):
         return batch_data if isinstance(batch_data, DeviceBatch) else DeviceBatch(self, batch_data)
 
     def ws_tensor(self, B, field, shape):
-        """View of a named workspace region (tests / introspection)."""
+        """View of a named workspace region (tests / introspection).  Per-slice regions hold
+        [B * A, .] rows when the batch ran with A = active_slices < T: pass A in place of T."""
         lay, buf = self._workspace(B)
         off = getattr(lay, field)
         n = int(np.prod(shape))

@@ -72,19 +72,27 @@ def run_ranks(world, fn):
     return res
 
 
-@pytest.mark.parametrize("world,model_type,cfg_args,B", [
-    (2, "SCORE", (203, 4, 8, 3, 3, 3, 4), 6),
-    (4, "SCORE", (5001, 16, 32, 5, 10, 3, 4), 16),
-    (3, "RCA", (1000, 16, 16, 4, 5, 1, 2), 8),
-    (2, "RIA", (777, 8, 16, 4, 4, 3, 4), 10),
+@pytest.mark.parametrize("world,model_type,cfg_args,B,len_caps", [
+    (2, "SCORE", (203, 4, 8, 3, 3, 3, 4), 6, None),
+    (4, "SCORE", (5001, 16, 32, 5, 10, 3, 4), 16, None),
+    (3, "RCA", (1000, 16, 16, 4, 5, 1, 2), 8, None),
+    (2, "RIA", (777, 8, 16, 4, 4, 3, 4), 10, None),
+    # every sample shorter than T, and a different longest sample per rank: each rank skips its own masked
+    # slices (score_batch_t.active_slices), the single device those of the concatenated batch
+    (2, "SCORE", (5001, 16, 32, 6, 5, 3, 4), 12, (3, 4)),
+    (8, "SCORE", (4099, 8, 16, 5, 4, 3, 4), 6, (3, 4, 2, 4, 1, 3, 4, 4)),
 ])
-def test_virtual_ranks_match_single_device(world, model_type, cfg_args, B):
+def test_virtual_ranks_match_single_device(world, model_type, cfg_args, B, len_caps):
     from score_amd.dist import ShardedSCORE
     from score_amd.model import MODELS
     cfg = so.Cfg(*cfg_args, model_type=model_type)
     params = so.init_params(cfg, 5)
     steps = 4
     batches = [[random_batch(np.random.default_rng(100 * r + s), cfg, B) for s in range(steps)] for r in range(world)]
+    if len_caps is not None:
+        for r in range(world):
+            for b in batches[r]:
+                b["length"] = np.minimum(b["length"], len_caps[r]).astype(np.int32)
 
     def fn(rank, comm):
         m = ShardedSCORE(*cfg_args, comm=comm, model_type=model_type)

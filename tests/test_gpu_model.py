@@ -52,24 +52,36 @@ def test_golden_forward_backward_adam(name):
     assert isinstance(pred, list) and len(pred) == B and label == b["label"].tolist()
     assert np.abs(np.asarray(pred) - z["fwd/y_pred"]).max() < LOGIT_TOL
     assert abs(loss - float(z["fwd/loss"])) < 1e-5 * max(1.0, abs(float(z["fwd/loss"])))
-    # intermediates
-    lay, ws = m.forward_backward(batch_tuple(b), lam, 1.0)
-    torch.cuda.synchronize()
+    # intermediates; with skip_masked_slices the per-slice regions hold [B * A, .] rows, A = max(length): the
+    # slices every sample masks (dynamic_rnn sequence_length, attention mask) are not computed at all
     T, I = cfg.T, cfg.Di + cfg.Du
-    logit = ws[lay.logit:lay.logit + B].cpu().numpy()
-    assert np.abs(logit - z["fwd/logit"]).max() < LOGIT_TOL
-    xs = m.ws_tensor(B, "xside", (2, B, T, I)).cpu().numpy()
-    us, its = z["fwd/user_side"], z["fwd/item_side"]      # (RRN: the summed 1-hop sets only -- the leading columns)
-    assert close(xs[0][..., :us.shape[-1]], us)[0] and close(xs[1][..., :its.shape[-1]], its)[0]
-    go = m.ws_tensor(B, "gru_out", (2, B, T, cfg.H)).cpu().numpy()
-    assert close(go[0], z["fwd/user_rep"])[0] and close(go[1], z["fwd/item_rep"])[0]
-    hi = m.ws_tensor(B, "head_inp", (B, cfg.Dhead)).cpu().numpy()
-    assert close(hi, z["fwd/head_inp"])[0]
-    if "fwd/att_score" in z.files:
-        sc = m.ws_tensor(B, "att_score", (B, T)).cpu().numpy()
-        assert close(sc, z["fwd/att_score"], atol=1e-6)[0]
+    for skip in (False, True):
+        m.skip_masked_slices = skip
+        lay, ws = m.forward_backward(batch_tuple(b), lam, 1.0)
+        torch.cuda.synchronize()
+        A = min(int(b["length"].max()), T) if skip else T
+        logit = ws[lay.logit:lay.logit + B].cpu().numpy()
+        assert np.abs(logit - z["fwd/logit"]).max() < LOGIT_TOL
+        xs = m.ws_tensor(B, "xside", (2, B * T * I))[:, :B * A * I].reshape(2, B, A, I).cpu().numpy()
+        us, its = z["fwd/user_side"][:, :A], z["fwd/item_side"][:, :A]   # (RRN: the summed 1-hop sets only -- the leading columns)
+        assert close(xs[0][..., :us.shape[-1]], us)[0] and close(xs[1][..., :its.shape[-1]], its)[0]
+        go = m.ws_tensor(B, "gru_out", (2, B * T * cfg.H))[:, :B * A * cfg.H].reshape(2, B, A, cfg.H).cpu().numpy()
+        assert close(go[0], z["fwd/user_rep"][:, :A])[0] and close(go[1], z["fwd/item_rep"][:, :A])[0]
+        hi = m.ws_tensor(B, "head_inp", (B, cfg.Dhead)).cpu().numpy()
+        assert close(hi, z["fwd/head_inp"])[0]
+        if "fwd/att_score" in z.files:
+            sc = m.ws_tensor(B, "att_score", (B, A)).cpu().numpy()
+            assert close(sc, z["fwd/att_score"][:, :A], atol=1e-6)[0]
+            assert not z["fwd/att_score"][:, A:].any()      # what is skipped carries exactly zero weight
+        if skip:
+            g_noskip = g
+            g = m.get_grads()
+            for k in g:      # same gradients with and without the masked slices
+                ok, err = close(g[k], g_noskip[k], rtol=2e-6, atol=1e-9)
+                assert ok, (k, err)
+        else:
+            g = m.get_grads()
     # gradients (dense emb grad with row 0 == 0; dense grads carry no L2 term: the oracle's do)
-    g = m.get_grads()
     for e in m.entries:
         want = z["grad/" + e[0]].copy()
         if e[4]:
@@ -166,6 +178,45 @@ def test_random_midsize_vs_oracle(mt):
     po, _, _ = om.eval(None, batch_tuple(b), 1e-4)
     assert np.abs(np.asarray(pg) - np.asarray(po)).max() < LOGIT_TOL
     assert round(roc_auc_score(lab, pg), 4) == round(roc_auc_score(lab, po), 4)
+
+
+@pytest.mark.parametrize("mt", so.MODEL_TYPES)
+def test_masked_slices_skipped_vs_oracle(mt):
+    # every sample shorter than T (the reference's train split: 9 of 11 slices, graph_loader.py:382): the slices
+    # past the longest sample are not gathered or computed (score_batch_t.active_slices) -- same losses,
+    # predictions and parameters as the oracle, which computes and masks them, and as the model with the skip off
+    cfg = so.Cfg(4000, 16, 32, 8, 6, 3, 4, mt)
+    rng = np.random.default_rng(23)
+    P = so.init_params(cfg, 4)
+    b = random_batch(rng, cfg, 64)
+    b["length"] = rng.integers(1, 6, 64).astype(np.int32)          # longest sample: 5 of T = 8
+    b["label"] = (np.arange(64) % 2).astype(np.int32)
+    m, m_all = make_model(cfg, P), make_model(cfg, P)
+    m_all.skip_masked_slices = False
+    assert m.device_batch(batch_tuple(b)).active_slices == 5 and m_all.device_batch(batch_tuple(b)).active_slices == 0
+    om = so.OracleModel(cfg.N, cfg.D, cfg.H, cfg.T, cfg.K, cfg.Fu, cfg.Fi, mt, params={k: v.copy() for k, v in P.items()})
+    for step in range(3):
+        lg = m.train(None, batch_tuple(b), 1e-3, 1e-4, keep_prob=1.0)
+        la = m_all.train(None, batch_tuple(b), 1e-3, 1e-4, keep_prob=1.0)
+        lo = om.train(None, batch_tuple(b), 1e-3, 1e-4, keep_prob=1.0)
+        assert abs(lg - lo) < 2e-5 * max(1.0, abs(lo)) and abs(lg - la) < 2e-6 * max(1.0, abs(la))
+        if step == 0:      # one Adam step: where the gradient is above noise the two tables agree
+            ga, gs = m_all.get_params()["emb_mtx"], m.get_params()["emb_mtx"]
+            assert (np.abs(ga - gs) <= 3e-6).mean() > 0.999
+    pg, lab, _ = m.eval(None, batch_tuple(b), 1e-4)
+    po, _, _ = om.eval(None, batch_tuple(b), 1e-4)
+    assert np.abs(np.asarray(pg) - np.asarray(po)).max() < LOGIT_TOL
+    # rows used only by masked slices get no gradient in the reference either: never marked, never moved
+    live = np.zeros(cfg.N, bool)
+    for k in NAMES[:4]:
+        for i in range(64):
+            live[b[k][i, :int(b["length"].max())].ravel()] = True
+    for k in NAMES[4:6]:
+        live[b[k].ravel()] = True
+    dead_only = np.setdiff1d(np.unique(np.concatenate([b[k].ravel() for k in NAMES[:6]])), np.nonzero(live)[0])
+    assert len(dead_only) > 0
+    assert np.array_equal(m.get_params()["emb_mtx"][dead_only], P["emb_mtx"][dead_only])
+    assert np.array_equal(m_all.get_params()["emb_mtx"][dead_only], P["emb_mtx"][dead_only])
 
 
 @pytest.mark.parametrize("H,B", [(48, 96), (256, 4096)])
