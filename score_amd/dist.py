@@ -219,13 +219,34 @@ class HipBackend(object):
         B = plan["db"].B
         return dict(lay=lay, ws=ws, st=st, y_pred=ws[lay.y_pred:lay.y_pred + B], loss=ws[lay.loss:lay.loss + 3])
 
-    def backward(self, plan, mini, fw, keep_prob):
+    def backward(self, plan, mini, fw, keep_prob, scatter_event=None):
+        """scatter_event (a torch.cuda.Event already recorded once): recorded by score_backward on its stream as
+        soon as the row gradients are complete (stage boundary 4), i.e. before the weight-gradient products of
+        the pass -- the caller starts the row-gradient exchange behind it.  Returns (mini_g, that event)."""
         m = self.m
-        mini_g = torch.zeros_like(mini)
+        # every unique position holds a row with at least one use in the batch, so the pull scatter stores it
+        # exactly once; position 0 (the dummy row, whose uses are skipped) is the only one left to clear
+        mini_g = torch.empty_like(mini)
+        mini_g[0].zero_()
+        events = list(m.bwd_events) if m.bwd_events else None
+        if scatter_event is not None:
+            if events is None:
+                events = [None] * 6
+            if events[4] is None:
+                events[4] = scatter_event
         rc = self.lib.score_backward(C.byref(m.cfg), C.byref(fw["st"]), C.byref(plan["remapped"]), float(keep_prob),
-                                     _ptr(m.w_g), _ptr(mini_g), m._event_array(m.bwd_events), m._stream())
+                                     _ptr(m.w_g), _ptr(mini_g), m._event_array(events), m._stream())
         _lib.check(rc, "score_backward")
+        if scatter_event is not None:
+            return mini_g, events[4]
         return mini_g
+
+    def dense_grad_with_loss(self, fw):
+        """[n_w + 4] buffer: the dense gradient followed by this rank's share of the global log-loss mean
+        (so one all-reduce carries both); element n_w is the global log-loss afterwards."""
+        m = self.m
+        m._w_g_ext[m.n_w:m.n_w + 1].copy_(fw["loss"][1:2])
+        return m._w_g_ext
 
     def accumulate(self, req_rows, grads_in, counts=None):
         """Combine the row gradients received from every rank into this shard's table gradient.
@@ -278,6 +299,7 @@ class ShardedSCORE(object):
         self.device = self.backend.device
         self.D = int(eb_dim)
         self._side, self._slot, self._slot_done, self._prefetched = None, 0, [None, None, None], None
+        self._gside = None
         if self.device.type == "cuda" and hasattr(self.comm, "index_comm"):
             # bring both communicators up now (every rank constructs the model): their lazy first-use
             # initialisation costs tens of ms and would otherwise land inside a training step
@@ -395,6 +417,28 @@ class ShardedSCORE(object):
         B = plan["B"] if "B" in plan else plan["db"].B
         be.set_global_batch(B * self.world)
         fw = be.forward(plan, mini, reg_lambda, keep_prob, dropout_masks)
+        if self.device.type == "cuda" and hasattr(be, "dense_grad_with_loss") and not os.environ.get("SCORE_LATE_GRADS"):
+            # The row gradients are complete before the weight-gradient products of the backward pass
+            # (score_backward's stage boundary 4): their all-to-all and the owner-side accumulate start there, on a
+            # side stream, under those products.  The dense gradient goes out at the end of the pass in ONE
+            # all-reduce together with the log-loss share.
+            if self._gside is None:
+                self._gside = torch.cuda.Stream(device=self.device)
+                self._ev_scatter = torch.cuda.Event()
+                self._ev_scatter.record(torch.cuda.current_stream(self.device))      # materialise the hipEvent_t
+            cur = torch.cuda.current_stream(self.device)
+            mini_g, ev = be.backward(plan, mini, fw, keep_prob, scatter_event=self._ev_scatter)
+            grads_in = torch.empty((plan["req"].numel(), self.D), dtype=torch.float32, device=self.device)
+            self._gside.wait_event(ev)
+            with torch.cuda.stream(self._gside):
+                cm.all_to_all(grads_in, mini_g, plan["recv"], plan["send"])
+                be.accumulate(plan["req"], grads_in, plan["recv"])
+                done = self._gside.record_event()
+            buf = be.dense_grad_with_loss(fw)
+            cm.all_reduce_sum(buf)
+            cur.wait_event(done)            # (also orders the frees of mini_g / grads_in behind their last use)
+            n_w = buf.numel() - 4
+            return (None, buf[n_w], fw["loss"][2]), fw      # [-, global log-loss, l2]
         mini_g = be.backward(plan, mini, fw, keep_prob)
         grads_in = torch.empty((plan["req"].numel(), self.D), dtype=torch.float32, device=self.device)
         cm.all_to_all(grads_in, mini_g, plan["recv"], plan["send"])

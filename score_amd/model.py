@@ -126,7 +126,10 @@ class SCOREBASE(object):
         self._flags_marked = False   # table_flags may hold 2s
         self.w_m = torch.zeros((self.n_w,), **f32)
         self.w_v = torch.zeros((self.n_w,), **f32)
-        self.w_g = torch.zeros((self.n_w,), **f32)
+        # four spare floats behind the dense gradient: the sharded path appends its share of the log-loss so that
+        # one all-reduce carries both (score_amd/dist.py)
+        self._w_g_ext = torch.zeros((self.n_w + 4,), **f32)
+        self.w_g = self._w_g_ext[:self.n_w]
 
     def _view(self, flat, entry):
         name, off, rows, cols, _, _ = entry
@@ -226,7 +229,7 @@ class SCOREBASE(object):
         """torch.cuda.Events (timing enabled, already recorded once) -> hipEvent_t[], or NULL."""
         if not events:
             return None
-        return (C.c_void_p * len(events))(*[C.c_void_p(e.cuda_event) for e in events])
+        return (C.c_void_p * len(events))(*[C.c_void_p(e.cuda_event if e is not None else 0) for e in events])
 
     def enable_stage_events(self, on=True):
         """Record stage-boundary events inside score_forward/backward (bench.py's live
