@@ -88,23 +88,25 @@ class SynthWorld(object):
         rows[picks < 0] = 0
         return rows.astype(np.int32)
 
-    def batch(self, B, batch_idx=0, length=None, as_lists=False):
-        assert B % 2 == 0, "train batches hold one positive + one negative per user"
+    def batch(self, B, batch_idx=0, length=None, as_lists=False, per_user=2):
+        """per_user = candidates per target line: 2 for training (one positive + one negative,
+        graph_loader.py:289-292), 100 for the ranking evaluation (1 + 99, train_score.py:19)."""
+        assert B % per_user == 0, "batches hold whole target lines (one positive + the negatives of a user)"
         rng = np.random.Generator(np.random.PCG64([self.seed, 7919, batch_idx]))
         T = self.T
         length = max(T - 2, 1) if length is None else length
-        nu = B // 2
+        nu = B // per_user
         users = rng.integers(0, self.U, nu)
         items = rng.integers(0, self.I, B)
         u1, u2 = self._history(rng, nu, True, length)
         i1, i2 = self._history(rng, B, False, length)
-        user_1hop = np.repeat(self._expand(u1, True), 2, axis=0)
-        user_2hop = np.repeat(self._expand(u2, False), 2, axis=0)
+        user_1hop = np.repeat(self._expand(u1, True), per_user, axis=0)
+        user_2hop = np.repeat(self._expand(u2, False), per_user, axis=0)
         item_1hop = self._expand(i1, False)
         item_2hop = self._expand(i2, True)
-        target_user = np.repeat(self._user_rows(users), 2, axis=0).astype(np.int32)
+        target_user = np.repeat(self._user_rows(users), per_user, axis=0).astype(np.int32)
         target_item = self._item_rows(items).astype(np.int32)
-        label = (np.arange(B) % 2 == 0).astype(np.int32)
+        label = (np.arange(B) % per_user == 0).astype(np.int32)
         length_arr = np.full((B,), length, dtype=np.int32)
         out = (user_1hop, user_2hop, item_1hop, item_2hop, target_user, target_item, label, length_arr)
         if as_lists:
