@@ -108,10 +108,11 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("SCORE_HIP_LIB") or LIB_PATH      # SCORE_HIP_LIB: another build of the same ABI (A/B runs)
+    if path == LIB_PATH and not os.path.exists(LIB_PATH):
         from . import build as _build
         _build.build()
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, args in _SIGS.items():
         fn = getattr(lib, name)      # AttributeError if a declared symbol is missing
         fn.argtypes = args

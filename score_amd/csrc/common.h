@@ -42,6 +42,52 @@ __device__ __forceinline__ float group_sum(float v, int gs) {
   return v;
 }
 __device__ __forceinline__ float wave_sum(float v) { return group_sum(v, SCORE_WAVE); }
+
+// N independent group sums at once (same contract as group_sum for each v[n]; the result is bitwise the
+// xor-butterfly's, so every lane of a group holds identical bits).  The four steps inside a row of 16 lanes
+// are DPP adds (quad_perm xor 1, xor 2, then row_half_mirror / row_mirror, which reach the partner quad /
+// half once the quads are uniform): one VALU instruction each, no LDS.  The two cross-row steps go through
+// ds_bpermute with the N values of a step in flight together and the partner address computed once.
+// A __shfl_xor chain per value costs ~9 VALU instructions and one dependent LDS round trip per step and value
+// (66 round trips for the 11 scores of a K = 10 unit: that, not memory, bounded the fused gather).
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+template <int N>
+__device__ __forceinline__ void group_sum_n(float (&v)[N], int gs) {
+  if (gs >= 2) {
+#pragma unroll
+    for (int n = 0; n < N; ++n) v[n] += dpp_f32<0xB1>(v[n]);     // quad_perm [1,0,3,2]
+  }
+  if (gs >= 4) {
+#pragma unroll
+    for (int n = 0; n < N; ++n) v[n] += dpp_f32<0x4E>(v[n]);     // quad_perm [2,3,0,1]
+  }
+  if (gs >= 8) {
+#pragma unroll
+    for (int n = 0; n < N; ++n) v[n] += dpp_f32<0x141>(v[n]);    // row_half_mirror: lane i <-> 7 - i
+  }
+  if (gs >= 16) {
+#pragma unroll
+    for (int n = 0; n < N; ++n) v[n] += dpp_f32<0x140>(v[n]);    // row_mirror: lane i <-> 15 - i
+  }
+  if (gs >= 32) {
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int a16 = (lane ^ 16) << 2, a32 = (lane ^ 32) << 2;
+    float t[N];
+#pragma unroll
+    for (int n = 0; n < N; ++n) t[n] = __int_as_float(__builtin_amdgcn_ds_bpermute(a16, __float_as_int(v[n])));
+#pragma unroll
+    for (int n = 0; n < N; ++n) v[n] += t[n];
+    if (gs >= 64) {
+#pragma unroll
+      for (int n = 0; n < N; ++n) t[n] = __int_as_float(__builtin_amdgcn_ds_bpermute(a32, __float_as_int(v[n])));
+#pragma unroll
+      for (int n = 0; n < N; ++n) v[n] += t[n];
+    }
+  }
+}
 __device__ __forceinline__ float wave_max(float v) {
   for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, SCORE_WAVE));
   return v;
