@@ -289,43 +289,53 @@ __global__ __launch_bounds__(256, (KMAX <= 10 && SPL == 1) ? 4 : 1) void coattn_
       continue;
     }
 
-    // pass 1: seq1 rows -> dp_k = g1 . seq1_k (seq1 stays in registers for dw1)
-    int32_t r1[SPL][KMAX];
+    // pass 1: seq1 rows -> dp_k = g1 . seq1_k (seq1 stays in registers for dw1).  All 2K row ids, then the K
+    // seq1 rows, are loaded unconditionally up front (clamped addresses, zeroed by selects afterwards): under
+    // `if (k < K && ok)` every k was a region of its own that waited for its id and then for its row
+    int32_t r1[SPL][KMAX], rb2[SPL][KMAX];
     float4 v1[SPL][KMAX];
     float dp[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      const int kc = k < K ? k : K - 1;
+#pragma unroll
+      for (int j = 0; j < SPL; ++j) {
+        r1[j][k] = i1[kc * F + f[j]];
+        rb2[j][k] = i2[kc * F + f[j]];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+#pragma unroll
+      for (int j = 0; j < SPL; ++j) v1[j][k] = ld4(table + (int64_t)r1[j][k] * D + coff[j]);
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) {
       dp[k] = 0.f;
 #pragma unroll
       for (int j = 0; j < SPL; ++j) {
-        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-        int32_t ra = 0;
-        if (k < K && ok[j]) {
-          ra = i1[k * F + f[j]];
-          x = ld4(table + (int64_t)ra * D + coff[j]);
-        }
-        r1[j][k] = ra;
-        v1[j][k] = x;
+        const bool live = ok[j] && k < K;
+        v1[j][k].x = live ? v1[j][k].x : 0.f; v1[j][k].y = live ? v1[j][k].y : 0.f;
+        v1[j][k].z = live ? v1[j][k].z : 0.f; v1[j][k].w = live ? v1[j][k].w : 0.f;
+        r1[j][k] = live ? r1[j][k] : 0;
+        rb2[j][k] = live ? rb2[j][k] : 0;
       }
     }
-    // the seq2 row ids go in flight behind the seq1 rows (pass 2 then waits for its rows only)
-    int32_t rb2[SPL][KMAX];
-#pragma unroll
-    for (int j = 0; j < SPL; ++j)
-#pragma unroll
-      for (int k = 0; k < KMAX; ++k) rb2[j][k] = (k < K && ok[j]) ? i2[k * F + f[j]] : 0;
 #pragma unroll
     for (int k = 0; k < KMAX; ++k)
 #pragma unroll
       for (int j = 0; j < SPL; ++j) dp[k] += dot4(v1[j][k], g1[j]);
     // softmax from the saved relu'd scores
-    float r[KMAX], p[KMAX];
+    float r[KMAX], p[KMAX], gik[KMAX];
     float rmax = 0.f, gsum = 0.f;
 #pragma unroll
-    for (int k = 0; k < KMAX; ++k) {
-      r[k] = (k < K) ? cc.rsave[(int64_t)u * K + k] : 0.f;
+    for (int k = 0; k < KMAX; ++k) {      // (clamped, unconditional loads: see above)
+      const int kc = k < K ? k : K - 1;
+      const float rv = cc.rsave[(int64_t)u * K + kc];
+      const float g2v = cc.ginfo[(int64_t)u * cc.ldi + K + kc];
+      gik[k] = cc.ginfo[(int64_t)u * cc.ldi + kc];
+      r[k] = (k < K) ? rv : 0.f;
       rmax = fmaxf(rmax, r[k]);
-      if (k < K) gsum += cc.ginfo[(int64_t)u * cc.ldi + K + k];
+      gsum += (k < K) ? g2v : 0.f;
     }
     float den = 0.f;
 #pragma unroll
@@ -347,7 +357,7 @@ __global__ __launch_bounds__(256, (KMAX <= 10 && SPL == 1) ? 4 : 1) void coattn_
     for (int k = 0; k < KMAX; ++k) {
       dz[k] = 0.f;
       if (k < K) {
-        float dr = (float)K * cc.ginfo[(int64_t)u * cc.ldi + k] + gsum + p[k] * (dp[k] - pdp);
+        float dr = (float)K * gik[k] + gsum + p[k] * (dp[k] - pdp);
         dz[k] = r[k] > 0.f ? dr : 0.f;
         dzs += dz[k];
       }
@@ -367,10 +377,8 @@ __global__ __launch_bounds__(256, (KMAX <= 10 && SPL == 1) ? 4 : 1) void coattn_
     // dw1 first (frees the seq1 registers), then the seq2 rows stream through: dw2 += dz_k seq2_k
 #pragma unroll
     for (int j = 0; j < SPL; ++j) {
-      if (!ok[j]) continue;
 #pragma unroll
       for (int k = 0; k < KMAX; ++k) {
-        if (k >= K) continue;
         dw1[j] = fma4(dz[k], v1[j][k], dw1[j]);
         if (ATOMIC && r1[j][k] != 0) {
           float4 d1 = fma4(dz[k], w1[j],
@@ -379,26 +387,17 @@ __global__ __launch_bounds__(256, (KMAX <= 10 && SPL == 1) ? 4 : 1) void coattn_
         }
       }
     }
+    // pass 2: the K seq2 rows, all in flight together (masked uses carry row id 0: the all-zero dummy row)
 #pragma unroll
     for (int j = 0; j < SPL; ++j) {
-      if (!ok[j]) continue;
-      float4 g2k = make_float4(g2[j].x * invK, g2[j].y * invK, g2[j].z * invK, g2[j].w * invK);
+      const float4 g2k = make_float4(g2[j].x * invK, g2[j].y * invK, g2[j].z * invK, g2[j].w * invK);
       float4 y[KMAX];
-      int32_t rb[KMAX];
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) y[k] = ld4(table + (int64_t)rb2[j][k] * D + coff[j]);
 #pragma unroll
       for (int k = 0; k < KMAX; ++k) {
-        rb[k] = 0;
-        y[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (k < K) {
-          rb[k] = rb2[j][k];
-          y[k] = ld4(table + (int64_t)rb[k] * D + coff[j]);
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < KMAX; ++k) {
-        if (k >= K) continue;
         dw2[j] = fma4(dz[k], y[k], dw2[j]);
-        if (ATOMIC && rb[k] != 0) atomic_add4(gtable + (int64_t)rb[k] * D + coff[j], fma4(dz[k], w2[j], g2k));
+        if (ATOMIC && rb2[j][k] != 0) atomic_add4(gtable + (int64_t)rb2[j][k] * D + coff[j], fma4(dz[k], w2[j], g2k));
       }
     }
   }
