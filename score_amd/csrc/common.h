@@ -23,6 +23,14 @@ static inline int64_t align_up64(int64_t a, int64_t b) { return cdiv64(a, b) * b
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+// loads through a pointer the compiler cannot prove global (e.g. one read back from LDS): say so, or it emits
+// flat_load, which also counts against lgkmcnt and so serialises with every LDS access around it
+typedef float score_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld4_global(const float* p) {
+  const score_v4f v = *(const __attribute__((address_space(1))) score_v4f*)p;
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float ld1_global(const float* p) { return *(const __attribute__((address_space(1))) float*)p; }
 __device__ __forceinline__ float dot4(float4 a, float4 b) {
   return fmaf(a.w, b.w, fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)));
 }

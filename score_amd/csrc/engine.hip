@@ -390,6 +390,7 @@ extern "C" int score_forward(const score_config_t* cfg, const score_state_t* st,
   HIPTRY(hipEventRecord(sd->fork, s));
   HIPTRY(hipStreamWaitEvent(sd->st, sd->fork, 0));
   G(score_launch_l2_partials(W, P.n_reg, ws + w.part, sd->st));
+  const bool head_fused = !getenv("SCORE_HEAD_UNFUSED");
   if (!d.attn) HIPTRY(hipEventRecord(sd->join, sd->st));
   if (d.attn) {
     float* scratch2 = ws + w.scratch2;
@@ -465,18 +466,31 @@ extern "C" int score_forward(const score_config_t* cfg, const score_state_t* st,
   EV(3);
   // build_fc_net (:68-76)
   const float rs = (float)(1.0 / sqrt(1.0 + 1e-3));
-  G(score_launch_bn_fwd(B, d.Dhead, ws + w.head_inp, W + P.bn_g, W + P.bn_b, rs, ws + w.bn, s));
   const int dflag = keep_prob < 1.f ? GF_DROP : 0;
-  G(gemm_mode_call(x3, 0, B, FC1, d.Dhead, ws + w.bn, d.Dhead, W + P.fc_w[0], FC1, ws + w.f1, FC1, W + P.fc_b[0],
-               GF_BIAS | GF_RELU | dflag, keep_prob, drop_mask0, drop_seed, scratch, w.scratch_floats, s));
-  G(gemm_mode_call(x3, 0, B, FC2, FC1, ws + w.f1, FC1, W + P.fc_w[1], FC2, ws + w.f2, FC2, W + P.fc_b[1],
-               GF_BIAS | GF_RELU | dflag, keep_prob, drop_mask1, drop_seed ^ 0x5DEECE66Dull, scratch,
-               w.scratch_floats, s));
-  // fc3, sigmoid, log-loss, l2 (:74-94)
+  const int Bg = st->global_batch > 0 ? st->global_batch : B;
   if (!d.attn) HIPTRY(hipStreamWaitEvent(s, sd->join, 0));     // (with attention the join was waited for there)
-  G(score_launch_head_out(B, FC2, ws + w.f2, W + P.fc_w[2], W + P.fc_b[2], bt->label, ws + w.logit, ws + w.y_pred,
-                          ws + w.lossb, ws + w.dlogit, ws + w.loss, reg_lambda, ws + w.part,
-                          st->global_batch > 0 ? st->global_batch : B, s));
+  // the whole head in one launch (head_fused.hip); shapes it does not cover take the layer-by-layer path
+  int hrc = !head_fused ? SCORE_E_SHAPE
+                : score_launch_head_fwd_fused(B, d.Dhead, FC1, FC2, ws + w.head_inp, W + P.bn_g, W + P.bn_b, rs, W + P.fc_w[0],
+                                              W + P.fc_b[0], W + P.fc_w[1], W + P.fc_b[1], W + P.fc_w[2], W + P.fc_b[2],
+                                              keep_prob, drop_mask0, drop_mask1, drop_seed, drop_seed ^ 0x5DEECE66Dull,
+                                              bt->label, ws + w.bn, ws + w.f1, ws + w.f2, ws + w.logit, ws + w.y_pred,
+                                              ws + w.lossb, ws + w.dlogit, Bg, s);
+  if (hrc == 0) {
+    G(score_launch_loss_final(B, ws + w.lossb, ws + w.loss, reg_lambda, ws + w.part, Bg, s));
+  } else if (hrc == SCORE_E_SHAPE) {
+    G(score_launch_bn_fwd(B, d.Dhead, ws + w.head_inp, W + P.bn_g, W + P.bn_b, rs, ws + w.bn, s));
+    G(gemm_mode_call(x3, 0, B, FC1, d.Dhead, ws + w.bn, d.Dhead, W + P.fc_w[0], FC1, ws + w.f1, FC1, W + P.fc_b[0],
+                 GF_BIAS | GF_RELU | dflag, keep_prob, drop_mask0, drop_seed, scratch, w.scratch_floats, s));
+    G(gemm_mode_call(x3, 0, B, FC2, FC1, ws + w.f1, FC1, W + P.fc_w[1], FC2, ws + w.f2, FC2, W + P.fc_b[1],
+                 GF_BIAS | GF_RELU | dflag, keep_prob, drop_mask1, drop_seed ^ 0x5DEECE66Dull, scratch,
+                 w.scratch_floats, s));
+    // fc3, sigmoid, log-loss, l2 (:74-94)
+    G(score_launch_head_out(B, FC2, ws + w.f2, W + P.fc_w[2], W + P.fc_b[2], bt->label, ws + w.logit, ws + w.y_pred,
+                            ws + w.lossb, ws + w.dlogit, ws + w.loss, reg_lambda, ws + w.part, Bg, s));
+  } else {
+    return hrc;
+  }
   EV(4);
   return 0;
 }

@@ -359,6 +359,15 @@ int score_launch_head_out(int B, int NF, const float* f2, const float* w3, const
   return 0;
 }
 
+// the loss reduction alone (the fused head kernel has already written lossb)
+int score_launch_loss_final(int B, const float* lossb, float* loss, float lambda, const float* part, int Bglobal,
+                            hipStream_t s) {
+  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, s, lossb, (int64_t)B, 1.0f / (float)Bglobal, part, lambda,
+                     loss);
+  SCORE_CHECK_LAUNCH();
+  return 0;
+}
+
 // dz[b][n] = [f[b][n] > 0] * dlogit[b] * w[n] / keep      (fc3 backward into relu+dropout of fc2)
 __global__ void outer_relu_bwd_kernel(int B, int NF, const float* __restrict__ dlogit, const float* __restrict__ w,
                                       const float* __restrict__ f, float keep, float* __restrict__ dz) {

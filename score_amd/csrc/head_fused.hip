@@ -1,0 +1,248 @@
+// build_fc_net forward in ONE launch (score.py:68-81): bn1 (inference-mode affine) -> fc1 200 relu dropout -> fc2 80
+// relu dropout -> fc3 -> sigmoid -> per-sample log-loss term and its gradient.
+//
+// As separate launches the head was five kernels of M = B = 1024 rows whose time is the latency of their K loops
+// (0.062 ms of a 1.57 ms step).  Here a workgroup of 8 waves owns 16 samples: their bn1 output sits in LDS, the three
+// layers run back to back on v_mfma_f32_16x16x4_f32 (exact fp32 products, fp32 accumulation) with the weights
+// streamed from L2, every intermediate a later pass needs (bn1 output, f1, f2, logit, y_pred, the loss term and
+// dlogit) is written once on the way.  K is dealt to the four lane quarters in contiguous runs, so a lane reads its
+// A operands of four consecutive MFMA steps with one ds_read_b128; the B operands (one weight per lane and step,
+// 64-B runs per 16 lanes) are fetched a 16-step chunk ahead.
+#include "common.h"
+#include "kernels.h"
+
+typedef float hf_f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int HF_ROWS = 16;     // samples per workgroup
+constexpr int HF_NW = 8;        // waves per workgroup
+constexpr int HF_CH = 16;       // MFMA steps per prefetched chunk of B operands
+
+// acc[t] (16 x 16, rows lq*4+r, column lc) += xs[16][Kp] . W[K][ldw] columns [n0[t], n0[t]+16) for NT tiles at once.
+// xs: LDS, row stride LD, zero beyond K up to Kp (Kp % 16 == 0, so KQ = Kp/4 is a multiple of 4).
+// (The weight operand read from a transposed copy, one 16-B load per lane and four steps, measured slower -- 0.056 vs
+// 0.051 ms for the stage: 16 lanes then touch 16 different rows per load instead of one 64-B run.)
+template <int NT>
+__device__ __forceinline__ void hf_tiles(hf_f32x4 (&acc)[NT], const float* __restrict__ xs, int LD, int Kp, int K,
+                                         const float* __restrict__ W, int ldw, const int (&n0)[NT], int N, int lc, int lq) {
+  const int KQ = Kp >> 2;
+  const int kbase = lq * KQ;
+  int col[NT];
+  bool cok[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    cok[t] = n0[t] >= 0 && n0[t] + lc < N;
+    col[t] = cok[t] ? n0[t] + lc : 0;
+  }
+  // B operands of two chunks in registers: chunk c+1 is requested before chunk c's MFMAs are issued
+  float b0[NT][HF_CH], b1[NT][HF_CH];
+  auto fetch = [&](float (&bb)[NT][HF_CH], int s0) {
+#pragma unroll
+    for (int i = 0; i < HF_CH; ++i) {
+      const int k = kbase + s0 + i;
+      const int kc = k < K ? k : K - 1;                 // clamped, unconditional loads; masked below
+#pragma unroll
+      for (int t = 0; t < NT; ++t) bb[t][i] = W[(int64_t)kc * ldw + col[t]];
+    }
+  };
+  const float* xrow = xs + lc * LD + kbase;
+  auto compute = [&](const float (&bb)[NT][HF_CH], int s0) {
+    float4 av[HF_CH / 4];
+#pragma unroll
+    for (int q = 0; q < HF_CH / 4; ++q) {
+      const int s = s0 + 4 * q;
+      av[q] = s < KQ ? *reinterpret_cast<const float4*>(xrow + s) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < HF_CH; ++i) {
+      const int k = kbase + s0 + i;
+      const bool kok = (s0 + i < KQ) && k < K;
+      const float a = (i & 3) == 0 ? av[i >> 2].x : (i & 3) == 1 ? av[i >> 2].y : (i & 3) == 2 ? av[i >> 2].z : av[i >> 2].w;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const float b = (kok && cok[t]) ? bb[t][i] : 0.f;
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kok ? a : 0.f, b, acc[t], 0, 0, 0);
+      }
+    }
+  };
+  fetch(b0, 0);
+  for (int s0 = 0; s0 < KQ; s0 += 2 * HF_CH) {
+    fetch(b1, s0 + HF_CH);          // (addresses past the quarter are clamped and their products masked)
+    compute(b0, s0);
+    fetch(b0, s0 + 2 * HF_CH);
+    if (s0 + HF_CH < KQ) compute(b1, s0 + HF_CH);
+  }
+}
+
+struct HeadFwdArgs {
+  int B, Dh, N1, N2, Bglobal;
+  const float* x; const float* gamma; const float* beta; float rs;
+  const float* W1; const float* b1; const float* W2; const float* b2; const float* W3; const float* b3;
+  float keep; int drop; const uint8_t* mask0; const uint8_t* mask1; uint64_t seed0, seed1;
+  const int32_t* label;
+  float* bn; float* f1; float* f2; float* logit; float* y; float* lossb; float* dlogit;
+};
+
+__device__ __forceinline__ float hf_act(float v, float bias, int drop, float keep, const uint8_t* mask, uint64_t seed,
+                                        int row, int col, int N) {
+  v = fmaxf(v + bias, 0.f);                             // dense(activation=relu)
+  if (drop) {                                           // tf.nn.dropout: x / keep * Bernoulli(keep)  (same element
+    const uint64_t e = (uint64_t)row * (uint64_t)N + (uint64_t)col;      // numbering as the GEMM epilogue's)
+    const bool on = mask ? (mask[e] != 0) : (hash_uniform(seed, e) < keep);
+    v = on ? v / keep : 0.f;
+  }
+  return v;
+}
+
+__global__ __launch_bounds__(64 * HF_NW) void head_fwd_fused_kernel(const HeadFwdArgs a) {
+  extern __shared__ float sm[];
+  const int Dh = a.Dh, N1 = a.N1, N2 = a.N2;
+  const int Kp0 = (Dh + 15) & ~15, LD0 = Kp0 + 4;
+  const int Kp1 = (N1 + 15) & ~15, LD1 = Kp1 + 4;
+  const int Kp2 = (N2 + 15) & ~15, LD2 = Kp2 + 4;
+  float* xs = sm;                          // [16][LD0]  bn1 output
+  float* f1s = xs + HF_ROWS * LD0;         // [16][LD1]
+  float* f2s = f1s + HF_ROWS * LD1;        // [16][LD2]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lc = lane & 15, lq = lane >> 4;
+  const int b0 = blockIdx.x * HF_ROWS;
+
+  // bn1: y = x * gamma * rs + beta  (moving mean 0 / variance 1, never updated: score.py:69 runs it in inference mode).
+  // float4 per thread and trip, four trips' loads in flight together (clamped addresses, no branch around a load)
+  for (int e = tid; e < HF_ROWS * LD0; e += 64 * HF_NW) xs[e] = 0.f;
+  __syncthreads();
+  if ((Dh & 3) == 0) {
+    const int n4 = Dh >> 2, total = HF_ROWS * n4;
+    for (int e0 = tid; e0 < total; e0 += 4 * 64 * HF_NW) {
+      float4 xv[4], gv[4], bv[4];
+      int ii[4], jj[4];
+      bool okv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = e0 + u * 64 * HF_NW;
+        const int ec = e < total ? e : 0;
+        ii[u] = ec / n4; jj[u] = (ec - ii[u] * n4) * 4;
+        okv[u] = e < total && b0 + ii[u] < a.B;
+        const int row = b0 + ii[u] < a.B ? b0 + ii[u] : a.B - 1;
+        xv[u] = ld4(a.x + (int64_t)row * Dh + jj[u]);
+        gv[u] = ld4(a.gamma + jj[u]);
+        bv[u] = ld4(a.beta + jj[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (!okv[u]) continue;
+        float4 v;
+        v.x = xv[u].x * (gv[u].x * a.rs) + bv[u].x; v.y = xv[u].y * (gv[u].y * a.rs) + bv[u].y;
+        v.z = xv[u].z * (gv[u].z * a.rs) + bv[u].z; v.w = xv[u].w * (gv[u].w * a.rs) + bv[u].w;
+        st4(a.bn + (int64_t)(b0 + ii[u]) * Dh + jj[u], v);
+        *reinterpret_cast<float4*>(xs + ii[u] * LD0 + jj[u]) = v;
+      }
+    }
+  } else {
+    for (int e = tid; e < HF_ROWS * Dh; e += 64 * HF_NW) {
+      const int i = e / Dh, j = e - i * Dh;
+      if (b0 + i < a.B) {
+        const float v = a.x[(int64_t)(b0 + i) * Dh + j] * (a.gamma[j] * a.rs) + a.beta[j];
+        a.bn[(int64_t)(b0 + i) * Dh + j] = v;
+        xs[i * LD0 + j] = v;
+      }
+    }
+  }
+  for (int e = tid; e < HF_ROWS * (LD1 + LD2); e += 64 * HF_NW) f1s[e] = 0.f;      // zero padding of the next layers' K
+  __syncthreads();
+
+  // fc1: tiles of 16 columns, two per wave and pass
+  const int nt1 = (N1 + 15) >> 4;
+  for (int tb = 0; tb < nt1; tb += 2 * HF_NW) {
+    hf_f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    const int t0 = tb + wave, t1 = tb + HF_NW + wave;
+    const int n0[2] = {t0 < nt1 ? t0 * 16 : -1, t1 < nt1 ? t1 * 16 : -1};
+    if (n0[0] >= 0) hf_tiles<2>(acc, xs, LD0, Kp0, Dh, a.W1, N1, n0, N1, lc, lq);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int col = n0[t] + lc;
+      if (n0[t] < 0 || col >= N1) continue;
+      const float bias = a.b1[col];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = lq * 4 + r, row = b0 + i;
+        const float v = hf_act(acc[t][r], bias, a.drop, a.keep, a.mask0, a.seed0, row, col, N1);
+        f1s[i * LD1 + col] = v;
+        if (row < a.B) a.f1[(int64_t)row * N1 + col] = v;
+      }
+    }
+  }
+  __syncthreads();
+
+  // fc2
+  const int nt2 = (N2 + 15) >> 4;
+  for (int tb = 0; tb < nt2; tb += HF_NW) {
+    hf_f32x4 acc[1] = {{0.f, 0.f, 0.f, 0.f}};
+    const int t0 = tb + wave;
+    const int n0[1] = {t0 < nt2 ? t0 * 16 : -1};
+    if (n0[0] >= 0) hf_tiles<1>(acc, f1s, LD1, Kp1, N1, a.W2, N2, n0, N2, lc, lq);
+    const int col = n0[0] + lc;
+    if (n0[0] >= 0 && col < N2) {
+      const float bias = a.b2[col];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = lq * 4 + r, row = b0 + i;
+        const float v = hf_act(acc[0][r], bias, a.drop, a.keep, a.mask1, a.seed1, row, col, N2);
+        f2s[i * LD2 + col] = v;
+        if (row < a.B) a.f2[(int64_t)row * N2 + col] = v;
+      }
+    }
+  }
+  __syncthreads();
+
+  // fc3 + sigmoid + log-loss term and its gradient: four lanes per sample, fixed-order partial sums
+  if (wave == 0) {
+    const int i = lane >> 2, part = lane & 3;
+    float s = 0.f;
+    for (int n = part; n < N2; n += 4) s = fmaf(f2s[i * LD2 + n], a.W3[n], s);
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    const int row = b0 + i;
+    if (part == 0 && row < a.B) {
+      const float z = s + a.b3[0];
+      const float p = sigmoidf_(z);
+      const float lab = (float)a.label[row];
+      const float eps = 1e-7f;
+      a.logit[row] = z;
+      a.y[row] = p;
+      a.lossb[row] = -lab * logf(p + eps) - (1.0f - lab) * logf(1.0f - p + eps);
+      const float dp = (-lab / (p + eps) + (1.0f - lab) / (1.0f - p + eps)) / (float)a.Bglobal;
+      a.dlogit[row] = dp * p * (1.0f - p);
+    }
+  }
+}
+
+}  // namespace
+
+// Returns SCORE_E_SHAPE when the shape does not fit the fused kernel (the caller then runs the layer-by-layer path).
+int score_launch_head_fwd_fused(int B, int Dh, int N1, int N2, const float* x, const float* gamma, const float* beta,
+                                float rs, const float* W1, const float* b1, const float* W2, const float* b2,
+                                const float* W3, const float* b3, float keep, const uint8_t* mask0, const uint8_t* mask1,
+                                uint64_t seed0, uint64_t seed1, const int32_t* label, float* bn, float* f1, float* f2,
+                                float* logit, float* y, float* lossb, float* dlogit, int Bglobal, hipStream_t s) {
+  const int LD0 = ((Dh + 15) & ~15) + 4, LD1 = ((N1 + 15) & ~15) + 4, LD2 = ((N2 + 15) & ~15) + 4;
+  const size_t lds = (size_t)HF_ROWS * (LD0 + LD1 + LD2) * sizeof(float);
+  if (lds > 150 * 1024 || B <= 0) return SCORE_E_SHAPE;
+  static thread_local bool attr_set = false;
+  if (!attr_set && lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(head_fwd_fused_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  HeadFwdArgs a;
+  a.B = B; a.Dh = Dh; a.N1 = N1; a.N2 = N2; a.Bglobal = Bglobal;
+  a.x = x; a.gamma = gamma; a.beta = beta; a.rs = rs;
+  a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.W3 = W3; a.b3 = b3;
+  a.keep = keep; a.drop = keep < 1.f ? 1 : 0; a.mask0 = mask0; a.mask1 = mask1; a.seed0 = seed0; a.seed1 = seed1;
+  a.label = label; a.bn = bn; a.f1 = f1; a.f2 = f2; a.logit = logit; a.y = y; a.lossb = lossb; a.dlogit = dlogit;
+  hipLaunchKernelGGL(head_fwd_fused_kernel, dim3((B + HF_ROWS - 1) / HF_ROWS), dim3(64 * HF_NW), lds, s, a);
+  SCORE_CHECK_LAUNCH();
+  return 0;
+}

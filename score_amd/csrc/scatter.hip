@@ -206,15 +206,15 @@ __device__ __forceinline__ float4 pull_contrib_t(const PullArgs& a, const PullSe
   const int64_t bt = desc & 0x1FFFFF;
   const int col = f * a.D + ch4;
   const PullSeg si = tab[seg];               // ds_read: no branch, so the loads below batch across occurrences
-  const float4 g = ld4(si.G + bt * si.ldg + si.gcol + col);
+  const float4 g = ld4_global(si.G + bt * si.ldg + si.gcol + col);
   float ca = si.constA;
   float4 r;
   if (MODE == 2) {
     // every segment has valid cA / cB / Wv pointers (the targets' point at the first call's arrays): the
     // loads are unconditional, useA / constA decide what is used
-    const float pa = si.cA[bt * a.K + k];
-    const float cb = si.cB[bt * a.K + k];
-    const float4 wv = ld4(si.Wv + col);
+    const float pa = ld1_global(si.cA + bt * a.K + k);
+    const float cb = ld1_global(si.cB + bt * a.K + k);
+    const float4 wv = ld4_global(si.Wv + col);
     ca = (si.useA & 1) ? pa : ca;
     r = make_float4(ca * g.x, ca * g.y, ca * g.z, ca * g.w);
     r = fma4((si.useA & 2) ? cb : 0.f, wv, r);
