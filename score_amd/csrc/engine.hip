@@ -200,7 +200,7 @@ void build_ws(const Dims& d, int B, WS* w) {
     // split-K partials of every queued weight-gradient product: ~24 slabs of each dense variable
     Params Pl;
     build_layout(d, nullptr, 0, &Pl);
-    w->dwslab_floats = 24 * Pl.n_floats;
+    w->dwslab_floats = 48 * Pl.n_floats;
     w->dwslab = take(w->dwslab_floats);
   }
   // sorted pull-form scatter (scatter.hip)
@@ -591,7 +591,9 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
   // ---- GRUs (score.py:205-208)
   // the weight gradients queued so far (head, attention) have everything they need: beside the recurrence
   SideStream* side = nullptr;
-  const int64_t slab_half = (w.dwslab_floats / 2) & ~(int64_t)3;
+  const bool wgrad_side = getenv("SCORE_WGRAD_SIDE") != nullptr;   // A/B: the recurrences' weight gradients beside the scatter
+  const int64_t slab_third = (w.dwslab_floats / 2) & ~(int64_t)3;      // region of the second side flush
+  const int64_t slab_half = (w.dwslab_floats / 4) & ~(int64_t)3;        // region of the first one
   if (gq.n > 0) {
     G(side_stream(&side));
     HIPTRY(hipEventRecord(side->fork, s));
@@ -636,6 +638,15 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
   }
 
   // ---- co-attention + embedding rows (score.py:147-167, 196-201, 51-66)
+  int64_t slab_used = slab_half;
+  if (wgrad_side && gq.n > 0) {     // the GRU kernels' weight gradients: beside the co-attention backward and the scatter
+    G(side_stream(&side));
+    HIPTRY(hipEventRecord(side->fork, s));
+    HIPTRY(hipStreamWaitEvent(side->st, side->fork, 0));
+    G(gemm_queue_flush(&gq, x3 != 0, ws + w.dwslab + slab_half, slab_third, side->st));
+    HIPTRY(hipEventRecord(side->join, side->st));
+    slab_used = slab_half + slab_third;
+  }
   EV(3);
   const bool atomic = st->scatter_mode == 1;
   uint32_t* keys_out = reinterpret_cast<uint32_t*>(ws + w.keys_out);
@@ -692,7 +703,7 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
   EV(4);
   // the remaining weight-gradient products of the pass, then the gradients assembled from them
   if (side) HIPTRY(hipStreamWaitEvent(s, side->join, 0));
-  G(gemm_queue_flush(&gq, x3 != 0, ws + w.dwslab + slab_half, w.dwslab_floats - slab_half, s));
+  G(gemm_queue_flush(&gq, x3 != 0, ws + w.dwslab + slab_used, w.dwslab_floats - slab_used, s));
   if (d.attn) G(score_launch_attn_w1_grad(d.Dk, AT1, ws + w.dweff, ws + w.dwq, gw + P.at_w[1], s));
   G(colsum_queue_flush(&cq, ws + w.cs_part, w.cs_part_floats, s));
   EV(5);
