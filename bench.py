@@ -100,6 +100,9 @@ def main():
     ap.add_argument("--no-prefetch", dest="prefetch", action="store_false",
                     help="sharded path: do NOT start the next batch's index plan under this step's compute "
                          "(default on: one rank through RCCL measured 2.31 vs 2.55 ms/step)")
+    ap.add_argument("--no-pipeline", dest="pipeline", action="store_false",
+                    help="sharded path: optimizer after the backward pass instead of the pipelined step (table update "
+                         "and the next batch's row fetch under this step's weight-gradient tail and dense all-reduce)")
     ap.add_argument("--event-every", type=int, default=4,
                     help="record the HIP stage events (live kernel timing for `roofline`) on every E-th timed step: "
                          "eleven timing events per step cost ~3 %% of a 1.8 ms step")
@@ -181,7 +184,9 @@ def main():
             model.fwd_events = model.bwd_events = e_a0 = e_a1 = None
         if sharded:   # optionally run the next batch's index-only phase (plan + row requests) inside this step
             nxt = batches[(i + 1) % len(batches)] if (args.prefetch and i + 1 < args.steps) else None
-            fb = model.forward_backward(batches[i % len(batches)], args.reg_lambda, 0.8, None, nxt)
+            # with a next batch the step is pipelined: the optimizer runs inside (apply_adam below is then a no-op)
+            fb = model.forward_backward(batches[i % len(batches)], args.reg_lambda, 0.8, None, nxt,
+                                        lr=args.lr if args.pipeline else None)
         else:
             fb = model.forward_backward(batches[i % len(batches)], args.reg_lambda, 0.8)
         if e_a0 is not None:
@@ -236,6 +241,9 @@ def main():
         model.forward_backward(batches[0], args.reg_lambda, 0.8)
         touched = int((inner.table_flags == 2).sum().item())
     adam_bytes = 4 * D * (6 * live_rows + touched) + rows_local + 7 * 4 * n_w
+    adam_timed = stages["adam_table_and_dense"] > 1e-3        # (pipelined sharded step: the update runs inside the step)
+    if not adam_timed:
+        stages["adam_table_and_dense"] = None
     scat_bytes = R * (4 + 4 * D) * B
 
     if rank != 0:
@@ -279,9 +287,9 @@ def main():
         "roofline_other": {
             "adam_rows (6 fp32 streams over the live table rows, + g on touched rows, + dense vars)": {
                 "live_row_frac": live_rows / float(rows_local), "rows_with_gradient_per_step": touched,
-                "bound": "hbm", "achieved": adam_bytes / (stages["adam_table_and_dense"] * 1e-3) / 1e9,
+                "bound": "hbm", "achieved": adam_bytes / (stages["adam_table_and_dense"] * 1e-3) / 1e9 if adam_timed else None,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": adam_bytes / (stages["adam_table_and_dense"] * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                "frac": adam_bytes / (stages["adam_table_and_dense"] * 1e-3) / 1e9 / HBM_PEAK_GBS if adam_timed else None},
             "coattn_bwd + scatter (R*(4+4D) per sample)": {
                 "bound": "hbm", "achieved": scat_bytes / (stages["bwd_coattn_scatter"] * 1e-3) / 1e9,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s",

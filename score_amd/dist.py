@@ -274,6 +274,14 @@ class HipBackend(object):
     def adam(self, lr, reg_lambda):
         self.m.apply_adam(lr, reg_lambda)
 
+    # the two halves of the update, for the pipelined step: the shard's rows need the row gradients only
+    def adam_table(self, lr):
+        self.m.adam_table(lr)
+
+    def adam_dense(self, lr, reg_lambda):
+        self.m.adam_dense(lr, reg_lambda)
+        self.m.adam_advance()
+
     def set_global_batch(self, n):
         self.m.global_batch = int(n)
 
@@ -300,6 +308,8 @@ class ShardedSCORE(object):
         self.D = int(eb_dim)
         self._side, self._slot, self._slot_done, self._prefetched = None, 0, [None, None, None], None
         self._gside = None
+        self._ready = None           # (batch, plan, mini-table) fetched for the next step by the pipelined one
+        self._adam_done = False
         if self.device.type == "cuda" and hasattr(self.comm, "index_comm"):
             # bring both communicators up now (every rank constructs the model): their lazy first-use
             # initialisation costs tens of ms and would otherwise land inside a training step
@@ -389,6 +399,12 @@ class ShardedSCORE(object):
 
     def _fetch(self, batch_data):
         """plan -> request rows from their owners -> gathered [U, D] mini-table"""
+        rd = getattr(self, "_ready", None)
+        self._ready = None
+        if rd is not None and rd[0] is batch_data:      # fetched by the previous (pipelined) step
+            self._slot = rd[1].get("slot", 0)
+            self._prefetched = None
+            return rd[1], rd[2]
         pf = getattr(self, "_prefetched", None)
         if pf is not None and pf[0] is batch_data:
             if pf[2] is None:
@@ -409,7 +425,14 @@ class ShardedSCORE(object):
         if self.device.type == "cuda":
             self._slot_done[self._slot] = torch.cuda.current_stream(self.device).record_event()
 
-    def forward_backward(self, batch_data, reg_lambda, keep_prob=1.0, dropout_masks=None, next_batch=None):
+    def forward_backward(self, batch_data, reg_lambda, keep_prob=1.0, dropout_masks=None, next_batch=None, lr=None):
+        """lr given (with next_batch, HIP backend): the PIPELINED step -- the optimizer runs inside.  The shard's
+        table update needs only the row gradients, which exist before the weight-gradient products that end the
+        backward pass; so behind the scatter a side stream runs: row-gradient all-to-all -> owner-side accumulate ->
+        ApplyAdam over the shard -> gather of the rows the NEXT batch asked for -> their all-to-all, all under this
+        step's weight-gradient tail, the dense all-reduce (on the index communicator, so it is not queued behind the
+        row traffic) and the dense ApplyAdam.  The next step starts with its mini-table in hand.  Returns with
+        the update applied; do not call apply_adam after it."""
         be, cm = self.backend, self.comm
         plan, mini = self._fetch(batch_data)
         if next_batch is not None:
@@ -429,14 +452,35 @@ class ShardedSCORE(object):
             cur = torch.cuda.current_stream(self.device)
             mini_g, ev = be.backward(plan, mini, fw, keep_prob, scatter_event=self._ev_scatter)
             grads_in = torch.empty((plan["req"].numel(), self.D), dtype=torch.float32, device=self.device)
+            pipelined = lr is not None and next_batch is not None and self._prefetched is not None \
+                and self._prefetched[1] is not None and not os.environ.get("SCORE_NO_PIPELINE")
+            nxt = None
+            if pipelined:       # the next batch's plan was launched a forward + backward ago: sizes and requests now
+                self._prefetch_finish()
+                nxt = self._prefetched
+                self._prefetched = None
+            icm = self.comm.index_comm() if hasattr(self.comm, "index_comm") else cm
             self._gside.wait_event(ev)
             with torch.cuda.stream(self._gside):
                 cm.all_to_all(grads_in, mini_g, plan["recv"], plan["send"])
                 be.accumulate(plan["req"], grads_in, plan["recv"])
+                if pipelined:
+                    be.adam_table(lr)
+                    plan_n = nxt[2]
+                    self._gside.wait_event(nxt[3])          # its row requests have arrived (index communicator)
+                    plan_n["req"].record_stream(self._gside)
+                    mini_n = self._rows(plan_n)
+                    self._ready = (next_batch, plan_n, mini_n)
                 done = self._gside.record_event()
             buf = be.dense_grad_with_loss(fw)
-            cm.all_reduce_sum(buf)
+            (icm if pipelined else cm).all_reduce_sum(buf)
+            if pipelined:
+                be.adam_dense(lr, reg_lambda)
             cur.wait_event(done)            # (also orders the frees of mini_g / grads_in behind their last use)
+            if pipelined:
+                mini_n.record_stream(cur)
+                self._mark_step_end()
+            self._adam_done = pipelined
             n_w = buf.numel() - 4
             return (None, buf[n_w], fw["loss"][2]), fw      # [-, global log-loss, l2]
         mini_g = be.backward(plan, mini, fw, keep_prob)
@@ -449,11 +493,14 @@ class ShardedSCORE(object):
         return loss, fw
 
     def apply_adam(self, lr, reg_lambda):
+        if getattr(self, "_adam_done", False):      # the pipelined forward_backward has applied it already
+            self._adam_done = False
+            return
         self.backend.adam(lr, reg_lambda)
         self._mark_step_end()
 
     def train_async(self, batch_data, lr, reg_lambda, keep_prob=0.8, dropout_masks=None, next_batch=None):
-        loss, _ = self.forward_backward(batch_data, reg_lambda, keep_prob, dropout_masks, next_batch)
+        loss, _ = self.forward_backward(batch_data, reg_lambda, keep_prob, dropout_masks, next_batch, lr=lr)
         self.apply_adam(lr, reg_lambda)
         return loss[1] + float(reg_lambda) * loss[2]
 

@@ -319,6 +319,12 @@ class SCOREBASE(object):
     def apply_adam(self, lr, reg_lambda):
         """tf.train.AdamOptimizer(lr).minimize(loss) update (score.py:96-99): dense over the
         whole table (the emb_mtx*mask gradient is dense) and over every dense variable."""
+        self.adam_table(lr)
+        self.adam_dense(lr, reg_lambda)
+        self.adam_advance()
+
+    def adam_table(self, lr):
+        """ApplyAdam over the table (shard) on the current stream: needs the row gradients only."""
         a = self._alpha(lr)
         s = self._stream()
         if self._row_grads:
@@ -333,9 +339,16 @@ class SCOREBASE(object):
             self.table_flags.fill_(1)       # dense sweep: any row may carry moments now
             self._flags_marked = False
         _lib.check(rc, "score_adam(table)")
+
+    def adam_dense(self, lr, reg_lambda):
+        """ApplyAdam over the flat dense variables (L2 term folded in) on the current stream."""
         rc = self.lib.score_adam(_ptr(self.w), _ptr(self.w_m), _ptr(self.w_v), _ptr(self.w_g), self.n_w,
-                                 self.n_reg, float(reg_lambda), a, ADAM_B1, ADAM_B2, ADAM_EPS, s)
+                                 self.n_reg, float(reg_lambda), self._alpha(lr), ADAM_B1, ADAM_B2, ADAM_EPS,
+                                 self._stream())
         _lib.check(rc, "score_adam(dense)")
+
+    def adam_advance(self):
+        """beta1^t, beta2^t and the step counter: once per step, after both halves."""
         self.beta1_power = np.float32(self.beta1_power * np.float32(ADAM_B1))
         self.beta2_power = np.float32(self.beta2_power * np.float32(ADAM_B2))
         self.step += 1
