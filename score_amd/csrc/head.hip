@@ -42,10 +42,34 @@ __global__ void attn_build_inp_kernel(int BT, int T, int H, int NI, const float*
   o[j] = k;
   o[Dk + j] = qq * k;
 }
+// the same, four columns per thread (H, NI multiples of 4): 16-B loads / stores, 32-bit index arithmetic, the
+// source segment chosen by a pointer select instead of a branch around the load
+__global__ __launch_bounds__(256) void attn_build_inp4_kernel(int BT, int T, int H, int NI, const float* __restrict__ q,
+                                                              const float* __restrict__ ur, const float* __restrict__ ir,
+                                                              const float* __restrict__ info, float* __restrict__ inp) {
+  const int Dk = 2 * H + NI, Dk4 = Dk >> 2;
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (unsigned)BT * (unsigned)Dk4) return;
+  const unsigned bt = i / (unsigned)Dk4;
+  const int j = (int)(i - bt * (unsigned)Dk4) * 4;
+  const unsigned b = bt / (unsigned)T;
+  const float* src = j < H ? ur + (int64_t)bt * H + j : (j < 2 * H ? ir + (int64_t)bt * H + (j - H) : info + (int64_t)bt * NI + (j - 2 * H));
+  const float4 k = ld4(src);
+  const float4 qq = ld4(q + (int64_t)b * Dk + j);
+  float* o = inp + (int64_t)bt * 2 * Dk;
+  st4(o + j, k);
+  st4(o + Dk + j, make_float4(qq.x * k.x, qq.y * k.y, qq.z * k.z, qq.w * k.w));
+}
 
 int score_launch_attn_build_inp(int B, int T, int H, int NI, const float* q, const float* ur, const float* ir,
                                 const float* info, float* inp, hipStream_t s) {
   int64_t n = (int64_t)B * T * (2 * H + NI);
+  if ((H & 3) == 0 && (NI & 3) == 0 && n / 4 < (int64_t)1 << 31) {
+    hipLaunchKernelGGL(attn_build_inp4_kernel, dim3((unsigned)cdiv64(n / 4, 256)), dim3(256), 0, s, B * T, T, H, NI, q, ur,
+                       ir, info, inp);
+    SCORE_CHECK_LAUNCH();
+    return 0;
+  }
   hipLaunchKernelGGL(attn_build_inp_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, s, B * T, T, H, NI, q,
                      ur, ir, info, inp);
   SCORE_CHECK_LAUNCH();
@@ -210,16 +234,29 @@ __global__ void attn_inp_bwd_kernel(int B, int T, int H, int NI, const float* __
   if (j < H && off_u >= 0) pooled = dhead[(int64_t)b * ldh + off_u + j];
   if (j >= H && j < 2 * H && off_i >= 0) pooled = dhead[(int64_t)b * ldh + off_i + (j - H)];
   float dqa = 0.f;
-  for (int t = 0; t < T; ++t) {
-    int64_t bt = (int64_t)b * T + t;
-    const float* d = dinp + bt * 2 * Dk;
-    float k = j < H ? ur[bt * H + j] : (j < 2 * H ? ir[bt * H + (j - H)] : info[bt * NI + (j - 2 * H)]);
-    float d1 = d[j], d3 = d[Dk + j];
-    dqa = fmaf(d3, k, dqa);
-    float dk = fmaf(d3, qq, d1);
-    if (j < H) dur[bt * H + j] = dk + pooled * score[bt];
-    else if (j < 2 * H) dir[bt * H + (j - H)] = dk + pooled * score[bt];
-    else dinfo[bt * NI + (j - 2 * H)] = dk;
+  // source / destination segment of column j by pointer select (row stride H or NI): no branch around a load, so
+  // the loads of several time slices are in flight together (they had been one dependent round trip per slice)
+  const float* ksrc = j < H ? ur + j : (j < 2 * H ? ir + (j - H) : info + (j - 2 * H));
+  float* kdst = j < H ? dur + j : (j < 2 * H ? dir + (j - H) : dinfo + (j - 2 * H));
+  const int kst = j < 2 * H ? H : NI;
+  const int64_t bt0 = (int64_t)b * T;
+  constexpr int U = 6;
+  for (int t0 = 0; t0 < T; t0 += U) {
+    float kv[U], d1[U], d3[U], sc[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t bt = bt0 + (t0 + u < T ? t0 + u : T - 1);
+      kv[u] = ksrc[bt * kst];
+      d1[u] = dinp[bt * 2 * Dk + j];
+      d3[u] = dinp[bt * 2 * Dk + Dk + j];
+      sc[u] = score[bt];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (t0 + u >= T) break;
+      dqa = fmaf(d3[u], kv[u], dqa);
+      kdst[(bt0 + t0 + u) * kst] = fmaf(d3[u], qq, d1[u]) + pooled * sc[u];    // (pooled = 0 for the atten_info columns)
+    }
   }
   dq[(int64_t)b * Dk + j] = dqa + dqd[(int64_t)b * Dk + j];
 }
