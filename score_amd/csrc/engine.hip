@@ -237,19 +237,20 @@ void build_ws(const Dims& d, int B, WS* w) {
 // occupy 128 workgroups (16 samples each at B = 1024), half the chip; the attention query branch (forward) and
 // the weight gradients already known (backward) run beside them.  One stream + two events per host thread
 // and device, created on first use; forked from / joined back into the caller's stream with events.
-struct SideStream { hipStream_t st; hipEvent_t fork, join; };
+struct SideStream { hipStream_t st; hipEvent_t fork, join, wx; };
 static thread_local SideStream g_side[16];
 static int side_stream(SideStream** out) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return SCORE_E_BADARG;
   SideStream& sd = g_side[dev];
   if (!sd.st) {
-    hipStream_t st; hipEvent_t a, b;
+    hipStream_t st; hipEvent_t a, b, c;
     if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return SCORE_E_BADARG;
     if (hipEventCreateWithFlags(&a, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&b, hipEventDisableTiming) != hipSuccess)
+        hipEventCreateWithFlags(&b, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c, hipEventDisableTiming) != hipSuccess)
       return SCORE_E_BADARG;
-    sd.st = st; sd.fork = a; sd.join = b;
+    sd.st = st; sd.fork = a; sd.join = b; sd.wx = c;
   }
   *out = &sd;
   return 0;
@@ -389,6 +390,11 @@ extern "C" int score_forward(const score_config_t* cfg, const score_state_t* st,
   G(side_stream(&sd));
   HIPTRY(hipEventRecord(sd->fork, s));
   HIPTRY(hipStreamWaitEvent(sd->st, sd->fork, 0));
+  // [Wx_gates | Wx_cand] copies for the hoisted GRU input projections: weights only, off the main stream
+  G(score_launch_gru_wxcat(W + P.gk[0], W + P.ck[0], W + P.gb[0], W + P.cb[0], W + P.gk[1], W + P.ck[1], W + P.gb[1],
+                           W + P.cb[1], d.Is[0], d.Is[1], d.I, H, ws + w.wxcat, sd->st));
+  hipEvent_t wx_ev = sd->wx;
+  HIPTRY(hipEventRecord(wx_ev, sd->st));
   G(score_launch_l2_partials(W, P.n_reg, ws + w.part, sd->st));
   const bool head_fused = !getenv("SCORE_HEAD_UNFUSED");
   if (!d.attn) HIPTRY(hipEventRecord(sd->join, sd->st));
@@ -430,14 +436,24 @@ extern "C" int score_forward(const score_config_t* cfg, const score_state_t* st,
     memset(&ga, 0, sizeof(ga));
     ga.B = B; ga.T = T; ga.H = H; ga.length = bt->length; ga.nw8 = 1;
     ga.tmp = ws + w.gru_tmp; ga.tmp_floats = 10 * (int64_t)B * H; ga.x3 = x3 != 0;   // H = 128: two waves per SIMD hide the LDS/epilogue latency (measured -0.08 ms/step)
-    G(score_launch_gru_wxcat(W + P.gk[0], W + P.ck[0], W + P.gb[0], W + P.cb[0], W + P.gk[1], W + P.ck[1], W + P.gb[1],
-                             W + P.cb[1], d.Is[0], d.Is[1], d.I, H, ws + w.wxcat, s));
+    HIPTRY(hipStreamWaitEvent(s, wx_ev, 0));
+    if (d.Is[0] == d.Is[1]) {    // both sides' projections in ONE grouped launch (each with its own bias row)
+      const float* c0 = ws + w.wxcat;
+      const float* c1 = c0 + (int64_t)(d.I + 1) * 3 * H;
+      const float* Ax[2] = {ws + w.xside[0], ws + w.xside[1]};
+      const float* Bx[2] = {c0, c1};
+      float* Cx[2] = {ws + w.xproj[0], ws + w.xproj[1]};
+      const float* bx[2] = {c0 + (int64_t)d.Is[0] * 3 * H, c1 + (int64_t)d.Is[1] * 3 * H};
+      G(score_gemm_same_shape(0, 2, BT, 3 * H, d.Is[0], Ax, d.I, Bx, 3 * H, Cx, 3 * H, GF_BIAS, x3 != 0, scratch,
+                              w.scratch_floats, s, bx));
+    }
     for (int sd = 0; sd < 2; ++sd) {
       float* xp = ws + w.xproj[sd];
       // x . [Wx_gates | Wx_cand] + [b_gates | b_cand]: one GEMM per side on the concatenated copy
       const float* cat = ws + w.wxcat + (int64_t)sd * (d.I + 1) * 3 * H;
-      G(gemm_mode_call(x3, 0, BT, 3 * H, d.Is[sd], ws + w.xside[sd], d.I, cat, 3 * H, xp, 3 * H, cat + (int64_t)d.Is[sd] * 3 * H,
-                       GF_BIAS, 1.f, nullptr, 0, scratch, w.scratch_floats, s));
+      if (d.Is[0] != d.Is[1])
+        G(gemm_mode_call(x3, 0, BT, 3 * H, d.Is[sd], ws + w.xside[sd], d.I, cat, 3 * H, xp, 3 * H, cat + (int64_t)d.Is[sd] * 3 * H,
+                         GF_BIAS, 1.f, nullptr, 0, scratch, w.scratch_floats, s));
       GruSide& g = ga.s[sd];
       g.xproj = xp; g.Wg = W + P.gk[sd] + (int64_t)d.Is[sd] * 2 * H; g.ldwg = 2 * H;
       g.Wc = W + P.ck[sd] + (int64_t)d.Is[sd] * H; g.ldwc = H;
@@ -565,16 +581,11 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
     // (gw + P.at_w[1] is assembled from dweff / dwq after the queue is flushed)
     G(gemm_mode_call(x3, 1, BT, 2 * d.Dk, AT1, ws + w.da1, AT1, ws + w.weff, AT1, ws + w.dainp, 2 * d.Dk, nullptr, 0,
                  1.f, nullptr, 0, scratch, SF, s));
-    G(gemm_mode_call(x3, 1, B, d.Dk, AT1, ws + w.adzsum, AT1, ws + w.wq, AT1, ws + w.dqd, d.Dk, nullptr, 0, 1.f, nullptr,
-                 0, scratch, SF, s));
+    // dq = sum_t d(q*k).k here; the per-sample q-term gradient dzsum . Wq^T is added, and the query projection's
+    // backward runs, on the side stream below (beside the recurrence: only the target rows consume them)
     G(score_launch_attn_inp_bwd(B, T, H, d.NI, ws + w.dainp, ws + w.q, ws + w.gru_out[0], ws + w.gru_out[1],
                                 ws + w.info, ws + w.att_score, ws + w.dhead, d.Dhead, d.off_u, d.off_i,
-                                ws + w.dqd, ws + w.dgru[0], ws + w.dgru[1], ws + w.dinfo, ws + w.dq, s));
-    // dense_2 (query projection)
-    G(gemm_queue_add(&gq, d.Dq, d.Dk, B, ws + w.query, d.Dq, ws + w.dq, d.Dk, gw + P.at_w[0], d.Dk));
-    G(colsum_queue_add(&cq, ws + w.dq, B, d.Dk, d.Dk, gw + P.at_b[0], 0));
-    G(gemm_mode_call(x3, 1, B, d.Dq, d.Dk, ws + w.dq, d.Dk, W + P.at_w[0], d.Dk, ws + w.dquery, d.Dq, nullptr, 0, 1.f,
-                 nullptr, 0, scratch, SF, s));
+                                nullptr, ws + w.dgru[0], ws + w.dgru[1], ws + w.dinfo, ws + w.dq, s));
   } else {
     // RIA: gradient enters through the final states only; atten_info is unused downstream
     for (int sd = 0; sd < 2; ++sd) {
@@ -594,10 +605,20 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
   const bool wgrad_side = getenv("SCORE_WGRAD_SIDE") != nullptr;   // A/B: the recurrences' weight gradients beside the scatter
   const int64_t slab_third = (w.dwslab_floats / 2) & ~(int64_t)3;      // region of the second side flush
   const int64_t slab_half = (w.dwslab_floats / 4) & ~(int64_t)3;        // region of the first one
-  if (gq.n > 0) {
+  if (gq.n > 0 || d.attn) {
     G(side_stream(&side));
     HIPTRY(hipEventRecord(side->fork, s));
     HIPTRY(hipStreamWaitEvent(side->st, side->fork, 0));
+    if (d.attn) {
+      float* scratch2 = ws + w.scratch2;
+      // dq += dzsum . Wq^T ; dense_2 (query projection): dW, db queued, d query = dq . W^T
+      G(gemm_mode_call(x3, 1, B, d.Dk, AT1, ws + w.adzsum, AT1, ws + w.wq, AT1, ws + w.dq, d.Dk, nullptr, GF_ACC, 1.f, nullptr,
+                       0, scratch2, SF, side->st));
+      G(gemm_queue_add(&gq, d.Dq, d.Dk, B, ws + w.query, d.Dq, ws + w.dq, d.Dk, gw + P.at_w[0], d.Dk));
+      G(colsum_queue_add(&cq, ws + w.dq, B, d.Dk, d.Dk, gw + P.at_b[0], 0));
+      G(gemm_mode_call(x3, 1, B, d.Dq, d.Dk, ws + w.dq, d.Dk, W + P.at_w[0], d.Dk, ws + w.dquery, d.Dq, nullptr, 0, 1.f,
+                       nullptr, 0, scratch2, SF, side->st));
+    }
     G(gemm_queue_flush(&gq, x3 != 0, ws + w.dwslab, slab_half, side->st));
     HIPTRY(hipEventRecord(side->join, side->st));
   }
@@ -633,8 +654,15 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
       he = hipMemsetAsync(ws + w.dxside[sd], 0, (int64_t)BT * d.I * sizeof(float), s);
       if (he != hipSuccess) return (int)he;
     }
-    G(gemm_mode_call(x3, 1, BT, d.Is[sd], 3 * H, dxp, 3 * H, cat, 3 * H, ws + w.dxside[sd], d.I, nullptr, 0, 1.f, nullptr, 0,
-                     scratch, SF, s));
+    if (d.Is[0] != d.Is[1])
+      G(gemm_mode_call(x3, 1, BT, d.Is[sd], 3 * H, dxp, 3 * H, cat, 3 * H, ws + w.dxside[sd], d.I, nullptr, 0, 1.f, nullptr, 0,
+                       scratch, SF, s));
+  }
+  if (d.Is[0] == d.Is[1]) {      // both sides' d x in ONE grouped launch: 2 x 576 tiles fill 512 slots better than twice 576
+    const float* Ad[2] = {ws + w.dxproj[0], ws + w.dxproj[1]};
+    const float* Bd[2] = {ws + w.wxcat, ws + w.wxcat + (int64_t)(d.I + 1) * 3 * H};
+    float* Cd[2] = {ws + w.dxside[0], ws + w.dxside[1]};
+    G(score_gemm_same_shape(1, 2, BT, d.Is[0], 3 * H, Ad, 3 * H, Bd, 3 * H, Cd, d.I, 0, x3 != 0, scratch, SF, s));
   }
 
   // ---- co-attention + embedding rows (score.py:147-167, 196-201, 51-66)
@@ -670,6 +698,7 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
     if (atomic || d.coattn)   // RCA in pull mode has nothing to prepare: every row gradient is G itself
       G(score_coattn_bwd_multi(ca, 2, d.D, B, dWs, ws + w.ca_slab, w.ca_slab_floats, atomic ? 1 : 0, &cq, s));
   }
+  if (side && d.attn) HIPTRY(hipStreamWaitEvent(s, side->join, 0));      // d query comes from the side stream
   G(score_launch_target_bwd(grad_table, d.D, d.Fu, d.Fi, B, T, bt->target_user, bt->target_item,
                             d.attn ? ws + w.dquery : nullptr, d.Dq, ws + w.dhead, d.Dhead, d.off_ti, d.off_tu,
                             ws + w.query, d.coattn ? W + P.ca_w[0] : nullptr, d.coattn ? W + P.ca_w[1] : nullptr,

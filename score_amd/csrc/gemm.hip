@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmGroup grp, cons
         if (slab) {
           slab[((int64_t)bz * M + row) * N + col] = acc[i][j][r];
         } else {
-          float v = epilogue(acc[i][j][r], row, col, N, bias, flags, keep, mask, seed);
+          float v = epilogue(acc[i][j][r], row, col, N, pr.bias ? pr.bias : bias, flags, keep, mask, seed);
           float* dst = C + (int64_t)row * ldc + col;
           *dst = (flags & F_ACC) ? *dst + v : v;
         }
@@ -242,7 +242,7 @@ __global__ void splitk_reduce_group_kernel(const ReduceGroup g) {
 
 static void fill_prob(GemmProb* p, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
                       int ldc, int k_chunk, float* slab, int gx, int gy, int gz) {
-  p->A = A; p->B = B; p->C = C; p->slab = slab; p->M = M; p->N = N; p->K = K; p->lda = lda; p->ldb = ldb;
+  p->A = A; p->B = B; p->C = C; p->slab = slab; p->bias = nullptr; p->M = M; p->N = N; p->K = K; p->lda = lda; p->ldb = ldb;
   p->ldc = ldc; p->k_chunk = k_chunk; p->gx = gx; p->gy = gy; p->nblocks = gx * gy * gz;
 }
 
@@ -369,8 +369,9 @@ extern "C" int score_gemm(int32_t trans, int32_t M, int32_t N, int32_t K, const 
 // tiles already fill the chip together); anything it cannot take goes through score_gemm one by one.
 int score_gemm_same_shape(int trans, int nprob, int M, int N, int K, const float* const* A, int lda,
                           const float* const* B, int ldb, float* const* C, int ldc, int flags, int x3, float* scratch,
-                          int64_t scratch_floats, hipStream_t s) {
-  if (nprob <= 0 || nprob > GEMM_GROUP_MAX || trans < 0 || trans > 2 || (flags & ~F_ACC)) return SCORE_E_BADARG;
+                          int64_t scratch_floats, hipStream_t s, const float* const* bias) {
+  if (nprob <= 0 || nprob > GEMM_GROUP_MAX || trans < 0 || trans > 2 || (flags & ~(F_ACC | F_BIAS))) return SCORE_E_BADARG;
+  if ((flags & F_BIAS) && !bias) return SCORE_E_BADARG;
   bool al = (lda & 3) == 0 && (ldb & 3) == 0;
   for (int i = 0; i < nprob; ++i)
     al = al && (reinterpret_cast<uintptr_t>(A[i]) & 15) == 0 && (reinterpret_cast<uintptr_t>(B[i]) & 15) == 0;
@@ -389,6 +390,7 @@ int score_gemm_same_shape(int trans, int nprob, int M, int N, int K, const float
       for (int i = 0; i < nprob; ++i) {
         fill_prob(&grp.p[i], M, N, K, A[i], lda, B[i], ldb, C[i], ldc, K, nullptr, (N + 127) / 128,
                   (M + 64 * wm - 1) / (64 * wm), 1);
+        grp.p[i].bias = bias ? bias[i] : nullptr;
         grp.total_blocks += (grp.p[i].nblocks + 7) & ~7;
       }
       return score_launch_gemm_bf16x3(trans, wm, grp, nullptr, flags, 1.f, nullptr, 0, s);
@@ -397,12 +399,13 @@ int score_gemm_same_shape(int trans, int nprob, int M, int N, int K, const float
   const int64_t tiles = (int64_t)nprob * ((N + 63) / 64) * ((M + 63) / 64);
   if (tiles < 128) {          // too few tiles even together: let score_gemm split K
     for (int i = 0; i < nprob; ++i)
-      SCORE_TRY(score_gemm(trans, M, N, K, A[i], lda, B[i], ldb, C[i], ldc, nullptr, flags | (x3 ? F_X3 : 0), 1.f, nullptr, 0,
-                           scratch, scratch_floats, s));
+      SCORE_TRY(score_gemm(trans, M, N, K, A[i], lda, B[i], ldb, C[i], ldc, bias ? bias[i] : nullptr, flags | (x3 ? F_X3 : 0),
+                           1.f, nullptr, 0, scratch, scratch_floats, s));
     return 0;
   }
   for (int i = 0; i < nprob; ++i) {
     fill_prob(&grp.p[i], M, N, K, A[i], lda, B[i], ldb, C[i], ldc, K, nullptr, (N + 63) / 64, (M + 63) / 64, 1);
+    grp.p[i].bias = bias ? bias[i] : nullptr;
     grp.total_blocks += (grp.p[i].nblocks + 7) & ~7;
   }
 #define LS(TR) hipLaunchKernelGGL((gemm_f32_kernel<TR, 1, 1, 16>), dim3(grp.total_blocks), dim3(256), 0, s, grp, nullptr, \

@@ -339,7 +339,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(const GemmGroup grp
         if (slab) {
           slab[((int64_t)bz * M + row) * N + col] = acc[i][j][r];
         } else {
-          float v = x3_epilogue(acc[i][j][r], row, col, N, bias, flags, keep, mask, seed);
+          float v = x3_epilogue(acc[i][j][r], row, col, N, pr.bias ? pr.bias : bias, flags, keep, mask, seed);
           float* dst = C + (int64_t)row * ldc + col;
           *dst = (flags & XF_ACC) ? *dst + v : v;
         }

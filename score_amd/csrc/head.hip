@@ -258,7 +258,7 @@ __global__ void attn_inp_bwd_kernel(int B, int T, int H, int NI, const float* __
       kdst[(bt0 + t0 + u) * kst] = fmaf(d3[u], qq, d1[u]) + pooled * sc[u];    // (pooled = 0 for the atten_info columns)
     }
   }
-  dq[(int64_t)b * Dk + j] = dqa + dqd[(int64_t)b * Dk + j];
+  dq[(int64_t)b * Dk + j] = dqd ? dqa + dqd[(int64_t)b * Dk + j] : dqa;   // (null: the caller adds the q-term gradient itself)
 }
 
 int score_launch_attn_inp_bwd(int B, int T, int H, int NI, const float* dinp, const float* q, const float* ur,

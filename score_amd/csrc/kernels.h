@@ -10,6 +10,7 @@
 #define GEMM_GROUP_MAX 16
 struct GemmProb {
   const float* A; const float* B; float* C; float* slab;   // slab: split-K partials [gz][M][N] (null: write C)
+  const float* bias;                                       // this problem's own bias (null: the launch's)
   int M, N, K, lda, ldb, ldc, k_chunk, gx, gy, nblocks;    // nblocks = gx*gy*gz; the launch gives it align8(nblocks)
 };
 struct GemmGroup { int n; int total_blocks; GemmProb p[GEMM_GROUP_MAX]; };
@@ -161,6 +162,6 @@ struct GruArgs {
 // nprob same-shape GEMMs C_i = op(A_i) op(B_i) in one launch (the two sides of a recurrence step); flags: 4 = C += .
 int score_gemm_same_shape(int trans, int nprob, int M, int N, int K, const float* const* A, int lda,
                           const float* const* B, int ldb, float* const* C, int ldc, int flags, int x3, float* scratch,
-                          int64_t scratch_floats, hipStream_t s);
+                          int64_t scratch_floats, hipStream_t s, const float* const* bias = nullptr);   // flags: 1 = + bias[i][N]
 int score_gru_fwd_multi(GruArgs& a, int nsides, hipStream_t s);
 int score_gru_bwd_multi(GruArgs& a, int nsides, hipStream_t s);
