@@ -576,7 +576,7 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
     // dense_3 (4Dk -> 80), folded: weight gradient from [k, q*k]^T da1 and q^T sum_t da1
     G(gemm_queue_add(&gq, 2 * d.Dk, AT1, BT, ws + w.ainp, 2 * d.Dk, ws + w.da1, AT1, ws + w.dweff, AT1));
     G(colsum_queue_add(&cq, ws + w.da1, BT, AT1, AT1, gw + P.at_b[1], 0));
-    G(score_launch_attn_dzsum(B, T, AT1, ws + w.da1, ws + w.adzsum, s));
+    // (sum_t da1 -> adzsum feeds the query branch only: computed on the side stream below)
     G(gemm_queue_add(&gq, d.Dk, AT1, B, ws + w.q, d.Dk, ws + w.adzsum, AT1, ws + w.dwq, AT1));
     // (gw + P.at_w[1] is assembled from dweff / dwq after the queue is flushed)
     G(gemm_mode_call(x3, 1, BT, 2 * d.Dk, AT1, ws + w.da1, AT1, ws + w.weff, AT1, ws + w.dainp, 2 * d.Dk, nullptr, 0,
@@ -611,6 +611,7 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
     HIPTRY(hipStreamWaitEvent(side->st, side->fork, 0));
     if (d.attn) {
       float* scratch2 = ws + w.scratch2;
+      G(score_launch_attn_dzsum(B, T, AT1, ws + w.da1, ws + w.adzsum, side->st));
       // dq += dzsum . Wq^T ; dense_2 (query projection): dW, db queued, d query = dq . W^T
       G(gemm_mode_call(x3, 1, B, d.Dk, AT1, ws + w.adzsum, AT1, ws + w.wq, AT1, ws + w.dq, d.Dk, nullptr, GF_ACC, 1.f, nullptr,
                        0, scratch2, SF, side->st));
@@ -620,6 +621,8 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
                        nullptr, 0, scratch2, SF, side->st));
     }
     G(gemm_queue_flush(&gq, x3 != 0, ws + w.dwslab, slab_half, side->st));
+    // the bias / bn1 gradients known so far (column sums of matrices that are final by now), same place
+    G(colsum_queue_flush(&cq, ws + w.cs_part, w.cs_part_floats / 2, side->st));
     HIPTRY(hipEventRecord(side->join, side->st));
   }
   {
@@ -734,7 +737,7 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
   if (side) HIPTRY(hipStreamWaitEvent(s, side->join, 0));
   G(gemm_queue_flush(&gq, x3 != 0, ws + w.dwslab + slab_used, w.dwslab_floats - slab_used, s));
   if (d.attn) G(score_launch_attn_w1_grad(d.Dk, AT1, ws + w.dweff, ws + w.dwq, gw + P.at_w[1], s));
-  G(colsum_queue_flush(&cq, ws + w.cs_part, w.cs_part_floats, s));
+  G(colsum_queue_flush(&cq, ws + w.cs_part + w.cs_part_floats / 2, w.cs_part_floats - w.cs_part_floats / 2, s));
   EV(5);
   return 0;
 }

@@ -231,7 +231,9 @@ template <int MODE>
 __global__ __launch_bounds__(256) void pull_kernel(const PullArgs a, const uint32_t* __restrict__ keys,
                                                    const uint32_t* __restrict__ vals, int64_t n, int WS,
                                                    float* __restrict__ out, float* __restrict__ pfirst,
-                                                   float* __restrict__ plast) {
+                                                   float* __restrict__ plast, int* __restrict__ long_count) {
+  // the long-chain counter pull_fixup_kernel (next launch) appends to: cleared here instead of by a memset launch
+  if (blockIdx.x == 0 && threadIdx.x < 4) long_count[threadIdx.x] = 0;
   const int LPR = a.LPRp;                                // lanes per group (power of two >= D/4)
   const int gpb = blockDim.x / LPR;                      // groups per block
   const int64_t w = (int64_t)blockIdx.x * gpb + threadIdx.x / LPR;
@@ -415,16 +417,14 @@ int score_launch_pull(PullArgs& a, const uint32_t* keys, const uint32_t* vals, i
   float* plast = partials + nw * a.D;
   int* long_count = reinterpret_cast<int*>(plast + nw * a.D);
   int2* long_list = reinterpret_cast<int2*>(long_count + 4);
-  hipError_t e = hipMemsetAsync(long_count, 0, 16, s);
-  if (e != hipSuccess) return (int)e;
   int gpb = 256 / LPR;
   unsigned blocks = (unsigned)cdiv64(nw, gpb);
   // contribution form: owner-side row sum (descriptors are source slots), constant coefficients, or the
   // co-attention's per-(unit, k) coefficients
   const int mode = (a.G[1] == nullptr && a.ldg[0] == 0) ? 0 : (a.cA[0] ? 2 : 1);
-  if (mode == 0) hipLaunchKernelGGL(pull_kernel<0>, dim3(blocks), dim3(256), 0, s, a, keys, vals, n, WS, out, pfirst, plast);
-  else if (mode == 1) hipLaunchKernelGGL(pull_kernel<1>, dim3(blocks), dim3(256), 0, s, a, keys, vals, n, WS, out, pfirst, plast);
-  else hipLaunchKernelGGL(pull_kernel<2>, dim3(blocks), dim3(256), 0, s, a, keys, vals, n, WS, out, pfirst, plast);
+  if (mode == 0) hipLaunchKernelGGL(pull_kernel<0>, dim3(blocks), dim3(256), 0, s, a, keys, vals, n, WS, out, pfirst, plast, long_count);
+  else if (mode == 1) hipLaunchKernelGGL(pull_kernel<1>, dim3(blocks), dim3(256), 0, s, a, keys, vals, n, WS, out, pfirst, plast, long_count);
+  else hipLaunchKernelGGL(pull_kernel<2>, dim3(blocks), dim3(256), 0, s, a, keys, vals, n, WS, out, pfirst, plast, long_count);
   SCORE_CHECK_LAUNCH();
   hipLaunchKernelGGL(pull_fixup_kernel, dim3(blocks), dim3(256), 0, s, a, keys, n, WS, out, pfirst, plast,
                      long_count, long_list);
