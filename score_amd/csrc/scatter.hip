@@ -33,21 +33,24 @@ __global__ void plan_fill_kernel(PlanFillArgs a, uint32_t* __restrict__ keys, ui
 #pragma unroll
   for (int s = 1; s < 6; ++s) seg += (i >= a.off[s]) ? 1 : 0;
   int64_t local = i - a.off[seg];
-  int F = a.F[seg];
+  const uint32_t F = (uint32_t)a.F[seg];
   uint32_t f, k, bt;
+  // 32-bit index arithmetic (one tensor holds < 2^31 ids: B*T <= 2^21, K <= 32, F <= 8): 64-bit division
+  // made this trivial kernel 35 us
+  const uint32_t l32 = (uint32_t)local;
   if (seg < 4) {
-    f = (uint32_t)(local % F);
-    int64_t q = local / F;
-    k = (uint32_t)(q % a.K);
-    bt = (uint32_t)(q / a.K);          // b * TA + t: the occurrence space holds the active slices only
+    const uint32_t q = l32 / F;
+    f = l32 - q * F;
+    bt = q / (uint32_t)a.K;            // b * TA + t: the occurrence space holds the active slices only
+    k = q - bt * (uint32_t)a.K;
     if (a.TA != a.T) {                 // position inside the [B, T, K, F] index tensor
       const uint32_t b = bt / (uint32_t)a.TA;
       local = (((int64_t)b * a.T + (bt - b * (uint32_t)a.TA)) * a.K + k) * F + f;
     }
   } else {
-    f = (uint32_t)(local % F);
+    bt = l32 / F;
+    f = l32 - bt * F;
     k = 0;
-    bt = (uint32_t)(local / F);
   }
   uint32_t row = (uint32_t)a.idx[seg][local];
   uint32_t key = row;
