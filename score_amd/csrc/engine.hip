@@ -609,20 +609,29 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
     G(side_stream(&side));
     HIPTRY(hipEventRecord(side->fork, s));
     HIPTRY(hipStreamWaitEvent(side->st, side->fork, 0));
+    // Sharded path (scatter_mode 2): the caller runs several streams of its own (plan prefetch, gradient exchange,
+    // two communicators) and the hardware queues are shared -- measured there, this side stream's kernels run 2-4x
+    // slower and the join below stalls the scatter (0.27 -> 0.40 ms): the query branch stays on the main stream
+    const bool q_on_side = st->scatter_mode != 2;
+    hipStream_t qs = q_on_side ? side->st : s;
     if (d.attn) {
-      float* scratch2 = ws + w.scratch2;
-      G(score_launch_attn_dzsum(B, T, AT1, ws + w.da1, ws + w.adzsum, side->st));
+      float* scratch2 = q_on_side ? ws + w.scratch2 : scratch;
+      G(score_launch_attn_dzsum(B, T, AT1, ws + w.da1, ws + w.adzsum, qs));
       // dq += dzsum . Wq^T ; dense_2 (query projection): dW, db queued, d query = dq . W^T
       G(gemm_mode_call(x3, 1, B, d.Dk, AT1, ws + w.adzsum, AT1, ws + w.wq, AT1, ws + w.dq, d.Dk, nullptr, GF_ACC, 1.f, nullptr,
-                       0, scratch2, SF, side->st));
+                       0, scratch2, SF, qs));
       G(gemm_queue_add(&gq, d.Dq, d.Dk, B, ws + w.query, d.Dq, ws + w.dq, d.Dk, gw + P.at_w[0], d.Dk));
       G(colsum_queue_add(&cq, ws + w.dq, B, d.Dk, d.Dk, gw + P.at_b[0], 0));
       G(gemm_mode_call(x3, 1, B, d.Dq, d.Dk, ws + w.dq, d.Dk, W + P.at_w[0], d.Dk, ws + w.dquery, d.Dq, nullptr, 0, 1.f,
-                       nullptr, 0, scratch2, SF, side->st));
+                       nullptr, 0, scratch2, SF, qs));
+      if (!q_on_side) {       // dq is final on the main stream: the side stream (its weight-gradient product) follows it
+        HIPTRY(hipEventRecord(side->fork, s));
+        HIPTRY(hipStreamWaitEvent(side->st, side->fork, 0));
+      }
     }
     G(gemm_queue_flush(&gq, x3 != 0, ws + w.dwslab, slab_half, side->st));
     // the bias / bn1 gradients known so far (column sums of matrices that are final by now), same place
-    G(colsum_queue_flush(&cq, ws + w.cs_part, w.cs_part_floats / 2, side->st));
+    if (q_on_side) G(colsum_queue_flush(&cq, ws + w.cs_part, w.cs_part_floats / 2, side->st));
     HIPTRY(hipEventRecord(side->join, side->st));
   }
   {
@@ -701,7 +710,7 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
     if (atomic || d.coattn)   // RCA in pull mode has nothing to prepare: every row gradient is G itself
       G(score_coattn_bwd_multi(ca, 2, d.D, B, dWs, ws + w.ca_slab, w.ca_slab_floats, atomic ? 1 : 0, &cq, s));
   }
-  if (side && d.attn) HIPTRY(hipStreamWaitEvent(s, side->join, 0));      // d query comes from the side stream
+  if (side && d.attn && st->scatter_mode != 2) HIPTRY(hipStreamWaitEvent(s, side->join, 0));   // d query comes from the side stream
   G(score_launch_target_bwd(grad_table, d.D, d.Fu, d.Fi, B, T, bt->target_user, bt->target_item,
                             d.attn ? ws + w.dquery : nullptr, d.Dq, ws + w.dhead, d.Dhead, d.off_ti, d.off_tu,
                             ws + w.query, d.coattn ? W + P.ca_w[0] : nullptr, d.coattn ? W + P.ca_w[1] : nullptr,

@@ -263,17 +263,33 @@ __global__ __launch_bounds__(256) void pull_kernel(const PullArgs a, const uint3
   const int64_t end = start + WS < n ? start + WS : n;
   if (a.zero_is_dummy && keys[end - 1] == 0) return;    // keys ascend: a window of dummy-row uses only
   uint32_t cur = keys[start];
+  // destination of the current run: the row id itself, or (sharded plan) its unique position -- the same for every
+  // occurrence of a run, so it is read with the trip's other loads and carried along (a lookup at each store
+  // had put a vmcnt(0) wait, i.e. a drain of everything in flight, behind every row: 0.27 -> 0.40 ms sharded)
+  const bool has_uid = a.uid != nullptr;
+  uint32_t cur_dst = has_uid ? a.uid[start] : cur;
   const bool first_open = start > 0 && keys[start - 1] == cur;
   bool is_first = true;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto store_cur = [&]() {
+    st4(out + (int64_t)cur_dst * a.D + ch4, acc);
+    if (a.flags && ch4 == 0) a.flags[cur_dst] = 2;
+  };
   for (int64_t i0 = start; i0 < end; i0 += PULL_U) {
-    uint32_t kk[PULL_U], vv[PULL_U];
+    uint32_t kk[PULL_U], vv[PULL_U], uu[PULL_U];
     float4 cc[PULL_U];
 #pragma unroll
     for (int u = 0; u < PULL_U; ++u) {
       const int64_t idx = i0 + u < end ? i0 + u : end - 1;
       kk[u] = keys[idx];
       vv[u] = vals[idx];
+    }
+    if (has_uid) {
+#pragma unroll
+      for (int u = 0; u < PULL_U; ++u) uu[u] = a.uid[i0 + u < end ? i0 + u : end - 1];
+    } else {
+#pragma unroll
+      for (int u = 0; u < PULL_U; ++u) uu[u] = kk[u];
     }
 #pragma unroll
     for (int u = 0; u < PULL_U; ++u) cc[u] = pull_contrib_t<MODE>(a, tab, vv[u], ch4);
@@ -284,10 +300,11 @@ __global__ __launch_bounds__(256) void pull_kernel(const PullArgs a, const uint3
       if (key != cur) {
         if (cur != 0 || !a.zero_is_dummy) {
           if (is_first && first_open) st4(pfirst + w * a.D + ch4, acc);
-          else store_row(a, out, cur, i0 + u - 1, ch4, acc);
+          else store_cur();
         }
         acc = make_float4(0.f, 0.f, 0.f, 0.f);
         cur = key;
+        cur_dst = uu[u];
         is_first = false;
       }
       if (key != 0 || !a.zero_is_dummy) acc = add4(acc, cc[u]);
@@ -297,7 +314,7 @@ __global__ __launch_bounds__(256) void pull_kernel(const PullArgs a, const uint3
     const bool open_right = end < n && keys[end] == cur;
     if (is_first && first_open) st4(pfirst + w * a.D + ch4, acc);
     else if (open_right) st4(plast + w * a.D + ch4, acc);
-    else store_row(a, out, cur, end - 1, ch4, acc);
+    else store_cur();
   }
 }
 
