@@ -43,6 +43,37 @@ def _to_host(t):
     return h
 
 
+def _concurrent_stream(device, candidates=8, cycles=1500000):
+    """A torch stream whose kernels really run beside the current stream's.  HIP deals streams onto a few hardware
+    queues in first-use order, and with the model's, the communicators' and the caller's streams around, two of them
+    can end up on the same queue -- where they serialise (seen in a kernel trace: the gradient-exchange chain ran
+    BEHIND the weight-gradient tail it was meant to hide under).  So: try a few streams, time a spin kernel on each
+    together with one on the current stream, take the first pair that overlaps.  ~1 ms per candidate, once."""
+    main = torch.cuda.current_stream(device)
+    mk = lambda: torch.cuda.Event(enable_timing=True)
+    best = None
+    for _ in range(candidates):
+        st = torch.cuda.Stream(device=device)
+        spans = []
+        for rep in range(2):                      # (the first use of a stream sets its queue up: timed on the second)
+            e0, e1, f1 = mk(), mk(), mk()
+            torch.cuda.synchronize(device)
+            e0.record(main)
+            torch.cuda._sleep(cycles)
+            e1.record(main)
+            with torch.cuda.stream(st):
+                torch.cuda._sleep(cycles)
+                f1.record(st)
+            torch.cuda.synchronize(device)
+            spans.append((e0.elapsed_time(e1), e0.elapsed_time(f1)))
+        single, span = spans[-1]
+        if best is None:
+            best = st
+        if span < 1.4 * single:
+            return st
+    return best
+
+
 class TorchDistComm(object):
     """torch.distributed collectives (nccl == RCCL on ROCm; gloo for the CPU tests)."""
 
@@ -446,7 +477,7 @@ class ShardedSCORE(object):
             # side stream, under those products.  The dense gradient goes out at the end of the pass in ONE
             # all-reduce together with the log-loss share.
             if self._gside is None:
-                self._gside = torch.cuda.Stream(device=self.device)
+                self._gside = _concurrent_stream(self.device)
                 self._ev_scatter = torch.cuda.Event()
                 self._ev_scatter.record(torch.cuda.current_stream(self.device))      # materialise the hipEvent_t
             cur = torch.cuda.current_stream(self.device)
