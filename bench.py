@@ -225,6 +225,16 @@ def main():
     # 11, graph_loader.py:382) and the slices past the longest sample, which the model masks out of every
     # result, are skipped (score_batch_t.active_slices) -- the numerator counts only what is gathered
     A = int(getattr(batches[0], "active_slices", 0)) or T
+    # what an EMPTY pair of timing events measures on this stream (two marker packets back to back): the stage
+    # durations above include it, rocprofv3's per-kernel durations do not
+    cal = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(40)]
+    pad = torch.zeros((1 << 20,), device="cuda")
+    for a_, b_ in cal:
+        pad.add_(1.0)
+        a_.record()
+        b_.record()
+    torch.cuda.synchronize()
+    ev_overhead_ms = float(np.median([a_.elapsed_time(b_) for a_, b_ in cal]))
     ab, R = alg_bytes_per_sample(A, K, D, Fu, Fi)
     ab_full, _ = alg_bytes_per_sample(T, K, D, Fu, Fi)
     gather_s = stages["fwd_gather_coattn"] * 1e-3
@@ -282,6 +292,8 @@ def main():
                      "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": ab * B, "avg_launch_ms": stages["fwd_gather_coattn"],
+                     "event_pair_overhead_ms": ev_overhead_ms,
+                     "avg_launch_ms_net_of_event_overhead": stages["fwd_gather_coattn"] - ev_overhead_ms,
                      "time_slices_gathered": A, "time_slices_fed": T,
                      "algorithmic_bytes_per_launch_if_all_fed_slices_were_gathered": ab_full * B},
         "roofline_other": {
