@@ -292,6 +292,12 @@ def main():
                      "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": ab * B, "avg_launch_ms": stages["fwd_gather_coattn"],
+                     "hbm_frac_measured_traffic": (traffic / gather_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                     "note": "achieved/frac use the ALGORITHMIC bytes of SURVEY 8(d) (every row use counted); about three "
+                             "quarters of them are repeats of hot rows and of the dummy row that L1/L2/Infinity Cache serve "
+                             "(traffic = HBM bytes measured with PMC counters), so frac can exceed 1: it says how close the "
+                             "kernel is to what HBM could deliver if every byte came from it.  What bounds it is the request "
+                             "latency of the L2-miss path x waves in flight (profiles/r01_cfg3_gather_counters.md)",
                      "event_pair_overhead_ms": ev_overhead_ms,
                      "avg_launch_ms_net_of_event_overhead": stages["fwd_gather_coattn"] - ev_overhead_ms,
                      "time_slices_gathered": A, "time_slices_fed": T,
