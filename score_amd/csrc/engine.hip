@@ -469,11 +469,19 @@ extern "C" int score_forward(const score_config_t* cfg, const score_state_t* st,
                                   ws + w.ainp, s));
     G(gemm_mode_call(x3, 0, BT, AT1, 2 * d.Dk, ws + w.ainp, 2 * d.Dk, ws + w.weff, AT1, ws + w.a1, AT1, ws + w.qz,
                      GF_BIAS | GF_RELU | (T << 16), 1.f, nullptr, 0, scratch, w.scratch_floats, s));
-    G(gemm_mode_call(x3, 0, BT, AT2, AT1, ws + w.a1, AT1, W + P.at_w[2], AT2, ws + w.a2, AT2, W + P.at_b[2],
-                 GF_BIAS | GF_RELU, 1.f, nullptr, 0, scratch, w.scratch_floats, s));
-    G(score_launch_attn_pool_fwd(B, T, H, AT2, ws + w.a2, W + P.at_w[3], W + P.at_b[3], bt->length,
-                                 ws + w.gru_out[0], ws + w.gru_out[1], ws + w.att_score, ws + w.head_inp, d.Dhead,
-                                 d.off_u, d.off_i, s));
+    // dense_4, dense_5, mask, softmax over T and the pooling: one launch, a block per sample (head.hip)
+    int trc = getenv("SCORE_ATTN_TAIL_UNFUSED") ? SCORE_E_SHAPE
+                  : score_launch_attn_tail_fwd(B, T, H, AT1, AT2, ws + w.a1, W + P.at_w[2], W + P.at_b[2], W + P.at_w[3],
+                                               W + P.at_b[3], bt->length, ws + w.gru_out[0], ws + w.gru_out[1], ws + w.a2,
+                                               ws + w.att_score, ws + w.head_inp, d.Dhead, d.off_u, d.off_i, s);
+    if (trc != 0 && trc != SCORE_E_SHAPE) return trc;
+    if (trc == SCORE_E_SHAPE) {
+      G(gemm_mode_call(x3, 0, BT, AT2, AT1, ws + w.a1, AT1, W + P.at_w[2], AT2, ws + w.a2, AT2, W + P.at_b[2],
+                   GF_BIAS | GF_RELU, 1.f, nullptr, 0, scratch, w.scratch_floats, s));
+      G(score_launch_attn_pool_fwd(B, T, H, AT2, ws + w.a2, W + P.at_w[3], W + P.at_b[3], bt->length,
+                                   ws + w.gru_out[0], ws + w.gru_out[1], ws + w.att_score, ws + w.head_inp, d.Dhead,
+                                   d.off_u, d.off_i, s));
+    }
   } else {
     // RIA: final GRU states feed the head (:244-249)
     G(score_launch_copy2d(B, H, ws + w.gru_final[0], H, ws + w.head_inp, d.Dhead, s));

@@ -169,6 +169,79 @@ int score_launch_attn_pool_fwd(int B, int T, int H, int NA, const float* a2, con
   return 0;
 }
 
+// The tail of the temporal attention in ONE launch, a block per sample (score.py:175-181, 214-215): dense_4
+// (a1 [T, N1] -> relu -> a2 [T, N2]), dense_5 (-> 1), where(mask, ., -2^32+1), softmax over T and the pooled states.
+// The sample's a1 rows and the layer's kernel sit in LDS; as two launches (an [B*T]-row GEMM with K = 80, N = 40 and
+// the pooling kernel) this was 21 + 12 us of mostly latency.
+__global__ __launch_bounds__(256) void attn_tail_fwd_kernel(
+    int B, int T, int H, int N1, int N2, const float* __restrict__ a1, const float* __restrict__ W4,
+    const float* __restrict__ b4, const float* __restrict__ w5, const float* __restrict__ b5,
+    const int32_t* __restrict__ length, const float* __restrict__ ur, const float* __restrict__ ir,
+    float* __restrict__ a2, float* __restrict__ score, float* __restrict__ head, int ldh, int off_u, int off_i) {
+  extern __shared__ float sh[];
+  const int L1 = N1 + 1, L2 = N2 + 1;
+  float* a1s = sh;                 // [T][L1]
+  float* w4s = a1s + T * L1;       // [N1][N2]
+  float* a2s = w4s + N1 * N2;      // [T][L2]
+  float* sc = a2s + T * L2;        // [T]
+  __shared__ float red[8];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* a1b = a1 + (int64_t)b * T * N1;
+  for (int i = tid; i < T * N1; i += 256) { const int t = i / N1; a1s[t * L1 + (i - t * N1)] = a1b[i]; }
+  for (int i = tid; i < N1 * N2; i += 256) w4s[i] = W4[i];
+  __syncthreads();
+  float* a2b = a2 + (int64_t)b * T * N2;
+  for (int i = tid; i < T * N2; i += 256) {
+    const int t = i / N2, n = i - t * N2;
+    float acc = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < N1; ++k) acc = fmaf(a1s[t * L1 + k], w4s[k * N2 + n], acc);
+    const float v = fmaxf(acc + b4[n], 0.f);
+    a2s[t * L2 + n] = v;
+    a2b[i] = v;
+  }
+  __syncthreads();
+  const int len = length[b];
+  for (int t = tid; t < T; t += 256) {
+    float acc = 0.f;
+    for (int n = 0; n < N2; ++n) acc = fmaf(a2s[t * L2 + n], w5[n], acc);
+    sc[t] = t < len ? acc + b5[0] : -4294967295.0f;
+  }
+  __syncthreads();
+  // softmax over T (max-subtracted), every thread walks the T scores in the same order
+  float mx = -INFINITY;
+  for (int t = 0; t < T; ++t) mx = fmaxf(mx, sc[t]);
+  float den = 0.f;
+  for (int t = 0; t < T; ++t) den += expf(sc[t] - mx);
+  __syncthreads();
+  for (int t = tid; t < T; t += 256) {
+    const float v = expf(sc[t] - mx) / den;
+    sc[t] = v;
+    score[(int64_t)b * T + t] = v;
+  }
+  __syncthreads();
+  (void)lane; (void)wave; (void)red;
+  for (int j = tid; j < 2 * H; j += 256) {
+    const bool us = j < H;
+    const float* rep = (us ? ur : ir) + (int64_t)b * T * H + (us ? j : j - H);
+    float s_ = 0.f;
+    for (int t = 0; t < T; ++t) s_ = fmaf(rep[(int64_t)t * H], sc[t], s_);
+    const int off = us ? off_u : off_i;
+    if (off >= 0) head[(int64_t)b * ldh + off + (us ? j : j - H)] = s_;
+  }
+}
+
+int score_launch_attn_tail_fwd(int B, int T, int H, int N1, int N2, const float* a1, const float* W4, const float* b4,
+                               const float* w5, const float* b5, const int32_t* length, const float* ur, const float* ir,
+                               float* a2, float* score, float* head, int ldh, int off_u, int off_i, hipStream_t s) {
+  const size_t lds = (size_t)(T * (N1 + 1) + N1 * N2 + T * (N2 + 1) + T) * sizeof(float);
+  if (lds > 60 * 1024) return SCORE_E_SHAPE;
+  hipLaunchKernelGGL(attn_tail_fwd_kernel, dim3(B), dim3(256), lds, s, B, T, H, N1, N2, a1, W4, b4, w5, b5, length, ur, ir,
+                     a2, score, head, ldh, off_u, off_i);
+  SCORE_CHECK_LAUNCH();
+  return 0;
+}
+
 // backward of the pooling + masked softmax + fc3:  one block per sample, the T slices side by side
 //   dscore_t = duf.ur_t + dif.ir_t ; ds_t = score_t (dscore_t - sum score*dscore) [t < len]
 //   da2[t][n] = ds_t * w5[n] * [a2 > 0]

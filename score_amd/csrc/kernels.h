@@ -70,6 +70,9 @@ int score_launch_attn_build_inp(int B, int T, int H, int NI, const float* q, con
 int score_launch_attn_pool_fwd(int B, int T, int H, int NA, const float* a2, const float* w5, const float* b5,
                                const int32_t* length, const float* ur, const float* ir, float* score, float* head,
                                int ldh, int off_u, int off_i, hipStream_t s);
+int score_launch_attn_tail_fwd(int B, int T, int H, int N1, int N2, const float* a1, const float* W4, const float* b4,
+                               const float* w5, const float* b5, const int32_t* length, const float* ur, const float* ir,
+                               float* a2, float* score, float* head, int ldh, int off_u, int off_i, hipStream_t s);
 int score_launch_attn_pool_bwd(int B, int T, int H, int NA, const float* a2, const float* w5,
                                const int32_t* length, const float* ur, const float* ir, const float* score,
                                const float* dhead, int ldh, int off_u, int off_i, float* ds, float* da2,
