@@ -219,6 +219,32 @@ def test_masked_slices_skipped_vs_oracle(mt):
     assert np.array_equal(m_all.get_params()["emb_mtx"][dead_only], P["emb_mtx"][dead_only])
 
 
+def test_fused_and_layerwise_paths_agree(monkeypatch):
+    # the one-launch head (head_fused.hip) and attention tail against the layer-by-layer paths they replace (still
+    # taken for shapes the fused kernels do not cover): same predictions, loss and gradients
+    cfg = so.Cfg(3000, 16, 32, 6, 5, 3, 4, "SCORE")
+    rng = np.random.default_rng(2)
+    P = so.init_params(cfg, 3)
+    b = random_batch(rng, cfg, 80)
+    m = make_model(cfg, P)
+    lay, ws = m.forward_backward(batch_tuple(b), 1e-4, 1.0)
+    torch.cuda.synchronize()
+    y0 = ws[lay.y_pred:lay.y_pred + 80].clone()
+    l0 = float(ws[lay.loss].item())
+    g0 = m.get_grads()
+    monkeypatch.setenv("SCORE_HEAD_UNFUSED", "1")
+    monkeypatch.setenv("SCORE_ATTN_TAIL_UNFUSED", "1")
+    lay, ws = m.forward_backward(batch_tuple(b), 1e-4, 1.0)
+    torch.cuda.synchronize()
+    y1 = ws[lay.y_pred:lay.y_pred + 80].clone()
+    l1 = float(ws[lay.loss].item())
+    g1 = m.get_grads()
+    assert float((y0 - y1).abs().max()) < 2e-6 and abs(l0 - l1) < 2e-6
+    for k in g0:
+        ok, err = close(g1[k], g0[k], rtol=2e-5, atol=1e-9)
+        assert ok, (k, err)
+
+
 @pytest.mark.parametrize("H,B", [(48, 96), (256, 4096)])
 def test_stepwise_recurrence_hidden_sizes(H, B):
     # hidden sizes without a register-resident GRU kernel run the recurrence step by step on grouped

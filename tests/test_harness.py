@@ -44,3 +44,20 @@ def test_evaluate_with_stub_model():
     batch = ([0] * 100, 0, 0, 0, 0, [[i + 1, 0] for i in range(100)], [1] + [0] * 99, 0)
     res = h.evaluate(Stub(), [batch, batch], 1e-4)
     assert len(res) == 9 and res[1] == 1.0 and res[4] == 1.0 and res[8] == 0.5
+
+
+def test_active_slices_rule():
+    # score_batch_t.active_slices = longest sample, clipped to [1, T]; 0 (= all T) when nothing is masked or the
+    # model has the skip switched off
+    from score_amd.model import active_slices
+
+    class Cfg(object):
+        max_time_len = 11
+
+    class M(object):
+        cfg = Cfg()
+        skip_masked_slices = True
+    assert active_slices(M(), 9) == 9 and active_slices(M(), 11) == 0 and active_slices(M(), 15) == 0
+    assert active_slices(M(), 0) == 1 and active_slices(M(), -3) == 1
+    M.skip_masked_slices = False
+    assert active_slices(M(), 9) == 0
