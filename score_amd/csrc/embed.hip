@@ -345,10 +345,11 @@ __global__ __launch_bounds__(256, (KMAX <= 10 && SPL == 1) ? 4 : 1) void coattn_
     }
     const float inv_den = 1.0f / den;
     float pdp = 0.f;
+    group_sum_n<KMAX>(dp, GS);       // dp_k = g1 . seq1_k: the K dot products reduced across the group together
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) {
       p[k] *= inv_den;
-      dp[k] = (k < K) ? group_sum(dp[k], GS) : 0.f;
+      dp[k] = (k < K) ? dp[k] : 0.f;
       pdp += p[k] * dp[k];
     }
     float dz[KMAX];
