@@ -570,17 +570,26 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
   const float* dfinal[2] = {nullptr, nullptr};
   if (d.attn) {
     // ---- temporal attention (score.py:169-186, 214-215)
-    G(score_launch_attn_pool_bwd(B, T, H, AT2, ws + w.a2, W + P.at_w[3], bt->length, ws + w.gru_out[0],
-                                 ws + w.gru_out[1], ws + w.att_score, ws + w.dhead, d.Dhead, d.off_u, d.off_i,
-                                 ws + w.ds, ws + w.da2, s));
+    // pooling / softmax / dense_5 backward and, in the same launch, dense_4's (da1 with dense_3's relu mask)
+    int prc = getenv("SCORE_ATTN_TAIL_UNFUSED") ? SCORE_E_SHAPE
+                  : score_launch_attn_pool_bwd(B, T, H, AT2, ws + w.a2, W + P.at_w[3], bt->length, ws + w.gru_out[0],
+                                               ws + w.gru_out[1], ws + w.att_score, ws + w.dhead, d.Dhead, d.off_u,
+                                               d.off_i, ws + w.ds, ws + w.da2, s, AT1, W + P.at_w[2], ws + w.a1, ws + w.da1);
+    if (prc != 0 && prc != SCORE_E_SHAPE) return prc;
+    const bool da1_done = prc == 0;
+    if (!da1_done)
+      G(score_launch_attn_pool_bwd(B, T, H, AT2, ws + w.a2, W + P.at_w[3], bt->length, ws + w.gru_out[0],
+                                   ws + w.gru_out[1], ws + w.att_score, ws + w.dhead, d.Dhead, d.off_u, d.off_i,
+                                   ws + w.ds, ws + w.da2, s));
     // dense_5 (40 -> 1): dW = a2^T ds ; db = sum ds
     G(gemm_queue_add(&gq, AT2, 1, BT, ws + w.a2, AT2, ws + w.ds, 1, gw + P.at_w[3], 1));
     G(colsum_queue_add(&cq, ws + w.ds, BT, 1, 1, gw + P.at_b[3], 0));
     // dense_4 (80 -> 40); da2 is already relu-masked
     G(gemm_queue_add(&gq, AT1, AT2, BT, ws + w.a1, AT1, ws + w.da2, AT2, gw + P.at_w[2], AT2));
     G(colsum_queue_add(&cq, ws + w.da2, BT, AT2, AT2, gw + P.at_b[2], 0));
-    G(gemm_mode_call(x3, 1, BT, AT1, AT2, ws + w.da2, AT2, W + P.at_w[2], AT2, ws + w.da1, AT1, nullptr, GF_RELUGRAD, 1.f,
-                     reinterpret_cast<const uint8_t*>(ws + w.a1), 0, scratch, SF, s));    // relu mask of dense_3 in the epilogue
+    if (!da1_done)
+      G(gemm_mode_call(x3, 1, BT, AT1, AT2, ws + w.da2, AT2, W + P.at_w[2], AT2, ws + w.da1, AT1, nullptr, GF_RELUGRAD, 1.f,
+                       reinterpret_cast<const uint8_t*>(ws + w.a1), 0, scratch, SF, s));    // relu mask of dense_3 in the epilogue
     // dense_3 (4Dk -> 80), folded: weight gradient from [k, q*k]^T da1 and q^T sum_t da1
     G(gemm_queue_add(&gq, 2 * d.Dk, AT1, BT, ws + w.ainp, 2 * d.Dk, ws + w.da1, AT1, ws + w.dweff, AT1));
     G(colsum_queue_add(&cq, ws + w.da1, BT, AT1, AT1, gw + P.at_b[1], 0));

@@ -249,8 +249,9 @@ __global__ __launch_bounds__(256) void attn_pool_bwd_kernel(
     int B, int T, int H, int NA, int LPT, const float* __restrict__ a2, const float* __restrict__ w5,
     const int32_t* __restrict__ length, const float* __restrict__ ur, const float* __restrict__ ir,
     const float* __restrict__ score, const float* __restrict__ dhead, int ldh, int off_u, int off_i,
-    float* __restrict__ ds, float* __restrict__ da2) {
-  extern __shared__ float sd[];   // [T] dscore
+    float* __restrict__ ds, float* __restrict__ da2, int N1, const float* __restrict__ W4,
+    const float* __restrict__ a1, float* __restrict__ da1) {
+  extern __shared__ float sd[];   // [T] dscore  (+ [T][NA+1] da2 and [N1][NA+1] W4 when N1 > 0)
   const int b = blockIdx.x;
   const int len = length[b];
   const int gl = threadIdx.x % LPT;          // LPT lanes (a power of two <= 64) share one slice
@@ -273,19 +274,43 @@ __global__ __launch_bounds__(256) void attn_pool_bwd_kernel(
     const int t = i / NA, n = i - t * NA;
     const int64_t bt = (int64_t)b * T + t;
     const float g = t < len ? score[bt] * (sd[t] - tot) : 0.f;
-    da2[bt * NA + n] = a2[bt * NA + n] > 0.f ? g * w5[n] : 0.f;
+    const float dv = a2[bt * NA + n] > 0.f ? g * w5[n] : 0.f;
+    da2[bt * NA + n] = dv;
+    if (N1 > 0) sd[T + t * (NA + 1) + n] = dv;
     if (n == 0) ds[bt] = g;
+  }
+  if (N1 <= 0) return;
+  // dense_4 backward in the same launch: da1[t][k] = [a1 > 0] sum_n da2[t][n] W4[k][n]  (the sample's da2 rows and the
+  // layer's kernel in LDS; as its own [B*T]-row GEMM with K = 40 this was 14 us of mostly latency)
+  float* d2s = sd + T;
+  float* w4s = d2s + T * (NA + 1);
+  for (int i = threadIdx.x; i < N1 * NA; i += 256) { const int k = i / NA; w4s[k * (NA + 1) + (i - k * NA)] = W4[i]; }
+  __syncthreads();
+  for (int i = threadIdx.x; i < T * N1; i += 256) {
+    const int t = i / N1, k = i - t * N1;
+    const int64_t e = ((int64_t)b * T + t) * N1 + k;
+    float acc = 0.f;
+#pragma unroll 8
+    for (int n = 0; n < NA; ++n) acc = fmaf(d2s[t * (NA + 1) + n], w4s[k * (NA + 1) + n], acc);
+    da1[e] = a1[e] > 0.f ? acc : 0.f;
   }
 }
 
 int score_launch_attn_pool_bwd(int B, int T, int H, int NA, const float* a2, const float* w5,
                                const int32_t* length, const float* ur, const float* ir, const float* score,
                                const float* dhead, int ldh, int off_u, int off_i, float* ds, float* da2,
-                               hipStream_t s) {
+                               hipStream_t s, int N1, const float* W4, const float* a1, float* da1) {
+  // N1 > 0: also dense_4's backward, da1 = [a1 > 0] (da2 . W4^T) with W4 [N1][NA]; returns SCORE_E_SHAPE if that does
+  // not fit LDS (the caller then runs it as a GEMM and calls again with N1 = 0)
   int LPT = 64;
   while (LPT > 1 && 256 / LPT < T) LPT >>= 1;      // as many slices side by side as the block holds
-  hipLaunchKernelGGL(attn_pool_bwd_kernel, dim3(B), dim3(256), (size_t)T * sizeof(float), s, B, T, H, NA, LPT, a2, w5,
-                     length, ur, ir, score, dhead, ldh, off_u, off_i, ds, da2);
+  size_t lds = (size_t)T * sizeof(float);
+  if (N1 > 0) {
+    lds += (size_t)(T + N1) * (NA + 1) * sizeof(float);
+    if (lds > 60 * 1024) return SCORE_E_SHAPE;
+  }
+  hipLaunchKernelGGL(attn_pool_bwd_kernel, dim3(B), dim3(256), lds, s, B, T, H, NA, LPT, a2, w5,
+                     length, ur, ir, score, dhead, ldh, off_u, off_i, ds, da2, N1, W4, a1, da1);
   SCORE_CHECK_LAUNCH();
   return 0;
 }

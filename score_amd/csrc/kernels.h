@@ -76,7 +76,8 @@ int score_launch_attn_tail_fwd(int B, int T, int H, int N1, int N2, const float*
 int score_launch_attn_pool_bwd(int B, int T, int H, int NA, const float* a2, const float* w5,
                                const int32_t* length, const float* ur, const float* ir, const float* score,
                                const float* dhead, int ldh, int off_u, int off_i, float* ds, float* da2,
-                               hipStream_t s);
+                               hipStream_t s, int N1 = 0, const float* W4 = nullptr, const float* a1 = nullptr,
+                               float* da1 = nullptr);
 int score_launch_attn_inp_bwd(int B, int T, int H, int NI, const float* dinp, const float* q, const float* ur,
                               const float* ir, const float* info, const float* score, const float* dhead, int ldh,
                               int off_u, int off_i, const float* dqd, float* dur, float* dir, float* dinfo, float* dq,
