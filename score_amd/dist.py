@@ -109,7 +109,9 @@ class TorchDistComm(object):
         if not self._gloo:
             self.dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)
             return
-        # gloo has no all_to_all_v for every dtype/shape: pairwise isend/irecv
+        # gloo has no all_to_all_v for every dtype/shape: pairwise isend/irecv.  Device tensors are staged through
+        # host memory (gloo moves host buffers): that is how several processes rehearse the HIP path on ONE GPU
+        # (tests/test_gpu_dist_procs.py); production multi-GPU runs use the RCCL branch above.
         outs = list(out.split(out_splits, 0))
         ins = list(inp.split(in_splits, 0))
         outs[self.rank].copy_(ins[self.rank])
@@ -118,17 +120,22 @@ class TorchDistComm(object):
             if p == self.rank:
                 continue
             if in_splits[p] > 0:
-                reqs.append(self.dist.isend(ins[p].contiguous(), p, group=self.group))
+                reqs.append(self.dist.isend(ins[p].contiguous().cpu(), p, group=self.group))
         for p in range(self.world):
             if p == self.rank or out_splits[p] == 0:
                 continue
-            buf = torch.empty_like(outs[p])
+            buf = torch.empty(outs[p].shape, dtype=outs[p].dtype)
             self.dist.recv(buf, p, group=self.group)
             outs[p].copy_(buf)
         for r in reqs:
             r.wait()
 
     def all_reduce_sum(self, t):
+        if self._gloo and t.device.type != "cpu":
+            h = t.cpu()
+            self.dist.all_reduce(h, op=self.dist.ReduceOp.SUM, group=self.group)
+            t.copy_(h)
+            return
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
 
 
