@@ -122,6 +122,11 @@ def main():
     if world_size != args.gpus:
         if world_size == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+    # rehearsal aids (several ranks on a one-GPU box): SCORE_BENCH_DEVICE pins every rank to one device,
+    # SCORE_DIST_BACKEND=gloo swaps RCCL for gloo (device tensors staged through host memory, score_amd/dist.py)
+    if os.environ.get("SCORE_BENCH_DEVICE"):
+        local_rank = int(os.environ["SCORE_BENCH_DEVICE"])
+    backend = os.environ.get("SCORE_DIST_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dist = None
     sharded = world_size > 1 or args.force_sharded
@@ -131,8 +136,11 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world_size,
-                                device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world_size,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world_size)
 
     from score_amd.synth import make_world
     from score_amd.model import SCORE
@@ -198,7 +206,7 @@ def main():
     dt = time.perf_counter() - t0
     model.enable_stage_events(False)
     if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     if sharded:
