@@ -287,14 +287,22 @@ class SCOREBASE(object):
                 self._side = torch.cuda.Stream(device=self.device)
                 self._ev_gather = torch.cuda.Event()
                 self._ev_gather.record(cur)          # materialise the hipEvent_t
+        # the occurrence sort starts together with the forward (an event recorded here, not between the gather and
+        # the input projections: a record between two launches costs ~5 us of bubble on the main stream, and the
+        # latency-bound gather hardly notices the sort beside it: 1.489 -> 1.476 ms/step); SCORE_PLAN_BEHIND_GATHER=1
+        # restores the old placement (score_state_t.gather_done_event)
+        early = self.scatter_mode == 0 and not os.environ.get("SCORE_PLAN_BEHIND_GATHER")
+        if early:
+            ev_start = cur.record_event()
         lay, ws, st = self._forward(db, reg_lambda, keep_prob, dropout_masks,
-                                    gather_event=self._ev_gather if self.scatter_mode == 0 else None)
+                                    gather_event=self._ev_gather if (self.scatter_mode == 0 and not early) else None)
         if self.scatter_mode == 0:
-            # occurrence sort for the pull-form scatter: depends on the indices only.  It starts on a side
-            # stream once the fused gather (HBM-bound, the whole chip) is through, runs under the GRUs /
-            # attention / head and the first half of the backward, and score_backward waits for it just
-            # before the row scatter (its workspace regions are its own)
-            self._side.wait_event(self._ev_gather)
+            # occurrence sort for the pull-form scatter: depends on the indices only.  It runs on a side
+            # stream from the start of the forward (see above), under the gather / GRUs / attention / head and
+            # the first half of the backward, and score_backward waits for it just before the row scatter
+            # (its workspace regions are its own; the previous step's scatter, their last reader, is behind
+            # the event the side stream waits for)
+            self._side.wait_event(ev_start if early else self._ev_gather)
             with torch.cuda.stream(self._side):
                 _lib.check(self.lib.score_index_plan(C.byref(self.cfg), C.byref(st), C.byref(db.struct), 1, 0,
                                                      self._stream()), "score_index_plan")
