@@ -5,7 +5,7 @@ extern "C" int probe_launch(int trans, int wm, int gx, int gy, int gz, int M, in
   GemmGroup g;
   g.n = 1;
   GemmProb& p = g.p[0];
-  p.A = A; p.B = B; p.C = C; p.slab = slab; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+  p.A = A; p.B = B; p.C = C; p.slab = slab; p.bias = nullptr; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
   p.k_chunk = kc; p.gx = gx; p.gy = gy; p.nblocks = gx * gy * gz;
   g.total_blocks = (p.nblocks + 7) & ~7;
   return score_launch_gemm_bf16x3(trans, wm, g, nullptr, 0, 1.f, nullptr, 0, (hipStream_t)s);
