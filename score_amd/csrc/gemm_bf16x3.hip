@@ -108,9 +108,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(const GemmGroup grp
 #pragma unroll
   for (int rep = 0; rep < NA4; ++rep) {
     if (A_KCONTIG) {
-      const int q = tid + 256 * rep;
-      offa[rep] = (uint32_t)min(bm + (q >> 3), M - 1) * (uint32_t)lda + (uint32_t)((q & 7) * 4);
-      ka[rep] = (q & 7) * 4;
+      // two adjacent quads per thread (8 consecutive k of one row): their three planes go to LDS as one 16-B
+      // write each instead of two 8-B ones (LDS writes cost 11.5 of this kernel's 53 us in situ, tools/x3_probe.py)
+      const int q = tid + 256 * (rep >> 1);
+      const int kq = (q & 3) * 8 + (rep & 1) * 4;
+      offa[rep] = (uint32_t)min(bm + (q >> 2), M - 1) * (uint32_t)lda + (uint32_t)kq;
+      ka[rep] = kq;
     } else {
       offa[rep] = (uint32_t)((tid & 7) * 4 + rep) * (uint32_t)lda + (uint32_t)min(bm + (tid >> 3) * 4, M - 4);
       ka[rep] = (tid & 7) * 4 + rep;
@@ -119,9 +122,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(const GemmGroup grp
 #pragma unroll
   for (int rep = 0; rep < 4; ++rep) {
     if (B_KCONTIG) {
-      const int q = tid + 256 * rep;
-      offb[rep] = (uint32_t)min(bn + (q >> 3), N - 1) * (uint32_t)ldb + (uint32_t)((q & 7) * 4);
-      kb4[rep] = (q & 7) * 4;
+      const int q = tid + 256 * (rep >> 1);
+      const int kq = (q & 3) * 8 + (rep & 1) * 4;
+      offb[rep] = (uint32_t)min(bn + (q >> 2), N - 1) * (uint32_t)ldb + (uint32_t)kq;
+      kb4[rep] = kq;
     } else {
       offb[rep] = (uint32_t)((tid & 7) * 4 + rep) * (uint32_t)ldb + (uint32_t)min(bn + (tid >> 3) * 4, N - 4);
       kb4[rep] = (tid & 7) * 4 + rep;
@@ -209,12 +213,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(const GemmGroup grp
 #endif
     if (A_KCONTIG) {
 #pragma unroll
-      for (int rep = 0; rep < NA4; ++rep) {
-        const int q = tid + 256 * rep;
+      for (int pr = 0; pr < NA4 / 2; ++pr) {
+        const int q = tid + 256 * pr;
 #pragma unroll
         for (int p = 0; p < 3; ++p)
-          *reinterpret_cast<uint2*>(&Ap[p][(q >> 3) * TLD + (q & 7) * 4]) =
-              make_uint2(pa[p * 2 * NA4 + rep * 2], pa[p * 2 * NA4 + rep * 2 + 1]);
+          *reinterpret_cast<uint4*>(&Ap[p][(q >> 2) * TLD + (q & 3) * 8]) =
+              make_uint4(pa[p * 2 * NA4 + pr * 4], pa[p * 2 * NA4 + pr * 4 + 1], pa[p * 2 * NA4 + pr * 4 + 2],
+                         pa[p * 2 * NA4 + pr * 4 + 3]);
       }
     } else if (a_mine) {
 #pragma unroll
@@ -226,12 +231,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(const GemmGroup grp
     }
     if (B_KCONTIG) {
 #pragma unroll
-      for (int rep = 0; rep < 4; ++rep) {
-        const int q = tid + 256 * rep;
+      for (int pr = 0; pr < 2; ++pr) {
+        const int q = tid + 256 * pr;
 #pragma unroll
         for (int p = 0; p < 3; ++p)
-          *reinterpret_cast<uint2*>(&Bp[p][(q >> 3) * TLD + (q & 7) * 4]) =
-              make_uint2(pb[p * 8 + rep * 2], pb[p * 8 + rep * 2 + 1]);
+          *reinterpret_cast<uint4*>(&Bp[p][(q >> 2) * TLD + (q & 3) * 8]) =
+              make_uint4(pb[p * 8 + pr * 4], pb[p * 8 + pr * 4 + 1], pb[p * 8 + pr * 4 + 2], pb[p * 8 + pr * 4 + 3]);
       }
     } else {
 #pragma unroll
