@@ -12,7 +12,12 @@
  *     this repo); the library never allocates, frees or retains device memory;
  *   - sizes are int64_t / int32_t, `stream` is a hipStream_t passed as void*;
  *   - return value: 0 = ok, >0 = hipError_t, <0 = SCORE_E_* argument error;
- *   - no global state: re-entrant across streams;
+ *   - state between calls: none, except the side stream + three events that score_forward/backward fork
+ *     independent work onto.  They live in a score_context_t the caller creates, passes in
+ *     score_state_t.context and destroys; calls with DIFFERENT contexts are re-entrant across streams and
+ *     host threads.  A NULL context selects one process-wide default context per device (created on
+ *     first use under a mutex, released by score_context_destroy(NULL)): calls sharing it must not
+ *     overlap in time.  The SCORE_* A/B environment switches are read once, at the first call;
  *   - all arithmetic is fp32, all indices int32 (score.py:21-30 placeholders);
  *   - table row 0 is the dummy node and must be all-zero in `table`
  *     (score.py:44-47 emb_mtx * mask): kernels rely on it and never update it.
@@ -29,6 +34,13 @@ extern "C" {
 #define SCORE_E_BADARG   (-1)  /* null pointer / non-positive size               */
 #define SCORE_E_SHAPE    (-2)  /* shape outside what the kernels are built for   */
 #define SCORE_E_WORKSPACE (-3) /* workspace too small                            */
+
+/* Per-caller resources of the whole-path entry points (one non-blocking HIP stream + three events on the
+ * current device).  Replaces nothing in the reference: it is what `tf.Session` owns there (train_score.py:188). */
+typedef void* score_context_t;
+int score_context_create(score_context_t* ctx);
+/* ctx == NULL: release the process-wide default contexts.  Synchronises the context's stream first. */
+int score_context_destroy(score_context_t ctx);
 
 /* model_type values (train_score.py:170-179 selects the class by name) */
 enum { SCORE_MODEL_SCORE = 0, SCORE_MODEL_RIA = 1, SCORE_MODEL_RCA = 2,
@@ -112,6 +124,15 @@ typedef struct {
 int score_workspace_layout(const score_config_t* cfg, int32_t B, score_workspace_t* out);
 
 /* ---- per-op entry points (each is also a stage of score_forward/backward) ---- */
+
+/* tf.truncated_normal_initializer (defaults: mean 0, stddev 1, resampled outside 2 sigma; score.py:44) for a
+ * row shard of emb_mtx: local row i holds global row i * row_stride + row_first (row_stride = number of shards,
+ * row_first = this shard's rank; 1 / 0 for the whole table).  Every element is a pure function of
+ * (seed, global row, column) -- the inverse-CDF of a counter-based uniform -- so any sharding of the same seed
+ * yields the same table, and no rank ever materialises rows it does not own.  Global row 0 (the masked dummy
+ * row, score.py:45-47) and local rows past n_global_rows are written as zeros. */
+int score_table_init(float* table, int64_t n_local_rows, int32_t D, int64_t row_stride, int64_t row_first,
+                     int64_t n_global_rows, uint64_t seed, void* stream);
 
 /* tf.nn.embedding_lookup + reshape (score.py:51-66): out[r, :] = table[idx[r], :].
  * Bit-exact copy. n_idx rows of D floats. */
@@ -223,6 +244,8 @@ typedef struct {
   void* plan_done_event;   /* optional hipEvent_t (recorded by the caller after score_index_plan on its own
                            stream): score_backward waits for it just before the row scatter, the first
                            consumer of the plan -- not at its start                                   */
+  score_context_t context; /* side stream + events of this caller (score_context_create); NULL = the
+                           process-wide default context of the current device                         */
 } score_state_t;
 
 /* Index plan of a batch (depends on the indices only; run it before score_backward, on

@@ -44,7 +44,7 @@ class State(C.Structure):
     _fields_ = [("table", c_f), ("n_table_rows", C.c_int64), ("w", c_f), ("workspace", c_f),
                 ("workspace_bytes", C.c_int64), ("scatter_mode", C.c_int32), ("global_batch", C.c_int32),
                 ("gemm_mode", C.c_int32), ("reserved", C.c_int32), ("row_flags", C.c_void_p),
-                ("gather_done_event", C.c_void_p), ("plan_done_event", C.c_void_p)]
+                ("gather_done_event", C.c_void_p), ("plan_done_event", C.c_void_p), ("context", C.c_void_p)]
 
 
 class Graph(C.Structure):
@@ -59,6 +59,9 @@ class BatchOut(C.Structure):
 
 
 _SIGS = {
+    "score_context_create": [C.POINTER(C.c_void_p)],
+    "score_context_destroy": [C.c_void_p],
+    "score_table_init": [c_f, C.c_int64, C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_uint64, C.c_void_p],
     "score_batch_assemble": [C.POINTER(Graph), c_i, c_i, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                              C.c_int32, C.c_uint64, C.POINTER(BatchOut), C.c_void_p],
     "score_param_layout": [C.POINTER(Config), C.POINTER(ParamEntry), C.c_int32, C.POINTER(C.c_int64),

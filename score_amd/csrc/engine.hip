@@ -5,6 +5,8 @@
 #include <stdlib.h>
 #include <stdio.h>
 #include <math.h>
+#include <mutex>
+#include <new>
 #include "common.h"
 #include "kernels.h"
 
@@ -235,25 +237,50 @@ void build_ws(const Dims& d, int B, WS* w) {
 
 // A second stream for work that is independent of the long narrow kernels of the path: the GRU recurrences
 // occupy 128 workgroups (16 samples each at B = 1024), half the chip; the attention query branch (forward) and
-// the weight gradients already known (backward) run beside them.  One stream + two events per host thread
-// and device, created on first use; forked from / joined back into the caller's stream with events.
-struct SideStream { hipStream_t st; hipEvent_t fork, join, wx; };
-static thread_local SideStream g_side[16];
-static int side_stream(SideStream** out) {
+// the weight gradients already known (backward) run beside them.  The stream and its three events belong to a
+// score_context_t (score_context_create / score_context_destroy, include/score_hip.h) that the caller passes in
+// score_state_t.context; forked from / joined back into the caller's stream with events.  A caller that passes no
+// context shares ONE process-wide default context per device (created on first use, released by
+// score_context_destroy(NULL)): the only state the library keeps between calls.
+struct SideStream { hipStream_t st; hipEvent_t fork, join, wx; int device; };
+static int side_stream_create(SideStream* sd) {
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return SCORE_E_BADARG;
-  SideStream& sd = g_side[dev];
-  if (!sd.st) {
-    hipStream_t st; hipEvent_t a, b, c;
-    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return SCORE_E_BADARG;
-    if (hipEventCreateWithFlags(&a, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&b, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c, hipEventDisableTiming) != hipSuccess)
-      return SCORE_E_BADARG;
-    sd.st = st; sd.fork = a; sd.join = b; sd.wx = c;
-  }
+  if (hipGetDevice(&dev) != hipSuccess) return SCORE_E_BADARG;
+  hipStream_t st; hipEvent_t a, b, c;
+  hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+  if (e != hipSuccess) return (int)e;
+  if ((e = hipEventCreateWithFlags(&a, hipEventDisableTiming)) != hipSuccess) { hipStreamDestroy(st); return (int)e; }
+  if ((e = hipEventCreateWithFlags(&b, hipEventDisableTiming)) != hipSuccess) { hipEventDestroy(a); hipStreamDestroy(st); return (int)e; }
+  if ((e = hipEventCreateWithFlags(&c, hipEventDisableTiming)) != hipSuccess) { hipEventDestroy(a); hipEventDestroy(b); hipStreamDestroy(st); return (int)e; }
+  sd->st = st; sd->fork = a; sd->join = b; sd->wx = c; sd->device = dev;
+  return 0;
+}
+static void side_stream_release(SideStream* sd) {
+  if (!sd->st) return;
+  hipStreamSynchronize(sd->st);
+  hipEventDestroy(sd->fork); hipEventDestroy(sd->join); hipEventDestroy(sd->wx);
+  hipStreamDestroy(sd->st);
+  sd->st = nullptr;
+}
+#define SCORE_MAX_DEVICES 16
+static SideStream g_default_ctx[SCORE_MAX_DEVICES];
+static std::mutex g_default_mu;
+static int side_stream(const score_state_t* st, SideStream** out) {
+  if (st && st->context) { *out = reinterpret_cast<SideStream*>(st->context); return 0; }
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SCORE_MAX_DEVICES) return SCORE_E_BADARG;
+  std::lock_guard<std::mutex> lock(g_default_mu);
+  SideStream& sd = g_default_ctx[dev];
+  if (!sd.st) SCORE_TRY(side_stream_create(&sd));
   *out = &sd;
   return 0;
+}
+// A/B switches of the launch sequence, read from the environment ONCE (first call), not per step
+struct EnvFlags { bool head_unfused, attn_tail_unfused, wgrad_side; };
+static const EnvFlags& env_flags() {
+  static const EnvFlags f = {getenv("SCORE_HEAD_UNFUSED") != nullptr, getenv("SCORE_ATTN_TAIL_UNFUSED") != nullptr,
+                             getenv("SCORE_WGRAD_SIDE") != nullptr};
+  return f;
 }
 #define HIPTRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return (int)e_; } while (0)
 
@@ -276,6 +303,29 @@ static inline int gemm_mode_call(int x3, int tr, int M, int N, int K, const floa
   } while (0)
 
 }  // namespace
+
+extern "C" int score_context_create(void** ctx) {
+  if (!ctx) return SCORE_E_BADARG;
+  SideStream* sd = new (std::nothrow) SideStream();
+  if (!sd) return SCORE_E_BADARG;
+  memset(sd, 0, sizeof(*sd));
+  int rc = side_stream_create(sd);
+  if (rc != 0) { delete sd; return rc; }
+  *ctx = sd;
+  return 0;
+}
+
+extern "C" int score_context_destroy(void* ctx) {
+  if (ctx) {
+    SideStream* sd = reinterpret_cast<SideStream*>(ctx);
+    side_stream_release(sd);
+    delete sd;
+    return 0;
+  }
+  std::lock_guard<std::mutex> lock(g_default_mu);
+  for (int i = 0; i < SCORE_MAX_DEVICES; ++i) side_stream_release(&g_default_ctx[i]);
+  return 0;
+}
 
 extern "C" int score_param_layout(const score_config_t* cfg, score_param_entry_t* out, int32_t max_entries,
                                   int64_t* n_floats, int64_t* n_reg_floats) {
@@ -387,7 +437,7 @@ extern "C" int score_forward(const score_config_t* cfg, const score_state_t* st,
   // side stream: the L2 norm of the weights (needs no batch), then the attention's query branch (target rows and
   // weights only) -- beside the gather and the GRUs
   SideStream* sd = nullptr;
-  G(side_stream(&sd));
+  G(side_stream(st, &sd));
   HIPTRY(hipEventRecord(sd->fork, s));
   HIPTRY(hipStreamWaitEvent(sd->st, sd->fork, 0));
   // [Wx_gates | Wx_cand] copies for the hoisted GRU input projections: weights only, off the main stream
@@ -396,7 +446,7 @@ extern "C" int score_forward(const score_config_t* cfg, const score_state_t* st,
   hipEvent_t wx_ev = sd->wx;
   HIPTRY(hipEventRecord(wx_ev, sd->st));
   G(score_launch_l2_partials(W, P.n_reg, ws + w.part, sd->st));
-  const bool head_fused = !getenv("SCORE_HEAD_UNFUSED");
+  const bool head_fused = !env_flags().head_unfused;
   if (!d.attn) HIPTRY(hipEventRecord(sd->join, sd->st));
   if (d.attn) {
     float* scratch2 = ws + w.scratch2;
@@ -470,7 +520,7 @@ extern "C" int score_forward(const score_config_t* cfg, const score_state_t* st,
     G(gemm_mode_call(x3, 0, BT, AT1, 2 * d.Dk, ws + w.ainp, 2 * d.Dk, ws + w.weff, AT1, ws + w.a1, AT1, ws + w.qz,
                      GF_BIAS | GF_RELU | (T << 16), 1.f, nullptr, 0, scratch, w.scratch_floats, s));
     // dense_4, dense_5, mask, softmax over T and the pooling: one launch, a block per sample (head.hip)
-    int trc = getenv("SCORE_ATTN_TAIL_UNFUSED") ? SCORE_E_SHAPE
+    int trc = env_flags().attn_tail_unfused ? SCORE_E_SHAPE
                   : score_launch_attn_tail_fwd(B, T, H, AT1, AT2, ws + w.a1, W + P.at_w[2], W + P.at_b[2], W + P.at_w[3],
                                                W + P.at_b[3], bt->length, ws + w.gru_out[0], ws + w.gru_out[1], ws + w.a2,
                                                ws + w.att_score, ws + w.head_inp, d.Dhead, d.off_u, d.off_i, s);
@@ -571,7 +621,7 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
   if (d.attn) {
     // ---- temporal attention (score.py:169-186, 214-215)
     // pooling / softmax / dense_5 backward and, in the same launch, dense_4's (da1 with dense_3's relu mask)
-    int prc = getenv("SCORE_ATTN_TAIL_UNFUSED") ? SCORE_E_SHAPE
+    int prc = env_flags().attn_tail_unfused ? SCORE_E_SHAPE
                   : score_launch_attn_pool_bwd(B, T, H, AT2, ws + w.a2, W + P.at_w[3], bt->length, ws + w.gru_out[0],
                                                ws + w.gru_out[1], ws + w.att_score, ws + w.dhead, d.Dhead, d.off_u,
                                                d.off_i, ws + w.ds, ws + w.da2, s, AT1, W + P.at_w[2], ws + w.a1, ws + w.da1);
@@ -619,11 +669,11 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
   // ---- GRUs (score.py:205-208)
   // the weight gradients queued so far (head, attention) have everything they need: beside the recurrence
   SideStream* side = nullptr;
-  const bool wgrad_side = getenv("SCORE_WGRAD_SIDE") != nullptr;   // A/B: the recurrences' weight gradients beside the scatter
+  const bool wgrad_side = env_flags().wgrad_side;   // A/B: the recurrences' weight gradients beside the scatter
   const int64_t slab_third = (w.dwslab_floats / 2) & ~(int64_t)3;      // region of the second side flush
   const int64_t slab_half = (w.dwslab_floats / 4) & ~(int64_t)3;        // region of the first one
   if (gq.n > 0 || d.attn) {
-    G(side_stream(&side));
+    G(side_stream(st, &side));
     HIPTRY(hipEventRecord(side->fork, s));
     HIPTRY(hipStreamWaitEvent(side->st, side->fork, 0));
     // Sharded path (scatter_mode 2): the caller runs several streams of its own (plan prefetch, gradient exchange,
@@ -697,7 +747,7 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
   // ---- co-attention + embedding rows (score.py:147-167, 196-201, 51-66)
   int64_t slab_used = slab_half;
   if (wgrad_side && gq.n > 0) {     // the GRU kernels' weight gradients: beside the co-attention backward and the scatter
-    G(side_stream(&side));
+    G(side_stream(st, &side));
     HIPTRY(hipEventRecord(side->fork, s));
     HIPTRY(hipStreamWaitEvent(side->st, side->fork, 0));
     G(gemm_queue_flush(&gq, x3 != 0, ws + w.dwslab + slab_half, slab_third, side->st));

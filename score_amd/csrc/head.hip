@@ -669,3 +669,41 @@ extern "C" int score_adam(float* p, float* m, float* v, const float* g, int64_t 
   SCORE_CHECK_LAUNCH();
   return 0;
 }
+
+// ---------------------------------------------------------------- table initialiser (score.py:44)
+// Truncated normal(0, 1) on [-2, 2] by inverse CDF: u uniform on (Phi(-2), Phi(2)), x = sqrt(2) * erfinv(2u - 1).
+// The uniform is a counter hash of (seed, global element index): the value of an element does not depend on
+// which shard holds it or on the launch geometry.
+__global__ __launch_bounds__(256) void table_init_kernel(float* __restrict__ table, int64_t n_local, int D,
+                                                         int64_t stride, int64_t first, int64_t n_global,
+                                                         uint64_t seed) {
+  const int64_t n = n_local * D;
+  const float lo = 0.02275013194817921f, span = 0.9544997361036416f;     // Phi(-2), Phi(2) - Phi(-2)
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t lr = e / D, col = e - lr * D;
+    const int64_t gr = lr * stride + first;
+    float x = 0.f;
+    if (gr != 0 && gr < n_global) {
+      // two 24-bit hashes -> a 48-bit uniform, so the tails are resolved finer than fp32's 2^-24 grid
+      const uint64_t idx = (uint64_t)gr * (uint64_t)D + (uint64_t)col;
+      const double u = ((double)hash_uniform(seed, 2 * idx) + (double)hash_uniform(seed ^ 0xD1B54A32D192ED03ull, 2 * idx + 1) *
+                        (1.0 / 16777216.0)) + (0.5 / 281474976710656.0);
+      x = 1.4142135623730951f * erfinvf((float)(2.0 * ((double)lo + (double)span * u) - 1.0));
+      x = fminf(fmaxf(x, -2.f), 2.f);
+    }
+    table[e] = x;
+  }
+}
+
+extern "C" int score_table_init(float* table, int64_t n_local_rows, int32_t D, int64_t row_stride, int64_t row_first,
+                                int64_t n_global_rows, uint64_t seed, void* stream) {
+  if (!table || n_local_rows <= 0 || D <= 0 || row_stride <= 0 || row_first < 0 || row_first >= row_stride ||
+      n_global_rows <= 0)
+    return SCORE_E_BADARG;
+  const int64_t want = cdiv64(n_local_rows * D, 256 * 8);
+  const int blocks = (int)(want < 65536 ? (want > 0 ? want : 1) : 65536);
+  hipLaunchKernelGGL(table_init_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, table, n_local_rows, (int)D,
+                     row_stride, row_first, n_global_rows, seed);
+  SCORE_CHECK_LAUNCH();
+  return 0;
+}

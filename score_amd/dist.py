@@ -87,11 +87,17 @@ class TorchDistComm(object):
         self._index = None
 
     def index_comm(self):
-        """A second communicator over the same ranks for the index-only collectives (split sizes, row
-        requests).  They depend on the batch's plan alone; on their own communicator they are not queued
-        behind the previous step's gradient exchange, so reading the sizes never waits for (or drains) the
-        compute stream.  SCORE_SINGLE_COMM=1 keeps everything on one communicator."""
-        if os.environ.get("SCORE_SINGLE_COMM") or self.world == 1 and self._gloo:
+        """The communicator of the index-only collectives (split sizes, row requests) and, in the pipelined step,
+        of the dense all-reduce.  DEFAULT: this communicator itself -- every collective of a rank then goes through
+        one process group in host program order, which is the same on every rank, so no cross-rank ordering hazard
+        exists by construction.
+        SCORE_DUAL_COMM=1 (opt-in, UNVERIFIED beyond one rank): a second communicator over the same ranks, so the
+        index collectives are not queued behind the previous step's gradient exchange.  Two communicators in
+        flight on different streams are only safe if their kernels can always run side by side on every GPU: RCCL
+        kernels block until their peers arrive, and if two ranks' hardware queues ever serialise the two
+        communicators' kernels in opposite orders the step hangs.  Measure on a real multi-GPU node before
+        enabling it (one rank through RCCL: 1.712 vs 1.752 ms/step at cfg-3)."""
+        if not os.environ.get("SCORE_DUAL_COMM") or self.world == 1 and self._gloo:
             return self
         if self._index is None:
             ranks = self.dist.get_process_group_ranks(self.group) if self.group is not None else None
@@ -99,11 +105,19 @@ class TorchDistComm(object):
             self._index._index = self._index
         return self._index
 
-    def exchange_counts(self, send_counts, device):
-        t = torch.tensor(send_counts, dtype=torch.int64, device=device)
+    def exchange_counts(self, send_counts, device, extra=None):
+        """all_to_all of one count per peer.  `extra` (an int): sent to every peer beside its count -- the reply is
+        (counts, extras), one extra per rank (the local batch sizes ride here, no second collective)."""
+        if extra is None:
+            t = torch.tensor(send_counts, dtype=torch.int64, device=device)
+            out = torch.empty_like(t)
+            self.all_to_all(out, t, [1] * self.world, [1] * self.world)
+            return [int(x) for x in _to_host(out).tolist()]
+        t = torch.tensor([[c, int(extra)] for c in send_counts], dtype=torch.int64, device=device)
         out = torch.empty_like(t)
         self.all_to_all(out, t, [1] * self.world, [1] * self.world)
-        return [int(x) for x in _to_host(out).tolist()]
+        got = _to_host(out).tolist()
+        return [int(r[0]) for r in got], [int(r[1]) for r in got]
 
     def all_to_all(self, out, inp, out_splits, in_splits):
         if not self._gloo:
@@ -150,34 +164,41 @@ class _ShardModel(SCOREBASE):
         self._rows_local = (self.N_global + world - 1) // world
         SCOREBASE.__init__(self, feature_size, *args, **kw)
 
-    def _alloc_optimizer(self):
-        if getattr(self, "_sharded", False):       # skip the base class's full-table slots
-            SCOREBASE._alloc_optimizer(self)
+    def _table_rows(self, feature_size):
+        return self._rows_local
 
     def _init_params(self, seed):
-        # same generator sequence as the single-device model: full table, then slice the shard
-        SCOREBASE._init_params(self, seed)
-        full = self.table
-        self.table = self._take_shard(full)
-        del full
-        self._sharded = True
-        self._alloc_optimizer()
-
-    def _take_shard(self, full):
-        shard = torch.zeros((self._rows_local, full.shape[1]), dtype=torch.float32, device=self.device)
-        part = full[self.rank::self.world]
-        shard[:part.shape[0]].copy_(part)
-        return shard
+        # shard-local: the initialiser is a pure function of (seed, global row, column), so this shard holds
+        # exactly the rows the single-device model of the same seed holds -- and never materialises the others
+        self._init_table(seed, self.world, self.rank, self.N_global)
+        self._init_dense(seed)
 
     def set_params(self, params):
+        """from the FULL variable set (emb_mtx [N, D]): keeps this shard's rows, sliced on the host"""
         emb = np.asarray(params["emb_mtx"], dtype=np.float32)
         self.row0 = emb[0].copy()
-        full = torch.from_numpy(emb).to(self.device)
-        full[0].zero_()
-        self.table.copy_(self._take_shard(full))
-        for e in self.entries:
-            v = self._view(self.w, e)
-            v.copy_(torch.from_numpy(np.asarray(params[e[0]], dtype=np.float32).reshape(tuple(v.shape))))
+        part = np.ascontiguousarray(emb[self.rank::self.world])
+        self.table.zero_()
+        self.table[:part.shape[0]].copy_(torch.from_numpy(part))
+        if self.rank == 0:
+            self.table[0].zero_()                                    # global row 0: the masked dummy row
+        self._set_dense(params)
+
+    # checkpoint hooks: the file of a shard holds the shard's rows (local row 0 is the dummy row on rank 0 only)
+    def _table_host(self):
+        t = self.table.cpu().numpy()
+        if self.rank == 0:
+            t[0] = self.row0
+        return t
+
+    def _table_load(self, emb):
+        emb = np.asarray(emb, dtype=np.float32)
+        if emb.shape != tuple(self.table.shape):
+            raise ValueError("emb_mtx shard shape %s != %s" % (emb.shape, tuple(self.table.shape)))
+        self.table.copy_(torch.from_numpy(emb))
+        if self.rank == 0:
+            self.row0 = emb[0].copy()
+            self.table[0].zero_()
 
 
 class HipBackend(object):
@@ -221,8 +242,10 @@ class HipBackend(object):
         # plan order: user_1hop, item_2hop, user_2hop, item_1hop, target_user, target_item
         remapped = _lib.Batch(_ptr(rm[0]), _ptr(rm[2]), _ptr(rm[3]), _ptr(rm[1]), _ptr(rm[4]), _ptr(rm[5]),
                               _ptr(db.tensors[6]), _ptr(db.tensors[7]), db.B, getattr(db, "active_slices", 0))
+        # the record keeps (lay, ws): the step that consumes the plan must use THIS buffer -- the sort output, the
+        # unique-row list and the remapped indices live in it -- whatever the workspace cache does in between
         return dict(db=db, remapped=remapped, keep=rm, U=U, offsets=offs, unique_rows=uniq, slot=h["slot"],
-                    event=h["event"])
+                    event=h["event"], lay=lay, ws=ws)
 
     def plan(self, batch_data, slot=0):
         return self.plan_finish(self.plan_launch(batch_data, slot))
@@ -237,9 +260,9 @@ class HipBackend(object):
 
     def _state(self, plan, mini):
         m = self.m
-        lay, ws = m._workspace(plan["db"].B, plan.get("slot", 0))
+        lay, ws = plan["lay"], plan["ws"]
         return lay, ws, _lib.State(_ptr(mini), mini.shape[0], _ptr(m.w), _ptr(ws), ws.numel() * 4, 2,
-                                   int(m.global_batch), int(m.gemm_mode), 0)
+                                   int(m.global_batch), int(m.gemm_mode), 0, None, None, None, m._ctx)
 
     def forward(self, plan, mini, reg_lambda, keep_prob, masks):
         m = self.m
@@ -349,10 +372,16 @@ class ShardedSCORE(object):
         self._ready = None           # (batch, plan, mini-table) fetched for the next step by the pipelined one
         self._adam_done = False
         if self.device.type == "cuda" and hasattr(self.comm, "index_comm"):
-            # bring both communicators up now (every rank constructs the model): their lazy first-use
+            # bring the communicator(s) up now (every rank constructs the model): their lazy first-use
             # initialisation costs tens of ms and would otherwise land inside a training step
-            for cm in (self.comm, self.comm.index_comm()):
+            for cm in {id(c): c for c in (self.comm, self.comm.index_comm())}.values():
                 cm.exchange_counts([0] * self.world, self.device)
+            if hasattr(self.backend, "dense_grad_with_loss"):
+                # the gradient-exchange stream (and its start-up probe, a handful of device-wide waits): here, not
+                # inside the first training step
+                self._gside = _concurrent_stream(self.device)
+                self._ev_scatter = torch.cuda.Event()
+                self._ev_scatter.record(torch.cuda.current_stream(self.device))      # materialise the hipEvent_t
 
     # bench.py compatibility with the single-device model
     @property
@@ -376,10 +405,13 @@ class ShardedSCORE(object):
         cm = cm if cm is not None else self.comm
         offs = plan["offsets"]
         send = [offs[o + 1] - offs[o] for o in range(self.world)]      # unique rows I need from shard o
-        recv = cm.exchange_counts(send, self.device)                    # rows shard-me must serve to rank p
+        B_local = plan["B"] if "B" in plan else plan["db"].B
+        # rows shard-me must serve to rank p; every rank's batch size rides along: the loss is the mean over the
+        # GLOBAL batch (sum of the local ones -- per-rank loaders end with short last batches of different sizes)
+        recv, sizes = cm.exchange_counts(send, self.device, extra=B_local)
         req = torch.empty((sum(recv),), dtype=torch.int32, device=self.device)
         cm.all_to_all(req, plan["unique_rows"], recv, send)
-        plan.update(send=send, recv=recv, req=req)
+        plan.update(send=send, recv=recv, req=req, global_B=sum(sizes))
         return plan
 
     def _plan_and_request(self, batch_data, slot=0, cm=None):
@@ -475,18 +507,13 @@ class ShardedSCORE(object):
         plan, mini = self._fetch(batch_data)
         if next_batch is not None:
             self._prefetch_launch(next_batch)     # its kernels run under this step's forward
-        B = plan["B"] if "B" in plan else plan["db"].B
-        be.set_global_batch(B * self.world)
+        be.set_global_batch(plan["global_B"])         # sum of every rank's batch size (exchanged with the row counts)
         fw = be.forward(plan, mini, reg_lambda, keep_prob, dropout_masks)
         if self.device.type == "cuda" and hasattr(be, "dense_grad_with_loss") and not os.environ.get("SCORE_LATE_GRADS"):
             # The row gradients are complete before the weight-gradient products of the backward pass
             # (score_backward's stage boundary 4): their all-to-all and the owner-side accumulate start there, on a
             # side stream, under those products.  The dense gradient goes out at the end of the pass in ONE
             # all-reduce together with the log-loss share.
-            if self._gside is None:
-                self._gside = _concurrent_stream(self.device)
-                self._ev_scatter = torch.cuda.Event()
-                self._ev_scatter.record(torch.cuda.current_stream(self.device))      # materialise the hipEvent_t
             cur = torch.cuda.current_stream(self.device)
             mini_g, ev = be.backward(plan, mini, fw, keep_prob, scatter_event=self._ev_scatter)
             grads_in = torch.empty((plan["req"].numel(), self.D), dtype=torch.float32, device=self.device)
@@ -504,16 +531,22 @@ class ShardedSCORE(object):
                 be.accumulate(plan["req"], grads_in, plan["recv"])
                 if pipelined:
                     be.adam_table(lr)
-                    plan_n = nxt[2]
-                    self._gside.wait_event(nxt[3])          # its row requests have arrived (index communicator)
-                    plan_n["req"].record_stream(self._gside)
-                    mini_n = self._rows(plan_n)
-                    self._ready = (next_batch, plan_n, mini_n)
-                done = self._gside.record_event()
+            # Host order = execution order on a communicator, identical on every rank: row gradients, then the dense
+            # all-reduce (on the critical path: the dense ApplyAdam and the next forward wait for it), then the next
+            # batch's rows (their all-to-all overlaps the dense ApplyAdam; with SCORE_DUAL_COMM the all-reduce has
+            # the index communicator to itself)
             buf = be.dense_grad_with_loss(fw)
             (icm if pipelined else cm).all_reduce_sum(buf)
             if pipelined:
                 be.adam_dense(lr, reg_lambda)
+            with torch.cuda.stream(self._gside):
+                if pipelined:
+                    plan_n = nxt[2]
+                    self._gside.wait_event(nxt[3])          # its row requests have arrived
+                    plan_n["req"].record_stream(self._gside)
+                    mini_n = self._rows(plan_n)
+                    self._ready = (next_batch, plan_n, mini_n)
+                done = self._gside.record_event()
             cur.wait_event(done)            # (also orders the frees of mini_g / grads_in behind their last use)
             if pipelined:
                 mini_n.record_stream(cur)
@@ -544,6 +577,31 @@ class ShardedSCORE(object):
 
     def train(self, sess, batch_data, lr, reg_lambda, keep_prob=0.8, dropout_masks=None, next_batch=None):
         return float(self.train_async(batch_data, lr, reg_lambda, keep_prob, dropout_masks, next_batch).item())
+
+    # -- checkpoint (score.py:135-142), one file per rank ---------------------------------------
+    def _shard_path(self, path):
+        return "%s.shard%d-of-%d" % (path, self.rank, self.world)
+
+    def save(self, sess, path):
+        """Every rank writes its own file `<path>.shard<r>-of-<G>.npz`: its row shard of emb_mtx with both Adam
+        slots, plus the (replicated) dense variables and their slots under the TF variable names -- the
+        single-device checkpoint format (SCOREBASE.save) with emb_mtx holding rows r, r+G, r+2G, ...  Call it on
+        every rank; no collective is involved."""
+        m = self.backend.m
+        torch.cuda.current_stream(self.device).synchronize()
+        if self._gside is not None:
+            self._gside.synchronize()
+        m.save(sess, self._shard_path(path))
+
+    def restore(self, sess, path):
+        """Inverse of save(); the world size must be the one the checkpoint was written with."""
+        m = self.backend.m
+        f = self._shard_path(path)
+        if not os.path.exists(f + ".npz"):
+            raise FileNotFoundError("%s.npz: no shard file for rank %d of %d (checkpoints are per world size)" %
+                                    (f, self.rank, self.world))
+        self._ready = self._prefetched = None        # rows fetched ahead belong to the old parameters
+        m.restore(sess, f)
 
     def eval(self, sess, batch_data, reg_lambda):
         be = self.backend

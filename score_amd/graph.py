@@ -51,10 +51,19 @@ class TemporalGraph(object):
     @classmethod
     def from_log(cls, uid, iid, t_idx, n_users, n_items, time_slice_num, user_rows, item_rows,
                  max_1hop=10, max_2hop=100, seed=11):
-        """From a remapped behaviour log (graph_storage.py:93-128 construct_coll_1hop, :130-246
-        construct_coll_2hop): 1-hop = neighbours in log order; 2-hop of a node in slice t = the slice-t
-        1-hop lists of (at most max_1hop of) its neighbours whose slice degree is > 1, each cut to
-        max_1hop, the union down-sampled to max_2hop."""
+        """From a remapped behaviour log, as GraphStore does (graph_storage.py:93-128 construct_coll_1hop,
+        :130-246 construct_coll_2hop; pinned by tests/golden/g5_graph_store.npz, documents written by the
+        reference itself):
+          1-hop of (node, slice t) = its neighbours in log order, repeats kept (:118-121);
+          2-hop = for each of the node's neighbours (all of them, or a random max_1hop of them when there
+            are more: the reference SHUFFLES the stored 1-hop list in place and keeps the first max_1hop,
+            :166-168, so the stored list of such a cell ends up permuted too) whose own slice-t degree is > 1,
+            that neighbour's slice-t list cut to its first max_1hop entries (:171-176), concatenated; more than
+            max_2hop entries are down-sampled without replacement (:180-183); `degrees` holds, aligned with
+            it, the degree of the neighbour each entry came through (what mode 'is' weights by);
+          items first, then users (:147-189, :193-237): the user pass cuts item lists the item pass has
+            already permuted.
+        The random choices come from `seed`, not from the reference's `random` / `np.random` streams."""
         rng = np.random.Generator(np.random.PCG64(seed))
         S, U, I = time_slice_num, n_users, n_items
         u1 = [[] for _ in range(U * S)]
@@ -64,29 +73,43 @@ class TemporalGraph(object):
             i1[(i - U - 1) * S + t].append(u)
 
         def two_hop(own, other, other_base, n):
-            out = []
+            out, deg = [], []
             for e in range(n):
                 for t in range(S):
                     nb = own[e * S + t]
                     if len(nb) > max_1hop:
-                        nb = [nb[j] for j in rng.permutation(len(nb))[:max_1hop]]
-                    acc = []
+                        nb[:] = [nb[j] for j in rng.permutation(len(nb))]      # in place, like random.shuffle
+                        nb = nb[:max_1hop]
+                    acc, dg = [], []
                     for x in nb:
                         lst = other[(x - other_base) * S + t]
-                        if len(lst) > 1:
+                        d = len(lst)
+                        if d > 1:
                             acc += lst[:max_1hop]
+                            dg += [d] * min(d, max_1hop)
                     if len(acc) > max_2hop:
-                        acc = [acc[j] for j in rng.permutation(len(acc))[:max_2hop]]
+                        idx = rng.permutation(len(acc))[:max_2hop]
+                        acc = [acc[j] for j in idx]
+                        dg = [dg[j] for j in idx]
                     out.append(acc)
-            return out
-        u2 = two_hop(u1, i1, U + 1, U)
-        i2 = two_hop(i1, u1, 1, I)
+                    deg.append(dg)
+            return out, deg
+        i2, ideg = two_hop(i1, u1, 1, I)
+        u2, udeg = two_hop(u1, i1, U + 1, U)
         uo1, un1 = _csr(u1)
         uo2, un2 = _csr(u2)
         io1, in1 = _csr(i1)
         io2, in2 = _csr(i2)
-        return cls(U, I, S, dict(off1=uo1, nbr1=un1, off2=uo2, nbr2=un2),
-                   dict(off1=io1, nbr1=in1, off2=io2, nbr2=in2), user_rows, item_rows)
+        g = cls(U, I, S, dict(off1=uo1, nbr1=un1, off2=uo2, nbr2=un2),
+                dict(off1=io1, nbr1=in1, off2=io2, nbr2=in2), user_rows, item_rows)
+        g.user_degrees, g.item_degrees = _csr(udeg)[1], _csr(ideg)[1]      # aligned with nbr2 (same offsets)
+        return g
+
+    def cell(self, side, hop, e, t):
+        """Neighbour list of 0-based entity e in slice t ('user' / 'item', hop 1 / 2) -- host view for tests."""
+        c = self.user_csr if side == "user" else self.item_csr
+        off, nbr = c["off%d" % hop], c["nbr%d" % hop]
+        return nbr[off[e * self.S + t]:off[e * self.S + t + 1]]
 
     # ---- device residency -------------------------------------------------------------
     def to_device(self, device=None):

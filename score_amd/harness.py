@@ -64,7 +64,10 @@ def evaluate(model, batches, reg_lambda, sess=None, neg_sample_num=TEST_NEG_SAMP
         preds += pred
         labels += label
         losses.append(loss)
-        target_iids += np.array(batch_data[5])[:, 0].tolist()
+        ids = batch_data[5]
+        if hasattr(ids, "cpu"):                   # device batches (DeviceGraphLoader) hand tensors over
+            ids = ids.cpu().numpy()
+        target_iids += np.array(ids)[:, 0].tolist()
     logloss = log_loss(labels, preds)
     auc = roc_auc_score(labels, preds)
     loss = sum(losses) / len(losses)
@@ -72,6 +75,83 @@ def evaluate(model, batches, reg_lambda, sess=None, neg_sample_num=TEST_NEG_SAMP
     if verbose:
         print("EVAL TIME: %.4fs" % (time.time() - t))
     return logloss, auc, ndcg_5, ndcg_10, hr_1, hr_5, hr_10, mrr, loss
+
+
+TRAIN_NEG_SAMPLE_NUM = 1          # train_score.py:18
+
+
+def train_loop(model, train_batches, vali_batches, lr, reg_lambda, train_batch_size, dataset_size, sess=None,
+               epochs=6, save_path=None, evaluate_fn=None, neg_sample_num=TEST_NEG_SAMPLE_NUM, log=print):
+    """The training loop train_score.py:165-275 wraps around model.train / model.eval, rule for rule:
+
+      * one evaluation before the first step (:205);
+      * ``eval_iter_num = (dataset_size // 3) // (train_batch_size / (1 + TRAIN_NEG_SAMPLE_NUM))`` (:217, a float
+        floor: three validation passes per epoch) -- every eval_iter_num-th step the mean training loss since the
+        last evaluation is recorded and the validation set is evaluated (:230-245);
+      * the model is saved whenever the new validation MRR beats every earlier one (:246-252);
+      * early stop, only after the first epoch and with more than two evaluations (:254-258): MRR fell twice in
+        a row, or improved by <= 0.001 twice in a row;
+      * at most ``epochs`` (6, :219) passes over the training targets, a fresh loader per epoch (:222).
+
+    ``train_batches`` / ``vali_batches``: zero-argument callables returning a fresh iterable of batches (the
+    reference constructs a new GraphLoader each time).  ``evaluate_fn(model, batches, reg_lambda)`` defaults to
+    evaluate_device when the model has eval_async, else evaluate.  Returns a dict with the curves the reference
+    pickles (:264-266), the index of the best validation MRR and ``best_mrr`` (its return value, :275)."""
+    if evaluate_fn is None:
+        if hasattr(model, "eval_async"):
+            evaluate_fn = lambda m, b, r: evaluate_device(m, b, r, neg_sample_num)
+        else:
+            evaluate_fn = lambda m, b, r: evaluate(m, b, r, sess, neg_sample_num)
+    curves = dict(train_losses=[], vali_losses=[], vali_ndcgs_5=[], vali_ndcgs_10=[], vali_hrs_1=[], vali_hrs_5=[],
+                  vali_hrs_10=[], vali_mrrs=[])
+
+    def validate():
+        _, _, n5, n10, h1, h5, h10, mrr, loss = evaluate_fn(model, vali_batches(), reg_lambda)
+        for k, v in (("vali_ndcgs_5", n5), ("vali_ndcgs_10", n10), ("vali_hrs_1", h1), ("vali_hrs_5", h5),
+                     ("vali_hrs_10", h10), ("vali_mrrs", mrr), ("vali_losses", loss)):
+            curves[k].append(v)
+        return n5, n10, h1, h5, h10, mrr, loss
+
+    step, saves = 0, []
+    n5, n10, h1, h5, h10, mrr, vloss = validate()
+    log("STEP %d  LOSS TRAIN: NULL  LOSS VALI: %.4f  NDCG@5 VALI: %.4f  NDCG@10 VALI: %.4f  HR@1 VALI: %.4f  "
+        "HR@5 VALI: %.4f  HR@10 VALI: %.4f  MRR VALI: %.4f" % (step, vloss, n5, n10, h1, h5, h10, mrr))
+    early_stop = False
+    eval_iter_num = (dataset_size // 3) // (train_batch_size / (1 + TRAIN_NEG_SAMPLE_NUM))
+    if eval_iter_num < 1:
+        raise ValueError("dataset_size %d too small for batch size %d: eval_iter_num = %r" %
+                         (dataset_size, train_batch_size, eval_iter_num))
+    losses_step = []
+    vali_mrrs = curves["vali_mrrs"]
+    for epoch in range(epochs):
+        if early_stop:
+            break
+        for batch_data in train_batches():
+            if early_stop:
+                break
+            loss = model.train(sess, batch_data, lr, reg_lambda)
+            step += 1
+            losses_step.append(loss)
+            if step % eval_iter_num == 0:
+                train_loss = sum(losses_step) / len(losses_step)
+                curves["train_losses"].append(train_loss)
+                losses_step = []
+                n5, n10, h1, h5, h10, mrr, vloss = validate()
+                log("STEP %d  LOSS TRAIN: %.4f  LOSS VALI: %.4f  NDCG@5 VALI: %.4f  NDCG@10 VALI: %.4f  HR@1 VALI: %.4f  "
+                    "HR@5 VALI: %.4f  HR@10 VALI: %.4f  MRR VALI: %.4f" % (step, train_loss, vloss, n5, n10, h1, h5, h10, mrr))
+                if vali_mrrs[-1] > max(vali_mrrs[:-1]):
+                    saves.append(step)
+                    if save_path is not None:
+                        model.save(sess, save_path)
+                if len(vali_mrrs) > 2 and epoch > 0:
+                    if vali_mrrs[-1] < vali_mrrs[-2] and vali_mrrs[-2] < vali_mrrs[-3]:
+                        early_stop = True
+                    if (vali_mrrs[-1] - vali_mrrs[-2]) <= 0.001 and (vali_mrrs[-2] - vali_mrrs[-3]) <= 0.001:
+                        early_stop = True
+    index = int(np.argmax(vali_mrrs))
+    curves.update(best_index=index, best_mrr=vali_mrrs[index], steps=step, saved_at_steps=saves,
+                  eval_iter_num=eval_iter_num, early_stopped=early_stop)
+    return curves
 
 
 def ranking_quality_device(preds, target_iids, neg_sample_num=TEST_NEG_SAMPLE_NUM, return_ranks=False):

@@ -97,10 +97,14 @@ class SCOREBASE(object):
         self.entries, self.n_w, self.n_reg = _lib.param_layout(self.cfg)
         N, D = int(feature_size), int(eb_dim)
         f32 = dict(dtype=torch.float32, device=self.device)
-        self.table = torch.empty((N, D), **f32)
+        self.table = torch.empty((self._table_rows(N), D), **f32)
         self.w = torch.zeros((self.n_w,), **f32)
         self._alloc_optimizer()
-        self._ws = {}
+        self._ws = {}              # (B, slot) -> (layout, buffer), least recently used first
+        self.max_workspaces = 8
+        ctx = C.c_void_p(0)
+        _lib.check(self.lib.score_context_create(C.byref(ctx)), "score_context_create")
+        self._ctx = ctx            # side stream + events of this model's score_forward/backward calls
         self.step = 0
         self.beta1_power = np.float32(ADAM_B1)
         self.beta2_power = np.float32(ADAM_B2)
@@ -113,6 +117,18 @@ class SCOREBASE(object):
         self.skip_masked_slices = True   # batches carry active_slices = max(length): slices every sample masks are skipped
         self.gemm_mode = 1         # 1: bf16x3 split (fp32-accurate) on the shapes where it measured faster, 0: f32 MFMA only
         self._init_params(seed)
+
+    def _table_rows(self, feature_size):
+        """rows of emb_mtx this object holds (a row shard overrides it, score_amd/dist.py)"""
+        return feature_size
+
+    def __del__(self):
+        ctx, self._ctx = getattr(self, "_ctx", None), None
+        if ctx is not None and ctx.value and getattr(self, "lib", None) is not None:
+            try:
+                self.lib.score_context_destroy(ctx)
+            except Exception:
+                pass
 
     # ------------------------------------------------------------------ parameters
     def _alloc_optimizer(self):
@@ -137,14 +153,24 @@ class SCOREBASE(object):
         v = flat[off:off + n]
         return v.view(rows, cols) if cols else v
 
+    def _init_table(self, seed, row_stride=1, row_first=0, n_global=None):
+        """score_table_init: element (global row, col) is a pure function of the seed, so every sharding of a seed
+        holds the same table and a shard initialises only its own rows.  Row 0 is the masked dummy row."""
+        _lib.check(self.lib.score_table_init(_ptr(self.table), self.table.shape[0], self.table.shape[1], int(row_stride),
+                                             int(row_first), int(n_global if n_global is not None else self.table.shape[0]),
+                                             C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), self._stream()),
+                   "score_table_init")
+        self.row0 = np.zeros((self.table.shape[1],), dtype=np.float32)
+
     def _init_params(self, seed):
         """TF initialiser families: truncated normal(0,1) table (score.py:44), glorot-uniform
         dense/GRU kernels, GRU gate bias 1, zeros elsewhere."""
+        self._init_table(seed)
+        self._init_dense(seed)
+
+    def _init_dense(self, seed):
         gen = torch.Generator(device=self.device)
         gen.manual_seed(int(seed))
-        torch.nn.init.trunc_normal_(self.table, mean=0.0, std=1.0, a=-2.0, b=2.0, generator=gen)
-        self.row0 = self.table[0].cpu().numpy().copy()
-        self.table[0].zero_()
         for e in self.entries:
             v = self._view(self.w, e)
             if e[5] == 2:
@@ -155,25 +181,36 @@ class SCOREBASE(object):
             else:
                 v.zero_()
 
-    def get_params(self):
-        """dict TF variable name -> ndarray (emb_mtx carries its masked row 0 value)."""
-        out = {"emb_mtx": self.table.cpu().numpy()}
-        out["emb_mtx"][0] = self.row0
-        for e in self.entries:
-            out[e[0]] = self._view(self.w, e).cpu().numpy().copy()
-        return out
+    def _table_host(self):
+        """the rows of emb_mtx this object holds, as the variable stores them (row 0 with its masked value)"""
+        t = self.table.cpu().numpy()
+        t[0] = self.row0
+        return t
 
-    def set_params(self, params):
-        emb = np.asarray(params["emb_mtx"], dtype=np.float32)
+    def _table_load(self, emb):
+        emb = np.asarray(emb, dtype=np.float32)
         if emb.shape != tuple(self.table.shape):
             raise ValueError("emb_mtx shape %s != %s" % (emb.shape, tuple(self.table.shape)))
         self.row0 = emb[0].copy()
         self.table.copy_(torch.from_numpy(emb))
         self.table[0].zero_()
+
+    def _set_dense(self, params):
         for e in self.entries:
             v = self._view(self.w, e)
             a = np.asarray(params[e[0]], dtype=np.float32).reshape(tuple(v.shape))
             v.copy_(torch.from_numpy(a))
+
+    def get_params(self):
+        """dict TF variable name -> ndarray (emb_mtx carries its masked row 0 value)."""
+        out = {"emb_mtx": self._table_host()}
+        for e in self.entries:
+            out[e[0]] = self._view(self.w, e).cpu().numpy().copy()
+        return out
+
+    def set_params(self, params):
+        self._table_load(params["emb_mtx"])
+        self._set_dense(params)
 
     def dense_table_grad(self):
         """[N, D] gradient of the last forward_backward (device tensor)."""
@@ -200,29 +237,39 @@ class SCOREBASE(object):
         self._row_grads = False
         self._flags_marked = False
 
+    def get_dense_grads(self):
+        """Gradients of the dense variables only (no [N, D] host copy of the table's)."""
+        return {e[0]: self._view(self.w_g, e).cpu().numpy().copy() for e in self.entries}
+
     def get_grads(self):
         out = {"emb_mtx": self.dense_table_grad().cpu().numpy()}
-        for e in self.entries:
-            out[e[0]] = self._view(self.w_g, e).cpu().numpy().copy()
+        out.update(self.get_dense_grads())
         return out
 
     # ------------------------------------------------------------------ device plumbing
     def _workspace(self, B, slot=0):
         """One workspace per (batch size, slot); slots let the sharded path plan batch t+1 while
         batch t is still computing."""
-        ent = self._ws.get((B, slot))
+        key = (B, slot)
+        ent = self._ws.pop(key, None)
         if ent is None:
             lay = _lib.workspace_layout(self.cfg, B)
             buf = torch.empty((lay.total_bytes // 4,), dtype=torch.float32, device=self.device)
-            if len(self._ws) > 6:
-                self._ws.clear()
-            ent = self._ws[(B, slot)] = (lay, buf)
+            # least-recently-used eviction, one entry at a time.  Whoever still needs an evicted buffer (an index
+            # plan in flight, score_amd/dist.py) holds its own reference to it, so dropping the cache entry never
+            # pulls memory from under a step; the device-wide wait keeps the allocator from handing the block to a
+            # new tensor while kernels enqueued on other streams still use it (evictions are rare: a new batch size).
+            while len(self._ws) >= self.max_workspaces:
+                torch.cuda.synchronize(self.device)
+                self._ws.pop(next(iter(self._ws)))
+            ent = (lay, buf)
+        self._ws[key] = ent          # most recently used last
         return ent
 
     def _state(self, ws):
         return _lib.State(_ptr(self.table), self.table.shape[0], _ptr(self.w), _ptr(ws), ws.numel() * 4,
                           int(self.scatter_mode), int(self.global_batch), int(self.gemm_mode), 0,
-                          _ptr(self.table_flags) if self.scatter_mode == 0 else None)
+                          _ptr(self.table_flags) if self.scatter_mode == 0 else None, None, None, self._ctx)
 
     @staticmethod
     def _event_array(events):
@@ -389,9 +436,9 @@ class SCOREBASE(object):
 
     def save(self, sess, path):
         """All global variables incl. the Adam slots, under the TF variable names."""
-        blob = {}
-        for k, v in self.get_params().items():
-            blob[k] = v
+        blob = {"emb_mtx": self._table_host()}
+        for e in self.entries:
+            blob[e[0]] = self._view(self.w, e).cpu().numpy().copy()
         tm, tv = self.table_m.cpu().numpy(), self.table_v.cpu().numpy()
         blob["emb_mtx/Adam"], blob["emb_mtx/Adam_1"] = tm, tv
         for e in self.entries:
@@ -408,7 +455,8 @@ class SCOREBASE(object):
 
     def restore(self, sess, path):
         z = np.load(path + ".npz")
-        self.set_params({k: z[k] for k in ["emb_mtx"] + [e[0] for e in self.entries]})
+        self._table_load(z["emb_mtx"])
+        self._set_dense({e[0]: z[e[0]] for e in self.entries})
         self.table_m.copy_(torch.from_numpy(z["emb_mtx/Adam"]))
         self.table_v.copy_(torch.from_numpy(z["emb_mtx/Adam_1"]))
         for e in self.entries:

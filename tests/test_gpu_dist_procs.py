@@ -60,6 +60,14 @@ def _worker(rank, world, port, out_dir):
         losses.append(model.train(None, bt, 1e-3, 1e-3, keep_prob=1.0, next_batch=bts[i + 1] if i + 1 < len(bts) else None))
     pred, _, _ = model.eval(None, bts[0], 1e-3)
     torch.cuda.synchronize()
+    # per-rank checkpoint (score.py:135-142): a fresh model restored from it continues bit for bit
+    ck = os.path.join(out_dir, "save_model_x", "SCORE_24", "ckpt")
+    model.save(None, ck)
+    twin = ShardedSCORE(*CFG_ARGS, comm=model.comm, seed=99)
+    twin.restore(None, ck)
+    l_a = model.train(None, bts[1], 1e-3, 1e-3, keep_prob=1.0)
+    l_b = twin.train(None, bts[1], 1e-3, 1e-3, keep_prob=1.0)
+    assert l_a == l_b and torch.equal(model.backend.m.table, twin.backend.m.table) and torch.equal(model.backend.m.w, twin.backend.m.w)
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), losses=np.asarray(losses), pred=np.asarray(pred),
              table=model.backend.m.table.cpu().numpy(), w=model.backend.m.w.cpu().numpy())
     dist.destroy_process_group()
@@ -81,6 +89,12 @@ def test_two_processes_share_the_gpu(tmp_path):
         lref = ref.train(None, cat, 1e-3, 1e-3, keep_prob=1.0)
         for r in range(world):
             assert abs(z[r]["losses"][s] - lref) < 2e-5 * max(1.0, abs(lref)), (s, r, z[r]["losses"][s], lref)
+    for r in range(world):
+        pref, _, _ = ref.eval(None, batch_tuple(per_rank[r][0]), 1e-3)
+        assert np.abs(z[r]["pred"] - np.asarray(pref)).max() < 1e-4
+    # (the workers then ran one more step on batch 1 for the checkpoint check: replay it here)
+    cat = tuple(np.concatenate([per_rank[r][1][n] for r in range(world)]) for n in NAMES)
+    ref.train(None, cat, 1e-3, 1e-3, keep_prob=1.0)
     assert np.array_equal(z[0]["w"], z[1]["w"])            # replicas: same all-reduced gradient, same Adam
     N, D = cfg.N, cfg.D
     full = np.zeros((N, D), dtype=np.float32)
@@ -88,7 +102,72 @@ def test_two_processes_share_the_gpu(tmp_path):
         n_r = len(range(r, N, world))
         full[r::world] = z[r]["table"][:n_r]
     d = np.abs(full - ref.table.cpu().numpy())
-    assert (d <= 3e-6).mean() > 0.999 and d.max() <= 2.2 * STEPS * 1e-3
+    assert (d <= 3e-6).mean() > 0.999 and d.max() <= 2.2 * (STEPS + 1) * 1e-3
+
+
+# ---------------------------------------------------------------------------------------------------
+# BASELINE.json configs[3]: Tmall-scale (N = 1,529,672 rows, T=20, K=10, D=64, H=128), table row-sharded over
+# 2 ranks (real processes, gloo exchange, one GPU), global batch 1024 + an UNEVEN second step (512 + 256).
+# ---------------------------------------------------------------------------------------------------
+TM_B = (512, 512, 256)          # rank-1 batch sizes per step; rank 0 always trains 512
+
+
+def _tm_batches(rank):
+    from score_amd.synth import make_world
+    w, kw = make_world("cfg3")
+    kw.pop("batch")
+    sizes = (512, 512, 512) if rank == 0 else TM_B
+    return w, kw, [w.batch(sizes[s], 40 + 10 * rank + s) for s in range(3)]
+
+
+def _tm_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    import torch.distributed as dist
+    from score_amd.dist import ShardedSCORE, TorchDistComm
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    w, kw, bts = _tm_batches(rank)
+    model = ShardedSCORE(seed=21, comm=TorchDistComm(), **kw)     # shard-local initialiser: no full table on any rank
+    assert model.backend.m.table.shape[0] == (kw["feature_size"] + world - 1) // world
+    losses = []
+    for i, bt in enumerate(bts):
+        losses.append(model.train(None, bt, 1e-3, 1e-4, keep_prob=1.0, next_batch=bts[i + 1] if i + 1 < len(bts) else None))
+    pred, _, _ = model.eval(None, bts[0], 1e-4)
+    torch.cuda.synchronize()
+    used = np.unique(np.concatenate([np.asarray(a).reshape(-1) for bt in bts for a in bt[:6]]))
+    extra = np.random.default_rng(7).choice(kw["feature_size"], 100000, replace=False)
+    rows = np.unique(np.concatenate([used, extra]))
+    mine = rows[rows % world == rank]
+    sel = torch.from_numpy(mine // world).to("cuda")
+    np.savez(os.path.join(out_dir, "tm_rank%d.npz" % rank), losses=np.asarray(losses), pred=np.asarray(pred),
+             rows=mine, vals=model.backend.m.table[sel].cpu().numpy(), w=model.backend.m.w.cpu().numpy())
+    dist.destroy_process_group()
+
+
+def test_tmall_scale_two_processes_uneven_batches(tmp_path):
+    from score_amd.model import SCORE
+    world = 2
+    mp.spawn(_tm_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    z = [np.load(str(tmp_path / ("tm_rank%d.npz" % r))) for r in range(world)]
+    per_rank = [_tm_batches(r) for r in range(world)]
+    kw = per_rank[0][1]
+    ref = SCORE(seed=21, **kw)                   # same seed: the shards of the workers ARE this table's rows
+    for s in range(3):
+        cat = tuple(np.concatenate([per_rank[r][2][s][i] for r in range(world)]) for i in range(8))
+        assert cat[6].shape[0] == 512 + TM_B[s]
+        lref = ref.train(None, cat, 1e-3, 1e-4, keep_prob=1.0)
+        for r in range(world):
+            assert abs(z[r]["losses"][s] - lref) < 2e-5 * max(1.0, abs(lref)), (s, r, z[r]["losses"][s], lref)
+    assert np.array_equal(z[0]["w"], z[1]["w"])
+    dw = np.abs(z[0]["w"] - ref.w.cpu().numpy())
+    assert np.median(dw) < 1e-6 and dw.max() <= 2.2 * 3 * 1e-3
+    tab = ref.table.cpu().numpy()
     for r in range(world):
-        pref, _, _ = ref.eval(None, batch_tuple(per_rank[r][0]), 1e-3)
-        assert np.abs(z[r]["pred"] - np.asarray(pref)).max() < 1e-4
+        d = np.abs(z[r]["vals"] - tab[z[r]["rows"]])
+        assert (d <= 3e-6).mean() > 0.999 and d.max() <= 2.2 * 3 * 1e-3, (r, float((d <= 3e-6).mean()), float(d.max()))
+        pref, _, _ = ref.eval(None, per_rank[r][2][0], 1e-4)
+        dp_ = np.abs(z[r]["pred"] - np.asarray(pref))
+        assert np.median(dp_) < 1e-4 and dp_.max() < 2e-3

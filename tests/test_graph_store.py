@@ -49,3 +49,127 @@ def test_to_device_requires_gpu():
     g = TemporalGraph.from_log([1], [2], [0], 1, 1, 1, np.array([[1]]), np.array([[2]]))
     with pytest.raises(RuntimeError):
         g.to_device()
+
+
+# ---------------------------------------------------------------------------------------------------
+# Pinned by the reference: tests/golden/g5_graph_store.npz holds the documents GraphStore itself wrote
+# (tests/golden/make_graph_golden.py imports code/graph_storage.py with in-memory collections).
+# ---------------------------------------------------------------------------------------------------
+import os
+
+import pytest
+
+G5 = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g5_graph_store.npz"))
+
+
+def _docs(tag, side, field):
+    a = G5["%s/%s_%s" % (tag, side, field)]
+    n = G5["%s/%s_%s_len" % (tag, side, "2hop" if field == "degrees" else field)]
+    return [[a[e, t, :n[e, t]].tolist() for t in range(a.shape[1])] for e in range(a.shape[0])]
+
+
+def _build(tag, seed=3):
+    U, I, S, m1, m2 = [int(x) for x in G5[tag + "/dims"]]
+    log = G5[tag + "/log"]
+    g = TemporalGraph.from_log(log[:, 0], log[:, 1], log[:, 2], U, I, S, np.arange(1, U + 1)[:, None],
+                               np.arange(U + 1, U + I + 1)[:, None], max_1hop=m1, max_2hop=m2, seed=seed)
+    return g, (U, I, S, m1, m2)
+
+
+def test_sparse_log_equals_reference_documents():
+    # no cap is hit: 1-hop, 2-hop and degree documents are a pure function of the log -> exact equality
+    g, (U, I, S, m1, m2) = _build("sparse")
+    for side, n in (("user", U), ("item", I)):
+        one, two, deg = _docs("sparse", side, "1hop"), _docs("sparse", side, "2hop"), _docs("sparse", side, "degrees")
+        assert max(len(l) for d in one for l in d) <= m1 and max(len(l) for d in two for l in d) <= m2
+        gd = g.user_degrees if side == "user" else g.item_degrees
+        off2 = (g.user_csr if side == "user" else g.item_csr)["off2"]
+        for e in range(n):
+            for t in range(S):
+                assert g.cell(side, 1, e, t).tolist() == one[e][t], (side, e, t)
+                assert g.cell(side, 2, e, t).tolist() == two[e][t], (side, e, t)
+                assert gd[off2[e * S + t]:off2[e * S + t + 1]].tolist() == deg[e][t]
+
+
+@pytest.mark.parametrize("seed", [3, 4])
+def test_dense_log_vs_reference_documents(seed):
+    # every cap is hit (max_1hop 3, max_2hop 8): cells the reference fills without a random choice must be equal;
+    # the others must have the reference's size and draw from the same support
+    from collections import Counter
+    g, (U, I, S, m1, m2) = _build("dense", seed)
+    ref1 = {"user": _docs("dense", "user", "1hop"), "item": _docs("dense", "item", "1hop")}
+    ref2 = {"user": _docs("dense", "user", "2hop"), "item": _docs("dense", "item", "2hop")}
+    refd = {"user": _docs("dense", "user", "degrees"), "item": _docs("dense", "item", "degrees")}
+    log = G5["dense/log"]
+    raw = {"user": [[[] for _ in range(S)] for _ in range(U)], "item": [[[] for _ in range(S)] for _ in range(I)]}
+    for u, i, t in log.tolist():
+        raw["user"][u - 1][t].append(i)
+        raw["item"][i - U - 1][t].append(u)
+    exact = sampled = 0
+    for side, other, n, obase in (("item", "user", I, 1), ("user", "item", U, U + 1)):
+        for e in range(n):
+            for t in range(S):
+                mine1, r1 = g.cell(side, 1, e, t).tolist(), ref1[side][e][t]
+                # stored 1-hop list: log order, or a permutation of it when longer than max_1hop (random.shuffle in place)
+                assert sorted(mine1) == sorted(r1) == sorted(raw[side][e][t])
+                if len(r1) <= m1:
+                    assert mine1 == r1 == raw[side][e][t]
+                mine2, r2 = g.cell(side, 2, e, t).tolist(), ref2[side][e][t]
+                nbs = raw[side][e][t]
+                lists = [raw[other][x - obase][t] for x in nbs]
+                # the item pass cuts user lists in log order; the user pass cuts item lists the item pass may have permuted
+                cut_random = side == "user" and any(len(l) > m1 for l in lists)
+                det = len(nbs) <= m1 and not cut_random
+                if det:
+                    full = [y for l in lists if len(l) > 1 for y in l[:m1]]
+                    fdeg = [len(l) for l in lists if len(l) > 1 for _ in l[:m1]]
+                    if len(full) <= m2:
+                        assert mine2 == r2 == full, (side, e, t)
+                        gd = g.user_degrees if side == "user" else g.item_degrees
+                        off2 = (g.user_csr if side == "user" else g.item_csr)["off2"]
+                        assert gd[off2[e * S + t]:off2[e * S + t + 1]].tolist() == refd[side][e][t] == fdeg
+                        exact += 1
+                        continue
+                    # only the final down-sampling is random: same size, sub-multiset of the same union
+                    assert len(mine2) == len(r2) == m2
+                    assert not (Counter(mine2) - Counter(full)) and not (Counter(r2) - Counter(full))
+                    sampled += 1
+                    continue
+                support = Counter(y for l in lists if len(l) > 1 for y in l)
+                assert len(mine2) <= m2 and len(r2) <= m2
+                assert not (Counter(mine2) - support) and not (Counter(r2) - support)
+                sampled += 1
+    assert exact >= 10 and sampled > 20         # the fixture exercises both kinds of cell
+
+
+def test_tmall_sample_remap_and_targets():
+    # cfg-1 host plumbing: bundled Tmall sample -> one id space (feateng_tmall.py:72-133) -> graph -> target lines
+    from score_amd import dataprep as dp
+    raw = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tmall_sample_log.npz"))["log"]
+    r = dp.remap_tmall_log(raw)
+    U, I = r["n_users"], r["n_items"]
+    assert (U, I) == (62, 5915) and r["vocab_sizes"][2:5] == (450, 1445, 1389)
+    assert r["feature_size"] == 1 + sum(r["vocab_sizes"])
+    assert r["uid"].min() == 1 and r["uid"].max() == U and r["iid"].min() == U + 1 and r["iid"].max() == U + I
+    assert r["t_idx"].min() == 0 and r["t_idx"].max() == 12
+    # a raw id always maps to the same row, and rows of different vocabularies never collide
+    for col, ids in ((0, r["uid"]), (1, r["iid"])):
+        m = {}
+        for a, b in zip(raw[:, col].tolist(), ids.tolist()):
+            assert m.setdefault(a, b) == b
+    ur, ir = r["user_rows"], r["item_rows"]
+    assert np.array_equal(ur[:, 0], np.arange(1, U + 1)) and np.array_equal(ir[:, 0], np.arange(U + 1, U + I + 1))
+    base = 1 + U + I
+    assert ir[:, 1].min() >= base and ir[:, 3].max() < ur[:, 1].min() <= ur[:, 1].max() < ur[:, 2].min()
+    assert ur[:, 2].max() == r["feature_size"] - 1
+    g = TemporalGraph.from_log(r["uid"], r["iid"], r["t_idx"], U, I, 14, ur, ir)     # TIME_SLICE_NUM_Tmall, graph_storage.py:47
+    assert int(g.user_csr["off1"][-1]) == len(raw) == int(g.item_csr["off1"][-1])
+    lines = dp.gen_target_lines(r["uid"], r["iid"], r["t_idx"], U, I, 9, 1)
+    assert 10 < len(lines) <= U
+    for u, its in lines:
+        assert len(its) == 2 and U < its[1] <= U + I
+        # first item of the prediction slice in LOG order (gen_target.py:112-113 reads the 1-hop database; the 2-hop
+        # database's copy of a long list is permuted, see from_log)
+        first = r["iid"][(r["uid"] == u) & (r["t_idx"] == 9)][0]
+        assert its[0] == first and first in g.cell("user", 1, u - 1, 9)
+        assert sum(len(g.cell("user", 1, u - 1, t)) for t in range(9)) > 0

@@ -4,6 +4,7 @@ import math
 import os
 
 import numpy as np
+import pytest
 
 from score_amd import harness as h
 
@@ -61,3 +62,60 @@ def test_active_slices_rule():
     assert active_slices(M(), 0) == 1 and active_slices(M(), -3) == 1
     M.skip_masked_slices = False
     assert active_slices(M(), 9) == 0
+
+
+# ---- the training loop's rules (train_score.py:217-258), with a scripted model ------------------------
+class _Scripted(object):
+    """train() returns 1/step; the validation MRR follows a script, one value per evaluation."""
+
+    def __init__(self, mrrs):
+        self.mrrs, self.n_eval, self.n_train, self.saved = list(mrrs), 0, 0, []
+
+    def train(self, sess, batch_data, lr, reg_lambda):
+        self.n_train += 1
+        return 1.0 / self.n_train
+
+    def save(self, sess, path):
+        self.saved.append((self.n_train, path))
+
+
+def _run(mrrs, n_batches=6, dataset_size=18, bs=4, epochs=6):
+    m = _Scripted(mrrs)
+
+    def ev(model, batches, reg_lambda):
+        list(batches)
+        v = model.mrrs[min(model.n_eval, len(model.mrrs) - 1)]
+        model.n_eval += 1
+        return 0.0, 0.5, v, v, v, v, v, v, 0.25
+    out = h.train_loop(m, lambda: range(n_batches), lambda: range(2), 1e-3, 1e-4, bs, dataset_size, epochs=epochs,
+                       save_path="ckpt", evaluate_fn=ev, log=lambda s: None)
+    return m, out
+
+
+def test_train_loop_eval_cadence_and_save_on_best():
+    # eval_iter_num = (18 // 3) // (4 / 2) = 3.0: evaluations before step 1 and after steps 3, 6, 9, ...
+    m, out = _run([0.1, 0.2, 0.15, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8, 0.9, 1.0, 1.1, 1.2], n_batches=6)
+    assert out["eval_iter_num"] == 3.0 and out["steps"] == 36 and m.n_eval == 13 and not out["early_stopped"]
+    assert out["saved_at_steps"] == [3, 9, 12, 15, 18, 21, 24, 27, 30, 33, 36]       # not at step 6 (0.15 < 0.2)
+    assert [s for s, _ in m.saved] == out["saved_at_steps"]
+    assert out["train_losses"][0] == pytest.approx((1 + 1 / 2 + 1 / 3) / 3)
+    assert out["train_losses"][1] == pytest.approx((1 / 4 + 1 / 5 + 1 / 6) / 3)       # reset after every evaluation
+    assert out["best_index"] == 12 and out["best_mrr"] == 1.2 and len(out["vali_losses"]) == 13
+
+
+def test_train_loop_early_stop_rules_only_after_first_epoch():
+    # two falls in a row inside epoch 0 do not stop; the first evaluation of epoch 1 (step 9) sees them and stops
+    m, out = _run([0.5, 0.4, 0.3, 0.2, 0.1], n_batches=6)
+    assert out["early_stopped"] and out["steps"] == 9 and m.n_eval == 4 and out["saved_at_steps"] == []
+    assert out["best_index"] == 0
+    # plateau rule: two successive gains <= 0.001
+    m, out = _run([0.1, 0.3, 0.5, 0.5005, 0.501, 0.9], n_batches=6)
+    assert out["early_stopped"] and out["steps"] == 12
+    # a gain of more than 0.001 in either of the last two evaluations keeps it going
+    m, out = _run([0.1, 0.3, 0.5, 0.5005, 0.6, 0.6005, 0.7, 0.7005, 0.8, 0.9, 1.0, 1.1, 1.2], n_batches=6)
+    assert not out["early_stopped"] and out["steps"] == 36
+
+
+def test_train_loop_rejects_degenerate_cadence():
+    with pytest.raises(ValueError):
+        _run([0.1], dataset_size=2, bs=200)
