@@ -376,12 +376,12 @@ class ShardedSCORE(object):
             # initialisation costs tens of ms and would otherwise land inside a training step
             for cm in {id(c): c for c in (self.comm, self.comm.index_comm())}.values():
                 cm.exchange_counts([0] * self.world, self.device)
-            if hasattr(self.backend, "dense_grad_with_loss"):
-                # the gradient-exchange stream (and its start-up probe, a handful of device-wide waits): here, not
-                # inside the first training step
-                self._gside = _concurrent_stream(self.device)
-                self._ev_scatter = torch.cuda.Event()
-                self._ev_scatter.record(torch.cuda.current_stream(self.device))      # materialise the hipEvent_t
+        if self.device.type == "cuda" and hasattr(self.backend, "dense_grad_with_loss"):
+            # the gradient-exchange stream (and its start-up probe, a handful of device-wide waits): here, not
+            # inside the first training step
+            self._gside = _concurrent_stream(self.device)
+            self._ev_scatter = torch.cuda.Event()
+            self._ev_scatter.record(torch.cuda.current_stream(self.device))      # materialise the hipEvent_t
 
     # bench.py compatibility with the single-device model
     @property

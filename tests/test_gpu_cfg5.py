@@ -74,8 +74,11 @@ def _check_vs_oracle(world, kw, m, B, ragged):
     regularised = {n for n, _, _, reg in so.param_spec(om.cfg) if reg}
     for k, v in gg.items():
         ref = go[k] - lam * om.params[k] if k in regularised else go[k]
-        scale = max(np.abs(ref).max(), 1e-12)
-        assert np.abs(v - ref).max() <= 2e-4 * scale + 1e-9, (k, float(np.abs(v - ref).max() / scale))
+        scale = np.abs(ref).max()
+        if scale < 1e-7:        # the last attention bias: softmax is shift-invariant, its true gradient is 0 (rounding noise)
+            assert k == "dense_5/bias" and np.abs(v).max() < 1e-7
+            continue
+        assert np.abs(v - ref).max() <= 2e-4 * scale, (k, float(np.abs(v - ref).max() / scale))
     gt = m.dense_table_grad()[rows].cpu().numpy()
     scale = np.abs(go["emb_mtx"]).max()
     assert np.abs(gt - go["emb_mtx"]).max() <= 2e-4 * scale, float(np.abs(gt - go["emb_mtx"]).max() / scale)
@@ -90,7 +93,10 @@ def _check_vs_oracle(world, kw, m, B, ragged):
     l_o = om.train(None, rb, 1e-3, lam, keep_prob=1.0)
     assert abs(l_g - l_o) < 1e-5 * max(1.0, abs(l_o))
     moved = (m.table[rows] != t_before).any(dim=1)
-    assert bool(moved[torch.from_numpy(marked).to(m.device)].all()) and not bool(moved[0])
+    # rows with a gradient move; a marked row whose every use sits past its own sample's length has a zero
+    # gradient (and zero moments at step 1) and stays; unmarked rows and the dummy row never move
+    has_grad = torch.from_numpy(np.abs(go["emb_mtx"]).max(axis=1) > 0).to(m.device)
+    assert bool(moved[has_grad].all()) and not bool(moved[~torch.from_numpy(marked).to(m.device)].any()) and not bool(moved[0])
     d_tab = np.abs(m.table[rows].cpu().numpy() - om.params["emb_mtx"])
     assert np.median(d_tab) < 1e-6 and d_tab.max() <= 2.2e-3
     pg2, _, _ = m.eval(None, b, lam)
@@ -158,7 +164,9 @@ def test_full_batch_properties(which, request):
     m.global_batch = 0
     m.scatter_mode = 1
     m.forward_backward(db, 1e-4, 1.0)
-    assert float((m.table_g[rows] - g0).abs().max()) <= 2e-5 * float(g0.abs().max())
+    # (float atomics add in arrival order: the hot categorical rows collect ~1e5 summands each here, and the fp32
+    #  rounding of such a sum is what the bound has to allow for -- 2e-5 at cfg-3, tests/test_gpu_fullsize.py)
+    assert float((m.table_g[rows] - g0).abs().max()) <= 5e-4 * float(g0.abs().max())
     assert not bool(m.table_g[~used].any())
     m.scatter_mode = 0
     # dense Adam: only the batch's rows move at step 1; they keep moving under a zero gradient at step 2

@@ -25,12 +25,13 @@ class ThreadComm(object):
     def __init__(self, group, rank):
         self.g, self.rank, self.world = group, rank, group.world
 
-    def exchange_counts(self, send_counts, device):
-        self.g.slots[self.rank] = list(send_counts)
+    def exchange_counts(self, send_counts, device, extra=None):
+        self.g.slots[self.rank] = (list(send_counts), extra)
         self.g.barrier.wait()
-        out = [self.g.slots[p][self.rank] for p in range(self.world)]
+        out = [self.g.slots[p][0][self.rank] for p in range(self.world)]
+        extras = [self.g.slots[p][1] for p in range(self.world)]
         self.g.barrier.wait()
-        return out
+        return out if extra is None else (out, extras)
 
     def all_to_all(self, out, inp, out_splits, in_splits):
         torch.cuda.synchronize()
