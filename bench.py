@@ -4,17 +4,24 @@
   python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg3]
   (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
 
-A "step" is one full training step of SCORE (score.py:101-116: forward, backward,
-dense TF-Adam over the whole table and all dense variables) on one synthetic
-Tmall-shaped batch whose int32 index tensors are already resident in HBM.
-Prints ONE JSON line (rank 0).  `roofline` describes the fused gather + co-attention
-forward kernel (the embedding-gather kernel BASELINE.json's north_star targets):
-algorithmic bytes per launch / its average duration measured with HIP
-events recorded on the launch stream inside the timed region.  `cpu_baseline` times
-the CPU restatement of the TF graph (oracle/, "port") on the host cores for a bounded
-number of steps of the same workload.
+A "step" is one full training step of SCORE (score.py:101-116: forward, backward, dense TF-Adam over the
+whole table and all dense variables) on one synthetic Tmall-shaped batch whose int32 index tensors are
+already resident in HBM.  Prints ONE JSON line (rank 0).
+
+`value` is the STEADY STATE of a long run: every table row carries Adam moments (dense ApplyAdam then moves six
+fp32 streams over the whole table every step -- in a short run from a fresh optimizer only the rows touched so
+far do), all other state as the loader produces it (length = T - 2 for every sample, mirroring the reference's
+train split 9 of 11, graph_loader.py:382; the slices every sample masks are skipped).  Beside it, in the same
+line and measured in the same process: `value_best_case` (fresh optimizer state), `value_all_slices` (nothing
+skipped), `ingestion` (device-side batch assembly inside the loop; nested Python lists as the reference feeds
+them), `roofline` (the fused embedding-gather + co-attention forward kernel on the bench workload: algorithmic
+bytes of SURVEY.md 8(d) / HIP-event duration on the launch stream), `roofline_lowdup` (the same kernel on a
+low-duplication batch over a table far larger than the Infinity Cache, where algorithmic bytes ~ memory
+traffic), `cpu_baseline` (CPU restatement of the TF graph, "port") and `cpu_baseline_literal_tile` (the
+materialised [B,T,K,K,3D] form TF really executes, at the Tmall-default shape).
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -26,7 +33,8 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable (float4 copy)
+PROFILE_ROUND = "r02"
 
 
 def alg_bytes_per_sample(T, K, D, Fu, Fi):
@@ -60,15 +68,16 @@ def usable_cpus():
     return max(1, n)
 
 
-def cpu_baseline(kw, world, B, params, budget_s=25.0, max_steps=4, max_threads=32):
-    """CPU restatement of the TF1 graph (Oracle B + dense TF-Adam), full train step, on a bounded
-    sample: the first step is timed too and is the whole sample if it alone exceeds the budget."""
+def cpu_baseline(kw, batch, params, budget_s=25.0, max_steps=4, max_threads=32, tiled=False):
+    """CPU restatement of the TF1 graph (oracle/: collapsed co-attention, or tiled=True the literal materialised
+    tile) + dense TF-Adam, full train step, on a bounded sample: the first step is timed too and is the whole
+    sample if it alone exceeds the budget."""
     from oracle import score_oracle as so
     threads = min(usable_cpus(), max_threads)
     torch.set_num_threads(threads)
     m = so.OracleModel(kw["feature_size"], kw["eb_dim"], kw["hidden_size"], kw["max_time_len"],
-                       kw["obj_per_time_slice"], kw["user_fnum"], kw["item_fnum"], "SCORE", params=params)
-    batch = world.batch(B, 1000)
+                       kw["obj_per_time_slice"], kw["user_fnum"], kw["item_fnum"], "SCORE", params=params, tiled=tiled)
+    B = len(batch[6])
     t0 = time.time()
     m.train(None, batch, 1e-3, 1e-4, keep_prob=1.0)
     first = time.time() - t0
@@ -79,39 +88,122 @@ def cpu_baseline(kw, world, B, params, budget_s=25.0, max_steps=4, max_threads=3
         m.train(None, batch, 1e-3, 1e-4, keep_prob=1.0)
         times.append(time.time() - t0)
     med = float(np.median(times)) if times else first
+    form = ("literal materialised [B,T,K,K,3D] co-attention tile (score.py:147-167 as TF executes it)" if tiled
+            else "collapsed co-attention")
     return {"value": B / med, "unit": "samples/s", "cores": threads, "kind": "port",
-            "sample": "%d full train step(s) (fwd+bwd+dense TF-Adam) of the same workload after one %s step, B=%d, "
-                      "median %.3f s/step; CPU restatement of the TF1 graph (TensorFlow unavailable), torch-CPU "
-                      "fp32, %d threads (os.cpu_count()=%d, usable=%d)"
-                      % (max(len(times), 1), "untimed warm-up" if times else "(timed, no warm-up)", B, med, threads,
-                         os.cpu_count(), usable_cpus())}
+            "sample": "%d full train step(s) (fwd+bwd+dense TF-Adam, %s) after one %s step, B=%d, N=%d rows, T=%d, K=%d, "
+                      "D=%d, H=%d, median %.3f s/step; CPU restatement of the TF1 graph (TensorFlow unavailable), "
+                      "torch-CPU fp32, %d threads (os.cpu_count()=%d, usable=%d)"
+                      % (max(len(times), 1), form, "untimed warm-up" if times else "(timed, no warm-up)", B,
+                         kw["feature_size"], kw["max_time_len"], kw["obj_per_time_slice"], kw["eb_dim"],
+                         kw["hidden_size"], med, threads, os.cpu_count(), usable_cpus())}
+
+
+def src_sha(name):
+    with open(os.path.join(ROOT, "score_amd", "csrc", name), "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
+def committed_traffic(config, key, kernel_substr):
+    """HBM bytes per launch of a kernel from a committed PMC profile (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
+    separate passes, gfx950 FETCH_SIZE x2 correction: tools/summarize_profile.py) -- only if that profile was taken
+    on THIS build of the kernel's source file; otherwise None (a stale profile is dropped, not quoted)."""
+    path = os.path.join(ROOT, "profiles", "%s_%s_pmc_traffic.json" % (PROFILE_ROUND, config))
+    try:
+        pj = json.load(open(path))
+        sec = pj[key]
+        if sec.get("embed_hip_sha16") != src_sha("embed.hip"):
+            return None, {"dropped": "profile %s was taken on another build of embed.hip" % os.path.basename(path)}
+        for k, v in sec["kernels"].items():
+            if kernel_substr in k:
+                return v["hbm_bytes"], {"profile": os.path.relpath(path, ROOT), "commit": sec.get("commit"),
+                                        "embed_hip_sha16": sec.get("embed_hip_sha16"), "workload": sec.get("workload")}
+    except Exception:
+        pass
+    return None, None
+
+
+def event_pair_overhead_ms():
+    """what an EMPTY pair of timing events measures on this stream: stage durations include it, rocprofv3's do not"""
+    cal = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(40)]
+    pad = torch.zeros((1 << 20,), device="cuda")
+    for a_, b_ in cal:
+        pad.add_(1.0)
+        a_.record()
+        b_.record()
+    torch.cuda.synchronize()
+    return float(np.median([a_.elapsed_time(b_) for a_, b_ in cal]))
+
+
+def gather_probe(model, kw, B, n_probe_rows, iters, seed=0):
+    """The fused gather + co-attention forward kernel on a LOW-DUPLICATION batch (score_amd.synth.lowdup_batch):
+    uniform ids over a probe table of n_probe_rows rows (far beyond the 256 MiB Infinity Cache), no dummy slices,
+    nothing shared.  Runs score_forward (eval) and reads the gather stage from the HIP events on the launch stream."""
+    import ctypes as C
+    from score_amd import _lib
+    from score_amd.synth import lowdup_batch
+    T, K, D, Fu, Fi = kw["max_time_len"], kw["obj_per_time_slice"], kw["eb_dim"], kw["user_fnum"], kw["item_fnum"]
+    table = torch.empty((n_probe_rows, D), dtype=torch.float32, device=model.device)
+    _lib.check(model.lib.score_table_init(C.c_void_p(table.data_ptr()), n_probe_rows, D, 1, 0, n_probe_rows,
+                                          C.c_uint64(12345), model._stream()), "score_table_init")
+    dbs = [model.device_batch(lowdup_batch(n_probe_rows, B, T, K, Fu, Fi, seed + i)) for i in range(4)]
+    saved, saved_rows = model.table, None
+    times = []
+    try:
+        model.table = table                      # score_state_t.table -> the probe table (forward only: no optimizer)
+        for i in range(iters + 3):
+            model.enable_stage_events(True)
+            ev = model.fwd_events
+            model._forward(dbs[i % 4], 1e-4, 1.0, None)
+            torch.cuda.synchronize()
+            if i >= 3:
+                times.append(ev[0].elapsed_time(ev[1]))
+    finally:
+        model.table = saved
+        model.enable_stage_events(False)
+    del table
+    torch.cuda.empty_cache()
+    ab, R = alg_bytes_per_sample(T, K, D, Fu, Fi)
+    # distinct rows a batch of uniform draws names, in expectation: what must come from memory at least once
+    uses = R * B
+    uniq = n_probe_rows * (1.0 - np.exp(-uses / float(n_probe_rows)))
+    return {"ms": float(np.mean(times)), "ms_min": float(np.min(times)), "alg_bytes": ab * B, "row_uses": uses,
+            "expected_distinct_rows": int(uniq), "compulsory_row_bytes": int(uniq) * 4 * D, "probe_rows": n_probe_rows}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="cfg3")
-    ap.add_argument("--batches", type=int, default=4, help="distinct pre-staged batches cycled through")
+    ap.add_argument("--batches", type=int, default=8, help="distinct pre-staged batches cycled through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-side", action="store_true",
+                    help="skip the side measurements (best case, all slices, gather probe, ingestion): headline only")
     ap.add_argument("--force-sharded", action="store_true",
                     help="use the row-sharded all-to-all path even with one rank (exercises RCCL plumbing)")
     ap.add_argument("--no-prefetch", dest="prefetch", action="store_false",
-                    help="sharded path: do NOT start the next batch's index plan under this step's compute "
-                         "(default on: one rank through RCCL measured 2.31 vs 2.55 ms/step)")
+                    help="sharded path: do NOT start the next batch's index plan under this step's compute")
     ap.add_argument("--no-pipeline", dest="pipeline", action="store_false",
                     help="sharded path: optimizer after the backward pass instead of the pipelined step (table update "
                          "and the next batch's row fetch under this step's weight-gradient tail and dense all-reduce)")
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="STRONG scaling: the global batch is fixed at this many samples and every rank trains "
+                         "global_batch / N of them (SURVEY 8d cfg-4: global B = 1024).  Default: weak scaling, every "
+                         "rank trains the config's batch")
     ap.add_argument("--event-every", type=int, default=4,
                     help="record the HIP stage events (live kernel timing for `roofline`) on every E-th timed step: "
                          "eleven timing events per step cost ~3 %% of a 1.8 ms step")
-    ap.add_argument("--all-rows-live", action="store_true",
-                    help="mark every table row as carrying Adam moments before the run: the long-run state of "
-                         "dense Adam (its sweep then moves 6 fp32 streams over the whole table every step)")
+    ap.add_argument("--fresh-state", action="store_true",
+                    help="headline from a FRESH optimizer state (only rows touched during the run carry moments): the "
+                         "best case; default is the steady state with every table row live")
     ap.add_argument("--no-skip-masked", action="store_true",
                     help="gather and compute all T time slices, also those past every sample's length (whose "
                          "results the model masks): A/B for score_batch_t.active_slices")
+    ap.add_argument("--gather-probe-only", action="store_true",
+                    help="run only the low-duplication gather probe (for rocprofv3 --pmc passes) and print its JSON")
+    ap.add_argument("--probe-rows", type=int, default=32_000_000)
     ap.add_argument("--lr", type=float, default=1e-3)
     ap.add_argument("--reg-lambda", type=float, default=1e-4)
     args = ap.parse_args()
@@ -146,6 +238,11 @@ def main():
     from score_amd.model import SCORE
     world, kw = make_world(args.config)
     B = kw.pop("batch")
+    strong = args.global_batch > 0
+    if strong:
+        if args.global_batch % (2 * world_size):
+            raise SystemExit("--global-batch must be a multiple of 2 * N (whole target lines per rank)")
+        B = args.global_batch // world_size
     T, K, D = kw["max_time_len"], kw["obj_per_time_slice"], kw["eb_dim"]
     Fu, Fi = kw["user_fnum"], kw["item_fnum"]
 
@@ -154,9 +251,17 @@ def main():
         model = ShardedSCORE(seed=1111, **kw)
     else:
         model = SCORE(seed=1111, **kw)
+    inner = model.backend.m if sharded else model     # owns the table (shard) and its optimizer state
+
+    if args.gather_probe_only:
+        pr = gather_probe(inner, kw, B, args.probe_rows, 20)
+        pr["achieved_GBs_algorithmic"] = pr["alg_bytes"] / (pr["ms"] * 1e-3) / 1e9
+        print(json.dumps(pr), flush=True)
+        return
+
     if args.no_skip_masked:
-        (model.backend.m if sharded else model).skip_masked_slices = False
-    # weak scaling: every rank trains on its own B-sample batches (global batch = B * N)
+        inner.skip_masked_slices = False
+    # every rank trains on its own batches (weak: B each, global B * N; strong: global_batch / N each)
     batches = [model.device_batch(world.batch(B, rank * 1000 + i)) for i in range(args.batches)]
 
     def barrier():
@@ -164,44 +269,43 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    inner = model.backend.m if sharded else model     # owns the table (shard) and its optimizer state
-    if args.all_rows_live:
-        inner.table_flags.fill_(1)
-    for i in range(args.warmup):
-        if sharded and args.prefetch:
-            model.train_async(batches[i % len(batches)], args.lr, args.reg_lambda,
-                              next_batch=batches[(i + 1) % len(batches)])
-        else:
-            model.train_async(batches[i % len(batches)], args.lr, args.reg_lambda)
-    # per-step stage events for the live kernel timing
-    ev_sets, ev_at = [], {}
+    def run_steps(n, first=0, events=None):
+        fb = None
+        for i in range(first, first + n):
+            e_a0 = e_a1 = None
+            if events is not None and i in events:
+                model.fwd_events, model.bwd_events, e_a0, e_a1 = events[i]
+            elif events is not None:
+                model.fwd_events = model.bwd_events = None
+            if sharded:   # optionally run the next batch's index-only phase (plan + row requests) inside this step
+                nxt = batches[(i + 1) % len(batches)] if (args.prefetch and i + 1 < first + n) else None
+                # with a next batch the step is pipelined: the optimizer runs inside (apply_adam below is then a no-op)
+                fb = model.forward_backward(batches[i % len(batches)], args.reg_lambda, 0.8, None, nxt,
+                                            lr=args.lr if args.pipeline else None)
+            else:
+                fb = model.forward_backward(batches[i % len(batches)], args.reg_lambda, 0.8)
+            if e_a0 is not None:
+                e_a0.record()
+            model.apply_adam(args.lr, args.reg_lambda)
+            if e_a1 is not None:
+                e_a1.record()
+        return fb
+
+    # ---------------------------------------------------------------- headline: steady state
+    if not args.fresh_state:
+        inner.table_flags.fill_(1)      # every row carries Adam moments: the state a long run converges to
+    run_steps(args.warmup)
+    events = {}
     every = max(1, args.event_every)
     for i in range(args.steps):
         if i % every:
             continue
         model.enable_stage_events(True)
-        ev_at[i] = len(ev_sets)
-        ev_sets.append((model.fwd_events, model.bwd_events, torch.cuda.Event(enable_timing=True),
-                        torch.cuda.Event(enable_timing=True)))
+        events[i] = (model.fwd_events, model.bwd_events, torch.cuda.Event(enable_timing=True),
+                     torch.cuda.Event(enable_timing=True))
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        if i in ev_at:
-            model.fwd_events, model.bwd_events, e_a0, e_a1 = ev_sets[ev_at[i]]
-        else:
-            model.fwd_events = model.bwd_events = e_a0 = e_a1 = None
-        if sharded:   # optionally run the next batch's index-only phase (plan + row requests) inside this step
-            nxt = batches[(i + 1) % len(batches)] if (args.prefetch and i + 1 < args.steps) else None
-            # with a next batch the step is pipelined: the optimizer runs inside (apply_adam below is then a no-op)
-            fb = model.forward_backward(batches[i % len(batches)], args.reg_lambda, 0.8, None, nxt,
-                                        lr=args.lr if args.pipeline else None)
-        else:
-            fb = model.forward_backward(batches[i % len(batches)], args.reg_lambda, 0.8)
-        if e_a0 is not None:
-            e_a0.record()
-        model.apply_adam(args.lr, args.reg_lambda)
-        if e_a1 is not None:
-            e_a1.record()
+    fb = run_steps(args.steps, 0, events)
     barrier()
     dt = time.perf_counter() - t0
     model.enable_stage_events(False)
@@ -214,7 +318,8 @@ def main():
     else:
         loss = float(fb[1][fb[0].loss].item())
 
-    # live stage timings (ms), averaged over the timed steps
+    ev_sets = list(events.values())
+
     def avg(fn):
         return float(np.mean([fn(s) for s in ev_sets]))
     stages = {
@@ -229,28 +334,14 @@ def main():
         "bwd_weight_grads": avg(lambda s: s[1][4].elapsed_time(s[1][5])),
         "adam_table_and_dense": avg(lambda s: s[2].elapsed_time(s[3])),
     }
-    # slices the gather really reads: synthetic batches have length = T-2 (the reference's train split has 9 of
-    # 11, graph_loader.py:382) and the slices past the longest sample, which the model masks out of every
-    # result, are skipped (score_batch_t.active_slices) -- the numerator counts only what is gathered
-    A = int(getattr(batches[0], "active_slices", 0)) or T
-    # what an EMPTY pair of timing events measures on this stream (two marker packets back to back): the stage
-    # durations above include it, rocprofv3's per-kernel durations do not
-    cal = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(40)]
-    pad = torch.zeros((1 << 20,), device="cuda")
-    for a_, b_ in cal:
-        pad.add_(1.0)
-        a_.record()
-        b_.record()
-    torch.cuda.synchronize()
-    ev_overhead_ms = float(np.median([a_.elapsed_time(b_) for a_, b_ in cal]))
+    A = int(getattr(batches[0], "active_slices", 0)) or T      # slices the gather really reads
+    ev_overhead_ms = event_pair_overhead_ms()
     ab, R = alg_bytes_per_sample(A, K, D, Fu, Fi)
     ab_full, _ = alg_bytes_per_sample(T, K, D, Fu, Fi)
     gather_s = stages["fwd_gather_coattn"] * 1e-3
     achieved = ab * B / gather_s / 1e9
     N = kw["feature_size"]
     n_w = model.n_w
-    # dense ApplyAdam driven by the row state bytes: live rows move p, m, v in and out (6 streams), rows with
-    # a gradient this step read it too, every row costs its state byte
     live_rows = int((inner.table_flags > 0).sum().item())
     rows_local = int(inner.table.shape[0])
     if sharded:
@@ -258,24 +349,109 @@ def main():
     else:                                             # one extra untimed backward: count the rows it marks
         model.forward_backward(batches[0], args.reg_lambda, 0.8)
         touched = int((inner.table_flags == 2).sum().item())
+        inner._drop_row_marks()
     adam_bytes = 4 * D * (6 * live_rows + touched) + rows_local + 7 * 4 * n_w
     adam_timed = stages["adam_table_and_dense"] > 1e-3        # (pipelined sharded step: the update runs inside the step)
     if not adam_timed:
         stages["adam_table_and_dense"] = None
     scat_bytes = R * (4 + 4 * D) * B
+    headline_live_frac = live_rows / float(rows_local)
+
+    # ---------------------------------------------------------------- side measurements (one GPU, unsharded)
+    side = {}
+    do_side = world_size == 1 and not sharded and not args.no_side and not args.fresh_state and not args.no_skip_masked
+    if do_side:
+        k2 = max(20, min(args.steps, 100))
+
+        def timed(n):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            run_steps(n)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t) / n
+        # (a) all time slices computed, every row live
+        model.skip_masked_slices = False
+        keep = batches
+        batches = [model.device_batch(tuple(db.tensors)) for db in keep]       # same tensors, active_slices = 0
+        assert all(db.active_slices == 0 for db in batches)
+        run_steps(3)
+        s_all = timed(k2)
+        side["value_all_slices"] = B / s_all
+        model.skip_masked_slices = True
+        batches = keep
+        # (b) best case: fresh optimizer state -- only rows touched during the run carry moments
+        for t_ in (model.table_m, model.table_v, model.w_m, model.w_v):
+            t_.zero_()
+        model.table_flags.zero_()
+        run_steps(args.warmup)
+        s_best = timed(k2)
+        side["value_best_case"] = B / s_best
+        side["best_case_live_row_frac"] = int((model.table_flags > 0).sum().item()) / float(rows_local)
+        model.table_flags.fill_(1)
+        # (c) low-duplication gather probe
+        try:
+            pr = gather_probe(model, kw, B, args.probe_rows, 20)
+            p_tr, p_src = committed_traffic(args.config, "gather_probe", "coattn_fwd_kernel")
+            s_ = pr["ms"] * 1e-3
+            side["roofline_lowdup"] = {
+                "kernel": "coattn_fwd_kernel on a low-duplication batch: uniform ids over a %d-row probe table (%.1f GB), no "
+                          "dummy slices, nothing shared between candidates, all %d slices" % (pr["probe_rows"],
+                                                                                        pr["probe_rows"] * D * 4 / 1e9, T),
+                "bound": "hbm", "achieved": pr["alg_bytes"] / s_ / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": pr["alg_bytes"] / s_ / 1e9 / HBM_PEAK_GBS, "traffic": p_tr, "traffic_source": p_src,
+                "frac_on_traffic": (p_tr / s_ / 1e9 / HBM_PEAK_GBS) if p_tr else None,
+                "algorithmic_bytes_per_launch": pr["alg_bytes"], "avg_launch_ms": pr["ms"], "min_launch_ms": pr["ms_min"],
+                "avg_launch_ms_net_of_event_overhead": pr["ms"] - ev_overhead_ms,
+                "expected_distinct_rows": pr["expected_distinct_rows"], "row_uses": pr["row_uses"],
+                "compulsory_row_bytes": pr["compulsory_row_bytes"]}
+        except Exception as e:          # an optional leg never takes the headline down
+            side["roofline_lowdup"] = {"error": repr(e)}
+        # (d) host ingestion included
+        try:
+            from score_amd.synth import make_graph
+            from score_amd.graph import DeviceGraphLoader
+            au, ai = min(world.U, 50000), min(world.I, 200000)
+            g = make_graph(world, T + 1, active_users=au, active_items=ai).to_device(model.device)
+            rng = np.random.default_rng(5)
+            n_lines = (B // 2) * 60
+            lines = list(zip(rng.integers(1, au + 1, n_lines).tolist(),
+                             np.stack([rng.integers(world.U + 1, world.U + ai + 1, n_lines),
+                                       rng.integers(world.U + 1, world.U + ai + 1, n_lines)], 1).tolist()))
+            loader = DeviceGraphLoader(g, B, lines, 0, T - 2, 1, T, K)
+            it = iter(loader)
+            for _ in range(5):
+                model.train_async(next(it), args.lr, args.reg_lambda)
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            n_ing = 0
+            for b_ in it:
+                model.train_async(b_, args.lr, args.reg_lambda)
+                n_ing += 1
+            torch.cuda.synchronize()
+            s_ing = (time.perf_counter() - t) / n_ing
+            nested = world.batch(B, 77, as_lists=True)
+            model.train(None, nested, args.lr, args.reg_lambda)
+            t = time.perf_counter()
+            for _ in range(2):
+                model.train(None, nested, args.lr, args.reg_lambda)
+            s_nested = (time.perf_counter() - t) / 2
+            side["ingestion"] = {
+                "device_assembly_samples_per_s": B / s_ing, "device_assembly_ms_per_step": s_ing * 1e3, "steps": n_ing,
+                "what": "DeviceGraphLoader (score_batch_assemble: CSR graph in HBM -> the eight int32 tensors, one launch per "
+                        "batch) + SCORE.train_async inside the timed loop; synthetic graph over the config's id space",
+                "nested_python_lists_samples_per_s": B / s_nested, "nested_python_lists_ms_per_step": s_nested * 1e3,
+                "nested_what": "model.train(sess, batch_data, ...) fed the 8-tuple of nested Python lists exactly as "
+                               "GraphLoader yields it (graph_loader.py:383): list -> int32 conversion + H2D copy + step; "
+                               "host-bound, never `value`"}
+            del g, loader
+        except Exception as e:
+            side["ingestion"] = {"error": repr(e)}
 
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
         return
-    # HBM bytes per launch of the gather kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
-    # --pmc WRITE_SIZE, separate runs, gfx950 FETCH_SIZE x2 correction; tools/summarize_profile.py)
-    traffic = None
-    try:
-        pj = json.load(open(os.path.join(ROOT, "profiles", "r01_%s_pmc_traffic.json" % args.config)))
-        traffic = [v["hbm_bytes"] for k, v in pj["kernels"].items() if "coattn_fwd_kernel" in k][0]
-    except Exception:
-        traffic = None
+    traffic, tsrc = committed_traffic(args.config, "bench_workload", "coattn_fwd_kernel")
     out = {
         "metric": "train samples/sec @ batch=1024",
         "value": B * world_size * args.steps / dt,
@@ -285,48 +461,69 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if strong else "weak",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
+        "parity": "partial: the CPU oracle the tests check against restates a TF-1.x graph; the reference ships no golden "
+                  "vectors and TensorFlow cannot run here, so the oracle itself is unpinned (DESIGN.md section 2)",
         "config": {"workload": "%s: SCORE full train step (fwd + bwd + dense TF-Adam), N=%d rows, T=%d, K=%d, "
                                "D=%d, H=%d, Fu=%d, Fi=%d, per-GPU batch %d (global %d), keep_prob 0.8, "
                                "%d distinct pre-staged batches, length=%d for every sample (slices >= length are "
                                "masked by the model and skipped)" % (args.config, N, T, K, D, kw["hidden_size"], Fu, Fi,
                                                                    B, B * world_size, len(batches), A),
+                   "optimizer_state": ("fresh (best case): only rows touched during the run carry Adam moments"
+                                       if args.fresh_state else
+                                       "steady state: every table row carries Adam moments (live_row_frac 1.0), so dense "
+                                       "ApplyAdam moves six fp32 streams over the whole table every step"),
+                   "live_row_frac": headline_live_frac,
                    "table": "row-sharded row%%G over %d GPU(s)" % world_size if world_size > 1 else "single GPU",
                    "final_loss": loss},
-        "roofline": {"kernel": "coattn_fwd_kernel (fused embedding gather + co-attention, both calls, one launch)",
+        "roofline": {"kernel": "coattn_fwd_kernel (fused embedding gather + co-attention, both calls, one launch) on the bench "
+                               "workload",
                      "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
+                     "frac_on_traffic": (traffic / gather_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
                      "algorithmic_bytes_per_launch": ab * B, "avg_launch_ms": stages["fwd_gather_coattn"],
-                     "hbm_frac_measured_traffic": (traffic / gather_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                     "note": "achieved/frac use the ALGORITHMIC bytes of SURVEY 8(d) (every row use counted); about three "
-                             "quarters of them are repeats of hot rows and of the dummy row that L1/L2/Infinity Cache serve "
-                             "(traffic = HBM bytes measured with PMC counters), so frac can exceed 1: it says how close the "
-                             "kernel is to what HBM could deliver if every byte came from it.  What bounds it is the request "
-                             "latency of the L2-miss path x waves in flight (profiles/r01_cfg3_gather_counters.md)",
+                     "note": "achieved/frac count the ALGORITHMIC bytes of SURVEY 8(d) (every row use); the loader-shaped batch "
+                             "repeats hot rows, the dummy row and the user side of both candidates, which L1/L2/Infinity Cache "
+                             "serve, so frac is NOT an HBM utilisation and can exceed 1.  frac_on_traffic (PMC bytes of a "
+                             "committed profile of this very build, else null) is; roofline_lowdup is the same kernel where "
+                             "algorithmic bytes ~ traffic",
                      "event_pair_overhead_ms": ev_overhead_ms,
                      "avg_launch_ms_net_of_event_overhead": stages["fwd_gather_coattn"] - ev_overhead_ms,
                      "time_slices_gathered": A, "time_slices_fed": T,
                      "algorithmic_bytes_per_launch_if_all_fed_slices_were_gathered": ab_full * B},
         "roofline_other": {
             "adam_rows (6 fp32 streams over the live table rows, + g on touched rows, + dense vars)": {
-                "live_row_frac": live_rows / float(rows_local), "rows_with_gradient_per_step": touched,
+                "live_row_frac": headline_live_frac, "rows_with_gradient_per_step": touched,
                 "bound": "hbm", "achieved": adam_bytes / (stages["adam_table_and_dense"] * 1e-3) / 1e9 if adam_timed else None,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": adam_bytes / (stages["adam_table_and_dense"] * 1e-3) / 1e9 / HBM_PEAK_GBS if adam_timed else None},
-            "coattn_bwd + scatter (R*(4+4D) per sample)": {
+            "coattn_bwd + scatter (R*(4+4D) per sample, algorithmic)": {
                 "bound": "hbm", "achieved": scat_bytes / (stages["bwd_coattn_scatter"] * 1e-3) / 1e9,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": scat_bytes / (stages["bwd_coattn_scatter"] * 1e-3) / 1e9 / HBM_PEAK_GBS}},
         "stages_ms": stages,
     }
+    out.update(side)
     if world_size == 1 and not args.no_cpu_baseline:
         params = model.get_params()
-        del model, batches
+        del model, batches, inner
         torch.cuda.empty_cache()
-        out["cpu_baseline"] = cpu_baseline(kw, world, B, params)
+        out["cpu_baseline"] = cpu_baseline(kw, world.batch(B, 1000), params)
+        if do_side:
+            # the literal materialised-tile form at the reference's own Tmall-default shape (BASELINE.md section 3;
+            # 11 GB per batch at cfg-3: infeasible beyond)
+            from oracle import score_oracle as so
+            w2, kw2 = make_world("tmall_default")
+            B2 = kw2.pop("batch")
+            cfg2 = so.Cfg(kw2["feature_size"], kw2["eb_dim"], kw2["hidden_size"], kw2["max_time_len"],
+                          kw2["obj_per_time_slice"], kw2["user_fnum"], kw2["item_fnum"], "SCORE")
+            P2 = so.init_params(cfg2, 3)
+            out["cpu_baseline_literal_tile"] = cpu_baseline(kw2, w2.batch(B2, 5), P2, budget_s=12.0, max_steps=3, tiled=True)
+            out["cpu_baseline_tmall_default_collapsed"] = cpu_baseline(kw2, w2.batch(B2, 5), so.init_params(cfg2, 3),
+                                                                       budget_s=8.0, max_steps=3)
     else:
         out["cpu_baseline"] = None
     if dist is not None:

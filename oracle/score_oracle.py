@@ -323,6 +323,26 @@ def _co_attention_collapsed(seq1, seq2, tgt, W, b):
     return seq1_result, seq2_result, atten_info
 
 
+def _co_attention_tiled(seq1, seq2, tgt, W, b):
+    """score.py:147-167 op for op in torch, MATERIALISING the [B,T,K,K,3Dx] tile the way the TF graph does (the
+    form whose cost the reference really pays; used for the CPU timing at the Tmall-default shape and as a
+    third check of the collapse).  tgt: [B, Dx] (tiled over T here, score.py:193-194)."""
+    B, T, K, Dx = seq1.shape
+    target = tgt[:, None, None, None, :].expand(B, T, K, K, Dx)               # :150-151 (after :193-194)
+    seq1_tile = seq1[:, :, :, None, :].expand(B, T, K, K, Dx)                  # :152  tile on axis 3
+    seq2_tile = seq2[:, :, :, None, :].expand(B, T, K, K, Dx)                  # :153  tile on axis 3 as well
+    inp = torch.cat([target, seq1_tile, seq2_tile], dim=-1)                    # :154  [B,T,K,K,3Dx], materialised
+    rel = torch.relu(inp @ W + b)                                              # :155  dense(1, relu)
+    atten = torch.softmax(rel.reshape(B, T, K * K), dim=-1).reshape(B, T, K, K)  # :156-158
+    seq1_w = atten.sum(3)[..., None]                                           # :159
+    seq2_w = atten.sum(2)[..., None]                                           # :160
+    seq1_result = (seq1 * seq1_w).sum(2)                                       # :162
+    seq2_result = (seq2 * seq2_w).sum(2)                                       # :163
+    rel = rel.reshape(B, T, K, K)
+    atten_info = torch.cat([rel.sum(3), rel.sum(2)], dim=2)                    # :165-166
+    return seq1_result, seq2_result, atten_info
+
+
 def _gru(x, length, Wg, bg, Wc, bc, H):
     B, T, I = x.shape
     h = x.new_zeros((B, H))
@@ -338,11 +358,13 @@ def _gru(x, length, Wg, bg, Wc, bc, H):
     return torch.stack(outs, 1), h
 
 
-def forward(cfg, P, batch, keep_prob=1.0, dropout_masks=None, reg_lambda=0.0):
+def forward(cfg, P, batch, keep_prob=1.0, dropout_masks=None, reg_lambda=0.0, tiled=False):
     """Oracle B.  ``P``: dict name -> torch tensor (any float dtype; requires_grad
     as the caller wishes).  ``batch``: dict of int64/int32 torch tensors.
-    Returns dict of named intermediates incl. 'loss' (log-loss + L2)."""
+    Returns dict of named intermediates incl. 'loss' (log-loss + L2).
+    tiled=True runs co_attention in its literal materialised form (_co_attention_tiled)."""
     c = cfg
+    coatt = _co_attention_tiled if tiled else _co_attention_collapsed
     dt = P["emb_mtx"].dtype
     emb_mask = torch.ones((c.N, 1), dtype=dt)
     emb_mask[0] = 0
@@ -363,10 +385,8 @@ def forward(cfg, P, batch, keep_prob=1.0, dropout_masks=None, reg_lambda=0.0):
         i1s, i2s = item_1hop.sum(2), item_2hop.sum(2)
         atten_info = None
     else:
-        u1s, i2s, info_item = _co_attention_collapsed(
-            user_1hop, item_2hop, target_item, P["dense/kernel"], P["dense/bias"])
-        u2s, i1s, info_user = _co_attention_collapsed(
-            user_2hop, item_1hop, target_user, P["dense_1/kernel"], P["dense_1/bias"])
+        u1s, i2s, info_item = coatt(user_1hop, item_2hop, target_item, P["dense/kernel"], P["dense/bias"])
+        u2s, i1s, info_user = coatt(user_2hop, item_1hop, target_user, P["dense_1/kernel"], P["dense_1/bias"])
         atten_info = (info_item + info_user) if c.model_type == "RIA" \
             else torch.cat([info_item, info_user], 2)
     if c.model_type != "RRN":
@@ -438,11 +458,11 @@ def to_torch_batch(batch):
 
 
 def loss_and_grads(cfg, params, batch, reg_lambda, keep_prob=1.0, dropout_masks=None,
-                   dtype=torch.float32):
+                   dtype=torch.float32, tiled=False):
     """Forward + autograd backward.  Returns (out dict, grads dict of ndarrays).
     The emb_mtx gradient is dense [N,D] with row 0 == 0 (mask, score.py:47)."""
     P = to_torch_params(params, dtype, requires_grad=True)
-    out = forward(cfg, P, to_torch_batch(batch), keep_prob, dropout_masks, reg_lambda)
+    out = forward(cfg, P, to_torch_batch(batch), keep_prob, dropout_masks, reg_lambda, tiled)
     out["loss"].backward()
     grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)).detach().numpy()
              for k, v in P.items()}
@@ -496,7 +516,8 @@ class OracleModel(object):
     (score.py:101-133), backed by Oracle B."""
 
     def __init__(self, feature_size, eb_dim, hidden_size, max_time_len, obj_per_time_slice,
-                 user_fnum, item_fnum, model_type="SCORE", seed=1111, params=None):
+                 user_fnum, item_fnum, model_type="SCORE", seed=1111, params=None, tiled=False):
+        self.tiled = tiled      # co_attention in the literal materialised-tile form (what TF executes)
         self.cfg = Cfg(feature_size, eb_dim, hidden_size, max_time_len, obj_per_time_slice,
                        user_fnum, item_fnum, model_type)
         self.params = params if params is not None else init_params(self.cfg, seed)
@@ -511,7 +532,8 @@ class OracleModel(object):
                              (torch.rand((B, 80), generator=gen) < keep_prob)]
         elif dropout_masks is not None:
             dropout_masks = [torch.as_tensor(np.asarray(m)) for m in dropout_masks]
-        out, grads = loss_and_grads(self.cfg, self.params, batch, reg_lambda, keep_prob, dropout_masks)
+        out, grads = loss_and_grads(self.cfg, self.params, batch, reg_lambda, keep_prob, dropout_masks,
+                                    tiled=self.tiled)
         self.opt.step(self.params, grads, lr)
         return float(out["loss"].detach())
 
@@ -519,6 +541,6 @@ class OracleModel(object):
         batch = batch_to_arrays(batch_data)
         with torch.no_grad():
             out = forward(self.cfg, to_torch_params(self.params), to_torch_batch(batch),
-                          1.0, None, reg_lambda)
+                          1.0, None, reg_lambda, self.tiled)
         return out["y_pred"].numpy().reshape(-1).tolist(), batch["label"].reshape(-1).tolist(), \
             float(out["loss"])

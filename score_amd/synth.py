@@ -130,3 +130,56 @@ def make_world(name, seed=1111):
     w = SynthWorld(U, I, T, K, Fu, Fi, iv, uv, seed)
     return w, dict(feature_size=w.feature_size, eb_dim=D, hidden_size=H, max_time_len=T,
                    obj_per_time_slice=K, user_fnum=Fu, item_fnum=Fi, batch=B)
+
+
+def lowdup_batch(n_rows, B, T, K, Fu, Fi, seed=0, length=None):
+    """LOW-DUPLICATION probe batch for the gather kernels: every index uniform over [1, n_rows), no dummy
+    slices, nothing shared between the candidates of a user, no replicated tail slices.  With n_rows far above
+    the R * B row uses of the batch nearly every use is a distinct row, so the kernel's algorithmic bytes
+     and its memory-side traffic coincide -- the case the HBM roofline is about.  Not a model of
+    what the loader produces (SynthWorld.batch is)."""
+    rng = np.random.Generator(np.random.PCG64([seed, 424242]))
+    u = lambda *s: rng.integers(1, n_rows, s, dtype=np.int64).astype(np.int32)
+    length = T if length is None else length
+    return (u(B, T, K, Fi), u(B, T, K, Fu), u(B, T, K, Fu), u(B, T, K, Fi), u(B, Fu), u(B, Fi),
+            (np.arange(B) % 2 == 0).astype(np.int32), np.full((B,), length, dtype=np.int32))
+
+
+def make_graph(world, time_slice_num, seed=7, p_empty=0.3, max_1hop=10, max_2hop=16, active_users=None,
+               active_items=None):
+    """A synthetic TemporalGraph over `world`'s id space for loader-inclusive measurements: per (entity, slice)
+    an empty cell with probability p_empty, else min(max_1hop, Geometric(0.15)) 1-hop neighbours (skewed over the
+    opposite id range: rank ~ n * u^3) and a 2-hop pool of up to max_2hop.  Only the first active_users /
+    active_items entities get histories (target lines must stay inside them); neighbours and feature rows span
+    the whole id space.  Vectorised."""
+    from .graph import TemporalGraph
+    rng = np.random.Generator(np.random.PCG64([seed, 99]))
+    S = time_slice_num
+
+    def skewed(n, count):
+        u = rng.random(count, dtype=np.float32)
+        return np.minimum((n * u * u * u).astype(np.int64), n - 1)
+
+    def side(n_ent, n_active, n1_range, base1, n2_range, base2):
+        cells = n_ent * S
+        act = n_active * S
+        d1 = np.zeros(cells, dtype=np.int64)
+        d1[:act] = np.minimum(max_1hop, rng.geometric(0.15, act))
+        d1[:act][rng.random(act, dtype=np.float32) < p_empty] = 0
+        d2 = np.zeros(cells, dtype=np.int64)
+        d2[:act] = np.where(d1[:act] > 0, rng.integers(1, max_2hop + 1, act), 0)
+        o1 = np.zeros(cells + 1, dtype=np.int64)
+        o2 = np.zeros(cells + 1, dtype=np.int64)
+        np.cumsum(d1, out=o1[1:])
+        np.cumsum(d2, out=o2[1:])
+        n1 = (skewed(n1_range, int(o1[-1])) + base1).astype(np.int32)
+        n2 = (skewed(n2_range, int(o2[-1])) + base2).astype(np.int32)
+        return dict(off1=o1, nbr1=n1, off2=o2, nbr2=n2)
+    w = world
+    au = w.U if active_users is None else min(active_users, w.U)
+    ai = w.I if active_items is None else min(active_items, w.I)
+    users = side(w.U, au, w.I, 1 + w.U, w.U, 1)
+    items = side(w.I, ai, w.U, 1, w.I, 1 + w.U)
+    g = TemporalGraph(w.U, w.I, S, users, items, w._user_rows(np.arange(w.U)), w._item_rows(np.arange(w.I)))
+    g.active_users, g.active_items = au, ai
+    return g

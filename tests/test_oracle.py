@@ -123,3 +123,19 @@ def test_oracle_model_interface():
     for _ in range(20):
         l1 = m.train(None, bd, 1e-3, 1e-4, keep_prob=1.0)
     assert l1 < l0
+
+
+def test_tiled_torch_form_equals_collapsed_form_and_gradients():
+    # third restatement: score.py:147-167 op for op in torch with the [B,T,K,K,3Dx] tile materialised (the form the
+    # CPU baseline times at the Tmall-default shape) against the collapsed form, values and gradients, fp64
+    cfg = so.Cfg(60, 4, 8, 3, 3, 3, 4, "SCORE")
+    rng = np.random.default_rng(8)
+    from helpers import random_batch
+    b = random_batch(rng, cfg, 5)
+    P = so.init_params(cfg, 4)
+    oa, ga = so.loss_and_grads(cfg, P, b, 1e-3, dtype=torch.float64, tiled=False)
+    ob, gb = so.loss_and_grads(cfg, P, b, 1e-3, dtype=torch.float64, tiled=True)
+    assert abs(float(oa["loss"]) - float(ob["loss"])) < 1e-12
+    assert np.abs(oa["y_pred"].detach().numpy() - ob["y_pred"].detach().numpy()).max() < 1e-12
+    for k in ga:
+        assert np.abs(ga[k] - gb[k]).max() < 1e-10, k

@@ -49,8 +49,37 @@ def pmc(fetch_dir, write_dir, out, tag=""):
     json.dump(res, open(out, "w"), indent=1)
 
 
+def pmc_round(bench_fetch, bench_write, probe_fetch, probe_write, out, config="cfg3"):
+    """The two-section file bench.py reads (committed_traffic): PMC bytes of the bench workload and of the
+    low-duplication gather probe, stamped with the commit and the sha of embed.hip they were taken on."""
+    import hashlib
+    import os
+    import subprocess
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sha = hashlib.sha256(open(os.path.join(root, "score_amd", "csrc", "embed.hip"), "rb").read()).hexdigest()[:16]
+    try:
+        commit = subprocess.check_output(["git", "-C", root, "rev-parse", "--short", "HEAD"]).decode().strip()
+    except Exception:
+        commit = None
+    res = {}
+    for key, fd, wd, wl in (("bench_workload", bench_fetch, bench_write,
+                             "%s loader-shaped batches: bench.py --steps 6 --warmup 2 --no-side --no-cpu-baseline" % config),
+                            ("gather_probe", probe_fetch, probe_write,
+                             "low-duplication probe: bench.py --gather-probe-only (uniform ids over a 32 M-row table)")):
+        tmp = tempfile.mktemp(suffix=".json")
+        pmc(fd, wd, tmp, wl)
+        sec = json.load(open(tmp))
+        os.unlink(tmp)
+        sec.update(commit=commit, embed_hip_sha16=sha, workload=wl)
+        res[key] = sec
+    json.dump(res, open(out, "w"), indent=1)
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3])
+    elif sys.argv[1] == "pmc_round":
+        pmc_round(*sys.argv[2:8])
     else:
         pmc(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5] if len(sys.argv) > 5 else "")
