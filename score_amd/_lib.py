@@ -43,7 +43,7 @@ class Workspace(C.Structure):
 class State(C.Structure):
     _fields_ = [("table", c_f), ("n_table_rows", C.c_int64), ("w", c_f), ("workspace", c_f),
                 ("workspace_bytes", C.c_int64), ("scatter_mode", C.c_int32), ("global_batch", C.c_int32),
-                ("gemm_mode", C.c_int32), ("reserved", C.c_int32), ("row_flags", C.c_void_p),
+                ("gemm_mode", C.c_int32), ("debug_flags", C.c_int32), ("row_flags", C.c_void_p),
                 ("gather_done_event", C.c_void_p), ("plan_done_event", C.c_void_p), ("context", C.c_void_p)]
 
 

@@ -137,7 +137,7 @@ struct WS {
   int64_t gru_out[2], gru_final[2], xproj[2], gates[2];
   int64_t q, ainp, a1, a2, bn, f1, f2, lossb, dlogit, part;
   int64_t weff, wq, qz, adzsum, dweff, dwq, dqd;   // folded first attention layer (head.hip)
-  int64_t dwslab, dwslab_floats, dgstage, scratch2, gru_tmp;          // deferred weight-gradient products (gemm.hip), bn1 dgamma staging
+  int64_t dwslab, dwslab_floats, dgstage, scratch2, gru_tmp, gru_tmp_floats;          // deferred weight-gradient products (gemm.hip), bn1 dgamma staging
   // backward
   int64_t dz2, dz1, dbn, dhead, ds, da2, da1, dainp, dgru[2], dinfo, dq, dquery, dfinal[2];
   int64_t dxproj[2], rh[2], hprev[2], dxside[2], dzsum[2], S, scratch;
@@ -197,7 +197,11 @@ void build_ws(const Dims& d, int B, WS* w) {
   w->wxcat = take(2 * (int64_t)(d.I + 1) * 3 * d.H);
   w->dgstage = take((int64_t)B * d.Dhead);
   w->scratch2 = take(w->scratch_floats);           // split-K scratch of the side stream's products
-  w->gru_tmp = take(10 * (int64_t)B * d.H);        // step-by-step recurrence (hidden sizes without a register kernel)
+  // scratch of the recurrences without a register-resident kernel: MFMA-fragment weight copies (H = 256) or the
+  // step-by-step form's state
+  w->gru_tmp_floats = 10 * (int64_t)B * d.H;
+  if (w->gru_tmp_floats < 12 * (int64_t)d.H * d.H) w->gru_tmp_floats = 12 * (int64_t)d.H * d.H;
+  w->gru_tmp = take(w->gru_tmp_floats);
   {
     // split-K partials of every queued weight-gradient product: ~24 slabs of each dense variable
     Params Pl;
@@ -276,10 +280,10 @@ static int side_stream(const score_state_t* st, SideStream** out) {
   return 0;
 }
 // A/B switches of the launch sequence, read from the environment ONCE (first call), not per step
-struct EnvFlags { bool head_unfused, attn_tail_unfused, wgrad_side; };
+struct EnvFlags { bool head_unfused, attn_tail_unfused, wgrad_side, gru_stepwise; };
 static const EnvFlags& env_flags() {
   static const EnvFlags f = {getenv("SCORE_HEAD_UNFUSED") != nullptr, getenv("SCORE_ATTN_TAIL_UNFUSED") != nullptr,
-                             getenv("SCORE_WGRAD_SIDE") != nullptr};
+                             getenv("SCORE_WGRAD_SIDE") != nullptr, getenv("SCORE_GRU_STEPWISE") != nullptr};
   return f;
 }
 #define HIPTRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return (int)e_; } while (0)
@@ -485,7 +489,7 @@ extern "C" int score_forward(const score_config_t* cfg, const score_state_t* st,
     GruArgs ga;
     memset(&ga, 0, sizeof(ga));
     ga.B = B; ga.T = T; ga.H = H; ga.length = bt->length; ga.nw8 = 1;
-    ga.tmp = ws + w.gru_tmp; ga.tmp_floats = 10 * (int64_t)B * H; ga.x3 = x3 != 0;   // H = 128: two waves per SIMD hide the LDS/epilogue latency (measured -0.08 ms/step)
+    ga.tmp = ws + w.gru_tmp; ga.tmp_floats = w.gru_tmp_floats; ga.x3 = x3 != 0; ga.stepwise = env_flags().gru_stepwise || (st->debug_flags & 1);   // H = 128: two waves per SIMD hide the LDS/epilogue latency (measured -0.08 ms/step)
     HIPTRY(hipStreamWaitEvent(s, wx_ev, 0));
     if (d.Is[0] == d.Is[1]) {    // both sides' projections in ONE grouped launch (each with its own bias row)
       const float* c0 = ws + w.wxcat;
@@ -705,7 +709,7 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
     GruArgs ga;
     memset(&ga, 0, sizeof(ga));
     ga.B = B; ga.T = T; ga.H = H; ga.length = bt->length; ga.nw8 = 1;
-    ga.tmp = ws + w.gru_tmp; ga.tmp_floats = 10 * (int64_t)B * H; ga.x3 = x3 != 0;   // H = 128: two waves per SIMD hide the LDS/epilogue latency (measured -0.08 ms/step)
+    ga.tmp = ws + w.gru_tmp; ga.tmp_floats = w.gru_tmp_floats; ga.x3 = x3 != 0; ga.stepwise = env_flags().gru_stepwise || (st->debug_flags & 1);   // H = 128: two waves per SIMD hide the LDS/epilogue latency (measured -0.08 ms/step)
     for (int sd = 0; sd < 2; ++sd) {
       GruSide& g = ga.s[sd];
       g.Wg = W + P.gk[sd] + (int64_t)d.Is[sd] * 2 * H; g.ldwg = 2 * H;

@@ -805,7 +805,9 @@ int score_gru_fwd_multi(GruArgs& a, int nsides, hipStream_t s) {
     SCORE_CHECK_LAUNCH();
     return 0;
   }
-  if (a.tmp && (nsides == 1 || (a.s[0].ldwg == a.s[1].ldwg && a.s[0].ldwc == a.s[1].ldwc)))
+  if (!a.stepwise && score_gru_stream_ok(H) && a.tmp && a.tmp_floats >= score_gru_stream_tmp_floats(H, nsides))
+    return score_gru_fwd_stream(a, nsides, s);
+  if (a.tmp && a.tmp_floats >= 10 * (int64_t)a.B * H && (nsides == 1 || (a.s[0].ldwg == a.s[1].ldwg && a.s[0].ldwc == a.s[1].ldwc)))
     return gru_fwd_steps(a, nsides, s);
   for (int i = 0; i < nsides; ++i) {
     const GruSide& sd = a.s[i];
@@ -834,7 +836,9 @@ int score_gru_bwd_multi(GruArgs& a, int nsides, hipStream_t s) {
     SCORE_CHECK_LAUNCH();
     return 0;
   }
-  if (a.tmp && (nsides == 1 || (a.s[0].ldwg == a.s[1].ldwg && a.s[0].ldwc == a.s[1].ldwc)))
+  if (!a.stepwise && score_gru_stream_ok(H) && a.tmp && a.tmp_floats >= score_gru_stream_tmp_floats(H, nsides))
+    return score_gru_bwd_stream(a, nsides, s);
+  if (a.tmp && a.tmp_floats >= 10 * (int64_t)a.B * H && (nsides == 1 || (a.s[0].ldwg == a.s[1].ldwg && a.s[0].ldwc == a.s[1].ldwc)))
     return gru_bwd_steps(a, nsides, s);
   for (int i = 0; i < nsides; ++i) {
     const GruSide& sd = a.s[i];

@@ -159,13 +159,19 @@ struct GruArgs {
   const int32_t* length;
   int B, T, H;
   int nw8;      // H = 128: 8 waves per workgroup (2 per SIMD) instead of 4
-  // hidden sizes without a register-resident kernel: the recurrence runs step by step (two grouped GEMMs +
-  // two pointwise launches per time slice) when this scratch is given (10 * B * H floats), x3 = bf16x3 allowed
-  float* tmp; int64_t tmp_floats; int x3;
+  // hidden sizes without a register-resident kernel: H = 256 streams its weights from L2 (gru_stream.hip; scratch
+  // = score_gru_stream_tmp_floats); others run the recurrence step by step (two grouped GEMMs + two pointwise
+  // launches per time slice; scratch 10 * B * H floats), x3 = bf16x3 allowed there.  stepwise != 0 forces that path (A/B)
+  float* tmp; int64_t tmp_floats; int x3; int stepwise;
 };
 // nprob same-shape GEMMs C_i = op(A_i) op(B_i) in one launch (the two sides of a recurrence step); flags: 4 = C += .
 int score_gemm_same_shape(int trans, int nprob, int M, int N, int K, const float* const* A, int lda,
                           const float* const* B, int ldb, float* const* C, int ldc, int flags, int x3, float* scratch,
                           int64_t scratch_floats, hipStream_t s, const float* const* bias = nullptr);   // flags: 1 = + bias[i][N]
+// gru_stream.hip: H = 256 (weights streamed from L2 in MFMA fragment order; tmp holds the fragment copies)
+bool score_gru_stream_ok(int H);
+int64_t score_gru_stream_tmp_floats(int H, int nsides);
+int score_gru_fwd_stream(GruArgs& a, int nsides, hipStream_t s);
+int score_gru_bwd_stream(GruArgs& a, int nsides, hipStream_t s);
 int score_gru_fwd_multi(GruArgs& a, int nsides, hipStream_t s);
 int score_gru_bwd_multi(GruArgs& a, int nsides, hipStream_t s);

@@ -262,7 +262,7 @@ class HipBackend(object):
         m = self.m
         lay, ws = plan["lay"], plan["ws"]
         return lay, ws, _lib.State(_ptr(mini), mini.shape[0], _ptr(m.w), _ptr(ws), ws.numel() * 4, 2,
-                                   int(m.global_batch), int(m.gemm_mode), 0, None, None, None, m._ctx)
+                                   int(m.global_batch), int(m.gemm_mode), int(m.debug_flags), None, None, None, m._ctx)
 
     def forward(self, plan, mini, reg_lambda, keep_prob, masks):
         m = self.m

@@ -115,6 +115,7 @@ class SCOREBASE(object):
         self.global_batch = 0      # >0: the loss mean runs over this many samples (data parallel)
         self._side = None
         self.skip_masked_slices = True   # batches carry active_slices = max(length): slices every sample masks are skipped
+        self.debug_flags = 0       # score_state_t.debug_flags (A/B switches; bit 0: step-by-step H = 256 recurrence)
         self.gemm_mode = 1         # 1: bf16x3 split (fp32-accurate) on the shapes where it measured faster, 0: f32 MFMA only
         self._init_params(seed)
 
@@ -268,7 +269,7 @@ class SCOREBASE(object):
 
     def _state(self, ws):
         return _lib.State(_ptr(self.table), self.table.shape[0], _ptr(self.w), _ptr(ws), ws.numel() * 4,
-                          int(self.scatter_mode), int(self.global_batch), int(self.gemm_mode), 0,
+                          int(self.scatter_mode), int(self.global_batch), int(self.gemm_mode), int(self.debug_flags),
                           _ptr(self.table_flags) if self.scatter_mode == 0 else None, None, None, self._ctx)
 
     @staticmethod

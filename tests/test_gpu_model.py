@@ -324,3 +324,38 @@ def test_scatter_modes_agree_and_pull_is_deterministic():
     assert float((g0 - g1).abs().max()) <= 2e-5 * scale
     assert torch.equal((g0 != 0).any(dim=1), (g1 != 0).any(dim=1))
     assert float(g0[0].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("B,T,ragged", [(64, 7, False), (50, 5, True), (33, 3, True), (256, 12, True)])
+def test_streaming_recurrence_h256(B, T, ragged):
+    # H = 256 (cfg-5): persistent kernel with the recurrent weights streamed from L2 in MFMA fragment order
+    # (gru_stream.hip) -- against the oracle AND against the step-by-step form (debug_flags bit 0), whole and
+    # partial 32-row tiles, ragged lengths
+    cfg = so.Cfg(2000, 8, 256, T, 3, 3, 4, "SCORE")
+    rng = np.random.default_rng(B)
+    P = so.init_params(cfg, 12)
+    b = random_batch(rng, cfg, B)
+    b["length"] = (rng.integers(1, T + 1, B) if ragged else np.full(B, T)).astype(np.int32)
+    m = make_model(cfg, P)
+    ms = make_model(cfg, P)
+    ms.debug_flags = 1
+    om = so.OracleModel(cfg.N, cfg.D, cfg.H, cfg.T, cfg.K, cfg.Fu, cfg.Fi, "SCORE", params={k: v.copy() for k, v in P.items()})
+    pg, _, lg = m.eval(None, batch_tuple(b), 1e-4)
+    ps, _, ls = ms.eval(None, batch_tuple(b), 1e-4)
+    po, _, lo = om.eval(None, batch_tuple(b), 1e-4)
+    assert np.abs(np.asarray(pg) - np.asarray(po)).max() < LOGIT_TOL and abs(lg - lo) < 1e-5 * max(1.0, abs(lo))
+    assert np.abs(np.asarray(pg) - np.asarray(ps)).max() < 2e-6
+    m.forward_backward(batch_tuple(b), 1e-4, 1.0)
+    ms.forward_backward(batch_tuple(b), 1e-4, 1.0)
+    g1, g2 = m.get_grads(), ms.get_grads()
+    _, go = so.loss_and_grads(cfg, P, b, 0.0)
+    for k in g1:
+        ok, err = close(g1[k], g2[k], rtol=2e-5, atol=1e-9)
+        assert ok, (k, err)
+        if np.abs(go[k]).max() > 1e-7:
+            ok, err = close(g1[k], go[k], rtol=2e-4, atol=1e-9)
+            assert ok, (k, err)
+    for _ in range(2):
+        l_g = m.train(None, batch_tuple(b), 1e-3, 1e-4, keep_prob=1.0)
+        l_o = om.train(None, batch_tuple(b), 1e-3, 1e-4, keep_prob=1.0)
+        assert abs(l_g - l_o) < 2e-5 * max(1.0, abs(l_o))
