@@ -1,6 +1,7 @@
 // Pointwise / small-reduction kernels of the temporal attention (score.py:169-186),
 // pooled states (:214-215), build_fc_net (:68-76), build_logloss / build_l2norm
 // (:78-94) and ApplyAdam (:96-99).  All HBM- or latency-bound; GEMMs live in gemm.hip.
+#include <stdlib.h>
 #include "common.h"
 #include "kernels.h"
 
@@ -612,28 +613,66 @@ __global__ void adam_kernel(float* __restrict__ p, float* __restrict__ m, float*
 }
 
 // One group of D/4 lanes per table row; the state byte decides what the row costs (see score_hip.h).
+// Two rows per group and trip: both state bytes, then both rows' streams are requested before anything is consumed
+// (one row per trip left two dependent round trips per 48 bytes of a lane's traffic in flight).
+#ifndef ADAM_NT
+#define ADAM_NT 0
+#endif
+__device__ __forceinline__ float4 adam_ld(const float* p) {
+#if ADAM_NT
+  const score_v4f t = __builtin_nontemporal_load(reinterpret_cast<const score_v4f*>(p));
+  return make_float4(t.x, t.y, t.z, t.w);
+#else
+  return ld4(p);
+#endif
+}
+__device__ __forceinline__ void adam_st(float* p, const float4& v) {
+#if ADAM_NT
+  score_v4f t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+  __builtin_nontemporal_store(t, reinterpret_cast<score_v4f*>(p));
+#else
+  st4(p, v);
+#endif
+}
 __global__ __launch_bounds__(256) void adam_rows_kernel(float* __restrict__ p, float* __restrict__ m,
                                                         float* __restrict__ v, const float* __restrict__ g,
                                                         int64_t n_rows, int D, int LPR, uint8_t* __restrict__ flags,
                                                         float alpha, float omb1, float omb2, float eps) {
   const int gpb = blockDim.x / LPR;
   const int ch4 = (threadIdx.x % LPR) * 4;
-  int64_t row = (int64_t)blockIdx.x * gpb + threadIdx.x / LPR;
   const int64_t stride = (int64_t)gridDim.x * gpb;
-  for (; row < n_rows; row += stride) {
-    const uint8_t f = flags[row];
-    if (f == 0 || ch4 >= D) continue;
-    const int64_t e = row * D + ch4;
-    float4 pp = ld4(p + e), mm = ld4(m + e), vv = ld4(v + e);
-    float4 gg = f == 2 ? ld4(g + e) : make_float4(0.f, 0.f, 0.f, 0.f);
-    adam1(pp.x, mm.x, vv.x, gg.x, omb1, omb2, alpha, eps);
-    adam1(pp.y, mm.y, vv.y, gg.y, omb1, omb2, alpha, eps);
-    adam1(pp.z, mm.z, vv.z, gg.z, omb1, omb2, alpha, eps);
-    adam1(pp.w, mm.w, vv.w, gg.w, omb1, omb2, alpha, eps);
-    st4(p + e, pp); st4(m + e, mm); st4(v + e, vv);
-    // (every lane of the group read the byte above; a group is inside one wave, so the store below
-    //  cannot overtake a sibling lane's load)
-    if (f == 2 && ch4 == 0) flags[row] = 1;
+  int64_t row0 = (int64_t)blockIdx.x * gpb + threadIdx.x / LPR;
+  if (ch4 >= D) return;
+  for (; row0 < n_rows; row0 += 2 * stride) {
+    const int64_t row1 = row0 + stride;
+    const bool has1 = row1 < n_rows;
+    const uint8_t f0 = flags[row0];
+    const uint8_t f1 = has1 ? flags[row1] : (uint8_t)0;
+    const int64_t e0 = row0 * D + ch4, e1 = (has1 ? row1 : row0) * D + ch4;
+    float4 p0, m0, v0, g0, p1, m1, v1, g1;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (f0) { p0 = adam_ld(p + e0); m0 = adam_ld(m + e0); v0 = adam_ld(v + e0); }
+    if (f1) { p1 = adam_ld(p + e1); m1 = adam_ld(m + e1); v1 = adam_ld(v + e1); }
+    g0 = f0 == 2 ? adam_ld(g + e0) : z;
+    g1 = f1 == 2 ? adam_ld(g + e1) : z;
+    if (f0) {
+      adam1(p0.x, m0.x, v0.x, g0.x, omb1, omb2, alpha, eps);
+      adam1(p0.y, m0.y, v0.y, g0.y, omb1, omb2, alpha, eps);
+      adam1(p0.z, m0.z, v0.z, g0.z, omb1, omb2, alpha, eps);
+      adam1(p0.w, m0.w, v0.w, g0.w, omb1, omb2, alpha, eps);
+      adam_st(p + e0, p0); adam_st(m + e0, m0); adam_st(v + e0, v0);
+      // (every lane of the group read the byte above; a group is inside one wave, so the store below
+      //  cannot overtake a sibling lane's load)
+      if (f0 == 2 && ch4 == 0) flags[row0] = 1;
+    }
+    if (f1) {
+      adam1(p1.x, m1.x, v1.x, g1.x, omb1, omb2, alpha, eps);
+      adam1(p1.y, m1.y, v1.y, g1.y, omb1, omb2, alpha, eps);
+      adam1(p1.z, m1.z, v1.z, g1.z, omb1, omb2, alpha, eps);
+      adam1(p1.w, m1.w, v1.w, g1.w, omb1, omb2, alpha, eps);
+      adam_st(p + e1, p1); adam_st(m + e1, m1); adam_st(v + e1, v1);
+      if (f1 == 2 && ch4 == 0) flags[row1] = 1;
+    }
   }
 }
 
@@ -649,6 +688,7 @@ extern "C" int score_adam_rows(float* p, float* m, float* v, const float* g, int
   const int gpb = 256 / LPR;
   int64_t want = cdiv64(n_rows, gpb);
   int blocks = (int)(want < 16384 ? want : 16384);
+  { static const char* e_ = getenv("SCORE_ADAM_BLOCKS"); if (e_ && atoi(e_) > 0 && atoi(e_) < blocks) blocks = atoi(e_); }   // EXPERIMENT
   hipLaunchKernelGGL(adam_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, m, v, g, n_rows, D, LPR,
                      row_flags, alpha, 1.0f - beta1, 1.0f - beta2, eps);
   SCORE_CHECK_LAUNCH();

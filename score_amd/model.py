@@ -97,7 +97,12 @@ class SCOREBASE(object):
         self.entries, self.n_w, self.n_reg = _lib.param_layout(self.cfg)
         N, D = int(feature_size), int(eb_dim)
         f32 = dict(dtype=torch.float32, device=self.device)
-        self.table = torch.empty((self._table_rows(N), D), **f32)
+        # emb_mtx, its two Adam slots and its gradient: ONE allocation, four [rows, D] views.  The dense optimizer sweep
+        # streams all four together; carved from one block it measured 5-8 % faster than from four separate
+        # allocations (tools/adam_layout_probe.py: 0.44-0.47 vs 0.47-0.51 ms at cfg-3)
+        rows = self._table_rows(N)
+        self._table_block = torch.empty((4, rows, D), **f32)
+        self.table = self._table_block[0]
         self.w = torch.zeros((self.n_w,), **f32)
         self._alloc_optimizer()
         self._ws = {}              # (B, slot) -> (layout, buffer), least recently used first
@@ -134,9 +139,8 @@ class SCOREBASE(object):
     # ------------------------------------------------------------------ parameters
     def _alloc_optimizer(self):
         f32 = dict(dtype=torch.float32, device=self.device)
-        self.table_m = torch.zeros_like(self.table)
-        self.table_v = torch.zeros_like(self.table)
-        self.table_g = torch.zeros_like(self.table)
+        self.table_m, self.table_v, self.table_g = self._table_block[1], self._table_block[2], self._table_block[3]
+        self._table_block[1:].zero_()
         # per-row optimizer state byte (score_adam_rows): 0 = moments zero, 1 = live, 2 = gradient this step
         self.table_flags = torch.zeros((self.table.shape[0],), dtype=torch.uint8, device=self.device)
         self._row_grads = False      # table_g holds valid rows only where table_flags == 2
