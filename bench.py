@@ -201,6 +201,9 @@ def main():
     ap.add_argument("--no-skip-masked", action="store_true",
                     help="gather and compute all T time slices, also those past every sample's length (whose "
                          "results the model masks): A/B for score_batch_t.active_slices")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the step as one captured hipGraph (SCOREBASE.enable_graph: launch-bound small shapes); "
+                         "the timed loop then carries no stage events -- stages_ms come from a few eager steps after it")
     ap.add_argument("--gather-probe-only", action="store_true",
                     help="run only the low-duplication gather probe (for rocprofv3 --pmc passes) and print its JSON")
     ap.add_argument("--probe-rows", type=int, default=32_000_000)
@@ -269,8 +272,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    graph = args.graph and not sharded
+    if graph:
+        model.enable_graph(True)
+    last_loss = [None]
+
     def run_steps(n, first=0, events=None):
         fb = None
+        if graph and events is None:
+            for i in range(first, first + n):
+                last_loss[0] = model.train_async(batches[i % len(batches)], args.lr, args.reg_lambda)
+            return None
         for i in range(first, first + n):
             e_a0 = e_a1 = None
             if events is not None and i in events:
@@ -305,9 +317,16 @@ def main():
                      torch.cuda.Event(enable_timing=True))
     barrier()
     t0 = time.perf_counter()
-    fb = run_steps(args.steps, 0, events)
+    fb = run_steps(args.steps, 0, None if graph else events)
     barrier()
     dt = time.perf_counter() - t0
+    if graph:                      # stage timings from eager steps, outside the timed region
+        model.enable_graph(False)
+        graph = False
+        fb = run_steps(4 * every, 0, {k: v for k, v in events.items() if k < 4 * every})
+        events = {k: v for k, v in events.items() if k < 4 * every}
+        torch.cuda.synchronize()
+        graph = True
     model.enable_stage_events(False)
     if dist is not None:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
@@ -467,6 +486,8 @@ def main():
         "data": "synthetic",
         "parity": "partial: the CPU oracle the tests check against restates a TF-1.x graph; the reference ships no golden "
                   "vectors and TensorFlow cannot run here, so the oracle itself is unpinned (DESIGN.md section 2)",
+        "launch": ("one captured hipGraph per step (SCOREBASE.enable_graph); stages_ms from eager steps outside the timed loop"
+                   if args.graph else "eager launches"),
         "config": {"workload": "%s: SCORE full train step (fwd + bwd + dense TF-Adam), N=%d rows, T=%d, K=%d, "
                                "D=%d, H=%d, Fu=%d, Fi=%d, per-GPU batch %d (global %d), keep_prob 0.8, "
                                "%d distinct pre-staged batches, length=%d for every sample (slices >= length are "

@@ -42,6 +42,16 @@ int score_context_create(score_context_t* ctx);
 /* ctx == NULL: release the process-wide default contexts.  Synchronises the context's stream first. */
 int score_context_destroy(score_context_t ctx);
 
+/* The scalars of a training step that change from step to step, kept in DEVICE memory so that a captured step
+ * (hipGraph: small shapes are launch-bound, ~60 launches of a few microseconds each) can be replayed with new
+ * values: ApplyAdam's alpha = lr * sqrt(1 - beta2^t) / (1 - beta1^t) (score.py:96-99) and the seed of the
+ * step's dropout masks (score.py:71,73).  The caller rewrites them (one 16-byte copy) before every step. */
+typedef struct {
+  float    adam_alpha;
+  uint32_t reserved;
+  uint64_t drop_seed;
+} score_step_scalars_t;
+
 /* model_type values (train_score.py:170-179 selects the class by name) */
 enum { SCORE_MODEL_SCORE = 0, SCORE_MODEL_RIA = 1, SCORE_MODEL_RCA = 2,
        SCORE_MODEL_SCORE_USER = 3, SCORE_MODEL_SCORE_ITEM = 4,
@@ -204,6 +214,12 @@ int score_gru_bwd(int32_t B, int32_t T, int32_t H, const float* Wg, int32_t ldwg
 int score_adam(float* p, float* m, float* v, const float* g, int64_t n, int64_t n_reg,
                float l2, float alpha, float beta1, float beta2, float eps, void* stream);
 
+/* score_adam / score_adam_rows with alpha read from device memory (sc->adam_alpha) at execution time. */
+int score_adam_dev(float* p, float* m, float* v, const float* g, int64_t n, int64_t n_reg, float l2,
+                   const score_step_scalars_t* sc, float beta1, float beta2, float eps, void* stream);
+int score_adam_rows_dev(float* p, float* m, float* v, const float* g, int64_t n_rows, int32_t D, uint8_t* row_flags,
+                        const score_step_scalars_t* sc, float beta1, float beta2, float eps, void* stream);
+
 /* The same update over the [n_rows, D] embedding table, driven by a per-row state byte so the
  * dense sweep only moves the rows dense ApplyAdam actually changes (bit-identical result):
  *   0  m = v = 0 and no gradient this step  -> ApplyAdam is the identity: nothing is read
@@ -245,6 +261,9 @@ typedef struct {
   void* plan_done_event;   /* optional hipEvent_t (recorded by the caller after score_index_plan on its own
                            stream): score_backward waits for it just before the row scatter, the first
                            consumer of the plan -- not at its start                                   */
+  const score_step_scalars_t* step_scalars; /* optional DEVICE pointer: score_forward then takes the dropout seed from it
+                           (its by-value drop_seed argument is ignored; shapes the fused head kernel does not cover
+                           return SCORE_E_SHAPE when keep_prob < 1), so the launch sequence holds no per-step value */
   score_context_t context; /* side stream + events of this caller (score_context_create); NULL = the
                            process-wide default context of the current device                         */
 } score_state_t;

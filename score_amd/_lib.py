@@ -44,7 +44,8 @@ class State(C.Structure):
     _fields_ = [("table", c_f), ("n_table_rows", C.c_int64), ("w", c_f), ("workspace", c_f),
                 ("workspace_bytes", C.c_int64), ("scatter_mode", C.c_int32), ("global_batch", C.c_int32),
                 ("gemm_mode", C.c_int32), ("debug_flags", C.c_int32), ("row_flags", C.c_void_p),
-                ("gather_done_event", C.c_void_p), ("plan_done_event", C.c_void_p), ("context", C.c_void_p)]
+                ("gather_done_event", C.c_void_p), ("plan_done_event", C.c_void_p), ("step_scalars", C.c_void_p),
+                ("context", C.c_void_p)]
 
 
 class Graph(C.Structure):
@@ -82,6 +83,10 @@ _SIGS = {
                       c_f, C.c_int32, c_f, c_f, c_f, c_f, C.c_void_p],
     "score_adam": [c_f, c_f, c_f, c_f, C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,
                    C.c_float, C.c_void_p],
+    "score_adam_dev": [c_f, c_f, c_f, c_f, C.c_int64, C.c_int64, C.c_float, C.c_void_p, C.c_float, C.c_float, C.c_float,
+                       C.c_void_p],
+    "score_adam_rows_dev": [c_f, c_f, c_f, c_f, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_float, C.c_float,
+                            C.c_float, C.c_void_p],
     "score_adam_rows": [c_f, c_f, c_f, c_f, C.c_int64, C.c_int32, C.c_void_p, C.c_float, C.c_float, C.c_float,
                         C.c_float, C.c_void_p],
     "score_index_plan": [C.POINTER(Config), C.POINTER(State), C.POINTER(Batch), C.c_int32, C.c_int32, C.c_void_p],

@@ -553,10 +553,12 @@ extern "C" int score_forward(const score_config_t* cfg, const score_state_t* st,
                                               W + P.fc_b[0], W + P.fc_w[1], W + P.fc_b[1], W + P.fc_w[2], W + P.fc_b[2],
                                               keep_prob, drop_mask0, drop_mask1, drop_seed, drop_seed ^ 0x5DEECE66Dull,
                                               bt->label, ws + w.bn, ws + w.f1, ws + w.f2, ws + w.logit, ws + w.y_pred,
-                                              ws + w.lossb, ws + w.dlogit, Bg, s);
+                                              ws + w.lossb, ws + w.dlogit, Bg, s,
+                                              st->step_scalars ? &st->step_scalars->drop_seed : nullptr);
   if (hrc == 0) {
     G(score_launch_loss_final(B, ws + w.lossb, ws + w.loss, reg_lambda, ws + w.part, Bg, s));
   } else if (hrc == SCORE_E_SHAPE) {
+    if (st->step_scalars && keep_prob < 1.f) return SCORE_E_SHAPE;   // the layer-by-layer path takes its seed by value
     G(score_launch_bn_fwd(B, d.Dhead, ws + w.head_inp, W + P.bn_g, W + P.bn_b, rs, ws + w.bn, s));
     G(gemm_mode_call(x3, 0, B, FC1, d.Dhead, ws + w.bn, d.Dhead, W + P.fc_w[0], FC1, ws + w.f1, FC1, W + P.fc_b[0],
                  GF_BIAS | GF_RELU | dflag, keep_prob, drop_mask0, drop_seed, scratch, w.scratch_floats, s));

@@ -578,7 +578,8 @@ __device__ __forceinline__ void adam1(float& p, float& m, float& v, float g, flo
 }
 __global__ void adam_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
                             const float* __restrict__ g, int64_t n4, int64_t n, int64_t n_reg, float l2, float alpha,
-                            float omb1, float omb2, float eps) {
+                            float omb1, float omb2, float eps, const float* __restrict__ alpha_dev) {
+  if (alpha_dev) alpha = *alpha_dev;          // score_step_scalars_t.adam_alpha (captured steps)
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (; i < n4; i += stride) {
@@ -637,7 +638,9 @@ __device__ __forceinline__ void adam_st(float* p, const float4& v) {
 __global__ __launch_bounds__(256) void adam_rows_kernel(float* __restrict__ p, float* __restrict__ m,
                                                         float* __restrict__ v, const float* __restrict__ g,
                                                         int64_t n_rows, int D, int LPR, uint8_t* __restrict__ flags,
-                                                        float alpha, float omb1, float omb2, float eps) {
+                                                        float alpha, float omb1, float omb2, float eps,
+                                                        const float* __restrict__ alpha_dev) {
+  if (alpha_dev) alpha = *alpha_dev;
   const int gpb = blockDim.x / LPR;
   const int ch4 = (threadIdx.x % LPR) * 4;
   const int64_t stride = (int64_t)gridDim.x * gpb;
@@ -676,8 +679,9 @@ __global__ __launch_bounds__(256) void adam_rows_kernel(float* __restrict__ p, f
   }
 }
 
-extern "C" int score_adam_rows(float* p, float* m, float* v, const float* g, int64_t n_rows, int32_t D,
-                               uint8_t* row_flags, float alpha, float beta1, float beta2, float eps, void* stream) {
+static int adam_rows_impl(float* p, float* m, float* v, const float* g, int64_t n_rows, int32_t D,
+                          uint8_t* row_flags, float alpha, const float* alpha_dev, float beta1, float beta2, float eps,
+                          void* stream) {
   if (!p || !m || !v || !g || !row_flags || n_rows <= 0 || D <= 0) return SCORE_E_BADARG;
   if ((D & 3) || D > 256) return SCORE_E_SHAPE;
   if ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v) |
@@ -690,13 +694,23 @@ extern "C" int score_adam_rows(float* p, float* m, float* v, const float* g, int
   int blocks = (int)(want < 16384 ? want : 16384);
   { static const char* e_ = getenv("SCORE_ADAM_BLOCKS"); if (e_ && atoi(e_) > 0 && atoi(e_) < blocks) blocks = atoi(e_); }   // EXPERIMENT
   hipLaunchKernelGGL(adam_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, m, v, g, n_rows, D, LPR,
-                     row_flags, alpha, 1.0f - beta1, 1.0f - beta2, eps);
+                     row_flags, alpha, 1.0f - beta1, 1.0f - beta2, eps, alpha_dev);
   SCORE_CHECK_LAUNCH();
   return 0;
 }
+extern "C" int score_adam_rows(float* p, float* m, float* v, const float* g, int64_t n_rows, int32_t D,
+                               uint8_t* row_flags, float alpha, float beta1, float beta2, float eps, void* stream) {
+  return adam_rows_impl(p, m, v, g, n_rows, D, row_flags, alpha, nullptr, beta1, beta2, eps, stream);
+}
+extern "C" int score_adam_rows_dev(float* p, float* m, float* v, const float* g, int64_t n_rows, int32_t D,
+                                   uint8_t* row_flags, const score_step_scalars_t* sc, float beta1, float beta2,
+                                   float eps, void* stream) {
+  if (!sc) return SCORE_E_BADARG;
+  return adam_rows_impl(p, m, v, g, n_rows, D, row_flags, 0.f, &sc->adam_alpha, beta1, beta2, eps, stream);
+}
 
-extern "C" int score_adam(float* p, float* m, float* v, const float* g, int64_t n, int64_t n_reg, float l2,
-                          float alpha, float beta1, float beta2, float eps, void* stream) {
+static int adam_impl(float* p, float* m, float* v, const float* g, int64_t n, int64_t n_reg, float l2,
+                     float alpha, const float* alpha_dev, float beta1, float beta2, float eps, void* stream) {
   if (!p || !m || !v || !g || n <= 0) return SCORE_E_BADARG;
   if ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v) |
        reinterpret_cast<uintptr_t>(g)) & 15)
@@ -705,9 +719,18 @@ extern "C" int score_adam(float* p, float* m, float* v, const float* g, int64_t 
   int64_t want = cdiv64(n4 > 0 ? n4 : 1, 256);
   int blocks = (int)(want < 8192 ? want : 8192);
   hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, m, v, g, n4, n, n_reg, l2,
-                     alpha, 1.0f - beta1, 1.0f - beta2, eps);
+                     alpha, 1.0f - beta1, 1.0f - beta2, eps, alpha_dev);
   SCORE_CHECK_LAUNCH();
   return 0;
+}
+extern "C" int score_adam(float* p, float* m, float* v, const float* g, int64_t n, int64_t n_reg, float l2,
+                          float alpha, float beta1, float beta2, float eps, void* stream) {
+  return adam_impl(p, m, v, g, n, n_reg, l2, alpha, nullptr, beta1, beta2, eps, stream);
+}
+extern "C" int score_adam_dev(float* p, float* m, float* v, const float* g, int64_t n, int64_t n_reg, float l2,
+                              const score_step_scalars_t* sc, float beta1, float beta2, float eps, void* stream) {
+  if (!sc) return SCORE_E_BADARG;
+  return adam_impl(p, m, v, g, n, n_reg, l2, 0.f, &sc->adam_alpha, beta1, beta2, eps, stream);
 }
 
 // ---------------------------------------------------------------- table initialiser (score.py:44)

@@ -80,6 +80,7 @@ struct HeadFwdArgs {
   const float* x; const float* gamma; const float* beta; float rs;
   const float* W1; const float* b1; const float* W2; const float* b2; const float* W3; const float* b3;
   float keep; int drop; const uint8_t* mask0; const uint8_t* mask1; uint64_t seed0, seed1;
+  const uint64_t* seed_dev;       // score_step_scalars_t.drop_seed (captured steps): overrides seed0 / seed1
   const int32_t* label;
   float* bn; float* f1; float* f2; float* logit; float* y; float* lossb; float* dlogit;
 };
@@ -97,6 +98,8 @@ __device__ __forceinline__ float hf_act(float v, float bias, int drop, float kee
 
 __global__ __launch_bounds__(64 * HF_NW) void head_fwd_fused_kernel(const HeadFwdArgs a) {
   extern __shared__ float sm[];
+  const uint64_t seed0 = a.seed_dev ? *a.seed_dev : a.seed0;
+  const uint64_t seed1 = a.seed_dev ? (seed0 ^ 0x5DEECE66Dull) : a.seed1;
   const int Dh = a.Dh, N1 = a.N1, N2 = a.N2;
   const int Kp0 = (Dh + 15) & ~15, LD0 = Kp0 + 4;
   const int Kp1 = (N1 + 15) & ~15, LD1 = Kp1 + 4;
@@ -167,7 +170,7 @@ __global__ __launch_bounds__(64 * HF_NW) void head_fwd_fused_kernel(const HeadFw
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = lq * 4 + r, row = b0 + i;
-        const float v = hf_act(acc[t][r], bias, a.drop, a.keep, a.mask0, a.seed0, row, col, N1);
+        const float v = hf_act(acc[t][r], bias, a.drop, a.keep, a.mask0, seed0, row, col, N1);
         f1s[i * LD1 + col] = v;
         if (row < a.B) a.f1[(int64_t)row * N1 + col] = v;
       }
@@ -188,7 +191,7 @@ __global__ __launch_bounds__(64 * HF_NW) void head_fwd_fused_kernel(const HeadFw
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = lq * 4 + r, row = b0 + i;
-        const float v = hf_act(acc[0][r], bias, a.drop, a.keep, a.mask1, a.seed1, row, col, N2);
+        const float v = hf_act(acc[0][r], bias, a.drop, a.keep, a.mask1, seed1, row, col, N2);
         f2s[i * LD2 + col] = v;
         if (row < a.B) a.f2[(int64_t)row * N2 + col] = v;
       }
@@ -225,7 +228,8 @@ int score_launch_head_fwd_fused(int B, int Dh, int N1, int N2, const float* x, c
                                 float rs, const float* W1, const float* b1, const float* W2, const float* b2,
                                 const float* W3, const float* b3, float keep, const uint8_t* mask0, const uint8_t* mask1,
                                 uint64_t seed0, uint64_t seed1, const int32_t* label, float* bn, float* f1, float* f2,
-                                float* logit, float* y, float* lossb, float* dlogit, int Bglobal, hipStream_t s) {
+                                float* logit, float* y, float* lossb, float* dlogit, int Bglobal, hipStream_t s,
+                                const uint64_t* seed_dev) {
   const int LD0 = ((Dh + 15) & ~15) + 4, LD1 = ((N1 + 15) & ~15) + 4, LD2 = ((N2 + 15) & ~15) + 4;
   const size_t lds = (size_t)HF_ROWS * (LD0 + LD1 + LD2) * sizeof(float);
   if (lds > 150 * 1024 || B <= 0) return SCORE_E_SHAPE;
@@ -240,7 +244,7 @@ int score_launch_head_fwd_fused(int B, int Dh, int N1, int N2, const float* x, c
   a.B = B; a.Dh = Dh; a.N1 = N1; a.N2 = N2; a.Bglobal = Bglobal;
   a.x = x; a.gamma = gamma; a.beta = beta; a.rs = rs;
   a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.W3 = W3; a.b3 = b3;
-  a.keep = keep; a.drop = keep < 1.f ? 1 : 0; a.mask0 = mask0; a.mask1 = mask1; a.seed0 = seed0; a.seed1 = seed1;
+  a.keep = keep; a.drop = keep < 1.f ? 1 : 0; a.mask0 = mask0; a.mask1 = mask1; a.seed0 = seed0; a.seed1 = seed1; a.seed_dev = seed_dev;
   a.label = label; a.bn = bn; a.f1 = f1; a.f2 = f2; a.logit = logit; a.y = y; a.lossb = lossb; a.dlogit = dlogit;
   hipLaunchKernelGGL(head_fwd_fused_kernel, dim3((B + HF_ROWS - 1) / HF_ROWS), dim3(64 * HF_NW), lds, s, a);
   SCORE_CHECK_LAUNCH();

@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .model import DeviceBatch, _ptr
+from .model import DeviceBatch, _ptr, carve_batch, flat_batch_size
 
 
 def _csr(lists_per_cell):
@@ -133,8 +133,12 @@ class TemporalGraph(object):
 
 
 class _AssembledBatch(DeviceBatch):
-    def __init__(self, tensors, B, active=0):   # bypass host conversion: tensors are already int32 on the device
+    """a batch assembled on the device (views of one flat buffer, like every DeviceBatch); indexable like the
+    reference's 8-tuple"""
+
+    def __init__(self, tensors, B, active=0, flat=None):
         self.tensors = tensors
+        self.flat = flat
         self.B = B
         self.active_slices = int(active)  # every sample has length pred_time - start_time (graph_loader.py:382)
         self.struct = _lib.Batch(*[_ptr(t) for t in tensors], B, self.active_slices)
@@ -188,11 +192,9 @@ class DeviceGraphLoader(object):
         n = min(self.lines_per_batch, self.n_lines - self._pos)      # the last batch is short (:321-324)
         c = 1 + self.neg
         B, g, T, K = n * c, self.g, self.T, self.K
-        i32 = dict(dtype=torch.int32, device=g.device)
-        tens = [torch.empty((B, T, K, g.Fi), **i32), torch.empty((B, T, K, g.Fu), **i32),
-                torch.empty((B, T, K, g.Fu), **i32), torch.empty((B, T, K, g.Fi), **i32),
-                torch.empty((B, g.Fu), **i32), torch.empty((B, g.Fi), **i32),
-                torch.empty((B,), **i32), torch.empty((B,), **i32)]
+        shapes = ((B, T, K, g.Fi), (B, T, K, g.Fu), (B, T, K, g.Fu), (B, T, K, g.Fi), (B, g.Fu), (B, g.Fi), (B,), (B,))
+        flat = torch.empty((flat_batch_size(shapes),), dtype=torch.int32, device=g.device)
+        tens = carve_batch(flat, shapes)
         out = _lib.BatchOut(*[_ptr(t) for t in tens])
         u = self.uids[self._pos:self._pos + n]
         it = self.iids[self._pos * c:(self._pos + n) * c]
@@ -203,4 +205,4 @@ class DeviceGraphLoader(object):
         self._pos += n
         self._batch_no += 1
         length = self.pred_time - self.start_time
-        return _AssembledBatch(tens, B, length if 0 < length < T else 0)
+        return _AssembledBatch(tens, B, length if 0 < length < T else 0, flat)

@@ -31,44 +31,84 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
+def batch_shapes(cfg, B):
+    T, K, Fu, Fi = cfg.max_time_len, cfg.obj_per_time_slice, cfg.user_fnum, cfg.item_fnum
+    return ((B, T, K, Fi), (B, T, K, Fu), (B, T, K, Fu), (B, T, K, Fi), (B, Fu), (B, Fi), (B,), (B,))
+
+
+def carve_batch(flat, shapes):
+    """the eight int32 tensors of a batch as views of one flat buffer (every tensor 16-B aligned)"""
+    out, off = [], 0
+    for sh in shapes:
+        n = int(np.prod(sh))
+        out.append(flat[off:off + n].view(*sh))
+        off += (n + 3) & ~3
+    return out
+
+
+def flat_batch_size(shapes):
+    return sum((int(np.prod(sh)) + 3) & ~3 for sh in shapes)
+
+
 class DeviceBatch(object):
-    """int32 device tensors of one batch + the C struct pointing at them."""
+    """int32 device tensors of one batch + the C struct pointing at them.  The eight tensors are views of ONE flat
+    allocation (`flat`): a host batch goes up in a single copy, and a captured step refreshes its static batch with
+    a single device-to-device copy."""
 
     def __init__(self, model, batch_data):
         if isinstance(batch_data, DeviceBatch):
             raise TypeError("already a DeviceBatch")
         if len(batch_data) != 8:
             raise ValueError("batch_data must be the 8-tuple of graph_loader.py:383")
-        c = model.cfg
-        T, K, Fu, Fi = c.max_time_len, c.obj_per_time_slice, c.user_fnum, c.item_fnum
-        self.tensors = []
         B = None
         max_len = None
-        shapes = ((T, K, Fi), (T, K, Fu), (T, K, Fu), (T, K, Fi), (Fu,), (Fi,), (), ())
+        parts, on_device = [], all(torch.is_tensor(x) for x in batch_data)
         for i, x in enumerate(batch_data):
             if torch.is_tensor(x):
-                t = x.to(device=model.device, dtype=torch.int32).contiguous()
+                a = x if on_device else x.cpu().numpy()
             else:
                 # nested lists hold ints, with float 0.0 in dummy slices (graph_loader.py:90-91)
                 a = np.asarray(x)
-                if a.dtype != np.int32:
-                    a = a.astype(np.int32)
-                t = torch.from_numpy(np.ascontiguousarray(a)).to(model.device, non_blocking=True)
-                if i == 7 and a.size:
-                    max_len = int(a.max())
+            if not torch.is_tensor(a) and a.dtype != np.int32:
+                a = a.astype(np.int32)
             if B is None:
-                B = t.shape[0]
-            if tuple(t.shape) != (B,) + shapes[i]:
+                B = int(a.shape[0]) if a.ndim else 0
+                shapes = batch_shapes(model.cfg, B)
+            if tuple(a.shape) != shapes[i]:
                 raise ValueError("batch_data[%d] (%s) has shape %s, expected %s" %
-                                 (i, BATCH_FIELDS[i], tuple(t.shape), (B,) + shapes[i]))
-            self.tensors.append(t)
+                                 (i, BATCH_FIELDS[i], tuple(a.shape), shapes[i]))
+            parts.append(a)
         if B == 0:
             raise ValueError("empty batch")
         self.B = B
-        if max_len is None:                  # `length` arrived as a device tensor: one read-back per batch object
-            max_len = int(self.tensors[7].max().item())
+        n_flat = flat_batch_size(shapes)
+        if on_device:
+            self.flat = torch.empty((n_flat,), dtype=torch.int32, device=model.device)
+            self.tensors = carve_batch(self.flat, shapes)
+            for dst, src in zip(self.tensors, parts):
+                dst.copy_(src)                              # (dtype / device conversion included)
+            max_len = int(self.tensors[7].max().item())     # one read-back per batch object
+        else:
+            host = np.zeros((n_flat,), dtype=np.int32)
+            for dst, src in zip(carve_batch(torch.from_numpy(host), shapes), parts):
+                dst.copy_(torch.from_numpy(np.ascontiguousarray(src)))
+            max_len = int(parts[7].max()) if parts[7].size else 0
+            self.flat = torch.from_numpy(host).to(model.device, non_blocking=True)
+            self.tensors = carve_batch(self.flat, shapes)
         self.active_slices = active_slices(model, max_len)
         self.struct = _lib.Batch(*[_ptr(t) for t in self.tensors], B, self.active_slices)
+
+    @classmethod
+    def empty(cls, model, B, active=0):
+        """uninitialised batch of B samples (a loader / a captured step fills it)"""
+        self = cls.__new__(cls)
+        shapes = batch_shapes(model.cfg, B)
+        self.flat = torch.empty((flat_batch_size(shapes),), dtype=torch.int32, device=model.device)
+        self.tensors = carve_batch(self.flat, shapes)
+        self.B = B
+        self.active_slices = int(active)
+        self.struct = _lib.Batch(*[_ptr(t) for t in self.tensors], B, self.active_slices)
+        return self
 
 
 def active_slices(model, max_len):
@@ -120,6 +160,11 @@ class SCOREBASE(object):
         self.global_batch = 0      # >0: the loss mean runs over this many samples (data parallel)
         self._side = None
         self.skip_masked_slices = True   # batches carry active_slices = max(length): slices every sample masks are skipped
+        # per-step scalars in device memory (score_step_scalars_t): what a captured step reads its alpha / dropout seed from
+        self._scalars = torch.zeros((4,), dtype=torch.int32, device=self.device)
+        self._scalars_host = torch.zeros((4,), dtype=torch.int32).pin_memory()
+        self._use_dev_scalars = False
+        self._graph_on, self._graphs = False, {}
         self.debug_flags = 0       # score_state_t.debug_flags (A/B switches; bit 0: step-by-step H = 256 recurrence)
         self.gemm_mode = 1         # 1: bf16x3 split (fp32-accurate) on the shapes where it measured faster, 0: f32 MFMA only
         self._init_params(seed)
@@ -274,7 +319,8 @@ class SCOREBASE(object):
     def _state(self, ws):
         return _lib.State(_ptr(self.table), self.table.shape[0], _ptr(self.w), _ptr(ws), ws.numel() * 4,
                           int(self.scatter_mode), int(self.global_batch), int(self.gemm_mode), int(self.debug_flags),
-                          _ptr(self.table_flags) if self.scatter_mode == 0 else None, None, None, self._ctx)
+                          _ptr(self.table_flags) if self.scatter_mode == 0 else None, None, None,
+                          _ptr(self._scalars) if self._use_dev_scalars else None, self._ctx)
 
     @staticmethod
     def _event_array(events):
@@ -388,9 +434,14 @@ class SCOREBASE(object):
         a = self._alpha(lr)
         s = self._stream()
         if self._row_grads:
-            rc = self.lib.score_adam_rows(_ptr(self.table), _ptr(self.table_m), _ptr(self.table_v),
-                                          _ptr(self.table_g), self.table.shape[0], self.table.shape[1],
-                                          _ptr(self.table_flags), a, ADAM_B1, ADAM_B2, ADAM_EPS, s)
+            if self._use_dev_scalars:
+                rc = self.lib.score_adam_rows_dev(_ptr(self.table), _ptr(self.table_m), _ptr(self.table_v),
+                                                  _ptr(self.table_g), self.table.shape[0], self.table.shape[1],
+                                                  _ptr(self.table_flags), _ptr(self._scalars), ADAM_B1, ADAM_B2, ADAM_EPS, s)
+            else:
+                rc = self.lib.score_adam_rows(_ptr(self.table), _ptr(self.table_m), _ptr(self.table_v),
+                                              _ptr(self.table_g), self.table.shape[0], self.table.shape[1],
+                                              _ptr(self.table_flags), a, ADAM_B1, ADAM_B2, ADAM_EPS, s)
             self._row_grads = False
             self._flags_marked = False
         else:
@@ -402,9 +453,14 @@ class SCOREBASE(object):
 
     def adam_dense(self, lr, reg_lambda):
         """ApplyAdam over the flat dense variables (L2 term folded in) on the current stream."""
-        rc = self.lib.score_adam(_ptr(self.w), _ptr(self.w_m), _ptr(self.w_v), _ptr(self.w_g), self.n_w,
-                                 self.n_reg, float(reg_lambda), self._alpha(lr), ADAM_B1, ADAM_B2, ADAM_EPS,
-                                 self._stream())
+        if self._use_dev_scalars:
+            rc = self.lib.score_adam_dev(_ptr(self.w), _ptr(self.w_m), _ptr(self.w_v), _ptr(self.w_g), self.n_w,
+                                         self.n_reg, float(reg_lambda), _ptr(self._scalars), ADAM_B1, ADAM_B2, ADAM_EPS,
+                                         self._stream())
+        else:
+            rc = self.lib.score_adam(_ptr(self.w), _ptr(self.w_m), _ptr(self.w_v), _ptr(self.w_g), self.n_w,
+                                     self.n_reg, float(reg_lambda), self._alpha(lr), ADAM_B1, ADAM_B2, ADAM_EPS,
+                                     self._stream())
         _lib.check(rc, "score_adam(dense)")
 
     def adam_advance(self):
@@ -415,9 +471,68 @@ class SCOREBASE(object):
 
     def train_async(self, batch_data, lr, reg_lambda, keep_prob=0.8, dropout_masks=None):
         """One training step; returns the loss as a 0-d device tensor (no host sync)."""
+        if self._graph_on and dropout_masks is None and self.scatter_mode == 0 and not self.fwd_events:
+            return self._train_captured(batch_data, lr, reg_lambda, keep_prob)
         lay, ws = self.forward_backward(batch_data, reg_lambda, keep_prob, dropout_masks)
         self.apply_adam(lr, reg_lambda)
         return ws[lay.loss]
+
+    # ------------------------------------------------------------------ captured step (hipGraph)
+    def enable_graph(self, on=True):
+        """Replay the training step as ONE captured hipGraph per (batch size, active slices, reg_lambda, keep_prob):
+        small shapes (the reference's own B = 100 / 200, D = 16, H = 32) are launch-bound -- ~60 launches of a few
+        microseconds of work each.  The first step of a shape runs eagerly, the second is captured, later ones are
+        replays of it: the batch is copied into the capture's static batch (one device-to-device copy), alpha and
+        the dropout seed are rewritten in device memory (score_step_scalars_t).  Same kernels, same arguments, same
+        order as the eager step: results are bit-identical (tests/test_gpu_graph.py)."""
+        self._graph_on = bool(on)
+        if not on:
+            self._graphs = {}
+            self._use_dev_scalars = False
+
+    def _write_step_scalars(self, lr):
+        h = self._scalars_host
+        h[0] = int(np.float32(self._alpha(lr)).view(np.int32))
+        seed = (self._drop_seed * 0x9E3779B1 + self.step * 0x85EBCA77) & 0xFFFFFFFFFFFFFFFF
+        lo, hi = seed & 0xFFFFFFFF, seed >> 32
+        h[1] = 0
+        h[2] = lo - (1 << 32) if lo >= (1 << 31) else lo
+        h[3] = hi - (1 << 32) if hi >= (1 << 31) else hi
+        self._scalars.copy_(h, non_blocking=True)
+
+    def _train_captured(self, batch_data, lr, reg_lambda, keep_prob):
+        db = self.device_batch(batch_data)
+        key = (db.B, db.active_slices, float(reg_lambda), float(keep_prob))
+        ent = self._graphs.get(key)
+        self._use_dev_scalars = True
+        try:
+            self._write_step_scalars(lr)
+            if ent is None or ent == "warm":
+                # eager (first: allocates the workspace, creates streams / events; second: settles the caching allocator)
+                lay, ws = self.forward_backward(db, reg_lambda, keep_prob, None)
+                self.apply_adam(lr, reg_lambda)
+                self._graphs[key] = "warm" if ent is None else "ready"
+                return ws[lay.loss]
+            if ent == "ready":
+                static = DeviceBatch.empty(self, db.B, db.active_slices)
+                static.flat.copy_(db.flat)
+                lay, ws = self._workspace(db.B)
+                torch.cuda.synchronize(self.device)
+                g = torch.cuda.CUDAGraph()
+                step, b1p, b2p = self.step, self.beta1_power, self.beta2_power
+                with torch.cuda.graph(g):
+                    self.forward_backward(static, reg_lambda, keep_prob, None)
+                    self.apply_adam(lr, reg_lambda)
+                # (capturing executed nothing: undo the host-side bookkeeping of the traced call)
+                self.step, self.beta1_power, self.beta2_power = step, b1p, b2p
+                ent = self._graphs[key] = (g, static, lay, ws)
+            g, static, lay, ws = ent
+            static.flat.copy_(db.flat, non_blocking=True)
+            g.replay()
+            self.adam_advance()
+            return ws[lay.loss]
+        finally:
+            self._use_dev_scalars = False
 
     # ------------------------------------------------------------------ reference interface
     def train(self, sess, batch_data, lr, reg_lambda, keep_prob=0.8, dropout_masks=None):
