@@ -330,6 +330,12 @@ typedef struct {
   const int64_t* item_off2; const int32_t* item_nbr2;   /* item -> co-interacted items         */
   const int32_t* user_rows; const int32_t* item_rows;
   int32_t n_users, n_items, time_slice_num, user_fnum, item_fnum;
+  /* GraphHandler mode (graph_loader.py:243-247, set per data set at train_score.py:295-301): 0 = 'rs', 2-hop neighbours
+   * drawn uniformly (:192); 1 = 'is', drawn with probability softmax_j(1 / (degree_j - 1)) (:118-120), degree_j being
+   * the slice degree of the 1-hop neighbour that 2-hop entry j was reached through (the 'degrees' lists of
+   * graph_storage.py:172-176).  user_deg2 / item_deg2 are aligned with user_nbr2 / item_nbr2 (mode 1 only). */
+  int32_t sample_mode;
+  const int32_t* user_deg2; const int32_t* item_deg2;
 } score_graph_t;
 
 typedef struct {   /* the 8-tuple of graph_loader.py:383, device int32, B = n_lines * (1 + neg) */
@@ -340,7 +346,8 @@ typedef struct {   /* the 8-tuple of graph_loader.py:383, device int32, B = n_li
 /* GraphHandler.gen_{user,item}_history + GraphLoader.worker (graph_loader.py:169-277, 340-383, mode
  * 'rs'): uids [n_lines], iids [n_lines*(1+neg)] (positive first).  1-hop lists are truncated /
  * cyclically padded exactly as the reference does; 2-hop lists are sampled K times with replacement
- * from a counter-based generator (`seed`), so draws differ from NumPy's but have its distribution. */
+ * (uniformly, or degree-weighted in mode 'is': score_graph_t.sample_mode) from a counter-based generator
+ * (`seed`), so draws differ from NumPy's but have its distribution. */
 int score_batch_assemble(const score_graph_t* g, const int32_t* uids, const int32_t* iids,
                          int32_t n_lines, int32_t neg_sample_num, int32_t T, int32_t K,
                          int32_t start_time, int32_t pred_time, uint64_t seed,

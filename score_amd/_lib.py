@@ -51,7 +51,8 @@ class State(C.Structure):
 class Graph(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("user_off1", "user_nbr1", "user_off2", "user_nbr2", "item_off1", "item_nbr1",
                                            "item_off2", "item_nbr2", "user_rows", "item_rows")] + \
-               [(n, C.c_int32) for n in ("n_users", "n_items", "time_slice_num", "user_fnum", "item_fnum")]
+               [(n, C.c_int32) for n in ("n_users", "n_items", "time_slice_num", "user_fnum", "item_fnum", "sample_mode")] + \
+               [("user_deg2", C.c_void_p), ("item_deg2", C.c_void_p)]
 
 
 class BatchOut(C.Structure):

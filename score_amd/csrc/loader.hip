@@ -14,6 +14,7 @@
 
 struct AssembleSide {
   const int64_t* off1; const int32_t* nbr1; const int64_t* off2; const int32_t* nbr2;
+  const int32_t* deg2;       // mode 'is': degree behind every 2-hop entry (aligned with nbr2), else null
   const int32_t* ent;        // entity ids of this side, one per slot
   const int32_t* rows1; int F1; int base1;   // feature rows of the 1-hop neighbour type; id - base1 = row
   const int32_t* rows2; int F2; int base2;
@@ -44,7 +45,23 @@ __global__ void assemble_kernel(AssembleSide sd, int S, int T, int K, int start_
     const int len = (int)(sd.off2[cs + 1] - b);
     if (len > 0) {
       const uint64_t ctr = ((uint64_t)(uint32_t)sd.ent[slot] << 20) ^ ((uint64_t)ts << 8) ^ (uint64_t)k;
-      int pick = (int)(hash_uniform(seed, ctr) * (float)len);
+      const float u = hash_uniform(seed, ctr);
+      int pick;
+      if (sd.deg2) {
+        // mode 'is' (graph_loader.py:118-120): p_j = softmax_j(1 / (degree_j - 1)); np.random.choice(p=...) walks the
+        // cumulative sum -- same here (lists hold at most max_2hop = 100 entries; degrees are >= 2 by construction)
+        float tot = 0.f;
+        for (int j = 0; j < len; ++j) tot += __expf(1.0f / (float)max(sd.deg2[b + j] - 1, 1));
+        const float target = u * tot;
+        float run = 0.f;
+        pick = len - 1;
+        for (int j = 0; j < len; ++j) {
+          run += __expf(1.0f / (float)max(sd.deg2[b + j] - 1, 1));
+          if (target < run) { pick = j; break; }
+        }
+      } else {
+        pick = (int)(u * (float)len);
+      }
       id2 = sd.nbr2[b + (pick < len ? pick : len - 1)];
     }
   }
@@ -84,12 +101,16 @@ extern "C" int score_batch_assemble(const score_graph_t* g, const int32_t* uids,
   hipStream_t s = (hipStream_t)stream;
   const int copies = 1 + neg_sample_num, B = n_lines * copies;
   AssembleSide us;
+  if (g->sample_mode != 0 && g->sample_mode != 1) return SCORE_E_BADARG;
+  if (g->sample_mode == 1 && (!g->user_deg2 || !g->item_deg2)) return SCORE_E_BADARG;
   us.off1 = g->user_off1; us.nbr1 = g->user_nbr1; us.off2 = g->user_off2; us.nbr2 = g->user_nbr2;
+  us.deg2 = g->sample_mode == 1 ? g->user_deg2 : nullptr;
   us.ent = uids; us.rows1 = g->item_rows; us.F1 = g->item_fnum; us.base1 = g->n_users + 1;
   us.rows2 = g->user_rows; us.F2 = g->user_fnum; us.base2 = 1;
   us.out1 = out->user_1hop; us.out2 = out->user_2hop; us.n_slots = n_lines; us.copies = copies; us.ent_base = 1;
   AssembleSide is;
   is.off1 = g->item_off1; is.nbr1 = g->item_nbr1; is.off2 = g->item_off2; is.nbr2 = g->item_nbr2;
+  is.deg2 = g->sample_mode == 1 ? g->item_deg2 : nullptr;
   is.ent = iids; is.rows1 = g->user_rows; is.F1 = g->user_fnum; is.base1 = 1;
   is.rows2 = g->item_rows; is.F2 = g->item_fnum; is.base2 = g->n_users + 1;
   is.out1 = out->item_1hop; is.out2 = out->item_2hop; is.n_slots = B; is.copies = 1; is.ent_base = g->n_users + 1;

@@ -35,18 +35,25 @@ class TemporalGraph(object):
         assert self.user_rows.shape[0] == self.U and self.item_rows.shape[0] == self.I
         self.Fu, self.Fi = self.user_rows.shape[1], self.item_rows.shape[1]
         self._dev = None
+        self.user_degrees = self.item_degrees = None      # mode 'is': degree behind every 2-hop entry (aligned with nbr2)
 
     # ---- construction -----------------------------------------------------------------
     @classmethod
-    def from_padded(cls, n_users, n_items, S, u1, u1len, u2, u2len, i1, i1len, i2, i2len, user_rows, item_rows):
-        """From padded per-(entity, slice) lists: x[e, t, :xlen[e, t]]."""
+    def from_padded(cls, n_users, n_items, S, u1, u1len, u2, u2len, i1, i1len, i2, i2len, user_rows, item_rows,
+                    user_deg=None, item_deg=None):
+        """From padded per-(entity, slice) lists: x[e, t, :xlen[e, t]].  user_deg / item_deg: the 'degrees' lists
+        padded like u2 / i2 (mode 'is')."""
         def side(a1, l1, a2, l2):
             c1 = [a1[e, t, :l1[e, t]].tolist() for e in range(a1.shape[0]) for t in range(S)]
             c2 = [a2[e, t, :l2[e, t]].tolist() for e in range(a2.shape[0]) for t in range(S)]
             o1, n1 = _csr(c1)
             o2, n2 = _csr(c2)
             return dict(off1=o1, nbr1=n1, off2=o2, nbr2=n2)
-        return cls(n_users, n_items, S, side(u1, u1len, u2, u2len), side(i1, i1len, i2, i2len), user_rows, item_rows)
+        g = cls(n_users, n_items, S, side(u1, u1len, u2, u2len), side(i1, i1len, i2, i2len), user_rows, item_rows)
+        if user_deg is not None:
+            flat = lambda a, l: _csr([a[e, t, :l[e, t]].tolist() for e in range(a.shape[0]) for t in range(S)])[1]
+            g.user_degrees, g.item_degrees = flat(user_deg, u2len), flat(item_deg, i2len)
+        return g
 
     @classmethod
     def from_log(cls, uid, iid, t_idx, n_users, n_items, time_slice_num, user_rows, item_rows,
@@ -112,7 +119,13 @@ class TemporalGraph(object):
         return nbr[off[e * self.S + t]:off[e * self.S + t + 1]]
 
     # ---- device residency -------------------------------------------------------------
-    def to_device(self, device=None):
+    def to_device(self, device=None, mode="rs"):
+        """mode: GraphHandler's 2-hop sampling mode -- 'rs' uniform (what train_score.py uses for all three data sets),
+        'is' degree-weighted (graph_loader.py:94-167; needs the degree lists from_log / from_padded keep)."""
+        if mode not in ("rs", "is"):
+            raise ValueError("WRONG GRAPH_HANDLER MODE: {}".format(mode))          # graph_loader.py:248
+        if mode == "is" and (self.user_degrees is None or self.item_degrees is None):
+            raise ValueError("mode 'is' needs the 2-hop degree lists")
         if not torch.cuda.is_available():
             raise RuntimeError("TemporalGraph.to_device needs an AMD GPU (HIP); batch assembly has no CPU path")
         dev = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
@@ -124,11 +137,16 @@ class TemporalGraph(object):
             if d[k].numel() == 0:
                 d[k] = torch.zeros((1,), dtype=d[k].dtype, device=dev)
         d["user_rows"], d["item_rows"] = t(self.user_rows), t(self.item_rows)
+        if mode == "is":
+            for k, a in (("u_deg2", self.user_degrees), ("i_deg2", self.item_degrees)):
+                d[k] = t(np.asarray(a, dtype=np.int32)) if len(a) else torch.zeros((1,), dtype=torch.int32, device=dev)
         self._dev = d
         self.device = dev
+        self.mode = mode
         self.struct = _lib.Graph(_ptr(d["u_off1"]), _ptr(d["u_nbr1"]), _ptr(d["u_off2"]), _ptr(d["u_nbr2"]),
                                  _ptr(d["i_off1"]), _ptr(d["i_nbr1"]), _ptr(d["i_off2"]), _ptr(d["i_nbr2"]),
-                                 _ptr(d["user_rows"]), _ptr(d["item_rows"]), self.U, self.I, self.S, self.Fu, self.Fi)
+                                 _ptr(d["user_rows"]), _ptr(d["item_rows"]), self.U, self.I, self.S, self.Fu, self.Fi,
+                                 1 if mode == "is" else 0, _ptr(d.get("u_deg2")), _ptr(d.get("i_deg2")))
         return self
 
 

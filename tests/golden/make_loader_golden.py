@@ -98,6 +98,23 @@ def main():
         blob[tag + "/user_feat"] = np.asarray([[u] + (ufeat[str(u)] if Fu > 1 else []) for u in range(1, U + 1)], dtype=np.int32)
         blob[tag + "/item_feat"] = np.asarray([[i] + (ifeat[str(i)] if Fi > 1 else []) for i in range(U + 1, U + I + 1)], dtype=np.int32)
         blob[tag + "/dims"] = np.asarray([U, I, S, K, Fu, Fi, start_time])
+        # mode 'is' (degree-weighted 2-hop draws, graph_loader.py:94-167): the degree lists + the reference's own draws
+        # for a few entities, as counts per drawn id (many calls; np.random's stream)
+        blob[tag + "/user_degrees"], _ = pad(user_docs, "degrees", S, 12)
+        blob[tag + "/item_degrees"], _ = pad(item_docs, "degrees", S, 12)
+        h_is = gl.GraphHandler(S, "nodb", K, U, I, start_time, 10000, 10000, "is", uf, itf, Fu, Fi)
+        h_is.user_colls, h_is.item_colls = h.user_colls, h.item_colls
+        np.random.seed(321)
+        calls = 300
+        for nm, ents, fn, first in (("user", [1, 2, 3], h_is.gen_user_history, U + 1), ("item", [U + 1, U + 2], h_is.gen_item_history, 1)):
+            draws = np.zeros((len(ents), S - 1, calls * K), dtype=np.int32)
+            for ei, e in enumerate(ents):
+                for c in range(calls):
+                    _, two = fn(e, S - 1)
+                    for t in range(S - 1):
+                        draws[ei, t, c * K:(c + 1) * K] = np.asarray(two[t], dtype=np.float64)[:, 0].astype(np.int32)
+            blob["%s_is/%s_ents" % (tag, nm)] = np.asarray(ents)
+            blob["%s_is/%s_draws" % (tag, nm)] = draws
     np.savez_compressed(os.path.join(HERE, "g4_loader.npz"), **blob)
     print("wrote g4_loader.npz", os.path.getsize(os.path.join(HERE, "g4_loader.npz")))
 

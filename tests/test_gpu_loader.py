@@ -111,3 +111,59 @@ def test_two_hop_draws_are_uniform():
         counts += np.bincount(d.ravel(), minlength=6)
     frac = counts[2:] / counts[2:].sum()
     assert counts[:2].sum() == 0 and np.abs(frac - 0.25).max() < 0.03
+
+
+@pytest.mark.parametrize("tag", ["f34", "f12"])
+def test_degree_weighted_2hop_sampling_mode_is(tag):
+    # GraphHandler mode 'is' (graph_loader.py:94-167): 2-hop entry j drawn with probability softmax_j(1 / (degree_j - 1)).
+    # Draws cannot match NumPy's stream; the reference's own draws (fixture) and the device sampler's must both follow
+    # the analytic distribution of the stored documents, and the device sampler must reproduce the 'rs' structure
+    # (dummy slices, tail replication, 1-hop tensors) unchanged.
+    from score_amd.graph import TemporalGraph, DeviceGraphLoader
+    U, I, S, K, Fu, Fi, st = [int(x) for x in Z[tag + "/dims"]]
+    g = TemporalGraph.from_padded(U, I, S, Z[tag + "/user_1hop"], Z[tag + "/user_1hop_len"], Z[tag + "/user_2hop"],
+                                  Z[tag + "/user_2hop_len"], Z[tag + "/item_1hop"], Z[tag + "/item_1hop_len"],
+                                  Z[tag + "/item_2hop"], Z[tag + "/item_2hop_len"], Z[tag + "/user_feat"],
+                                  Z[tag + "/item_feat"], Z[tag + "/user_degrees"], Z[tag + "/item_degrees"])
+    with pytest.raises(ValueError):
+        g.to_device(mode="xs")
+    g.to_device(mode="is")
+    T, pred = S - 1 - st, S - 1
+    u_ents, i_ents = Z[tag + "_is/user_ents"].tolist(), Z[tag + "_is/item_ents"].tolist()
+    lines = [(u, [i_ents[0]]) for u in u_ents] + [(u_ents[0], [i]) for i in i_ents]
+    calls = 300
+    mine_u = np.zeros((len(u_ents), T, calls * K), dtype=np.int64)
+    mine_i = np.zeros((len(i_ents), T, calls * K), dtype=np.int64)
+    first = None
+    for c in range(calls):
+        b = next(DeviceGraphLoader(g, len(lines), lines, st, pred, 0, T, K, seed=1000 + c))
+        t = [x.cpu().numpy() for x in b.tensors]
+        if first is None:
+            first = t
+        assert np.array_equal(t[0], first[0]) and np.array_equal(t[2], first[2])       # 1-hop tensors do not depend on the draws
+        mine_u[:, :, c * K:(c + 1) * K] = t[1][:len(u_ents), :, :, 0]
+        mine_i[:, :, c * K:(c + 1) * K] = t[3][len(u_ents):, :, :, 0]
+    worst = 0.0
+    for name, ents, base, mine in (("user", u_ents, 1, mine_u), ("item", i_ents, U + 1, mine_i)):
+        lists, lens, degs = Z["%s/%s_2hop" % (tag, name)], Z["%s/%s_2hop_len" % (tag, name)], Z["%s/%s_degrees" % (tag, name)]
+        ref = Z["%s_is/%s_draws" % (tag, name)]
+        for ei, e in enumerate(ents):
+            for t_ in range(T):
+                n = int(lens[e - base, st + t_])
+                if n == 0:
+                    assert not mine[ei, t_].any() and not ref[ei, t_].any()                # dummy slice in both
+                    continue
+                ids, d = lists[e - base, st + t_, :n], degs[e - base, st + t_, :n].astype(np.float64)
+                w = np.exp(1.0 / (d - 1.0))
+                p = {}
+                for j, w_j in zip(ids.tolist(), (w / w.sum()).tolist()):
+                    p[j] = p.get(j, 0.0) + w_j
+                for draws in (mine[ei, t_], ref[ei, t_]):
+                    assert set(np.unique(draws).tolist()) <= set(p)
+                    for j, pj in p.items():
+                        worst = max(worst, abs(float((draws == j).mean()) - pj))
+    assert worst < 0.07, worst                                        # ~4.5 sigma of 900-1200 draws
+    # the uniform sampler on the same documents is measurably different wherever the degrees differ
+    g.to_device(mode="rs")
+    b = next(DeviceGraphLoader(g, len(lines), lines, st, pred, 0, T, K, seed=1000))
+    assert np.array_equal(b.tensors[0].cpu().numpy(), first[0])
