@@ -78,6 +78,9 @@ _SIGS = {
                          C.c_int32, C.c_void_p],
     "score_gemm": [C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_f, C.c_int32, c_f, C.c_int32, c_f, C.c_int32,
                    c_f, C.c_int32, C.c_float, C.c_void_p, C.c_uint64, c_f, C.c_int64, C.c_void_p],
+    "score_gemm_weights": [C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_f, C.c_int32, c_f, C.c_int32, c_f, C.c_int32, c_f,
+                           C.c_int32, c_f, C.c_int64, C.c_void_p],
+    "score_gemm_weights_scratch_floats": [C.c_int32, C.c_int32],
     "score_gru_fwd": [C.c_int32, C.c_int32, C.c_int32, c_f, c_f, C.c_int32, c_f, C.c_int32, c_i, c_f, C.c_int32,
                       c_f, c_f, C.c_void_p],
     "score_gru_bwd": [C.c_int32, C.c_int32, C.c_int32, c_f, C.c_int32, c_f, C.c_int32, c_i, c_f, C.c_int32, c_f,
@@ -125,7 +128,7 @@ def load():
     for name, args in _SIGS.items():
         fn = getattr(lib, name)      # AttributeError if a declared symbol is missing
         fn.argtypes = args
-        fn.restype = C.c_int64 if name.endswith("_bytes") else C.c_int
+        fn.restype = C.c_int64 if name.endswith("_bytes") or name.endswith("_floats") else C.c_int
     _lib = lib
     return lib
 

@@ -123,13 +123,34 @@ def train_loop(model, train_batches, vali_batches, lr, reg_lambda, train_batch_s
                          (dataset_size, train_batch_size, eval_iter_num))
     losses_step = []
     vali_mrrs = curves["vali_mrrs"]
+    # a model whose train() takes next_batch= (the row-sharded ShardedSCORE) is fed one batch ahead: its index plan and
+    # row requests for batch t+1 then run under step t instead of on its critical path (two host read-backs per step)
+    import inspect
+    try:
+        ahead = "next_batch" in inspect.signature(model.train).parameters
+    except (TypeError, ValueError):
+        ahead = False
+
+    def with_next(it):
+        it = iter(it)
+        try:
+            cur = next(it)
+        except StopIteration:
+            return
+        for nxt in it:
+            yield cur, nxt
+            cur = nxt
+        yield cur, None
     for epoch in range(epochs):
         if early_stop:
             break
-        for batch_data in train_batches():
+        for batch_data, next_data in with_next(train_batches()):
             if early_stop:
                 break
-            loss = model.train(sess, batch_data, lr, reg_lambda)
+            if ahead:
+                loss = model.train(sess, batch_data, lr, reg_lambda, next_batch=next_data)
+            else:
+                loss = model.train(sess, batch_data, lr, reg_lambda)
             step += 1
             losses_step.append(loss)
             if step % eval_iter_num == 0:

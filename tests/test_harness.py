@@ -119,3 +119,18 @@ def test_train_loop_early_stop_rules_only_after_first_epoch():
 def test_train_loop_rejects_degenerate_cadence():
     with pytest.raises(ValueError):
         _run([0.1], dataset_size=2, bs=200)
+
+
+def test_train_loop_feeds_lookahead_models_one_batch_ahead():
+    class Ahead(_Scripted):
+        def __init__(self, mrrs):
+            _Scripted.__init__(self, mrrs)
+            self.pairs = []
+
+        def train(self, sess, batch_data, lr, reg_lambda, next_batch=None):
+            self.pairs.append((batch_data, next_batch))
+            return _Scripted.train(self, sess, batch_data, lr, reg_lambda)
+    m = Ahead([0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7])
+    ev = lambda model, batches, reg: (0.0, 0.5, 0, 0, 0, 0, 0, model.mrrs[min(len(model.pairs) // 3, 6)], 0.1)
+    h.train_loop(m, lambda: iter([10, 11, 12]), lambda: [], 1e-3, 1e-4, 4, 18, epochs=2, evaluate_fn=ev, log=lambda s: None)
+    assert m.pairs == [(10, 11), (11, 12), (12, None)] * 2        # the last batch of an epoch has no successor
