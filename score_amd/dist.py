@@ -261,8 +261,9 @@ class HipBackend(object):
     def _state(self, plan, mini):
         m = self.m
         lay, ws = plan["lay"], plan["ws"]
-        return lay, ws, _lib.State(_ptr(mini), mini.shape[0], _ptr(m.w), _ptr(ws), ws.numel() * 4, 2,
-                                   int(m.global_batch), int(m.gemm_mode), int(m.debug_flags), None, None, None, m._ctx)
+        return lay, ws, _lib.State(table=_ptr(mini), n_table_rows=mini.shape[0], w=_ptr(m.w), workspace=_ptr(ws),
+                                   workspace_bytes=ws.numel() * 4, scatter_mode=2, global_batch=int(m.global_batch),
+                                   gemm_mode=int(m.gemm_mode), debug_flags=int(m.debug_flags), context=m._ctx)
 
     def forward(self, plan, mini, reg_lambda, keep_prob, masks):
         m = self.m

@@ -317,10 +317,12 @@ class SCOREBASE(object):
         return ent
 
     def _state(self, ws):
-        return _lib.State(_ptr(self.table), self.table.shape[0], _ptr(self.w), _ptr(ws), ws.numel() * 4,
-                          int(self.scatter_mode), int(self.global_batch), int(self.gemm_mode), int(self.debug_flags),
-                          _ptr(self.table_flags) if self.scatter_mode == 0 else None, None, None,
-                          _ptr(self._scalars) if self._use_dev_scalars else None, self._ctx)
+        return _lib.State(table=_ptr(self.table), n_table_rows=self.table.shape[0], w=_ptr(self.w), workspace=_ptr(ws),
+                          workspace_bytes=ws.numel() * 4, scatter_mode=int(self.scatter_mode),
+                          global_batch=int(self.global_batch), gemm_mode=int(self.gemm_mode),
+                          debug_flags=int(self.debug_flags),
+                          row_flags=_ptr(self.table_flags) if self.scatter_mode == 0 else None,
+                          step_scalars=_ptr(self._scalars) if self._use_dev_scalars else None, context=self._ctx)
 
     @staticmethod
     def _event_array(events):
