@@ -163,3 +163,29 @@ def workspace_layout(cfg, B):
     ws = Workspace()
     check(lib.score_workspace_layout(C.byref(cfg), int(B), C.byref(ws)), "score_workspace_layout")
     return ws
+
+
+_listpack = None
+
+
+def listpack():
+    """The CPython extension that flattens nested feed lists into int32 (score_amd/cext/listpack.c), built in-tree
+    with gcc on first use.  Host-side ingestion only -- no compute; returns None if it cannot be built (the caller
+    then converts with NumPy, ~15x slower)."""
+    global _listpack
+    if _listpack is None:
+        import importlib.machinery
+        import importlib.util
+        path = os.path.join(_HERE, "lib", "_listpack.so")
+        try:
+            if not os.path.exists(path):
+                from . import build as _build
+                _build.build_listpack()
+            loader = importlib.machinery.ExtensionFileLoader("_listpack", path)
+            spec = importlib.util.spec_from_file_location("_listpack", path, loader=loader)
+            mod = importlib.util.module_from_spec(spec)
+            loader.exec_module(mod)
+            _listpack = mod
+        except Exception:
+            _listpack = False
+    return _listpack or None

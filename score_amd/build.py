@@ -49,7 +49,20 @@ def build(force=False, verbose=False):
     if force or procs or _stale(LIB, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         subprocess.check_call(cmd)
+    build_listpack(force)
     return LIB
+
+
+def build_listpack(force=False):
+    """The CPython helper that flattens nested feed lists (score_amd/cext/listpack.c): plain gcc, in-tree."""
+    import sysconfig
+    src = os.path.join(HERE, "cext", "listpack.c")
+    out = os.path.join(LIBDIR, "_listpack.so")
+    os.makedirs(LIBDIR, exist_ok=True)
+    if force or _stale(out, [src]):
+        subprocess.check_call([os.environ.get("CC", "gcc"), "-O2", "-shared", "-fPIC", "-I" + sysconfig.get_paths()["include"],
+                               src, "-o", out])
+    return out
 
 
 if __name__ == "__main__":

@@ -60,39 +60,44 @@ class DeviceBatch(object):
             raise TypeError("already a DeviceBatch")
         if len(batch_data) != 8:
             raise ValueError("batch_data must be the 8-tuple of graph_loader.py:383")
-        B = None
         max_len = None
-        parts, on_device = [], all(torch.is_tensor(x) for x in batch_data)
-        for i, x in enumerate(batch_data):
-            if torch.is_tensor(x):
-                a = x if on_device else x.cpu().numpy()
-            else:
-                # nested lists hold ints, with float 0.0 in dummy slices (graph_loader.py:90-91)
-                a = np.asarray(x)
-            if not torch.is_tensor(a) and a.dtype != np.int32:
-                a = a.astype(np.int32)
-            if B is None:
-                B = int(a.shape[0]) if a.ndim else 0
-                shapes = batch_shapes(model.cfg, B)
-            if tuple(a.shape) != shapes[i]:
-                raise ValueError("batch_data[%d] (%s) has shape %s, expected %s" %
-                                 (i, BATCH_FIELDS[i], tuple(a.shape), shapes[i]))
-            parts.append(a)
+        on_device = all(torch.is_tensor(x) and x.device.type == "cuda" for x in batch_data)
+        B = int(batch_data[6].shape[0]) if hasattr(batch_data[6], "shape") else len(batch_data[6])
         if B == 0:
             raise ValueError("empty batch")
+        shapes = batch_shapes(model.cfg, B)
         self.B = B
         n_flat = flat_batch_size(shapes)
+
+        def bad(i, got):
+            return ValueError("batch_data[%d] (%s) has shape %s, expected %s" % (i, BATCH_FIELDS[i], tuple(got), shapes[i]))
         if on_device:
             self.flat = torch.empty((n_flat,), dtype=torch.int32, device=model.device)
             self.tensors = carve_batch(self.flat, shapes)
-            for dst, src in zip(self.tensors, parts):
+            for i, (dst, src) in enumerate(zip(self.tensors, batch_data)):
+                if tuple(src.shape) != shapes[i]:
+                    raise bad(i, src.shape)
                 dst.copy_(src)                              # (dtype / device conversion included)
             max_len = int(self.tensors[7].max().item())     # one read-back per batch object
         else:
+            # the whole feed tuple into ONE int32 staging buffer, then one copy to the device.  Nested lists (what the
+            # reference's loader yields: ints, with float 0.0 in dummy slices, graph_loader.py:90-91) are walked in C
+            # (_listpack: ~15x faster than np.asarray on lists); arrays / host tensors are copied
             host = np.zeros((n_flat,), dtype=np.int32)
-            for dst, src in zip(carve_batch(torch.from_numpy(host), shapes), parts):
-                dst.copy_(torch.from_numpy(np.ascontiguousarray(src)))
-            max_len = int(parts[7].max()) if parts[7].size else 0
+            views = carve_batch(torch.from_numpy(host), shapes)
+            lp = _lib.listpack()
+            for i, (dst, x) in enumerate(zip(views, batch_data)):
+                if lp is not None and isinstance(x, (list, tuple)):
+                    try:
+                        lp.pack(x, dst.numpy(), shapes[i])
+                    except ValueError:
+                        raise bad(i, np.asarray(x).shape)
+                    continue
+                a = x.cpu().numpy() if torch.is_tensor(x) else np.asarray(x)
+                if tuple(a.shape) != shapes[i]:
+                    raise bad(i, a.shape)
+                dst.copy_(torch.from_numpy(np.ascontiguousarray(a.astype(np.int32, copy=False))))
+            max_len = int(views[7].max()) if B else 0
             self.flat = torch.from_numpy(host).to(model.device, non_blocking=True)
             self.tensors = carve_batch(self.flat, shapes)
         self.active_slices = active_slices(model, max_len)
