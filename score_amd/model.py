@@ -509,7 +509,10 @@ class SCOREBASE(object):
 
     def _train_captured(self, batch_data, lr, reg_lambda, keep_prob):
         db = self.device_batch(batch_data)
-        key = (db.B, db.active_slices, float(reg_lambda), float(keep_prob))
+        # everything the launch sequence bakes in by value (pointers are stable: the table, the flat parameter
+        # buffers and the workspace of a batch size never move)
+        key = (db.B, db.active_slices, float(reg_lambda), float(keep_prob), int(self.global_batch), int(self.gemm_mode),
+               int(self.debug_flags))
         ent = self._graphs.get(key)
         self._use_dev_scalars = True
         try:
