@@ -19,7 +19,23 @@ if os.environ.get("PROBE_STREAM") == "plain":
 else:
     from score_amd.dist import _concurrent_stream
     bg = _concurrent_stream(torch.device("cuda:0"))      # a stream whose kernels really run beside the main stream's
+ev4 = torch.cuda.Event(); ev4.record(main)
+def step_tail(i):
+    """the table sweep on the side stream from the moment the row gradients exist (stage boundary 4 of score_backward),
+    i.e. beside the weight-gradient products that end the pass; exact (same inputs, same kernel)"""
+    m.bwd_events = [None, None, None, None, ev4, None]
+    m.forward_backward(bs[i % 8], 1e-4, 0.8)
+    bg.wait_event(ev4)
+    with torch.cuda.stream(bg):
+        m.adam_table(1e-3)
+        done = bg.record_event()
+    m.adam_dense(1e-3, 1e-4)
+    m.adam_advance()
+    main.wait_event(done)
+    return None
 def step(i, prev_done):
+    if mode == "tail":
+        return step_tail(i)
     m.forward_backward(bs[i % 8], 1e-4, 0.8)
     m.adam_dense(1e-3, 1e-4)
     if mode == "serial":
