@@ -131,6 +131,8 @@ def train_loop(model, train_batches, vali_batches, lr, reg_lambda, train_batch_s
     except (TypeError, ValueError):
         ahead = False
 
+    use_async = not ahead and hasattr(model, "train_async") and hasattr(model, "device")
+
     def with_next(it):
         it = iter(it)
         try:
@@ -149,11 +151,18 @@ def train_loop(model, train_batches, vali_batches, lr, reg_lambda, train_batch_s
                 break
             if ahead:
                 loss = model.train(sess, batch_data, lr, reg_lambda, next_batch=next_data)
+            elif use_async:
+                # the loss stays on the device until the next evaluation needs the mean: the host does not wait for the
+                # GPU every step, so preparing batch t+1 (list flattening, loader work) overlaps step t
+                loss = model.train_async(batch_data, lr, reg_lambda).clone()
             else:
                 loss = model.train(sess, batch_data, lr, reg_lambda)
             step += 1
             losses_step.append(loss)
             if step % eval_iter_num == 0:
+                if use_async:
+                    import torch
+                    losses_step = torch.stack(losses_step).cpu().tolist()
                 train_loss = sum(losses_step) / len(losses_step)
                 curves["train_losses"].append(train_loss)
                 losses_step = []
