@@ -201,3 +201,51 @@ def test_segment_sum_rows_op():
     want[touched] = acc[touched]
     got = out.cpu().numpy()
     assert np.allclose(got, want, rtol=1e-5, atol=1e-3 * 1e-2 * np.abs(acc).max())
+
+
+def test_cfg5_shape_eight_virtual_ranks():
+    # BASELINE.json configs[4] as it is meant to run: Taobao-scale table (N = 5,042,754, D = 128) row-sharded over 8 ranks
+    # (virtual: threads on the one GPU), T = 50, K = 20, H = 256, global batch 4096 = 8 x 512 -- against one device on the
+    # concatenated batch.  Shards are initialised shard-locally from the seed (no rank, and no host array, ever holds
+    # the 2.6 GB table); 23-bit (owner, row) plan keys.
+    from score_amd.dist import ShardedSCORE
+    from score_amd.model import SCORE
+    from score_amd.synth import make_world
+    world, steps = 8, 2
+    w, kw = make_world("cfg5_taobao")
+    kw.pop("batch")
+    Bl = 512
+    batches = [[w.batch(Bl, 700 + 10 * r + s) for s in range(steps)] for r in range(world)]
+
+    def fn(rank, comm):
+        m = ShardedSCORE(seed=31, comm=comm, **kw)
+        assert m.backend.m.table.shape[0] == (kw["feature_size"] + world - 1) // world
+        losses = []
+        for i, bt in enumerate(batches[rank]):
+            losses.append(m.train(None, bt, 1e-3, 1e-4, keep_prob=1.0,
+                                  next_batch=batches[rank][i + 1] if i + 1 < steps else None))
+        pred, _, _ = m.eval(None, batches[rank][0], 1e-4)
+        torch.cuda.synchronize()
+        rows = torch.arange(rank, kw["feature_size"], world, device="cuda")[:200000:97]       # a sample of this shard's rows
+        return losses, (rows.cpu().numpy(), m.backend.m.table[(rows - rank) // world].cpu().numpy()), m.backend.m.w.cpu().numpy(), pred
+
+    res = run_ranks(world, fn)
+    ref = SCORE(seed=31, **kw)
+    for s in range(steps):
+        cat = tuple(np.concatenate([batches[r][s][i] for r in range(world)]) for i in range(8))
+        lref = ref.train(None, cat, 1e-3, 1e-4, keep_prob=1.0)
+        for r in range(world):
+            assert abs(res[r][0][s] - lref) < 2e-5 * max(1.0, abs(lref)), (s, r, res[r][0][s], lref)
+    for r in range(1, world):
+        assert np.array_equal(res[0][2], res[r][2])
+    dw = np.abs(res[0][2] - ref.w.cpu().numpy())
+    assert np.median(dw) < 1e-6 and dw.max() <= 2.2 * steps * 1e-3
+    for r in range(world):
+        rows, vals = res[r][1]
+        d = np.abs(vals - ref.table[torch.from_numpy(rows).cuda()].cpu().numpy())
+        # (Adam's first steps turn a rounding-level gradient difference into a +-lr move: a few elements in a thousand
+        #  differ by up to the step bound, the rest agree to rounding)
+        assert (d <= 3e-6).mean() > 0.995 and d.max() <= 2.2 * steps * 1e-3
+        pref, _, _ = ref.eval(None, batches[r][0], 1e-4)
+        dp = np.abs(np.asarray(res[r][3]) - np.asarray(pref))
+        assert np.median(dp) < 1e-4 and dp.max() < 3e-3
