@@ -59,11 +59,20 @@ static int walk(PyObject* o, const Py_ssize_t* shape, int nd, int32_t** dst) {
     int32_t* d = *dst;
     for (Py_ssize_t i = 0; i < n; ++i) {
       PyObject* it = items[i];
+      if (i + 4 < n) __builtin_prefetch(items[i + 4]);      /* boxed ints are scattered over the heap */
       if (PyLong_CheckExact(it)) {
+#if PY_VERSION_HEX < 0x030C0000
+        /* CPython < 3.12: non-negative ints below 2^30 are one 30-bit digit -- every row id of the path */
+        const Py_ssize_t sz = Py_SIZE(it);
+        if (sz == 1) { d[i] = (int32_t)((PyLongObject*)it)->ob_digit[0]; continue; }
+        if (sz == 0) { d[i] = 0; continue; }
+#endif
         int ovf = 0;
         long v = PyLong_AsLongAndOverflow(it, &ovf);
         if (ovf || v < INT32_MIN || v > INT32_MAX) { PyErr_SetString(PyExc_OverflowError, "feed value outside int32"); return -1; }
         d[i] = (int32_t)v;
+      } else if (PyFloat_CheckExact(it) && PyFloat_AS_DOUBLE(it) == 0.0) {
+        d[i] = 0;                                   /* the dummy node's float zeros (graph_loader.py:90-91) */
       } else if (leaf(it, d + i) < 0) {
         return -1;
       }
@@ -71,8 +80,13 @@ static int walk(PyObject* o, const Py_ssize_t* shape, int nd, int32_t** dst) {
     *dst += n;
     return 0;
   }
-  for (Py_ssize_t i = 0; i < n; ++i)
+  for (Py_ssize_t i = 0; i < n; ++i) {
+    if (i + 1 < n) {
+      __builtin_prefetch(items[i + 1]);
+      if (nd == 2 && PyList_CheckExact(items[i + 1])) __builtin_prefetch(((PyListObject*)items[i + 1])->ob_item);
+    }
     if (walk(items[i], shape + 1, nd - 1, dst) < 0) return -1;
+  }
   return 0;
 }
 
