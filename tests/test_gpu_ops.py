@@ -48,7 +48,10 @@ def test_gather_bit_exact():
 
 @pytest.mark.parametrize("trans", [0, 1, 2])
 @pytest.mark.parametrize("shape", [(64, 64, 16), (130, 70, 37), (2048, 384, 448), (5, 1, 80), (200, 80, 1000),
-                                   (1184, 80, 4096)])
+                                   (1184, 80, 4096),
+                                   # the dense layers of the reference's own shapes (K = 80 .. 256 on small grids), odd K
+                                   (256, 200, 80), (2560, 80, 168), (1800, 96, 112), (200, 176, 200), (300, 70, 255),
+                                   (130, 130, 256), (77, 33, 129), (2000, 80, 208), (64, 64, 1)])
 def test_gemm_fp32(trans, shape):
     lib = _lib.load()
     M, N, K = shape
