@@ -290,6 +290,22 @@ extern "C" int score_gru_bwd(int32_t B, int32_t T, int32_t H, const float* Wg, i
 // ======================================================================================
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define RRB 16
+// tools/gru_reg_probe.py builds this file with one ingredient stripped at a time (wrong results, timing only)
+#if defined(GRP_NOMFMA)
+#define GR_MFMA(a, b, c) ([&] { f32x4 t_ = (c); t_[0] += (a) * (b); return t_; }())
+#else
+#define GR_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+#endif
+#if defined(GRP_NOSTORE)
+#define GR_STORE(lhs, v) do { if ((v) == 123.456f) lhs = (v); } while (0)
+#else
+#define GR_STORE(lhs, v) lhs = (v)
+#endif
+#if defined(GRP_NOXLOAD)
+#define GR_XLOAD(e) 0.5f
+#else
+#define GR_XLOAD(e) (e)
+#endif
 // fast transcendental forms for the recurrence epilogues (v_exp_f32 / v_rcp_f32; abs error ~1e-7)
 __device__ __forceinline__ float sigmoid_fast(float x) { return __frcp_rn(1.0f + __expf(-x)); }
 __device__ __forceinline__ float tanh_fast(float x) { return 1.0f - 2.0f * __frcp_rn(__expf(2.0f * x) + 1.0f); }
@@ -356,9 +372,9 @@ __global__ __launch_bounds__(64 * NW) void gru_fwd_reg_kernel(const GruArgs a) {
     for (int r = 0; r < 4; ++r) {
       const float* xr = sd.xproj + (rowb[r] + tc) * 3 * H;
 #pragma unroll
-      for (int tt = 0; tt < TGW; ++tt) nxg[tt][r] = xr[min(wave + NW * tt, NTG - 1) * 16 + lc];
+      for (int tt = 0; tt < TGW; ++tt) nxg[tt][r] = GR_XLOAD(xr[min(wave + NW * tt, NTG - 1) * 16 + lc]);
 #pragma unroll
-      for (int tt = 0; tt < TCW; ++tt) nxc[tt][r] = xr[2 * H + min(wave + NW * tt, NTC - 1) * 16 + lc];
+      for (int tt = 0; tt < TCW; ++tt) nxc[tt][r] = GR_XLOAD(xr[2 * H + min(wave + NW * tt, NTC - 1) * 16 + lc]);
     }
   };
   fetch_x(0);
@@ -384,7 +400,7 @@ __global__ __launch_bounds__(64 * NW) void gru_fwd_reg_kernel(const GruArgs a) {
       for (int ks = 0; ks < KS; ++ks) {
         const float av = (ks & 3) == 0 ? av4[ks >> 2].x : (ks & 3) == 1 ? av4[ks >> 2].y : (ks & 3) == 2 ? av4[ks >> 2].z : av4[ks >> 2].w;
 #pragma unroll
-        for (int tt = 0; tt < TGW; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wg[tt][ks], acc[tt], 0, 0, 0);
+        for (int tt = 0; tt < TGW; ++tt) acc[tt] = GR_MFMA(av, wg[tt][ks], acc[tt]);
       }
     }
 #pragma unroll
@@ -396,7 +412,7 @@ __global__ __launch_bounds__(64 * NW) void gru_fwd_reg_kernel(const GruArgs a) {
       for (int r = 0; r < 4; ++r) {
         const int i = lq * 4 + r;
         const float g = sigmoid_fast(acc[tt][r] + xg[tt][r]);
-        if (rok[r]) sd.gates[(rowb[r] + t) * 3 * H + j] = g;
+        if (rok[r]) GR_STORE(sd.gates[(rowb[r] + t) * 3 * H + j], g);
         if (j < H) rhs[i * LD + j] = g * hs[i * LD + j];
         else us[i * LD + (j - H)] = g;
       }
@@ -415,7 +431,7 @@ __global__ __launch_bounds__(64 * NW) void gru_fwd_reg_kernel(const GruArgs a) {
         const float av = (ks & 3) == 0 ? av4[ks >> 2].x : (ks & 3) == 1 ? av4[ks >> 2].y : (ks & 3) == 2 ? av4[ks >> 2].z : av4[ks >> 2].w;
 #pragma unroll
         for (int tt = 0; tt < TCW; ++tt)
-          acc2[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wc[tt][ks], acc2[tt], 0, 0, 0);
+          acc2[tt] = GR_MFMA(av, wc[tt][ks], acc2[tt]);
       }
     }
 #pragma unroll
@@ -432,8 +448,8 @@ __global__ __launch_bounds__(64 * NW) void gru_fwd_reg_kernel(const GruArgs a) {
         const bool live = t < len[r];
         if (rok[r]) {
           const int64_t row = rowb[r] + t;
-          sd.gates[row * 3 * H + 2 * H + j] = c;
-          sd.out[row * sd.ldo + j] = live ? hn : 0.f;
+          GR_STORE(sd.gates[row * 3 * H + 2 * H + j], c);
+          GR_STORE(sd.out[row * sd.ldo + j], (live ? hn : 0.f));
         }
         hs[i * LD + j] = live ? hn : h;
       }
@@ -509,11 +525,11 @@ __global__ __launch_bounds__(64 * NW) void gru_bwd_reg_kernel(const GruArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int64_t row = rowb[r] + tc;
-        n_r[tt][r] = sd.gates[row * 3 * H + j];
-        n_u[tt][r] = sd.gates[row * 3 * H + H + j];
-        n_c[tt][r] = sd.gates[row * 3 * H + 2 * H + j];
-        n_hp[tt][r] = sd.out[(row - (tc > 0 ? 1 : 0)) * sd.ldo + j];
-        n_do[tt][r] = sd.dout[row * sd.lddo + j];
+        n_r[tt][r] = GR_XLOAD(sd.gates[row * 3 * H + j]);
+        n_u[tt][r] = GR_XLOAD(sd.gates[row * 3 * H + H + j]);
+        n_c[tt][r] = GR_XLOAD(sd.gates[row * 3 * H + 2 * H + j]);
+        n_hp[tt][r] = GR_XLOAD(sd.out[(row - (tc > 0 ? 1 : 0)) * sd.ldo + j]);
+        n_do[tt][r] = GR_XLOAD(sd.dout[row * sd.lddo + j]);
       }
     }
   };
@@ -550,9 +566,9 @@ __global__ __launch_bounds__(64 * NW) void gru_bwd_reg_kernel(const GruArgs a) {
         dh[i * LD + j] = live ? d * u : dold;
         if (rok[r]) {
           const int64_t row = rowb[r] + t;
-          sd.hprev[row * H + j] = c_hp[tt][r];
-          sd.dxproj[row * 3 * H + H + j] = v_dpu;
-          sd.dxproj[row * 3 * H + 2 * H + j] = v_dpc;
+          GR_STORE(sd.hprev[row * H + j], c_hp[tt][r]);
+          GR_STORE(sd.dxproj[row * 3 * H + H + j], v_dpu);
+          GR_STORE(sd.dxproj[row * 3 * H + 2 * H + j], v_dpc);
         }
         dpc[i * LD + j] = v_dpc;
         dpg[i * LD2 + H + j] = v_dpu;
@@ -572,7 +588,7 @@ __global__ __launch_bounds__(64 * NW) void gru_bwd_reg_kernel(const GruArgs a) {
         const float av = (ks & 3) == 0 ? av4[ks >> 2].x : (ks & 3) == 1 ? av4[ks >> 2].y : (ks & 3) == 2 ? av4[ks >> 2].z : av4[ks >> 2].w;
 #pragma unroll
         for (int tt = 0; tt < TW; ++tt)
-          acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wct[tt][ks], acc[tt], 0, 0, 0);
+          acc[tt] = GR_MFMA(av, wct[tt][ks], acc[tt]);
       }
 #pragma unroll
       for (int tt = 0; tt < TW; ++tt) {
@@ -589,8 +605,8 @@ __global__ __launch_bounds__(64 * NW) void gru_bwd_reg_kernel(const GruArgs a) {
           dh[i * LD + j] += live ? drh * rr : 0.f;
           if (rok[r]) {
             const int64_t row = rowb[r] + t;
-            sd.dxproj[row * 3 * H + j] = v_dpr;
-            sd.rh[row * H + j] = rr * hp;
+            GR_STORE(sd.dxproj[row * 3 * H + j], v_dpr);
+            GR_STORE(sd.rh[row * H + j], (rr * hp));
           }
           dpg[i * LD2 + j] = v_dpr;
         }
@@ -610,7 +626,7 @@ __global__ __launch_bounds__(64 * NW) void gru_bwd_reg_kernel(const GruArgs a) {
         const float av = (ks & 3) == 0 ? av4[ks >> 2].x : (ks & 3) == 1 ? av4[ks >> 2].y : (ks & 3) == 2 ? av4[ks >> 2].z : av4[ks >> 2].w;
 #pragma unroll
         for (int tt = 0; tt < TW; ++tt)
-          acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wgt[tt][ks], acc[tt], 0, 0, 0);
+          acc[tt] = GR_MFMA(av, wgt[tt][ks], acc[tt]);
       }
 #pragma unroll
       for (int tt = 0; tt < TW; ++tt) {
