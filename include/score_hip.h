@@ -238,9 +238,49 @@ int score_adam_rows_dev(float* p, float* m, float* v, const float* g, int64_t n_
  *   1  m or v nonzero, no gradient this step -> g = 0 (moments decay, p moves); g is not read
  *   2  gradient written this step (score_backward / score_segment_sum_rows set it) -> full
  *      update from g, then the state becomes 1
+ *   (3 exists only inside score_adam_catchup_ids: a live row the batch is about to read, see below)
  * g rows in state 0/1 are never read, so grad_table needs no zero fill between steps. */
 int score_adam_rows(float* p, float* m, float* v, const float* g, int64_t n_rows, int32_t D,
                     uint8_t* row_flags, float alpha, float beta1, float beta2, float eps, void* stream);
+
+/* ---- time-tiled ApplyAdam over the table ----------------------------------------------------------------------
+ * Dense ApplyAdam moves every live row every step, but the update of a row WITHOUT a gradient (m *= b1, v *= b2,
+ * p -= alpha_t m/(sqrt(v)+eps)) reads nothing except the row and the step's alpha.  These entry points apply such
+ * updates late, in step order, the first time a row is needed: the same fp32 operations in the same order as the
+ * sweep of score_adam_rows, so the table, m and v are bit-identical to it at every point where they are observed
+ * -- while a row's HBM traffic drops from once per step to once per use.  Nothing is skipped: every (row, step)
+ * update is executed exactly once.
+ *   row_step[r]   optimizer steps already applied to row r (meaningful for rows in state 1 / 2)
+ *   alpha_ring    SCORE_ADAM_RING + 1 floats: alpha of step s at [s % SCORE_ADAM_RING] (score_adam_touched writes
+ *                 it), and one sticky error word at [SCORE_ADAM_RING], nonzero if a row ever lagged more steps than
+ *                 the ring remembers (the caller's window sweep must keep every live row within
+ *                 SCORE_ADAM_RING - 2 steps)
+ * Protocol of step n (1-based), single table (no row sharding):
+ *   score_adam_catchup_ids(ids of the batch, upto = n-1)      before score_forward
+ *   score_adam_catchup_rows(slice n % window, upto = n-1)     any time after that call has finished and before
+ *                                                            the next step's catchup_ids; may run on another
+ *                                                            stream beside forward/backward/score_adam_touched
+ *   score_forward, score_backward (scatter_mode 0: rows with a gradient end in state 2)
+ *   score_adam_touched(step = n, alpha_n)                     state-2 rows: ApplyAdam from g, state 1, row_step n
+ * and score_adam_catchup_rows(0, n_rows, upto = n) before anything else reads p, m or v. */
+#define SCORE_ADAM_RING 64
+typedef struct {
+  float* p; float* m; float* v;   /* [n_rows, D] variable and its two Adam slots           */
+  const float* g;                 /* [n_rows, D] row gradients (rows in state 2 are valid) */
+  int64_t n_rows;
+  int32_t D;
+  int32_t reserved;
+  uint8_t* row_flags;             /* [n_rows] state bytes of score_adam_rows               */
+  uint32_t* row_step;             /* [n_rows]                                              */
+  float* alpha_ring;              /* [SCORE_ADAM_RING + 1]                                 */
+  float beta1, beta2, eps;
+} score_adam_table_t;
+int score_adam_touched(const score_adam_table_t* t, uint32_t step, float alpha, void* stream);
+/* every value of ids[0..n_ids) that names a live row (values outside [0, n_rows) are ignored, so a whole flat batch
+ * buffer may be passed): replay the zero-gradient steps row_step+1 .. upto of that row */
+int score_adam_catchup_ids(const score_adam_table_t* t, const int32_t* ids, int64_t n_ids, uint32_t upto, void* stream);
+/* the same for every state-1 row of [row_begin, row_end) */
+int score_adam_catchup_rows(const score_adam_table_t* t, int64_t row_begin, int64_t row_end, uint32_t upto, void* stream);
 
 /* ---- whole-path entry points --------------------------------------------- */
 

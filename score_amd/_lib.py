@@ -60,6 +60,15 @@ class BatchOut(C.Structure):
                                            "target_item", "label", "length")]
 
 
+class AdamTable(C.Structure):
+    """score_adam_table_t"""
+    _fields_ = [("p", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("g", C.c_void_p), ("n_rows", C.c_int64),
+                ("D", C.c_int32), ("reserved", C.c_int32), ("row_flags", C.c_void_p), ("row_step", C.c_void_p),
+                ("alpha_ring", C.c_void_p), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float)]
+
+
+ADAM_RING = 64          # SCORE_ADAM_RING
+
 _SIGS = {
     "score_context_create": [C.POINTER(C.c_void_p)],
     "score_context_destroy": [C.c_void_p],
@@ -93,6 +102,9 @@ _SIGS = {
                             C.c_float, C.c_void_p],
     "score_adam_rows": [c_f, c_f, c_f, c_f, C.c_int64, C.c_int32, C.c_void_p, C.c_float, C.c_float, C.c_float,
                         C.c_float, C.c_void_p],
+    "score_adam_touched": [C.POINTER(AdamTable), C.c_uint32, C.c_float, C.c_void_p],
+    "score_adam_catchup_ids": [C.POINTER(AdamTable), c_i, C.c_int64, C.c_uint32, C.c_void_p],
+    "score_adam_catchup_rows": [C.POINTER(AdamTable), C.c_int64, C.c_int64, C.c_uint32, C.c_void_p],
     "score_index_plan": [C.POINTER(Config), C.POINTER(State), C.POINTER(Batch), C.c_int32, C.c_int32, C.c_void_p],
     "score_segment_sum_rows": [c_i, c_f, C.c_int64, C.c_int32, C.c_int64, c_f, C.c_void_p, C.c_void_p, C.c_int64,
                                C.c_void_p],

@@ -1,0 +1,218 @@
+// Time-tiled ApplyAdam over the embedding table (score.py:96-99 applied to emb_mtx, dense).
+//
+// tf.train.AdamOptimizer on the masked dense table moves EVERY row each step: a row no sample of the batch used
+// still gets m *= beta1, v *= beta2, p -= alpha_t m / (sqrt(v) + eps).  In steady state that sweep is six fp32
+// streams over the whole table (2.35 GB at cfg-3, 0.48 ms of a 1.78 ms step) although a batch touches ~12 % of
+// the rows.  The zero-gradient update of a row reads nothing but the row itself and the step's alpha, so it can be
+// applied later, in step order, the first time anybody needs the row -- the same fp32 operations in the same
+// order, hence the same bits.  Per row we keep the number of optimizer steps already applied (row_step) and per
+// step its alpha (a ring of the last SCORE_ADAM_RING values); then
+//   score_adam_catchup_ids   before the forward: every row the batch is about to read is brought up to step n-1
+//   score_adam_touched       after the backward: rows with a gradient (state 2) get step n from g, like the sweep
+//   score_adam_catchup_rows  one 1/window slice of the table per step is brought up to date beside the forward,
+//                            so no row ever lags more than `window` steps; over the whole table it is the flush
+//                            that every observer of the table runs first (save, get_params, a dense step, ...)
+// A row's HBM traffic drops from once per step to once per use (plus once per window).  The arithmetic is not
+// skipped: each (row, step) update is executed exactly once, by whichever of the three gets to the row first.
+#include "common.h"
+#include "kernels.h"
+
+struct TiledArgs {
+  float* p; float* m; float* v; const float* g;
+  uint8_t* flags; uint32_t* step; float* ring;
+  int64_t n_rows; int D; int LPR;
+  float omb1, omb2, eps;
+};
+
+__device__ __forceinline__ int tiled_lane() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+// Sub-group `sg` of the wave takes the sg-th set bit of `mask` (a lane index), and the first `nper` set bits
+// leave the mask.  `mask` is wave-uniform, so is the loop.
+__device__ __forceinline__ int tiled_pick(uint64_t& mask, int sg, int nper) {
+  int src = -1;
+  for (int j = 0; j < nper && mask; ++j) {
+    const int b = __ffsll((long long)mask) - 1;
+    if (j == sg) src = b;
+    mask &= mask - 1;
+  }
+  return src;
+}
+__device__ __forceinline__ uint32_t tiled_wave_min(uint32_t x) {
+  for (int off = 32; off > 0; off >>= 1) {
+    const uint32_t y = (uint32_t)__shfl_xor((int)x, off, SCORE_WAVE);
+    x = y < x ? y : x;
+  }
+  return x;
+}
+
+// The lanes whose bit is set in `mask` each hold a row (my_row) to process; groups of LPR lanes take them over, up to
+// 64/LPR rows at a time.  MODE 0: one ApplyAdam with the row's gradient (step `upto`, alpha_now).  MODE 1 / 2: the
+// zero-gradient updates of steps my_old+1 .. upto; areg of lane L holds alpha of step upto - L (2: state 3 -> 1).
+template <int MODE>
+__device__ __forceinline__ void tiled_rows(const TiledArgs& a, uint64_t mask, int my_row, uint32_t my_old, uint32_t upto,
+                                           float alpha_now, float areg, int lane) {
+  const int nper = SCORE_WAVE / a.LPR, sg = lane / a.LPR, ch4 = (lane % a.LPR) * 4;
+  while (mask) {
+    const int src = tiled_pick(mask, sg, nper);
+    const int srcl = src < 0 ? 0 : src;
+    const int row = __shfl(my_row, srcl, SCORE_WAVE);
+    const uint32_t old = (uint32_t)__shfl((int)my_old, srcl, SCORE_WAVE);
+    const bool on = src >= 0 && ch4 < a.D;
+    const int64_t e = (int64_t)row * a.D + ch4;
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f), m = p, v = p, g = p;
+    if (on) {
+      p = ld4(a.p + e); m = ld4(a.m + e); v = ld4(a.v + e);
+      if (MODE == 0) g = ld4(a.g + e);
+    }
+    if (MODE == 0) {
+      if (on) {
+        score_adam1(p.x, m.x, v.x, g.x, a.omb1, a.omb2, alpha_now, a.eps);
+        score_adam1(p.y, m.y, v.y, g.y, a.omb1, a.omb2, alpha_now, a.eps);
+        score_adam1(p.z, m.z, v.z, g.z, a.omb1, a.omb2, alpha_now, a.eps);
+        score_adam1(p.w, m.w, v.w, g.w, a.omb1, a.omb2, alpha_now, a.eps);
+        st4(a.p + e, p); st4(a.m + e, m); st4(a.v + e, v);
+        if (ch4 == 0) { a.flags[row] = 1; a.step[row] = upto; }
+      }
+    } else {
+      const uint32_t smin = (uint32_t)__builtin_amdgcn_readfirstlane((int)tiled_wave_min(on ? old : upto));
+      // a lag beyond the ring cannot be replayed: raise the sticky error word behind the ring (the window sweep makes
+      // this unreachable; score_adam_catchup_rows' caller checks the word whenever it synchronises anyway)
+      if (upto - smin > SCORE_ADAM_RING - 1 && lane == 0) atomicOr(reinterpret_cast<unsigned int*>(a.ring + SCORE_ADAM_RING), 1u);
+      for (uint32_t s = smin + 1; s <= upto; ++s) {          // wave-uniform trip count: alpha comes from a lane read
+        const float al = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(areg), (int)(upto - s)));
+        if (on && s > old) {
+          score_adam1(p.x, m.x, v.x, 0.f, a.omb1, a.omb2, al, a.eps);
+          score_adam1(p.y, m.y, v.y, 0.f, a.omb1, a.omb2, al, a.eps);
+          score_adam1(p.z, m.z, v.z, 0.f, a.omb1, a.omb2, al, a.eps);
+          score_adam1(p.w, m.w, v.w, 0.f, a.omb1, a.omb2, al, a.eps);
+        }
+      }
+      if (on) {
+        st4(a.p + e, p); st4(a.m + e, m); st4(a.v + e, v);
+        if (ch4 == 0) {
+          a.step[row] = upto;
+          if (MODE == 2) a.flags[row] = 1;
+        }
+      }
+    }
+  }
+}
+
+// rows whose state byte is 2: the step's ApplyAdam from their gradient.  One lane per row scans the state bytes.
+__global__ __launch_bounds__(256) void adam_touched_kernel(const TiledArgs a, uint32_t step, float alpha) {
+  const int lane = tiled_lane();
+  if (blockIdx.x == 0 && threadIdx.x == 0) a.ring[step % SCORE_ADAM_RING] = alpha;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t base = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) - lane; base < a.n_rows; base += stride) {
+    const int64_t r = base + lane;
+    const bool hit = r < a.n_rows && a.flags[r] == 2;
+    const uint64_t mask = __ballot(hit);
+    tiled_rows<0>(a, mask, (int)r, 0u, step, alpha, 0.f, lane);
+  }
+}
+
+// live rows of [row_begin, row_end) that lag behind `upto`: replay what they missed.  State 2 rows are left alone:
+// they belong to the step in flight (score_adam_touched), and are current up to the step before by construction.
+__global__ __launch_bounds__(256) void adam_catchup_rows_kernel(const TiledArgs a, int64_t row_begin, int64_t row_end,
+                                                                uint32_t upto) {
+  const int lane = tiled_lane();
+  const float areg = a.ring[(upto - (uint32_t)lane) % SCORE_ADAM_RING];
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t base = row_begin + ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) - lane; base < row_end; base += stride) {
+    const int64_t r = base + lane;
+    uint32_t old = upto;
+    bool hit = false;
+    if (r < row_end && a.flags[r] == 1) {
+      old = a.step[r];
+      hit = old < upto;
+    }
+    const uint64_t mask = __ballot(hit);
+    tiled_rows<1>(a, mask, (int)r, old, upto, 0.f, areg, lane);
+  }
+}
+
+// score_adam_catchup_ids, first half: every value of ids[] that names a live row lagging behind `upto` puts that
+// row into state 3.  Plain byte stores, no claim: a padding id or a hot categorical row occurs 10^5..10^6 times in a
+// batch, and that many atomics on one address took 1.1 ms (an atomicMax claim on row_step was the first version);
+// same-address stores of a wave merge, and waves that arrive after the first store has landed read 3 and skip theirs.
+// Values outside [0, n_rows) are ignored, so the caller may pass a whole flat batch buffer (the lengths and labels
+// in it name low rows: catching a row up early is always valid).
+__global__ __launch_bounds__(256) void adam_mark_ids_kernel(const TiledArgs a, const int32_t* __restrict__ ids, int64_t n,
+                                                            uint32_t upto) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int row = ids[i];
+    if (row >= 0 && (int64_t)row < a.n_rows && a.flags[row] == 1 && a.step[row] < upto) a.flags[row] = 3;
+  }
+}
+// second half: the rows in state 3 are replayed up to `upto` and return to state 1 (the scan of score_adam_touched)
+__global__ __launch_bounds__(256) void adam_catchup_marked_kernel(const TiledArgs a, uint32_t upto) {
+  const int lane = tiled_lane();
+  const float areg = a.ring[(upto - (uint32_t)lane) % SCORE_ADAM_RING];
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t base = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) - lane; base < a.n_rows; base += stride) {
+    const int64_t r = base + lane;
+    const bool hit = r < a.n_rows && a.flags[r] == 3;
+    const uint32_t old = hit ? a.step[r] : upto;
+    const uint64_t mask = __ballot(hit);
+    tiled_rows<2>(a, mask, (int)r, old, upto, 0.f, areg, lane);
+  }
+}
+
+static int tiled_args(const score_adam_table_t* t, TiledArgs* a, bool need_g) {
+  if (!t || !t->p || !t->m || !t->v || (need_g && !t->g) || !t->row_flags || !t->row_step || !t->alpha_ring ||
+      t->n_rows <= 0 || t->n_rows > 0x7fffffffLL || t->D <= 0)
+    return SCORE_E_BADARG;
+  if ((t->D & 3) || t->D > 256) return SCORE_E_SHAPE;
+  if ((reinterpret_cast<uintptr_t>(t->p) | reinterpret_cast<uintptr_t>(t->m) | reinterpret_cast<uintptr_t>(t->v) |
+       reinterpret_cast<uintptr_t>(t->g)) & 15)
+    return SCORE_E_SHAPE;
+  a->p = t->p; a->m = t->m; a->v = t->v; a->g = t->g;
+  a->flags = t->row_flags; a->step = t->row_step; a->ring = t->alpha_ring;
+  a->n_rows = t->n_rows; a->D = t->D;
+  int LPR = 1;
+  while (LPR < t->D / 4) LPR <<= 1;
+  a->LPR = LPR;
+  a->omb1 = 1.0f - t->beta1; a->omb2 = 1.0f - t->beta2; a->eps = t->eps;
+  return 0;
+}
+static int tiled_blocks(int64_t n) {
+  const int64_t want = cdiv64(n, 256);
+  return (int)(want < 1 ? 1 : want < 32768 ? want : 32768);
+}
+
+extern "C" int score_adam_touched(const score_adam_table_t* t, uint32_t step, float alpha, void* stream) {
+  TiledArgs a;
+  SCORE_TRY(tiled_args(t, &a, true));
+  if (step == 0) return SCORE_E_BADARG;
+  hipLaunchKernelGGL(adam_touched_kernel, dim3(tiled_blocks(a.n_rows)), dim3(256), 0, (hipStream_t)stream, a, step, alpha);
+  SCORE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int score_adam_catchup_rows(const score_adam_table_t* t, int64_t row_begin, int64_t row_end, uint32_t upto,
+                                       void* stream) {
+  TiledArgs a;
+  SCORE_TRY(tiled_args(t, &a, false));
+  if (row_begin < 0 || row_end > a.n_rows || row_begin > row_end) return SCORE_E_BADARG;
+  if (row_begin == row_end) return 0;
+  hipLaunchKernelGGL(adam_catchup_rows_kernel, dim3(tiled_blocks(row_end - row_begin)), dim3(256), 0, (hipStream_t)stream,
+                     a, row_begin, row_end, upto);
+  SCORE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int score_adam_catchup_ids(const score_adam_table_t* t, const int32_t* ids, int64_t n_ids, uint32_t upto,
+                                      void* stream) {
+  TiledArgs a;
+  SCORE_TRY(tiled_args(t, &a, false));
+  if (!ids || n_ids < 0) return SCORE_E_BADARG;
+  if (n_ids == 0) return 0;
+  if (upto == 0) return 0;         // nothing has been applied yet: nothing can lag
+  hipLaunchKernelGGL(adam_mark_ids_kernel, dim3(tiled_blocks(cdiv64(n_ids, 4))), dim3(256), 0, (hipStream_t)stream, a, ids,
+                     n_ids, upto);
+  SCORE_CHECK_LAUNCH();
+  hipLaunchKernelGGL(adam_catchup_marked_kernel, dim3(tiled_blocks(a.n_rows)), dim3(256), 0, (hipStream_t)stream, a, upto);
+  SCORE_CHECK_LAUNCH();
+  return 0;
+}

@@ -42,6 +42,15 @@ __device__ __forceinline__ float4 fma4(float s, float4 a, float4 acc) {
 __device__ __forceinline__ float4 add4(float4 a, float4 b) {
   return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
 }
+// tf.train.AdamOptimizer's ApplyAdam on one element (TF training_ops): m += (g - m)(1-b1); v += (g*g - v)(1-b2);
+// var -= m*alpha / (sqrt(v) + eps).  The contractions are spelled out so that every kernel applying it (the dense
+// sweeps in head.hip, the time-tiled ones in adam_tiled.hip) rounds the same way whatever the compiler would choose.
+__device__ __forceinline__ void score_adam1(float& p, float& m, float& v, float g, float omb1, float omb2, float alpha,
+                                            float eps) {
+  m = __builtin_fmaf(g - m, omb1, m);
+  v = __builtin_fmaf(__builtin_fmaf(g, g, -v), omb2, v);
+  p = p - (m * alpha) / (sqrtf(v) + eps);
+}
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // sum over the `gs` (power of two <= 64) consecutive lanes of a group; every lane gets the sum

@@ -570,12 +570,7 @@ int score_launch_gru_wxcat(const float* gk0, const float* ck0, const float* gb0,
 }
 // ------------------------------------------------------------------ ApplyAdam (score.py:96-99)
 // TF training_ops: m += (g - m)(1-b1); v += (g*g - v)(1-b2); var -= m*alpha / (sqrt(v) + eps)
-__device__ __forceinline__ void adam1(float& p, float& m, float& v, float g, float omb1, float omb2, float alpha,
-                                      float eps) {
-  m += (g - m) * omb1;
-  v += (g * g - v) * omb2;
-  p -= (m * alpha) / (sqrtf(v) + eps);
-}
+#define adam1 score_adam1     /* common.h */
 __global__ void adam_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
                             const float* __restrict__ g, int64_t n4, int64_t n, int64_t n_reg, float l2, float alpha,
                             float omb1, float omb2, float eps, const float* __restrict__ alpha_dev) {

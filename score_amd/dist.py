@@ -156,6 +156,7 @@ class TorchDistComm(object):
 class _ShardModel(SCOREBASE):
     """SCOREBASE whose `table` is one row shard: local row i holds global row i*G + rank."""
     model_type = "SCORE"
+    _tiled_supported = False     # a shard's optimizer is the per-step sweep over its own rows (1/G of the table)
 
     def __init__(self, rank, world, model_type, feature_size, *args, **kw):
         self.model_type = model_type

@@ -147,7 +147,16 @@ class SCOREBASE(object):
         # allocations (tools/adam_layout_probe.py: 0.44-0.47 vs 0.47-0.51 ms at cfg-3)
         rows = self._table_rows(N)
         self._table_block = torch.empty((4, rows, D), **f32)
-        self.table = self._table_block[0]
+        self._tbl = self._table_block[0]
+        # time-tiled table optimizer (include/score_hip.h, score_adam_table_t): live rows without a gradient are
+        # updated the next time they are needed (or once per `adam_window` steps) instead of every step.  Bit-identical
+        # to the per-step sweep wherever the table is observed; 0 = sweep the whole table every step
+        self.adam_window = int(os.environ.get("SCORE_ADAM_WINDOW", "16"))
+        self._adam_dirty = False     # live rows may lag behind self.step (row_step says by how much)
+        self._tiled_ready = False    # row_step / alpha_ring describe the table
+        self._tiled = None           # (row_step, alpha_ring, score_adam_table_t)
+        self._pending_sweep = None   # (row range, step, event) of the window slice not launched yet
+        self._ev_sweep = None
         self.w = torch.zeros((self.n_w,), **f32)
         self._alloc_optimizer()
         self._ws = {}              # (B, slot) -> (layout, buffer), least recently used first
@@ -178,6 +187,27 @@ class SCOREBASE(object):
         """rows of emb_mtx this object holds (a row shard overrides it, score_amd/dist.py)"""
         return feature_size
 
+    # emb_mtx and its Adam slots as everybody outside the training step sees them: brought up to date first
+    @property
+    def table(self):
+        self._flush_adam()
+        return self._tbl
+
+    @table.setter
+    def table(self, t):
+        self._flush_adam()
+        self._tbl, self._tiled, self._tiled_ready = t, None, False
+
+    @property
+    def table_m(self):
+        self._flush_adam()
+        return self._tbl_m
+
+    @property
+    def table_v(self):
+        self._flush_adam()
+        return self._tbl_v
+
     def __del__(self):
         ctx, self._ctx = getattr(self, "_ctx", None), None
         if ctx is not None and ctx.value and getattr(self, "lib", None) is not None:
@@ -189,10 +219,10 @@ class SCOREBASE(object):
     # ------------------------------------------------------------------ parameters
     def _alloc_optimizer(self):
         f32 = dict(dtype=torch.float32, device=self.device)
-        self.table_m, self.table_v, self.table_g = self._table_block[1], self._table_block[2], self._table_block[3]
+        self._tbl_m, self._tbl_v, self.table_g = self._table_block[1], self._table_block[2], self._table_block[3]
         self._table_block[1:].zero_()
         # per-row optimizer state byte (score_adam_rows): 0 = moments zero, 1 = live, 2 = gradient this step
-        self.table_flags = torch.zeros((self.table.shape[0],), dtype=torch.uint8, device=self.device)
+        self.table_flags = torch.zeros((self._tbl.shape[0],), dtype=torch.uint8, device=self.device)
         self._row_grads = False      # table_g holds valid rows only where table_flags == 2
         self._flags_marked = False   # table_flags may hold 2s
         self.w_m = torch.zeros((self.n_w,), **f32)
@@ -291,6 +321,7 @@ class SCOREBASE(object):
         self.table_flags.copy_(live.to(torch.uint8))
         self._row_grads = False
         self._flags_marked = False
+        self._tiled_ready = False
 
     def get_dense_grads(self):
         """Gradients of the dense variables only (no [N, D] host copy of the table's)."""
@@ -322,7 +353,7 @@ class SCOREBASE(object):
         return ent
 
     def _state(self, ws):
-        return _lib.State(table=_ptr(self.table), n_table_rows=self.table.shape[0], w=_ptr(self.w), workspace=_ptr(ws),
+        return _lib.State(table=_ptr(self._tbl), n_table_rows=self._tbl.shape[0], w=_ptr(self.w), workspace=_ptr(ws),
                           workspace_bytes=ws.numel() * 4, scatter_mode=int(self.scatter_mode),
                           global_batch=int(self.global_batch), gemm_mode=int(self.gemm_mode),
                           debug_flags=int(self.debug_flags),
@@ -362,9 +393,13 @@ class SCOREBASE(object):
         return buf[off:off + n].view(*shape)
 
     # ------------------------------------------------------------------ forward / backward / update
-    def _forward(self, db, reg_lambda, keep_prob, masks, gather_event=None):
+    def _forward(self, db, reg_lambda, keep_prob, masks, gather_event=None, sweep=False):
         lay, ws = self._workspace(db.B)
         st = self._state(ws)
+        if self._tiled_on():
+            self._catchup(db, sweep)
+        else:
+            self._flush_adam()
         if gather_event is not None:
             st.gather_done_event = C.c_void_p(gather_event.cuda_event)
         m0 = m1 = None
@@ -400,7 +435,8 @@ class SCOREBASE(object):
         if early:
             ev_start = cur.record_event()
         lay, ws, st = self._forward(db, reg_lambda, keep_prob, dropout_masks,
-                                    gather_event=self._ev_gather if (self.scatter_mode == 0 and not early) else None)
+                                    gather_event=self._ev_gather if (self.scatter_mode == 0 and not early) else None,
+                                    sweep=True)
         if self.scatter_mode == 0:
             # occurrence sort for the pull-form scatter: depends on the indices only.  It runs on a side
             # stream from the start of the forward (see above), under the gather / GRUs / attention / head and
@@ -414,6 +450,7 @@ class SCOREBASE(object):
                 plan_done = self._side.record_event()
             st.plan_done_event = C.c_void_p(plan_done.cuda_event)
             self._plan_done = plan_done                  # keep the event alive until the backward has run
+            self._launch_sweep(self._side)               # time-tiled optimizer: this step's slice of the table
         if self.scatter_mode == 0:
             self._begin_row_grads()         # the pull kernels mark what they write; no zero fill
         else:
@@ -432,28 +469,133 @@ class SCOREBASE(object):
     def apply_adam(self, lr, reg_lambda):
         """tf.train.AdamOptimizer(lr).minimize(loss) update (score.py:96-99): dense over the
         whole table (the emb_mtx*mask gradient is dense) and over every dense variable."""
-        self.adam_table(lr)
+        if self._tiled_on() and self._row_grads:
+            self._adam_table_tiled(lr)
+        else:
+            self.adam_table(lr)
         self.adam_dense(lr, reg_lambda)
         self.adam_advance()
+
+    # ------------------------------------------------------------------ time-tiled table optimizer
+    _tiled_supported = True          # (a row shard sweeps its own rows: score_amd/dist.py)
+
+    def _tiled_on(self):
+        return self.adam_window > 0 and self._tiled_supported and self.scatter_mode == 0 and not self._use_dev_scalars
+
+    def _tiled_table(self):
+        if self._tiled is None:
+            if not 2 <= self.adam_window <= _lib.ADAM_RING - 2:
+                raise ValueError("adam_window must be 0 (off) or 2..%d" % (_lib.ADAM_RING - 2))
+            row_step = torch.zeros((self._tbl.shape[0],), dtype=torch.int32, device=self.device)
+            ring = torch.zeros((_lib.ADAM_RING + 1,), dtype=torch.float32, device=self.device)
+            T = _lib.AdamTable(p=_ptr(self._tbl), m=_ptr(self._tbl_m), v=_ptr(self._tbl_v), g=_ptr(self.table_g),
+                               n_rows=self._tbl.shape[0], D=self._tbl.shape[1], row_flags=_ptr(self.table_flags),
+                               row_step=_ptr(row_step), alpha_ring=_ptr(ring), beta1=ADAM_B1, beta2=ADAM_B2, eps=ADAM_EPS)
+            self._tiled = (row_step, ring, T)
+            self._tiled_ready = False
+        return self._tiled
+
+    def _join_sweep(self, cur):
+        if self._ev_sweep is not None:
+            cur.wait_event(self._ev_sweep)
+            self._ev_sweep = None
+
+    def _catchup(self, db, sweep):
+        """Before a forward: the rows this batch reads are brought up to self.step (score_adam_catchup_ids); in a
+        training step the window's slice of the table follows on its own stream, beside the step."""
+        if not self._adam_dirty:
+            return
+        _, _, T = self._tiled_table()
+        cur = torch.cuda.current_stream(self.device)
+        self._join_sweep(cur)
+        if self._flags_marked:
+            self._drop_row_marks()        # (a backward nobody applied left state-2 marks)
+        upto = int(self.step)
+        if db.flat is not None:
+            spans = [db.flat]
+        else:
+            spans = list(db.tensors[:6])
+        for t in spans:
+            _lib.check(self.lib.score_adam_catchup_ids(C.byref(T), _ptr(t), t.numel(), upto, self._stream()),
+                       "score_adam_catchup_ids")
+        if sweep:
+            # the window's slice of the table: must start after the rows above are done (it would take them for lagging
+            # ones) and finish before the next step's catch-up; forward_backward puts it behind the occurrence sort on
+            # the side stream, where it runs beside the recurrences (beside the HBM-bound gather it cost the gather
+            # 0.05 ms; SCORE_ADAM_SWEEP_INLINE=1 runs it on the main stream instead: measured 0.03 ms/step slower)
+            rows, K = self._tbl.shape[0], self.adam_window
+            j = (upto + 1) % K
+            self._pending_sweep = (rows * j // K, rows * (j + 1) // K, upto, cur.record_event())
+            if os.environ.get("SCORE_ADAM_SWEEP_INLINE"):
+                self._launch_sweep(cur)
+
+    def _launch_sweep(self, stream):
+        if self._pending_sweep is None:
+            return
+        lo, hi, upto, after = self._pending_sweep
+        self._pending_sweep = None
+        _, _, T = self._tiled
+        cur = torch.cuda.current_stream(self.device)
+        if stream is not cur:
+            stream.wait_event(after)
+        _lib.check(self.lib.score_adam_catchup_rows(C.byref(T), lo, hi, upto, C.c_void_p(stream.cuda_stream)),
+                   "score_adam_catchup_rows")
+        if stream is not cur:
+            self._ev_sweep = stream.record_event()
+
+    def _adam_table_tiled(self, lr):
+        """ApplyAdam of step self.step + 1 on the rows that have a gradient; every other live row owes it."""
+        row_step, ring, T = self._tiled_table()
+        if not self._tiled_ready:
+            # (only reached with no row lagging: _flush_adam ran, or nothing tiled has happened yet)
+            row_step.fill_(int(self.step))
+            self._tiled_ready = True
+        _lib.check(self.lib.score_adam_touched(C.byref(T), int(self.step) + 1, self._alpha(lr), self._stream()),
+                   "score_adam_touched")
+        self._row_grads = False
+        self._flags_marked = False
+        self._adam_dirty = True
+
+    def _flush_adam(self):
+        """Every live row up to self.step: what any reader of table / table_m / table_v other than the training
+        step itself sees first (no-op unless tiled steps have run since the last flush)."""
+        if not self._adam_dirty:
+            return
+        self._adam_dirty = False
+        self._pending_sweep = None
+        _, ring, T = self._tiled
+        cur = torch.cuda.current_stream(self.device)
+        self._join_sweep(cur)
+        if self._flags_marked:
+            self._drop_row_marks()
+        _lib.check(self.lib.score_adam_catchup_rows(C.byref(T), 0, self._tbl.shape[0], int(self.step), self._stream()),
+                   "score_adam_catchup_rows")
+        if int(ring[_lib.ADAM_RING].view(torch.int32).item()) != 0:
+            raise RuntimeError("time-tiled Adam: a row lagged more steps than the alpha ring holds")
 
     def adam_table(self, lr):
         """ApplyAdam over the table (shard) on the current stream: needs the row gradients only."""
         a = self._alpha(lr)
         s = self._stream()
+        marked = self._flags_marked
+        self._flags_marked = False          # (the flush must not take this step's state-2 marks for stale ones)
+        self._flush_adam()
+        self._flags_marked = marked
+        self._tiled_ready = False           # a sweep moves every row: row_step no longer describes the table
         if self._row_grads:
             if self._use_dev_scalars:
-                rc = self.lib.score_adam_rows_dev(_ptr(self.table), _ptr(self.table_m), _ptr(self.table_v),
-                                                  _ptr(self.table_g), self.table.shape[0], self.table.shape[1],
+                rc = self.lib.score_adam_rows_dev(_ptr(self._tbl), _ptr(self._tbl_m), _ptr(self._tbl_v),
+                                                  _ptr(self.table_g), self._tbl.shape[0], self._tbl.shape[1],
                                                   _ptr(self.table_flags), _ptr(self._scalars), ADAM_B1, ADAM_B2, ADAM_EPS, s)
             else:
-                rc = self.lib.score_adam_rows(_ptr(self.table), _ptr(self.table_m), _ptr(self.table_v),
-                                              _ptr(self.table_g), self.table.shape[0], self.table.shape[1],
+                rc = self.lib.score_adam_rows(_ptr(self._tbl), _ptr(self._tbl_m), _ptr(self._tbl_v),
+                                              _ptr(self.table_g), self._tbl.shape[0], self._tbl.shape[1],
                                               _ptr(self.table_flags), a, ADAM_B1, ADAM_B2, ADAM_EPS, s)
             self._row_grads = False
             self._flags_marked = False
         else:
-            rc = self.lib.score_adam(_ptr(self.table), _ptr(self.table_m), _ptr(self.table_v), _ptr(self.table_g),
-                                     self.table.numel(), 0, 0.0, a, ADAM_B1, ADAM_B2, ADAM_EPS, s)
+            rc = self.lib.score_adam(_ptr(self._tbl), _ptr(self._tbl_m), _ptr(self._tbl_v), _ptr(self.table_g),
+                                     self._tbl.numel(), 0, 0.0, a, ADAM_B1, ADAM_B2, ADAM_EPS, s)
             self.table_flags.fill_(1)       # dense sweep: any row may carry moments now
             self._flags_marked = False
         _lib.check(rc, "score_adam(table)")

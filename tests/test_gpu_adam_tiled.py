@@ -1,0 +1,117 @@
+"""The time-tiled table optimizer (score_adam_touched / score_adam_catchup_ids / score_adam_catchup_rows,
+include/score_hip.h) against the per-step dense ApplyAdam sweep it replaces (score.py:96-99 on emb_mtx):
+the table and both Adam slots must be BIT-identical wherever they are observed -- after any number of
+steps, with evals in between, through save/restore, and when switching between the two."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import score_oracle as so
+from helpers import batch_tuple, random_batch
+
+pytestmark = pytest.mark.gpu
+
+
+def make(cfg, window, seed=5):
+    from score_amd.model import MODELS
+    m = MODELS[cfg.model_type](cfg.N, cfg.D, cfg.H, cfg.T, cfg.K, cfg.Fu, cfg.Fi, seed=seed)
+    m.adam_window = window
+    return m
+
+
+def batches(cfg, n, B, seed, hot_rows=None):
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        b = random_batch(rng, cfg, B)
+        if hot_rows is not None and i % 3:        # most batches draw from a small hot set: the rest of the table lags
+            for k in ("user_1hop", "user_2hop", "item_1hop", "item_2hop", "target_user", "target_item"):
+                b[k] = np.where(b[k] > 0, 1 + b[k] % hot_rows, 0).astype(np.int32)
+        out.append(batch_tuple(b))
+    return out
+
+
+def same_state(a, b):
+    ok = torch.equal(a.table, b.table) and torch.equal(a.table_m, b.table_m) and torch.equal(a.table_v, b.table_v)
+    return ok and torch.equal(a.w, b.w) and torch.equal(a.w_m, b.w_m)
+
+
+@pytest.mark.parametrize("D,window", [(16, 2), (16, 5), (64, 16), (32, 7)])
+def test_bitwise_equal_to_dense_sweep(D, window):
+    cfg = so.Cfg(6000, D, 32, 6, 4, 2, 3, "SCORE")
+    dense, tiled = make(cfg, 0), make(cfg, window)
+    assert same_state(dense, tiled)
+    bs = batches(cfg, 45, 24, seed=3, hot_rows=300)
+    ev = batches(cfg, 2, 16, seed=9)
+    for i, b in enumerate(bs):
+        ld = dense.train(None, b, 1e-2, 1e-4, keep_prob=0.8)
+        lt = tiled.train(None, b, 1e-2, 1e-4, keep_prob=0.8)
+        assert ld == lt, (i, ld, lt)                 # the forward saw the same rows
+        if i in (6, 30):                             # eval between steps reads rows the training batches may not have
+            pd, _, xd = dense.eval(None, ev[0], 1e-4)
+            pt, _, xt = tiled.eval(None, ev[0], 1e-4)
+            assert pd == pt and xd == xt
+        if i in (12, 44):
+            assert tiled._adam_dirty
+            assert same_state(dense, tiled), i       # (reading .table flushes)
+            assert not tiled._adam_dirty
+    # rows really lagged in between: the raw table differs from the flushed one right after a step
+    tiled.train(None, bs[1], 1e-2, 1e-4)
+    dense.train(None, bs[1], 1e-2, 1e-4)
+    raw = tiled._tbl.clone()
+    assert not torch.equal(raw, dense.table)
+    assert same_state(dense, tiled)
+
+
+def test_switching_modes_and_checkpoint(tmp_path):
+    cfg = so.Cfg(3000, 16, 32, 5, 3, 2, 2, "SCORE")
+    dense, tiled = make(cfg, 0), make(cfg, 4)
+    bs = batches(cfg, 30, 16, seed=11, hot_rows=200)
+    for i, b in enumerate(bs):
+        if i == 8:
+            tiled.adam_window = 0        # back to the sweep ...
+        if i == 14:
+            tiled.adam_window = 6        # ... and to a different window
+        if i == 20:                      # through a checkpoint into a fresh object
+            tiled.save(None, str(tmp_path / "ck"))
+            tiled = make(cfg, 6)         # (same dropout stream; the variables come from the checkpoint)
+            tiled._tbl.zero_()
+            tiled.restore(None, str(tmp_path / "ck"))
+        if i == 25:                      # gradients without an update in between (marks nobody consumed)
+            tiled.forward_backward(b, 1e-4, 1.0)
+            dense.forward_backward(b, 1e-4, 1.0)
+        assert dense.train(None, b, 5e-3, 1e-4) == tiled.train(None, b, 5e-3, 1e-4), i
+    assert same_state(dense, tiled)
+    p_d, p_t = dense.get_params(), tiled.get_params()
+    assert all(np.array_equal(p_d[k], p_t[k]) for k in p_d)
+
+
+def test_fresh_rows_and_abi_errors():
+    """rows the optimizer has never seen (state 0) stay bit-identical to their initial value until a batch uses them;
+    the entry points reject what they cannot run"""
+    from score_amd import _lib
+    cfg = so.Cfg(4000, 16, 32, 4, 3, 1, 1, "SCORE")
+    tiled = make(cfg, 3)
+    init = tiled.table.clone()
+    bs = batches(cfg, 10, 8, seed=2, hot_rows=100)
+    for b in bs:
+        tiled.train(None, b, 1e-2, 1e-4)
+    flags = tiled.table_flags.cpu().numpy()
+    t = tiled.table
+    assert (flags == 0).sum() > 1000
+    assert torch.equal(t[torch.from_numpy(flags == 0).to(t.device)], init[torch.from_numpy(flags == 0).to(t.device)])
+    lib = _lib.load()
+    _, _, T = tiled._tiled_table()
+    bad = _lib.AdamTable.from_buffer_copy(T)
+    bad.D = 18
+    assert lib.score_adam_touched(C.byref(bad), 1, 0.1, None) != 0
+    assert lib.score_adam_touched(C.byref(T), 0, 0.1, None) != 0
+    assert lib.score_adam_catchup_rows(C.byref(T), 5, 3, 1, None) != 0
+    assert lib.score_adam_catchup_rows(C.byref(T), 0, cfg.N + 1, 1, None) != 0
+    assert lib.score_adam_catchup_ids(C.byref(T), None, 4, 1, None) != 0
+    with pytest.raises(ValueError):
+        m = make(cfg, 63)
+        m._tiled_table()

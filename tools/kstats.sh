@@ -11,4 +11,4 @@ tot = sum(float(r["TotalDurationNs"]) for r in rows)
 for r in rows[:28]:
     print("%-64s n=%4s avg=%9.1f us %5.1f%%" % (r["Name"][:64], r["Calls"], float(r["AverageNs"]) / 1e3, 100 * float(r["TotalDurationNs"]) / tot))
 PY
-tail -1 $O/run.log | python3 -c "import sys,json; j=json.loads(sys.stdin.read()); print(round(j['value']), round(j['ms_per_step'],3), {k:(round(v,3) if v else v) for k,v in j['stages_ms'].items()})"
+grep '^{' $O/run.log | tail -1 | python3 -c "import sys,json; j=json.loads(sys.stdin.read()); print(round(j['value']), round(j['ms_per_step'],3), {k:(round(v,3) if v else v) for k,v in j['stages_ms'].items()})"
