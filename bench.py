@@ -8,9 +8,11 @@ A "step" is one full training step of SCORE (score.py:101-116: forward, backward
 whole table and all dense variables) on one synthetic Tmall-shaped batch whose int32 index tensors are
 already resident in HBM.  Prints ONE JSON line (rank 0).
 
-`value` is the STEADY STATE of a long run: every table row carries Adam moments (dense ApplyAdam then moves six
-fp32 streams over the whole table every step -- in a short run from a fresh optimizer only the rows touched so
-far do), all other state as the loader produces it (length = T - 2 for every sample, mirroring the reference's
+`value` is the STEADY STATE of a long run: every table row carries Adam moments (dense ApplyAdam then owes every
+row an update every step -- in a short run from a fresh optimizer only the rows touched so far).  The table
+optimizer is the time-tiled one (score_amd/csrc/adam_tiled.hip: bit-identical to the per-step sweep, which
+`value_dense_adam_sweep` times in the same process; updates still owed after the last step are applied inside
+the timed region), all other state as the loader produces it (length = T - 2 for every sample, mirroring the reference's
 train split 9 of 11, graph_loader.py:382; the slices every sample masks are skipped).  Beside it, in the same
 line and measured in the same process: `value_best_case` (fresh optimizer state), `value_all_slices` (nothing
 skipped), `ingestion` (device-side batch assembly inside the loop; nested Python lists as the reference feeds
@@ -286,9 +288,10 @@ def main():
         for i in range(first, first + n):
             e_a0 = e_a1 = None
             if events is not None and i in events:
-                model.fwd_events, model.bwd_events, e_a0, e_a1 = events[i]
+                model.fwd_events, model.bwd_events, e_a0, e_a1 = events[i][:4]
+                inner.catchup_events = events[i][4:6]
             elif events is not None:
-                model.fwd_events = model.bwd_events = None
+                model.fwd_events = model.bwd_events = inner.catchup_events = None
             if sharded:   # optionally run the next batch's index-only phase (plan + row requests) inside this step
                 nxt = batches[(i + 1) % len(batches)] if (args.prefetch and i + 1 < first + n) else None
                 # with a next batch the step is pipelined: the optimizer runs inside (apply_adam below is then a no-op)
@@ -303,6 +306,13 @@ def main():
                 e_a1.record()
         return fb
 
+    def finish_adam():
+        """time-tiled table optimizer: apply every update still owed (score_adam_catchup_rows over the whole table)"""
+        f = getattr(inner, "_flush_adam", None)
+        if f is not None:
+            f()
+    tiled = bool(getattr(inner, "_tiled_on", lambda: False)()) and not graph
+
     # ---------------------------------------------------------------- headline: steady state
     if not args.fresh_state:
         inner.table_flags.fill_(1)      # every row carries Adam moments: the state a long run converges to
@@ -313,11 +323,11 @@ def main():
         if i % every:
             continue
         model.enable_stage_events(True)
-        events[i] = (model.fwd_events, model.bwd_events, torch.cuda.Event(enable_timing=True),
-                     torch.cuda.Event(enable_timing=True))
+        events[i] = (model.fwd_events, model.bwd_events) + tuple(torch.cuda.Event(enable_timing=True) for _ in range(4))
     barrier()
     t0 = time.perf_counter()
     fb = run_steps(args.steps, 0, None if graph else events)
+    finish_adam()                  # inside the timed region: no update is left owing when the clock stops
     barrier()
     dt = time.perf_counter() - t0
     if graph:                      # stage timings from eager steps, outside the timed region
@@ -353,6 +363,8 @@ def main():
         "bwd_weight_grads": avg(lambda s: s[1][4].elapsed_time(s[1][5])),
         "adam_table_and_dense": avg(lambda s: s[2].elapsed_time(s[3])),
     }
+    if tiled:      # the rows of the batch brought up to date before the forward (outside every stage above)
+        stages["adam_catchup_batch_rows"] = avg(lambda s: s[4].elapsed_time(s[5]))
     A = int(getattr(batches[0], "active_slices", 0)) or T      # slices the gather really reads
     ev_overhead_ms = event_pair_overhead_ms()
     ab, R = alg_bytes_per_sample(A, K, D, Fu, Fi)
@@ -369,7 +381,14 @@ def main():
         model.forward_backward(batches[0], args.reg_lambda, 0.8)
         touched = int((inner.table_flags == 2).sum().item())
         inner._drop_row_marks()
-    adam_bytes = 4 * D * (6 * live_rows + touched) + rows_local + 7 * 4 * n_w
+    if tiled:   # score_adam_touched: p, m, v read and written + g read on the rows with a gradient; state-byte scan; dense vars
+        adam_bytes = 4 * D * 7 * touched + rows_local + 7 * 4 * n_w
+        adam_name = ("adam_touched (time-tiled optimizer: 7 fp32 streams over the rows with a gradient, the state-byte scan, "
+                     "+ dense vars; the owed zero-gradient updates run in adam_catchup_batch_rows and, beside the step, in "
+                     "score_adam_catchup_rows)")
+    else:
+        adam_bytes = 4 * D * (6 * live_rows + touched) + rows_local + 7 * 4 * n_w
+        adam_name = "adam_rows (6 fp32 streams over the live table rows, + g on touched rows, + dense vars)"
     adam_timed = stages["adam_table_and_dense"] > 1e-3        # (pipelined sharded step: the update runs inside the step)
     if not adam_timed:
         stages["adam_table_and_dense"] = None
@@ -386,6 +405,7 @@ def main():
             torch.cuda.synchronize()
             t = time.perf_counter()
             run_steps(n)
+            finish_adam()
             torch.cuda.synchronize()
             return (time.perf_counter() - t) / n
         # (a) all time slices computed, every row live
@@ -407,6 +427,13 @@ def main():
         side["value_best_case"] = B / s_best
         side["best_case_live_row_frac"] = int((model.table_flags > 0).sum().item()) / float(rows_local)
         model.table_flags.fill_(1)
+        if tiled:
+            # (b2) the per-step dense sweep the time-tiled optimizer replaces (bit-identical results), same state
+            w_ = inner.adam_window
+            inner.adam_window = 0
+            run_steps(3)
+            side["value_dense_adam_sweep"] = B / timed(k2)
+            inner.adam_window = w_
         # (c) low-duplication gather probe
         try:
             pr = gather_probe(model, kw, B, args.probe_rows, 20)
@@ -496,7 +523,13 @@ def main():
                    "optimizer_state": ("fresh (best case): only rows touched during the run carry Adam moments"
                                        if args.fresh_state else
                                        "steady state: every table row carries Adam moments (live_row_frac 1.0), so dense "
-                                       "ApplyAdam moves six fp32 streams over the whole table every step"),
+                                       "ApplyAdam owes every row an update every step"),
+                   "table_optimizer": (("time-tiled ApplyAdam, window %d (include/score_hip.h: the zero-gradient update of a "
+                                        "row is applied when the row is next read, or once per window, in step order: "
+                                        "bit-identical to the per-step sweep, tests/test_gpu_adam_tiled.py; every update "
+                                        "still owed when the timed steps end is applied INSIDE the timed region); "
+                                        "value_dense_adam_sweep is the same run with the per-step sweep") % inner.adam_window
+                                       if tiled else "dense ApplyAdam sweep over the live rows every step"),
                    "live_row_frac": headline_live_frac,
                    "table": "row-sharded row%%G over %d GPU(s)" % world_size if world_size > 1 else "single GPU",
                    "final_loss": loss},
@@ -516,7 +549,7 @@ def main():
                      "time_slices_gathered": A, "time_slices_fed": T,
                      "algorithmic_bytes_per_launch_if_all_fed_slices_were_gathered": ab_full * B},
         "roofline_other": {
-            "adam_rows (6 fp32 streams over the live table rows, + g on touched rows, + dense vars)": {
+            adam_name: {
                 "live_row_frac": headline_live_frac, "rows_with_gradient_per_step": touched,
                 "bound": "hbm", "achieved": adam_bytes / (stages["adam_table_and_dense"] * 1e-3) / 1e9 if adam_timed else None,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -156,6 +156,7 @@ class SCOREBASE(object):
         self._tiled_ready = False    # row_step / alpha_ring describe the table
         self._tiled = None           # (row_step, alpha_ring, score_adam_table_t)
         self._pending_sweep = None   # (row range, step, event) of the window slice not launched yet
+        self.catchup_events = None   # optional (start, end) torch events around score_adam_catchup_ids (bench.py)
         self._ev_sweep = None
         self.w = torch.zeros((self.n_w,), **f32)
         self._alloc_optimizer()
@@ -503,7 +504,10 @@ class SCOREBASE(object):
     def _catchup(self, db, sweep):
         """Before a forward: the rows this batch reads are brought up to self.step (score_adam_catchup_ids); in a
         training step the window's slice of the table follows on its own stream, beside the step."""
+        ev = self.catchup_events
         if not self._adam_dirty:
+            if ev:
+                ev[0].record(); ev[1].record()
             return
         _, _, T = self._tiled_table()
         cur = torch.cuda.current_stream(self.device)
@@ -511,6 +515,8 @@ class SCOREBASE(object):
         if self._flags_marked:
             self._drop_row_marks()        # (a backward nobody applied left state-2 marks)
         upto = int(self.step)
+        if ev:
+            ev[0].record()
         if db.flat is not None:
             spans = [db.flat]
         else:
@@ -518,6 +524,8 @@ class SCOREBASE(object):
         for t in spans:
             _lib.check(self.lib.score_adam_catchup_ids(C.byref(T), _ptr(t), t.numel(), upto, self._stream()),
                        "score_adam_catchup_ids")
+        if ev:
+            ev[1].record()
         if sweep:
             # the window's slice of the table: must start after the rows above are done (it would take them for lagging
             # ones) and finish before the next step's catch-up; forward_backward puts it behind the occurrence sort on
