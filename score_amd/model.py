@@ -152,6 +152,10 @@ class SCOREBASE(object):
         # updated the next time they are needed (or once per `adam_window` steps) instead of every step.  Bit-identical
         # to the per-step sweep wherever the table is observed; 0 = sweep the whole table every step
         self.adam_window = int(os.environ.get("SCORE_ADAM_WINDOW", "16"))
+        # ... and only where the sweep is worth replacing: its six streams over the table against two extra scans of
+        # the state bytes and three more launches per step (cfg-2's 62 MB table: 0.391 ms/step swept, 0.425 tiled;
+        # the reference's own shape, 587 MB: 0.513 -> 0.466; cfg-3, 2.35 GB: 1.76 -> 1.48)
+        self.adam_tiled_min_bytes = int(os.environ.get("SCORE_ADAM_TILED_MIN_BYTES", str(256 << 20)))
         self._adam_dirty = False     # live rows may lag behind self.step (row_step says by how much)
         self._tiled_ready = False    # row_step / alpha_ring describe the table
         self._tiled = None           # (row_step, alpha_ring, score_adam_table_t)
@@ -481,7 +485,8 @@ class SCOREBASE(object):
     _tiled_supported = True          # (a row shard sweeps its own rows: score_amd/dist.py)
 
     def _tiled_on(self):
-        return self.adam_window > 0 and self._tiled_supported and self.scatter_mode == 0 and not self._use_dev_scalars
+        return (self.adam_window > 0 and self._tiled_supported and self.scatter_mode == 0 and not self._use_dev_scalars
+                and self._tbl.numel() * 24 >= self.adam_tiled_min_bytes)
 
     def _tiled_table(self):
         if self._tiled is None:

@@ -19,6 +19,7 @@ def make(cfg, window, seed=5):
     from score_amd.model import MODELS
     m = MODELS[cfg.model_type](cfg.N, cfg.D, cfg.H, cfg.T, cfg.K, cfg.Fu, cfg.Fi, seed=seed)
     m.adam_window = window
+    m.adam_tiled_min_bytes = 0          # (by default tables this small keep the per-step sweep)
     return m
 
 

@@ -11,9 +11,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(*args):
+def _run(*args, **env):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(args), capture_output=True, text=True,
-                         timeout=600, cwd=ROOT)
+                         timeout=600, cwd=ROOT, env=dict(os.environ, **env))
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.strip().splitlines() if l.strip()]
     return json.loads(lines[-1])           # the JSON is the LAST line
@@ -49,3 +49,14 @@ def test_flags_change_what_they_say():
     assert j["launch"].startswith("one captured hipGraph") and j["value"] > 0
     j = _run("--steps", "4", "--warmup", "1", "--config", "cfg2", "--no-cpu-baseline", "--force-sharded", "--global-batch", "256")
     assert j["scaling"] == "strong" and j["n_gpus"] == 1 and "value_best_case" not in j
+
+
+def test_time_tiled_optimizer_line():
+    """the headline's table optimizer (on by default from 256 MB of sweep traffic; forced here on the small shape) and
+    the per-step sweep it replaces, timed in the same process"""
+    j = _run("--steps", "20", "--warmup", "3", "--config", "cfg2", "--no-cpu-baseline", SCORE_ADAM_TILED_MIN_BYTES="0")
+    assert j["config"]["table_optimizer"].startswith("time-tiled ApplyAdam, window 16")
+    assert j["value_dense_adam_sweep"] > 0 and j["stages_ms"]["adam_catchup_batch_rows"] > 0
+    assert any(k.startswith("adam_touched") for k in j["roofline_other"])
+    j = _run("--steps", "6", "--warmup", "2", "--config", "cfg2", "--no-cpu-baseline", "--no-side", SCORE_ADAM_WINDOW="0")
+    assert j["config"]["table_optimizer"].startswith("dense ApplyAdam sweep") and "adam_catchup_batch_rows" not in j["stages_ms"]
