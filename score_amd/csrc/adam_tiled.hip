@@ -14,6 +14,7 @@
 //                            that every observer of the table runs first (save, get_params, a dense step, ...)
 // A row's HBM traffic drops from once per step to once per use (plus once per window).  The arithmetic is not
 // skipped: each (row, step) update is executed exactly once, by whichever of the three gets to the row first.
+#include <cstdlib>
 #include "common.h"
 #include "kernels.h"
 
