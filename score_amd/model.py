@@ -510,11 +510,11 @@ class SCOREBASE(object):
         """Before a forward: the rows this batch reads are brought up to self.step (score_adam_catchup_ids); in a
         training step the window's slice of the table follows on its own stream, beside the step."""
         ev = self.catchup_events
+        _, _, T = self._tiled_table()     # (created here, on the main stream, well before the side stream first uses it)
         if not self._adam_dirty:
             if ev:
                 ev[0].record(); ev[1].record()
             return
-        _, _, T = self._tiled_table()
         cur = torch.cuda.current_stream(self.device)
         self._join_sweep(cur)
         if self._flags_marked:
@@ -557,8 +557,14 @@ class SCOREBASE(object):
             self._ev_sweep = stream.record_event()
 
     def _adam_table_tiled(self, lr):
-        """ApplyAdam of step self.step + 1 on the rows that have a gradient; every other live row owes it."""
+        """ApplyAdam of step self.step + 1 on the rows that have a gradient; every other live row owes it.
+        (On the main stream: behind the row-gradient event on the side stream, beside the weight-gradient products,
+        it slowed those by what it saved -- bwd_weight_grads 0.180 -> 0.246 ms, profiles/r02_probes.md.)"""
         row_step, ring, T = self._tiled_table()
+        cur = torch.cuda.current_stream(self.device)
+        # this step's window slice first: it must not see a row half-way through its first update (state 0 -> 2 -> 1
+        # with row_step still unset); it finished long ago (it runs beside the forward)
+        self._join_sweep(cur)
         if not self._tiled_ready:
             # (only reached with no row lagging: _flush_adam ran, or nothing tiled has happened yet)
             row_step.fill_(int(self.step))
