@@ -586,25 +586,17 @@ int score_launch_target_fwd(const float* table, int D, int Fu, int Fi, int B, co
   return 0;
 }
 
-// S[c][b] = sum_t dzsum_c[b*T+t]
-__global__ void dzsum_reduce_kernel(const float* __restrict__ dz1, const float* __restrict__ dz2, int B, int T,
-                                    float* __restrict__ S) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 2 * B) return;
-  const float* src = i < B ? dz1 : dz2;
-  int b = i < B ? i : i - B;
-  float s = 0.f;
-  if (src)
-    for (int t = 0; t < T; ++t) s += src[(int64_t)b * T + t];
-  S[i] = s;
-}
-
-// d target rows = dquery + dhead + S * w_t ; scatter-add into the table gradient
-__global__ void target_bwd_kernel(float* __restrict__ gtable, int D4, int Fu, int Fi, int B,
+// d target rows = dquery + dhead + S * w_t ; scatter-add into the table gradient.
+// S[c][b] = sum_t dzsum_c[b*T+t] (c = 0: co-attention 1, whose target is the item; c = 1: the user) is summed here by
+// every thread that needs it, in t order (the few rows of dzsum a block reads sit in L1), and stored once per (c, b)
+// for the weight / bias gradients queued behind this launch -- it was a launch of its own in front of this one, two
+// 5-us kernels on the critical path between the co-attention backward and the row scatter.
+__global__ void target_bwd_kernel(float* __restrict__ gtable, int D4, int Fu, int Fi, int B, int T,
                                   const int32_t* __restrict__ tu, const int32_t* __restrict__ ti,
                                   const float* __restrict__ dquery, int ldq, const float* __restrict__ dhead,
                                   int ldh, int off_ti, int off_tu, const float* __restrict__ W1,
-                                  const float* __restrict__ W2, const float* __restrict__ S,
+                                  const float* __restrict__ W2, const float* __restrict__ dz1,
+                                  const float* __restrict__ dz2, float* __restrict__ S,
                                   float* __restrict__ dtgt) {
   const int cu = Fu * D4, ci = Fi * D4;
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -614,13 +606,22 @@ __global__ void target_bwd_kernel(float* __restrict__ gtable, int D4, int Fu, in
   float4 g;
   int64_t row;
   int c;
-  if (s < cu) {
+  const bool user = s < cu;
+  float Sb = 0.f;
+  if (S) {       // (co-attention models only)
+    const float* src = user ? dz2 : dz1;
+    if (src)
+      for (int t = 0; t < T; ++t) Sb += src[(int64_t)b * T + t];
+    if (s == 0) S[B + b] = Sb;
+    if (s == cu) S[b] = Sb;
+  }
+  if (user) {
     int fidx = s / D4;
     c = s - fidx * D4;
     row = tu[b * Fu + fidx];
     g = ld4(dhead + (int64_t)b * ldh + off_tu + s * 4);
     if (dquery) g = add4(g, ld4(dquery + (int64_t)b * ldq + s * 4));
-    if (W2) g = fma4(S[B + b], ld4(W2 + s * 4), g);  // co-attention 2 targets the user (score.py:197)
+    if (W2) g = fma4(Sb, ld4(W2 + s * 4), g);  // co-attention 2 targets the user (score.py:197)
   } else {
     int s2 = s - cu;
     int fidx = s2 / D4;
@@ -628,7 +629,7 @@ __global__ void target_bwd_kernel(float* __restrict__ gtable, int D4, int Fu, in
     row = ti[b * Fi + fidx];
     g = ld4(dhead + (int64_t)b * ldh + off_ti + s2 * 4);
     if (dquery) g = add4(g, ld4(dquery + (int64_t)b * ldq + cu * 4 + s2 * 4));
-    if (W1) g = fma4(S[b], ld4(W1 + s2 * 4), g);     // co-attention 1 targets the item (score.py:196)
+    if (W1) g = fma4(Sb, ld4(W1 + s2 * 4), g);     // co-attention 1 targets the item (score.py:196)
   }
   if (dtgt) {  // pull mode: hand the [B, Du+Di] row gradients to the sorted scatter
     st4(dtgt + (int64_t)b * (cu + ci) * 4 + s * 4, g);
@@ -644,13 +645,10 @@ int score_launch_target_bwd(float* grad_table, int D, int Fu, int Fi, int B, int
                             float* dW2, float* dB2, float* dtgt_out, float* scratch, int64_t scratch_floats,
                             ColsumJobs* cq, GemmQueue* gq, hipStream_t s) {
   const bool coattn = W1 != nullptr;
-  if (coattn) {
-    hipLaunchKernelGGL(dzsum_reduce_kernel, dim3((2 * B + 255) / 256), dim3(256), 0, s, dzsum1, dzsum2, B, T, S);
-    SCORE_CHECK_LAUNCH();
-  }
   int64_t n = (int64_t)B * (Fu + Fi) * (D / 4);
   hipLaunchKernelGGL(target_bwd_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, s, grad_table, D / 4, Fu,
-                     Fi, B, tu, ti, dquery, ldq, dhead, ldh, off_ti, off_tu, W1, W2, S, dtgt_out);
+                     Fi, B, T, tu, ti, dquery, ldq, dhead, ldh, off_ti, off_tu, W1, W2, dzsum1, dzsum2,
+                     coattn ? S : nullptr, dtgt_out);
   SCORE_CHECK_LAUNCH();
   if (coattn) {
     // dW_t = tgt^T S (call 0 targets the item: query cols Du.., call 1 the user: cols 0..), dbias = sum_b S
