@@ -449,8 +449,8 @@ extern "C" int score_forward(const score_config_t* cfg, const score_state_t* st,
                            W + P.cb[1], d.Is[0], d.Is[1], d.I, H, ws + w.wxcat, sd->st));
   hipEvent_t wx_ev = sd->wx;
   HIPTRY(hipEventRecord(wx_ev, sd->st));
-  G(score_launch_l2_partials(W, P.n_reg, ws + w.part, sd->st));
   const bool head_fused = !env_flags().head_unfused;
+  G(score_launch_l2_partials(W, P.n_reg, ws + w.part, sd->st));
   if (!d.attn) HIPTRY(hipEventRecord(sd->join, sd->st));
   if (d.attn) {
     float* scratch2 = ws + w.scratch2;
@@ -554,9 +554,9 @@ extern "C" int score_forward(const score_config_t* cfg, const score_state_t* st,
                                               keep_prob, drop_mask0, drop_mask1, drop_seed, drop_seed ^ 0x5DEECE66Dull,
                                               bt->label, ws + w.bn, ws + w.f1, ws + w.f2, ws + w.logit, ws + w.y_pred,
                                               ws + w.lossb, ws + w.dlogit, Bg, s,
-                                              st->step_scalars ? &st->step_scalars->drop_seed : nullptr);
+                                              st->step_scalars ? &st->step_scalars->drop_seed : nullptr, ws + w.dz2);
   if (hrc == 0) {
-    G(score_launch_loss_final(B, ws + w.lossb, ws + w.loss, reg_lambda, ws + w.part, Bg, s));
+    G(score_launch_loss_final(B, ws + w.lossb, ws + w.loss, reg_lambda, ws + w.part, Bg, s));    // (dz2 came with the head)
   } else if (hrc == SCORE_E_SHAPE) {
     if (st->step_scalars && keep_prob < 1.f) return SCORE_E_SHAPE;   // the layer-by-layer path takes its seed by value
     G(score_launch_bn_fwd(B, d.Dhead, ws + w.head_inp, W + P.bn_g, W + P.bn_b, rs, ws + w.bn, s));
@@ -599,7 +599,14 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
   // weight gradients C = X^T dY have no consumer inside the pass: queued, issued together at its end
   GemmQueue gq;
   gq.n = 0;
-  hipError_t he = hipMemsetAsync(gw, 0, P.n_floats * sizeof(float), s);
+  // The dense gradient starts from zero (some of its pieces are accumulated, some variables of some model types get
+  // none).  Nothing on the main stream writes it before the side stream's join below -- every weight / bias
+  // gradient is queued -- so the fill runs on the side stream, off the chain of dependent launches.
+  SideStream* side = nullptr;
+  G(side_stream(st, &side));
+  HIPTRY(hipEventRecord(side->fork, s));
+  HIPTRY(hipStreamWaitEvent(side->st, side->fork, 0));
+  hipError_t he = hipMemsetAsync(gw, 0, P.n_floats * sizeof(float), side->st);
   if (he != hipSuccess) return (int)he;
 
   EV(0);
@@ -607,7 +614,8 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
   // fc3: dW = f2^T dlogit, db = sum dlogit, dz2 = [f2>0] dlogit w3 / keep
   G(gemm_queue_add(&gq, FC2, 1, B, ws + w.f2, FC2, ws + w.dlogit, 1, gw + P.fc_w[2], 1));
   G(colsum_queue_add(&cq, ws + w.dlogit, B, 1, 1, gw + P.fc_b[2], 0));
-  G(score_launch_outer_relu_bwd(B, FC2, ws + w.dlogit, W + P.fc_w[2], ws + w.f2, keep_prob, ws + w.dz2, s));
+  if (env_flags().head_unfused || !score_head_fwd_fused_fits(B, d.Dhead, FC1, FC2))     // (else score_forward's fused head wrote dz2)
+    G(score_launch_outer_relu_bwd(B, FC2, ws + w.dlogit, W + P.fc_w[2], ws + w.f2, keep_prob, ws + w.dz2, s));
   // fc2
   G(gemm_queue_add(&gq, FC1, FC2, B, ws + w.f1, FC1, ws + w.dz2, FC2, gw + P.fc_w[1], FC2));
   G(colsum_queue_add(&cq, ws + w.dz2, B, FC2, FC2, gw + P.fc_b[1], 0));
@@ -674,12 +682,10 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
   EV(2);
   // ---- GRUs (score.py:205-208)
   // the weight gradients queued so far (head, attention) have everything they need: beside the recurrence
-  SideStream* side = nullptr;
   const bool wgrad_side = env_flags().wgrad_side;   // A/B: the recurrences' weight gradients beside the scatter
   const int64_t slab_third = (w.dwslab_floats / 2) & ~(int64_t)3;      // region of the second side flush
   const int64_t slab_half = (w.dwslab_floats / 4) & ~(int64_t)3;        // region of the first one
-  if (gq.n > 0 || d.attn) {
-    G(side_stream(st, &side));
+  {
     HIPTRY(hipEventRecord(side->fork, s));
     HIPTRY(hipStreamWaitEvent(side->st, side->fork, 0));
     // Sharded path (scatter_mode 2): the caller runs several streams of its own (plan prefetch, gradient exchange,
@@ -753,7 +759,6 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
   // ---- co-attention + embedding rows (score.py:147-167, 196-201, 51-66)
   int64_t slab_used = slab_half;
   if (wgrad_side && gq.n > 0) {     // the GRU kernels' weight gradients: beside the co-attention backward and the scatter
-    G(side_stream(st, &side));
     HIPTRY(hipEventRecord(side->fork, s));
     HIPTRY(hipStreamWaitEvent(side->st, side->fork, 0));
     G(gemm_queue_flush(&gq, x3 != 0, ws + w.dwslab + slab_half, slab_third, side->st));

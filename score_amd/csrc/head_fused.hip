@@ -83,6 +83,7 @@ struct HeadFwdArgs {
   const uint64_t* seed_dev;       // score_step_scalars_t.drop_seed (captured steps): overrides seed0 / seed1
   const int32_t* label;
   float* bn; float* f1; float* f2; float* logit; float* y; float* lossb; float* dlogit;
+  float* dz2;                     // [B, N2] fc3's backward into relu+dropout of fc2 (what the backward pass starts from)
 };
 
 __device__ __forceinline__ float hf_act(float v, float bias, int drop, float keep, const uint8_t* mask, uint64_t seed,
@@ -216,12 +217,30 @@ __global__ __launch_bounds__(64 * HF_NW) void head_fwd_fused_kernel(const HeadFw
       a.y[row] = p;
       a.lossb[row] = -lab * logf(p + eps) - (1.0f - lab) * logf(1.0f - p + eps);
       const float dp = (-lab / (p + eps) + (1.0f - lab) / (1.0f - p + eps)) / (float)a.Bglobal;
-      a.dlogit[row] = dp * p * (1.0f - p);
+      const float dl = dp * p * (1.0f - p);
+      a.dlogit[row] = dl;
+      xs[i] = dl;                       // (bn1's tile is dead by now)
+    }
+  }
+  __syncthreads();
+  // dz2[b][n] = [f2 > 0] * dlogit[b] * w3[n] / keep: the first thing the backward pass needs, and everything it is made
+  // of is here (it was a launch of its own at the head of score_backward).  (The loss reduction did NOT move in here:
+  // done by the last workgroup to arrive, it cost this kernel 6.6 us -- more than the one-block launch behind it.)
+  if (a.dz2) {
+    for (int e = tid; e < HF_ROWS * N2; e += 64 * HF_NW) {
+      const int i = e / N2, n = e - i * N2, row = b0 + i;
+      if (row < a.B) a.dz2[(int64_t)row * N2 + n] = f2s[i * LD2 + n] > 0.f ? xs[i] * a.W3[n] / a.keep : 0.f;
     }
   }
 }
 
 }  // namespace
+
+// (what score_backward asks to know whether the forward pass has left dz2 behind)
+bool score_head_fwd_fused_fits(int B, int Dh, int N1, int N2) {
+  const int LD0 = ((Dh + 15) & ~15) + 4, LD1 = ((N1 + 15) & ~15) + 4, LD2 = ((N2 + 15) & ~15) + 4;
+  return B > 0 && (size_t)HF_ROWS * (LD0 + LD1 + LD2) * sizeof(float) <= 150 * 1024;
+}
 
 // Returns SCORE_E_SHAPE when the shape does not fit the fused kernel (the caller then runs the layer-by-layer path).
 int score_launch_head_fwd_fused(int B, int Dh, int N1, int N2, const float* x, const float* gamma, const float* beta,
@@ -229,10 +248,10 @@ int score_launch_head_fwd_fused(int B, int Dh, int N1, int N2, const float* x, c
                                 const float* W3, const float* b3, float keep, const uint8_t* mask0, const uint8_t* mask1,
                                 uint64_t seed0, uint64_t seed1, const int32_t* label, float* bn, float* f1, float* f2,
                                 float* logit, float* y, float* lossb, float* dlogit, int Bglobal, hipStream_t s,
-                                const uint64_t* seed_dev) {
+                                const uint64_t* seed_dev, float* dz2) {
   const int LD0 = ((Dh + 15) & ~15) + 4, LD1 = ((N1 + 15) & ~15) + 4, LD2 = ((N2 + 15) & ~15) + 4;
   const size_t lds = (size_t)HF_ROWS * (LD0 + LD1 + LD2) * sizeof(float);
-  if (lds > 150 * 1024 || B <= 0) return SCORE_E_SHAPE;
+  if (!score_head_fwd_fused_fits(B, Dh, N1, N2)) return SCORE_E_SHAPE;
   static thread_local bool attr_set = false;
   if (!attr_set && lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(head_fwd_fused_kernel),
@@ -246,6 +265,7 @@ int score_launch_head_fwd_fused(int B, int Dh, int N1, int N2, const float* x, c
   a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.W3 = W3; a.b3 = b3;
   a.keep = keep; a.drop = keep < 1.f ? 1 : 0; a.mask0 = mask0; a.mask1 = mask1; a.seed0 = seed0; a.seed1 = seed1; a.seed_dev = seed_dev;
   a.label = label; a.bn = bn; a.f1 = f1; a.f2 = f2; a.logit = logit; a.y = y; a.lossb = lossb; a.dlogit = dlogit;
+  a.dz2 = dz2;
   hipLaunchKernelGGL(head_fwd_fused_kernel, dim3((B + HF_ROWS - 1) / HF_ROWS), dim3(64 * HF_NW), lds, s, a);
   SCORE_CHECK_LAUNCH();
   return 0;

@@ -102,7 +102,8 @@ int score_launch_head_fwd_fused(int B, int Dh, int N1, int N2, const float* x, c
                                 const float* W3, const float* b3, float keep, const uint8_t* mask0, const uint8_t* mask1,
                                 uint64_t seed0, uint64_t seed1, const int32_t* label, float* bn, float* f1, float* f2,
                                 float* logit, float* y, float* lossb, float* dlogit, int Bglobal, hipStream_t s,
-                                const uint64_t* seed_dev = nullptr);
+                                const uint64_t* seed_dev = nullptr, float* dz2 = nullptr);
+bool score_head_fwd_fused_fits(int B, int Dh, int N1, int N2);
 int score_launch_outer_relu_bwd(int B, int NF, const float* dlogit, const float* w, const float* f, float keep,
                                 float* dz, hipStream_t s);
 int score_launch_gru_wxcat(const float* gk0, const float* ck0, const float* gb0, const float* cb0, const float* gk1,
