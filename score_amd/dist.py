@@ -156,7 +156,8 @@ class TorchDistComm(object):
 class _ShardModel(SCOREBASE):
     """SCOREBASE whose `table` is one row shard: local row i holds global row i*G + rank."""
     model_type = "SCORE"
-    _tiled_supported = False     # a shard's optimizer is the per-step sweep over its own rows (1/G of the table)
+    # (the time-tiled table optimizer works on a shard as on the whole table: the rows other ranks ask for are the
+    #  "batch", HipBackend.gather catches them up before it reads them; on from 256 MB of sweep traffic per shard)
 
     def __init__(self, rank, world, model_type, feature_size, *args, **kw):
         self.model_type = model_type
@@ -252,11 +253,18 @@ class HipBackend(object):
         return self.plan_finish(self.plan_launch(batch_data, slot))
 
     def gather(self, req_rows):
+        m = self.m
         n = req_rows.numel()
         out = torch.empty((n, self.D), dtype=torch.float32, device=self.device)
+        if m._tiled_on():
+            # time-tiled optimizer: the requested rows (local indices) up to date first, then this step's slice of
+            # the shard, on this same stream (the shard path runs enough streams already)
+            m._catchup_ids([req_rows] if n else [], True, inline_sweep=True)
+        else:
+            m._flush_adam()
         if n:
-            _lib.check(self.lib.score_gather_fwd(_ptr(self.m.table), self.m.table.shape[0], self.D, _ptr(req_rows),
-                                                 n, _ptr(out), self.m._stream()), "score_gather_fwd")
+            _lib.check(self.lib.score_gather_fwd(_ptr(m._tbl), m._tbl.shape[0], self.D, _ptr(req_rows),
+                                                 n, _ptr(out), m._stream()), "score_gather_fwd")
         return out
 
     def _state(self, plan, mini):
@@ -326,7 +334,7 @@ class HipBackend(object):
             c = int(c)
             if c:
                 rc = self.lib.score_rows_accumulate(_ptr(req_rows[off:off + c]), _ptr(grads_in[off:off + c]), c,
-                                                    self.D, m.table.shape[0], _ptr(m.table_g), _ptr(m.table_flags),
+                                                    self.D, m._tbl.shape[0], _ptr(m.table_g), _ptr(m.table_flags),
                                                     m._stream())
                 _lib.check(rc, "score_rows_accumulate")
             off += c
@@ -339,7 +347,11 @@ class HipBackend(object):
 
     # the two halves of the update, for the pipelined step: the shard's rows need the row gradients only
     def adam_table(self, lr):
-        self.m.adam_table(lr)
+        m = self.m
+        if m._tiled_on() and m._row_grads:
+            m._adam_table_tiled(lr)
+        else:
+            m.adam_table(lr)
 
     def adam_dense(self, lr, reg_lambda):
         self.m.adam_dense(lr, reg_lambda)

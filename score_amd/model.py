@@ -151,7 +151,7 @@ class SCOREBASE(object):
         # time-tiled table optimizer (include/score_hip.h, score_adam_table_t): live rows without a gradient are
         # updated the next time they are needed (or once per `adam_window` steps) instead of every step.  Bit-identical
         # to the per-step sweep wherever the table is observed; 0 = sweep the whole table every step
-        self.adam_window = int(os.environ.get("SCORE_ADAM_WINDOW", "16"))
+        self._adam_window = int(os.environ.get("SCORE_ADAM_WINDOW", "16"))
         # ... and only where the sweep is worth replacing: its six streams over the table against two extra scans of
         # the state bytes and three more launches per step (cfg-2's 62 MB table: 0.391 ms/step swept, 0.425 tiled;
         # the reference's own shape, 587 MB: 0.513 -> 0.466; cfg-3, 2.35 GB: 1.76 -> 1.48)
@@ -202,6 +202,18 @@ class SCOREBASE(object):
     def table(self, t):
         self._flush_adam()
         self._tbl, self._tiled, self._tiled_ready = t, None, False
+
+    @property
+    def adam_window(self):
+        return self._adam_window
+
+    @adam_window.setter
+    def adam_window(self, k):
+        # a new window restarts the slice schedule: nothing may be owed across the change (a row could otherwise wait
+        # old + new window steps for its slice, past what the alpha ring remembers)
+        if int(k) != self._adam_window:
+            self._flush_adam()
+            self._adam_window = int(k)
 
     @property
     def table_m(self):
@@ -509,6 +521,10 @@ class SCOREBASE(object):
     def _catchup(self, db, sweep):
         """Before a forward: the rows this batch reads are brought up to self.step (score_adam_catchup_ids); in a
         training step the window's slice of the table follows on its own stream, beside the step."""
+        self._catchup_ids([db.flat] if db.flat is not None else list(db.tensors[:6]), sweep)
+
+    def _catchup_ids(self, spans, sweep, inline_sweep=False):
+        """spans: int32 device tensors of row ids (values outside the table are ignored)"""
         ev = self.catchup_events
         _, _, T = self._tiled_table()     # (created here, on the main stream, well before the side stream first uses it)
         if not self._adam_dirty:
@@ -522,10 +538,6 @@ class SCOREBASE(object):
         upto = int(self.step)
         if ev:
             ev[0].record()
-        if db.flat is not None:
-            spans = [db.flat]
-        else:
-            spans = list(db.tensors[:6])
         for t in spans:
             _lib.check(self.lib.score_adam_catchup_ids(C.byref(T), _ptr(t), t.numel(), upto, self._stream()),
                        "score_adam_catchup_ids")
@@ -539,7 +551,7 @@ class SCOREBASE(object):
             rows, K = self._tbl.shape[0], self.adam_window
             j = (upto + 1) % K
             self._pending_sweep = (rows * j // K, rows * (j + 1) // K, upto, cur.record_event())
-            if os.environ.get("SCORE_ADAM_SWEEP_INLINE"):
+            if inline_sweep or os.environ.get("SCORE_ADAM_SWEEP_INLINE"):
                 self._launch_sweep(cur)
 
     def _launch_sweep(self, stream):
