@@ -364,7 +364,13 @@ def main():
         "adam_table_and_dense": avg(lambda s: s[2].elapsed_time(s[3])),
     }
     if tiled:      # the rows of the batch brought up to date before the forward (outside every stage above)
-        stages["adam_catchup_batch_rows"] = avg(lambda s: s[4].elapsed_time(s[5]))
+        vals = []
+        for s_ in ev_sets:      # (the sharded path fetches a step ahead: a step may contain no catch-up at all)
+            try:
+                vals.append(s_[4].elapsed_time(s_[5]))
+            except Exception:
+                pass
+        stages["adam_catchup_batch_rows"] = float(np.mean(vals)) if vals else None
     A = int(getattr(batches[0], "active_slices", 0)) or T      # slices the gather really reads
     ev_overhead_ms = event_pair_overhead_ms()
     ab, R = alg_bytes_per_sample(A, K, D, Fu, Fi)
