@@ -224,6 +224,12 @@ def main():
     if os.environ.get("SCORE_BENCH_DEVICE"):
         local_rank = int(os.environ["SCORE_BENCH_DEVICE"])
     backend = os.environ.get("SCORE_DIST_BACKEND", "nccl")
+    if world_size > 1 or args.force_sharded:
+        # The sharded step runs five streams (main, the engine's side stream, gradient exchange, index prefetch,
+        # RCCL's own).  HIP deals streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues in first-use order; two
+        # of them on one queue serialise, and which two changes from process to process: 1.89 - 2.30 ms/step with 4
+        # queues, 1.77 every time with 8 (profiles/r02_probes.md).  Read when the HIP runtime starts: set before it.
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     torch.cuda.set_device(local_rank)
     dist = None
     sharded = world_size > 1 or args.force_sharded

@@ -26,6 +26,13 @@ import os
 import numpy as np
 import torch
 
+# The sharded step uses five streams; HIP maps streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues in first-use
+# order and two streams on one queue serialise (1.89 - 2.30 ms/step from process to process with 4, 1.77 with 8).  The
+# runtime reads the variable when it starts: this only helps when score_amd.dist is imported before the first HIP
+# call of the process (bench.py sets it itself; INTEGRATION.md says so for other callers).
+if not torch.cuda.is_initialized():
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 from . import _lib
 from .model import SCOREBASE, DeviceBatch, _ptr, ADAM_B1, ADAM_B2, ADAM_EPS
 
@@ -67,6 +74,10 @@ def _concurrent_stream(device, candidates=8, cycles=1500000):
             torch.cuda.synchronize(device)
             spans.append((e0.elapsed_time(e1), e0.elapsed_time(f1)))
         single, span = spans[-1]
+        if os.environ.get("SCORE_STREAM_PROBE_DEBUG"):
+            import sys
+            print("stream probe: candidate %d spans %s -> %s" % (_, spans, "taken" if span < 1.4 * single else "serialises"),
+                  file=sys.stderr, flush=True)
         if best is None:
             best = st
         if span < 1.4 * single:
