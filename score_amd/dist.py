@@ -270,6 +270,8 @@ class HipBackend(object):
         if m._tiled_on():
             # time-tiled optimizer: the requested rows (local indices) up to date first, then this step's slice of
             # the shard, on this same stream (the shard path runs enough streams already)
+            # (the slice on a stream of its own, off the gradient-exchange chain the main stream waits for at the end
+            #  of the step, measured 2.25-2.29 ms/step against 1.76 inline)
             m._catchup_ids([req_rows] if n else [], True, inline_sweep=True)
         else:
             m._flush_adam()
