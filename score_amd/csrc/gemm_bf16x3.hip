@@ -289,6 +289,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(const GemmGroup grp
     constexpr int TA[6] = {1, 0, 2, 0, 1, 0}, TB[6] = {1, 2, 0, 1, 0, 0};
 #pragma unroll
     for (int f = 0; f < NF1; ++f) read_frag(0, f);
+#ifdef X3_SETPRIO      // tools/x3_probe.py: the matrix phase of this wave ahead of the co-resident block's split / LDS-write
+    __builtin_amdgcn_s_setprio(X3_SETPRIO);      // phase.  In isolation 53.3 -> 50.0 us (projection), 70.2 -> 68.2 (X^T dY); in the step nothing
+#endif                 // (cfg-3 1.4784 vs 1.4852, cfg-5 20.47 vs 20.64 ms): the side streams' kernels pay it back.  Off.
 #pragma unroll
     for (int g = 0; g < NM; ++g) {
       const int ks = g / NM1, t = (g % NM1) / (WM * 2), i = (g / 2) % WM, j = g % 2;
@@ -302,6 +305,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(const GemmGroup grp
       for (int m = g * MU / NM; m < (g + 1) * MU / NM; ++m) split_micro(m, k0 + TBK, k0 + 2 * TBK, kcheck);
       __builtin_amdgcn_sched_barrier(0);
     }
+#ifdef X3_SETPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
   };
 
   // tiles [0, nfull) are whole; the main loop only ever splits and loads whole tiles (no bounds work at

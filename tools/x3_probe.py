@@ -3,7 +3,7 @@ MFMA stripped) and times each on the path's GEMM shapes.  Run on the GPU box: py
 import ctypes as C, os, subprocess, sys, tempfile
 import torch
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-variants = [("full", []), ("nosplit", ["-DX3_PROBE_NOSPLIT"]), ("nomfma", ["-DX3_PROBE_NOMFMA"]),
+variants = [("full", []), ("setprio1", ["-DX3_SETPRIO=1"]), ("setprio3", ["-DX3_SETPRIO=3"]), ("nosplit", ["-DX3_PROBE_NOSPLIT"]), ("nomfma", ["-DX3_PROBE_NOMFMA"]),
             ("neither", ["-DX3_PROBE_NOSPLIT", "-DX3_PROBE_NOMFMA"]),
             ("n-noA", ["-DX3_PROBE_NOSPLIT", "-DX3_PROBE_NOMFMA", "-DX3_PROBE_NOLOADA"]),
             ("n-noB", ["-DX3_PROBE_NOSPLIT", "-DX3_PROBE_NOMFMA", "-DX3_PROBE_NOLOADB"]),
@@ -21,6 +21,8 @@ variants = [("full", []), ("nosplit", ["-DX3_PROBE_NOSPLIT"]), ("nomfma", ["-DX3
             ("full-noldsr", ["-DX3_PROBE_NOLDSR"]),
             ("mfma-only", ["-DX3_PROBE_NOSPLIT", "-DX3_PROBE_NOLOADA", "-DX3_PROBE_NOLOADB",
                           "-DX3_PROBE_NOSTORE", "-DX3_PROBE_NOLDSR", "-DX3_PROBE_NOLDSW"])]
+if len(sys.argv) > 1:       # python tools/x3_probe.py full setprio1 ...
+    variants = [v for v in variants if v[0] in sys.argv[1:]]
 tmp = tempfile.mkdtemp()
 libs = {}
 for name, defs in variants:
