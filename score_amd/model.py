@@ -597,8 +597,8 @@ class SCOREBASE(object):
         _, ring, T = self._tiled
         cur = torch.cuda.current_stream(self.device)
         self._join_sweep(cur)
-        if self._flags_marked:
-            self._drop_row_marks()
+        # (rows in state 2 -- a gradient not applied yet -- are left alone, marks and all: they were brought up to
+        #  date before the forward that produced the gradient, and the update that follows still needs the marks)
         _lib.check(self.lib.score_adam_catchup_rows(C.byref(T), 0, self._tbl.shape[0], int(self.step), self._stream()),
                    "score_adam_catchup_rows")
         if int(ring[_lib.ADAM_RING].view(torch.int32).item()) != 0:
@@ -608,10 +608,7 @@ class SCOREBASE(object):
         """ApplyAdam over the table (shard) on the current stream: needs the row gradients only."""
         a = self._alpha(lr)
         s = self._stream()
-        marked = self._flags_marked
-        self._flags_marked = False          # (the flush must not take this step's state-2 marks for stale ones)
         self._flush_adam()
-        self._flags_marked = marked
         self._tiled_ready = False           # a sweep moves every row: row_step no longer describes the table
         if self._row_grads:
             if self._use_dev_scalars:

@@ -84,6 +84,13 @@ def test_switching_modes_and_checkpoint(tmp_path):
         if i == 25:                      # gradients without an update in between (marks nobody consumed)
             tiled.forward_backward(b, 1e-4, 1.0)
             dense.forward_backward(b, 1e-4, 1.0)
+        if i == 27:                      # somebody reads the variables between the backward and the update
+            tiled.forward_backward(b, 1e-4, 0.8)
+            assert tiled._adam_dirty
+            tiled.get_params()           # (flushes: the rows' pending gradient marks must survive it)
+            tiled.apply_adam(5e-3, 1e-4)
+            dense.train(None, b, 5e-3, 1e-4)
+            continue
         assert dense.train(None, b, 5e-3, 1e-4) == tiled.train(None, b, 5e-3, 1e-4), i
     assert same_state(dense, tiled)
     p_d, p_t = dense.get_params(), tiled.get_params()

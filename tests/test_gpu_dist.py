@@ -167,6 +167,7 @@ def test_tiled_shard_optimizer_bitwise_equal_to_swept(world, cfg_args, B, pipeli
         def fn(rank, comm):
             m = ShardedSCORE(*cfg_args, comm=comm, model_type="SCORE")
             sm = m.backend.m
+            m.backend.auto_sweep = False       # (this test fixes the optimizer mode itself)
             sm.adam_tiled_min_bytes = 0
             sm.adam_window = window
             sm.set_params(params)
@@ -189,6 +190,38 @@ def test_tiled_shard_optimizer_bitwise_equal_to_swept(world, cfg_args, B, pipeli
         assert swept[r][0] == tiled[r][0], r
         for k in (1, 2, 3):
             assert np.array_equal(swept[r][k], tiled[r][k]), (r, k)
+
+
+def test_shard_falls_back_to_the_sweep_when_most_rows_get_a_gradient():
+    """eight ranks on a small table: nearly every row of a shard is requested every step, the shard's optimizer
+    switches itself to the per-step sweep after four steps (HipBackend.note_requests) -- results unchanged"""
+    from score_amd.dist import ShardedSCORE
+    world, cfg_args, B = 8, (1600, 16, 16, 4, 4, 2, 3), 8
+    cfg = so.Cfg(*cfg_args, model_type="SCORE")
+    params = so.init_params(cfg, 3)
+    steps = 9
+    batches = [[random_batch(np.random.default_rng(1000 * r + s_), cfg, B) for s_ in range(steps)] for r in range(world)]
+
+    def run(auto):
+        def fn(rank, comm):
+            m = ShardedSCORE(*cfg_args, comm=comm, model_type="SCORE")
+            sm = m.backend.m
+            m.backend.auto_sweep = auto
+            sm.adam_tiled_min_bytes = 0
+            sm.adam_window = 4 if auto else 0
+            sm.set_params(params)
+            bts = [batch_tuple(b) for b in batches[rank]]
+            losses = [m.train(None, bt, 5e-3, 1e-3, keep_prob=1.0, next_batch=bts[i + 1] if i + 1 < steps else None)
+                      for i, bt in enumerate(bts)]
+            torch.cuda.synchronize()
+            return losses, sm.table.cpu().numpy(), sm.table_m.cpu().numpy(), int(sm.adam_window)
+        return run_ranks(world, fn)
+
+    auto, swept = run(True), run(False)
+    for r in range(world):
+        assert auto[r][3] == 0, (r, auto[r][3])            # decided: sweep
+        assert auto[r][0] == swept[r][0]
+        assert np.array_equal(auto[r][1], swept[r][1]) and np.array_equal(auto[r][2], swept[r][2])
 
 
 def test_rows_accumulate_op():
