@@ -336,6 +336,7 @@ def main():
     finish_adam()                  # inside the timed region: no update is left owing when the clock stops
     barrier()
     dt = time.perf_counter() - t0
+    tiled = tiled and bool(inner._tiled_on())       # (a shard may have gone back to the sweep: HipBackend.note_requests)
     if graph:                      # stage timings from eager steps, outside the timed region
         model.enable_graph(False)
         graph = False
