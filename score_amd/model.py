@@ -494,7 +494,7 @@ class SCOREBASE(object):
         self.adam_advance()
 
     # ------------------------------------------------------------------ time-tiled table optimizer
-    _tiled_supported = True          # (a row shard sweeps its own rows: score_amd/dist.py)
+    _tiled_supported = True          # (a subclass may opt out)
 
     def _tiled_on(self):
         return (self.adam_window > 0 and self._tiled_supported and self.scatter_mode == 0 and not self._use_dev_scalars
