@@ -123,3 +123,75 @@ def test_fresh_rows_and_abi_errors():
     with pytest.raises(ValueError):
         m = make(cfg, 63)
         m._tiled_table()
+
+
+@pytest.mark.parametrize("n_rows,D,window", [(1000, 24, 3), (777, 8, 5), (300, 256, 2), (4097, 64, 7), (65, 4, 4)])
+def test_entry_points_bitwise_against_the_row_sweep(n_rows, D, window):
+    """score_adam_touched / _catchup_ids / _catchup_rows driven directly through the C-ABI (row widths that leave
+    lanes of a group idle, one-group-per-wave rows, a table that is not a multiple of the 64-row scan) against
+    score_adam_rows on a second copy of the same state: identical bits after every flush"""
+    from score_amd import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(n_rows + D)
+    rnd = lambda *s: torch.randn(s, device=dev, generator=g)
+    P = lambda t: C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    blk = rnd(4, n_rows, D) * 0.1
+    blk[1:3].zero_()
+    ref = blk.clone()
+    flags = torch.zeros(n_rows, dtype=torch.uint8, device=dev)
+    flags_ref = flags.clone()
+    row_step = torch.zeros(n_rows, dtype=torch.int32, device=dev)
+    ring = torch.zeros(_lib.ADAM_RING + 1, dtype=torch.float32, device=dev)
+    T = _lib.AdamTable(p=P(blk[0]), m=P(blk[1]), v=P(blk[2]), g=P(blk[3]), n_rows=n_rows, D=D, row_flags=P(flags),
+                       row_step=P(row_step), alpha_ring=P(ring), beta1=0.9, beta2=0.999, eps=1e-8)
+    b1p = b2p = 1.0
+    pending = None
+    for step in range(1, 26):
+        # the rows of this step's "batch" (with repeats, padding zeros and out-of-range values, as a flat batch buffer has)
+        k = max(1, n_rows // (3 if step % 4 else 1))
+        ids = torch.randint(0, k, (257,), device=dev, generator=g, dtype=torch.int32)
+        ids[::7] = 0
+        ids[3] = n_rows + 5
+        ids[4] = -2
+        assert lib.score_adam_catchup_ids(C.byref(T), P(ids), ids.numel(), step - 1, st) == 0
+        lo, hi = n_rows * (step % window) // window, n_rows * (step % window + 1) // window
+        assert lib.score_adam_catchup_rows(C.byref(T), lo, hi, step - 1, st) == 0
+        # what the forward would read is what the swept copy holds
+        rows = ids[(ids >= 0) & (ids < n_rows)].long().unique()
+        assert torch.equal(blk[0][rows], ref[0][rows]), step
+        grads = rnd(rows.numel(), D)
+        for t_, f_ in ((blk, flags), (ref, flags_ref)):
+            t_[3][rows] = grads
+            f_[rows] = 2
+        b1p *= 0.9
+        b2p *= 0.999
+        alpha = float(np.float32(np.float32(1e-2) * np.sqrt(np.float32(1) - np.float32(b2p)) / (np.float32(1) - np.float32(b1p))))
+        assert lib.score_adam_touched(C.byref(T), step, alpha, st) == 0
+        assert lib.score_adam_rows(P(ref[0]), P(ref[1]), P(ref[2]), P(ref[3]), n_rows, D, P(flags_ref), alpha, 0.9, 0.999,
+                                   1e-8, st) == 0
+        if step % 6 == 0 or step == 25:
+            assert lib.score_adam_catchup_rows(C.byref(T), 0, n_rows, step, st) == 0
+            assert torch.equal(blk[:3], ref[:3]), step
+            assert torch.equal(flags, flags_ref)
+    assert int(ring[_lib.ADAM_RING].view(torch.int32).item()) == 0
+
+
+def test_captured_steps_after_tiled_ones():
+    """a captured (hipGraph) step keeps the per-step sweep: switching it on after time-tiled steps applies what is
+    owed first, switching it off resumes the tiled optimizer -- same bits as the sweep all the way"""
+    cfg = so.Cfg(3000, 16, 32, 5, 3, 2, 2, "SCORE")
+    dense, tiled = make(cfg, 0), make(cfg, 5)
+    bs = batches(cfg, 16, 16, seed=21, hot_rows=150)
+    for i, b in enumerate(bs):
+        if i == 4:
+            tiled.enable_graph(True)
+        if i == 11:
+            tiled.enable_graph(False)
+        assert dense.train(None, b, 5e-3, 1e-4) == tiled.train(None, b, 5e-3, 1e-4), i
+        if i in (3, 12):
+            assert tiled._adam_dirty
+        if 5 <= i <= 10:
+            assert not tiled._adam_dirty
+    assert same_state(dense, tiled)
