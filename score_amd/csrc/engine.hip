@@ -165,7 +165,7 @@ void build_ws(const Dims& d, int B, WS* w) {
   for (int s = 0; s < 2; ++s) w->gates[s] = take(BT * 3 * d.H);
   w->q = take((int64_t)B * d.Dk);
   w->ainp = take(BT * 2 * d.Dk);
-  w->weff = take(2 * (int64_t)d.Dk * AT1); w->wq = take((int64_t)d.Dk * AT1); w->qz = take((int64_t)B * AT1);
+  w->weff = take(SCORE_WEFF_COPIES * align_up64(2 * (int64_t)d.Dk * AT1 + 48, 4)); w->wq = take((int64_t)d.Dk * AT1); w->qz = take((int64_t)B * AT1);
   w->a1 = take(BT * AT1); w->a2 = take(BT * AT2);
   w->bn = take((int64_t)B * d.Dhead);
   w->f1 = take((int64_t)B * FC1); w->f2 = take((int64_t)B * FC2);
@@ -280,10 +280,11 @@ static int side_stream(const score_state_t* st, SideStream** out) {
   return 0;
 }
 // A/B switches of the launch sequence, read from the environment ONCE (first call), not per step
-struct EnvFlags { bool head_unfused, attn_tail_unfused, wgrad_side, gru_stepwise; };
+struct EnvFlags { bool head_unfused, attn_tail_unfused, wgrad_side, gru_stepwise, attn_fwd_unfused; };
 static const EnvFlags& env_flags() {
   static const EnvFlags f = {getenv("SCORE_HEAD_UNFUSED") != nullptr, getenv("SCORE_ATTN_TAIL_UNFUSED") != nullptr,
-                             getenv("SCORE_WGRAD_SIDE") != nullptr, getenv("SCORE_GRU_STEPWISE") != nullptr};
+                             getenv("SCORE_WGRAD_SIDE") != nullptr, getenv("SCORE_GRU_STEPWISE") != nullptr,
+                             getenv("SCORE_ATTN_FWD_UNFUSED") != nullptr};
   return f;
 }
 #define HIPTRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return (int)e_; } while (0)
@@ -450,6 +451,7 @@ extern "C" int score_forward(const score_config_t* cfg, const score_state_t* st,
   hipEvent_t wx_ev = sd->wx;
   HIPTRY(hipEventRecord(wx_ev, sd->st));
   const bool head_fused = !env_flags().head_unfused;
+  const int64_t weff_stride = align_up64(2 * (int64_t)d.Dk * AT1 + 48, 4);     // replicas of the folded attention weight (build_ws)
   G(score_launch_l2_partials(W, P.n_reg, ws + w.part, sd->st));
   if (!d.attn) HIPTRY(hipEventRecord(sd->join, sd->st));
   if (d.attn) {
@@ -457,7 +459,7 @@ extern "C" int score_forward(const score_config_t* cfg, const score_state_t* st,
     G(gemm_mode_call(x3, 0, B, d.Dk, d.Dq, ws + w.query, d.Dq, W + P.at_w[0], d.Dk, ws + w.q, d.Dk, W + P.at_b[0], GF_BIAS,
                      1.f, nullptr, 0, scratch2, w.scratch_floats, sd->st));
     // dense_3 on [q, k, q-k, q*k], folded (head.hip): a1 = relu([k, q*k] . Weff + (q . Wq + b)[sample])
-    G(score_launch_attn_fold_w1(d.Dk, AT1, W + P.at_w[1], ws + w.weff, ws + w.wq, sd->st));
+    G(score_launch_attn_fold_w1(d.Dk, AT1, W + P.at_w[1], ws + w.weff, ws + w.wq, sd->st, SCORE_WEFF_COPIES, weff_stride));
     G(gemm_mode_call(x3, 0, B, AT1, d.Dk, ws + w.q, d.Dk, ws + w.wq, AT1, ws + w.qz, AT1, W + P.at_b[1], GF_BIAS, 1.f,
                      nullptr, 0, scratch2, w.scratch_floats, sd->st));
     HIPTRY(hipEventRecord(sd->join, sd->st));
@@ -519,6 +521,15 @@ extern "C" int score_forward(const score_config_t* cfg, const score_state_t* st,
   if (d.attn) {
     // temporal attention (:169-186, 210-215); q, Weff/Wq and qz come from the side stream
     HIPTRY(hipStreamWaitEvent(s, sd->join, 0));
+    // all of it in one launch (head_fused.hip) where the shape allows ...
+    int frc = (env_flags().attn_fwd_unfused || env_flags().attn_tail_unfused) ? SCORE_E_SHAPE
+                  : score_launch_attn_fwd_fused(B, T, H, d.NI, AT1, AT2, ws + w.q, ws + w.gru_out[0], ws + w.gru_out[1],
+                                                ws + w.info, ws + w.weff, ws + w.qz, W + P.at_w[2], W + P.at_b[2],
+                                                W + P.at_w[3], W + P.at_b[3], bt->length, ws + w.ainp, ws + w.a1, ws + w.a2,
+                                                ws + w.att_score, ws + w.head_inp, d.Dhead, d.off_u, d.off_i, s,
+                                                SCORE_WEFF_COPIES, weff_stride);
+    if (frc != 0 && frc != SCORE_E_SHAPE) return frc;
+    if (frc == SCORE_E_SHAPE) {
     G(score_launch_attn_build_inp(B, T, H, d.NI, ws + w.q, ws + w.gru_out[0], ws + w.gru_out[1], ws + w.info,
                                   ws + w.ainp, s));
     G(gemm_mode_call(x3, 0, BT, AT1, 2 * d.Dk, ws + w.ainp, 2 * d.Dk, ws + w.weff, AT1, ws + w.a1, AT1, ws + w.qz,
@@ -536,6 +547,7 @@ extern "C" int score_forward(const score_config_t* cfg, const score_state_t* st,
                                    ws + w.gru_out[0], ws + w.gru_out[1], ws + w.att_score, ws + w.head_inp, d.Dhead,
                                    d.off_u, d.off_i, s));
     }
+    }     // (... else the separate launches above)
   } else {
     // RIA: final GRU states feed the head (:244-249)
     G(score_launch_copy2d(B, H, ws + w.gru_final[0], H, ws + w.head_inp, d.Dhead, s));

@@ -11,18 +11,25 @@
 // so the [B*T]-row product only needs [k, q*k] (2 Dk columns, half the bytes and flops of the literal
 // form) against Weff = [Wb - Wc; Wd]; the q term is one [B, Dk] x [Dk, 80] product added per sample
 // (score_gemm's row-grouped bias).
+// `copies` replicas of Weff, `copy_stride` floats apart: the fused attention forward (head_fused.hip) has every workgroup
+// read all of Weff at its start, and 32 CUs of an XCD asking one L2 channel for the same line at the same moment took
+// 34 us for 189 KB; neighbouring workgroups read different replicas (different lines, different channels).
 __global__ void attn_fold_w1_kernel(int Dk, int NA, const float* __restrict__ W1, float* __restrict__ weff,
-                                    float* __restrict__ wq) {
+                                    float* __restrict__ wq, int copies, int64_t copy_stride) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= Dk * NA) return;
   const float wa = W1[i], wb = W1[Dk * NA + i], wc = W1[2 * Dk * NA + i], wd = W1[3 * Dk * NA + i];
-  weff[i] = wb - wc;
-  weff[Dk * NA + i] = wd;
+  for (int c = 0; c < copies; ++c) {
+    weff[c * copy_stride + i] = wb - wc;
+    weff[c * copy_stride + Dk * NA + i] = wd;
+  }
   wq[i] = wa + wc;
 }
 
-int score_launch_attn_fold_w1(int Dk, int NA, const float* W1, float* weff, float* wq, hipStream_t s) {
-  hipLaunchKernelGGL(attn_fold_w1_kernel, dim3((Dk * NA + 255) / 256), dim3(256), 0, s, Dk, NA, W1, weff, wq);
+int score_launch_attn_fold_w1(int Dk, int NA, const float* W1, float* weff, float* wq, hipStream_t s, int copies,
+                              int64_t copy_stride) {
+  hipLaunchKernelGGL(attn_fold_w1_kernel, dim3((Dk * NA + 255) / 256), dim3(256), 0, s, Dk, NA, W1, weff, wq, copies,
+                     copy_stride);
   SCORE_CHECK_LAUNCH();
   return 0;
 }

@@ -234,6 +234,234 @@ __global__ __launch_bounds__(64 * HF_NW) void head_fwd_fused_kernel(const HeadFw
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Temporal attention forward in ONE launch (score.py:169-186, 210-215), a workgroup per group of S samples:
+//   inp rows [k, q o k] (k = [user state | item state | atten_info] of a slice, q the sample's projected query) -> LDS
+//   (and to global memory: the backward pass reads them) -> dense_3, folded (a1 = relu(inp . Weff + qz[sample])) on
+//   v_mfma_f32_16x16x4_f32 with the weights streamed from L2 (hf_tiles) -> dense_4 -> dense_5 -> mask -> softmax over
+//   the slices -> pooled states into the head's input.
+// As four launches (build [B*T, 2Dk] in global memory, a bf16x3 GEMM with N = 80 on 128-wide tiles plus its split-K
+// reduce, the tail kernel) this was 0.018 + 0.046 + 0.019 + 0.023 ms at cfg-3; the [B*T, 2Dk] matrix went out to HBM
+// and came straight back.  Here the rows of S samples form M-tiles of 16 (rows of different samples share a tile: the
+// fold puts the per-sample q into the A operand, the weight is common); waves 0..4 own the five 16-column tiles of
+// dense_3, waves 5..7 build the next M-tile meanwhile (two tile buffers).
+constexpr int AF_NW = 8;
+
+struct AttnFwdArgs {
+  int B, T, H, NI, N1, N2, S;
+  const float* q; const float* ur; const float* ir; const float* info;
+  const float* Weff; const float* qz;
+  const float* W4; const float* b4; const float* w5; const float* b5; const int32_t* length;
+  float* inp; float* a1; float* a2; float* score; float* head; int ldh, off_u, off_i;
+  int wcopies; int64_t wstride;   // replicas of Weff (head.hip: attn_fold_w1_kernel)
+};
+
+__device__ __forceinline__ void af_build(const AttnFwdArgs& a, float* __restrict__ xs, int LD, int Kp, int row0,
+                                         int row_end, int t0, int nthr) {
+  const int Dk = 2 * a.H + a.NI, Dk4 = Dk >> 2, K2 = 2 * Dk;
+  const int total = 16 * Dk4;
+  constexpr int U = 4;                 // items per trip: their loads go out together (one dependent round trip per item
+                                       // made the three building waves the slowest part of the kernel)
+  for (int e0 = t0; e0 < total; e0 += U * nthr) {
+    float4 k[U], qq[U];
+    int ii[U], jj[U], gg[U];
+    bool ok[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int e = e0 + u * nthr;
+      const int ec = e < total ? e : 0;
+      ii[u] = ec / Dk4; jj[u] = (ec - ii[u] * Dk4) * 4;
+      gg[u] = row0 + ii[u];
+      ok[u] = e < total && gg[u] < row_end;
+      const int g = gg[u] < row_end ? gg[u] : row_end - 1;           // clamped, unconditional loads
+      const int j = jj[u];
+      const float* src = j < a.H ? a.ur + (int64_t)g * a.H + j
+                                 : (j < 2 * a.H ? a.ir + (int64_t)g * a.H + (j - a.H) : a.info + (int64_t)g * a.NI + (j - 2 * a.H));
+      k[u] = ld4(src);
+      qq[u] = ld4(a.q + (int64_t)(g / a.T) * Dk + j);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (e0 + u * nthr >= total) continue;
+      float4 kk = k[u], qk = make_float4(qq[u].x * kk.x, qq[u].y * kk.y, qq[u].z * kk.z, qq[u].w * kk.w);
+      if (ok[u]) {
+#ifndef AFP_NOINP
+        st4(a.inp + (int64_t)gg[u] * K2 + jj[u], kk);
+        st4(a.inp + (int64_t)gg[u] * K2 + Dk + jj[u], qk);
+#endif
+      } else {
+        kk = make_float4(0.f, 0.f, 0.f, 0.f); qk = kk;
+      }
+      *reinterpret_cast<float4*>(xs + ii[u] * LD + jj[u]) = kk;
+      *reinterpret_cast<float4*>(xs + ii[u] * LD + Dk + jj[u]) = qk;
+    }
+  }
+  for (int e = t0; e < 16 * (Kp - K2); e += nthr) {      // zero padding of K up to a multiple of 16
+    const int i = e / (Kp - K2), j = e - i * (Kp - K2);
+    xs[i * LD + K2 + j] = 0.f;
+  }
+}
+
+// KQ = Kp / 4: k-steps per lane quarter.  A wave of the dense_3 phase keeps its tile's B operands -- one weight per
+// lane and k-step, KQ registers -- for the whole launch (streamed from L2 per M-tile, 10 chunks of 16 dependent-latency
+// loads each, that phase alone was ~50 us: the kernel measured 102 us against 78-95 for the launches it replaces).
+template <int KQ>
+__global__ __launch_bounds__(64 * AF_NW) void attn_fwd_fused_kernel(const AttnFwdArgs a) {
+  extern __shared__ float sm[];
+  const int T = a.T, H = a.H, N1 = a.N1, N2 = a.N2;
+  const int Dk = 2 * H + a.NI, K2 = 2 * Dk, Kp = 4 * KQ, LD = Kp + 4;
+  const int L1 = N1 + 1, L2 = N2 + 1;
+  float* xs0 = sm;                              // [16][LD] two M-tile buffers
+  float* xs1 = xs0 + 16 * LD;
+  float* a1s = xs1 + 16 * LD;                   // [S*T][L1]
+  float* w4s = a1s + a.S * T * L1;              // [N1][N2]
+  float* a2s = w4s + N1 * N2;                   // [S][T][L2]
+  float* scs = a2s + a.S * T * L2;              // [S][T]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lc = lane & 15, lq = lane >> 4;
+  const int b0 = blockIdx.x * a.S;
+  const int ns = min(a.S, a.B - b0);
+  const int row0 = b0 * T, row_end = row0 + ns * T;      // (B*T < 2^31: checked by the launcher)
+  const int ntile = (ns * T + 15) >> 4;
+  const int ntn = (N1 + 15) >> 4;               // <= 5 (checked by the launcher)
+
+  float breg[KQ];
+  if (wave < ntn) {
+    const int col = wave * 16 + lc;
+    // (workgroups b, b+8, ... share an XCD and its L2: they take different replicas)
+    const float* Wsrc = a.Weff + (int64_t)((blockIdx.x >> 3) % a.wcopies) * a.wstride;
+#pragma unroll
+    for (int s_ = 0; s_ < KQ; ++s_) {
+      const int k = lq * KQ + s_;
+#ifdef AFP_NOPRELOAD
+      const float w = (float)(k + col) * 1e-3f;
+#else
+      const float w = Wsrc[(int64_t)(k < K2 ? k : K2 - 1) * N1 + (col < N1 ? col : N1 - 1)];   // clamped, unconditional
+#endif
+      // (masked by a multiplication: behind a select the compiler puts every load under its own exec-mask branch with a
+      //  vmcnt(0) wait -- 148 dependent round trips, 34 us)
+      breg[s_] = w * ((k < K2 && col < N1) ? 1.0f : 0.0f);
+    }
+  }
+  for (int i = tid; i < N1 * N2; i += 64 * AF_NW) w4s[i] = a.W4[i];
+  af_build(a, xs0, LD, Kp, row0, row_end, tid, 64 * AF_NW);
+  __syncthreads();
+  for (int m = 0; m < ntile; ++m) {
+    float* xs = (m & 1) ? xs1 : xs0;
+    if (wave < ntn) {
+      hf_f32x4 acc[1] = {{0.f, 0.f, 0.f, 0.f}};
+      const int n0[1] = {wave * 16};
+      const float* xrow = xs + lc * LD + lq * KQ;
+#ifndef AFP_NOMFMA
+#ifdef AFP_TWOACC
+      hf_f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s4 = 0; s4 < KQ; s4 += 4) {
+        const float4 av = *reinterpret_cast<const float4*>(xrow + s4);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, breg[s4 + 0], acc[0], 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, breg[s4 + 1], acc2, 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, breg[s4 + 2], acc[0], 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, breg[s4 + 3], acc2, 0, 0, 0);
+      }
+      acc[0] += acc2;
+#else
+#pragma unroll
+      for (int s4 = 0; s4 < KQ; s4 += 4) {
+        const float4 av = *reinterpret_cast<const float4*>(xrow + s4);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, breg[s4 + 0], acc[0], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, breg[s4 + 1], acc[0], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, breg[s4 + 2], acc[0], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, breg[s4 + 3], acc[0], 0, 0, 0);
+      }
+#endif
+#else
+      acc[0][0] = xrow[0] * breg[0] + breg[KQ - 1];
+#endif
+      const int col = n0[0] + lc;
+      if (col < N1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = m * 16 + lq * 4 + r;
+          const int g = row0 + i;
+          if (g < row_end) {
+#ifdef AFP_NOEPI
+            const float v = fmaxf(acc[0][r], 0.f);
+            a1s[i * L1 + col] = v;
+#else
+            const float v = fmaxf(acc[0][r] + a.qz[(int64_t)(g / T) * N1 + col], 0.f);
+            a1s[i * L1 + col] = v;
+            a.a1[(int64_t)g * N1 + col] = v;
+#endif
+          }
+        }
+      }
+    } else if (m + 1 < ntile) {
+#ifndef AFP_NOBUILD
+      af_build(a, (m & 1) ? xs0 : xs1, LD, Kp, row0 + (m + 1) * 16, row_end, tid - 64 * ntn, 64 * (AF_NW - ntn));
+#endif
+    }
+    __syncthreads();
+  }
+
+#ifdef AFP_NOTAIL
+  return;
+#endif
+  // the tail (attn_tail_fwd_kernel's arithmetic, same order): the workgroup's S samples side by side, 512 / S threads each
+  const int gsz = 64 * AF_NW / a.S, s_ = tid / gsz, gt = tid - s_ * gsz;
+  const bool live = s_ < ns;
+  const int b = b0 + (live ? s_ : 0);
+  const float* a1b = a1s + s_ * T * L1;
+  float* a2l = a2s + s_ * T * L2;
+  float* sc = scs + s_ * T;
+  if (live) {
+    float* a2b = a.a2 + (int64_t)b * T * N2;
+    for (int i = gt; i < T * N2; i += gsz) {
+      const int t = i / N2, n = i - t * N2;
+      float acc = 0.f;
+#pragma unroll 8
+      for (int k = 0; k < N1; ++k) acc = fmaf(a1b[t * L1 + k], w4s[k * N2 + n], acc);
+      const float v = fmaxf(acc + a.b4[n], 0.f);
+      a2l[t * L2 + n] = v;
+      a2b[i] = v;
+    }
+  }
+  __syncthreads();
+  if (live) {
+    const int len = a.length[b];
+    for (int t = gt; t < T; t += gsz) {
+      float acc = 0.f;
+      for (int n = 0; n < N2; ++n) acc = fmaf(a2l[t * L2 + n], a.w5[n], acc);
+      sc[t] = t < len ? acc + a.b5[0] : -4294967295.0f;
+    }
+  }
+  __syncthreads();
+  float mx = -INFINITY, den = 0.f;
+  if (live) {
+    for (int t = 0; t < T; ++t) mx = fmaxf(mx, sc[t]);
+    for (int t = 0; t < T; ++t) den += expf(sc[t] - mx);
+  }
+  __syncthreads();
+  if (live) {
+    for (int t = gt; t < T; t += gsz) {
+      const float v = expf(sc[t] - mx) / den;
+      sc[t] = v;
+      a.score[(int64_t)b * T + t] = v;
+    }
+  }
+  __syncthreads();
+  if (live) {
+    for (int j = gt; j < 2 * H; j += gsz) {
+      const bool us = j < H;
+      const float* rep = (us ? a.ur : a.ir) + (int64_t)b * T * H + (us ? j : j - H);
+      float acc = 0.f;
+      for (int t = 0; t < T; ++t) acc = fmaf(rep[(int64_t)t * H], sc[t], acc);
+      const int off = us ? a.off_u : a.off_i;
+      if (off >= 0) a.head[(int64_t)b * a.ldh + off + (us ? j : j - H)] = acc;
+    }
+  }
+}
+
 }  // namespace
 
 // (what score_backward asks to know whether the forward pass has left dz2 behind)
@@ -267,6 +495,52 @@ int score_launch_head_fwd_fused(int B, int Dh, int N1, int N2, const float* x, c
   a.label = label; a.bn = bn; a.f1 = f1; a.f2 = f2; a.logit = logit; a.y = y; a.lossb = lossb; a.dlogit = dlogit;
   a.dz2 = dz2;
   hipLaunchKernelGGL(head_fwd_fused_kernel, dim3((B + HF_ROWS - 1) / HF_ROWS), dim3(64 * HF_NW), lds, s, a);
+  SCORE_CHECK_LAUNCH();
+  return 0;
+}
+
+// Returns SCORE_E_SHAPE when the shape does not fit (the caller then runs build + GEMM + tail as separate launches).
+int score_launch_attn_fwd_fused(int B, int T, int H, int NI, int N1, int N2, const float* q, const float* ur,
+                                const float* ir, const float* info, const float* Weff, const float* qz, const float* W4,
+                                const float* b4, const float* w5, const float* b5, const int32_t* length, float* inp,
+                                float* a1, float* a2, float* score, float* head, int ldh, int off_u, int off_i,
+                                hipStream_t s, int weff_copies, int64_t weff_copy_stride) {
+  if (B <= 0 || T <= 0 || (H & 3) || (NI & 3) || N1 > 16 * 5 || N1 <= 0 || N2 <= 0 || (int64_t)B * T >= (1LL << 30))
+    return SCORE_E_SHAPE;
+  const int K2 = 2 * (2 * H + NI), Kp = (K2 + 15) & ~15, LD = Kp + 4;
+  // samples per workgroup: enough workgroups for the chip first, then fuller M-tiles (4 samples of 18 slices: 72 rows in
+  // five tiles); bounded by LDS
+  int S = B >= 4 * 256 ? 4 : B >= 2 * 256 ? 2 : 1;
+  size_t lds = 0;
+  for (; S >= 1; S >>= 1) {
+    lds = ((size_t)2 * 16 * LD + (size_t)S * T * (N1 + 1) + (size_t)N1 * N2 + (size_t)S * T * (N2 + 1) + (size_t)S * T) * sizeof(float);
+    if (lds <= 150 * 1024) break;
+  }
+  if (S < 1) return SCORE_E_SHAPE;
+  if (Kp / 4 != 148 && Kp / 4 != 52 && Kp / 4 != 44) return SCORE_E_SHAPE;    // the instantiated register-resident widths
+  static thread_local bool attr_set = false;
+  if (!attr_set) {
+    for (const void* f : {reinterpret_cast<const void*>(attn_fwd_fused_kernel<148>),
+                          reinterpret_cast<const void*>(attn_fwd_fused_kernel<52>),
+                          reinterpret_cast<const void*>(attn_fwd_fused_kernel<44>)}) {
+      hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+      if (e != hipSuccess) return (int)e;
+    }
+    attr_set = true;
+  }
+  AttnFwdArgs a;
+  a.B = B; a.T = T; a.H = H; a.NI = NI; a.N1 = N1; a.N2 = N2; a.S = S;
+  a.q = q; a.ur = ur; a.ir = ir; a.info = info; a.Weff = Weff; a.qz = qz;
+  a.W4 = W4; a.b4 = b4; a.w5 = w5; a.b5 = b5; a.length = length;
+  a.inp = inp; a.a1 = a1; a.a2 = a2; a.score = score; a.head = head; a.ldh = ldh; a.off_u = off_u; a.off_i = off_i;
+  a.wcopies = weff_copies > 0 ? weff_copies : 1; a.wstride = weff_copy_stride;
+  const dim3 grid((B + S - 1) / S), block(64 * AF_NW);
+  switch (Kp / 4) {
+    case 148: hipLaunchKernelGGL(attn_fwd_fused_kernel<148>, grid, block, lds, s, a); break;   // H = 128, K = 10
+    case 52: hipLaunchKernelGGL(attn_fwd_fused_kernel<52>, grid, block, lds, s, a); break;     // H = 32, K = 10
+    case 44: hipLaunchKernelGGL(attn_fwd_fused_kernel<44>, grid, block, lds, s, a); break;     // H = 32, K = 5
+    default: return SCORE_E_SHAPE;
+  }
   SCORE_CHECK_LAUNCH();
   return 0;
 }

@@ -82,7 +82,9 @@ int score_launch_attn_inp_bwd(int B, int T, int H, int NI, const float* dinp, co
                               const float* ir, const float* info, const float* score, const float* dhead, int ldh,
                               int off_u, int off_i, const float* dqd, float* dur, float* dir, float* dinfo, float* dq,
                               hipStream_t s);
-int score_launch_attn_fold_w1(int Dk, int NA, const float* W1, float* weff, float* wq, hipStream_t s);
+int score_launch_attn_fold_w1(int Dk, int NA, const float* W1, float* weff, float* wq, hipStream_t s, int copies = 1,
+                              int64_t copy_stride = 0);
+#define SCORE_WEFF_COPIES 8       /* replicas of the folded attention weight (head.hip: attn_fold_w1_kernel) */
 int score_launch_attn_dzsum(int B, int T, int NA, const float* dz, float* dzsum, hipStream_t s);
 int score_launch_attn_w1_grad(int Dk, int NA, const float* dweff, const float* dwq, float* gW1, hipStream_t s);
 int score_launch_bn_fwd(int B, int Dh, const float* x, const float* gamma, const float* beta, float rs, float* y,
@@ -104,6 +106,12 @@ int score_launch_head_fwd_fused(int B, int Dh, int N1, int N2, const float* x, c
                                 float* logit, float* y, float* lossb, float* dlogit, int Bglobal, hipStream_t s,
                                 const uint64_t* seed_dev = nullptr, float* dz2 = nullptr);
 bool score_head_fwd_fused_fits(int B, int Dh, int N1, int N2);
+// head_fused.hip: attention input rows + dense_3 (folded) + dense_4 + dense_5 + masked softmax + pooling in one launch
+int score_launch_attn_fwd_fused(int B, int T, int H, int NI, int N1, int N2, const float* q, const float* ur,
+                                const float* ir, const float* info, const float* Weff, const float* qz, const float* W4,
+                                const float* b4, const float* w5, const float* b5, const int32_t* length, float* inp,
+                                float* a1, float* a2, float* score, float* head, int ldh, int off_u, int off_i,
+                                hipStream_t s, int weff_copies = 1, int64_t weff_copy_stride = 0);
 int score_launch_outer_relu_bwd(int B, int NF, const float* dlogit, const float* w, const float* f, float keep,
                                 float* dz, hipStream_t s);
 int score_launch_gru_wxcat(const float* gk0, const float* ck0, const float* gb0, const float* cb0, const float* gk1,

@@ -160,6 +160,7 @@ class SCOREBASE(object):
         self._tiled_ready = False    # row_step / alpha_ring describe the table
         self._tiled = None           # (row_step, alpha_ring, score_adam_table_t)
         self._pending_sweep = None   # (row range, step, event) of the window slice not launched yet
+        self._ev_stage = None        # a stage boundary of the backward pass (where the window slice starts)
         self.catchup_events = None   # optional (start, end) torch events around score_adam_catchup_ids (bench.py)
         self._ev_sweep = None
         self.w = torch.zeros((self.n_w,), **f32)
@@ -467,16 +468,38 @@ class SCOREBASE(object):
                 plan_done = self._side.record_event()
             st.plan_done_event = C.c_void_p(plan_done.cuda_event)
             self._plan_done = plan_done                  # keep the event alive until the backward has run
-            self._launch_sweep(self._side)               # time-tiled optimizer: this step's slice of the table
+        # time-tiled optimizer: where this step's slice of the table starts.  Beside the backward recurrence (stage
+        # boundary 2 of score_backward: a 140-us VALU-bound kernel next to a matrix-bound one that fills half the CUs)
+        # costs the step 0.02 ms; behind the occurrence sort -- beside the fused attention forward, whose 8-wave, 232-
+        # register workgroups cannot share a CU with it -- 0.06; boundaries 1 / 3 / 4: 0.03 / 0.03 / 0.2
+        # (SCORE_ADAM_SWEEP_AT=plan|1|2|3|4, profiles/r02_probes.md)
+        sweep_at = os.environ.get("SCORE_ADAM_SWEEP_AT", "2") if self._pending_sweep is not None else ""
+        if sweep_at == "plan":
+            self._launch_sweep(self._side)
         if self.scatter_mode == 0:
             self._begin_row_grads()         # the pull kernels mark what they write; no zero fill
         else:
             self._drop_row_marks()
             self.table_g.zero_()
+        events = self.bwd_events
+        ev_sweep_start = None
+        if sweep_at in ("1", "2", "3", "4"):
+            # the slice starts at a stage boundary of the backward pass (score_backward records the event there)
+            if self._ev_stage is None:
+                self._ev_stage = torch.cuda.Event()
+                self._ev_stage.record(cur)              # materialise the hipEvent_t
+            events = list(events) if events else [None] * 6
+            k = int(sweep_at)
+            if events[k] is None:
+                events[k] = self._ev_stage
+            ev_sweep_start = events[k]
         rc = self.lib.score_backward(C.byref(self.cfg), C.byref(st), C.byref(db.struct), float(keep_prob),
-                                     _ptr(self.w_g), _ptr(self.table_g), self._event_array(self.bwd_events),
+                                     _ptr(self.w_g), _ptr(self.table_g), self._event_array(events),
                                      self._stream())
         _lib.check(rc, "score_backward")
+        if ev_sweep_start is not None:
+            self._side.wait_event(ev_sweep_start)
+            self._launch_sweep(self._side)
         return lay, ws
 
     def _alpha(self, lr):
@@ -545,9 +568,8 @@ class SCOREBASE(object):
             ev[1].record()
         if sweep:
             # the window's slice of the table: must start after the rows above are done (it would take them for lagging
-            # ones) and finish before the next step's catch-up; forward_backward puts it behind the occurrence sort on
-            # the side stream, where it runs beside the recurrences (beside the HBM-bound gather it cost the gather
-            # 0.05 ms; SCORE_ADAM_SWEEP_INLINE=1 runs it on the main stream instead: measured 0.03 ms/step slower)
+            # ones) and finish before the next step's catch-up; forward_backward starts it on the side stream beside
+            # the backward recurrence (SCORE_ADAM_SWEEP_INLINE=1 runs it here on the main stream instead)
             rows, K = self._tbl.shape[0], self.adam_window
             j = (upto + 1) % K
             self._pending_sweep = (rows * j // K, rows * (j + 1) // K, upto, cur.record_event())
