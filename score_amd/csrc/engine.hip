@@ -281,10 +281,10 @@ static int side_stream(const score_state_t* st, SideStream** out) {
 }
 // A/B switches of the launch sequence, read from the environment ONCE (first call), not per step
 struct EnvFlags { bool head_unfused, attn_tail_unfused, wgrad_side, gru_stepwise, attn_fwd_unfused; };
+static bool env_on(const char* name) { const char* v = getenv(name); return v && *v && !(v[0] == '0' && !v[1]); }   // (set, not empty, not "0")
 static const EnvFlags& env_flags() {
-  static const EnvFlags f = {getenv("SCORE_HEAD_UNFUSED") != nullptr, getenv("SCORE_ATTN_TAIL_UNFUSED") != nullptr,
-                             getenv("SCORE_WGRAD_SIDE") != nullptr, getenv("SCORE_GRU_STEPWISE") != nullptr,
-                             getenv("SCORE_ATTN_FWD_UNFUSED") != nullptr};
+  static const EnvFlags f = {env_on("SCORE_HEAD_UNFUSED"), env_on("SCORE_ATTN_TAIL_UNFUSED"), env_on("SCORE_WGRAD_SIDE"),
+                             env_on("SCORE_GRU_STEPWISE"), env_on("SCORE_ATTN_FWD_UNFUSED")};
   return f;
 }
 #define HIPTRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return (int)e_; } while (0)
@@ -672,13 +672,21 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
     // (sum_t da1 -> adzsum feeds the query branch only: computed on the side stream below)
     G(gemm_queue_add(&gq, d.Dk, AT1, B, ws + w.q, d.Dk, ws + w.adzsum, AT1, ws + w.dwq, AT1));
     // (gw + P.at_w[1] is assembled from dweff / dwq after the queue is flushed)
-    G(gemm_mode_call(x3, 1, BT, 2 * d.Dk, AT1, ws + w.da1, AT1, ws + w.weff, AT1, ws + w.dainp, 2 * d.Dk, nullptr, 0,
-                 1.f, nullptr, 0, scratch, SF, s));
+    // d inp = da1 . Weff^T and its way into d (states, atten_info, q): one launch where the shape allows (head_fused.hip).
     // dq = sum_t d(q*k).k here; the per-sample q-term gradient dzsum . Wq^T is added, and the query projection's
     // backward runs, on the side stream below (beside the recurrence: only the target rows consume them)
-    G(score_launch_attn_inp_bwd(B, T, H, d.NI, ws + w.dainp, ws + w.q, ws + w.gru_out[0], ws + w.gru_out[1],
-                                ws + w.info, ws + w.att_score, ws + w.dhead, d.Dhead, d.off_u, d.off_i,
-                                nullptr, ws + w.dgru[0], ws + w.dgru[1], ws + w.dinfo, ws + w.dq, s));
+    int brc = env_flags().attn_fwd_unfused ? SCORE_E_SHAPE
+                  : score_launch_attn_inp_bwd_fused(B, T, H, d.NI, AT1, ws + w.da1, ws + w.weff, ws + w.q, ws + w.gru_out[0],
+                                                    ws + w.gru_out[1], ws + w.info, ws + w.att_score, ws + w.dhead, d.Dhead,
+                                                    d.off_u, d.off_i, ws + w.dgru[0], ws + w.dgru[1], ws + w.dinfo, ws + w.dq, s);
+    if (brc != 0 && brc != SCORE_E_SHAPE) return brc;
+    if (brc == SCORE_E_SHAPE) {
+      G(gemm_mode_call(x3, 1, BT, 2 * d.Dk, AT1, ws + w.da1, AT1, ws + w.weff, AT1, ws + w.dainp, 2 * d.Dk, nullptr, 0,
+                   1.f, nullptr, 0, scratch, SF, s));
+      G(score_launch_attn_inp_bwd(B, T, H, d.NI, ws + w.dainp, ws + w.q, ws + w.gru_out[0], ws + w.gru_out[1],
+                                  ws + w.info, ws + w.att_score, ws + w.dhead, d.Dhead, d.off_u, d.off_i,
+                                  nullptr, ws + w.dgru[0], ws + w.dgru[1], ws + w.dinfo, ws + w.dq, s));
+    }
   } else {
     // RIA: gradient enters through the final states only; atten_info is unused downstream
     for (int sd = 0; sd < 2; ++sd) {

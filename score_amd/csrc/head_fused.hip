@@ -462,6 +462,160 @@ __global__ __launch_bounds__(64 * AF_NW) void attn_fwd_fused_kernel(const AttnFw
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Backward of the folded dense_3 into the attention's input rows, and of the rows into the recurrent states, in ONE
+// launch: d inp = da1 . Weff^T ([B*T, 2Dk], K = 80) on v_mfma_f32_16x16x4_f32 with Weff^T resident in registers, then
+//   d k[b,t]  = d inp[:, :Dk] + q[b] o d inp[:, Dk:]  (+ the pooled-state path score[b,t] * d head into the two states)
+//   d q[b]    = sum_t k[b,t] o d inp[:, Dk:]
+// straight from the tile in LDS.  As two launches (an N = 592, K = 80 bf16x3 product of 51 us whose 43 MB result
+// attn_inp_bwd_kernel read back, 22 us) the [B*T, 2Dk] matrix went out to HBM and came straight back.
+constexpr int AB_NTW = 5;          // 16-column tiles of d inp per wave (8 waves: 2Dk <= 640)
+constexpr int AB_KQ = 20;          // k-steps per lane quarter: N1 = 80
+
+struct AttnBwdArgs {
+  int B, T, H, NI, S;
+  const float* da1; const float* Weff; const float* q; const float* ur; const float* ir; const float* info;
+  const float* score; const float* dhead; int ldh, off_u, off_i;
+  float* dur; float* dir; float* dinfo; float* dq;
+};
+
+__global__ __launch_bounds__(64 * AF_NW) void attn_inp_bwd_fused_kernel(const AttnBwdArgs a) {
+  extern __shared__ float sm[];
+  const int T = a.T, H = a.H, NI = a.NI;
+  const int Dk = 2 * H + NI, Dk4 = Dk >> 2, K2 = 2 * Dk, N1 = 4 * AB_KQ;
+  const int LDA = N1 + 4, LDO = K2 + 4;
+  float* xa = sm;                         // [16][LDA]  da1 rows of the M-tile
+  float* ot = xa + 16 * LDA;              // [16][LDO]  d inp tile, then (first half) k o d inp[:, Dk:]
+  float* dqs = ot + 16 * LDO;             // [S][Dk]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lc = lane & 15, lq = lane >> 4;
+  const int b0 = blockIdx.x * a.S;
+  const int ns = min(a.S, a.B - b0);
+  const int row0 = b0 * T, row_end = row0 + ns * T;
+  const int ntile = (ns * T + 15) >> 4;
+  const int ntn = (K2 + 15) >> 4;         // <= 8 * AB_NTW (checked by the launcher)
+
+  // B operands: B[k][n] = Weff[n][k], k contiguous -- five 16-byte loads per tile and lane, unconditional (clamped
+  // row, masked by a multiplication: see attn_fwd_fused_kernel)
+  float breg[AB_NTW][AB_KQ];
+#pragma unroll
+  for (int t = 0; t < AB_NTW; ++t) {
+    const int n = (wave + AF_NW * t) * 16 + lc;
+    const float msk = n < K2 ? 1.0f : 0.0f;
+    const float* wrow = a.Weff + (int64_t)(n < K2 ? n : K2 - 1) * N1 + lq * AB_KQ;
+#pragma unroll
+    for (int s4 = 0; s4 < AB_KQ; s4 += 4) {
+      const float4 w = ld4(wrow + s4);
+      breg[t][s4 + 0] = w.x * msk; breg[t][s4 + 1] = w.y * msk; breg[t][s4 + 2] = w.z * msk; breg[t][s4 + 3] = w.w * msk;
+    }
+  }
+  for (int i = tid; i < a.S * Dk; i += 64 * AF_NW) dqs[i] = 0.f;
+
+  for (int m = 0; m < ntile; ++m) {
+    const int g0 = row0 + m * 16;
+    // da1 rows of this tile
+    for (int e = tid; e < 16 * (N1 / 4); e += 64 * AF_NW) {
+      const int i = e / (N1 / 4), c = (e - i * (N1 / 4)) * 4;
+      const int g = g0 + i;
+      float4 v = ld4(a.da1 + (int64_t)(g < row_end ? g : row_end - 1) * N1 + c);
+      if (g >= row_end) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(xa + i * LDA + c) = v;
+    }
+    __syncthreads();
+    {
+      float4 av[AB_KQ / 4];
+#pragma unroll
+      for (int s4 = 0; s4 < AB_KQ / 4; ++s4) av[s4] = *reinterpret_cast<const float4*>(xa + lc * LDA + lq * AB_KQ + 4 * s4);
+#pragma unroll
+      for (int t = 0; t < AB_NTW; ++t) {
+        const int n0 = (wave + AF_NW * t) * 16;
+        if (n0 >= ntn * 16) continue;                   // (wave-uniform)
+        hf_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s4 = 0; s4 < AB_KQ / 4; ++s4) {
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s4].x, breg[t][4 * s4 + 0], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s4].y, breg[t][4 * s4 + 1], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s4].z, breg[t][4 * s4 + 2], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s4].w, breg[t][4 * s4 + 3], acc, 0, 0, 0);
+        }
+        const int col = n0 + lc;
+        if (col < K2) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ot[(lq * 4 + r) * LDO + col] = acc[r];
+        }
+      }
+    }
+    __syncthreads();
+    // d k rows out; k o d inp[:, Dk:] left in the tile's first half for the d q sums
+    constexpr int U = 3;
+    for (int e0 = tid; e0 < 16 * Dk4; e0 += U * 64 * AF_NW) {
+      float4 kv[U], qq[U], pl[U];
+      float sc[U];
+      int ii[U], jj[U], gg[U];
+      bool ok[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int e = e0 + u * 64 * AF_NW;
+        const int ec = e < 16 * Dk4 ? e : 0;
+        ii[u] = ec / Dk4; jj[u] = (ec - ii[u] * Dk4) * 4;
+        gg[u] = g0 + ii[u];
+        ok[u] = e < 16 * Dk4 && gg[u] < row_end;
+        const int g = gg[u] < row_end ? gg[u] : row_end - 1;
+        const int j = jj[u], b = g / T;
+        const float* src = j < H ? a.ur + (int64_t)g * H + j : (j < 2 * H ? a.ir + (int64_t)g * H + (j - H) : a.info + (int64_t)g * NI + (j - 2 * H));
+        kv[u] = ld4(src);
+        qq[u] = ld4(a.q + (int64_t)b * Dk + j);
+        sc[u] = a.score[g];
+        // pooled-state gradient of the column's state (none for the atten_info columns / a side the head does not take)
+        const int off = j < H ? a.off_u : a.off_i;
+        const bool hasp = j < 2 * H && off >= 0;
+        const float4 p4 = ld4(a.dhead + (int64_t)b * a.ldh + (hasp ? off + (j < H ? j : j - H) : 0));
+        const float pm = hasp ? 1.0f : 0.0f;
+        pl[u] = make_float4(p4.x * pm, p4.y * pm, p4.z * pm, p4.w * pm);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (e0 + u * 64 * AF_NW >= 16 * Dk4) continue;
+        float* o1 = ot + ii[u] * LDO + jj[u];
+        const float4 d1 = *reinterpret_cast<const float4*>(o1);
+        const float4 d3 = *reinterpret_cast<const float4*>(o1 + Dk);
+        float4 pr = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok[u]) {
+          const int j = jj[u];
+          float4 o;
+          o.x = fmaf(d3.x, qq[u].x, d1.x) + pl[u].x * sc[u]; o.y = fmaf(d3.y, qq[u].y, d1.y) + pl[u].y * sc[u];
+          o.z = fmaf(d3.z, qq[u].z, d1.z) + pl[u].z * sc[u]; o.w = fmaf(d3.w, qq[u].w, d1.w) + pl[u].w * sc[u];
+          float* dst = j < H ? a.dur + (int64_t)gg[u] * H + j
+                             : (j < 2 * H ? a.dir + (int64_t)gg[u] * H + (j - H) : a.dinfo + (int64_t)gg[u] * NI + (j - 2 * H));
+          st4(dst, o);
+          pr = make_float4(d3.x * kv[u].x, d3.y * kv[u].y, d3.z * kv[u].z, d3.w * kv[u].w);
+        }
+        *reinterpret_cast<float4*>(o1) = pr;
+      }
+    }
+    __syncthreads();
+    // d q[s][j] += sum over the tile's rows of sample s, in row order
+    for (int e = tid; e < ns * Dk4; e += 64 * AF_NW) {
+      const int s_ = e / Dk4, j = (e - s_ * Dk4) * 4;
+      const int lo = max(0, s_ * T - m * 16), hi = min(16, (s_ + 1) * T - m * 16);
+      if (lo < hi) {
+        float4 acc = *reinterpret_cast<const float4*>(dqs + s_ * Dk + j);
+        for (int i = lo; i < hi; ++i) {
+          const float4 v = *reinterpret_cast<const float4*>(ot + i * LDO + j);
+          acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        *reinterpret_cast<float4*>(dqs + s_ * Dk + j) = acc;
+      }
+    }
+    __syncthreads();
+  }
+  for (int e = tid; e < ns * Dk4; e += 64 * AF_NW) {
+    const int s_ = e / Dk4, j = (e - s_ * Dk4) * 4;
+    st4(a.dq + (int64_t)(b0 + s_) * Dk + j, *reinterpret_cast<const float4*>(dqs + s_ * Dk + j));
+  }
+}
+
 }  // namespace
 
 // (what score_backward asks to know whether the forward pass has left dz2 behind)
@@ -541,6 +695,34 @@ int score_launch_attn_fwd_fused(int B, int T, int H, int NI, int N1, int N2, con
     case 44: hipLaunchKernelGGL(attn_fwd_fused_kernel<44>, grid, block, lds, s, a); break;     // H = 32, K = 5
     default: return SCORE_E_SHAPE;
   }
+  SCORE_CHECK_LAUNCH();
+  return 0;
+}
+
+// Returns SCORE_E_SHAPE when the shape does not fit (the caller then runs the product and attn_inp_bwd_kernel).
+int score_launch_attn_inp_bwd_fused(int B, int T, int H, int NI, int N1, const float* da1, const float* Weff, const float* q,
+                                    const float* ur, const float* ir, const float* info, const float* score,
+                                    const float* dhead, int ldh, int off_u, int off_i, float* dur, float* dir, float* dinfo,
+                                    float* dq, hipStream_t s) {
+  const int Dk = 2 * H + NI, K2 = 2 * Dk;
+  if (B <= 0 || T <= 0 || (H & 3) || (NI & 3) || N1 != 4 * AB_KQ || K2 > 16 * AF_NW * AB_NTW || (int64_t)B * T >= (1LL << 30) ||
+      (ldh & 3) || (off_u >= 0 && (off_u & 3)) || (off_i >= 0 && (off_i & 3)))
+    return SCORE_E_SHAPE;
+  const int S = B >= 4 * 256 ? 4 : B >= 2 * 256 ? 2 : 1;
+  const size_t lds = ((size_t)16 * (N1 + 4) + (size_t)16 * (K2 + 4) + (size_t)S * Dk) * sizeof(float);
+  if (lds > 150 * 1024) return SCORE_E_SHAPE;
+  static thread_local bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_inp_bwd_fused_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  AttnBwdArgs a;
+  a.B = B; a.T = T; a.H = H; a.NI = NI; a.S = S;
+  a.da1 = da1; a.Weff = Weff; a.q = q; a.ur = ur; a.ir = ir; a.info = info; a.score = score; a.dhead = dhead;
+  a.ldh = ldh; a.off_u = off_u; a.off_i = off_i; a.dur = dur; a.dir = dir; a.dinfo = dinfo; a.dq = dq;
+  hipLaunchKernelGGL(attn_inp_bwd_fused_kernel, dim3((B + S - 1) / S), dim3(64 * AF_NW), lds, s, a);
   SCORE_CHECK_LAUNCH();
   return 0;
 }
