@@ -647,7 +647,12 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
   if (d.attn) {
     // ---- temporal attention (score.py:169-186, 214-215)
     // pooling / softmax / dense_5 backward and, in the same launch, dense_4's (da1 with dense_3's relu mask)
-    int prc = env_flags().attn_tail_unfused ? SCORE_E_SHAPE
+    // (on small batches the fused attention backward below does this part too -- one launch less: 0.0218 -> 0.0183 ms for
+    //  the stage at the reference's own shape; at cfg-3, where a workgroup per four samples serialises what 1024 small
+    //  workgroups do side by side, the separate launch stays: 0.0613 vs 0.0629)
+    const bool pool_in_fused = !env_flags().attn_fwd_unfused && !env_flags().attn_tail_unfused && (int64_t)B * T < 8192 &&
+                               score_attn_inp_bwd_fused_fits(B, T, H, d.NI, AT1, AT2, d.Dhead, d.off_u, d.off_i, true);
+    int prc = pool_in_fused ? 0 : env_flags().attn_tail_unfused ? SCORE_E_SHAPE
                   : score_launch_attn_pool_bwd(B, T, H, AT2, ws + w.a2, W + P.at_w[3], bt->length, ws + w.gru_out[0],
                                                ws + w.gru_out[1], ws + w.att_score, ws + w.dhead, d.Dhead, d.off_u,
                                                d.off_i, ws + w.ds, ws + w.da2, s, AT1, W + P.at_w[2], ws + w.a1, ws + w.da1);
@@ -676,9 +681,16 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
     // dq = sum_t d(q*k).k here; the per-sample q-term gradient dzsum . Wq^T is added, and the query projection's
     // backward runs, on the side stream below (beside the recurrence: only the target rows consume them)
     int brc = env_flags().attn_fwd_unfused ? SCORE_E_SHAPE
+              : pool_in_fused
+                  ? score_launch_attn_inp_bwd_fused(B, T, H, d.NI, AT1, nullptr, ws + w.weff, ws + w.q, ws + w.gru_out[0],
+                                                    ws + w.gru_out[1], ws + w.info, ws + w.att_score, ws + w.dhead, d.Dhead,
+                                                    d.off_u, d.off_i, ws + w.dgru[0], ws + w.dgru[1], ws + w.dinfo, ws + w.dq, s,
+                                                    AT2, ws + w.a2, ws + w.a1, W + P.at_w[3], W + P.at_w[2], bt->length,
+                                                    ws + w.ds, ws + w.da2, ws + w.da1)
                   : score_launch_attn_inp_bwd_fused(B, T, H, d.NI, AT1, ws + w.da1, ws + w.weff, ws + w.q, ws + w.gru_out[0],
                                                     ws + w.gru_out[1], ws + w.info, ws + w.att_score, ws + w.dhead, d.Dhead,
                                                     d.off_u, d.off_i, ws + w.dgru[0], ws + w.dgru[1], ws + w.dinfo, ws + w.dq, s);
+    if (pool_in_fused && brc != 0) return brc == SCORE_E_SHAPE ? SCORE_E_BADARG : brc;     // (the predicate said it fits)
     if (brc != 0 && brc != SCORE_E_SHAPE) return brc;
     if (brc == SCORE_E_SHAPE) {
       G(gemm_mode_call(x3, 1, BT, 2 * d.Dk, AT1, ws + w.da1, AT1, ws + w.weff, AT1, ws + w.dainp, 2 * d.Dk, nullptr, 0,

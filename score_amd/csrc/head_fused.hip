@@ -478,6 +478,11 @@ struct AttnBwdArgs {
   const float* da1; const float* Weff; const float* q; const float* ur; const float* ir; const float* info;
   const float* score; const float* dhead; int ldh, off_u, off_i;
   float* dur; float* dir; float* dinfo; float* dq;
+  // pool != 0: the pooling / masked softmax / dense_5 / dense_4 backward of the samples runs here first
+  // (attn_pool_bwd_kernel's arithmetic) and da1 is an OUTPUT, like ds and da2
+  int pool, N2;
+  const float* a2; const float* a1; const float* w5; const float* W4; const int32_t* length;
+  float* ds; float* da2; float* da1_out;
 };
 
 __global__ __launch_bounds__(64 * AF_NW) void attn_inp_bwd_fused_kernel(const AttnBwdArgs a) {
@@ -485,9 +490,13 @@ __global__ __launch_bounds__(64 * AF_NW) void attn_inp_bwd_fused_kernel(const At
   const int T = a.T, H = a.H, NI = a.NI;
   const int Dk = 2 * H + NI, Dk4 = Dk >> 2, K2 = 2 * Dk, N1 = 4 * AB_KQ;
   const int LDA = N1 + 4, LDO = K2 + 4;
-  float* xa = sm;                         // [16][LDA]  da1 rows of the M-tile
-  float* ot = xa + 16 * LDA;              // [16][LDO]  d inp tile, then (first half) k o d inp[:, Dk:]
+  const int RT = ((a.S * T + 15) >> 4) << 4;      // rows of the workgroup, padded to whole M-tiles
+  float* da1s = sm;                       // [RT][LDA]  da1 rows of the workgroup's samples
+  float* ot = da1s + RT * LDA;            // [16][LDO]  d inp tile, then (first half) k o d inp[:, Dk:]
   float* dqs = ot + 16 * LDO;             // [S][Dk]
+  float* sds = dqs + a.S * Dk;            // [S][T]            (pool)
+  float* d2s = sds + a.S * T;             // [S][T][N2 + 1]    (pool)
+  float* w4s = d2s + a.S * T * (a.N2 + 1);  // [N1][N2 + 1]   (pool)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lc = lane & 15, lq = lane >> 4;
   const int b0 = blockIdx.x * a.S;
@@ -511,22 +520,80 @@ __global__ __launch_bounds__(64 * AF_NW) void attn_inp_bwd_fused_kernel(const At
     }
   }
   for (int i = tid; i < a.S * Dk; i += 64 * AF_NW) dqs[i] = 0.f;
+  for (int i = tid; i < RT * LDA; i += 64 * AF_NW) da1s[i] = 0.f;
+  __syncthreads();
+  if (!a.pool) {
+    // da1 rows of the workgroup's samples (computed by an earlier launch)
+    for (int e = tid; e < ns * T * (N1 / 4); e += 64 * AF_NW) {
+      const int i = e / (N1 / 4), c = (e - i * (N1 / 4)) * 4;
+      *reinterpret_cast<float4*>(da1s + i * LDA + c) = ld4(a.da1 + (int64_t)(row0 + i) * N1 + c);
+    }
+  } else {
+    // attn_pool_bwd_kernel's part, the S samples side by side (512 / S threads each):
+    //   dscore_t = duf.ur_t + dif.ir_t ; ds_t = score_t (dscore_t - sum score*dscore) [t < len]
+    //   da2[t][n] = ds_t * w5[n] * [a2 > 0] ; da1[t][k] = [a1 > 0] sum_n da2[t][n] W4[k][n]
+    const int NA = a.N2, LW = NA + 1;
+    const int gsz = 64 * AF_NW / a.S, s_ = tid / gsz, gt = tid - s_ * gsz;
+    const bool live = s_ < ns;
+    const int b = b0 + (live ? s_ : 0);
+    float* sd = sds + s_ * T;
+    float* d2 = d2s + s_ * T * LW;
+    for (int i = tid; i < N1 * NA; i += 64 * AF_NW) { const int k = i / NA; w4s[k * LW + (i - k * NA)] = a.W4[i]; }
+    constexpr int LPT = 4;                           // lanes per slice of the dscore dot products
+    if (live) {
+      const int gl = gt % LPT;
+      const float* du = a.off_u >= 0 ? a.dhead + (int64_t)b * a.ldh + a.off_u : nullptr;
+      const float* di = a.off_i >= 0 ? a.dhead + (int64_t)b * a.ldh + a.off_i : nullptr;
+      for (int t0 = 0; t0 < T; t0 += gsz / LPT) {
+        const int t = t0 + gt / LPT;
+        const int64_t bt = (int64_t)b * T + (t < T ? t : T - 1);
+        float part = 0.f;
+        for (int j = gl; j < H; j += LPT) {
+          if (du) part = fmaf(du[j], a.ur[bt * H + j], part);
+          if (di) part = fmaf(di[j], a.ir[bt * H + j], part);
+        }
+        part = group_sum(part, LPT);
+        if (gl == 0 && t < T) sd[t] = part;
+      }
+    }
+    __syncthreads();
+    if (live) {
+      const int len = a.length[b];
+      float tot = 0.f;
+      for (int t = 0; t < T; ++t) tot = fmaf(a.score[(int64_t)b * T + t], sd[t], tot);
+      for (int i = gt; i < T * NA; i += gsz) {
+        const int t = i / NA, n = i - t * NA;
+        const int64_t bt = (int64_t)b * T + t;
+        const float g = t < len ? a.score[bt] * (sd[t] - tot) : 0.f;
+        const float dv = a.a2[bt * NA + n] > 0.f ? g * a.w5[n] : 0.f;
+        a.da2[bt * NA + n] = dv;
+        d2[t * LW + n] = dv;
+        if (n == 0) a.ds[bt] = g;
+      }
+    }
+    __syncthreads();
+    if (live) {
+      for (int i = gt; i < T * N1; i += gsz) {
+        const int t = i / N1, k = i - t * N1;
+        const int64_t e = ((int64_t)b * T + t) * N1 + k;
+        float acc = 0.f;
+#pragma unroll 8
+        for (int n = 0; n < NA; ++n) acc = fmaf(d2[t * LW + n], w4s[k * LW + n], acc);
+        const float v = a.a1[e] > 0.f ? acc : 0.f;
+        a.da1_out[e] = v;
+        da1s[(s_ * T + t) * LDA + k] = v;
+      }
+    }
+  }
+  __syncthreads();
 
   for (int m = 0; m < ntile; ++m) {
     const int g0 = row0 + m * 16;
-    // da1 rows of this tile
-    for (int e = tid; e < 16 * (N1 / 4); e += 64 * AF_NW) {
-      const int i = e / (N1 / 4), c = (e - i * (N1 / 4)) * 4;
-      const int g = g0 + i;
-      float4 v = ld4(a.da1 + (int64_t)(g < row_end ? g : row_end - 1) * N1 + c);
-      if (g >= row_end) v = make_float4(0.f, 0.f, 0.f, 0.f);
-      *reinterpret_cast<float4*>(xa + i * LDA + c) = v;
-    }
-    __syncthreads();
     {
       float4 av[AB_KQ / 4];
 #pragma unroll
-      for (int s4 = 0; s4 < AB_KQ / 4; ++s4) av[s4] = *reinterpret_cast<const float4*>(xa + lc * LDA + lq * AB_KQ + 4 * s4);
+      for (int s4 = 0; s4 < AB_KQ / 4; ++s4)
+        av[s4] = *reinterpret_cast<const float4*>(da1s + (m * 16 + lc) * LDA + lq * AB_KQ + 4 * s4);
 #pragma unroll
       for (int t = 0; t < AB_NTW; ++t) {
         const int n0 = (wave + AF_NW * t) * 16;
@@ -699,18 +766,35 @@ int score_launch_attn_fwd_fused(int B, int T, int H, int NI, int N1, int N2, con
   return 0;
 }
 
+static bool ab_plan(int B, int T, int H, int NI, int N1, int N2, int ldh, int off_u, int off_i, bool pool, int* S_out,
+                    size_t* lds_out) {
+  const int Dk = 2 * H + NI, K2 = 2 * Dk;
+  if (B <= 0 || T <= 0 || (H & 3) || (NI & 3) || N1 != 4 * AB_KQ || K2 > 16 * AF_NW * AB_NTW || (int64_t)B * T >= (1LL << 30) ||
+      (ldh & 3) || (off_u >= 0 && (off_u & 3)) || (off_i >= 0 && (off_i & 3)) || (pool && N2 <= 0))
+    return false;
+  const int S = B >= 4 * 256 ? 4 : B >= 2 * 256 ? 2 : 1;
+  const int RT = ((S * T + 15) >> 4) << 4;
+  const size_t lds = ((size_t)RT * (N1 + 4) + (size_t)16 * (K2 + 4) + (size_t)S * Dk +
+                      (pool ? (size_t)S * T + (size_t)S * T * (N2 + 1) + (size_t)N1 * (N2 + 1) : 0)) * sizeof(float);
+  if (lds > 150 * 1024) return false;
+  *S_out = S; *lds_out = lds;
+  return true;
+}
+bool score_attn_inp_bwd_fused_fits(int B, int T, int H, int NI, int N1, int N2, int ldh, int off_u, int off_i, bool pool) {
+  int S; size_t lds;
+  return ab_plan(B, T, H, NI, N1, N2, ldh, off_u, off_i, pool, &S, &lds);
+}
+
 // Returns SCORE_E_SHAPE when the shape does not fit (the caller then runs the product and attn_inp_bwd_kernel).
 int score_launch_attn_inp_bwd_fused(int B, int T, int H, int NI, int N1, const float* da1, const float* Weff, const float* q,
                                     const float* ur, const float* ir, const float* info, const float* score,
                                     const float* dhead, int ldh, int off_u, int off_i, float* dur, float* dir, float* dinfo,
-                                    float* dq, hipStream_t s) {
-  const int Dk = 2 * H + NI, K2 = 2 * Dk;
-  if (B <= 0 || T <= 0 || (H & 3) || (NI & 3) || N1 != 4 * AB_KQ || K2 > 16 * AF_NW * AB_NTW || (int64_t)B * T >= (1LL << 30) ||
-      (ldh & 3) || (off_u >= 0 && (off_u & 3)) || (off_i >= 0 && (off_i & 3)))
-    return SCORE_E_SHAPE;
-  const int S = B >= 4 * 256 ? 4 : B >= 2 * 256 ? 2 : 1;
-  const size_t lds = ((size_t)16 * (N1 + 4) + (size_t)16 * (K2 + 4) + (size_t)S * Dk) * sizeof(float);
-  if (lds > 150 * 1024) return SCORE_E_SHAPE;
+                                    float* dq, hipStream_t s, int N2, const float* a2, const float* a1, const float* w5,
+                                    const float* W4, const int32_t* length, float* ds, float* da2, float* da1_out) {
+  const int pool = a2 != nullptr;
+  if (pool && (!a1 || !w5 || !W4 || !length || !ds || !da2 || !da1_out)) return SCORE_E_BADARG;
+  int S; size_t lds;
+  if (!ab_plan(B, T, H, NI, N1, N2, ldh, off_u, off_i, pool != 0, &S, &lds)) return SCORE_E_SHAPE;
   static thread_local bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_inp_bwd_fused_kernel),
@@ -722,6 +806,8 @@ int score_launch_attn_inp_bwd_fused(int B, int T, int H, int NI, int N1, const f
   a.B = B; a.T = T; a.H = H; a.NI = NI; a.S = S;
   a.da1 = da1; a.Weff = Weff; a.q = q; a.ur = ur; a.ir = ir; a.info = info; a.score = score; a.dhead = dhead;
   a.ldh = ldh; a.off_u = off_u; a.off_i = off_i; a.dur = dur; a.dir = dir; a.dinfo = dinfo; a.dq = dq;
+  a.pool = pool; a.N2 = pool ? N2 : 0; a.a2 = a2; a.a1 = a1; a.w5 = w5; a.W4 = W4; a.length = length; a.ds = ds; a.da2 = da2;
+  a.da1_out = da1_out;
   hipLaunchKernelGGL(attn_inp_bwd_fused_kernel, dim3((B + S - 1) / S), dim3(64 * AF_NW), lds, s, a);
   SCORE_CHECK_LAUNCH();
   return 0;

@@ -87,7 +87,10 @@ int score_launch_attn_fold_w1(int Dk, int NA, const float* W1, float* weff, floa
 int score_launch_attn_inp_bwd_fused(int B, int T, int H, int NI, int N1, const float* da1, const float* Weff, const float* q,
                                     const float* ur, const float* ir, const float* info, const float* score,
                                     const float* dhead, int ldh, int off_u, int off_i, float* dur, float* dir, float* dinfo,
-                                    float* dq, hipStream_t s);
+                                    float* dq, hipStream_t s, int N2 = 0, const float* a2 = nullptr, const float* a1 = nullptr,
+                                    const float* w5 = nullptr, const float* W4 = nullptr, const int32_t* length = nullptr,
+                                    float* ds = nullptr, float* da2 = nullptr, float* da1_out = nullptr);
+bool score_attn_inp_bwd_fused_fits(int B, int T, int H, int NI, int N1, int N2, int ldh, int off_u, int off_i, bool pool);
 #define SCORE_WEFF_COPIES 8       /* replicas of the folded attention weight (head.hip: attn_fold_w1_kernel) */
 int score_launch_attn_dzsum(int B, int T, int NA, const float* dz, float* dzsum, hipStream_t s);
 int score_launch_attn_w1_grad(int Dk, int NA, const float* dweff, const float* dwq, float* gW1, hipStream_t s);
