@@ -631,16 +631,28 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
   // fc2
   G(gemm_queue_add(&gq, FC1, FC2, B, ws + w.f1, FC1, ws + w.dz2, FC2, gw + P.fc_w[1], FC2));
   G(colsum_queue_add(&cq, ws + w.dz2, B, FC2, FC2, gw + P.fc_b[1], 0));
-  G(gemm_mode_call(x3, 1, B, FC1, FC2, ws + w.dz2, FC2, W + P.fc_w[1], FC2, ws + w.dz1, FC1, nullptr, GF_RELUGRAD, keep_prob,
-                   reinterpret_cast<const uint8_t*>(ws + w.f1), 0, scratch, SF, s));   // relu/dropout mask of fc1 in the epilogue
+  const float rs = (float)(1.0 / sqrt(1.0 + 1e-3));
+  // dz1, d bn1, d head input and bn1's d gamma terms: one launch (head_fused.hip) ...
+  int hbrc = env_flags().head_unfused ? SCORE_E_SHAPE
+                 : score_launch_head_bwd_fused(B, d.Dhead, FC1, FC2, ws + w.dz2, W + P.fc_w[1], ws + w.f1, keep_prob,
+                                               W + P.fc_w[0], ws + w.head_inp, W + P.bn_g, rs, ws + w.dz1, ws + w.dbn,
+                                               ws + w.dhead, ws + w.dgstage, s);
+  if (hbrc != 0 && hbrc != SCORE_E_SHAPE) return hbrc;
+  if (hbrc == SCORE_E_SHAPE)      // ... or layer by layer
+    G(gemm_mode_call(x3, 1, B, FC1, FC2, ws + w.dz2, FC2, W + P.fc_w[1], FC2, ws + w.dz1, FC1, nullptr, GF_RELUGRAD, keep_prob,
+                     reinterpret_cast<const uint8_t*>(ws + w.f1), 0, scratch, SF, s));   // relu/dropout mask of fc1 in the epilogue
   // fc1 + bn1
   G(gemm_queue_add(&gq, d.Dhead, FC1, B, ws + w.bn, d.Dhead, ws + w.dz1, FC1, gw + P.fc_w[0], FC1));
   G(colsum_queue_add(&cq, ws + w.dz1, B, FC1, FC1, gw + P.fc_b[0], 0));
-  G(gemm_mode_call(x3, 1, B, d.Dhead, FC1, ws + w.dz1, FC1, W + P.fc_w[0], FC1, ws + w.dbn, d.Dhead, nullptr, 0, 1.f,
-               nullptr, 0, scratch, SF, s));
-  const float rs = (float)(1.0 / sqrt(1.0 + 1e-3));
-  G(score_launch_bn_bwd(B, d.Dhead, ws + w.head_inp, W + P.bn_g, rs, ws + w.dbn, ws + w.dhead, gw + P.bn_g,
-                        gw + P.bn_b, ws + w.dgstage, scratch, SF, &cq, s));
+  if (hbrc == SCORE_E_SHAPE) {
+    G(gemm_mode_call(x3, 1, B, d.Dhead, FC1, ws + w.dz1, FC1, W + P.fc_w[0], FC1, ws + w.dbn, d.Dhead, nullptr, 0, 1.f,
+                 nullptr, 0, scratch, SF, s));
+    G(score_launch_bn_bwd(B, d.Dhead, ws + w.head_inp, W + P.bn_g, rs, ws + w.dbn, ws + w.dhead, gw + P.bn_g,
+                          gw + P.bn_b, ws + w.dgstage, scratch, SF, &cq, s));
+  } else {                        // (bn1's d gamma / d beta: column sums of what the fused kernel wrote)
+    G(colsum_queue_add(&cq, ws + w.dgstage, B, d.Dhead, d.Dhead, gw + P.bn_g, 0));
+    G(colsum_queue_add(&cq, ws + w.dbn, B, d.Dhead, d.Dhead, gw + P.bn_b, 0));
+  }
 
   EV(1);
   const float* dfinal[2] = {nullptr, nullptr};

@@ -683,6 +683,139 @@ __global__ __launch_bounds__(64 * AF_NW) void attn_inp_bwd_fused_kernel(const At
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// build_fc_net backward down to the head's input in ONE launch (score.py:68-76 backwards): from dz2 (written by the
+// fused forward) a workgroup of 16 samples computes dz1 = [f1 > 0] (dz2 . W2^T) / keep and d bn1 = dz1 . W1^T on
+// v_mfma_f32_16x16x4_f32, then bn1's backward (d head = d bn * gamma * rs, the d gamma terms d bn * x * rs).  The
+// transposed weights are k-contiguous per output column, so a lane takes its B operands with 16-byte loads: fc2's two
+// tiles per wave stay in registers, fc1's are streamed a tile ahead.  It was three launches (two K = 80 / K = 200
+// products of 1024 rows and the element-wise bn1 backward: 14 + 13 + 6 us).
+constexpr int HB_K2Q = 20;      // fc2: K = FC2 = 80 -> k-steps per lane quarter
+constexpr int HB_K1Q = 52;      // fc1: K = FC1 = 200 -> padded to 208
+
+struct HeadBwdArgs {
+  int B, Dh;
+  const float* dz2; const float* W2; const float* f1; float keep;
+  const float* W1; const float* x; const float* gamma; float rs;
+  float* dz1; float* dbn; float* dhead; float* tmp;
+};
+
+__global__ __launch_bounds__(64 * HF_NW) void head_bwd_fused_kernel(const HeadBwdArgs a) {
+  constexpr int N1 = 4 * HB_K2Q * 0 + 200, N2 = 80, KP1 = 4 * HB_K1Q;     // FC1, FC2, FC1 padded
+  constexpr int LD2 = N2 + 4, LD1 = KP1 + 4;
+  __shared__ __attribute__((aligned(16))) float z2s[HF_ROWS * LD2];          // dz2 rows
+  __shared__ __attribute__((aligned(16))) float z1s[HF_ROWS * LD1];          // dz1 rows, zero beyond FC1
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lc = lane & 15, lq = lane >> 4;
+  const int b0 = blockIdx.x * HF_ROWS;
+  for (int e = tid; e < HF_ROWS * (N2 / 4); e += 64 * HF_NW) {
+    const int i = e / (N2 / 4), c = (e - i * (N2 / 4)) * 4;
+    const int row = b0 + i < a.B ? b0 + i : a.B - 1;
+    float4 v = ld4(a.dz2 + (int64_t)row * N2 + c);
+    if (b0 + i >= a.B) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4*>(z2s + i * LD2 + c) = v;
+  }
+  for (int e = tid; e < HF_ROWS * (LD1 - N1); e += 64 * HF_NW) {
+    const int i = e / (LD1 - N1), c = e - i * (LD1 - N1);
+    z1s[i * LD1 + N1 + c] = 0.f;
+  }
+  // fc2 backward: tiles wave and wave + 8 of the 13; B[k][n] = W2[n][k]
+  float b2[2][HB_K2Q];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int n = (wave + HF_NW * t) * 16 + lc;
+    const float msk = n < N1 ? 1.0f : 0.0f;
+    const float* wrow = a.W2 + (int64_t)(n < N1 ? n : N1 - 1) * N2 + lq * HB_K2Q;
+#pragma unroll
+    for (int s4 = 0; s4 < HB_K2Q; s4 += 4) {
+      const float4 w = ld4(wrow + s4);
+      b2[t][s4 + 0] = w.x * msk; b2[t][s4 + 1] = w.y * msk; b2[t][s4 + 2] = w.z * msk; b2[t][s4 + 3] = w.w * msk;
+    }
+  }
+  __syncthreads();
+  {
+    float4 av[HB_K2Q / 4];
+#pragma unroll
+    for (int s4 = 0; s4 < HB_K2Q / 4; ++s4) av[s4] = *reinterpret_cast<const float4*>(z2s + lc * LD2 + lq * HB_K2Q + 4 * s4);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int n0 = (wave + HF_NW * t) * 16;
+      if (n0 >= N1) continue;
+      hf_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s4 = 0; s4 < HB_K2Q / 4; ++s4) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s4].x, b2[t][4 * s4 + 0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s4].y, b2[t][4 * s4 + 1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s4].z, b2[t][4 * s4 + 2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s4].w, b2[t][4 * s4 + 3], acc, 0, 0, 0);
+      }
+      const int col = n0 + lc;
+      if (col < N1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = lq * 4 + r, row = b0 + i;
+          float v = 0.f;
+          if (row < a.B) {
+            v = a.f1[(int64_t)row * N1 + col] > 0.f ? acc[r] / a.keep : 0.f;      // relu (+ dropout) of fc1, as the GEMM epilogue had it
+            a.dz1[(int64_t)row * N1 + col] = v;
+          }
+          z1s[i * LD1 + col] = v;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // fc1 backward + bn1 backward: tiles wave, wave + 8, ... of ceil(Dh / 16); B[k][n] = W1[n][k], streamed one tile ahead
+  const int nt = (a.Dh + 15) >> 4;
+  float4 av[HB_K1Q / 4];
+#pragma unroll
+  for (int s4 = 0; s4 < HB_K1Q / 4; ++s4) av[s4] = *reinterpret_cast<const float4*>(z1s + lc * LD1 + lq * HB_K1Q + 4 * s4);
+  float4 bw[2][HB_K1Q / 4];
+  auto fetch = [&](float4 (&dst)[HB_K1Q / 4], int tile) {
+    const int n = tile * 16 + lc;
+    const float* wrow = a.W1 + (int64_t)(n < a.Dh ? n : a.Dh - 1) * N1 + lq * HB_K1Q;
+#pragma unroll
+    for (int s4 = 0; s4 < HB_K1Q / 4; ++s4) {
+      // (the last quarter's k range runs past FC1 = 200 into the next row: those products meet the zero padding of z1s)
+      const int k = lq * HB_K1Q + 4 * s4;
+      dst[s4] = ld4(k + 3 < N1 ? wrow + 4 * s4 : a.W1);
+    }
+  };
+  if (wave < nt) fetch(bw[0], wave);
+  int cur = 0;
+  for (int tile = wave; tile < nt; tile += HF_NW, cur ^= 1) {
+    if (tile + HF_NW < nt) {
+      if (cur == 0) fetch(bw[1], tile + HF_NW); else fetch(bw[0], tile + HF_NW);
+    }
+    hf_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int col = tile * 16 + lc;
+    const float cm = col < a.Dh ? 1.0f : 0.0f;
+#pragma unroll
+    for (int s4 = 0; s4 < HB_K1Q / 4; ++s4) {
+      const float4 w = cur == 0 ? bw[0][s4] : bw[1][s4];
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s4].x, w.x * cm, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s4].y, w.y * cm, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s4].z, w.z * cm, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s4].w, w.w * cm, acc, 0, 0, 0);
+    }
+    if (col < a.Dh) {
+      const float gs = a.gamma[col] * a.rs;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = b0 + lq * 4 + r;
+        if (row < a.B) {
+          const int64_t e = (int64_t)row * a.Dh + col;
+          const float dy = acc[r];
+          a.dbn[e] = dy;
+          a.dhead[e] = dy * gs;
+          a.tmp[e] = dy * (a.x[e] * a.rs);
+        }
+      }
+    }
+  }
+}
+
 }  // namespace
 
 // (what score_backward asks to know whether the forward pass has left dz2 behind)
@@ -809,6 +942,19 @@ int score_launch_attn_inp_bwd_fused(int B, int T, int H, int NI, int N1, const f
   a.pool = pool; a.N2 = pool ? N2 : 0; a.a2 = a2; a.a1 = a1; a.w5 = w5; a.W4 = W4; a.length = length; a.ds = ds; a.da2 = da2;
   a.da1_out = da1_out;
   hipLaunchKernelGGL(attn_inp_bwd_fused_kernel, dim3((B + S - 1) / S), dim3(64 * AF_NW), lds, s, a);
+  SCORE_CHECK_LAUNCH();
+  return 0;
+}
+
+// Returns SCORE_E_SHAPE when the layer widths are not build_fc_net's (the caller then runs the layer-by-layer path).
+int score_launch_head_bwd_fused(int B, int Dh, int N1, int N2, const float* dz2, const float* W2, const float* f1, float keep,
+                                const float* W1, const float* x, const float* gamma, float rs, float* dz1, float* dbn,
+                                float* dhead, float* tmp, hipStream_t s) {
+  if (B <= 0 || Dh <= 0 || N1 != 200 || N2 != 80) return SCORE_E_SHAPE;
+  HeadBwdArgs a;
+  a.B = B; a.Dh = Dh; a.dz2 = dz2; a.W2 = W2; a.f1 = f1; a.keep = keep; a.W1 = W1; a.x = x; a.gamma = gamma; a.rs = rs;
+  a.dz1 = dz1; a.dbn = dbn; a.dhead = dhead; a.tmp = tmp;
+  hipLaunchKernelGGL(head_bwd_fused_kernel, dim3((B + HF_ROWS - 1) / HF_ROWS), dim3(64 * HF_NW), 0, s, a);
   SCORE_CHECK_LAUNCH();
   return 0;
 }

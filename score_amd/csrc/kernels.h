@@ -113,6 +113,9 @@ int score_launch_head_fwd_fused(int B, int Dh, int N1, int N2, const float* x, c
                                 float* logit, float* y, float* lossb, float* dlogit, int Bglobal, hipStream_t s,
                                 const uint64_t* seed_dev = nullptr, float* dz2 = nullptr);
 bool score_head_fwd_fused_fits(int B, int Dh, int N1, int N2);
+int score_launch_head_bwd_fused(int B, int Dh, int N1, int N2, const float* dz2, const float* W2, const float* f1, float keep,
+                                const float* W1, const float* x, const float* gamma, float rs, float* dz1, float* dbn,
+                                float* dhead, float* tmp, hipStream_t s);
 // head_fused.hip: attention input rows + dense_3 (folded) + dense_4 + dense_5 + masked softmax + pooling in one launch
 int score_launch_attn_fwd_fused(int B, int T, int H, int NI, int N1, int N2, const float* q, const float* ur,
                                 const float* ir, const float* info, const float* Weff, const float* qz, const float* W4,
