@@ -397,7 +397,9 @@ int score_gemm_same_shape(int trans, int nprob, int M, int N, int K, const float
     }
   }
   const int64_t tiles = (int64_t)nprob * ((N + 63) / 64) * ((M + 63) / 64);
-  if (tiles < 128) {          // too few tiles even together: let score_gemm split K
+  if (tiles < 128 && K >= GEMM_SPLITK_MIN_K && scratch) {          // too few tiles even together: let score_gemm split K
+    // (with a K too short to split the separate launches gain nothing: the small shapes' projections -- 2 x 58 tiles, K = 112
+    //  at the reference's own shape -- go out together below)
     for (int i = 0; i < nprob; ++i)
       SCORE_TRY(score_gemm(trans, M, N, K, A[i], lda, B[i], ldb, C[i], ldc, bias ? bias[i] : nullptr, flags | (x3 ? F_X3 : 0),
                            1.f, nullptr, 0, scratch, scratch_floats, s));
