@@ -871,12 +871,15 @@ int score_launch_attn_fwd_fused(int B, int T, int H, int NI, int N1, int N2, con
     if (lds <= 150 * 1024) break;
   }
   if (S < 1) return SCORE_E_SHAPE;
-  if (Kp / 4 != 148 && Kp / 4 != 52 && Kp / 4 != 44) return SCORE_E_SHAPE;    // the instantiated register-resident widths
+  const int kq = Kp / 4;
+  if (kq != 148 && kq != 52 && kq != 44 && kq != 36 && kq != 84) return SCORE_E_SHAPE;    // the instantiated register-resident widths
   static thread_local bool attr_set = false;
   if (!attr_set) {
     for (const void* f : {reinterpret_cast<const void*>(attn_fwd_fused_kernel<148>),
                           reinterpret_cast<const void*>(attn_fwd_fused_kernel<52>),
-                          reinterpret_cast<const void*>(attn_fwd_fused_kernel<44>)}) {
+                          reinterpret_cast<const void*>(attn_fwd_fused_kernel<44>),
+                          reinterpret_cast<const void*>(attn_fwd_fused_kernel<36>),
+                          reinterpret_cast<const void*>(attn_fwd_fused_kernel<84>)}) {
       hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
       if (e != hipSuccess) return (int)e;
     }
@@ -893,6 +896,8 @@ int score_launch_attn_fwd_fused(int B, int T, int H, int NI, int N1, int N2, con
     case 148: hipLaunchKernelGGL(attn_fwd_fused_kernel<148>, grid, block, lds, s, a); break;   // H = 128, K = 10
     case 52: hipLaunchKernelGGL(attn_fwd_fused_kernel<52>, grid, block, lds, s, a); break;     // H = 32, K = 10
     case 44: hipLaunchKernelGGL(attn_fwd_fused_kernel<44>, grid, block, lds, s, a); break;     // H = 32, K = 5
+    case 36: hipLaunchKernelGGL(attn_fwd_fused_kernel<36>, grid, block, lds, s, a); break;     // H = 16, K = 10
+    case 84: hipLaunchKernelGGL(attn_fwd_fused_kernel<84>, grid, block, lds, s, a); break;     // H = 64, K = 10
     default: return SCORE_E_SHAPE;
   }
   SCORE_CHECK_LAUNCH();

@@ -180,6 +180,32 @@ def test_random_midsize_vs_oracle(mt):
     assert round(roc_auc_score(lab, pg), 4) == round(roc_auc_score(lab, po), 4)
 
 
+@pytest.mark.parametrize("H,K,B,T", [(16, 10, 40, 5), (64, 10, 24, 6), (32, 5, 300, 4), (32, 10, 530, 3), (128, 10, 20, 7), (48, 6, 32, 5)])
+def test_fused_attention_and_head_widths_vs_oracle(H, K, B, T):
+    """the register-resident widths of the fused attention kernels (head_fused.hip: KQ = 36 / 84 / 44 / 52 / 148), their
+    one-, two- and four-samples-per-workgroup forms (B < 512, < 1024, >= 1024 is cfg-3's test) and a shape that takes the
+    separate launches (H = 48): losses, predictions and every gradient against the oracle"""
+    cfg = so.Cfg(1500, 8, H, T, K, 2, 3, "SCORE")
+    rng = np.random.default_rng(H + K)
+    P = so.init_params(cfg, 4)
+    b = random_batch(rng, cfg, B)
+    m = make_model(cfg, P)
+    om = so.OracleModel(cfg.N, cfg.D, cfg.H, cfg.T, cfg.K, cfg.Fu, cfg.Fi, "SCORE", params={k: v.copy() for k, v in P.items()})
+    m.forward_backward(batch_tuple(b), 0.0, 1.0)
+    g = m.get_grads()
+    _, go = so.loss_and_grads(cfg, P, b, 0.0)
+    for k in go:
+        ok, err = close(g[k].reshape(np.asarray(go[k]).shape), go[k], rtol=2e-4, atol=2e-6)
+        assert ok, (k, err)
+    for _ in range(2):
+        lg = m.train(None, batch_tuple(b), 1e-3, 1e-4, keep_prob=1.0)
+        lo = om.train(None, batch_tuple(b), 1e-3, 1e-4, keep_prob=1.0)
+        assert abs(lg - lo) < 2e-5 * max(1.0, abs(lo))
+    pg, _, _ = m.eval(None, batch_tuple(b), 1e-4)
+    po, _, _ = om.eval(None, batch_tuple(b), 1e-4)
+    assert np.abs(np.asarray(pg) - np.asarray(po)).max() < LOGIT_TOL
+
+
 @pytest.mark.parametrize("mt", so.MODEL_TYPES)
 def test_masked_slices_skipped_vs_oracle(mt):
     # every sample shorter than T (the reference's train split: 9 of 11 slices, graph_loader.py:382): the slices
