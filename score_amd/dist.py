@@ -227,6 +227,7 @@ class HipBackend(object):
         # time-tiled table optimizer or per-step sweep?  Decided once from the first steps' row requests (note_requests)
         self.auto_sweep = True
         self._req_seen, self._want_sweep = [], False
+        self.defer_sweep = False         # gather(): leave the optimizer's window slice to the next backward pass
 
     # -- index plan ---------------------------------------------------------------------
     def plan_launch(self, batch_data, slot=0):
@@ -273,9 +274,11 @@ class HipBackend(object):
         if m._tiled_on():
             # time-tiled optimizer: the requested rows (local indices) up to date first, then this step's slice of
             # the shard, on this same stream (the shard path runs enough streams already)
-            # (the slice on a stream of its own, off the gradient-exchange chain the main stream waits for at the end
-            #  of the step, measured 2.25-2.29 ms/step against 1.76 inline)
-            m._catchup_ids([req_rows] if n else [], True, inline_sweep=True)
+            # The window slice: in a training step it is left pending and started by the backward pass at its stage
+            # boundary 2, beside the recurrence (ShardedSCORE.forward_backward) -- inline here it sat on the
+            # gradient-exchange chain the main stream waits for at the end of the step (0.13 ms of ~0.4); on a stream
+            # of its own right here it measured 2.25-2.29 ms/step against 1.76.
+            m._catchup_ids([req_rows] if n else [], True, inline_sweep=not self.defer_sweep)
         else:
             m._flush_adam()
         if n:
@@ -321,12 +324,36 @@ class HipBackend(object):
                 events = [None] * 6
             if events[4] is None:
                 events[4] = scatter_event
+        self.sweep_start_event = None
+        if m._pending_sweep is not None:       # time-tiled optimizer: the window slice starts at stage boundary 2
+            if m._ev_stage is None:
+                m._ev_stage = torch.cuda.Event()
+                m._ev_stage.record(torch.cuda.current_stream(self.device))     # materialise the hipEvent_t
+            if events is None:
+                events = [None] * 6
+            if events[2] is None:
+                events[2] = m._ev_stage
+            self.sweep_start_event = events[2]
         rc = self.lib.score_backward(C.byref(m.cfg), C.byref(fw["st"]), C.byref(plan["remapped"]), float(keep_prob),
                                      _ptr(m.w_g), _ptr(mini_g), m._event_array(events), m._stream())
         _lib.check(rc, "score_backward")
         if scatter_event is not None:
             return mini_g, events[4]
         return mini_g
+
+    def launch_sweep(self, stream=None):
+        """the pending window slice of the shard's optimizer: behind backward's stage boundary 2 on `stream` (the
+        caller's side stream), or on the current stream"""
+        m = self.m
+        if m._pending_sweep is None:
+            return
+        cur = torch.cuda.current_stream(self.device)
+        if stream is None or self.sweep_start_event is None:
+            m._launch_sweep(cur)
+            return
+        stream.wait_event(self.sweep_start_event)
+        with torch.cuda.stream(stream):
+            m._launch_sweep(stream)
 
     def dense_grad_with_loss(self, fw):
         """[n_w + 4] buffer: the dense gradient followed by this rank's share of the global log-loss mean
@@ -553,6 +580,8 @@ class ShardedSCORE(object):
         row traffic) and the dense ApplyAdam.  The next step starts with its mini-table in hand.  Returns with
         the update applied; do not call apply_adam after it."""
         be, cm = self.backend, self.comm
+        if hasattr(be, "defer_sweep"):
+            be.defer_sweep = self.device.type == "cuda"
         plan, mini = self._fetch(batch_data)
         if next_batch is not None:
             self._prefetch_launch(next_batch)     # its kernels run under this step's forward
@@ -565,6 +594,7 @@ class ShardedSCORE(object):
             # all-reduce together with the log-loss share.
             cur = torch.cuda.current_stream(self.device)
             mini_g, ev = be.backward(plan, mini, fw, keep_prob, scatter_event=self._ev_scatter)
+            be.launch_sweep(self._gside)      # (first on that stream: it is through before the row gradients are)
             grads_in = torch.empty((plan["req"].numel(), self.D), dtype=torch.float32, device=self.device)
             pipelined = lr is not None and next_batch is not None and self._prefetched is not None \
                 and self._prefetched[1] is not None and not os.environ.get("SCORE_NO_PIPELINE")
@@ -604,6 +634,8 @@ class ShardedSCORE(object):
             n_w = buf.numel() - 4
             return (None, buf[n_w], fw["loss"][2]), fw      # [-, global log-loss, l2]
         mini_g = be.backward(plan, mini, fw, keep_prob)
+        if hasattr(be, "launch_sweep"):
+            be.launch_sweep(None)
         grads_in = torch.empty((plan["req"].numel(), self.D), dtype=torch.float32, device=self.device)
         cm.all_to_all(grads_in, mini_g, plan["recv"], plan["send"])
         cm.all_reduce_sum(be.dense_grad())
@@ -654,6 +686,8 @@ class ShardedSCORE(object):
 
     def eval(self, sess, batch_data, reg_lambda):
         be = self.backend
+        if hasattr(be, "defer_sweep"):
+            be.defer_sweep = False
         plan, mini = self._fetch(batch_data)
         B = plan["B"] if "B" in plan else plan["db"].B
         be.set_global_batch(B)             # eval reports the local batch's loss, as the reference does
