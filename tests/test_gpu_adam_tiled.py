@@ -195,3 +195,18 @@ def test_captured_steps_after_tiled_ones():
         if 5 <= i <= 10:
             assert not tiled._adam_dirty
     assert same_state(dense, tiled)
+
+
+def test_many_steps_wrap_the_alpha_ring():
+    """more steps than the alpha ring has slots (64), with a window close to its limit: the ring is reused many times
+    over and rows that are never in a batch are only ever moved by the window slice"""
+    cfg = so.Cfg(2500, 16, 16, 3, 3, 1, 2, "SCORE")
+    dense, tiled = make(cfg, 0), make(cfg, 31)
+    bs = batches(cfg, 12, 8, seed=5, hot_rows=120)
+    for i in range(200):
+        b = bs[i % len(bs)]
+        ld = dense.train(None, b, 1e-2, 1e-4, keep_prob=1.0)
+        lt = tiled.train(None, b, 1e-2, 1e-4, keep_prob=1.0)
+        assert ld == lt, i
+        if i in (70, 133, 199):
+            assert same_state(dense, tiled), i
