@@ -752,14 +752,17 @@ __global__ __launch_bounds__(64 * HF_NW) void head_bwd_fused_kernel(const HeadBw
       }
       const int col = n0 + lc;
       if (col < N1) {
+        // (the four mask values first, from clamped rows: a load behind `row < B` sits in its own exec-mask branch with a
+        //  vmcnt(0) wait -- four dependent round trips per tile)
+        float y[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) y[r] = a.f1[(int64_t)min(b0 + lq * 4 + r, a.B - 1) * N1 + col];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int i = lq * 4 + r, row = b0 + i;
-          float v = 0.f;
-          if (row < a.B) {
-            v = a.f1[(int64_t)row * N1 + col] > 0.f ? acc[r] / a.keep : 0.f;      // relu (+ dropout) of fc1, as the GEMM epilogue had it
-            a.dz1[(int64_t)row * N1 + col] = v;
-          }
+          const float q = acc[r] / a.keep;
+          const float v = (row < a.B && y[r] > 0.f) ? q : 0.f;      // relu (+ dropout) of fc1, as the GEMM epilogue had it
+          if (row < a.B) a.dz1[(int64_t)row * N1 + col] = v;
           z1s[i * LD1 + col] = v;
         }
       }
@@ -799,17 +802,21 @@ __global__ __launch_bounds__(64 * HF_NW) void head_bwd_fused_kernel(const HeadBw
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s4].z, w.z * cm, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s4].w, w.w * cm, acc, 0, 0, 0);
     }
-    if (col < a.Dh) {
-      const float gs = a.gamma[col] * a.rs;
+    {
+      const int cc = col < a.Dh ? col : a.Dh - 1;
+      const float gs = a.gamma[cc] * a.rs;
+      float xv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xv[r] = a.x[(int64_t)min(b0 + lq * 4 + r, a.B - 1) * a.Dh + cc];     // clamped, unconditional
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = b0 + lq * 4 + r;
-        if (row < a.B) {
+        if (row < a.B && col < a.Dh) {
           const int64_t e = (int64_t)row * a.Dh + col;
           const float dy = acc[r];
           a.dbn[e] = dy;
           a.dhead[e] = dy * gs;
-          a.tmp[e] = dy * (a.x[e] * a.rs);
+          a.tmp[e] = dy * (xv[r] * a.rs);
         }
       }
     }
