@@ -163,11 +163,14 @@ __global__ __launch_bounds__(64 * HF_NW) void head_fwd_fused_kernel(const HeadFw
     const int t0 = tb + wave, t1 = tb + HF_NW + wave;
     const int n0[2] = {t0 < nt1 ? t0 * 16 : -1, t1 < nt1 ? t1 * 16 : -1};
     if (n0[0] >= 0) hf_tiles<2>(acc, xs, LD0, Kp0, Dh, a.W1, N1, n0, N1, lc, lq);
+    float bias1[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) bias1[t] = a.b1[min(max(n0[t] + lc, 0), N1 - 1)];     // clamped, unconditional (no load behind a branch)
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int col = n0[t] + lc;
       if (n0[t] < 0 || col >= N1) continue;
-      const float bias = a.b1[col];
+      const float bias = bias1[t];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = lq * 4 + r, row = b0 + i;
@@ -187,8 +190,9 @@ __global__ __launch_bounds__(64 * HF_NW) void head_fwd_fused_kernel(const HeadFw
     const int n0[1] = {t0 < nt2 ? t0 * 16 : -1};
     if (n0[0] >= 0) hf_tiles<1>(acc, f1s, LD1, Kp1, N1, a.W2, N2, n0, N2, lc, lq);
     const int col = n0[0] + lc;
+    const float bias2 = a.b2[min(max(col, 0), N2 - 1)];
     if (n0[0] >= 0 && col < N2) {
-      const float bias = a.b2[col];
+      const float bias = bias2;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = lq * 4 + r, row = b0 + i;
@@ -229,7 +233,8 @@ __global__ __launch_bounds__(64 * HF_NW) void head_fwd_fused_kernel(const HeadFw
   if (a.dz2) {
     for (int e = tid; e < HF_ROWS * N2; e += 64 * HF_NW) {
       const int i = e / N2, n = e - i * N2, row = b0 + i;
-      if (row < a.B) a.dz2[(int64_t)row * N2 + n] = f2s[i * LD2 + n] > 0.f ? xs[i] * a.W3[n] / a.keep : 0.f;
+      const float q = xs[i] * a.W3[n] / a.keep;                   // (computed for every element: no load behind the branch)
+      if (row < a.B) a.dz2[(int64_t)row * N2 + n] = f2s[i * LD2 + n] > 0.f ? q : 0.f;
     }
   }
 }
