@@ -340,6 +340,34 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(const GemmGroup grp
     for (int j = 0; j < 2; ++j) {
       const int col = bn + wn * 64 + j * 32 + r31;
       if (col >= N) continue;
+      // What the epilogue reads per element (bias, the relu-gradient mask, the accumulate target) is fetched for the 16
+      // rows of the sub-tile TOGETHER, from clamped rows, before anything is consumed: one element at a time every
+      // load sat behind its own branch with a vmcnt(0) wait -- 64 dependent (cache-hit) round trips per lane and tile.
+      const float* bsrc = pr.bias ? pr.bias : bias;
+      const int bg = flags >> 16;
+      float eb[16], ey[16], ec[16];
+      const bool has_b = !slab && (flags & XF_BIAS), has_y = !slab && (flags & XF_RELUGRAD), has_c = !slab && (flags & XF_ACC);
+      int rows[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) rows[r] = min(bm + wm * 32 * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh, M - 1);
+      if (has_b) {
+        if (bg) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) eb[r] = bsrc[(int64_t)(rows[r] / bg) * N + col];
+        } else {
+          const float b0 = bsrc[col];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) eb[r] = b0;
+        }
+      }
+      if (has_y) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ey[r] = reinterpret_cast<const float*>(mask)[(int64_t)rows[r] * N + col];
+      }
+      if (has_c) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ec[r] = C[(int64_t)rows[r] * ldc + col];
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = bm + wm * 32 * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
@@ -350,9 +378,16 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(const GemmGroup grp
         if (slab) {
           slab[((int64_t)bz * M + row) * N + col] = acc[i][j][r];
         } else {
-          float v = x3_epilogue(acc[i][j][r], row, col, N, pr.bias ? pr.bias : bias, flags, keep, mask, seed);
-          float* dst = C + (int64_t)row * ldc + col;
-          *dst = (flags & XF_ACC) ? *dst + v : v;
+          float v = acc[i][j][r];
+          if (has_b) v += eb[r];
+          if (flags & XF_RELU) v = fmaxf(v, 0.f);
+          if (flags & XF_DROP) {
+            const uint64_t e = (uint64_t)row * (uint64_t)N + (uint64_t)col;
+            const bool on = mask ? (mask[e] != 0) : (hash_uniform(seed, e) < keep);
+            v = on ? v / keep : 0.f;
+          }
+          if (has_y) v = ey[r] > 0.f ? v / keep : 0.f;
+          C[(int64_t)row * ldc + col] = has_c ? ec[r] + v : v;
         }
       }
     }
