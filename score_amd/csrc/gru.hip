@@ -123,7 +123,7 @@ extern "C" int score_gru_fwd(int32_t B, int32_t T, int32_t H, const float* xproj
   if (gru_reg_ok(H)) {
     GruArgs a;
     memset(&a, 0, sizeof(a));
-    a.B = B; a.T = T; a.H = H; a.length = length; a.nw8 = 1;
+    a.B = B; a.T = T; a.H = H; a.length = length; a.nw8 = 1; a.x3_rec = 1;
     a.s[0].xproj = xproj; a.s[0].Wg = Wg; a.s[0].ldwg = ldwg; a.s[0].Wc = Wc; a.s[0].ldwc = ldwc;
     a.s[0].out = out; a.s[0].ldo = ldo; a.s[0].gates = gates_save; a.s[0].final_state = final_state;
     return score_gru_fwd_multi(a, 1, (hipStream_t)stream);
@@ -256,7 +256,7 @@ extern "C" int score_gru_bwd(int32_t B, int32_t T, int32_t H, const float* Wg, i
   if (gru_reg_ok(H)) {
     GruArgs a;
     memset(&a, 0, sizeof(a));
-    a.B = B; a.T = T; a.H = H; a.length = length; a.nw8 = 1;
+    a.B = B; a.T = T; a.H = H; a.length = length; a.nw8 = 1; a.x3_rec = 1;
     GruSide& g = a.s[0];
     g.Wg = Wg; g.ldwg = ldwg; g.Wc = Wc; g.ldwc = ldwc; g.out = const_cast<float*>(out); g.ldo = ldo;
     g.gates = const_cast<float*>(gates_save); g.dout = dout; g.lddo = lddo; g.dfinal = dfinal;
@@ -801,9 +801,15 @@ static int gru_bwd_steps(GruArgs& a, int nsides, hipStream_t s) {
 }
 
 static bool gru_reg_ok(int H) { return H == 16 || H == 32 || H == 64 || H == 128; }
+// SCORE_GRU_F32 (set, not empty, not "0"; read once): keep the H = 128 recurrences on the f32-input MFMA (A/B)
+static bool gru_x3_allowed() {
+  static const bool off = [] { const char* v = getenv("SCORE_GRU_F32"); return v && *v && !(v[0] == '0' && !v[1]); }();
+  return !off;
+}
 
 int score_gru_fwd_multi(GruArgs& a, int nsides, hipStream_t s) {
   const int H = a.H;
+  if (a.x3_rec && gru_x3_allowed() && score_gru_x3_ok(H, a.nw8)) return score_gru_fwd_x3(a, nsides, s);
   if (gru_reg_ok(H)) {
     dim3 grid(nsides * ((a.B + RRB - 1) / RRB));
     const bool full = a.B % RRB == 0;
@@ -835,6 +841,7 @@ int score_gru_fwd_multi(GruArgs& a, int nsides, hipStream_t s) {
 
 int score_gru_bwd_multi(GruArgs& a, int nsides, hipStream_t s) {
   const int H = a.H;
+  if (a.x3_rec && gru_x3_allowed() && score_gru_x3_ok(H, a.nw8)) return score_gru_bwd_x3(a, nsides, s);
   if (gru_reg_ok(H)) {
     dim3 grid(nsides * ((a.B + RRB - 1) / RRB));
     const bool full = a.B % RRB == 0;

@@ -183,6 +183,7 @@ struct GruArgs {
   // = score_gru_stream_tmp_floats); others run the recurrence step by step (two grouped GEMMs + two pointwise
   // launches per time slice; scratch 10 * B * H floats), x3 = bf16x3 allowed there.  stepwise != 0 forces that path (A/B)
   float* tmp; int64_t tmp_floats; int x3; int stepwise;
+  int x3_rec;   // H = 128: the recurrence itself on the bf16 matrix cores, fp32-accurate (gru_x3.hip)
 };
 // nprob same-shape GEMMs C_i = op(A_i) op(B_i) in one launch (the two sides of a recurrence step); flags: 4 = C += .
 int score_gemm_same_shape(int trans, int nprob, int M, int N, int K, const float* const* A, int lda,
@@ -199,5 +200,9 @@ bool score_gru_stream_ok(int H);
 int64_t score_gru_stream_tmp_floats(int H, int nsides);
 int score_gru_fwd_stream(GruArgs& a, int nsides, hipStream_t s);
 int score_gru_bwd_stream(GruArgs& a, int nsides, hipStream_t s);
+// gru_x3.hip: H = 128 recurrences as bf16x3 products (weights resident in registers as split planes)
+bool score_gru_x3_ok(int H, int nw8);
+int score_gru_fwd_x3(GruArgs& a, int nsides, hipStream_t s);
+int score_gru_bwd_x3(GruArgs& a, int nsides, hipStream_t s);
 int score_gru_fwd_multi(GruArgs& a, int nsides, hipStream_t s);
 int score_gru_bwd_multi(GruArgs& a, int nsides, hipStream_t s);
