@@ -158,54 +158,58 @@ __global__ __launch_bounds__(64 * XNW) void gru_fwd_x3_kernel(const GruArgs a) {
   float h[4] = {0.f, 0.f, 0.f, 0.f};
   __syncthreads();
 
-  float nx[3][4];                     // x-projection of the next step, read unconditionally (clamped)
-  auto fetch_x = [&](int t) {
-    const int64_t u3 = (int64_t)min(t, T - 1) * 3 * H * 4;
+  // x-projection of a step, read unconditionally (clamped) about one step ahead: each of its three parts is
+  // fetched again right after its last use (r, u, candidate epilogue), into the registers it is consumed from
+  float x[3][4];
+  auto fetch_x = [&](int g, int t) {
+    const int64_t u3 = ((int64_t)min(t, T - 1) * 3 * H + g * H) * 4;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      nx[0][r] = ldg(sd.xproj, u3, rb3[r]); nx[1][r] = ldg(sd.xproj, u3 + H * 4, rb3[r]);
-      nx[2][r] = ldg(sd.xproj, u3 + 2 * H * 4, rb3[r]);
-    }
+    for (int r = 0; r < 4; ++r) x[g][r] = ldg(sd.xproj, u3, rb3[r]);
   };
-  fetch_x(0);
+  fetch_x(0, 0); fetch_x(1, 0); fetch_x(2, 0);
   const int aoff = lc * XLD + 8 * lq;
-  for (int t = 0; t < T; ++t) {
-    float x[3][4];
-#pragma unroll
-    for (int g = 0; g < 3; ++g)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) x[g][r] = nx[g][r];
-    fetch_x(t + 1);
+  // The first step is peeled: at the loop header the compiler's s_waitcnt placement merges the state of the
+  // prologue (loads with nothing behind them) with the back edge's (loads with the step's sixteen stores behind
+  // them) and keeps the stricter count, so every step waited for the previous step's stores to be acknowledged.
+  auto step = [&](const int t) {
     const int64_t u3 = (int64_t)t * 3 * H * 4;
     // gates = sigmoid(xproj[:, :2H] + h . Wg)
     f32x4 ar = {0.f, 0.f, 0.f, 0.f}, au = {0.f, 0.f, 0.f, 0.f};
+    {
+      bf16x8 af[XKS][3];             // all of the phase's operand reads go out before its MFMA chain
 #pragma unroll
-    for (int s = 0; s < XKS; ++s) {
-      bf16x8 af[3];
-      get3(hp, PS, aoff + 32 * s, af);
-      ar = mfma6(af, wr[s], ar);
-      au = mfma6(af, wu[s], au);
+      for (int s = 0; s < XKS; ++s) get3(hp, PS, aoff + 32 * s, af[s]);
+#pragma unroll
+      for (int s = 0; s < XKS; ++s) {
+        ar = mfma6(af[s], wr[s], ar);
+        au = mfma6(af[s], wu[s], au);
+      }
     }
-    float u[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int i = lq * 4 + r;
       const float rg = x_sigmoid(ar[r] + x[0][r]);
-      u[r] = x_sigmoid(au[r] + x[1][r]);
-      if (rok[r]) {
-        XG_STORE(*stp(sd.gates, u3, rb3[r]), rg);
-        XG_STORE(*stp(sd.gates, u3 + H * 4, rb3[r]), u[r]);
-      }
+      if (rok[r]) XG_STORE(*stp(sd.gates, u3, rb3[r]), rg);
       put3(rp, PS, i * XLD + j, rg * h[r]);
     }
+    fetch_x(0, t + 1);
     __syncthreads();
-    // c = tanh(xproj[:, 2H:] + (r*h) . Wc) ; h' = u*h + (1-u)*c
+    // c = tanh(xproj[:, 2H:] + (r*h) . Wc) ; h' = u*h + (1-u)*c.  The update gate's epilogue is not on the
+    // r -> r*h -> barrier chain: it runs behind the barrier, in the shadow of the candidate product's operand reads.
     f32x4 ac = {0.f, 0.f, 0.f, 0.f};
+    float u[4];
+    {
+      bf16x8 af[XKS][3];
 #pragma unroll
-    for (int s = 0; s < XKS; ++s) {
-      bf16x8 af[3];
-      get3(rp, PS, aoff + 32 * s, af);
-      ac = mfma6(af, wc[s], ac);
+      for (int s = 0; s < XKS; ++s) get3(rp, PS, aoff + 32 * s, af[s]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        u[r] = x_sigmoid(au[r] + x[1][r]);
+        if (rok[r]) XG_STORE(*stp(sd.gates, u3 + H * 4, rb3[r]), u[r]);
+      }
+      fetch_x(1, t + 1);
+#pragma unroll
+      for (int s = 0; s < XKS; ++s) ac = mfma6(af[s], wc[s], ac);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -220,8 +224,11 @@ __global__ __launch_bounds__(64 * XNW) void gru_fwd_x3_kernel(const GruArgs a) {
       h[r] = live ? hn : h[r];
       put3(hp, PS, i * XLD + j, h[r]);
     }
+    fetch_x(2, t + 1);
     __syncthreads();
-  }
+  };
+  step(0);
+  for (int t = 1; t < T; ++t) step(t);
   if (sd.final_state) {
 #pragma unroll
     for (int r = 0; r < 4; ++r)
@@ -300,11 +307,12 @@ __global__ __launch_bounds__(64 * XNW) void gru_bwd_x3_kernel(const GruArgs a) {
   fetch_ucd(T - 1); fetch_r(T - 1); fetch_hp(T - 1);
   const int aoff = lc * XLD + 8 * lq, aoff2 = lc * XLD2 + 8 * lq;
 
-  for (int t = T - 1; t >= 0; --t) {
+  auto step = [&](const int t) {      // (first step peeled, as in the forward)
     float c_hp[4];                   // h_{t-1}, 0 past the length and at t = 0
 #pragma unroll
     for (int r = 0; r < 4; ++r) c_hp[r] = (t < len[r] && t > 0) ? n_hp[r] : 0.f;
-    fetch_hp(t - 1);
+    __builtin_amdgcn_sched_barrier(0);     // (a fetch hoisted above the last use of its registers costs a copy
+    fetch_hp(t - 1);                       //  behind a wait for the load just issued)
     // phase 1 (elementwise): dpu, dpc ; dh <- dh_tot * u      (results of a dead step are discarded by `live`)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -324,6 +332,7 @@ __global__ __launch_bounds__(64 * XNW) void gru_bwd_x3_kernel(const GruArgs a) {
       put3(dpc, PS, i * XLD + j, v_dpc);
       put3(dpg, PS2, i * XLD2 + H + j, v_dpu);
     }
+    __builtin_amdgcn_sched_barrier(0);
     fetch_ucd(t - 1);
     __syncthreads();
     // phase 2: d(rh) = dpc . Wc^T ; dpr = d(rh)*h_prev*r(1-r) ; dh += d(rh)*r
@@ -349,6 +358,7 @@ __global__ __launch_bounds__(64 * XNW) void gru_bwd_x3_kernel(const GruArgs a) {
         }
         put3(dpg, PS2, i * XLD2 + j, v_dpr);
       }
+      __builtin_amdgcn_sched_barrier(0);
       fetch_r(t - 1);
     }
     __syncthreads();
@@ -365,7 +375,9 @@ __global__ __launch_bounds__(64 * XNW) void gru_bwd_x3_kernel(const GruArgs a) {
       for (int r = 0; r < 4; ++r) dh[r] += acc[r];
     }
     __syncthreads();
-  }
+    };
+  step(T - 1);
+  for (int t = T - 2; t >= 0; --t) step(t);
 }
 
 }  // namespace
