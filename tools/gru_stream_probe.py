@@ -6,7 +6,8 @@ import torch
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 variants = [("full", []), ("nomfma", ["-DGSP_NOMFMA"]), ("nostore", ["-DGSP_NOSTORE"]), ("nobload", ["-DGSP_NOBLOAD"]),
             ("noxload", ["-DGSP_NOXLOAD"]), ("mfma-only", ["-DGSP_NOSTORE", "-DGSP_NOBLOAD", "-DGSP_NOXLOAD"]),
-            ("nomem", ["-DGSP_NOSTORE", "-DGSP_NOXLOAD"])]
+            ("nomem", ["-DGSP_NOSTORE", "-DGSP_NOXLOAD"]), ("spf1-8", ["-DSPF1=8"]), ("spf1-16", ["-DSPF1=16"]), ("spf2-8", ["-DSPF2=8"]),
+           ]
 if len(sys.argv) > 1:
     variants = [v for v in variants if v[0] in sys.argv[1:]]
 tmp = tempfile.mkdtemp()
