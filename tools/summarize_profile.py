@@ -33,7 +33,7 @@ def _per_kernel(d, counter):
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == counter:
-            acc[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+            acc[r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]].append(float(r["Counter_Value"]))
     return acc
 
 
