@@ -306,9 +306,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #else
 #define GR_XLOAD(e) (e)
 #endif
-// fast transcendental forms for the recurrence epilogues (v_exp_f32 / v_rcp_f32; abs error ~1e-7)
-__device__ __forceinline__ float sigmoid_fast(float x) { return __frcp_rn(1.0f + __expf(-x)); }
-__device__ __forceinline__ float tanh_fast(float x) { return 1.0f - 2.0f * __frcp_rn(__expf(2.0f * x) + 1.0f); }
+// fast transcendental forms for the recurrence epilogues (v_exp_f32 / v_rcp_f32; abs error ~1e-7; __frcp_rn would be
+// the ten-instruction correctly rounded division)
+__device__ __forceinline__ float sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanh_fast(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f); }
 
 
 // FULL: the batch is a whole number of 16-row tiles and every wave owns whole column tiles -- the time loop
@@ -333,7 +334,7 @@ __global__ __launch_bounds__(64 * NW) void gru_fwd_reg_kernel(const GruArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lc = lane & 15, lq = lane >> 4;  // column inside a tile / k-quarter == output row group
   const int T = a.T;
-  auto tile_ok = [&](int tile, int nt) { return (FULL && TEX) ? true : tile < nt; };
+  auto tile_ok = [&](int tile, int nt) { return TEX ? true : tile < nt; };
 
   float wg[TGW][KS], wc[TCW][KS];
 #pragma unroll
@@ -350,44 +351,46 @@ __global__ __launch_bounds__(64 * NW) void gru_fwd_reg_kernel(const GruArgs a) {
     for (int ks = 0; ks < KS; ++ks)
       wc[tt][ks] = tile < NTC ? sd.Wc[(int64_t)(lq * KS + ks) * sd.ldwc + tile * 16 + lc] : 0.f;
   }
+  // Rows past the batch are DUPLICATES of the last sample: same inputs, same arithmetic, the same values stored to
+  // the same addresses (a benign race) -- so a ragged batch needs no predicated memory operation either (with
+  // stores under exec-mask branches the compiler's s_waitcnt placement falls back to vmcnt(0) in the time loop).
   int len[4];
-  bool rok[4];
-  int64_t rowb[4];                // row of (sample, t = 0); samples past the batch read the last one's (never stored)
+  int64_t rowb[4];                // row of (sample, t = 0)
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const int b = b0 + lq * 4 + r;
-    rok[r] = FULL ? true : b < a.B;
-    const int bc = FULL ? b : min(b, a.B - 1);
-    len[r] = rok[r] ? a.length[bc] : 0;
+    const int bc = min(b0 + lq * 4 + r, a.B - 1);
+    len[r] = a.length[bc];
     rowb[r] = (int64_t)bc * T;
   }
+  constexpr bool rok[4] = {true, true, true, true};
   for (int e = tid; e < RRB * LD; e += 64 * NW) hs[e] = 0.f;
   __syncthreads();
 
-  // x-projection values are read one step ahead, unconditionally (clamped addresses)
-  float nxg[TGW][4], nxc[TCW][4];
-  auto fetch_x = [&](int t) {
+  // x-projection values are read about one step ahead, unconditionally (clamped addresses): each half is fetched
+  // again right after its last use (gate / candidate epilogue), into the registers it is consumed from -- a prefetch
+  // into a second set is copied by v_mov behind a wait for the load just issued.  The first step is peeled: at the
+  // loop header the waitcnt pass merges the prologue's state with the back edge's and keeps the stricter count.
+  float xg[TGW][4], xc[TCW][4];
+  auto fetch_xg = [&](int t) {
     const int tc = min(t, T - 1);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float* xr = sd.xproj + (rowb[r] + tc) * 3 * H;
 #pragma unroll
-      for (int tt = 0; tt < TGW; ++tt) nxg[tt][r] = GR_XLOAD(xr[min(wave + NW * tt, NTG - 1) * 16 + lc]);
-#pragma unroll
-      for (int tt = 0; tt < TCW; ++tt) nxc[tt][r] = GR_XLOAD(xr[2 * H + min(wave + NW * tt, NTC - 1) * 16 + lc]);
+      for (int tt = 0; tt < TGW; ++tt) xg[tt][r] = GR_XLOAD(xr[min(wave + NW * tt, NTG - 1) * 16 + lc]);
     }
   };
-  fetch_x(0);
-  for (int t = 0; t < T; ++t) {
-    float xg[TGW][4], xc[TCW][4];
+  auto fetch_xc = [&](int t) {
+    const int tc = min(t, T - 1);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
+      const float* xr = sd.xproj + (rowb[r] + tc) * 3 * H;
 #pragma unroll
-      for (int tt = 0; tt < TGW; ++tt) xg[tt][r] = nxg[tt][r];
-#pragma unroll
-      for (int tt = 0; tt < TCW; ++tt) xc[tt][r] = nxc[tt][r];
+      for (int tt = 0; tt < TCW; ++tt) xc[tt][r] = GR_XLOAD(xr[2 * H + min(wave + NW * tt, NTC - 1) * 16 + lc]);
     }
-    fetch_x(t + 1);
+  };
+  fetch_xg(0); fetch_xc(0);
+  auto step = [&](const int t) {
     // gates = sigmoid(xproj[:, :2H] + h . Wg)
     f32x4 acc[TGW];
 #pragma unroll
@@ -417,6 +420,8 @@ __global__ __launch_bounds__(64 * NW) void gru_fwd_reg_kernel(const GruArgs a) {
         else us[i * LD + (j - H)] = g;
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
+    fetch_xg(t + 1);
     __syncthreads();
     // c = tanh(xproj[:, 2H:] + (r*h) . Wc) ; h' = u*h + (1-u)*c
     f32x4 acc2[TCW];
@@ -454,8 +459,12 @@ __global__ __launch_bounds__(64 * NW) void gru_fwd_reg_kernel(const GruArgs a) {
         hs[i * LD + j] = live ? hn : h;
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
+    fetch_xc(t + 1);
     __syncthreads();
-  }
+  };
+  step(0);
+  for (int t = 1; t < T; ++t) step(t);
   if (sd.final_state)
     for (int e = tid; e < RRB * H; e += 64 * NW) {
       const int i = e / H, j = e - i * H;
@@ -478,7 +487,7 @@ __global__ __launch_bounds__(64 * NW) void gru_bwd_reg_kernel(const GruArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lc = lane & 15, lq = lane >> 4;
   const int T = a.T;
-  auto tile_ok = [&](int tile) { return (FULL && TEX) ? true : tile < NT; };
+  auto tile_ok = [&](int tile) { return TEX ? true : tile < NT; };
 
   // B operands of the two transposed products: B[k][j] = Wc[j][k] (k < H), Wg[j][k] (k < 2H)
   float wct[TW][KS], wgt[TW][2 * KS];
@@ -492,17 +501,16 @@ __global__ __launch_bounds__(64 * NW) void gru_bwd_reg_kernel(const GruArgs a) {
     for (int ks = 0; ks < 2 * KS; ++ks) wgt[tt][ks] = tile < NT ? sd.Wg[(int64_t)j * sd.ldwg + lq * 2 * KS + ks] : 0.f;
   }
   // every thread owns the elements (row i = lq*4 + r, column j = (wave + NW*tt)*16 + lc) in all three
-  // phases, so the saved activations of a step are read once, one step ahead of their use
-  int len[4];
-  bool rok[4];
+  // phases, so the saved activations of a step are read once, about one step ahead of their use.
+  // Rows past the batch are duplicates of the last sample (see the forward): no predicated memory operation.
+  int len[4], bcs[4];
   int64_t rowb[4];
+  constexpr bool rok[4] = {true, true, true, true};
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const int b = b0 + lq * 4 + r;
-    rok[r] = FULL ? true : b < a.B;
-    const int bc = FULL ? b : min(b, a.B - 1);
-    len[r] = rok[r] ? a.length[bc] : 0;
-    rowb[r] = (int64_t)bc * T;
+    bcs[r] = min(b0 + lq * 4 + r, a.B - 1);
+    len[r] = a.length[bcs[r]];
+    rowb[r] = (int64_t)bcs[r] * T;
   }
 #pragma unroll
   for (int tt = 0; tt < TW; ++tt) {
@@ -510,14 +518,15 @@ __global__ __launch_bounds__(64 * NW) void gru_bwd_reg_kernel(const GruArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int i = lq * 4 + r, j = tile * 16 + lc;
-      if (tile < NT) dh[i * LD + j] = (sd.dfinal && rok[r]) ? sd.dfinal[(int64_t)(b0 + i) * H + j] : 0.f;
+      if (tile < NT) dh[i * LD + j] = sd.dfinal ? sd.dfinal[(int64_t)bcs[r] * H + j] : 0.f;
     }
   }
-  // saved activations of step t, read unconditionally (clamped addresses) one step ahead; the raw values are
-  // zeroed past the length only when the step that uses them starts (a select right after the load would
-  // make the wave wait for it on the spot)
+  // Saved activations, read unconditionally (clamped addresses): each array is fetched again right after its last
+  // use in the step (u, c, dout: phase 1; r: phase 2), into the registers it is consumed from; only h_prev, which
+  // both phases and the stores need masked, keeps a copy.  (A prefetch into a second register set is copied by
+  // v_mov behind a wait for the load just issued; the first step is peeled for the loop header's waitcnt state.)
   float n_u[TW][4], n_c[TW][4], n_r[TW][4], n_hp[TW][4], n_do[TW][4];
-  auto prefetch = [&](int t) {
+  auto fetch_ucd = [&](int t) {
     const int tc = max(t, 0);
 #pragma unroll
     for (int tt = 0; tt < TW; ++tt) {
@@ -525,28 +534,41 @@ __global__ __launch_bounds__(64 * NW) void gru_bwd_reg_kernel(const GruArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int64_t row = rowb[r] + tc;
-        n_r[tt][r] = GR_XLOAD(sd.gates[row * 3 * H + j]);
         n_u[tt][r] = GR_XLOAD(sd.gates[row * 3 * H + H + j]);
         n_c[tt][r] = GR_XLOAD(sd.gates[row * 3 * H + 2 * H + j]);
-        n_hp[tt][r] = GR_XLOAD(sd.out[(row - (tc > 0 ? 1 : 0)) * sd.ldo + j]);
         n_do[tt][r] = GR_XLOAD(sd.dout[row * sd.lddo + j]);
       }
     }
   };
-  prefetch(T - 1);
+  auto fetch_r = [&](int t) {
+    const int tc = max(t, 0);
+#pragma unroll
+    for (int tt = 0; tt < TW; ++tt) {
+      const int j = min(wave + NW * tt, NT - 1) * 16 + lc;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) n_r[tt][r] = GR_XLOAD(sd.gates[(rowb[r] + tc) * 3 * H + j]);
+    }
+  };
+  auto fetch_hp = [&](int t) {
+    const int tp = max(t - 1, 0);          // (h_prev of t = 0 is never used)
+#pragma unroll
+    for (int tt = 0; tt < TW; ++tt) {
+      const int j = min(wave + NW * tt, NT - 1) * 16 + lc;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) n_hp[tt][r] = GR_XLOAD(sd.out[(rowb[r] + tp) * sd.ldo + j]);
+    }
+  };
+  fetch_ucd(T - 1); fetch_r(T - 1); fetch_hp(T - 1);
   __syncthreads();
 
-  for (int t = T - 1; t >= 0; --t) {
-    float c_u[TW][4], c_c[TW][4], c_r[TW][4], c_hp[TW][4], c_do[TW][4];
+  auto step = [&](const int t) {
+    float c_hp[TW][4];                  // h_{t-1}, 0 past the length and at t = 0
 #pragma unroll
     for (int tt = 0; tt < TW; ++tt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const bool ok = t < len[r];
-        c_u[tt][r] = ok ? n_u[tt][r] : 0.f; c_c[tt][r] = ok ? n_c[tt][r] : 0.f; c_r[tt][r] = ok ? n_r[tt][r] : 0.f;
-        c_hp[tt][r] = (ok && t > 0) ? n_hp[tt][r] : 0.f; c_do[tt][r] = ok ? n_do[tt][r] : 0.f;
-      }
-    prefetch(t - 1);
+      for (int r = 0; r < 4; ++r) c_hp[tt][r] = (t < len[r] && t > 0) ? n_hp[tt][r] : 0.f;
+    __builtin_amdgcn_sched_barrier(0);
+    fetch_hp(t - 1);
     // phase 1 (elementwise): dpu, dpc ; dh <- dh_tot * u      (selects, no branches: see FULL above)
 #pragma unroll
     for (int tt = 0; tt < TW; ++tt) {
@@ -557,9 +579,9 @@ __global__ __launch_bounds__(64 * NW) void gru_bwd_reg_kernel(const GruArgs a) {
       for (int r = 0; r < 4; ++r) {
         const int i = lq * 4 + r;
         const bool live = t < len[r];
-        const float u = c_u[tt][r], c = c_c[tt][r];
+        const float u = n_u[tt][r], c = n_c[tt][r];      // (a dead step's results are discarded by `live`)
         const float dold = dh[i * LD + j];
-        const float d = dold + c_do[tt][r];
+        const float d = dold + n_do[tt][r];
         const float du = d * (c_hp[tt][r] - c), dc = d * (1.0f - u);
         const float v_dpu = live ? du * u * (1.0f - u) : 0.f;
         const float v_dpc = live ? dc * (1.0f - c * c) : 0.f;
@@ -574,6 +596,8 @@ __global__ __launch_bounds__(64 * NW) void gru_bwd_reg_kernel(const GruArgs a) {
         dpg[i * LD2 + H + j] = v_dpu;
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
+    fetch_ucd(t - 1);
     __syncthreads();
     // phase 2: d(rh) = dpc . Wc^T ; dpr = d(rh)*h_prev*r(1-r) ; dh += d(rh)*r
     {
@@ -598,8 +622,8 @@ __global__ __launch_bounds__(64 * NW) void gru_bwd_reg_kernel(const GruArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int i = lq * 4 + r;
-          const float rr = c_r[tt][r], hp = c_hp[tt][r];   // both 0 past the length
           const bool live = t < len[r];
+          const float rr = live ? n_r[tt][r] : 0.f, hp = c_hp[tt][r];   // both 0 past the length
           const float drh = acc[tt][r];
           const float v_dpr = live ? drh * hp * rr * (1.0f - rr) : 0.f;
           dh[i * LD + j] += live ? drh * rr : 0.f;
@@ -611,6 +635,8 @@ __global__ __launch_bounds__(64 * NW) void gru_bwd_reg_kernel(const GruArgs a) {
           dpg[i * LD2 + j] = v_dpr;
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
+      fetch_r(t - 1);
     }
     __syncthreads();
     // phase 3: dh += [dpr | dpu] . Wg^T
@@ -638,7 +664,9 @@ __global__ __launch_bounds__(64 * NW) void gru_bwd_reg_kernel(const GruArgs a) {
       }
     }
     __syncthreads();
-  }
+  };
+  step(T - 1);
+  for (int t = T - 2; t >= 0; --t) step(t);
 }
 
 // ------------------------------------------------------------------ step-by-step recurrence (any H)

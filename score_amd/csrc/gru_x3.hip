@@ -148,9 +148,9 @@ __global__ __launch_bounds__(64 * XNW) void gru_fwd_x3_kernel(const GruArgs a) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int b = b0 + lq * 4 + r;
-    rok[r] = FULL ? true : b < a.B;
-    const int bc = FULL ? b : min(b, a.B - 1);   // samples past the batch read the last one's (never stored)
-    len[r] = rok[r] ? a.length[bc] : 0;
+    rok[r] = true;                      // rows past the batch duplicate the last sample (same values to the same
+    const int bc = min(b, a.B - 1);     // addresses: a benign race), so a ragged batch has no predicated access either   // samples past the batch read the last one's (never stored)
+    len[r] = a.length[bc];
     rb3[r] = (uint32_t)(((int64_t)bc * T * 3 * H + j) * 4);
     rbo[r] = (uint32_t)(((int64_t)bc * T * sd.ldo + j) * 4);
   }
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(64 * XNW) void gru_fwd_x3_kernel(const GruArgs a) {
   if (sd.final_state) {
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-      if (rok[r]) sd.final_state[(int64_t)(b0 + lq * 4 + r) * H + j] = h[r];
+      sd.final_state[(int64_t)min(b0 + lq * 4 + r, a.B - 1) * H + j] = h[r];
   }
 }
 
@@ -271,9 +271,9 @@ __global__ __launch_bounds__(64 * XNW) void gru_bwd_x3_kernel(const GruArgs a) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int b = b0 + lq * 4 + r;
-    rok[r] = FULL ? true : b < a.B;
-    const int bc = FULL ? b : min(b, a.B - 1);
-    len[r] = rok[r] ? a.length[bc] : 0;
+    rok[r] = true;                      // rows past the batch duplicate the last sample (same values to the same
+    const int bc = min(b, a.B - 1);     // addresses: a benign race), so a ragged batch has no predicated access either
+    len[r] = a.length[bc];
     rb3[r] = (uint32_t)(((int64_t)bc * T * 3 * H + j) * 4);
     rbh[r] = (uint32_t)(((int64_t)bc * T * H + j) * 4);
     rbo[r] = (uint32_t)(((int64_t)bc * T * sd.ldo + j) * 4);
