@@ -84,6 +84,11 @@ struct HeadFwdArgs {
   const int32_t* label;
   float* bn; float* f1; float* f2; float* logit; float* y; float* lossb; float* dlogit;
   float* dz2;                     // [B, N2] fc3's backward into relu+dropout of fc2 (what the backward pass starts from)
+  // phase 0: the whole head in one launch (small batches: launch-bound).  Batches of many 16-row tiles run it as two:
+  // phase 1 = bn1 + fc1 with the column tiles of fc1 dealt to gridDim.y workgroups per row tile (a row tile's fc1 is
+  // 563 KB of weights streamed by ONE workgroup otherwise, on B/16 of the chip's CUs), phase 2 = fc2, fc3, loss, dz2
+  // from the saved fc1 output.  Same arithmetic per element either way.
+  int phase;
 };
 
 __device__ __forceinline__ float hf_act(float v, float bias, int drop, float keep, const uint8_t* mask, uint64_t seed,
@@ -112,11 +117,15 @@ __global__ __launch_bounds__(64 * HF_NW) void head_fwd_fused_kernel(const HeadFw
   const int lc = lane & 15, lq = lane >> 4;
   const int b0 = blockIdx.x * HF_ROWS;
 
+  const int phase = a.phase;
+  const bool store_bn = blockIdx.y == 0;
   // bn1: y = x * gamma * rs + beta  (moving mean 0 / variance 1, never updated: score.py:69 runs it in inference mode).
   // float4 per thread and trip, four trips' loads in flight together (clamped addresses, no branch around a load)
   for (int e = tid; e < HF_ROWS * LD0; e += 64 * HF_NW) xs[e] = 0.f;
   __syncthreads();
-  if ((Dh & 3) == 0) {
+  if (phase == 2) {
+    // (phase 2 starts from the saved fc1 output)
+  } else if ((Dh & 3) == 0) {
     const int n4 = Dh >> 2, total = HF_ROWS * n4;
     for (int e0 = tid; e0 < total; e0 += 4 * 64 * HF_NW) {
       float4 xv[4], gv[4], bv[4];
@@ -139,7 +148,7 @@ __global__ __launch_bounds__(64 * HF_NW) void head_fwd_fused_kernel(const HeadFw
         float4 v;
         v.x = xv[u].x * (gv[u].x * a.rs) + bv[u].x; v.y = xv[u].y * (gv[u].y * a.rs) + bv[u].y;
         v.z = xv[u].z * (gv[u].z * a.rs) + bv[u].z; v.w = xv[u].w * (gv[u].w * a.rs) + bv[u].w;
-        st4(a.bn + (int64_t)(b0 + ii[u]) * Dh + jj[u], v);
+        if (store_bn) st4(a.bn + (int64_t)(b0 + ii[u]) * Dh + jj[u], v);
         *reinterpret_cast<float4*>(xs + ii[u] * LD0 + jj[u]) = v;
       }
     }
@@ -148,7 +157,7 @@ __global__ __launch_bounds__(64 * HF_NW) void head_fwd_fused_kernel(const HeadFw
       const int i = e / Dh, j = e - i * Dh;
       if (b0 + i < a.B) {
         const float v = a.x[(int64_t)(b0 + i) * Dh + j] * (a.gamma[j] * a.rs) + a.beta[j];
-        a.bn[(int64_t)(b0 + i) * Dh + j] = v;
+        if (store_bn) a.bn[(int64_t)(b0 + i) * Dh + j] = v;
         xs[i * LD0 + j] = v;
       }
     }
@@ -156,9 +165,37 @@ __global__ __launch_bounds__(64 * HF_NW) void head_fwd_fused_kernel(const HeadFw
   for (int e = tid; e < HF_ROWS * (LD1 + LD2); e += 64 * HF_NW) f1s[e] = 0.f;      // zero padding of the next layers' K
   __syncthreads();
 
-  // fc1: tiles of 16 columns, two per wave and pass
   const int nt1 = (N1 + 15) >> 4;
-  for (int tb = 0; tb < nt1; tb += 2 * HF_NW) {
+  if (phase == 1) {       // this workgroup's share of fc1's column tiles, one per wave and pass; straight to global memory
+    const int tpg = (nt1 + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int tend = min(nt1, ((int)blockIdx.y + 1) * tpg);
+    for (int tb = (int)blockIdx.y * tpg; tb < tend; tb += HF_NW) {
+      hf_f32x4 acc[1] = {{0.f, 0.f, 0.f, 0.f}};
+      const int t0 = tb + wave;
+      const int n0[1] = {t0 < tend ? t0 * 16 : -1};
+      if (n0[0] >= 0) hf_tiles<1>(acc, xs, LD0, Kp0, Dh, a.W1, N1, n0, N1, lc, lq);
+      const int col = n0[0] + lc;
+      const float bias = a.b1[min(max(col, 0), N1 - 1)];
+      if (n0[0] >= 0 && col < N1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = b0 + lq * 4 + r;
+          const float v = hf_act(acc[0][r], bias, a.drop, a.keep, a.mask0, seed0, row, col, N1);
+          if (row < a.B) a.f1[(int64_t)row * N1 + col] = v;
+        }
+      }
+    }
+    return;
+  }
+  if (phase == 2) {       // the saved fc1 output of this row tile -> LDS (its padding is zero already)
+    for (int e = tid; e < HF_ROWS * N1; e += 64 * HF_NW) {
+      const int i = e / N1, j = e - i * N1;
+      const int row = min(b0 + i, a.B - 1);
+      f1s[i * LD1 + j] = a.f1[(int64_t)row * N1 + j];
+    }
+  }
+  // fc1: tiles of 16 columns, two per wave and pass
+  for (int tb = 0; phase == 0 && tb < nt1; tb += 2 * HF_NW) {
     hf_f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     const int t0 = tb + wave, t1 = tb + HF_NW + wave;
     const int n0[2] = {t0 < nt1 ? t0 * 16 : -1, t1 < nt1 ? t1 * 16 : -1};
@@ -860,7 +897,21 @@ int score_launch_head_fwd_fused(int B, int Dh, int N1, int N2, const float* x, c
   a.keep = keep; a.drop = keep < 1.f ? 1 : 0; a.mask0 = mask0; a.mask1 = mask1; a.seed0 = seed0; a.seed1 = seed1; a.seed_dev = seed_dev;
   a.label = label; a.bn = bn; a.f1 = f1; a.f2 = f2; a.logit = logit; a.y = y; a.lossb = lossb; a.dlogit = dlogit;
   a.dz2 = dz2;
-  hipLaunchKernelGGL(head_fwd_fused_kernel, dim3((B + HF_ROWS - 1) / HF_ROWS), dim3(64 * HF_NW), lds, s, a);
+  const int mt = (B + HF_ROWS - 1) / HF_ROWS, nt1 = (N1 + 15) >> 4;
+  // SCORE_HEAD_SPLIT=0 / 1 forces one launch / two (read once); default: two from 32 row tiles up
+  static const int split_env = [] { const char* v = getenv("SCORE_HEAD_SPLIT"); return (v && *v) ? (v[0] == '0' ? 0 : 1) : -1; }();
+  const bool split = nt1 >= 4 && (split_env < 0 ? mt >= 32 : split_env == 1);
+  if (!split) {
+    a.phase = 0;
+    hipLaunchKernelGGL(head_fwd_fused_kernel, dim3(mt), dim3(64 * HF_NW), lds, s, a);
+    SCORE_CHECK_LAUNCH();
+    return 0;
+  }
+  a.phase = 1;
+  hipLaunchKernelGGL(head_fwd_fused_kernel, dim3(mt, 4), dim3(64 * HF_NW), lds, s, a);
+  SCORE_CHECK_LAUNCH();
+  a.phase = 2;
+  hipLaunchKernelGGL(head_fwd_fused_kernel, dim3(mt), dim3(64 * HF_NW), lds, s, a);
   SCORE_CHECK_LAUNCH();
   return 0;
 }
