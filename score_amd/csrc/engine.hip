@@ -491,7 +491,7 @@ extern "C" int score_forward(const score_config_t* cfg, const score_state_t* st,
     GruArgs ga;
     memset(&ga, 0, sizeof(ga));
     ga.B = B; ga.T = T; ga.H = H; ga.length = bt->length; ga.nw8 = 1;
-    ga.tmp = ws + w.gru_tmp; ga.tmp_floats = w.gru_tmp_floats; ga.x3 = x3 != 0; ga.x3_rec = ga.x3; ga.stepwise = env_flags().gru_stepwise || (st->debug_flags & 1);   // H = 128: two waves per SIMD hide the LDS/epilogue latency (measured -0.08 ms/step)
+    ga.tmp = ws + w.gru_tmp; ga.tmp_floats = w.gru_tmp_floats; ga.x3 = x3 != 0; ga.x3_rec = ga.x3 && !(st->debug_flags & 4); ga.stepwise = env_flags().gru_stepwise || (st->debug_flags & 1);   // H = 128: two waves per SIMD hide the LDS/epilogue latency (measured -0.08 ms/step)
     HIPTRY(hipStreamWaitEvent(s, wx_ev, 0));
     if (d.Is[0] == d.Is[1]) {    // both sides' projections in ONE grouped launch (each with its own bias row)
       const float* c0 = ws + w.wxcat;
@@ -566,7 +566,8 @@ extern "C" int score_forward(const score_config_t* cfg, const score_state_t* st,
                                               keep_prob, drop_mask0, drop_mask1, drop_seed, drop_seed ^ 0x5DEECE66Dull,
                                               bt->label, ws + w.bn, ws + w.f1, ws + w.f2, ws + w.logit, ws + w.y_pred,
                                               ws + w.lossb, ws + w.dlogit, Bg, s,
-                                              st->step_scalars ? &st->step_scalars->drop_seed : nullptr, ws + w.dz2);
+                                              st->step_scalars ? &st->step_scalars->drop_seed : nullptr, ws + w.dz2,
+                                              (st->debug_flags & 2) ? 1 : 0);
   if (hrc == 0) {
     G(score_launch_loss_final(B, ws + w.lossb, ws + w.loss, reg_lambda, ws + w.part, Bg, s));    // (dz2 came with the head)
   } else if (hrc == SCORE_E_SHAPE) {
@@ -761,7 +762,7 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
     GruArgs ga;
     memset(&ga, 0, sizeof(ga));
     ga.B = B; ga.T = T; ga.H = H; ga.length = bt->length; ga.nw8 = 1;
-    ga.tmp = ws + w.gru_tmp; ga.tmp_floats = w.gru_tmp_floats; ga.x3 = x3 != 0; ga.x3_rec = ga.x3; ga.stepwise = env_flags().gru_stepwise || (st->debug_flags & 1);   // H = 128: two waves per SIMD hide the LDS/epilogue latency (measured -0.08 ms/step)
+    ga.tmp = ws + w.gru_tmp; ga.tmp_floats = w.gru_tmp_floats; ga.x3 = x3 != 0; ga.x3_rec = ga.x3 && !(st->debug_flags & 4); ga.stepwise = env_flags().gru_stepwise || (st->debug_flags & 1);   // H = 128: two waves per SIMD hide the LDS/epilogue latency (measured -0.08 ms/step)
     for (int sd = 0; sd < 2; ++sd) {
       GruSide& g = ga.s[sd];
       g.Wg = W + P.gk[sd] + (int64_t)d.Is[sd] * 2 * H; g.ldwg = 2 * H;

@@ -879,7 +879,7 @@ int score_launch_head_fwd_fused(int B, int Dh, int N1, int N2, const float* x, c
                                 const float* W3, const float* b3, float keep, const uint8_t* mask0, const uint8_t* mask1,
                                 uint64_t seed0, uint64_t seed1, const int32_t* label, float* bn, float* f1, float* f2,
                                 float* logit, float* y, float* lossb, float* dlogit, int Bglobal, hipStream_t s,
-                                const uint64_t* seed_dev, float* dz2) {
+                                const uint64_t* seed_dev, float* dz2, int single_launch) {
   const int LD0 = ((Dh + 15) & ~15) + 4, LD1 = ((N1 + 15) & ~15) + 4, LD2 = ((N2 + 15) & ~15) + 4;
   const size_t lds = (size_t)HF_ROWS * (LD0 + LD1 + LD2) * sizeof(float);
   if (!score_head_fwd_fused_fits(B, Dh, N1, N2)) return SCORE_E_SHAPE;
@@ -900,7 +900,7 @@ int score_launch_head_fwd_fused(int B, int Dh, int N1, int N2, const float* x, c
   const int mt = (B + HF_ROWS - 1) / HF_ROWS, nt1 = (N1 + 15) >> 4;
   // SCORE_HEAD_SPLIT=0 / 1 forces one launch / two (read once); default: two from 32 row tiles up
   static const int split_env = [] { const char* v = getenv("SCORE_HEAD_SPLIT"); return (v && *v) ? (v[0] == '0' ? 0 : 1) : -1; }();
-  const bool split = nt1 >= 4 && (split_env < 0 ? mt >= 32 : split_env == 1);
+  const bool split = !single_launch && nt1 >= 4 && (split_env < 0 ? mt >= 32 : split_env == 1);
   if (!split) {
     a.phase = 0;
     hipLaunchKernelGGL(head_fwd_fused_kernel, dim3(mt), dim3(64 * HF_NW), lds, s, a);

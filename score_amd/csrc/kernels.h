@@ -111,7 +111,7 @@ int score_launch_head_fwd_fused(int B, int Dh, int N1, int N2, const float* x, c
                                 const float* W3, const float* b3, float keep, const uint8_t* mask0, const uint8_t* mask1,
                                 uint64_t seed0, uint64_t seed1, const int32_t* label, float* bn, float* f1, float* f2,
                                 float* logit, float* y, float* lossb, float* dlogit, int Bglobal, hipStream_t s,
-                                const uint64_t* seed_dev = nullptr, float* dz2 = nullptr);
+                                const uint64_t* seed_dev = nullptr, float* dz2 = nullptr, int single_launch = 0);
 bool score_head_fwd_fused_fits(int B, int Dh, int N1, int N2);
 int score_launch_head_bwd_fused(int B, int Dh, int N1, int N2, const float* dz2, const float* W2, const float* f1, float keep,
                                 const float* W1, const float* x, const float* gamma, float rs, float* dz1, float* dbn,

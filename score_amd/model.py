@@ -185,7 +185,7 @@ class SCOREBASE(object):
         self._scalars_host = torch.zeros((4,), dtype=torch.int32).pin_memory()
         self._use_dev_scalars = False
         self._graph_on, self._graphs = False, {}
-        self.debug_flags = 0       # score_state_t.debug_flags (A/B switches; bit 0: step-by-step H = 256 recurrence)
+        self.debug_flags = 0       # score_state_t.debug_flags (A/B switches; bit 0: step-by-step H = 256 recurrence, bit 1: head forward in one launch, bit 2: f32-MFMA H = 128 recurrence)
         self.gemm_mode = 1         # 1: bf16x3 split (fp32-accurate) on the shapes where it measured faster, 0: f32 MFMA only
         self._init_params(seed)
 

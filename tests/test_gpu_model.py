@@ -385,3 +385,34 @@ def test_streaming_recurrence_h256(B, T, ragged):
         l_g = m.train(None, batch_tuple(b), 1e-3, 1e-4, keep_prob=1.0)
         l_o = om.train(None, batch_tuple(b), 1e-3, 1e-4, keep_prob=1.0)
         assert abs(l_g - l_o) < 2e-5 * max(1.0, abs(l_o))
+
+
+def test_head_two_launch_form_and_x3_recurrence_against_their_references():
+    # B = 544 is 34 row tiles of 16: the head's forward runs as two launches (bn1 + fc1 column slices, then fc2 / fc3 /
+    # loss) -- same arithmetic per element as the one-launch form (debug_flags bit 1): bitwise equal.  H = 128 puts the
+    # recurrences on the bf16x3 kernels (gru_x3.hip); debug_flags bit 2 keeps the f32-input MFMA kernels: equal to the
+    # last fp32 bits, and both equal to the oracle.  B is not a multiple of 16 * 4 either: ragged tiles, ragged lengths.
+    cfg = so.Cfg(3000, 8, 128, 6, 3, 3, 4, "SCORE")
+    rng = np.random.default_rng(77)
+    P = so.init_params(cfg, 5)
+    B = 544 + 7
+    b = random_batch(rng, cfg, B)
+    b["length"] = rng.integers(1, cfg.T + 1, B).astype(np.int32)
+    m, m1, mf = make_model(cfg, P), make_model(cfg, P), make_model(cfg, P)
+    m1.debug_flags = 2
+    mf.debug_flags = 4
+    om = so.OracleModel(cfg.N, cfg.D, cfg.H, cfg.T, cfg.K, cfg.Fu, cfg.Fi, "SCORE", params={k: v.copy() for k, v in P.items()})
+    p, _, l = m.eval(None, batch_tuple(b), 1e-4)
+    p1, _, l1 = m1.eval(None, batch_tuple(b), 1e-4)
+    pf, _, lf = mf.eval(None, batch_tuple(b), 1e-4)
+    po, _, lo = om.eval(None, batch_tuple(b), 1e-4)
+    assert p == p1 and l == l1
+    assert np.abs(np.asarray(p) - np.asarray(pf)).max() < 2e-6
+    assert np.abs(np.asarray(p) - np.asarray(po)).max() < LOGIT_TOL and abs(l - lo) < 1e-5 * max(1.0, abs(lo))
+    for mm in (m, m1, mf):
+        mm.forward_backward(batch_tuple(b), 1e-4, 0.8)
+    g, g1, gf = m.get_grads(), m1.get_grads(), mf.get_grads()
+    for k in g:
+        assert np.array_equal(g[k], g1[k]), k
+        ok, err = close(g[k], gf[k], rtol=2e-5, atol=1e-9)
+        assert ok, (k, err)
