@@ -245,7 +245,8 @@ def test_coattn_rca_sum_mode():
     assert np.allclose(o2.cpu().numpy(), w2, rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize("B,T,H", [(5, 3, 8), (70, 11, 32), (33, 6, 128), (64, 9, 128), (9, 4, 20), (17, 5, 16), (40, 7, 64)])
+@pytest.mark.parametrize("B,T,H", [(5, 3, 8), (70, 11, 32), (33, 6, 128), (64, 9, 128), (9, 4, 20), (17, 5, 16), (40, 7, 64),
+                                   (20, 1, 128), (16, 1, 32), (3, 2, 64), (35, 1, 256), (64, 2, 256)])
 def test_gru_fwd_bwd(B, T, H):
     # dynamic_rnn(GRUCell) recurrence (score.py:205-208) vs the oracle's _gru + autograd
     lib = _lib.load()
