@@ -312,11 +312,11 @@ __device__ __forceinline__ float sigmoid_fast(float x) { return __builtin_amdgcn
 __device__ __forceinline__ float tanh_fast(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f); }
 
 
-// FULL: the batch is a whole number of 16-row tiles and every wave owns whole column tiles -- the time loop
-// then has no predicated memory operation at all.  That matters beyond the saved compares: with loads and
-// stores under exec-mask branches the compiler's s_waitcnt placement falls back to vmcnt(0) in the loop,
-// so every step waited for the prefetch it had just issued (43 % of the kernel's wave time).
-template <int H, int NW, bool FULL>
+// The time loops have no predicated memory operation at all (rows past the batch duplicate the last sample, see
+// below).  That matters beyond the saved compares: with loads and stores under exec-mask branches the compiler's
+// s_waitcnt placement falls back to vmcnt(0) in the loop, so every step waited for the prefetch it had just issued
+// (43 % of the kernel's wave time in the first version).
+template <int H, int NW>
 __global__ __launch_bounds__(64 * NW) void gru_fwd_reg_kernel(const GruArgs a) {
   constexpr int KS = H / 4;                 // k-steps of 4
   constexpr int NTG = 2 * H / 16, NTC = H / 16;
@@ -472,7 +472,7 @@ __global__ __launch_bounds__(64 * NW) void gru_fwd_reg_kernel(const GruArgs a) {
     }
 }
 
-template <int H, int NW, bool FULL>
+template <int H, int NW>
 __global__ __launch_bounds__(64 * NW) void gru_bwd_reg_kernel(const GruArgs a) {
   constexpr int KS = H / 4;
   constexpr int NT = H / 16;
@@ -569,7 +569,7 @@ __global__ __launch_bounds__(64 * NW) void gru_bwd_reg_kernel(const GruArgs a) {
       for (int r = 0; r < 4; ++r) c_hp[tt][r] = (t < len[r] && t > 0) ? n_hp[tt][r] : 0.f;
     __builtin_amdgcn_sched_barrier(0);
     fetch_hp(t - 1);
-    // phase 1 (elementwise): dpu, dpc ; dh <- dh_tot * u      (selects, no branches: see FULL above)
+    // phase 1 (elementwise): dpu, dpc ; dh <- dh_tot * u      (selects, no branches)
 #pragma unroll
     for (int tt = 0; tt < TW; ++tt) {
       const int tile = wave + NW * tt;
@@ -840,12 +840,7 @@ int score_gru_fwd_multi(GruArgs& a, int nsides, hipStream_t s) {
   if (a.x3_rec && gru_x3_allowed() && score_gru_x3_ok(H, a.nw8)) return score_gru_fwd_x3(a, nsides, s);
   if (gru_reg_ok(H)) {
     dim3 grid(nsides * ((a.B + RRB - 1) / RRB));
-    const bool full = a.B % RRB == 0;
-#define LF(Hv, NWv)                                                                                         \
-  do {                                                                                                      \
-    if (full) hipLaunchKernelGGL((gru_fwd_reg_kernel<Hv, NWv, true>), grid, dim3(64 * NWv), 0, s, a);       \
-    else hipLaunchKernelGGL((gru_fwd_reg_kernel<Hv, NWv, false>), grid, dim3(64 * NWv), 0, s, a);           \
-  } while (0)
+#define LF(Hv, NWv) hipLaunchKernelGGL((gru_fwd_reg_kernel<Hv, NWv>), grid, dim3(64 * NWv), 0, s, a)
     if (H == 16) LF(16, 4);
     else if (H == 32) LF(32, 4);
     else if (H == 64) LF(64, 4);
@@ -872,12 +867,7 @@ int score_gru_bwd_multi(GruArgs& a, int nsides, hipStream_t s) {
   if (a.x3_rec && gru_x3_allowed() && score_gru_x3_ok(H, a.nw8)) return score_gru_bwd_x3(a, nsides, s);
   if (gru_reg_ok(H)) {
     dim3 grid(nsides * ((a.B + RRB - 1) / RRB));
-    const bool full = a.B % RRB == 0;
-#define LB(Hv, NWv)                                                                                         \
-  do {                                                                                                      \
-    if (full) hipLaunchKernelGGL((gru_bwd_reg_kernel<Hv, NWv, true>), grid, dim3(64 * NWv), 0, s, a);       \
-    else hipLaunchKernelGGL((gru_bwd_reg_kernel<Hv, NWv, false>), grid, dim3(64 * NWv), 0, s, a);           \
-  } while (0)
+#define LB(Hv, NWv) hipLaunchKernelGGL((gru_bwd_reg_kernel<Hv, NWv>), grid, dim3(64 * NWv), 0, s, a)
     if (H == 16) LB(16, 4);
     else if (H == 32) LB(32, 4);
     else if (H == 64) LB(64, 4);

@@ -115,8 +115,7 @@ __device__ __forceinline__ gfloat* stp(float* base, int64_t uni, uint32_t voff) 
   return (gfloat*)(uni_addr(base, uni) + voff);
 }
 
-// FULL: the batch is a whole number of 16-row tiles -- no predicated memory operation in the time loop (gru.hip)
-template <bool FULL>
+// (no predicated memory operation in the time loop: rows past the batch duplicate the last sample, see below)
 __global__ __launch_bounds__(64 * XNW) void gru_fwd_x3_kernel(const GruArgs a) {
   constexpr int H = XH, PS = XRB * XLD;
   __shared__ __attribute__((aligned(16))) unsigned short hp[3 * PS], rp[3 * PS];
@@ -236,7 +235,6 @@ __global__ __launch_bounds__(64 * XNW) void gru_fwd_x3_kernel(const GruArgs a) {
   }
 }
 
-template <bool FULL>
 __global__ __launch_bounds__(64 * XNW) void gru_bwd_x3_kernel(const GruArgs a) {
   constexpr int H = XH, PS = XRB * XLD, PS2 = XRB * XLD2;
   __shared__ __attribute__((aligned(16))) unsigned short dpc[3 * PS], dpg[3 * PS2];
@@ -393,8 +391,7 @@ static bool x3_fits(const GruArgs& a, int nsides) {
 int score_gru_fwd_x3(GruArgs& a, int nsides, hipStream_t s) {
   if (!score_gru_x3_ok(a.H, a.nw8) || a.B <= 0 || a.T <= 0 || !x3_fits(a, nsides)) return SCORE_E_SHAPE;
   dim3 grid(nsides * ((a.B + XRB - 1) / XRB));
-  if (a.B % XRB == 0) hipLaunchKernelGGL(gru_fwd_x3_kernel<true>, grid, dim3(64 * XNW), 0, s, a);
-  else hipLaunchKernelGGL(gru_fwd_x3_kernel<false>, grid, dim3(64 * XNW), 0, s, a);
+  hipLaunchKernelGGL(gru_fwd_x3_kernel, grid, dim3(64 * XNW), 0, s, a);
   SCORE_CHECK_LAUNCH();
   return 0;
 }
@@ -402,8 +399,7 @@ int score_gru_fwd_x3(GruArgs& a, int nsides, hipStream_t s) {
 int score_gru_bwd_x3(GruArgs& a, int nsides, hipStream_t s) {
   if (!score_gru_x3_ok(a.H, a.nw8) || a.B <= 0 || a.T <= 0 || !x3_fits(a, nsides)) return SCORE_E_SHAPE;
   dim3 grid(nsides * ((a.B + XRB - 1) / XRB));
-  if (a.B % XRB == 0) hipLaunchKernelGGL(gru_bwd_x3_kernel<true>, grid, dim3(64 * XNW), 0, s, a);
-  else hipLaunchKernelGGL(gru_bwd_x3_kernel<false>, grid, dim3(64 * XNW), 0, s, a);
+  hipLaunchKernelGGL(gru_bwd_x3_kernel, grid, dim3(64 * XNW), 0, s, a);
   SCORE_CHECK_LAUNCH();
   return 0;
 }

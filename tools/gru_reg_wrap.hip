@@ -4,6 +4,9 @@ bool score_gru_stream_ok(int) { return false; }
 int64_t score_gru_stream_tmp_floats(int, int) { return 0; }
 int score_gru_fwd_stream(GruArgs&, int, hipStream_t) { return SCORE_E_SHAPE; }
 int score_gru_bwd_stream(GruArgs&, int, hipStream_t) { return SCORE_E_SHAPE; }
+bool score_gru_x3_ok(int, int) { return false; }
+int score_gru_fwd_x3(GruArgs&, int, hipStream_t) { return SCORE_E_SHAPE; }
+int score_gru_bwd_x3(GruArgs&, int, hipStream_t) { return SCORE_E_SHAPE; }
 int score_gemm_same_shape(int, int, int, int, int, const float* const*, int, const float* const*, int, float* const*, int, int, int,
                           float*, int64_t, hipStream_t, const float* const*) { return SCORE_E_SHAPE; }
 extern "C" int probe_gru(int dir, int B, int T, int H, const float* xproj, const float* Wg, const float* Wc,
