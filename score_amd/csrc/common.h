@@ -49,7 +49,15 @@ __device__ __forceinline__ void score_adam1(float& p, float& m, float& v, float 
                                             float eps) {
   m = __builtin_fmaf(g - m, omb1, m);
   v = __builtin_fmaf(__builtin_fmaf(g, g, -v), omb2, v);
+#if defined(SCORE_ADAM_IEEE_DIV)
   p = p - (m * alpha) / (sqrtf(v) + eps);
+#else
+  // v_sqrt_f32 / v_rcp_f32 (1 ulp each) instead of the correctly rounded sqrtf and division (~25 instructions): the
+  // zero-gradient replay of the time-tiled optimizer is one of these per owed step and element and was VALU-bound
+  // (the window slice: 147 MB in 170 - 200 us).  The update term moves by <= 2 ulp of itself, far inside what the
+  // order of the sums feeding g already varies; every Adam kernel goes through here, so they still agree bit for bit.
+  p = p - (m * alpha) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v) + eps);
+#endif
 }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 

@@ -150,8 +150,10 @@ class SCOREBASE(object):
         self._tbl = self._table_block[0]
         # time-tiled table optimizer (include/score_hip.h, score_adam_table_t): live rows without a gradient are
         # updated the next time they are needed (or once per `adam_window` steps) instead of every step.  Bit-identical
-        # to the per-step sweep wherever the table is observed; 0 = sweep the whole table every step
-        self._adam_window = int(os.environ.get("SCORE_ADAM_WINDOW", "16"))
+        # to the per-step sweep wherever the table is observed; 0 = sweep the whole table every step.  24: at cfg-3 the
+        # slice of a step (1/24 of 1.53 M rows) is through before the scatter starts; 12 - 22 measure 0.03 - 0.06 ms/step
+        # slower, 26 - 32 the same, 36+ slower again (profiles/r02_probes.md)
+        self._adam_window = int(os.environ.get("SCORE_ADAM_WINDOW", "24"))
         # ... and only where the sweep is worth replacing: its six streams over the table against two extra scans of
         # the state bytes and three more launches per step (cfg-2's 62 MB table: 0.391 ms/step swept, 0.425 tiled;
         # the reference's own shape, 587 MB: 0.513 -> 0.466; cfg-3, 2.35 GB: 1.76 -> 1.48)

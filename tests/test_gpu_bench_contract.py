@@ -55,7 +55,7 @@ def test_time_tiled_optimizer_line():
     """the headline's table optimizer (on by default from 256 MB of sweep traffic; forced here on the small shape) and
     the per-step sweep it replaces, timed in the same process"""
     j = _run("--steps", "20", "--warmup", "3", "--config", "cfg2", "--no-cpu-baseline", SCORE_ADAM_TILED_MIN_BYTES="0")
-    assert j["config"]["table_optimizer"].startswith("time-tiled ApplyAdam, window 16")
+    assert j["config"]["table_optimizer"].startswith("time-tiled ApplyAdam, window 24")
     assert j["value_dense_adam_sweep"] > 0 and j["stages_ms"]["adam_catchup_batch_rows"] > 0
     assert any(k.startswith("adam_touched") for k in j["roofline_other"])
     j = _run("--steps", "6", "--warmup", "2", "--config", "cfg2", "--no-cpu-baseline", "--no-side", SCORE_ADAM_WINDOW="0")
