@@ -22,6 +22,8 @@ def make_model(cfg, params):
 
 def close(a, b, rtol=1e-4, atol=2e-6):
     a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    if max(np.abs(a).max(), np.abs(b).max()) < 1e-7:     # rounding noise on both sides (e.g. dense_5/bias: its gradient
+        return True, 0.0                                  # is zero in exact arithmetic, the softmax is shift-invariant)
     scale = max(np.abs(b).max(), 1e-12)
     return np.abs(a - b).max() <= atol + rtol * scale, float(np.abs(a - b).max() / scale)
 
@@ -376,11 +378,13 @@ def test_streaming_recurrence_h256(B, T, ragged):
     g1, g2 = m.get_grads(), ms.get_grads()
     _, go = so.loss_and_grads(cfg, P, b, 0.0)
     for k in g1:
+        if np.abs(go[k]).max() <= 1e-7:      # (a gradient that is zero in exact arithmetic -- dense_5/bias under the
+            assert max(np.abs(g1[k]).max(), np.abs(g2[k]).max()) < 1e-6, k      # softmax --: rounding noise on both sides)
+            continue
         ok, err = close(g1[k], g2[k], rtol=2e-5, atol=1e-9)
         assert ok, (k, err)
-        if np.abs(go[k]).max() > 1e-7:
-            ok, err = close(g1[k], go[k], rtol=2e-4, atol=1e-9)
-            assert ok, (k, err)
+        ok, err = close(g1[k], go[k], rtol=2e-4, atol=1e-9)
+        assert ok, (k, err)
     for _ in range(2):
         l_g = m.train(None, batch_tuple(b), 1e-3, 1e-4, keep_prob=1.0)
         l_o = om.train(None, batch_tuple(b), 1e-3, 1e-4, keep_prob=1.0)
