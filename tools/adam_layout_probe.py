@@ -1,32 +1,38 @@
-"""Run-to-run spread of the dense table sweep (score_adam_rows, every row live) and its sensitivity to the
-relative placement of the p / m / v / g arrays: one allocation, the four arrays `pad` bytes apart beyond their size.
-  python tools/adam_layout_probe.py <pad_bytes> [...]      (one fresh process per launch gives a new physical layout)"""
-import ctypes as C, os, sys
+"""Would an interleaved [N][4][D] table block (p, m, v, g of a row contiguous: 1 KB) serve the table optimizer's row
+kernels better than four separate [N][D] arrays?  Times the touched-rows access pattern of cfg-3 (177 k of 1.53 M rows,
+D = 64) in both layouts, and what the forward's gather of p rows would pay for the interleaving.
+Run on the GPU box: python tools/adam_layout_probe.py"""
+import ctypes as C, os, subprocess, tempfile
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from score_amd import _lib
-lib = _lib.load()
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+so = os.path.join(tempfile.mkdtemp(), "probe.so")
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
+                       os.path.join(root, "tools", "adam_layout_wrap.hip"), "-o", so])
+lib = C.CDLL(so)
 N, D = 1529672, 64
+g = torch.Generator(device="cuda").manual_seed(1)
+split = torch.rand(4, N, D, device="cuda", generator=g)
+inter = torch.rand(N, 4, D, device="cuda", generator=g)
 P = lambda t: C.c_void_p(t.data_ptr())
-for pad in [int(x) for x in sys.argv[1:]] or [0]:
-    n = N * D
-    stride = n + pad // 4
-    if pad < 0:       # separate allocations (what the model does)
-        arrs = [torch.zeros(n, device="cuda") for _ in range(4)]
+st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
+for name, n in (("touched rows of a step (177 k, sorted)", 176700), ("rows a batch reads (2.0 M uses, random order)", 2000000)):
+    if n < N:
+        rows = torch.randperm(N, device="cuda", generator=g)[:n].sort().values.int()
     else:
-        buf = torch.zeros(4 * stride, device="cuda")
-        arrs = [buf[i * stride:i * stride + n] for i in range(4)]
-    flags = torch.ones(N, dtype=torch.uint8, device="cuda")
-    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    call = lambda: lib.score_adam_rows(P(arrs[0]), P(arrs[1]), P(arrs[2]), P(arrs[3]), N, D, P(flags), 1e-3, 0.9, 0.999, 1e-8, st)
-    for _ in range(3): call()
-    torch.cuda.synchronize()
-    ts = []
-    for _ in range(5):
-        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(10): call()
-        e1.record(); torch.cuda.synchronize()
-        ts.append(e0.elapsed_time(e1) / 10)
-    print("pad %8d: %s ms  (%.2f TB/s best)" % (pad, " ".join("%.3f" % t for t in ts), 6 * n * 4 / min(ts) / 1e9))
-    del arrs
+        rows = torch.randint(0, N, (n,), device="cuda", generator=g).int()
+    out = torch.empty(n, D, device="cuda")
+    for which, label, byts in ((0, "four arrays   read p,m,v,g write p,m,v", n * D * 4 * 7), (1, "interleaved   read p,m,v,g write p,m,v", n * D * 4 * 7),
+                               (2, "gather p rows, row stride 256 B", n * D * 4 * 2), (3, "gather p rows, row stride 1 KB ", n * D * 4 * 2)):
+        a = split if which in (0, 2) else inter
+        args = (P(split[0]), P(split[1]), P(split[2]), P(split[3])) if which == 0 else (P(a), None, None, None)
+        call = lambda: lib.probe(which, *args, P(rows), n, P(out), st())
+        assert call() == 0
+        torch.cuda.synchronize()
+        best = 1e9
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10): call()
+            e1.record(); torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1) / 10)
+        print("%-46s %-42s %7.1f us  %5.2f TB/s" % (name, label, best * 1e3, byts / best / 1e9), flush=True)
