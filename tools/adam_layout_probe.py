@@ -20,11 +20,11 @@ for name, n in (("touched rows of a step (177 k, sorted)", 176700), ("rows a bat
         rows = torch.randperm(N, device="cuda", generator=g)[:n].sort().values.int()
     else:
         rows = torch.randint(0, N, (n,), device="cuda", generator=g).int()
-    out = torch.empty(n, D, device="cuda")
-    for which, label, byts in ((0, "four arrays   read p,m,v,g write p,m,v", n * D * 4 * 7), (1, "interleaved   read p,m,v,g write p,m,v", n * D * 4 * 7),
+    out = torch.empty(max(n, 200000), D, device="cuda")     # (also the state arrays of variant 4: 1.53 M bytes + 1.53 M words)
+    for which, label, byts in ((0, "four arrays   read p,m,v,g write p,m,v", n * D * 4 * 7), (1, "interleaved   read p,m,v,g write p,m,v", n * D * 4 * 7), (4, "four arrays + state byte + step counter", n * D * 4 * 7),
                                (2, "gather p rows, row stride 256 B", n * D * 4 * 2), (3, "gather p rows, row stride 1 KB ", n * D * 4 * 2)):
-        a = split if which in (0, 2) else inter
-        args = (P(split[0]), P(split[1]), P(split[2]), P(split[3])) if which == 0 else (P(a), None, None, None)
+        a = split if which in (0, 2, 4) else inter
+        args = (P(split[0]), P(split[1]), P(split[2]), P(split[3])) if which in (0, 4) else (P(a), None, None, None)
         call = lambda: lib.probe(which, *args, P(rows), n, P(out), st())
         assert call() == 0
         torch.cuda.synchronize()

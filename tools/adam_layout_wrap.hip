@@ -20,6 +20,18 @@ __global__ __launch_bounds__(256) void rows_split(float* p, float* m, float* v, 
   upd(P, M, V, G);
   st4g(p + e, P); st4g(m + e, M); st4g(v + e, V);
 }
+// ... plus the per-row state the shipped kernel also writes: a state byte and a step counter
+__global__ __launch_bounds__(256) void rows_split_state(float* p, float* m, float* v, const float* g, const int* rows, int n,
+                                                        unsigned char* flags, unsigned int* step) {
+  const int64_t gi = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  if (gi >= n) return;
+  const int r = rows[gi];
+  const int64_t e = (int64_t)r * 64 + (threadIdx.x & 15) * 4;
+  float4 P = ld4g(p + e), M = ld4g(m + e), V = ld4g(v + e), G = ld4g(g + e);
+  upd(P, M, V, G);
+  st4g(p + e, P); st4g(m + e, M); st4g(v + e, V);
+  if ((threadIdx.x & 15) == 0) { flags[r] = 1; step[r] = 7u; }
+}
 __global__ __launch_bounds__(256) void rows_inter(float* t, const int* rows, int n) {
   const int64_t gi = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
   if (gi >= n) return;
@@ -38,6 +50,8 @@ extern "C" int probe(int which, float* a, float* b, float* c, float* d, const in
   const unsigned blocks = (unsigned)(((int64_t)n * 16 + 255) / 256);
   if (which == 0) hipLaunchKernelGGL(rows_split, dim3(blocks), dim3(256), 0, (hipStream_t)s, a, b, c, d, rows, n);
   else if (which == 1) hipLaunchKernelGGL(rows_inter, dim3(blocks), dim3(256), 0, (hipStream_t)s, a, rows, n);
+  else if (which == 4) hipLaunchKernelGGL(rows_split_state, dim3(blocks), dim3(256), 0, (hipStream_t)s, a, b, c, d, rows, n,
+                                          reinterpret_cast<unsigned char*>(out), reinterpret_cast<unsigned int*>(out) + (1 << 20));
   else if (which == 2) hipLaunchKernelGGL(gather_p, dim3(blocks), dim3(256), 0, (hipStream_t)s, a, (int64_t)64, rows, n, out);
   else hipLaunchKernelGGL(gather_p, dim3(blocks), dim3(256), 0, (hipStream_t)s, a, (int64_t)256, rows, n, out);
   return (int)hipGetLastError();
