@@ -2,7 +2,8 @@
 """bench.py -- train samples/sec of the SCoRe hot path on MI355X.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg3]
-  (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+  (N > 1: either launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`, or called
+   plainly -- `python bench.py --gpus N` then starts that launcher itself as a child process, before touching the GPU)
 
 A "step" is one full training step of SCORE (score.py:101-116: forward, backward, dense TF-Adam over the
 whole table and all dense variables) on one synthetic Tmall-shaped batch whose int32 index tensors are
@@ -173,6 +174,35 @@ def gather_probe(model, kw, B, n_probe_rows, iters, seed=0):
             "expected_distinct_rows": int(uniq), "compulsory_row_bytes": int(uniq) * 4 * D, "probe_rows": n_probe_rows}
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port <free port> bench.py <same arguments>` as a child process (one rank per GPU
+    over RCCL; rank 0 prints the one JSON line to the inherited stdout) and return its exit code.  Called before
+    anything in this process has initialised the GPU; torch.cuda.device_count() only counts."""
+    import socket
+    import subprocess
+    rehearsal = os.environ.get("SCORE_BENCH_DEVICE") is not None      # several ranks on ONE device (gloo rehearsal)
+    n_dev = torch.cuda.device_count()
+    if n_dev < n and not rehearsal:
+        sys.stderr.write("bench.py: --gpus %d asked for, %d GPU(s) visible on this box: not started (nothing has touched the "
+                         "GPU).  To rehearse N ranks on one device: SCORE_BENCH_DEVICE=0 SCORE_DIST_BACKEND=gloo "
+                         "python bench.py --gpus %d\n" % (n, n_dev, n))
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("GPU_MAX_HW_QUEUES", "8")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, usable_cpus() // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stderr.write("bench.py: starting %d ranks: %s\n" % (n, " ".join(cmd)))
+    sys.stderr.flush()
+    return subprocess.call(cmd, env=env, cwd=ROOT)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -213,12 +243,18 @@ def main():
     ap.add_argument("--reg-lambda", type=float, default=1e-4)
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # called as plain `python bench.py --gpus N`: start the N ranks ourselves.  Nothing above this line has touched
+        # the GPU (no torch.cuda call that initialises HIP, no _lib.load()): the ranks are CHILD processes of
+        # torch.distributed.run, this process only waits for them and hands their exit code on
+        sys.exit(spawn_ranks(args.gpus))
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world_size != args.gpus:
-        if world_size == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node %d (or without "
+                         "torch.distributed.run: `python bench.py --gpus N` starts its own ranks)"
+                         % (args.gpus, world_size, args.gpus))
     # rehearsal aids (several ranks on a one-GPU box): SCORE_BENCH_DEVICE pins every rank to one device,
     # SCORE_DIST_BACKEND=gloo swaps RCCL for gloo (device tensors staged through host memory, score_amd/dist.py)
     if os.environ.get("SCORE_BENCH_DEVICE"):
@@ -345,10 +381,16 @@ def main():
         torch.cuda.synchronize()
         graph = True
     model.enable_stage_events(False)
+    dt_ranks = [dt]
+    ranks_seen = 1
     if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        # the step time of record is the MAX over ranks; every rank's own time rides in the same all_gather
+        ranks_seen = dist.get_world_size()
+        mine = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        got = [torch.zeros_like(mine) for _ in range(ranks_seen)]
+        dist.all_gather(got, mine)
+        dt_ranks = [float(t.item()) for t in got]
+        dt = max(dt_ranks)
     if sharded:
         loss = float((fb[0][1] + args.reg_lambda * fb[0][2]).item())
     else:
@@ -519,6 +561,9 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3,
+        "ms_per_step_ranks": {"min": min(dt_ranks) / args.steps * 1e3, "max": max(dt_ranks) / args.steps * 1e3},
+        "rccl_ranks": ranks_seen if (dist is not None and backend == "nccl") else 0,
+        "dist": ({"backend": backend, "world_size": ranks_seen} if dist is not None else None),
         "higher_is_better": True,
         "scaling": "strong" if strong else "weak",
         "vs_baseline": None,

@@ -60,3 +60,72 @@ def test_time_tiled_optimizer_line():
     assert any(k.startswith("adam_touched") for k in j["roofline_other"])
     j = _run("--steps", "6", "--warmup", "2", "--config", "cfg2", "--no-cpu-baseline", "--no-side", SCORE_ADAM_WINDOW="0")
     assert j["config"]["table_optimizer"].startswith("dense ApplyAdam sweep") and "adam_catchup_batch_rows" not in j["stages_ms"]
+
+
+def test_gpus_n_starts_its_own_ranks():
+    """`python bench.py --gpus N` (no launcher) starts N ranks itself, before anything touches the GPU.
+    On this one-GPU box: refused with a clear message for N = 2 over RCCL; the same command line rehearsed with two gloo
+    ranks on device 0 prints the one JSON line with n_gpus = 2."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
+                         timeout=300, cwd=ROOT)
+    import torch
+    if torch.cuda.device_count() < 2:
+        assert out.returncode == 2 and "2 GPU" not in out.stdout and "GPU(s) visible" in out.stderr, out.stderr[-500:]
+    j = _run("--gpus", "2", "--steps", "4", "--warmup", "1", "--config", "cfg2", SCORE_BENCH_DEVICE="0", SCORE_DIST_BACKEND="gloo")
+    assert j["n_gpus"] == 2 and j["dist"] == {"backend": "gloo", "world_size": 2} and j["rccl_ranks"] == 0
+    assert j["cpu_baseline"] is None and j["ms_per_step_ranks"]["min"] <= j["ms_per_step_ranks"]["max"] == j["ms_per_step"]
+    assert abs(j["value"] - 2 * 256 / (j["ms_per_step"] * 1e-3)) < 1e-6 * j["value"]
+
+
+_RCCL_ONE_RANK = r"""
+import json, os, sys
+sys.path.insert(0, %(root)r)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=%(port)r, RANK="0", WORLD_SIZE="1")
+import torch
+import torch.distributed as dist
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+from score_amd.synth import make_world
+from score_amd.model import SCORE
+from score_amd.dist import ShardedSCORE
+world, kw = make_world("cfg2")
+B = kw.pop("batch")
+a, b = SCORE(seed=1111, **kw), ShardedSCORE(seed=1111, **kw)
+assert torch.equal(a.table, b.backend.m.table) and torch.equal(a.w, b.backend.m.w)
+bts = [world.batch(B, i) for i in range(6)]
+la, lb = [], []
+for i, bt in enumerate(bts):
+    la.append(a.train(None, bt, 1e-3, 1e-4))
+    lb.append(b.train(None, bt, 1e-3, 1e-4, next_batch=bts[i + 1] if i + 1 < len(bts) else None))
+pa, _, _ = a.eval(None, bts[0], 1e-4)
+pb, _, _ = b.eval(None, bts[0], 1e-4)
+dp = max(abs(x - y) for x, y in zip(pa, pb))
+dt = float((a.table - b.backend.m.table).abs().max().item())
+print(json.dumps({"unsharded": la, "sharded": lb, "max_dpred": dp, "max_dtable": dt, "rccl_ranks": dist.get_world_size(),
+                  "backend": dist.get_backend()}))
+dist.destroy_process_group()
+"""
+
+
+def test_one_rank_through_rccl_equals_unsharded():
+    """the row-sharded path with ONE rank over RCCL (backend nccl: all_to_all_single + all_reduce really go through the
+    communicator) against the unsharded model: same seed, six different batches, dropout on (rank 0's seed stream is the
+    single-device one).  The two differ only in the order row gradients are summed (owner-side accumulate vs pull
+    scatter): losses to 1e-6 relative, predictions to 1e-5."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = str(s.getsockname()[1])
+    s.close()
+    out = subprocess.run([sys.executable, "-c", _RCCL_ONE_RANK % {"root": ROOT, "port": port}], capture_output=True, text=True,
+                         timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    j = json.loads([l for l in out.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert j["backend"] == "nccl" and j["rccl_ranks"] == 1
+    for x, y in zip(j["unsharded"], j["sharded"]):
+        assert abs(x - y) <= 1e-6 * max(1.0, abs(x)), (j["unsharded"], j["sharded"])
+    assert j["max_dpred"] < 1e-5 and j["max_dtable"] < 1e-5, j
+    # and bench.py itself through that path says so in its line
+    b = _run("--steps", "6", "--warmup", "2", "--config", "cfg2", "--no-cpu-baseline", "--force-sharded")
+    assert b["rccl_ranks"] == 1 and b["dist"]["backend"] == "nccl" and b["n_gpus"] == 1
