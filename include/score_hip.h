@@ -34,6 +34,7 @@ extern "C" {
 #define SCORE_E_BADARG   (-1)  /* null pointer / non-positive size               */
 #define SCORE_E_SHAPE    (-2)  /* shape outside what the kernels are built for   */
 #define SCORE_E_WORKSPACE (-3) /* workspace too small                            */
+#define SCORE_E_INDEX    (-4)  /* a feature id outside [0, feature_size) was fed (score_id_status) */
 
 /* Per-caller resources of the whole-path entry points (one non-blocking HIP stream + three events on the
  * current device).  Replaces nothing in the reference: it is what `tf.Session` owns there (train_score.py:188). */
@@ -320,7 +321,23 @@ typedef struct {
                            return SCORE_E_SHAPE when keep_prob < 1), so the launch sequence holds no per-step value */
   score_context_t context; /* side stream + events of this caller (score_context_create); NULL = the
                            process-wide default context of the current device                         */
+  int32_t* id_status;   /* optional DEVICE word, zero-initialised by the caller, sticky: tf.nn.embedding_lookup on the
+                           CPU raises for an id outside [0, feature_size) (score.py:51-66).  Here every kernel that turns an
+                           id into an address reads such an id as the dummy row 0 instead (never an out-of-bounds access,
+                           with or without this word), and the kernels that see the ids as fed -- the fused gather and
+                           the target-row gather of score_forward, the occurrence fill of score_index_plan -- OR bit i
+                           into the word, i = position of the tensor in the feed tuple (0 user_1hop, 1 user_2hop,
+                           2 item_1hop, 3 item_2hop, 4 target_user, 5 target_item; graph_loader.py:383).  No extra launch,
+                           no read-back: score_forward's loss reduction reads the word and, if it is set, writes NaN
+                           to loss[0] / loss[1] and the bits to loss[3], so whoever reads the loss learns of it;
+                           score_id_status() is the synchronous query.  Ids of time slices >= active_slices are never
+                           dereferenced and not checked.                                                         */
 } score_state_t;
+
+/* Synchronous query of a score_state_t.id_status word: copies it to *bits (optional), waits for `stream`, clears the
+ * word when `clear` != 0, and returns SCORE_E_INDEX if any bit was set (0 otherwise): the status TF's
+ * InvalidArgumentError "indices[...] is not in [0, N)" corresponds to (score.py:51-66). */
+int score_id_status(int32_t* id_status, int32_t* bits, int32_t clear, void* stream);
 
 /* Index plan of a batch (depends on the indices only; run it before score_backward, on
  * any stream ordered before it).  Radix-sorts all R*B row uses by (owner shard, row).

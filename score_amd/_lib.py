@@ -45,7 +45,7 @@ class State(C.Structure):
                 ("workspace_bytes", C.c_int64), ("scatter_mode", C.c_int32), ("global_batch", C.c_int32),
                 ("gemm_mode", C.c_int32), ("debug_flags", C.c_int32), ("row_flags", C.c_void_p),
                 ("gather_done_event", C.c_void_p), ("plan_done_event", C.c_void_p), ("step_scalars", C.c_void_p),
-                ("context", C.c_void_p)]
+                ("context", C.c_void_p), ("id_status", C.c_void_p)]
 
 
 class Graph(C.Structure):
@@ -72,6 +72,7 @@ ADAM_RING = 64          # SCORE_ADAM_RING
 _SIGS = {
     "score_context_create": [C.POINTER(C.c_void_p)],
     "score_context_destroy": [C.c_void_p],
+    "score_id_status": [C.c_void_p, C.POINTER(C.c_int32), C.c_int32, C.c_void_p],
     "score_table_init": [c_f, C.c_int64, C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_uint64, C.c_void_p],
     "score_batch_assemble": [C.POINTER(Graph), c_i, c_i, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                              C.c_int32, C.c_uint64, C.POINTER(BatchOut), C.c_void_p],
@@ -147,7 +148,8 @@ def load():
 
 def check(rc, what):
     if rc != 0:
-        kinds = {-1: "bad argument", -2: "unsupported shape", -3: "workspace too small"}
+        kinds = {-1: "bad argument", -2: "unsupported shape", -3: "workspace too small",
+                 -4: "a feature id outside [0, feature_size) was fed"}
         raise ScoreHipError("%s failed: %s" % (what, kinds.get(rc, "hipError_t %d" % rc)))
 
 

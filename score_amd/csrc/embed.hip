@@ -107,6 +107,20 @@ __global__ __launch_bounds__(256) void coattn_fwd_kernel(const CoattnArgs a) {
       rb[j][k] = i2[kc * F + f[j]];
     }
   }
+  // ids outside the table: read as the dummy row, reported once per lane that saw one (clamped positions repeat real
+  // ids of the tensor, so nothing is reported that the feed does not hold)
+  const uint32_t NR = a.n_rows;
+  bool bad1 = false, bad2 = false;
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k)
+#pragma unroll
+    for (int j = 0; j < SPL; ++j) {
+      const bool b1 = (uint32_t)ra[j][k] >= NR, b2 = (uint32_t)rb[j][k] >= NR;
+      bad1 |= b1; bad2 |= b2;
+      ra[j][k] = b1 ? 0 : ra[j][k];
+      rb[j][k] = b2 ? 0 : rb[j][k];
+    }
+  if (a.id_status && (bad1 || bad2)) atomicOr(a.id_status, (bad1 ? 1 << cc.bit1 : 0) | (bad2 ? 1 << cc.bit2 : 0));
   float4 yv[SPL][KMAX];
 #pragma unroll
   for (int k = 0; k < KMAX; ++k)
@@ -282,6 +296,8 @@ __global__ __launch_bounds__(256, (KMAX <= 10 && SPL == 1) ? 4 : 1) void coattn_
           if (!ok[j] || k >= K) continue;
           if (!ATOMIC) continue;  // pull mode: every row gradient is g itself, nothing to prepare
           int64_t r1 = i1[k * F + f[j]], r2 = i2[k * F + f[j]];
+          r1 = (uint64_t)r1 < a.n_rows ? r1 : 0;
+          r2 = (uint64_t)r2 < a.n_rows ? r2 : 0;
           if (r1 != 0) atomic_add4(gtable + r1 * D + coff[j], g1[j]);
           if (r2 != 0) atomic_add4(gtable + r2 * D + coff[j], g2[j]);
         }
@@ -302,6 +318,8 @@ __global__ __launch_bounds__(256, (KMAX <= 10 && SPL == 1) ? 4 : 1) void coattn_
       for (int j = 0; j < SPL; ++j) {
         r1[j][k] = i1[kc * F + f[j]];
         rb2[j][k] = i2[kc * F + f[j]];
+        r1[j][k] = (uint32_t)r1[j][k] < a.n_rows ? r1[j][k] : 0;      // (the forward reported it: score_state_t.id_status)
+        rb2[j][k] = (uint32_t)rb2[j][k] < a.n_rows ? rb2[j][k] : 0;
       }
     }
 #pragma unroll
@@ -459,6 +477,7 @@ int score_coattn_fwd_multi(CoattnArgs& a, int ncalls, int D, int B, hipStream_t 
   a.D4 = D / 4;
   a.n_units = B * a.T;
   if (a.Tidx <= 0) a.Tidx = a.T;
+  if (a.n_rows == 0) a.n_rows = 0x80000000u;      // (no row count given: int32 ids >= 0 pass)
   for (int c = 0; c < 2; ++c) {
     if (c >= ncalls) { a.c[c] = a.c[0]; a.c[c].first_block = 0x7fffffff; continue; }
     int SPLc;
@@ -482,6 +501,7 @@ int score_coattn_bwd_multi(CoattnArgs& a, int ncalls, int D, int B, float* const
   a.D4 = D / 4;
   a.n_units = B * a.T;
   if (a.Tidx <= 0) a.Tidx = a.T;
+  if (a.n_rows == 0) a.n_rows = 0x80000000u;
   for (int c = 0; c < 2; ++c) {
     if (c >= ncalls) { a.c[c] = a.c[0]; a.c[c].first_block = 0x7fffffff; continue; }
     int SPLc;
@@ -526,7 +546,7 @@ extern "C" int score_coattn_fwd(const float* table, int64_t n_rows, int32_t D, i
   if ((ld1 & 3) || (ld2 & 3)) return SCORE_E_SHAPE;
   CoattnArgs a;
   memset(&a, 0, sizeof(a));
-  a.table = table; a.K = K; a.T = T; a.mode = mode;
+  a.table = table; a.K = K; a.T = T; a.mode = mode; a.n_rows = (uint32_t)(n_rows < 0x80000000ll ? n_rows : 0x80000000ll);
   CoattnCall& c = a.c[0];
   c.idx1 = idx1; c.idx2 = idx2; c.tgt = tgt; c.ldt = F * D; c.W = W; c.bias = bias;
   c.out1 = out1; c.ld1 = ld1; c.out2 = out2; c.ld2 = ld2; c.info = info; c.ldi = ldi; c.rsave = rsave; c.F = F;
@@ -545,6 +565,7 @@ extern "C" int score_coattn_bwd(const float* table, float* grad_table, int64_t n
   CoattnArgs a;
   memset(&a, 0, sizeof(a));
   a.table = table; a.gtable = grad_table; a.K = K; a.T = T; a.mode = mode;
+  a.n_rows = (uint32_t)(n_rows < 0x80000000ll ? n_rows : 0x80000000ll);
   CoattnCall& c = a.c[0];
   c.idx1 = idx1; c.idx2 = idx2; c.W = W; c.rsave = const_cast<float*>(rsave); c.g1 = g1; c.ld1 = ld1; c.g2 = g2; c.ld2 = ld2;
   c.ginfo = ginfo; c.ldi = ldi; c.dzsum = dzsum; c.F = F;
@@ -556,7 +577,7 @@ extern "C" int score_coattn_bwd(const float* table, float* grad_table, int64_t n
 __global__ void target_fwd_kernel(const float* __restrict__ table, int D4, int Fu, int Fi, int B,
                                   const int32_t* __restrict__ tu, const int32_t* __restrict__ ti,
                                   float* __restrict__ query, int ldq, float* __restrict__ head, int ldh,
-                                  int off_ti, int off_tu) {
+                                  int off_ti, int off_tu, uint32_t n_rows, int32_t* __restrict__ id_status) {
   const int cu = Fu * D4, ci = Fi * D4;
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (int64_t)B * (cu + ci)) return;
@@ -564,13 +585,23 @@ __global__ void target_fwd_kernel(const float* __restrict__ table, int D4, int F
   int s = (int)(i - (int64_t)b * (cu + ci));
   if (s < cu) {  // target_user slot
     int fidx = s / D4, c = s - fidx * D4;
-    float4 v = ld4(table + ((int64_t)tu[b * Fu + fidx] * D4 + c) * 4);
+    uint32_t row = (uint32_t)tu[b * Fu + fidx];
+    if (row >= n_rows) {        // outside the table: the dummy row, reported (bit 4 = target_user)
+      row = 0;
+      if (id_status && c == 0) atomicOr(id_status, 1 << 4);
+    }
+    float4 v = ld4(table + ((int64_t)row * D4 + c) * 4);
     if (query) st4(query + (int64_t)b * ldq + s * 4, v);
     st4(head + (int64_t)b * ldh + off_tu + s * 4, v);
   } else {
     int s2 = s - cu;
     int fidx = s2 / D4, c = s2 - fidx * D4;
-    float4 v = ld4(table + ((int64_t)ti[b * Fi + fidx] * D4 + c) * 4);
+    uint32_t row = (uint32_t)ti[b * Fi + fidx];
+    if (row >= n_rows) {        // (bit 5 = target_item)
+      row = 0;
+      if (id_status && c == 0) atomicOr(id_status, 1 << 5);
+    }
+    float4 v = ld4(table + ((int64_t)row * D4 + c) * 4);
     if (query) st4(query + (int64_t)b * ldq + cu * 4 + s2 * 4, v);
     st4(head + (int64_t)b * ldh + off_ti + s2 * 4, v);
   }
@@ -578,10 +609,11 @@ __global__ void target_fwd_kernel(const float* __restrict__ table, int D4, int F
 
 int score_launch_target_fwd(const float* table, int D, int Fu, int Fi, int B, const int32_t* tu,
                             const int32_t* ti, float* query, int ldq, float* head, int ldh, int off_ti,
-                            int off_tu, hipStream_t s) {
+                            int off_tu, hipStream_t s, int64_t n_rows, int32_t* id_status) {
   int64_t n = (int64_t)B * (Fu + Fi) * (D / 4);
+  const uint32_t nr = (n_rows <= 0 || n_rows > 0x80000000ll) ? 0x80000000u : (uint32_t)n_rows;
   hipLaunchKernelGGL(target_fwd_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, s, table, D / 4, Fu, Fi, B,
-                     tu, ti, query, ldq, head, ldh, off_ti, off_tu);
+                     tu, ti, query, ldq, head, ldh, off_ti, off_tu, nr, id_status);
   SCORE_CHECK_LAUNCH();
   return 0;
 }
@@ -597,7 +629,7 @@ __global__ void target_bwd_kernel(float* __restrict__ gtable, int D4, int Fu, in
                                   int ldh, int off_ti, int off_tu, const float* __restrict__ W1,
                                   const float* __restrict__ W2, const float* __restrict__ dz1,
                                   const float* __restrict__ dz2, float* __restrict__ S,
-                                  float* __restrict__ dtgt) {
+                                  float* __restrict__ dtgt, uint32_t n_rows) {
   const int cu = Fu * D4, ci = Fi * D4;
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (int64_t)B * (cu + ci)) return;
@@ -633,7 +665,7 @@ __global__ void target_bwd_kernel(float* __restrict__ gtable, int D4, int Fu, in
   }
   if (dtgt) {  // pull mode: hand the [B, Du+Di] row gradients to the sorted scatter
     st4(dtgt + (int64_t)b * (cu + ci) * 4 + s * 4, g);
-  } else if (row != 0) {
+  } else if (row != 0 && (uint64_t)row < n_rows) {      // (an id outside the table was read as the dummy row)
     atomic_add4(gtable + (row * D4 + c) * 4, g);
   }
 }
@@ -643,12 +675,13 @@ int score_launch_target_bwd(float* grad_table, int D, int Fu, int Fi, int B, int
                             int off_ti, int off_tu, const float* query, const float* W1, const float* W2,
                             const float* dzsum1, const float* dzsum2, float* S, float* dW1, float* dB1,
                             float* dW2, float* dB2, float* dtgt_out, float* scratch, int64_t scratch_floats,
-                            ColsumJobs* cq, GemmQueue* gq, hipStream_t s) {
+                            ColsumJobs* cq, GemmQueue* gq, hipStream_t s, int64_t n_rows) {
   const bool coattn = W1 != nullptr;
   int64_t n = (int64_t)B * (Fu + Fi) * (D / 4);
   hipLaunchKernelGGL(target_bwd_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, s, grad_table, D / 4, Fu,
                      Fi, B, T, tu, ti, dquery, ldq, dhead, ldh, off_ti, off_tu, W1, W2, dzsum1, dzsum2,
-                     coattn ? S : nullptr, dtgt_out);
+                     coattn ? S : nullptr, dtgt_out,
+                     (n_rows <= 0 || n_rows > 0x80000000ll) ? 0x80000000u : (uint32_t)n_rows);
   SCORE_CHECK_LAUNCH();
   if (coattn) {
     // dW_t = tgt^T S (call 0 targets the item: query cols Du.., call 1 the user: cols 0..), dbias = sum_b S

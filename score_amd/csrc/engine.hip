@@ -332,6 +332,20 @@ extern "C" int score_context_destroy(void* ctx) {
   return 0;
 }
 
+extern "C" int score_id_status(int32_t* id_status, int32_t* bits, int32_t clear, void* stream) {
+  if (!id_status) return SCORE_E_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  int32_t host = 0;
+  HIPTRY(hipMemcpyAsync(&host, id_status, sizeof(host), hipMemcpyDeviceToHost, s));
+  HIPTRY(hipStreamSynchronize(s));
+  if (host && clear) {
+    HIPTRY(hipMemsetAsync(id_status, 0, sizeof(host), s));
+    HIPTRY(hipStreamSynchronize(s));
+  }
+  if (bits) *bits = host;
+  return host ? SCORE_E_INDEX : 0;
+}
+
 extern "C" int score_param_layout(const score_config_t* cfg, score_param_entry_t* out, int32_t max_entries,
                                   int64_t* n_floats, int64_t* n_reg_floats) {
   Dims d;
@@ -384,6 +398,7 @@ extern "C" int score_index_plan(const score_config_t* cfg, const score_state_t* 
     off += (g < 4 ? (int64_t)BT * d.K : (int64_t)B) * Fs[g];
   }
   pf.off[6] = off; pf.K = d.K; pf.G = n_shards; pf.T = d.T; pf.TA = TA;
+  pf.n_rows = (uint32_t)(d.N < 0x80000000ll ? d.N : 0x80000000ll); pf.id_status = st->id_status;
   // key = row (1 shard) or (owner = row % G) << shift | (row / G)
   const int64_t rows_local = cdiv64(d.N, n_shards);
   int shift = 1;
@@ -438,7 +453,7 @@ extern "C" int score_forward(const score_config_t* cfg, const score_state_t* st,
 
   // target rows -> query [tu | ti] and head_inp [.., ti, tu]      (score.py:62-66, 210, 217)
   G(score_launch_target_fwd(st->table, d.D, d.Fu, d.Fi, B, bt->target_user, bt->target_item, ws + w.query, d.Dq,
-                            ws + w.head_inp, d.Dhead, d.off_ti, d.off_tu, s));
+                            ws + w.head_inp, d.Dhead, d.off_ti, d.off_tu, s, st->n_table_rows, st->id_status));
   // side stream: the L2 norm of the weights (needs no batch), then the attention's query branch (target rows and
   // weights only) -- beside the gather and the GRUs
   SideStream* sd = nullptr;
@@ -471,6 +486,8 @@ extern "C" int score_forward(const score_config_t* cfg, const score_state_t* st,
     CoattnArgs ca;
     memset(&ca, 0, sizeof(ca));
     ca.table = st->table; ca.K = d.K; ca.T = T; ca.Tidx = d.T; ca.mode = d.coattn ? 0 : 1;
+    ca.n_rows = (uint32_t)(st->n_table_rows < 0x80000000ll ? st->n_table_rows : 0x80000000ll); ca.id_status = st->id_status;
+    ca.c[0].bit1 = 0; ca.c[0].bit2 = 3; ca.c[1].bit1 = 1; ca.c[1].bit2 = 2;      // positions in the feed tuple (graph_loader.py:383)
     const int ldi = 4 * d.K;
     CoattnCall& c0 = ca.c[0];
     c0.idx1 = bt->user_1hop; c0.idx2 = bt->item_2hop; c0.tgt = ws + w.query + d.Du; c0.ldt = d.Dq;
@@ -569,7 +586,7 @@ extern "C" int score_forward(const score_config_t* cfg, const score_state_t* st,
                                               st->step_scalars ? &st->step_scalars->drop_seed : nullptr, ws + w.dz2,
                                               (st->debug_flags & 2) ? 1 : 0);
   if (hrc == 0) {
-    G(score_launch_loss_final(B, ws + w.lossb, ws + w.loss, reg_lambda, ws + w.part, Bg, s));    // (dz2 came with the head)
+    G(score_launch_loss_final(B, ws + w.lossb, ws + w.loss, reg_lambda, ws + w.part, Bg, s, st->id_status));    // (dz2 came with the head)
   } else if (hrc == SCORE_E_SHAPE) {
     if (st->step_scalars && keep_prob < 1.f) return SCORE_E_SHAPE;   // the layer-by-layer path takes its seed by value
     G(score_launch_bn_fwd(B, d.Dhead, ws + w.head_inp, W + P.bn_g, W + P.bn_b, rs, ws + w.bn, s));
@@ -580,7 +597,7 @@ extern "C" int score_forward(const score_config_t* cfg, const score_state_t* st,
                  w.scratch_floats, s));
     // fc3, sigmoid, log-loss, l2 (:74-94)
     G(score_launch_head_out(B, FC2, ws + w.f2, W + P.fc_w[2], W + P.fc_b[2], bt->label, ws + w.logit, ws + w.y_pred,
-                            ws + w.lossb, ws + w.dlogit, ws + w.loss, reg_lambda, ws + w.part, Bg, s));
+                            ws + w.lossb, ws + w.dlogit, ws + w.loss, reg_lambda, ws + w.part, Bg, s, st->id_status));
   } else {
     return hrc;
   }
@@ -818,6 +835,7 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
     CoattnArgs ca;
     memset(&ca, 0, sizeof(ca));
     ca.table = st->table; ca.gtable = grad_table; ca.K = d.K; ca.T = T; ca.Tidx = d.T; ca.mode = d.coattn ? 0 : 1;
+    ca.n_rows = (uint32_t)(st->n_table_rows < 0x80000000ll ? st->n_table_rows : 0x80000000ll);
     const int ldi = 4 * d.K;
     CoattnCall& c0 = ca.c[0];
     c0.idx1 = bt->user_1hop; c0.idx2 = bt->item_2hop; c0.W = d.coattn ? W + P.ca_w[0] : nullptr;
@@ -840,7 +858,7 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
                             ws + w.dzsum[0], ws + w.dzsum[1], ws + w.S, d.coattn ? gw + P.ca_w[0] : nullptr,
                             d.coattn ? gw + P.ca_b[0] : nullptr, d.coattn ? gw + P.ca_w[1] : nullptr,
                             d.coattn ? gw + P.ca_b[1] : nullptr, atomic ? nullptr : ws + w.dtgt, scratch, SF, &cq, &gq,
-                            s));
+                            s, st->n_table_rows));
   if (!atomic) {
     if (st->plan_done_event) HIPTRY(hipStreamWaitEvent(s, (hipEvent_t)st->plan_done_event, 0));
     PullArgs pa;

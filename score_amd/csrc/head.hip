@@ -470,7 +470,8 @@ int score_launch_l2_partials(const float* wreg, int64_t n_reg, float* part /* L2
 // (fixed-order tree sums: reproducible)
 __global__ __launch_bounds__(256) void loss_final_kernel(const float* __restrict__ lossb, int64_t B, float scale,
                                                          const float* __restrict__ part, float lambda,
-                                                         float* __restrict__ loss) {
+                                                         float* __restrict__ loss,
+                                                         const int32_t* __restrict__ id_status) {
   __shared__ float sh[256], sp[256];
   float s = 0.f;
   for (int64_t i = threadIdx.x; i < B; i += 256) s += lossb[i];
@@ -485,28 +486,33 @@ __global__ __launch_bounds__(256) void loss_final_kernel(const float* __restrict
     loss[1] = sh[0] * scale;
     loss[2] = 0.5f * sp[0];
     loss[0] = loss[1] + lambda * loss[2];
+    // an id outside the table (score_state_t.id_status; tf.nn.embedding_lookup raises there, score.py:51-66): the loss
+    // of the step is poisoned so that whoever reads it learns of it without a second read-back; the bits ride in loss[3]
+    const int32_t bad = id_status ? *id_status : 0;
+    loss[3] = (float)bad;
+    if (bad) loss[0] = loss[1] = __int_as_float(0x7fc00000);
   }
 }
 
 int score_launch_head_out(int B, int NF, const float* f2, const float* w3, const float* b3, const int32_t* label,
                           float* logit, float* y, float* lossb, float* dlogit, float* loss, float lambda,
                           const float* part /* L2_PARTS sums of squares from score_launch_l2_partials */, int Bglobal,
-                          hipStream_t s) {
+                          hipStream_t s, const int32_t* id_status) {
   // Bglobal = samples the mean is taken over (the local batch, or the global batch when data-parallel)
   hipLaunchKernelGGL(head_out_kernel, dim3((B + 63) / 64), dim3(64), 0, s, B, NF, f2, w3, b3, label, logit, y,
                      lossb, dlogit, Bglobal);
   SCORE_CHECK_LAUNCH();
   hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, s, lossb, (int64_t)B, 1.0f / (float)Bglobal, part, lambda,
-                     loss);
+                     loss, id_status);
   SCORE_CHECK_LAUNCH();
   return 0;
 }
 
 // the loss reduction alone (the fused head kernel has already written lossb)
 int score_launch_loss_final(int B, const float* lossb, float* loss, float lambda, const float* part, int Bglobal,
-                            hipStream_t s) {
+                            hipStream_t s, const int32_t* id_status) {
   hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, s, lossb, (int64_t)B, 1.0f / (float)Bglobal, part, lambda,
-                     loss);
+                     loss, id_status);
   SCORE_CHECK_LAUNCH();
   return 0;
 }

@@ -45,25 +45,30 @@ struct CoattnCall {
   float* dzsum; float* slab;
   float* pcoef; float* dzcoef;                // backward, pull mode: softmax p_i and dz_i per (unit, i)
   int F, GS, nslots, first_block;
+  int bit1, bit2;                             // bits of *CoattnArgs.id_status that name idx1 / idx2 (position in the feed tuple)
 };
 struct CoattnArgs {
   CoattnCall c[2];
   const float* table; float* gtable;
   int D4, K, T, n_units, mode;
   int Tidx;                                   // time stride of the index tensors ([B, Tidx, K, F]); 0 = T.  T = slices computed
+  // ids outside [0, n_rows) (tf.nn.embedding_lookup raises there, score.py:51-66) are read as the dummy row 0 and
+  // reported: bit1 / bit2 of the call OR-ed into *id_status (optional device word, score_state_t.id_status)
+  uint32_t n_rows; int32_t* id_status;
 };
 int score_coattn_fwd_multi(CoattnArgs& a, int ncalls, int D, int B, hipStream_t s);
 int score_coattn_bwd_multi(CoattnArgs& a, int ncalls, int D, int B, float* const dW[2], float* scratch,
                            int64_t scratch_floats, int atomic_scatter, ColsumJobs* cq, hipStream_t s);
 int score_launch_target_fwd(const float* table, int D, int Fu, int Fi, int B, const int32_t* tu,
                             const int32_t* ti, float* query, int ldq, float* head, int ldh,
-                            int off_ti, int off_tu, hipStream_t s);
+                            int off_ti, int off_tu, hipStream_t s, int64_t n_rows = 0, int32_t* id_status = nullptr);
 int score_launch_target_bwd(float* grad_table, int D, int Fu, int Fi, int B, int T, const int32_t* tu,
                             const int32_t* ti, const float* dquery, int ldq, const float* dhead, int ldh,
                             int off_ti, int off_tu, const float* query, const float* W1, const float* W2,
                             const float* dzsum1, const float* dzsum2, float* S /*[2][B]*/,
                             float* dW1, float* dB1, float* dW2, float* dB2, float* dtgt_out, float* scratch,
-                            int64_t scratch_floats, ColsumJobs* cq, struct GemmQueue* gq, hipStream_t s);
+                            int64_t scratch_floats, ColsumJobs* cq, struct GemmQueue* gq, hipStream_t s,
+                            int64_t n_rows = 0);
 // head.hip
 int score_launch_attn_build_inp(int B, int T, int H, int NI, const float* q, const float* ur, const float* ir,
                                 const float* info, float* inp, hipStream_t s);
@@ -102,9 +107,9 @@ int score_launch_bn_bwd(int B, int Dh, const float* x, const float* gamma, float
 int score_launch_l2_partials(const float* wreg, int64_t n_reg, float* part /* 256 floats */, hipStream_t s);
 int score_launch_head_out(int B, int NF, const float* f2, const float* w3, const float* b3, const int32_t* label,
                           float* logit, float* y, float* lossb, float* dlogit, float* loss, float lambda,
-                          const float* part, int Bglobal, hipStream_t s);
+                          const float* part, int Bglobal, hipStream_t s, const int32_t* id_status = nullptr);
 int score_launch_loss_final(int B, const float* lossb, float* loss, float lambda, const float* part, int Bglobal,
-                            hipStream_t s);
+                            hipStream_t s, const int32_t* id_status = nullptr);
 // head_fused.hip: bn1 + fc1 + fc2 + fc3 + sigmoid + loss terms in one launch (SCORE_E_SHAPE: shape not covered)
 int score_launch_head_fwd_fused(int B, int Dh, int N1, int N2, const float* x, const float* gamma, const float* beta,
                                 float rs, const float* W1, const float* b1, const float* W2, const float* b2,
@@ -136,6 +141,8 @@ struct PlanFillArgs {
   int F[6];
   int K, G, shift;         // G > 1: key = (row % G) << shift | row / G
   int T, TA;               // index tensors are [B, T, K, F]; only slices t < TA are enumerated (bt = b * TA + t)
+  uint32_t n_rows;         // ids >= n_rows (feature_size) become the dummy row 0 and are reported in *id_status
+  int32_t* id_status;      // optional device word (score_state_t.id_status)
 };
 struct PullArgs {
   const float* G[6]; int ldg[6]; int gcol[6];     // activation-gradient matrix per segment

@@ -53,6 +53,10 @@ __global__ void plan_fill_kernel(PlanFillArgs a, uint32_t* __restrict__ keys, ui
     k = 0;
   }
   uint32_t row = (uint32_t)a.idx[seg][local];
+  if (row >= a.n_rows) {     // outside the table (tf.nn.embedding_lookup raises, score.py:51-66): the dummy row, reported
+    row = 0;
+    if (a.id_status) atomicOr(a.id_status, 1 << ((0x542130 >> (4 * seg)) & 15));   // segment -> position in the feed tuple
+  }
   uint32_t key = row;
   if (a.G > 1) key = ((row % a.G) << a.shift) | (row / a.G);   // (owner, local row)
   keys[i] = key;

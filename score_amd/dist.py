@@ -291,7 +291,8 @@ class HipBackend(object):
         lay, ws = plan["lay"], plan["ws"]
         return lay, ws, _lib.State(table=_ptr(mini), n_table_rows=mini.shape[0], w=_ptr(m.w), workspace=_ptr(ws),
                                    workspace_bytes=ws.numel() * 4, scatter_mode=2, global_batch=int(m.global_batch),
-                                   gemm_mode=int(m.gemm_mode), debug_flags=int(m.debug_flags), context=m._ctx)
+                                   gemm_mode=int(m.gemm_mode), debug_flags=int(m.debug_flags), context=m._ctx,
+                                   id_status=_ptr(m._id_status))     # (set by this batch's score_index_plan)
 
     def forward(self, plan, mini, reg_lambda, keep_prob, masks):
         m = self.m
@@ -657,7 +658,37 @@ class ShardedSCORE(object):
         return loss[1] + float(reg_lambda) * loss[2]
 
     def train(self, sess, batch_data, lr, reg_lambda, keep_prob=0.8, dropout_masks=None, next_batch=None):
-        return float(self.train_async(batch_data, lr, reg_lambda, keep_prob, dropout_masks, next_batch).item())
+        loss = float(self.train_async(batch_data, lr, reg_lambda, keep_prob, dropout_masks, next_batch).item())
+        if loss != loss:
+            self.check_ids()
+        return loss
+
+    def check_ids(self, collective=True):
+        """ValueError on EVERY rank if any rank fed an id outside [0, feature_size) (SCOREBASE.check_ids; the index
+        plan of the offending batch reported it and routed the id to the dummy row).  The global loss is NaN on
+        all ranks then (it is all-reduced), so all of them arrive here together: one small all-reduce of the
+        status words keeps them in step.  collective=False checks the local word only."""
+        m = getattr(self.backend, "m", None)
+        if m is None:
+            return
+        word = m._id_status.clone()
+        if collective and self.world > 1:
+            w64 = word.to(torch.int64) << (6 * self.rank) if self.world <= 10 else word.to(torch.int64)
+            self.comm.all_reduce_sum(w64)          # disjoint bit fields per rank: the sum is their union
+            allbits = int(w64.item())
+        else:
+            allbits = int(word.item()) << (6 * self.rank if self.world <= 10 else 0)
+        if allbits:
+            m._id_status.zero_()
+            from .model import BATCH_FIELDS
+            msgs = []
+            for r in range(self.world if self.world <= 10 else 1):
+                b = allbits >> (6 * r) & 63
+                if b:
+                    msgs.append("rank %d: %s" % (r, ", ".join("batch_data[%d] (%s)" % (i, BATCH_FIELDS[i])
+                                                                for i in range(6) if b >> i & 1)))
+            raise ValueError("feature id outside [0, %d) -- %s (tf.nn.embedding_lookup would raise: score.py:51-66)"
+                             % (m.N_global, "; ".join(msgs) or "some rank"))
 
     # -- checkpoint (score.py:135-142), one file per rank ---------------------------------------
     def _shard_path(self, path):
@@ -696,4 +727,7 @@ class ShardedSCORE(object):
         pred = fw["y_pred"].cpu().numpy().reshape([-1, ]).tolist()
         label = be.labels(plan).cpu().numpy().reshape([-1, ]).tolist()
         loss = fw["loss"]
-        return pred, label, float((loss[1] + float(reg_lambda) * loss[2]).item())
+        val = float((loss[1] + float(reg_lambda) * loss[2]).item())
+        if val != val:
+            self.check_ids(collective=False)      # (eval reports the local batch's loss: only this rank knows)
+        return pred, label, val

@@ -183,6 +183,8 @@ class SCOREBASE(object):
         self._side = None
         self.skip_masked_slices = True   # batches carry active_slices = max(length): slices every sample masks are skipped
         # per-step scalars in device memory (score_step_scalars_t): what a captured step reads its alpha / dropout seed from
+        # sticky device word the kernels OR a bit into when a fed id lies outside the table (score_state_t.id_status)
+        self._id_status = torch.zeros((1,), dtype=torch.int32, device=self.device)
         self._scalars = torch.zeros((4,), dtype=torch.int32, device=self.device)
         self._scalars_host = torch.zeros((4,), dtype=torch.int32).pin_memory()
         self._use_dev_scalars = False
@@ -378,7 +380,8 @@ class SCOREBASE(object):
                           global_batch=int(self.global_batch), gemm_mode=int(self.gemm_mode),
                           debug_flags=int(self.debug_flags),
                           row_flags=_ptr(self.table_flags) if self.scatter_mode == 0 else None,
-                          step_scalars=_ptr(self._scalars) if self._use_dev_scalars else None, context=self._ctx)
+                          step_scalars=_ptr(self._scalars) if self._use_dev_scalars else None, context=self._ctx,
+                          id_status=_ptr(self._id_status))
 
     @staticmethod
     def _event_array(events):
@@ -740,7 +743,24 @@ class SCOREBASE(object):
 
     # ------------------------------------------------------------------ reference interface
     def train(self, sess, batch_data, lr, reg_lambda, keep_prob=0.8, dropout_masks=None):
-        return float(self.train_async(batch_data, lr, reg_lambda, keep_prob, dropout_masks).item())
+        loss = float(self.train_async(batch_data, lr, reg_lambda, keep_prob, dropout_masks).item())
+        if loss != loss:
+            self.check_ids()
+        return loss
+
+    def check_ids(self):
+        """Raises ValueError if any batch fed since the last call held a feature id outside [0, feature_size) --
+        where tf.nn.embedding_lookup raises InvalidArgumentError (score.py:51-66).  The kernels that read the ids
+        report into a sticky device word (score_state_t.id_status) and treat such an id as the dummy row 0, so
+        nothing is ever read or written out of bounds; the loss of such a step is NaN, which is how train() / eval()
+        learn of it without an extra read-back.  Callers of train_async / eval_async call this at their own sync
+        points.  The offending step has been applied with those ids read as padding."""
+        bits = int(self._id_status.item())
+        if bits:
+            self._id_status.zero_()
+            names = ["batch_data[%d] (%s)" % (i, BATCH_FIELDS[i]) for i in range(6) if bits >> i & 1]
+            raise ValueError("feature id outside [0, %d) in %s (tf.nn.embedding_lookup would raise: score.py:51-66)"
+                             % (int(self.cfg.feature_size), ", ".join(names)))
 
     def eval_async(self, batch_data, reg_lambda):
         """eval without the host round trip: (y_pred [B] device view of the workspace -- copy it before the next
@@ -756,6 +776,8 @@ class SCOREBASE(object):
         pred = ws[lay.y_pred:lay.y_pred + B].cpu().numpy()
         label = db.tensors[6].cpu().numpy()
         loss = float(ws[lay.loss].item())
+        if loss != loss:
+            self.check_ids()
         return pred.reshape([-1, ]).tolist(), label.reshape([-1, ]).tolist(), loss
 
     def save(self, sess, path):

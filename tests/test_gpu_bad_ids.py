@@ -1,0 +1,148 @@
+"""Feature ids outside [0, feature_size): tf.nn.embedding_lookup raises on the reference's CPU path (score.py:51-66).
+Here every kernel that turns an id into an address reads such an id as the dummy row (no out-of-bounds access), the
+kernels that see the ids as fed report the tensor in a sticky device word (score_state_t.id_status) and the step's
+loss is NaN, so train() / eval() raise ValueError naming the tensor -- without an extra launch or read-back on the
+good path."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from helpers import NAMES, batch_tuple, random_batch      # noqa: E402
+from oracle import score_oracle as so                      # noqa: E402
+
+CFG = (3001, 16, 32, 6, 5, 3, 4)
+
+
+def _model(mt="SCORE"):
+    from score_amd.model import MODELS
+    return MODELS[mt](*CFG)
+
+
+@pytest.mark.parametrize("bad", [3001, -1, 2 ** 31 - 1])
+@pytest.mark.parametrize("which", range(6))
+def test_train_and_eval_raise_naming_the_tensor(which, bad):
+    cfg = so.Cfg(*CFG, model_type="SCORE")
+    m = _model()
+    rng = np.random.default_rng(which)
+    good = random_batch(rng, cfg, 12)
+    good["length"][:] = cfg.T                       # every slice live: the bad id below is really dereferenced
+    l0 = m.train(None, batch_tuple(good), 1e-3, 1e-4)
+    assert np.isfinite(l0)
+    b = {k: v.copy() for k, v in good.items()}
+    flat = b[NAMES[which]].reshape(-1)
+    flat[len(flat) // 2] = bad
+    with pytest.raises(ValueError) as ei:
+        m.train(None, batch_tuple(b), 1e-3, 1e-4)
+    assert "batch_data[%d] (%s)" % (which, NAMES[which]) in str(ei.value)
+    others = [n for i, n in enumerate(NAMES[:6]) if i != which]
+    assert not any("(%s)" % n in str(ei.value) for n in others)
+    with pytest.raises(ValueError):
+        m.eval(None, batch_tuple(b), 1e-4)
+    # the word is cleared by the raise; the model goes on (the bad id was read as the dummy row: nothing was corrupted)
+    l1 = m.train(None, batch_tuple(good), 1e-3, 1e-4)
+    assert np.isfinite(l1)
+    p, _, le = m.eval(None, batch_tuple(good), 1e-4)
+    assert np.isfinite(le) and np.isfinite(np.asarray(p)).all()
+    assert torch.isfinite(m.table).all() and torch.isfinite(m.w).all()
+
+
+@pytest.mark.parametrize("mt", ["RCA", "RRN", "RIA"])
+def test_other_model_types_raise_too(mt):
+    cfg = so.Cfg(*CFG, model_type=mt)
+    m = _model(mt)
+    b = random_batch(np.random.default_rng(3), cfg, 8)
+    b["length"][:] = cfg.T
+    b["user_1hop"][1, 2, 3, 0] = CFG[0] + 7
+    b["target_item"][0, 1] = -5
+    with pytest.raises(ValueError) as ei:
+        m.train(None, batch_tuple(b), 1e-3, 1e-4)
+    assert "(user_1hop)" in str(ei.value) and "(target_item)" in str(ei.value)
+
+
+def test_bad_id_equals_dummy_row_semantics_and_async_check():
+    """the offending id is read as row 0: the step's predictions equal those of the batch with 0 in its place;
+    train_async / eval_async users query the status themselves"""
+    cfg = so.Cfg(*CFG, model_type="SCORE")
+    m = _model()
+    good = random_batch(np.random.default_rng(9), cfg, 10)
+    good["length"][:] = cfg.T
+    bad = {k: v.copy() for k, v in good.items()}
+    bad["item_1hop"][4, 1, 2, 1] = 10 ** 6
+    zero = {k: v.copy() for k, v in good.items()}
+    zero["item_1hop"][4, 1, 2, 1] = 0
+    pz, _, _ = m.eval(None, batch_tuple(zero), 1e-4)
+    yb, _, lb = m.eval_async(batch_tuple(bad), 1e-4)
+    yb = yb.clone()
+    assert torch.isnan(lb)
+    with pytest.raises(ValueError) as ei:
+        m.check_ids()
+    assert "(item_1hop)" in str(ei.value)
+    m.check_ids()                                   # cleared
+    assert np.array_equal(yb.cpu().numpy(), np.asarray(pz, dtype=np.float32))
+    # the C-ABI's synchronous query
+    from score_amd import _lib
+    m.eval_async(batch_tuple(bad), 1e-4)
+    bits = C.c_int32(0)
+    rc = m.lib.score_id_status(C.c_void_p(m._id_status.data_ptr()), C.byref(bits), 1, m._stream())
+    assert rc == -4 and bits.value == 1 << 2
+    assert m.lib.score_id_status(C.c_void_p(m._id_status.data_ptr()), C.byref(bits), 1, m._stream()) == 0 and bits.value == 0
+    with pytest.raises(_lib.ScoreHipError):
+        _lib.check(-4, "score_id_status")
+
+
+def test_masked_slices_are_not_dereferenced():
+    """ids of slices every sample masks (t >= max length) are never turned into addresses: garbage there is harmless
+    and -- documented in include/score_hip.h -- not reported"""
+    cfg = so.Cfg(*CFG, model_type="SCORE")
+    m = _model()
+    b = random_batch(np.random.default_rng(5), cfg, 8)
+    b["length"][:] = 3
+    ref = m.eval(None, batch_tuple(b), 1e-4)[0]
+    b2 = {k: v.copy() for k, v in b.items()}
+    b2["user_2hop"][:, 4:, :, :] = 2 ** 30
+    assert m.eval(None, batch_tuple(b2), 1e-4)[0] == ref
+    assert np.isfinite(m.train(None, batch_tuple(b2), 1e-3, 1e-4))
+
+
+def test_tiled_optimizer_and_sharded_plan_report():
+    """the time-tiled table optimizer's id scan ignores such ids; the sharded path's index plan reports them (its
+    forward only sees unique positions) and routes them to the dummy row"""
+    from score_amd.dist import ShardedSCORE
+    cfg = so.Cfg(*CFG, model_type="SCORE")
+    m = _model()
+    m.adam_tiled_min_bytes = 0
+    good = random_batch(np.random.default_rng(11), cfg, 10)
+    good["length"][:] = cfg.T
+    bad = {k: v.copy() for k, v in good.items()}
+    bad["user_1hop"][0, 0, 0, 0] = CFG[0]
+    for _ in range(3):
+        m.train(None, batch_tuple(good), 1e-3, 1e-4)
+    with pytest.raises(ValueError):
+        m.train(None, batch_tuple(bad), 1e-3, 1e-4)
+    assert np.isfinite(m.train(None, batch_tuple(good), 1e-3, 1e-4)) and torch.isfinite(m.table).all()
+
+    class OneRank(object):           # a one-rank communicator without a process group
+        rank, world = 0, 1
+
+        def exchange_counts(self, send, device, extra=None):
+            return (list(send), [extra]) if extra is not None else list(send)
+
+        def all_to_all(self, out, inp, out_splits, in_splits):
+            out.copy_(inp)
+
+        def all_reduce_sum(self, t):
+            pass
+    s = ShardedSCORE(*CFG, comm=OneRank())
+    assert np.isfinite(s.train(None, batch_tuple(good), 1e-3, 1e-4))
+    with pytest.raises(ValueError) as ei:
+        s.train(None, batch_tuple(bad), 1e-3, 1e-4)
+    assert "(user_1hop)" in str(ei.value) and "rank 0" in str(ei.value)
+    assert np.isfinite(s.train(None, batch_tuple(good), 1e-3, 1e-4))
