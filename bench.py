@@ -530,20 +530,41 @@ def main():
                 n_ing += 1
             torch.cuda.synchronize()
             s_ing = (time.perf_counter() - t) / n_ing
-            nested = world.batch(B, 77, as_lists=True)
+            nested3 = [world.batch(B, 77 + i, as_lists=True) for i in range(3)]
+            nested = nested3[0]
             model.train(None, nested, args.lr, args.reg_lambda)
             t = time.perf_counter()
-            for _ in range(2):
-                model.train(None, nested, args.lr, args.reg_lambda)
-            s_nested = (time.perf_counter() - t) / 2
+            for i in range(6):
+                model.train(None, nested3[i % 3], args.lr, args.reg_lambda)
+            s_nested = (time.perf_counter() - t) / 6
+            # the same tuples through SCOREBASE.feed: converted and uploaded one or two batches ahead on a worker thread
+            n_feed = 24
+            t = time.perf_counter()
+            for db_ in model.feed((nested3[i % 3] for i in range(n_feed))):
+                model.train(None, db_, args.lr, args.reg_lambda)
+            s_feed = (time.perf_counter() - t) / n_feed
+            ft = model.feed_threads
+            model.feed_threads = 1
+            t = time.perf_counter()
+            for i in range(3):
+                model.train(None, nested3[i % 3], args.lr, args.reg_lambda)
+            s_nested_1t = (time.perf_counter() - t) / 3
+            model.feed_threads = ft
+            del nested3
             side["ingestion"] = {
                 "device_assembly_samples_per_s": B / s_ing, "device_assembly_ms_per_step": s_ing * 1e3, "steps": n_ing,
                 "what": "DeviceGraphLoader (score_batch_assemble: CSR graph in HBM -> the eight int32 tensors, one launch per "
                         "batch) + SCORE.train_async inside the timed loop; synthetic graph over the config's id space",
                 "nested_python_lists_samples_per_s": B / s_nested, "nested_python_lists_ms_per_step": s_nested * 1e3,
                 "nested_what": "model.train(sess, batch_data, ...) fed the 8-tuple of nested Python lists exactly as "
-                               "GraphLoader yields it (graph_loader.py:383): list -> int32 conversion + H2D copy + step; "
-                               "host-bound, never `value`"}
+                               "GraphLoader yields it (graph_loader.py:383), one synchronous call after the other: list -> "
+                               "int32 conversion (%d native threads without the GIL, pinned staging) + H2D copy + step + "
+                               "loss read-back; host-bound, never `value`" % ft,
+                "nested_python_lists_feed_ahead_samples_per_s": B / s_feed,
+                "nested_python_lists_feed_ahead_ms_per_step": s_feed * 1e3,
+                "feed_ahead_what": "for b in model.feed(loader): model.train(sess, b, ...) -- the same tuples converted and "
+                                   "uploaded by a worker thread one or two batches ahead, under the running step",
+                "nested_python_lists_single_thread_samples_per_s": B / s_nested_1t, "feed_threads": ft}
             del g, loader
         except Exception as e:
             side["ingestion"] = {"error": repr(e)}

@@ -47,8 +47,12 @@ def build(force=False, verbose=False):
             sys.stderr.write(out.decode())
             raise RuntimeError("hipcc failed on %s" % src)
     if force or procs or _stale(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        # linked under a private name and renamed into place: another rank starting at the same moment (mp.spawn,
+        # torchrun) either sees no file yet or a complete one, never a half-written .so
+        tmp = "%s.%d.tmp" % (LIB, os.getpid())
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs
         subprocess.check_call(cmd)
+        os.replace(tmp, LIB)
     build_listpack(force)
     return LIB
 
@@ -60,8 +64,10 @@ def build_listpack(force=False):
     out = os.path.join(LIBDIR, "_listpack.so")
     os.makedirs(LIBDIR, exist_ok=True)
     if force or _stale(out, [src]):
-        subprocess.check_call([os.environ.get("CC", "gcc"), "-O2", "-shared", "-fPIC", "-I" + sysconfig.get_paths()["include"],
-                               src, "-o", out])
+        tmp = "%s.%d.tmp" % (out, os.getpid())          # (atomic, as above: several ranks may get here together)
+        subprocess.check_call([os.environ.get("CC", "gcc"), "-O2", "-shared", "-fPIC", "-pthread",
+                               "-I" + sysconfig.get_paths()["include"], src, "-o", tmp])
+        os.replace(tmp, out)
     return out
 
 

@@ -466,6 +466,11 @@ class ShardedSCORE(object):
     def device_batch(self, batch_data):
         return self.backend.m.device_batch(batch_data) if hasattr(self.backend, "m") else batch_data
 
+    def feed(self, batches, depth=2):
+        """SCOREBASE.feed: the host conversion of the next feed tuples on a worker thread, one or two batches ahead"""
+        m = getattr(self.backend, "m", None)
+        return m.feed(batches, depth) if m is not None else iter(batches)
+
     def enable_stage_events(self, on=True):
         self.backend.m.enable_stage_events(on)
 

@@ -81,7 +81,7 @@ TRAIN_NEG_SAMPLE_NUM = 1          # train_score.py:18
 
 
 def train_loop(model, train_batches, vali_batches, lr, reg_lambda, train_batch_size, dataset_size, sess=None,
-               epochs=6, save_path=None, evaluate_fn=None, neg_sample_num=TEST_NEG_SAMPLE_NUM, log=print):
+               epochs=6, save_path=None, evaluate_fn=None, neg_sample_num=TEST_NEG_SAMPLE_NUM, log=print, feed_ahead=True):
     """The training loop train_score.py:165-275 wraps around model.train / model.eval, rule for rule:
 
       * one evaluation before the first step (:205);
@@ -105,8 +105,26 @@ def train_loop(model, train_batches, vali_batches, lr, reg_lambda, train_batch_s
     curves = dict(train_losses=[], vali_losses=[], vali_ndcgs_5=[], vali_ndcgs_10=[], vali_hrs_1=[], vali_hrs_5=[],
                   vali_hrs_10=[], vali_mrrs=[])
 
+    # A model sharded over several ranks (score_amd.dist.ShardedSCORE): every train / eval call is a collective, so all
+    # ranks must take the same branches.  The validation metrics every rule below looks at are therefore the MEAN over
+    # the ranks (each rank evaluates its own validation shard), and an epoch ends for everybody as soon as any rank's
+    # loader runs out (ranks may hold different numbers of batches); checkpoints are then all from the same step.
+    comm = getattr(model, "comm", None)
+    multi = comm is not None and getattr(comm, "world", 1) > 1
+
+    def across_ranks(values, op="mean"):
+        if not multi:
+            return list(values)
+        import torch
+        dev = getattr(model, "device", "cpu")
+        t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=dev)
+        comm.all_reduce_sum(t)
+        out = t.cpu().tolist()
+        return [v / comm.world for v in out] if op == "mean" else out
+
     def validate():
         _, _, n5, n10, h1, h5, h10, mrr, loss = evaluate_fn(model, vali_batches(), reg_lambda)
+        n5, n10, h1, h5, h10, mrr, loss = across_ranks((n5, n10, h1, h5, h10, mrr, loss))
         for k, v in (("vali_ndcgs_5", n5), ("vali_ndcgs_10", n10), ("vali_hrs_1", h1), ("vali_hrs_5", h5),
                      ("vali_hrs_10", h10), ("vali_mrrs", mrr), ("vali_losses", loss)):
             curves[k].append(v)
@@ -143,10 +161,31 @@ def train_loop(model, train_batches, vali_batches, lr, reg_lambda, train_batch_s
             yield cur, nxt
             cur = nxt
         yield cur, None
+
+    def in_step(pairs):
+        """several ranks: stop together -- a step is taken only if EVERY rank still has a batch for it (one small
+        all-reduce per step, ahead of the step's own collectives); the look-ahead batch is dropped when some rank has
+        none, so nobody prefetches for a step that will not happen"""
+        if not multi:
+            for p in pairs:
+                yield p
+            return
+        it = iter(pairs)
+        while True:
+            p = next(it, None)
+            have = across_ranks((0.0 if p is None else 1.0, 0.0 if (p is None or p[1] is None) else 1.0), op="sum")
+            if have[0] < comm.world:
+                return
+            yield (p[0], p[1] if have[1] == comm.world else None)
     for epoch in range(epochs):
         if early_stop:
             break
-        for batch_data, next_data in with_next(train_batches()):
+        # host feed tuples (nested lists, as GraphLoader yields them) are converted and uploaded a batch or two ahead on a
+        # worker thread (SCOREBASE.feed), under the step that is running
+        source = train_batches()
+        if hasattr(model, "feed") and feed_ahead:
+            source = model.feed(source)
+        for batch_data, next_data in in_step(with_next(source)):
             if early_stop:
                 break
             if ahead:
@@ -163,6 +202,8 @@ def train_loop(model, train_batches, vali_batches, lr, reg_lambda, train_batch_s
                 if use_async:
                     import torch
                     losses_step = torch.stack(losses_step).cpu().tolist()
+                    if any(v != v for v in losses_step) and hasattr(model, "check_ids"):
+                        model.check_ids()       # a NaN loss is how an out-of-range feature id shows (SCOREBASE.check_ids)
                 train_loss = sum(losses_step) / len(losses_step)
                 curves["train_losses"].append(train_loss)
                 losses_step = []

@@ -16,6 +16,7 @@ include/score_hip.h; PyTorch only owns device memory and streams.  There is no C
 import ctypes as C
 import math
 import os
+import threading
 
 import numpy as np
 import torch
@@ -29,6 +30,13 @@ BATCH_FIELDS = ("user_1hop", "user_2hop", "item_1hop", "item_2hop",
 
 def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _usable_cpus():
+    try:
+        return len(os.sched_getaffinity(0))
+    except Exception:
+        return os.cpu_count() or 1
 
 
 def batch_shapes(cfg, B):
@@ -80,25 +88,33 @@ class DeviceBatch(object):
                 dst.copy_(src)                              # (dtype / device conversion included)
             max_len = int(self.tensors[7].max().item())     # one read-back per batch object
         else:
-            # the whole feed tuple into ONE int32 staging buffer, then one copy to the device.  Nested lists (what the
-            # reference's loader yields: ints, with float 0.0 in dummy slices, graph_loader.py:90-91) are walked in C
-            # (_listpack: ~15x faster than np.asarray on lists); arrays / host tensors are copied
-            host = np.zeros((n_flat,), dtype=np.int32)
-            views = carve_batch(torch.from_numpy(host), shapes)
+            # the whole feed tuple into ONE pinned int32 staging buffer, then one asynchronous copy to the device.  Nested
+            # lists (what the reference's loader yields: ints, with float 0.0 in dummy slices, graph_loader.py:90-91) are
+            # walked in C (_listpack: ~15x faster than np.asarray on lists, and on several native threads without the
+            # GIL -- the walk is one cache miss per boxed int); arrays / host tensors are copied
+            pinned, slot = model._staging(B, n_flat)
+            views = carve_batch(pinned, shapes)
             lp = _lib.listpack()
-            for i, (dst, x) in enumerate(zip(views, batch_data)):
-                if lp is not None and isinstance(x, (list, tuple)):
-                    try:
-                        lp.pack(x, dst.numpy(), shapes[i])
-                    except ValueError:
-                        raise bad(i, np.asarray(x).shape)
-                    continue
-                a = x.cpu().numpy() if torch.is_tensor(x) else np.asarray(x)
-                if tuple(a.shape) != shapes[i]:
-                    raise bad(i, a.shape)
-                dst.copy_(torch.from_numpy(np.ascontiguousarray(a.astype(np.int32, copy=False))))
-            max_len = int(views[7].max()) if B else 0
-            self.flat = torch.from_numpy(host).to(model.device, non_blocking=True)
+            nthreads = int(getattr(model, "feed_threads", 1))
+            try:
+                for i, (dst, x) in enumerate(zip(views, batch_data)):
+                    if lp is not None and isinstance(x, (list, tuple)):
+                        try:
+                            lp.pack(x, dst.numpy(), shapes[i], nthreads)
+                        except ValueError:
+                            raise bad(i, np.asarray(x).shape)
+                        continue
+                    a = x.cpu().numpy() if torch.is_tensor(x) else np.asarray(x)
+                    if tuple(a.shape) != shapes[i]:
+                        raise bad(i, a.shape)
+                    dst.copy_(torch.from_numpy(np.ascontiguousarray(a.astype(np.int32, copy=False))))
+                max_len = int(views[7].max()) if B else 0
+                self.flat = torch.empty((n_flat,), dtype=torch.int32, device=model.device)
+                self.flat.copy_(pinned, non_blocking=True)
+            finally:
+                # the slot may be rewritten once this copy has run (or at once, if the conversion raised)
+                slot[1] = torch.cuda.current_stream(model.device).record_event()
+                slot[2] = False
             self.tensors = carve_batch(self.flat, shapes)
         self.active_slices = active_slices(model, max_len)
         self.struct = _lib.Batch(*[_ptr(t) for t in self.tensors], B, self.active_slices)
@@ -186,12 +202,96 @@ class SCOREBASE(object):
         # sticky device word the kernels OR a bit into when a fed id lies outside the table (score_state_t.id_status)
         self._id_status = torch.zeros((1,), dtype=torch.int32, device=self.device)
         self._scalars = torch.zeros((4,), dtype=torch.int32, device=self.device)
-        self._scalars_host = torch.zeros((4,), dtype=torch.int32).pin_memory()
+        # pinned staging ring for them: with a captured step the host runs many steps ahead of the GPU, so the slot a
+        # queued H2D copy reads from must not be rewritten before that copy has run (one event per slot says when)
+        self._scalars_ring = None
+        self._scalars_slot = 0
         self._use_dev_scalars = False
         self._graph_on, self._graphs = False, {}
         self.debug_flags = 0       # score_state_t.debug_flags (A/B switches; bit 0: step-by-step H = 256 recurrence, bit 1: head forward in one launch, bit 2: f32-MFMA H = 128 recurrence)
         self.gemm_mode = 1         # 1: bf16x3 split (fp32-accurate) on the shapes where it measured faster, 0: f32 MFMA only
+        # host feed path (nested lists / arrays -> pinned staging -> device): native threads of the list walk, and a ring
+        # of pinned staging buffers per batch size (a buffer is reused once the H2D copy that read it has run)
+        self.feed_threads = int(os.environ.get("SCORE_FEED_THREADS", str(max(1, min(8, _usable_cpus() // 2)))))
+        self._stage, self._stage_lock = {}, threading.Lock()
         self._init_params(seed)
+
+    STAGING_SLOTS = 4
+
+    def _staging(self, B, n_flat):
+        """-> (pinned int32 [n_flat] whose padding words are zero, its ring slot [tensor, copy-done event, busy])"""
+        with self._stage_lock:
+            ring = self._stage.get(B)
+            if ring is None or ring[0][0][0].numel() != n_flat:
+                # (zeroed once: the 16-byte alignment padding between the eight tensors is never written afterwards)
+                ring = self._stage[B] = [[[torch.zeros((n_flat,), dtype=torch.int32).pin_memory(), None, False]
+                                         for _ in range(self.STAGING_SLOTS)], 0]
+                while len(self._stage) > 4:
+                    self._stage.pop(next(iter(self._stage)))
+            for _ in range(self.STAGING_SLOTS):
+                slot = ring[0][ring[1]]
+                ring[1] = (ring[1] + 1) % self.STAGING_SLOTS
+                if not slot[2]:
+                    break
+            else:                                   # every slot is being filled by another thread: a private buffer
+                slot = [torch.zeros((n_flat,), dtype=torch.int32).pin_memory(), None, False]
+            slot[2] = True
+        if slot[1] is not None:
+            slot[1].synchronize()
+        return slot[0], slot
+
+    def feed(self, batches, depth=2):
+        """Iterate over `batches` (feed tuples as the reference's GraphLoader yields them, graph_loader.py:383,397)
+        `depth` batches AHEAD: a worker thread turns the next tuples into DeviceBatch objects -- list walk on native
+        threads without the GIL, pinned staging, H2D copy on a stream of its own -- while the caller trains on the
+        current one, so `for b in model.feed(loader): model.train(sess, b, lr, reg)` hides the host ingestion behind
+        the step.  Yields DeviceBatch objects (train / eval take them as they take the tuples); results are those of
+        feeding the tuples directly."""
+        import queue
+        q = queue.Queue(maxsize=max(1, int(depth)))
+        stop = threading.Event()
+        END = object()
+
+        def work():
+            try:
+                torch.cuda.set_device(self.device)
+                st = torch.cuda.Stream(device=self.device)
+                with torch.cuda.stream(st):
+                    for b in batches:
+                        db = self.device_batch(b)
+                        item = (db, st.record_event())
+                        while not stop.is_set():
+                            try:
+                                q.put(item, timeout=0.1)
+                                break
+                            except queue.Full:
+                                pass
+                        if stop.is_set():
+                            return
+                q.put((END, None))
+            except BaseException as e:              # handed to the consumer, raised there
+                q.put((e, None))
+        t = threading.Thread(target=work, name="score-feed", daemon=True)
+        t.start()
+        try:
+            while True:
+                db, ev = q.get()
+                if db is END:
+                    return
+                if isinstance(db, BaseException):
+                    raise db
+                cur = torch.cuda.current_stream(self.device)
+                cur.wait_event(ev)
+                db.flat.record_stream(cur)          # (allocated on the worker's stream, consumed on this one)
+                yield db
+        finally:
+            stop.set()
+            while t.is_alive():
+                try:
+                    q.get_nowait()
+                except queue.Empty:
+                    pass
+                t.join(timeout=0.05)
 
     def _table_rows(self, feature_size):
         """rows of emb_mtx this object holds (a row shard overrides it, score_amd/dist.py)"""
@@ -479,6 +579,8 @@ class SCOREBASE(object):
         # register workgroups cannot share a CU with it -- 0.06; boundaries 1 / 3 / 4: 0.03 / 0.03 / 0.2
         # (SCORE_ADAM_SWEEP_AT=plan|1|2|3|4, profiles/r02_probes.md)
         sweep_at = os.environ.get("SCORE_ADAM_SWEEP_AT", "2") if self._pending_sweep is not None else ""
+        if sweep_at not in ("", "plan", "1", "2", "3", "4"):
+            sweep_at = "2"                  # (an unknown value must not leave the window slice unlaunched)
         if sweep_at == "plan":
             self._launch_sweep(self._side)
         if self.scatter_mode == 0:
@@ -588,11 +690,12 @@ class SCOREBASE(object):
         self._pending_sweep = None
         _, _, T = self._tiled
         cur = torch.cuda.current_stream(self.device)
-        if stream is not cur:
+        other = stream.cuda_stream != cur.cuda_stream       # (current_stream() returns a new wrapper object every call)
+        if other:
             stream.wait_event(after)
         _lib.check(self.lib.score_adam_catchup_rows(C.byref(T), lo, hi, upto, C.c_void_p(stream.cuda_stream)),
                    "score_adam_catchup_rows")
-        if stream is not cur:
+        if other:
             self._ev_sweep = stream.record_event()
 
     def _adam_table_tiled(self, lr):
@@ -694,8 +797,16 @@ class SCOREBASE(object):
             self._graphs = {}
             self._use_dev_scalars = False
 
+    SCALAR_SLOTS = 16
+
     def _write_step_scalars(self, lr):
-        h = self._scalars_host
+        if self._scalars_ring is None:
+            self._scalars_ring = [[torch.zeros((4,), dtype=torch.int32).pin_memory(), None] for _ in range(self.SCALAR_SLOTS)]
+        slot = self._scalars_ring[self._scalars_slot]
+        self._scalars_slot = (self._scalars_slot + 1) % self.SCALAR_SLOTS
+        if slot[1] is not None:
+            slot[1].synchronize()          # the copy that last read this slot (SCALAR_SLOTS steps ago) has run
+        h = slot[0]
         h[0] = int(np.float32(self._alpha(lr)).view(np.int32))
         seed = (self._drop_seed * 0x9E3779B1 + self.step * 0x85EBCA77) & 0xFFFFFFFFFFFFFFFF
         lo, hi = seed & 0xFFFFFFFF, seed >> 32
@@ -703,6 +814,7 @@ class SCOREBASE(object):
         h[2] = lo - (1 << 32) if lo >= (1 << 31) else lo
         h[3] = hi - (1 << 32) if hi >= (1 << 31) else hi
         self._scalars.copy_(h, non_blocking=True)
+        slot[1] = torch.cuda.current_stream(self.device).record_event()
 
     def _train_captured(self, batch_data, lr, reg_lambda, keep_prob):
         db = self.device_batch(batch_data)
@@ -721,6 +833,8 @@ class SCOREBASE(object):
                 self._graphs[key] = "warm" if ent is None else "ready"
                 return ws[lay.loss]
             if ent == "ready":
+                self._flush_adam()
+                self._tiled_ready = False
                 static = DeviceBatch.empty(self, db.B, db.active_slices)
                 static.flat.copy_(db.flat)
                 lay, ws = self._workspace(db.B)
@@ -734,6 +848,11 @@ class SCOREBASE(object):
                 self.step, self.beta1_power, self.beta2_power = step, b1p, b2p
                 ent = self._graphs[key] = (g, static, lay, ws)
             g, static, lay, ws = ent
+            # the capture bakes the per-step SWEEP in: every update the time-tiled optimizer still owes (an eager step
+            # in between -- explicit dropout masks, stage events -- may have run it) is applied first, and row_step no
+            # longer describes the table after the replayed sweep
+            self._flush_adam()
+            self._tiled_ready = False
             static.flat.copy_(db.flat, non_blocking=True)
             g.replay()
             self.adam_advance()

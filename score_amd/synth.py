@@ -120,6 +120,11 @@ CONFIGS = {
     "cfg2": (100000, 50000, 10, 5, 16, 32, 256, 3, 4, (1500, 5000, 5000), (9, 3)),
     "tmall_default": (424170, 1090390, 11, 10, 16, 32, 200, 3, 4, TMALL_ITEM_VOCABS, TMALL_USER_VOCABS),
     "cfg3": (424170, 1090390, 20, 10, 64, 128, 1024, 3, 4, TMALL_ITEM_VOCABS, TMALL_USER_VOCABS),
+    # the reference's other two data sets at its own hyper-parameters (train_score.py:15-16, 23-43, 285-338, 372):
+    # CCMR  N = 1 + 4,920,695 + 190,129 + 80,172 + 213,482 + 63 + 1,044 = 5,405,586, T = 41 - 0 - 1 = 40 (train length 38),
+    # Fu = 1, Fi = 5;  Taobao  N = 1 + 984,080 + 4,049,268 + 9,405 = 5,042,754, T = 8 (train length 6), Fu = 1, Fi = 2
+    "ccmr_default": (4920695, 190129, 40, 10, 16, 32, 200, 1, 5, (80172, 213482, 63, 1044), ()),
+    "taobao_default": (984080, 4049268, 8, 10, 16, 32, 200, 1, 2, (9405,), ()),
     "cfg5_taobao": (984080, 4049268, 50, 20, 128, 256, 4096, 1, 2, (9405,), ()),
     "cfg5_tmall": (984080, 4049268, 50, 20, 128, 256, 4096, 3, 4, (3000, 3000, 3396), (6, 3)),
 }

@@ -95,3 +95,65 @@ def test_two_rank_sharded_training_matches_single_model(tmp_path, model_type):
         pref, _, lref = ref.eval(None, b, 1e-3)
         assert np.allclose(z[r]["pred"], pref, atol=1e-5)
         assert abs(float(z[r]["eloss"]) - lref) < 1e-5
+
+
+# ---- harness.train_loop with several ranks: every rank must take the same branches -----------------
+def _loop_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from score_amd import harness as h
+    from score_amd.dist import TorchDistComm
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    class Model(object):
+        """train / eval are collectives (as ShardedSCORE's are): a rank that takes one step more than the others, or
+        evaluates when they do not, would hang here (the process group times out) or pair up mismatched calls"""
+        device = "cpu"
+
+        def __init__(self):
+            self.comm, self.n_train, self.n_eval, self.saved, self.pairs = TorchDistComm(), 0, 0, [], []
+
+        def train(self, sess, batch_data, lr, reg_lambda, next_batch=None):
+            t = torch.tensor([1.0 + self.n_train])
+            self.comm.all_reduce_sum(t)
+            assert float(t) == world * (1.0 + self.n_train)        # everybody is at the same step
+            self.n_train += 1
+            self.pairs.append((batch_data, next_batch))
+            return 1.0 / self.n_train
+
+        def save(self, sess, path):
+            self.saved.append(self.n_train)
+
+    m = Model()
+    script = [[0.10, 0.30, 0.20, 0.50, 0.40, 0.45, 0.9], [0.30, 0.20, 0.50, 0.10, 0.70, 0.65, 0.1]][rank]
+
+    def ev(model, batches, reg_lambda):
+        t = torch.tensor([100.0 + model.n_eval])
+        model.comm.all_reduce_sum(t)
+        assert float(t) == world * (100.0 + model.n_eval)
+        v = script[min(model.n_eval, len(script) - 1)]
+        model.n_eval += 1
+        return 0.0, 0.5, v, v, v, v, v, v, 0.25 + rank
+    n_batches = 5 if rank == 0 else 3                          # rank 1's loader ends first: everybody stops there
+    out = h.train_loop(m, lambda: list(range(10 * rank, 10 * rank + n_batches)), lambda: [], 1e-3, 1e-4, 4, 18, epochs=2,
+                       save_path="ckpt", evaluate_fn=ev, log=lambda s: None)
+    np.savez(os.path.join(out_dir, "loop%d.npz" % rank), steps=out["steps"], mrrs=np.asarray(out["vali_mrrs"]),
+             vloss=np.asarray(out["vali_losses"]), saved=np.asarray(m.saved), n_eval=m.n_eval,
+             last_next=np.asarray([-1 if p[1] is None else p[1] for p in m.pairs]))
+    dist.destroy_process_group()
+
+
+def test_train_loop_two_ranks_take_the_same_branches(tmp_path):
+    world = 2
+    mp.spawn(_loop_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    z = [np.load(str(tmp_path / ("loop%d.npz" % r))) for r in range(world)]
+    # 3 steps per epoch (the shorter loader), eval_iter_num = 3: evaluations at steps 0, 3, 6
+    assert int(z[0]["steps"]) == int(z[1]["steps"]) == 6 and int(z[0]["n_eval"]) == int(z[1]["n_eval"]) == 3
+    for k in ("mrrs", "vloss", "saved"):
+        assert np.array_equal(z[0][k], z[1][k]), k             # the rules saw the same numbers on both ranks
+    assert np.allclose(z[0]["mrrs"], [0.2, 0.25, 0.35]) and np.allclose(z[0]["vloss"], [0.75] * 3)
+    assert z[0]["saved"].tolist() == [3, 6]
+    # nobody prefetches for a step that does not happen: the third step of an epoch has no look-ahead batch on either rank
+    assert z[0]["last_next"].tolist() == [1, 2, -1, 1, 2, -1] and z[1]["last_next"].tolist() == [11, 12, -1, 11, 12, -1]

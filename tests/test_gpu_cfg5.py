@@ -95,7 +95,9 @@ def _check_vs_oracle(world, kw, m, B, ragged):
     moved = (m.table[rows] != t_before).any(dim=1)
     # rows with a gradient move; a marked row whose every use sits past its own sample's length has a zero
     # gradient (and zero moments at step 1) and stays; unmarked rows and the dummy row never move
-    has_grad = torch.from_numpy(np.abs(go["emb_mtx"]).max(axis=1) > 0).to(m.device)
+    # (a gradient below ~1e-8 -- the far end of a 40-slice recurrence -- gives an update m / (sqrt(v) + 1e-8) under one ulp
+    #  of the parameter: "moves" is asserted where the gradient is above that)
+    has_grad = torch.from_numpy(np.abs(go["emb_mtx"]).max(axis=1) > 1e-7).to(m.device)
     assert bool(moved[has_grad].all()) and not bool(moved[~torch.from_numpy(marked).to(m.device)].any()) and not bool(moved[0])
     d_tab = np.abs(m.table[rows].cpu().numpy() - om.params["emb_mtx"])
     assert np.median(d_tab) < 1e-6 and d_tab.max() <= 2.2e-3
@@ -125,8 +127,12 @@ def test_tmall_shape_vs_oracle(tmall):
 def test_full_batch_properties(which, request):
     """B = 4096 at full size: bit-exact gather, reproducible forward and gradients, permutation equivariance,
     linearity of the gradient in the loss scale, sorted scatter == atomic scatter, dense-Adam row semantics."""
+    full_batch_properties(*request.getfixturevalue(which))
+
+
+def full_batch_properties(w, kw, B, m):
+    """the size-independent properties of a full-size batch (also used by tests/test_gpu_ccmr.py)"""
     import ctypes as C
-    w, kw, B, m = request.getfixturevalue(which)
     db = m.device_batch(w.batch(B, 21))
     # embedding_lookup is a bit-exact copy, also from the top of a 2.6 GB table
     idx = db.tensors[0].reshape(-1)[:2_000_000].contiguous()

@@ -76,3 +76,31 @@ def test_captured_step_with_device_loader_batches():
         lb = [b.train(None, bt, 1e-3, 1e-4) for bt in DeviceGraphLoader(g, 16, targets["train"], 0, 9, 1, T, K)]
         assert la == lb
     assert torch.equal(a.w, b.w) and torch.equal(a.table, b.table)
+
+
+def test_async_captured_steps_keep_their_own_scalars():
+    """with a captured step the host runs many steps ahead of the GPU (train_async, no sync), and every
+    step's alpha / dropout seed travels through a pinned staging slot.  One shared slot was rewritten for step t+1
+    before step t's queued copy had read it; now a ring of slots, each guarded by the event of its copy.  Different
+    learning rates per step (alpha differs visibly) and dropout on: 40 unsynchronised replays must equal the eager run."""
+    cfg = so.Cfg(3001, 16, 32, 6, 5, 3, 4, "SCORE")
+    rng = np.random.default_rng(8)
+    eager, graphed = _pair(cfg)
+    graphed.enable_graph(True)
+    bs = [batch_tuple(random_batch(rng, cfg, 64)) for _ in range(4)]
+    dbs_e = [eager.device_batch(b) for b in bs]
+    dbs_g = [graphed.device_batch(b) for b in bs]
+    lrs = [1e-3 * (1 + (i % 7)) for i in range(44)]
+    le = [eager.train_async(dbs_e[i % 4], lr, 1e-4).clone() for i, lr in enumerate(lrs)]
+    lg = []
+    torch.cuda.synchronize()
+    pad = torch.zeros((1 << 26,), device="cuda")
+    for i, lr in enumerate(lrs):
+        if i == 4:
+            for _ in range(30):          # a backlog on the stream: the replays below are queued far ahead of execution
+                pad.add_(1.0)
+        lg.append(graphed.train_async(dbs_g[i % 4], lr, 1e-4).clone())
+    torch.cuda.synchronize()
+    assert len([v for v in graphed._graphs.values() if isinstance(v, tuple)]) == 1
+    assert torch.equal(torch.stack(le), torch.stack(lg))
+    assert torch.equal(eager.w, graphed.w) and torch.equal(eager.table, graphed.table) and torch.equal(eager.w_m, graphed.w_m)

@@ -420,3 +420,46 @@ def test_head_two_launch_form_and_x3_recurrence_against_their_references():
         assert np.array_equal(g[k], g1[k]), k
         ok, err = close(g[k], gf[k], rtol=2e-5, atol=1e-9)
         assert ok, (k, err)
+
+
+def test_feed_prefetcher_and_threaded_list_walk_give_the_same_steps():
+    """nested-list feed tuples (graph_loader.py:383) converted on native threads without the GIL into
+    pinned staging buffers, a batch or two ahead on a worker thread (SCOREBASE.feed) -- the losses, parameters and the
+    error behaviour are those of feeding the tuples one by one"""
+    from score_amd.model import SCORE, DeviceBatch
+    cfg = so.Cfg(3001, 16, 32, 6, 5, 3, 4, "SCORE")
+    P = so.init_params(cfg, 3)
+    rng = np.random.default_rng(2)
+    lists = []
+    for i in range(9):
+        b = random_batch(rng, cfg, 40 if i % 4 else 24)          # two batch sizes: two staging rings
+        t = [a.tolist() for a in batch_tuple(b)]
+        t[0][1][2] = np.zeros((cfg.K, cfg.Fi)).tolist()          # float dummies as the loader writes them
+        lists.append(tuple(t))
+    a, b_, c = (SCORE(*[cfg.N, cfg.D, cfg.H, cfg.T, cfg.K, cfg.Fu, cfg.Fi], seed=7) for _ in range(3))
+    for m in (a, b_, c):
+        m.set_params(P)
+    a.feed_threads, b_.feed_threads, c.feed_threads = 1, 6, 6
+    la = [a.train(None, t, 1e-3, 1e-4) for t in lists]
+    lb = [b_.train(None, t, 1e-3, 1e-4) for t in lists]
+    lc = []
+    for db in c.feed(iter(lists), depth=2):
+        assert isinstance(db, DeviceBatch)
+        lc.append(c.train(None, db, 1e-3, 1e-4))
+    assert la == lb == lc
+    assert torch.equal(a.w, b_.w) and torch.equal(a.w, c.w) and torch.equal(a.table, c.table)
+    # a malformed tuple in the stream surfaces as the same ValueError, in the consumer, at its position
+    bad = list(lists[:3])
+    bad[1] = bad[1][:4] + (bad[1][4][:-1],) + bad[1][5:]
+    seen = 0
+    with pytest.raises(ValueError):
+        for db in c.feed(iter(bad)):
+            seen += 1
+    assert seen == 1
+    # leaving the loop early stops the worker
+    for db in c.feed(iter(lists)):
+        break
+    import threading
+    import time
+    time.sleep(0.3)
+    assert not [t for t in threading.enumerate() if t.name == "score-feed" and t.is_alive()]

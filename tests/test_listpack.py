@@ -61,3 +61,37 @@ def test_pack_is_what_the_model_feed_path_uses():
     views = carve_batch(flat, shapes)
     assert [tuple(v.shape) for v in views] == list(shapes)
     assert all(v.data_ptr() % 16 == 0 for v in views)          # every tensor 16-B aligned inside the flat buffer
+
+
+def test_threaded_walk_equals_serial(lp):
+    """pack(..., nthreads): the outermost dimension dealt to native threads that run without the GIL; same result, and
+    everything the threads do not expect (numpy scalars, long ints, ragged lists) falls back to the serial walk, which
+    handles it or raises as before"""
+    rng = np.random.default_rng(4)
+    shape = (64, 11, 10, 4)                       # 28,160 elements: below the size where threads start ...
+    big = (256, 11, 10, 4)                        # ... and above it
+    for sh in (shape, big):
+        a = rng.integers(-3, 1_600_000, sh)
+        nested = a.tolist()
+        nested[1][2] = np.zeros(sh[2:]).tolist()                 # float dummies
+        nested[5][0][3][1] = 7.9                                  # truncated like ndarray.astype(int32)
+        want = np.asarray(nested).astype(np.int32)
+        for nt in (1, 2, 3, 8, 64):
+            out = np.full(want.size + 2, -7, dtype=np.int32)
+            lp.pack(nested, out, sh, nt)
+            assert np.array_equal(out[:want.size].reshape(sh), want) and (out[want.size:] == -7).all(), (sh, nt)
+    a = rng.integers(0, 100, big)
+    nested = a.tolist()
+    nested[200][3][4][2] = np.int64(55)                          # not an exact int: the serial walk converts it
+    out = np.zeros(a.size, dtype=np.int32)
+    lp.pack(nested, out, big, 4)
+    a[200, 3, 4, 2] = 55
+    assert np.array_equal(out.reshape(big), a)
+    nested[17][0][0][0] = 2 ** 40
+    with pytest.raises(OverflowError):
+        lp.pack(nested, out, big, 4)
+    nested[17][0][0][0] = 1
+    nested[255][10] = nested[255][10][:-1]                       # ragged in the last thread's share
+    with pytest.raises(ValueError):
+        lp.pack(nested, out, big, 4)
+    assert lp.NOGIL_THREADS in (0, 1)
