@@ -37,7 +37,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable (float4 copy)
-PROFILE_ROUND = "r02"
+PROFILE_ROUND = "r03"
 
 
 def alg_bytes_per_sample(T, K, D, Fu, Fi):
@@ -107,20 +107,38 @@ def src_sha(name):
         return hashlib.sha256(f.read()).hexdigest()[:16]
 
 
-def committed_traffic(config, key, kernel_substr):
-    """HBM bytes per launch of a kernel from a committed PMC profile (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
-    separate passes, gfx950 FETCH_SIZE x2 correction: tools/summarize_profile.py) -- only if that profile was taken
-    on THIS build of the kernel's source file; otherwise None (a stale profile is dropped, not quoted)."""
+def committed_traffic(config, key, kernel_substr, sources=("embed.hip",)):
+    """HBM bytes per launch of a kernel (kernel_substr a string) or per step of a group of kernels (a tuple of
+    substrings: every kernel whose name contains one of them, bytes x launches per step summed) from a committed PMC
+    profile (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 FETCH_SIZE x2 correction:
+    tools/summarize_profile.py) -- only if that profile was taken on THIS build of the source files the kernels live in
+    (`sources`); otherwise None (a stale profile is dropped, not quoted)."""
     path = os.path.join(ROOT, "profiles", "%s_%s_pmc_traffic.json" % (PROFILE_ROUND, config))
     try:
         pj = json.load(open(path))
         sec = pj[key]
-        if sec.get("embed_hip_sha16") != src_sha("embed.hip"):
-            return None, {"dropped": "profile %s was taken on another build of embed.hip" % os.path.basename(path)}
+        shas = sec.get("source_sha16") or {"embed.hip": sec.get("embed_hip_sha16")}
+        for src in sources:
+            if shas.get(src) != src_sha(src):
+                return None, {"dropped": "profile %s was taken on another build of %s" % (os.path.basename(path), src)}
+        info = {"profile": os.path.relpath(path, ROOT), "commit": sec.get("commit"), "workload": sec.get("workload"),
+                "source_sha16": {s_: shas.get(s_) for s_ in sources}}
+        if isinstance(kernel_substr, str):
+            for k, v in sec["kernels"].items():
+                if kernel_substr in k:
+                    return v["hbm_bytes"], info
+            return None, None
+        steps = float(sec.get("steps_profiled") or 0)
+        if steps <= 0:
+            return None, None
+        tot, used = 0.0, {}
         for k, v in sec["kernels"].items():
-            if kernel_substr in k:
-                return v["hbm_bytes"], {"profile": os.path.relpath(path, ROOT), "commit": sec.get("commit"),
-                                        "embed_hip_sha16": sec.get("embed_hip_sha16"), "workload": sec.get("workload")}
+            if any(sub in k for sub in kernel_substr):
+                per_step = max(1, int(round(v["dispatches"] / steps)))     # (the profiled run holds one extra backward pass)
+                tot += v["hbm_bytes"] * per_step
+                used[k.split("<")[0]] = used.get(k.split("<")[0], 0) + v["hbm_bytes"] * per_step
+        info["kernels_bytes_per_step"] = used
+        return (tot if used else None), (info if used else None)
     except Exception:
         pass
     return None, None
@@ -574,6 +592,39 @@ def main():
             dist.destroy_process_group()
         return
     traffic, tsrc = committed_traffic(args.config, "bench_workload", "coattn_fwd_kernel")
+    scat_tr, scat_src = committed_traffic(args.config, "bench_workload",
+                                          ("coattn_bwd_kernel_t", "pull_kernel", "pull_fixup_kernel", "pull_long_kernel",
+                                           "target_bwd_kernel"), ("embed.hip", "scatter.hip"))
+    adam_tr, adam_src = committed_traffic(args.config, "bench_workload",
+                                          ("adam_touched_kernel", "adam_rows_kernel", "adam_kernel"), ("adam_tiled.hip", "head.hip"))
+    bench_block = {"kernel": "coattn_fwd_kernel (fused embedding gather + co-attention, both calls, one launch) on the bench "
+                             "workload",
+                   "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
+                   "frac_on_traffic": (traffic / gather_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                   "algorithmic_bytes_per_launch": ab * B, "avg_launch_ms": stages["fwd_gather_coattn"],
+                   "note": "achieved/frac count the ALGORITHMIC bytes of SURVEY 8(d) (every row use); the loader-shaped batch "
+                           "repeats hot rows, the dummy row and the user side of both candidates, which L1/L2/Infinity Cache "
+                           "serve, so this frac is NOT an HBM utilisation and can exceed 1: frac_on_traffic (PMC bytes of a "
+                           "committed profile of this very build, else null) is.  The block named `roofline` is the same "
+                           "kernel where algorithmic bytes ~ traffic",
+                   "event_pair_overhead_ms": ev_overhead_ms,
+                   "avg_launch_ms_net_of_event_overhead": stages["fwd_gather_coattn"] - ev_overhead_ms,
+                   "time_slices_gathered": A, "time_slices_fed": T,
+                   "algorithmic_bytes_per_launch_if_all_fed_slices_were_gathered": ab_full * B}
+    lowdup = side.pop("roofline_lowdup", None)
+    if lowdup is not None and "error" not in lowdup:
+        roofline = dict(lowdup)
+        roofline["note"] = ("the dominant HBM-bound kernel of the path, measured where its algorithmic bytes (SURVEY 8(d): every "
+                            "row use + ids + reduced outputs) equal what memory has to deliver: ids uniform over a probe table "
+                            "far beyond the 256 MiB Infinity Cache.  avg_launch_ms: HIP events on the launch stream, live in "
+                            "this run; traffic: PMC bytes of the committed profile of this build of embed.hip (null if the "
+                            "profile is stale).  The same kernel on the loader-shaped bench batches: roofline_bench_workload")
+    else:
+        roofline = dict(bench_block)
+        roofline["note"] = ("low-duplication probe not run in this invocation (%s): this is the loader-shaped bench workload, "
+                            "whose algorithmic bytes exceed its memory traffic -- see roofline_bench_workload.note"
+                            % ("--no-side / sharded / non-default state" if lowdup is None else lowdup.get("error")))
     out = {
         "metric": "train samples/sec @ batch=1024",
         "value": B * world_size * args.steps / dt,
@@ -612,31 +663,23 @@ def main():
                    "live_row_frac": headline_live_frac,
                    "table": "row-sharded row%%G over %d GPU(s)" % world_size if world_size > 1 else "single GPU",
                    "final_loss": loss},
-        "roofline": {"kernel": "coattn_fwd_kernel (fused embedding gather + co-attention, both calls, one launch) on the bench "
-                               "workload",
-                     "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
-                     "frac_on_traffic": (traffic / gather_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                     "algorithmic_bytes_per_launch": ab * B, "avg_launch_ms": stages["fwd_gather_coattn"],
-                     "note": "achieved/frac count the ALGORITHMIC bytes of SURVEY 8(d) (every row use); the loader-shaped batch "
-                             "repeats hot rows, the dummy row and the user side of both candidates, which L1/L2/Infinity Cache "
-                             "serve, so frac is NOT an HBM utilisation and can exceed 1.  frac_on_traffic (PMC bytes of a "
-                             "committed profile of this very build, else null) is; roofline_lowdup is the same kernel where "
-                             "algorithmic bytes ~ traffic",
-                     "event_pair_overhead_ms": ev_overhead_ms,
-                     "avg_launch_ms_net_of_event_overhead": stages["fwd_gather_coattn"] - ev_overhead_ms,
-                     "time_slices_gathered": A, "time_slices_fed": T,
-                     "algorithmic_bytes_per_launch_if_all_fed_slices_were_gathered": ab_full * B},
+        "roofline": roofline,
+        "roofline_bench_workload": bench_block,
         "roofline_other": {
             adam_name: {
                 "live_row_frac": headline_live_frac, "rows_with_gradient_per_step": touched,
                 "bound": "hbm", "achieved": adam_bytes / (stages["adam_table_and_dense"] * 1e-3) / 1e9 if adam_timed else None,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": adam_bytes / (stages["adam_table_and_dense"] * 1e-3) / 1e9 / HBM_PEAK_GBS if adam_timed else None},
+                "frac": adam_bytes / (stages["adam_table_and_dense"] * 1e-3) / 1e9 / HBM_PEAK_GBS if adam_timed else None,
+                "algorithmic_bytes_per_step": adam_bytes, "traffic": adam_tr, "traffic_source": adam_src,
+                "frac_on_traffic": (adam_tr / (stages["adam_table_and_dense"] * 1e-3) / 1e9 / HBM_PEAK_GBS)
+                if (adam_tr and adam_timed) else None},
             "coattn_bwd + scatter (R*(4+4D) per sample, algorithmic)": {
                 "bound": "hbm", "achieved": scat_bytes / (stages["bwd_coattn_scatter"] * 1e-3) / 1e9,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": scat_bytes / (stages["bwd_coattn_scatter"] * 1e-3) / 1e9 / HBM_PEAK_GBS}},
+                "frac": scat_bytes / (stages["bwd_coattn_scatter"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "algorithmic_bytes_per_step": scat_bytes, "traffic": scat_tr, "traffic_source": scat_src,
+                "frac_on_traffic": (scat_tr / (stages["bwd_coattn_scatter"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if scat_tr else None}},
         "stages_ms": stages,
     }
     out.update(side)

@@ -58,6 +58,9 @@ def pmc_round(bench_fetch, bench_write, probe_fetch, probe_write, out, config="c
     import tempfile
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sha = hashlib.sha256(open(os.path.join(root, "score_amd", "csrc", "embed.hip"), "rb").read()).hexdigest()[:16]
+    csrc = os.path.join(root, "score_amd", "csrc")
+    shas = {f: hashlib.sha256(open(os.path.join(csrc, f), "rb").read()).hexdigest()[:16]
+            for f in sorted(os.listdir(csrc)) if f.endswith(".hip") or f.endswith(".h")}
     try:
         commit = subprocess.check_output(["git", "-C", root, "rev-parse", "--short", "HEAD"]).decode().strip()
     except Exception:
@@ -71,7 +74,8 @@ def pmc_round(bench_fetch, bench_write, probe_fetch, probe_write, out, config="c
         pmc(fd, wd, tmp, wl)
         sec = json.load(open(tmp))
         os.unlink(tmp)
-        sec.update(commit=commit, embed_hip_sha16=sha, workload=wl)
+        sec.update(commit=commit, embed_hip_sha16=sha, source_sha16=shas, workload=wl,
+                   steps_profiled=(8 if key == "bench_workload" else None))      # bench.py --steps 6 --warmup 2
         res[key] = sec
     json.dump(res, open(out, "w"), indent=1)
 
