@@ -17,11 +17,14 @@ the timed region), all other state as the loader produces it (length = T - 2 for
 train split 9 of 11, graph_loader.py:382; the slices every sample masks are skipped).  Beside it, in the same
 line and measured in the same process: `value_best_case` (fresh optimizer state), `value_all_slices` (nothing
 skipped), `ingestion` (device-side batch assembly inside the loop; nested Python lists as the reference feeds
-them), `roofline` (the fused embedding-gather + co-attention forward kernel on the bench workload: algorithmic
-bytes of SURVEY.md 8(d) / HIP-event duration on the launch stream), `roofline_lowdup` (the same kernel on a
-low-duplication batch over a table far larger than the Infinity Cache, where algorithmic bytes ~ memory
-traffic), `cpu_baseline` (CPU restatement of the TF graph, "port") and `cpu_baseline_literal_tile` (the
-materialised [B,T,K,K,3D] form TF really executes, at the Tmall-default shape).
+them), `roofline` (the fused embedding-gather + co-attention forward kernel -- the dominant HBM-bound kernel -- on a
+LOW-DUPLICATION batch over a table far larger than the Infinity Cache, where the algorithmic bytes of SURVEY.md 8(d)
+are what memory has to deliver: frac <= 1 and reproducible from profiles/r03_cfg3_gather_probe_kernel_stats.csv;
+HIP-event duration on the launch stream, PMC traffic of the committed profile of the same build),
+`roofline_bench_workload` (the same kernel on the loader-shaped bench batches, whose repeats the caches serve),
+`roofline_other` (row scatter and table optimizer, with PMC traffic), `cpu_baseline` (CPU restatement of the TF graph,
+"port") and `cpu_baseline_literal_tile` (the materialised [B,T,K,K,3D] form TF really executes, at the Tmall-default
+shape).
 """
 import argparse
 import hashlib

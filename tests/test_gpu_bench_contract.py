@@ -26,16 +26,19 @@ def test_default_line_carries_the_contract():
         assert j[k] == v, (k, j[k])
     assert j["value"] > 0 and abs(j["value"] - 256 / (j["ms_per_step"] * 1e-3)) < 1e-6 * j["value"]
     assert "workload" in j["config"] and "model" not in j["config"] and j["config"]["live_row_frac"] == 1.0
-    r = j["roofline"]
-    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
-    assert "traffic" in r and r["algorithmic_bytes_per_launch"] > 0 and r["avg_launch_ms"] > 0
+    for key in ("roofline", "roofline_bench_workload"):
+        r = j[key]
+        assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+        assert "traffic" in r and r["algorithmic_bytes_per_launch"] > 0 and r["avg_launch_ms"] > 0
+    assert abs(j["roofline"]["achieved"] - j["roofline"]["algorithmic_bytes_per_launch"] / (j["roofline"]["avg_launch_ms"] * 1e-3) / 1e9) < 1e-6 * j["roofline"]["achieved"]
     c = j["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "samples/s" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     # the headline's companions
     assert j["value_best_case"] > 0 and j["value_all_slices"] > 0 and 0 < j["best_case_live_row_frac"] <= 1
-    lo = j["roofline_lowdup"]
-    assert lo["bound"] == "hbm" and lo["algorithmic_bytes_per_launch"] > 0 and lo["avg_launch_ms"] > 0
-    assert lo["expected_distinct_rows"] <= lo["row_uses"]
+    lo = j["roofline"]                  # the headline block is the low-duplication probe
+    assert "low-duplication" in lo["kernel"] and lo["frac"] <= 1.0 and lo["expected_distinct_rows"] <= lo["row_uses"]
+    for v in j["roofline_other"].values():
+        assert "traffic" in v and v["algorithmic_bytes_per_step"] > 0
     ing = j["ingestion"]
     assert ing["device_assembly_samples_per_s"] > 0 and ing["nested_python_lists_samples_per_s"] > 0
     assert j["cpu_baseline_literal_tile"]["value"] > 0 and "materialised" in j["cpu_baseline_literal_tile"]["sample"]
