@@ -277,6 +277,12 @@ typedef struct {
   float beta1, beta2, eps;
 } score_adam_table_t;
 int score_adam_touched(const score_adam_table_t* t, uint32_t step, float alpha, void* stream);
+/* score_adam_touched driven by a row LIST instead of a scan of the state bytes: rows[0 .. *n_rows_dev) (device int32,
+ * the count is read on the device; max_rows bounds it for the launch) names every row that may be in state 2 -- what
+ * score_index_plan(dedup = 2) leaves in the workspace (plan_unique_rows / plan_meta[0]).  Entries not in state 2 are
+ * skipped (the dummy row 0); rows in state 2 that the list misses would be left for score_adam_touched. */
+int score_adam_touched_rows(const score_adam_table_t* t, const int32_t* rows, const int32_t* n_rows_dev, int64_t max_rows,
+                            uint32_t step, float alpha, void* stream);
 /* every value of ids[0..n_ids) that names a live row (values outside [0, n_rows) are ignored, so a whole flat batch
  * buffer may be passed): replay the zero-gradient steps row_step+1 .. upto of that row */
 int score_adam_catchup_ids(const score_adam_table_t* t, const int32_t* ids, int64_t n_ids, uint32_t upto, void* stream);
@@ -344,7 +350,8 @@ int score_id_status(int32_t* id_status, int32_t* bits, int32_t clear, void* stre
  * n_shards > 1 (table row-sharded, owner = row % n_shards) or dedup != 0 additionally
  * de-duplicates them: unique rows grouped by owner -> what to request from each shard --
  * and writes the six index tensors remapped to unique positions, so the same kernels run
- * on the gathered [U, D] mini-table.  Replaces nothing in the reference (it has no multi-device code);
+ * on the gathered [U, D] mini-table.  dedup == 2 (one shard): only the unique row list and its count are written
+ * (plan_unique_rows, plan_meta[0]; no remapped tensors) -- the rows score_adam_touched_rows updates.  Replaces nothing in the reference (it has no multi-device code);
  * it is the index-routing step BASELINE.json's north_star asks for. */
 int score_index_plan(const score_config_t* cfg, const score_state_t* st, const score_batch_t* batch,
                      int32_t n_shards, int32_t dedup, void* stream);

@@ -112,6 +112,46 @@ __global__ __launch_bounds__(256) void adam_touched_kernel(const TiledArgs a, ui
   }
 }
 
+// The same update driven by a LIST of rows (the unique rows of the batch, score_index_plan with dedup == 2) instead of a
+// scan of the state bytes: a group of LPR lanes per list entry, four entries per group and trip with their four rows'
+// streams requested together.  Entries whose row is not in state 2 (the dummy row 0, whose uses carry no gradient) are
+// skipped, so the list may be a superset of the rows with a gradient.
+__global__ __launch_bounds__(256) void adam_touched_rows_kernel(const TiledArgs a, const int32_t* __restrict__ rows,
+                                                                const int32_t* __restrict__ n_rows_dev, uint32_t step,
+                                                                float alpha) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) a.ring[step % SCORE_ADAM_RING] = alpha;
+  const int n = *n_rows_dev;
+  const int gpb = blockDim.x / a.LPR;
+  const int ch4 = ((int)threadIdx.x % a.LPR) * 4;
+  const int64_t ngroups = (int64_t)gridDim.x * gpb;
+  constexpr int U = 4;
+  for (int64_t i0 = ((int64_t)blockIdx.x * gpb + threadIdx.x / a.LPR) * U; i0 < n; i0 += ngroups * U) {
+    int row[U];
+    bool on[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) row[u] = rows[i0 + u < n ? i0 + u : n - 1];
+#pragma unroll
+    for (int u = 0; u < U; ++u) on[u] = i0 + u < n && ch4 < a.D && a.flags[row[u]] == 2;
+    float4 p[U], m[U], v[U], g[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t e = (int64_t)row[u] * a.D + (ch4 < a.D ? ch4 : 0);
+      p[u] = ld4(a.p + e); m[u] = ld4(a.m + e); v[u] = ld4(a.v + e); g[u] = ld4(a.g + e);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (!on[u]) continue;
+      const int64_t e = (int64_t)row[u] * a.D + ch4;
+      score_adam1(p[u].x, m[u].x, v[u].x, g[u].x, a.omb1, a.omb2, alpha, a.eps);
+      score_adam1(p[u].y, m[u].y, v[u].y, g[u].y, a.omb1, a.omb2, alpha, a.eps);
+      score_adam1(p[u].z, m[u].z, v[u].z, g[u].z, a.omb1, a.omb2, alpha, a.eps);
+      score_adam1(p[u].w, m[u].w, v[u].w, g[u].w, a.omb1, a.omb2, alpha, a.eps);
+      st4(a.p + e, p[u]); st4(a.m + e, m[u]); st4(a.v + e, v[u]);
+      if (ch4 == 0) { a.flags[row[u]] = 1; a.step[row[u]] = step; }
+    }
+  }
+}
+
 // live rows of [row_begin, row_end) that lag behind `upto`: replay what they missed.  State 2 rows are left alone:
 // they belong to the step in flight (score_adam_touched), and are current up to the step before by construction.
 __global__ __launch_bounds__(256) void adam_catchup_rows_kernel(const TiledArgs a, int64_t row_begin, int64_t row_end,
@@ -187,6 +227,20 @@ extern "C" int score_adam_touched(const score_adam_table_t* t, uint32_t step, fl
   SCORE_TRY(tiled_args(t, &a, true));
   if (step == 0) return SCORE_E_BADARG;
   hipLaunchKernelGGL(adam_touched_kernel, dim3(tiled_blocks(a.n_rows)), dim3(256), 0, (hipStream_t)stream, a, step, alpha);
+  SCORE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int score_adam_touched_rows(const score_adam_table_t* t, const int32_t* rows, const int32_t* n_rows_dev,
+                                       int64_t max_rows, uint32_t step, float alpha, void* stream) {
+  TiledArgs a;
+  SCORE_TRY(tiled_args(t, &a, true));
+  if (step == 0 || !rows || !n_rows_dev || max_rows <= 0) return SCORE_E_BADARG;
+  const int gpb = 256 / a.LPR;
+  int64_t blocks = cdiv64(cdiv64(max_rows, 4), gpb);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(adam_touched_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, rows, n_rows_dev,
+                     step, alpha);
   SCORE_CHECK_LAUNCH();
   return 0;
 }

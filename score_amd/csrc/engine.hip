@@ -280,11 +280,11 @@ static int side_stream(const score_state_t* st, SideStream** out) {
   return 0;
 }
 // A/B switches of the launch sequence, read from the environment ONCE (first call), not per step
-struct EnvFlags { bool head_unfused, attn_tail_unfused, wgrad_side, gru_stepwise, attn_fwd_unfused; };
+struct EnvFlags { bool head_unfused, attn_tail_unfused, wgrad_side, gru_stepwise, attn_fwd_unfused, gru_bias_colsum; };
 static bool env_on(const char* name) { const char* v = getenv(name); return v && *v && !(v[0] == '0' && !v[1]); }   // (set, not empty, not "0")
 static const EnvFlags& env_flags() {
   static const EnvFlags f = {env_on("SCORE_HEAD_UNFUSED"), env_on("SCORE_ATTN_TAIL_UNFUSED"), env_on("SCORE_WGRAD_SIDE"),
-                             env_on("SCORE_GRU_STEPWISE"), env_on("SCORE_ATTN_FWD_UNFUSED")};
+                             env_on("SCORE_GRU_STEPWISE"), env_on("SCORE_ATTN_FWD_UNFUSED"), env_on("SCORE_GRU_BIAS_COLSUM")};
   return f;
 }
 #define HIPTRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return (int)e_; } while (0)
@@ -423,7 +423,7 @@ extern "C" int score_index_plan(const score_config_t* cfg, const score_state_t* 
     G(score_launch_plan_unique(ra, keys_out, vals_out, off + 1, keys_in, reinterpret_cast<uint32_t*>(ws + w.uid),
                                vals_in, reinterpret_cast<int32_t*>(ws + w.unique_rows),
                                reinterpret_cast<int32_t*>(ws + w.meta), n_shards, shift, ws + w.sort_temp,
-                               (size_t)w.sort_temp_bytes, s));
+                               (size_t)w.sort_temp_bytes, s, n_shards > 1 || dedup != 2));
   }
   return 0;
 }
@@ -742,6 +742,7 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
   }
 
   EV(2);
+  int gru_bias_rows = 0;
   // ---- GRUs (score.py:205-208)
   // the weight gradients queued so far (head, attention) have everything they need: beside the recurrence
   const bool wgrad_side = env_flags().wgrad_side;   // A/B: the recurrences' weight gradients beside the scatter
@@ -787,8 +788,13 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
       g.out = ws + w.gru_out[sd]; g.ldo = H; g.gates = ws + w.gates[sd];
       g.dout = ws + w.dgru[sd]; g.lddo = H; g.dfinal = dfinal[sd];
       g.dxproj = ws + w.dxproj[sd]; g.rh = ws + w.rh[sd]; g.hprev = ws + w.hprev[sd];
+      // per-workgroup column sums of dxproj (the recurrence's bias gradients), where the kernel that runs provides them;
+      // one row per 16 samples at most: far inside the scratch that only the other recurrence kernels use
+      g.bias_slab = (!env_flags().gru_bias_colsum && 2 * ((int64_t)B / 16 + 1) * 3 * H <= w.gru_tmp_floats) ? ws + w.gru_tmp + (int64_t)sd * (B / 16 + 1) * 3 * H
+                                                                          : nullptr;
     }
     G(score_gru_bwd_multi(ga, 2, s));
+    gru_bias_rows = ga.bias_slab_rows;
   }
   for (int sd = 0; sd < 2; ++sd) {
     float* dxp = ws + w.dxproj[sd];
@@ -800,8 +806,14 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
     G(gemm_queue_add(&gq, d.Is[sd], H, BT, ws + w.xside[sd], d.I, dxp + 2 * H, 3 * H, gw + P.ck[sd], H));
     G(gemm_queue_add(&gq, H, 2 * H, BT, ws + w.hprev[sd], H, dxp, 3 * H, gw + P.gk[sd] + (int64_t)d.Is[sd] * 2 * H, 2 * H));
     G(gemm_queue_add(&gq, H, H, BT, ws + w.rh[sd], H, dxp + 2 * H, 3 * H, gw + P.ck[sd] + (int64_t)d.Is[sd] * H, H));
-    G(colsum_queue_add(&cq, dxp, BT, 2 * H, 3 * H, gw + P.gb[sd], 0));
-    G(colsum_queue_add(&cq, dxp + 2 * H, BT, H, 3 * H, gw + P.cb[sd], 0));
+    if (gru_bias_rows > 0) {     // (the recurrence left per-workgroup column sums of dxproj: a few dozen rows instead of B*T)
+      const float* slab = ws + w.gru_tmp + (int64_t)sd * (B / 16 + 1) * 3 * H;
+      G(colsum_queue_add(&cq, slab, gru_bias_rows, 2 * H, 3 * H, gw + P.gb[sd], 0));
+      G(colsum_queue_add(&cq, slab + 2 * H, gru_bias_rows, H, 3 * H, gw + P.cb[sd], 0));
+    } else {
+      G(colsum_queue_add(&cq, dxp, BT, 2 * H, 3 * H, gw + P.gb[sd], 0));
+      G(colsum_queue_add(&cq, dxp + 2 * H, BT, H, 3 * H, gw + P.cb[sd], 0));
+    }
     // d x = [dgates | dcand] . [Wx_gates | Wx_cand]^T
     if (d.Is[sd] != d.I) {   // RRN: the 2-hop columns of this side carry no gradient
       he = hipMemsetAsync(ws + w.dxside[sd], 0, (int64_t)BT * d.I * sizeof(float), s);

@@ -238,11 +238,16 @@ __global__ __launch_bounds__(64 * XNW) void gru_fwd_x3_kernel(const GruArgs a) {
 __global__ __launch_bounds__(64 * XNW) void gru_bwd_x3_kernel(const GruArgs a) {
   constexpr int H = XH, PS = XRB * XLD, PS2 = XRB * XLD2;
   __shared__ __attribute__((aligned(16))) unsigned short dpc[3 * PS], dpg[3 * PS2];
+  // column sums of what each lane writes into dxproj (its columns j, H + j, 2H + j; rows of real samples only): the GRU
+  // bias gradients' partial sums, so that nobody reads the [B*T, 3H] matrix again for them.  Kept in LDS, one private
+  // slot per lane and gate (ds_add_f32, no contention): three more live registers spilt 39 in this kernel
+  __shared__ float sbias[3][64 * XNW];
   const int tiles_b = (a.B + XRB - 1) / XRB;
   const int side = blockIdx.x / tiles_b;
   const GruSide& sd = a.s[side];
   const int b0 = (blockIdx.x - side * tiles_b) * XRB;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  sbias[0][tid] = 0.f; sbias[1][tid] = 0.f; sbias[2][tid] = 0.f;
   const int lc = lane & 15, lq = lane >> 4;
   const int T = a.T;
   const int j = wave * 16 + lc;
@@ -264,8 +269,10 @@ __global__ __launch_bounds__(64 * XNW) void gru_bwd_x3_kernel(const GruArgs a) {
   }
   int len[4];
   bool rok[4];
+  const int nreal = a.B - (b0 + lq * 4);      // rows r < nreal of this lane are real samples (the rest duplicate the last one)
   uint32_t rb3[4], rbh[4], rbo[4], rbd[4];   // byte offsets of (sample, t = 0, column j): [.,3H] / [.,H] arrays, out, dout
   float dh[4];                       // running dL/dh of this lane's four (row, column) elements
+  const bool want_bias = sd.bias_slab != nullptr;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int b = b0 + lq * 4 + r;
@@ -312,6 +319,7 @@ __global__ __launch_bounds__(64 * XNW) void gru_bwd_x3_kernel(const GruArgs a) {
     __builtin_amdgcn_sched_barrier(0);     // (a fetch hoisted above the last use of its registers costs a copy
     fetch_hp(t - 1);                       //  behind a wait for the load just issued)
     // phase 1 (elementwise): dpu, dpc ; dh <- dh_tot * u      (results of a dead step are discarded by `live`)
+    float su = 0.f, sc = 0.f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int i = lq * 4 + r;
@@ -322,6 +330,8 @@ __global__ __launch_bounds__(64 * XNW) void gru_bwd_x3_kernel(const GruArgs a) {
       const float v_dpu = live ? du * u * (1.0f - u) : 0.f;
       const float v_dpc = live ? dc * (1.0f - c * c) : 0.f;
       dh[r] = live ? d * u : dh[r];
+      su += r < nreal ? v_dpu : 0.f;
+      sc += r < nreal ? v_dpc : 0.f;
       if (rok[r]) {
         XG_STORE(*stp(sd.hprev, (int64_t)t * H * 4, rbh[r]), c_hp[r]);
         XG_STORE(*stp(sd.dxproj, ((int64_t)t * 3 * H + H) * 4, rb3[r]), v_dpu);
@@ -330,6 +340,7 @@ __global__ __launch_bounds__(64 * XNW) void gru_bwd_x3_kernel(const GruArgs a) {
       put3(dpc, PS, i * XLD + j, v_dpc);
       put3(dpg, PS2, i * XLD2 + H + j, v_dpu);
     }
+    if (want_bias) { atomicAdd(&sbias[1][tid], su); atomicAdd(&sbias[2][tid], sc); }
     __builtin_amdgcn_sched_barrier(0);
     fetch_ucd(t - 1);
     __syncthreads();
@@ -342,6 +353,7 @@ __global__ __launch_bounds__(64 * XNW) void gru_bwd_x3_kernel(const GruArgs a) {
         get3(dpc, PS, aoff + 32 * s, af);
         acc = mfma6(af, wct[s], acc);
       }
+      float sr = 0.f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = lq * 4 + r;
@@ -350,12 +362,14 @@ __global__ __launch_bounds__(64 * XNW) void gru_bwd_x3_kernel(const GruArgs a) {
         const float drh = acc[r];
         const float v_dpr = live ? drh * hp * rr * (1.0f - rr) : 0.f;
         dh[r] += live ? drh * rr : 0.f;
+        sr += r < nreal ? v_dpr : 0.f;
         if (rok[r]) {
           XG_STORE(*stp(sd.dxproj, (int64_t)t * 3 * H * 4, rb3[r]), v_dpr);
           XG_STORE(*stp(sd.rh, (int64_t)t * H * 4, rbh[r]), (rr * hp));
         }
         put3(dpg, PS2, i * XLD2 + j, v_dpr);
       }
+      if (want_bias) atomicAdd(&sbias[0][tid], sr);
       __builtin_amdgcn_sched_barrier(0);
       fetch_r(t - 1);
     }
@@ -376,6 +390,15 @@ __global__ __launch_bounds__(64 * XNW) void gru_bwd_x3_kernel(const GruArgs a) {
     };
   step(T - 1);
   for (int t = T - 2; t >= 0; --t) step(t);
+  if (want_bias) {     // the four row groups of a column (lanes lc, lc + 16, lc + 32, lc + 48) in a fixed order
+    float sb_r = sbias[0][tid], sb_u = sbias[1][tid], sb_c = sbias[2][tid];
+    sb_r += __shfl_xor(sb_r, 16, 64); sb_u += __shfl_xor(sb_u, 16, 64); sb_c += __shfl_xor(sb_c, 16, 64);
+    sb_r += __shfl_xor(sb_r, 32, 64); sb_u += __shfl_xor(sb_u, 32, 64); sb_c += __shfl_xor(sb_c, 32, 64);
+    if (lq == 0) {
+      float* o = sd.bias_slab + (int64_t)(blockIdx.x - side * tiles_b) * 3 * H;
+      o[j] = sb_r; o[H + j] = sb_u; o[2 * H + j] = sb_c;
+    }
+  }
 }
 
 }  // namespace
@@ -401,5 +424,8 @@ int score_gru_bwd_x3(GruArgs& a, int nsides, hipStream_t s) {
   dim3 grid(nsides * ((a.B + XRB - 1) / XRB));
   hipLaunchKernelGGL(gru_bwd_x3_kernel, grid, dim3(64 * XNW), 0, s, a);
   SCORE_CHECK_LAUNCH();
+  bool slabs = true;
+  for (int i = 0; i < nsides; ++i) slabs = slabs && a.s[i].bias_slab != nullptr;
+  a.bias_slab_rows = slabs ? (a.B + XRB - 1) / XRB : 0;
   return 0;
 }

@@ -157,7 +157,8 @@ struct PullArgs {
 struct PlanRemapArgs { int32_t* out[6]; int F[6]; int K; int T, TA; };
 int score_launch_plan_unique(const PlanRemapArgs& ra, const uint32_t* keys, const uint32_t* vals, int64_t n,
                              uint32_t* flags_scratch, uint32_t* uid, uint32_t* unique_keys, int32_t* unique_rows,
-                             int32_t* meta, int G, int shift, void* temp, size_t temp_bytes, hipStream_t s);
+                             int32_t* meta, int G, int shift, void* temp, size_t temp_bytes, hipStream_t s,
+                             bool remap = true);
 int score_scan_temp_bytes(int64_t n, size_t* bytes);
 int score_plan_temp_bytes(int64_t n, int end_bit, size_t* bytes);
 int score_launch_plan(const PlanFillArgs& a, int key_bits, uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys_out,
@@ -180,6 +181,8 @@ struct GruSide {
   float* dxproj;                 // [B*T, 3H] pre-activation grads
   float* rh;                     // [B*T, H] r * h_{t-1}
   float* hprev;                  // [B*T, H] h_{t-1}  (+ 3*H*H scratch floats at its end for the fallback)
+  float* bias_slab;              // optional [workgroups of this side][3H]: column sums of the dxproj rows a workgroup wrote
+                                 // (the bias gradients' partial sums; only kernels that report GruArgs.bias_slab_rows fill it)
 };
 struct GruArgs {
   GruSide s[2];
@@ -191,6 +194,7 @@ struct GruArgs {
   // launches per time slice; scratch 10 * B * H floats), x3 = bf16x3 allowed there.  stepwise != 0 forces that path (A/B)
   float* tmp; int64_t tmp_floats; int x3; int stepwise;
   int x3_rec;   // H = 128: the recurrence itself on the bf16 matrix cores, fp32-accurate (gru_x3.hip)
+  int bias_slab_rows;   // out (backward): rows of GruSide.bias_slab written per side, 0 if the kernel that ran does not
 };
 // nprob same-shape GEMMs C_i = op(A_i) op(B_i) in one launch (the two sides of a recurrence step); flags: 4 = C += .
 int score_gemm_same_shape(int trans, int nprob, int M, int N, int K, const float* const* A, int lda,

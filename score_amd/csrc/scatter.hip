@@ -141,7 +141,7 @@ __global__ void plan_remap_kernel(PlanRemapArgs a, const uint32_t* __restrict__ 
 
 int score_launch_plan_unique(const PlanRemapArgs& ra, const uint32_t* keys, const uint32_t* vals, int64_t n,
                              uint32_t* flags_scratch, uint32_t* uid, uint32_t* unique_keys, int32_t* unique_rows,
-                             int32_t* meta, int G, int shift, void* temp, size_t temp_bytes, hipStream_t s) {
+                             int32_t* meta, int G, int shift, void* temp, size_t temp_bytes, hipStream_t s, bool remap) {
   unsigned blocks = (unsigned)cdiv64(n, 256);
   hipLaunchKernelGGL(plan_flags_kernel, dim3(blocks), dim3(256), 0, s, keys, n, flags_scratch);
   SCORE_CHECK_LAUNCH();
@@ -157,6 +157,7 @@ int score_launch_plan_unique(const PlanRemapArgs& ra, const uint32_t* keys, cons
   SCORE_CHECK_LAUNCH();
   hipLaunchKernelGGL(plan_localrow_kernel, dim3(blocks), dim3(256), 0, s, unique_keys, meta, shift, unique_rows);
   SCORE_CHECK_LAUNCH();
+  if (!remap) return 0;          // (only the unique row list was asked for: score_index_plan dedup == 2)
   hipLaunchKernelGGL(plan_remap_kernel, dim3(blocks), dim3(256), 0, s, ra, vals, uid, n);
   SCORE_CHECK_LAUNCH();
   return 0;

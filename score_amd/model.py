@@ -181,6 +181,7 @@ class SCOREBASE(object):
         self._ev_stage = None        # a stage boundary of the backward pass (where the window slice starts)
         self.catchup_events = None   # optional (start, end) torch events around score_adam_catchup_ids (bench.py)
         self._ev_sweep = None
+        self._row_list = None
         self.w = torch.zeros((self.n_w,), **f32)
         self._alloc_optimizer()
         self._ws = {}              # (B, slot) -> (layout, buffer), least recently used first
@@ -431,6 +432,7 @@ class SCOREBASE(object):
             self.table_flags.clamp_(max=1)
         self._flags_marked = False
         self._row_grads = False
+        self._row_list = None        # (the unique-row list of a plan describes THAT backward pass's marks only)
 
     def _begin_row_grads(self):
         self._drop_row_marks()
@@ -568,8 +570,15 @@ class SCOREBASE(object):
             # the event the side stream waits for)
             self._side.wait_event(ev_start if early else self._ev_gather)
             with torch.cuda.stream(self._side):
-                _lib.check(self.lib.score_index_plan(C.byref(self.cfg), C.byref(st), C.byref(db.struct), 1, 0,
-                                                     self._stream()), "score_index_plan")
+                # (dedup = 2: also the list of the batch's unique rows, for score_adam_touched_rows -- the touched-row update
+                #  driven by that list instead of a scan of the table's state bytes.  OFF by default: measured on one box,
+                #  alternating runs (tools/ab_env.sh), the update itself is 8 - 10 us shorter but the three extra plan kernels
+                #  on the side stream cost the input projections / recurrence beside them 16 - 18 us: 1.306 vs 1.298 ms/step.
+                #  SCORE_ADAM_TOUCHED_LIST=1 turns it on.)
+                want_list = self._tiled_on() and bool(os.environ.get("SCORE_ADAM_TOUCHED_LIST"))
+                _lib.check(self.lib.score_index_plan(C.byref(self.cfg), C.byref(st), C.byref(db.struct), 1,
+                                                     2 if want_list else 0, self._stream()), "score_index_plan")
+                row_list = (lay, ws) if want_list else None
                 plan_done = self._side.record_event()
             st.plan_done_event = C.c_void_p(plan_done.cuda_event)
             self._plan_done = plan_done                  # keep the event alive until the backward has run
@@ -585,6 +594,7 @@ class SCOREBASE(object):
             self._launch_sweep(self._side)
         if self.scatter_mode == 0:
             self._begin_row_grads()         # the pull kernels mark what they write; no zero fill
+            self._row_list = row_list       # (the rows they will mark, listed by the plan)
         else:
             self._drop_row_marks()
             self.table_g.zero_()
@@ -711,8 +721,17 @@ class SCOREBASE(object):
             # (only reached with no row lagging: _flush_adam ran, or nothing tiled has happened yet)
             row_step.fill_(int(self.step))
             self._tiled_ready = True
-        _lib.check(self.lib.score_adam_touched(C.byref(T), int(self.step) + 1, self._alpha(lr), self._stream()),
-                   "score_adam_touched")
+        rl, self._row_list = getattr(self, "_row_list", None), None
+        if rl is not None:
+            lay, ws = rl          # (the plan's buffers: its side-stream work is behind the event score_backward waited for)
+            rows = ws[lay.plan_unique_rows:]
+            meta = ws[lay.plan_meta:]
+            _lib.check(self.lib.score_adam_touched_rows(C.byref(T), _ptr(rows), _ptr(meta), int(lay.n_occurrences) + 1,
+                                                        int(self.step) + 1, self._alpha(lr), self._stream()),
+                       "score_adam_touched_rows")
+        else:
+            _lib.check(self.lib.score_adam_touched(C.byref(T), int(self.step) + 1, self._alpha(lr), self._stream()),
+                       "score_adam_touched")
         self._row_grads = False
         self._flags_marked = False
         self._adam_dirty = True

@@ -326,3 +326,27 @@ def test_g6_optimizer_alone_on_the_oracles_gradients(window):
                                 "errors": {"step%d/%s" % k: v for k, v in worst.items()}}) + "\n")
     for (step, k), e in worst.items():
         assert e <= (5e-7 if k == "emb_mtx" else 1e-6), (step, k, e)
+
+
+def test_row_list_and_state_scan_forms_of_the_touched_update_agree(monkeypatch):
+    """score_adam_touched_rows (driven by the plan's unique-row list, SCORE_ADAM_TOUCHED_LIST=1) against score_adam_touched
+    (scan of the state bytes, the default): the same rows get the same update -- bit-identical tables -- also when a
+    backward pass nobody applied sits between two steps"""
+    cfg = so.Cfg(6000, 32, 32, 6, 4, 2, 3, "SCORE")
+    a, b = make(cfg, 5), make(cfg, 5)
+    bs = batches(cfg, 14, 24, seed=11, hot_rows=400)
+    for i, bt in enumerate(bs):
+        monkeypatch.setenv("SCORE_ADAM_TOUCHED_LIST", "1")
+        la = a.train(None, bt, 1e-2, 1e-4)
+        assert a._row_list is None                       # consumed by the step
+        monkeypatch.delenv("SCORE_ADAM_TOUCHED_LIST", raising=False)
+        lb = b.train(None, bt, 1e-2, 1e-4)
+        assert la == lb
+        if i == 6:
+            monkeypatch.setenv("SCORE_ADAM_TOUCHED_LIST", "1")
+            a.forward_backward(bs[0], 1e-4, 1.0)         # marks + a row list that no optimizer step consumes
+            assert a._row_list is not None
+            monkeypatch.delenv("SCORE_ADAM_TOUCHED_LIST", raising=False)
+            b.forward_backward(bs[0], 1e-4, 1.0)
+            assert b._row_list is None
+    assert same_state(a, b)
