@@ -72,6 +72,90 @@ class TemporalGraph(object):
             already permuted.
         The random choices come from `seed`, not from the reference's `random` / `np.random` streams."""
         rng = np.random.Generator(np.random.PCG64(seed))
+        S, U, I = int(time_slice_num), int(n_users), int(n_items)
+        uid, iid, t_idx = (np.asarray(a).astype(np.int64) for a in (uid, iid, t_idx))
+        # Round 3: sort-based CSR instead of one Python list per (entity, slice) cell (21 M lists at Tmall scale).  The
+        # result is the list build's, element for element (tests/test_graph_store.py compares the two and the
+        # reference's own documents): a stable sort keeps the log order inside a cell, and the random choices are drawn
+        # in the list build's order -- cell by cell, a cell's 1-hop shuffle before its 2-hop down-sampling -- by a loop
+        # over the few cells that need one.
+
+        def one_hop(ent0, nbr, n_ent):
+            key = ent0 * S + t_idx
+            order = np.argsort(key, kind="stable")
+            off = np.zeros(n_ent * S + 1, dtype=np.int64)
+            np.cumsum(np.bincount(key, minlength=n_ent * S), out=off[1:])
+            return off, nbr[order].astype(np.int32)
+        uo1, un1 = one_hop(uid - 1, iid, U)
+        io1, in1 = one_hop(iid - U - 1, uid, I)
+
+        def expand(own_off, own_nbr, other_off, other_nbr, other_base, cells):
+            """2-hop candidates of `cells` (sorted cell indices), before down-sampling: (values, degrees, lengths)"""
+            len1 = np.minimum(own_off[cells + 1] - own_off[cells], max_1hop)        # the first max_1hop neighbours
+            tot1 = int(len1.sum())
+            cell_rep = np.repeat(np.arange(len(cells)), len1)
+            pos = np.arange(tot1) - np.repeat(np.cumsum(len1) - len1, len1)
+            x = own_nbr[own_off[cells][cell_rep] + pos].astype(np.int64)
+            oc = (x - other_base) * S + (cells[cell_rep] % S)
+            d = other_off[oc + 1] - other_off[oc]
+            L = np.where(d > 1, np.minimum(d, max_1hop), 0)
+            tot2 = int(L.sum())
+            within = np.arange(tot2) - np.repeat(np.cumsum(L) - L, L)
+            vals = other_nbr[np.repeat(other_off[oc], L) + within]
+            degs = np.repeat(d, L).astype(np.int32)
+            lens = np.bincount(np.repeat(cell_rep, L), minlength=len(cells)).astype(np.int64)
+            return vals, degs, lens
+
+        def two_hop(own_off, own_nbr, other_off, other_nbr, other_base, n_ent):
+            ncell = n_ent * S
+            all_cells = np.arange(ncell, dtype=np.int64)
+            len1 = own_off[1:] - own_off[:-1]
+            over1 = len1 > max_1hop
+            # candidate counts of the cells whose neighbour set is already final (no 1-hop shuffle)
+            _, _, lens = expand(own_off, own_nbr, other_off, other_nbr, other_base, all_cells)
+            special = np.nonzero(over1 | (lens > max_2hop))[0]
+            picks = {}
+            for c in special.tolist():                     # the list build's order of random draws
+                if over1[c]:
+                    seg = own_nbr[own_off[c]:own_off[c + 1]]
+                    seg[:] = seg[rng.permutation(len(seg))]                  # in place, like random.shuffle
+                    lens[c] = expand(own_off, own_nbr, other_off, other_nbr, other_base, np.asarray([c]))[2][0]
+                if lens[c] > max_2hop:
+                    picks[c] = rng.permutation(int(lens[c]))[:max_2hop]
+            vals, degs, lens = expand(own_off, own_nbr, other_off, other_nbr, other_base, all_cells)
+            off = np.zeros(ncell + 1, dtype=np.int64)
+            np.cumsum(lens, out=off[1:])
+            if picks:
+                new_len = lens.copy()
+                for c in picks:
+                    new_len[c] = max_2hop
+                noff = np.zeros(ncell + 1, dtype=np.int64)
+                np.cumsum(new_len, out=noff[1:])
+                src = np.arange(int(off[-1]), dtype=np.int64)
+                cell_of = np.repeat(all_cells, lens)
+                keep = np.ones(len(src), dtype=bool)
+                for c in picks:
+                    keep[off[c]:off[c + 1]] = False
+                dst_idx = np.empty(int(noff[-1]), dtype=np.int64)
+                kept = src[keep]
+                dst_idx[noff[cell_of[keep]] + (kept - off[cell_of[keep]])] = kept
+                for c, idx in picks.items():
+                    dst_idx[noff[c]:noff[c + 1]] = off[c] + idx
+                vals, degs, off = vals[dst_idx], degs[dst_idx], noff
+            return off, vals.astype(np.int32), degs.astype(np.int32)
+        io2, in2, ideg = two_hop(io1, in1, uo1, un1, 1, I)              # items first: the user pass below cuts item lists
+        uo2, un2, udeg = two_hop(uo1, un1, io1, in1, U + 1, U)          # the item pass has already permuted
+        g = cls(U, I, S, dict(off1=uo1, nbr1=un1, off2=uo2, nbr2=un2),
+                dict(off1=io1, nbr1=in1, off2=io2, nbr2=in2), user_rows, item_rows)
+        g.user_degrees, g.item_degrees = udeg, ideg                      # aligned with nbr2 (same offsets)
+        return g
+
+    @classmethod
+    def _from_log_lists(cls, uid, iid, t_idx, n_users, n_items, time_slice_num, user_rows, item_rows,
+                        max_1hop=10, max_2hop=100, seed=11):
+        """The per-cell Python-list form of from_log (rounds 1 - 2), kept as the statement the sort-based build is
+        tested against: same arguments, same result, element for element."""
+        rng = np.random.Generator(np.random.PCG64(seed))
         S, U, I = time_slice_num, n_users, n_items
         u1 = [[] for _ in range(U * S)]
         i1 = [[] for _ in range(I * S)]

@@ -173,3 +173,28 @@ def test_tmall_sample_remap_and_targets():
         first = r["iid"][(r["uid"] == u) & (r["t_idx"] == 9)][0]
         assert its[0] == first and first in g.cell("user", 1, u - 1, 9)
         assert sum(len(g.cell("user", 1, u - 1, t)) for t in range(9)) > 0
+
+
+def test_sort_based_build_equals_the_list_build():
+    """TemporalGraph.from_log (round 3: stable sort + vectorised 2-hop expansion, random draws in the list build's order)
+    against the per-cell Python-list form it replaces (`_from_log_lists`, what rounds 1 - 2 pinned to the reference's
+    documents above): every offset, neighbour and degree equal -- also with cells above max_1hop (shuffled in place,
+    items before users) and 2-hop lists above max_2hop (down-sampled)"""
+    import numpy as np
+    from score_amd.graph import TemporalGraph
+    for U, I, S, n, m1, m2, seed in ((30, 40, 4, 3000, 10, 100, 1), (200, 50, 6, 20000, 10, 100, 2), (50, 8, 3, 6000, 5, 20, 3),
+                                    (600, 900, 11, 9000, 10, 100, 4)):
+        rng = np.random.default_rng(seed)
+        uid = rng.integers(1, U + 1, n)
+        iid = U + 1 + np.minimum((I * rng.random(n) ** 3).astype(np.int64), I - 1)
+        t = rng.integers(0, S, n)
+        ur, ir = np.zeros((U, 3), np.int32), np.zeros((I, 4), np.int32)
+        a = TemporalGraph.from_log(uid, iid, t, U, I, S, ur, ir, m1, m2, seed=5)
+        b = TemporalGraph._from_log_lists(uid, iid, t, U, I, S, ur, ir, m1, m2, seed=5)
+        for side in ("user_csr", "item_csr"):
+            for k in ("off1", "nbr1", "off2", "nbr2"):
+                assert np.array_equal(getattr(a, side)[k], getattr(b, side)[k]), (U, side, k)
+        assert np.array_equal(a.user_degrees, b.user_degrees) and np.array_equal(a.item_degrees, b.item_degrees)
+        over = (np.diff(a.user_csr["off1"]) > m1).sum() + (np.diff(a.item_csr["off1"]) > m1).sum()
+        capped = (np.diff(a.user_csr["off2"]) == m2).sum() + (np.diff(a.item_csr["off2"]) == m2).sum()
+        assert seed == 4 or (over > 0 and capped > 0)            # the random paths were really taken
