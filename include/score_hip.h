@@ -191,18 +191,6 @@ int score_gemm(int32_t trans, int32_t M, int32_t N, int32_t K,
                float keep_prob, const uint8_t* drop_mask, uint64_t drop_seed,
                float* scratch, int64_t scratch_floats, void* stream);
 
-/* C[M,N] = epi(A[M,K] . op(W)) for a WEIGHT operand, fp32-accurate on the bf16 matrix cores (same bf16x3 arithmetic as
- * score_gemm's flag 16) with the weights split once into MFMA fragment order and streamed from L2 -- no LDS staging
- * (gemm_x3w.hip).  An ALTERNATIVE data path for the products against weights (the GRU input projections of
- * score.py:205-208 and their d x); measured slower than score_gemm's LDS-staged kernel on MI355X (the CU's vector L1
- * saturates first, see the file's header), so score_forward / score_backward do not use it.  trans 0: W is [K, N];
- * 1: W is [N, K] (C = A . W^T).  flags: 1 add bias[N], 2 relu.  K must be a multiple of 64, M >= 512 (else
- * SCORE_E_SHAPE: use score_gemm).  scratch: score_gemm_weights_scratch_floats(N, K) floats, 16-B aligned. */
-int score_gemm_weights(int32_t trans, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* W,
-                       int32_t ldw, float* C, int32_t ldc, const float* bias, int32_t flags, float* scratch,
-                       int64_t scratch_floats, void* stream);
-int64_t score_gemm_weights_scratch_floats(int32_t N, int32_t K);
-
 /* tf.nn.dynamic_rnn(GRUCell(H), sequence_length) recurrence (score.py:205-208)
  * given the hoisted input projection xproj [B*T,3H] = x.[Wx_gates|Wx_cand]+bias.
  * Wg/Wc point at the h-rows of gates/kernel [H,2H] and candidate/kernel [H,H].

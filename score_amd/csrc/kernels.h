@@ -200,12 +200,6 @@ struct GruArgs {
 int score_gemm_same_shape(int trans, int nprob, int M, int N, int K, const float* const* A, int lda,
                           const float* const* B, int ldb, float* const* C, int ldc, int flags, int x3, float* scratch,
                           int64_t scratch_floats, hipStream_t s, const float* const* bias = nullptr);   // flags: 1 = + bias[i][N]
-// gemm_x3w.hip: bf16x3 product against a weight operand pre-split into MFMA fragment order (no LDS)
-bool score_x3w_ok(int M, int N, int K, int lda);
-int64_t score_x3w_frag_floats(int N, int K);
-int score_launch_x3w_frag(const float* W, int ldw, int K, int N, int trans, float* out, hipStream_t s);
-int score_launch_gemm_x3w(int n, int M, int N, int K, const float* const* A, int lda, const float* const* Bfrag,
-                          float* const* C, int ldc, const float* const* bias, int flags, hipStream_t s);
 // gru_stream.hip: H = 256 (weights streamed from L2 in MFMA fragment order; tmp holds the fragment copies)
 bool score_gru_stream_ok(int H);
 int64_t score_gru_stream_tmp_floats(int H, int nsides);

@@ -323,39 +323,3 @@ def test_adam_matches_tf_form():
         torch.cuda.synchronize()
         assert np.allclose(dp.cpu().numpy()[:n], params["p"], rtol=1e-6, atol=1e-7)
         assert np.allclose(dm.cpu().numpy()[:n], opt.m["p"], rtol=1e-6, atol=1e-7)   # fma contraction: <= 1 ulp of the operands
-
-
-@pytest.mark.parametrize("trans", [0, 1])
-@pytest.mark.parametrize("shape", [(2048, 384, 448), (20480, 384, 448), (1000, 100, 64), (513, 33, 128), (4096, 448, 384), (777, 768, 384)])
-def test_gemm_weights_x3w_is_fp32_accurate(trans, shape):
-    # the weight-stationary bf16x3 kernel (gemm_x3w.hip: weights pre-split into MFMA fragment order, activations
-    # split in registers, no LDS): SAME error bound as the f32-MFMA and the LDS-staged bf16x3 kernels; row / column
-    # tails (M, N not multiples of the 128 x 128 tile), padding columns untouched
-    lib = _lib.load()
-    M, N, K = shape
-    g = torch.Generator(device="cuda").manual_seed(M + N + K + trans)
-    a = torch.randn((M, K), device="cuda", generator=g) * torch.logspace(-3, 3, K, device="cuda")
-    b = torch.randn((K, N), device="cuda", generator=g)
-    bias = torch.randn((N,), device="cuda", generator=g)
-    W = b if trans == 0 else b.t().contiguous()
-    scratch = torch.empty((int(lib.score_gemm_weights_scratch_floats(N, K)),), device="cuda")
-    assert scratch.numel() > 0
-    ref = a.double() @ b.double()
-    tol = 2e-6 * (a.abs().double() @ b.abs().double()) + 1e-6
-    for flags in (0, 1, 1 | 2):
-        c0 = torch.randn((M, N + 4), device="cuda", generator=g)
-        c = c0.clone()
-        _lib.check(lib.score_gemm_weights(trans, M, N, K, P(a), K, P(W), W.shape[1], P(c), N + 4, P(bias), flags, P(scratch),
-                                          scratch.numel(), stream()), "gemm_weights")
-        torch.cuda.synchronize()
-        want = ref.clone()
-        if flags & 1:
-            want = want + bias.double()
-        if flags & 2:
-            want = want.clamp_min(0)
-        assert torch.equal(c[:, N:], c0[:, N:])
-        err = (c[:, :N].double() - want).abs()
-        assert bool((err <= tol).all()), float((err / tol).max())
-    # shapes it is not built for are refused, not mis-computed
-    assert lib.score_gemm_weights(0, M, N, 100, P(a), K, P(W), W.shape[1], P(c), N + 4, P(bias), 0, P(scratch), scratch.numel(), stream()) == -2
-    assert lib.score_gemm_weights(0, 64, N, K, P(a), K, P(W), W.shape[1], P(c), N + 4, P(bias), 0, P(scratch), scratch.numel(), stream()) == -2

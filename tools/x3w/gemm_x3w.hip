@@ -23,8 +23,19 @@
 //
 // k is dealt so that a 128-byte line of A is consumed whole by two consecutive k-steps: step st = 2*kt + s covers
 // k = 32*kt + 16*kh + 8*s + j (kh = lane >> 5, j = 0..7) -- the fragment builder uses the same map.
-#include "common.h"
-#include "kernels.h"
+#include "../../score_amd/csrc/common.h"
+#include "../../score_amd/csrc/kernels.h"
+// (round 3: out of the product library -- measured slower than the LDS-staged kernel, the step never used it; kept here with
+//  its probes, tools/x3w_probe.py and tools/x3w_strip.py, which build it through tools/x3w_wrap.hip)
+bool score_x3w_ok(int M, int N, int K, int lda);
+int64_t score_x3w_frag_floats(int N, int K);
+int score_launch_x3w_frag(const float* W, int ldw, int K, int N, int trans, float* out, hipStream_t s);
+int score_launch_gemm_x3w(int n, int M, int N, int K, const float* const* A, int lda, const float* const* Bfrag,
+                          float* const* C, int ldc, const float* const* bias, int flags, hipStream_t s);
+extern "C" int score_gemm_weights(int32_t trans, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* W,
+                                  int32_t ldw, float* C, int32_t ldc, const float* bias, int32_t flags, float* scratch,
+                                  int64_t scratch_floats, void* stream);
+extern "C" int64_t score_gemm_weights_scratch_floats(int32_t N, int32_t K);
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
