@@ -184,6 +184,41 @@ static int pack_threads(PyObject* o, const Py_ssize_t* shape, int nd, int32_t* d
   Py_END_ALLOW_THREADS
   return bad;
 }
+/* several tensors in ONE threaded region: the threads are created once for the whole feed tuple (thread creation, ~30 us
+ * each, was most of what eight separate pack() calls with 8 threads cost) and every thread takes its share of the
+ * outermost dimension of every tensor.  status[i] = 0 packed / 1 needs the serial walk. */
+#define LP_MAXT 16
+typedef struct { PyObject** items; const Py_ssize_t* shape; int nd; int32_t* dst; Py_ssize_t n, sub; int status[LP_MAXT]; } lp_tensor;
+typedef struct { lp_tensor* t; int nt, tid, nthreads; } lp_multi;
+static void* lp_multi_thread(void* arg) {
+  lp_multi* m = (lp_multi*)arg;
+  for (int i = 0; i < m->nt; ++i) {
+    lp_tensor* t = &m->t[i];
+    const Py_ssize_t lo = t->n * m->tid / m->nthreads, hi = t->n * (m->tid + 1) / m->nthreads;
+    int st = 0;
+    for (Py_ssize_t r = lo; r < hi && !st; ++r) st = walk_nogil(t->items[r], t->shape + 1, t->nd - 1, t->dst + r * t->sub, t->sub);
+    t->status[m->tid] = st;
+  }
+  return NULL;
+}
+static void pack_many_threads(lp_tensor* t, int nt, int nthreads) {
+  if (nthreads > LP_MAXT) nthreads = LP_MAXT;
+  lp_multi jobs[LP_MAXT];
+  pthread_t th[LP_MAXT];
+  int started[LP_MAXT];
+  Py_BEGIN_ALLOW_THREADS
+  for (int k = 0; k < nthreads; ++k) {
+    jobs[k].t = t; jobs[k].nt = nt; jobs[k].tid = k; jobs[k].nthreads = nthreads;
+    started[k] = 0;
+    if (k > 0) started[k] = pthread_create(&th[k], NULL, lp_multi_thread, &jobs[k]) == 0;
+  }
+  lp_multi_thread(&jobs[0]);
+  for (int k = 1; k < nthreads; ++k) {
+    if (started[k]) pthread_join(th[k], NULL);
+    else lp_multi_thread(&jobs[k]);
+  }
+  Py_END_ALLOW_THREADS
+}
 #else
 #define LISTPACK_NOGIL 0
 static int pack_threads(PyObject* o, const Py_ssize_t* shape, int nd, int32_t* dst, Py_ssize_t total, int nthreads) { return 1; }
@@ -220,7 +255,101 @@ done:
   return res;
 }
 
-static PyMethodDef methods[] = {{"pack", pack, METH_VARARGS, "pack(obj, out, shape, nthreads=1): nested lists -> int32 buffer"}, {NULL, NULL, 0, NULL}};
+/* pack_many(items, nthreads) -- items: a sequence of (obj, out, shape) triples as pack() takes them.  Same results and
+ * errors as calling pack() on each in turn; the large tensors share one threaded region. */
+static PyObject* pack_many(PyObject* self, PyObject* args) {
+  PyObject* seq;
+  int nthreads = 1;
+  if (!PyArg_ParseTuple(args, "O|i", &seq, &nthreads)) return NULL;
+  PyObject* fast = PySequence_Fast(seq, "pack_many: items must be a sequence of (obj, out, shape)");
+  if (!fast) return NULL;
+  const Py_ssize_t n = PySequence_Fast_GET_SIZE(fast);
+  if (n > 16) { Py_DECREF(fast); PyErr_SetString(PyExc_ValueError, "pack_many: at most 16 tensors"); return NULL; }
+  Py_buffer bufs[16];
+  Py_ssize_t shapes[16][8];
+  int nds[16];
+  Py_ssize_t totals[16];
+  PyObject* objs[16];
+  Py_ssize_t got = 0;
+  PyObject* res = NULL;
+  for (; got < n; ++got) {
+    PyObject* it = PySequence_Fast_GET_ITEM(fast, got);
+    PyObject *shape_o, *out_o;
+    if (!PyTuple_Check(it) || PyTuple_GET_SIZE(it) != 3) { PyErr_SetString(PyExc_ValueError, "pack_many: item must be (obj, out, shape)"); goto done; }
+    objs[got] = PyTuple_GET_ITEM(it, 0); out_o = PyTuple_GET_ITEM(it, 1); shape_o = PyTuple_GET_ITEM(it, 2);
+    if (!PyTuple_Check(shape_o)) { PyErr_SetString(PyExc_ValueError, "shape must be a tuple"); goto done; }
+    if (PyObject_GetBuffer(out_o, &bufs[got], PyBUF_WRITABLE | PyBUF_C_CONTIGUOUS) < 0) goto done;
+    const Py_ssize_t nd = PyTuple_GET_SIZE(shape_o);
+    if (nd < 1 || nd > 8) { PyBuffer_Release(&bufs[got]); PyErr_SetString(PyExc_ValueError, "shape must have 1..8 dimensions"); goto done; }
+    Py_ssize_t total = 1;
+    for (Py_ssize_t i = 0; i < nd; ++i) {
+      shapes[got][i] = PyLong_AsSsize_t(PyTuple_GET_ITEM(shape_o, i));
+      if (shapes[got][i] < 0) { PyBuffer_Release(&bufs[got]); if (!PyErr_Occurred()) PyErr_SetString(PyExc_ValueError, "negative dimension"); goto done; }
+      total *= shapes[got][i];
+    }
+    if (bufs[got].len < (Py_ssize_t)(total * sizeof(int32_t)) || ((uintptr_t)bufs[got].buf & 3)) {
+      PyBuffer_Release(&bufs[got]);
+      PyErr_SetString(PyExc_ValueError, "out must be a C-contiguous, 4-byte aligned buffer of at least prod(shape) int32");
+      goto done;
+    }
+    nds[got] = (int)nd; totals[got] = total;
+  }
+  {
+    int threaded[16];
+    for (Py_ssize_t i = 0; i < n; ++i) threaded[i] = 0;
+#if LISTPACK_NOGIL
+    if (nthreads > 1) {
+      lp_tensor ts[16];
+      int map[16], nt = 0;
+      for (Py_ssize_t i = 0; i < n; ++i) {
+        PyObject* o = objs[i];
+        Py_ssize_t len;
+        PyObject** items;
+        if (nds[i] < 2 || totals[i] < 65536) continue;
+        if (PyList_CheckExact(o)) { len = PyList_GET_SIZE(o); items = ((PyListObject*)o)->ob_item; }
+        else if (PyTuple_CheckExact(o)) { len = PyTuple_GET_SIZE(o); items = ((PyTupleObject*)o)->ob_item; }
+        else continue;
+        if (len != shapes[i][0] || len == 0) continue;
+        ts[nt].items = items; ts[nt].shape = shapes[i]; ts[nt].nd = nds[i]; ts[nt].dst = (int32_t*)bufs[i].buf;
+        ts[nt].n = len; ts[nt].sub = totals[i] / len;
+        map[nt++] = (int)i;
+      }
+      if (nt > 0) {
+        const int use = nthreads > LP_MAXT ? LP_MAXT : nthreads;
+        pack_many_threads(ts, nt, use);
+        for (int k = 0; k < nt; ++k) {
+          int bad = 0;
+          for (int q = 0; q < use; ++q) bad |= ts[k].status[q];
+          threaded[map[k]] = !bad;
+        }
+      }
+    }
+#endif
+    for (Py_ssize_t i = 0; i < n; ++i) {
+      if (threaded[i]) continue;
+      int32_t* dst = (int32_t*)bufs[i].buf;
+      if (walk(objs[i], shapes[i], nds[i], &dst) < 0) {
+        /* tell the caller which tensor it was: the exception keeps its type and message, plus the index as an attribute-free note */
+        PyObject *et, *ev, *tb;
+        PyErr_Fetch(&et, &ev, &tb);
+        PyErr_NormalizeException(&et, &ev, &tb);
+        if (ev) { PyObject* idx = PyLong_FromSsize_t(i); if (idx) { PyObject_SetAttrString(ev, "tensor_index", idx); Py_DECREF(idx); } }
+        PyErr_Restore(et, ev, tb);
+        goto done;
+      }
+    }
+  }
+  res = Py_None;
+  Py_INCREF(res);
+done:
+  for (Py_ssize_t i = 0; i < got; ++i) PyBuffer_Release(&bufs[i]);
+  Py_DECREF(fast);
+  return res;
+}
+
+static PyMethodDef methods[] = {{"pack", pack, METH_VARARGS, "pack(obj, out, shape, nthreads=1): nested lists -> int32 buffer"},
+                                {"pack_many", pack_many, METH_VARARGS, "pack_many([(obj, out, shape), ...], nthreads=1)"},
+                                {NULL, NULL, 0, NULL}};
 static struct PyModuleDef moddef = {PyModuleDef_HEAD_INIT, "_listpack", "nested feed lists -> int32", -1, methods};
 PyMODINIT_FUNC PyInit__listpack(void) {
   PyObject* m = PyModule_Create(&moddef);

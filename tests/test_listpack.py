@@ -95,3 +95,31 @@ def test_threaded_walk_equals_serial(lp):
     with pytest.raises(ValueError):
         lp.pack(nested, out, big, 4)
     assert lp.NOGIL_THREADS in (0, 1)
+
+
+def test_pack_many_equals_pack_per_tensor(lp):
+    """pack_many: the whole feed tuple in one call (one threaded region: the threads are created once); results and errors
+    are those of pack() on each tensor, and the exception says which tensor it was"""
+    rng = np.random.default_rng(6)
+    B, T, K = 256, 11, 10
+    arrs = [rng.integers(-2, 1_500_000, (B, T, K, 4)), rng.integers(0, 99, (B, T, K, 3)), rng.integers(0, 9, (B, 3)),
+            rng.integers(0, 2, (B,))]
+    lists = [a.tolist() for a in arrs]
+    lists[0][3][2] = np.zeros((K, 4)).tolist()
+    want = [np.asarray(l).astype(np.int32) for l in lists]
+    for nt in (1, 3, 8, 32):
+        outs = [np.full(a.size, -7, np.int32) for a in arrs]
+        lp.pack_many([(l, o, tuple(a.shape)) for l, o, a in zip(lists, outs, arrs)], nt)
+        assert all(np.array_equal(o.reshape(a.shape), w) for o, a, w in zip(outs, arrs, want)), nt
+    outs = [np.zeros(a.size, np.int32) for a in arrs]
+    ragged = list(lists)
+    ragged[1] = ragged[1][:-1]
+    with pytest.raises(ValueError) as ei:
+        lp.pack_many([(l, o, tuple(a.shape)) for l, o, a in zip(ragged, outs, arrs)], 4)
+    assert ei.value.tensor_index == 1
+    lists[0][200][5][5][1] = 2 ** 40
+    with pytest.raises(OverflowError) as ei:
+        lp.pack_many([(l, o, tuple(a.shape)) for l, o, a in zip(lists, outs, arrs)], 4)
+    assert ei.value.tensor_index == 0
+    with pytest.raises(ValueError):
+        lp.pack_many([(lists[3], np.zeros(3, np.int32), (B,))], 2)          # buffer too small
