@@ -33,7 +33,17 @@ __global__ __launch_bounds__(512, 1) void x3p_kernel(const unsigned short* __res
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];      // two stages
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int bx = blockIdx.x % gx, by = blockIdx.x / gx;
+#ifdef X3P_XCD      // workgroups are dealt round-robin over the 8 XCDs: give every XCD a contiguous run of tiles (x fastest), so
+  int wg;          // the column tiles that stream the same A panel share one L2 (common.h: xcd_tile_coords_n)
+  {
+    const int nwg = (int)gridDim.x, orig = (int)blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+  }
+#else
+  const int wg = (int)blockIdx.x;
+#endif
+  const int bx = wg % gx, by = wg / gx;
   const int bm = by * PBM, bn = bx * PBN;
   const int r31 = lane & 31, kh = lane >> 5;
   const int64_t planeA = (int64_t)M * K, planeB = (int64_t)N * K;
@@ -84,12 +94,21 @@ __global__ __launch_bounds__(512, 1) void x3p_kernel(const unsigned short* __res
     }
 
   const int nt = K / PBK;
+  auto issue_one = [&](int i, int k0, int stage) {
+#ifndef X3P_NOLOAD
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + k0),
+                                     (__attribute__((address_space(3))) void*)(lds + stage * STAGE_BYTES + dst[i]), 16, 0, 0);
+#endif
+  };
   issue(0, 0);
   for (int t = 0; t < nt; ++t) {
     __syncthreads();                       // tile t has landed (the compiler drains the LDS-DMA before the barrier); tile t - 1 is read
+#ifndef X3P_SPREAD
     if (t + 1 < nt) issue((t + 1) * PBK, (t + 1) & 1);
+#endif
     const unsigned char* st = lds + (t & 1) * STAGE_BYTES;
     constexpr int TA[6] = {1, 0, 2, 0, 1, 0}, TB[6] = {1, 2, 0, 1, 0, 0};
+    const bool more = t + 1 < nt;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8 af[2][3], bf[2][3];
@@ -109,12 +128,23 @@ __global__ __launch_bounds__(512, 1) void x3p_kernel(const unsigned short* __res
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j)
+          for (int j = 0; j < 2; ++j) {
 #ifndef X3P_NOMFMA
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][TA[tt]], bf[j][TB[tt]], acc[i][j], 0, 0, 0);
 #else
             acc[i][j][tt] += (float)af[i][TA[tt]][0] * (float)bf[j][TB[tt]][1];
 #endif
+#ifdef X3P_SPREAD      // the next tile's nine LDS-DMA pieces dealt over this tile's 48 MFMA slots (one every five) instead of
+            {          // back to back in front of them: a piece costs its wave 100 - 185 issue cycles inside a busy phase
+              const int g = ks * 24 + tt * 4 + i * 2 + j;
+#ifndef X3P_GAP
+#define X3P_GAP 5
+#endif
+              if (more && g % X3P_GAP == X3P_GAP / 2 && g / X3P_GAP < 9) issue_one(g / X3P_GAP, (t + 1) * PBK, (t + 1) & 1);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+#endif
+          }
     }
   }
 #pragma unroll
