@@ -198,3 +198,53 @@ def test_tmall_scale_two_processes_uneven_batches(tmp_path):
         pref, _, _ = ref.eval(None, per_rank[r][2][0], 1e-4)
         dp_ = np.abs(z[r]["pred"] - np.asarray(pref))
         assert np.median(dp_) < 1e-4 and dp_.max() < 2e-3
+
+
+# ---------------------------------------------------------------------------------------------------
+# Round 3: an out-of-range feature id on ONE rank (tf.nn.embedding_lookup would raise, score.py:51-66).  The index plan
+# of that rank reports it and routes the id to the dummy row; the global loss is NaN on every rank (it is all-reduced),
+# so every rank takes the check together, all-reduces the status words and raises -- nobody is left in a collective.
+# ---------------------------------------------------------------------------------------------------
+def _badid_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    import torch.distributed as dist
+    from oracle import score_oracle as so
+    from score_amd.dist import ShardedSCORE, TorchDistComm
+    from helpers import batch_tuple, random_batch
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg = so.Cfg(*CFG_ARGS, model_type="SCORE")
+    model = ShardedSCORE(*CFG_ARGS, comm=TorchDistComm())
+    model.backend.m.set_params(so.init_params(cfg, 5))
+    good = [random_batch(np.random.default_rng(70 * rank + s), cfg, B) for s in range(3)]
+    for b in good:
+        b["length"][:] = cfg.T
+    msgs = []
+    l0 = model.train(None, batch_tuple(good[0]), 1e-3, 1e-3, keep_prob=1.0)
+    bad = {k: v.copy() for k, v in good[1].items()}
+    if rank == 1:
+        bad["item_2hop"][2, 1, 0, 3] = CFG_ARGS[0] + 5          # only rank 1 feeds it
+        bad["target_user"][0, 0] = -3
+    try:
+        model.train(None, batch_tuple(bad), 1e-3, 1e-3, keep_prob=1.0)
+        msgs.append("no error")
+    except ValueError as e:
+        msgs.append(str(e))
+    l2 = model.train(None, batch_tuple(good[2]), 1e-3, 1e-3, keep_prob=1.0)       # both ranks go on, in step
+    np.savez(os.path.join(out_dir, "bad%d.npz" % rank), l0=l0, l2=l2, msg=np.asarray(msgs[0]),
+             finite=bool(torch.isfinite(model.backend.m.table).all() and torch.isfinite(model.backend.m.w).all()))
+    dist.destroy_process_group()
+
+
+def test_bad_id_on_one_rank_raises_on_every_rank(tmp_path):
+    world = 2
+    mp.spawn(_badid_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    z = [np.load(str(tmp_path / ("bad%d.npz" % r))) for r in range(world)]
+    for r in range(world):
+        msg = str(z[r]["msg"])
+        assert "rank 1" in msg and "(item_2hop)" in msg and "(target_user)" in msg and "rank 0" not in msg, (r, msg)
+        assert np.isfinite(float(z[r]["l0"])) and np.isfinite(float(z[r]["l2"])) and bool(z[r]["finite"])
+    assert float(z[0]["l2"]) == float(z[1]["l2"])          # the same global loss on both ranks after the error
