@@ -33,6 +33,8 @@ for name, defs in variants:
     libs[name] = C.CDLL(so)
 P = lambda t: C.c_void_p(t.data_ptr())
 shapes = [(0, 2, 20480, 384, 448), (2, 2, 448, 384, 20480)]
+if os.environ.get('X3_WM1'):
+    shapes = [(0, 1, 20480, 384, 448), (0, 2, 20480, 384, 448), (1, 1, 18432, 448, 384), (1, 2, 18432, 448, 384)]
 for tr, wm, M, N, K in shapes:
     a = torch.randn((M, K), device="cuda"); b = torch.randn((K, N), device="cuda")
     A = a if tr != 2 else a.t().contiguous(); Bm = b if tr != 1 else b.t().contiguous()
