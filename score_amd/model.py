@@ -273,6 +273,16 @@ class SCOREBASE(object):
         stop = threading.Event()
         END = object()
 
+        def hand_over(item):
+            """False once the consumer has left (it drains the queue then: nothing may block on it for ever)"""
+            while not stop.is_set():
+                try:
+                    q.put(item, timeout=0.1)
+                    return True
+                except queue.Full:
+                    pass
+            return False
+
         def work():
             try:
                 torch.cuda.set_device(self.device)
@@ -280,18 +290,11 @@ class SCOREBASE(object):
                 with torch.cuda.stream(st):
                     for b in batches:
                         db = self.device_batch(b)
-                        item = (db, st.record_event())
-                        while not stop.is_set():
-                            try:
-                                q.put(item, timeout=0.1)
-                                break
-                            except queue.Full:
-                                pass
-                        if stop.is_set():
+                        if not hand_over((db, st.record_event())):
                             return
-                q.put((END, None))
+                hand_over((END, None))
             except BaseException as e:              # handed to the consumer, raised there
-                q.put((e, None))
+                hand_over((e, None))
         t = threading.Thread(target=work, name="score-feed", daemon=True)
         t.start()
         try:
