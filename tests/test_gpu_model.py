@@ -463,3 +463,43 @@ def test_feed_prefetcher_and_threaded_list_walk_give_the_same_steps():
     import time
     time.sleep(0.3)
     assert not [t for t in threading.enumerate() if t.name == "score-feed" and t.is_alive()]
+
+
+EXTREMES = [
+    # (N, D, H, T, K, Fu, Fi, B, model type): the corners of what include/score_hip.h admits
+    (40, 4, 8, 1, 1, 1, 1, 1, "SCORE"),          # one sample, one slice, one neighbour, one feature, the smallest D
+    (300, 8, 16, 2, 32, 2, 3, 2, "SCORE"),       # K = 32 (the largest), one target line
+    (500, 256, 32, 3, 4, 1, 1, 5, "SCORE"),      # D = 256 with F = 1 (F * D / 4 = 64 slots)
+    (400, 32, 64, 4, 3, 8, 8, 6, "SCORE"),       # F = 8 on both sides (F * D / 4 = 64)
+    (300, 12, 24, 9, 7, 3, 2, 33, "RCA"),        # D not a power of two, odd batch, Fu > Fi
+    (300, 20, 40, 5, 20, 2, 2, 17, "RIA"),       # K = 20 (the 20-wide instantiation), H = 40 (no register-resident recurrence)
+    (200, 16, 32, 12, 2, 1, 5, 9, "RRN"),        # the CCMR feature split on the slice baseline
+]
+
+
+@pytest.mark.parametrize("N,D,H,T,K,Fu,Fi,B,mt", EXTREMES)
+def test_extreme_shapes_vs_oracle(N, D, H, T, K, Fu, Fi, B, mt):
+    """gradients of one pass, two TF-Adam steps and the predictions against the oracle at the corners of the shape space
+    (every kernel family has its own instantiations, fall-backs and clamps there)"""
+    cfg = so.Cfg(N, D, H, T, K, Fu, Fi, mt)
+    rng = np.random.default_rng(N + K)
+    P = so.init_params(cfg, 8)
+    b = random_batch(rng, cfg, B)
+    m = make_model(cfg, P)
+    om = so.OracleModel(N, D, H, T, K, Fu, Fi, mt, params={k: v.copy() for k, v in P.items()})
+    m.forward_backward(batch_tuple(b), 0.0, 1.0)
+    g = m.get_grads()
+    _, go = so.loss_and_grads(cfg, P, b, 0.0)
+    for k in go:
+        ok, err = close(g[k].reshape(np.asarray(go[k]).shape), go[k], rtol=3e-4, atol=2e-6)
+        assert ok, (k, err)
+    for _ in range(2):
+        lg = m.train(None, batch_tuple(b), 1e-3, 1e-4, keep_prob=1.0)
+        lo = om.train(None, batch_tuple(b), 1e-3, 1e-4, keep_prob=1.0)
+        assert abs(lg - lo) < 2e-5 * max(1.0, abs(lo))
+    pg, lab, _ = m.eval(None, batch_tuple(b), 1e-4)
+    po, _, _ = om.eval(None, batch_tuple(b), 1e-4)
+    assert lab == b["label"].tolist() and np.abs(np.asarray(pg) - np.asarray(po)).max() < LOGIT_TOL
+    # the nested-list form of the same batch (threaded walk) gives the same predictions
+    pl, _, _ = m.eval(None, tuple(a.tolist() for a in batch_tuple(b)), 1e-4)
+    assert pl == pg
