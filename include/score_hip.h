@@ -359,6 +359,13 @@ int64_t score_segment_sum_scratch_bytes(int64_t n, int32_t D);
  * rows already in state 2 are added to, every row touched ends in state 2 (score_adam_rows). */
 int score_rows_accumulate(const int32_t* rows, const float* src, int64_t n, int32_t D, int64_t n_out_rows,
                           float* out, uint8_t* row_flags, void* stream);
+/* All source ranks in ONE launch: rows / src hold the sources' lists back to back, source p at [offsets[p], offsets[p+1])
+ * (offsets: HOST array of n_sources + 1 entries, offsets[0] = 0; n_sources <= 64), every list unique and ascending (what
+ * score_index_plan's unique-row lists are).  The result is bit for bit that of n_sources score_rows_accumulate calls in
+ * source order: the slot of the lowest source that names a row adds the later sources' rows in source order (binary search
+ * per list) and stores once. */
+int score_rows_accumulate_multi(const int32_t* rows, const float* src, const int64_t* offsets, int32_t n_sources, int32_t D,
+                                int64_t n_out_rows, float* out, uint8_t* row_flags, void* stream);
 
 /* Forward of SCORE / RIA / RCA / SCORE_USER / SCORE_ITEM (score.py:188-369) +
  * build_fc_net / build_logloss / build_l2norm (:68-94).  keep_prob 1.0 = eval

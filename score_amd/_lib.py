@@ -109,6 +109,7 @@ _SIGS = {
                                C.c_void_p],
     "score_segment_sum_scratch_bytes": [C.c_int64, C.c_int32],
     "score_rows_accumulate": [c_i, c_f, C.c_int64, C.c_int32, C.c_int64, c_f, C.c_void_p, C.c_void_p],
+    "score_rows_accumulate_multi": [c_i, c_f, C.POINTER(C.c_int64), C.c_int32, C.c_int32, C.c_int64, c_f, C.c_void_p, C.c_void_p],
     "score_auc_logloss": [c_f, c_i, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p],
     "score_auc_scratch_bytes": [C.c_int64],
     "score_ranking_quality": [c_f, c_i, C.c_int64, C.c_int32, c_f, c_i, c_f, C.c_int64, C.c_void_p],

@@ -528,6 +528,70 @@ extern "C" int score_rows_accumulate(const int32_t* rows, const float* src, int6
   return 0;
 }
 
+// The same for ALL source ranks in one launch.  rows = the sources' lists back to back (source p: [off[p], off[p+1]),
+// each list unique and ASCENDING -- they are segments of score_index_plan's unique-row lists).  The slot of the LOWEST
+// source that names a row owns the row: it adds the later sources' contributions in source order (a binary search per
+// later list) and stores once -- the association ((g_p0 + g_p1) + g_p2) ... of the per-source launches, so the result is
+// the same bits; slots whose row an earlier source names do nothing.  Eight ranks: one launch instead of eight.
+#define ACC_MAX_SOURCES 64
+struct AccMultiArgs { int64_t off[ACC_MAX_SOURCES + 1]; int n_sources; };
+__device__ __forceinline__ int64_t acc_find(const int32_t* __restrict__ rows, int64_t lo, int64_t hi, int32_t r) {
+  while (lo < hi) {                        // first index in [lo, hi) with rows[idx] >= r
+    const int64_t mid = (lo + hi) >> 1;
+    if (rows[mid] < r) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+__global__ __launch_bounds__(256) void rows_accumulate_multi_kernel(const AccMultiArgs a, const int32_t* __restrict__ rows,
+                                                                    const float* __restrict__ src, int D, int LPR,
+                                                                    float* __restrict__ out, uint8_t* __restrict__ flags) {
+  const int gpb = blockDim.x / LPR;
+  const int64_t i = (int64_t)blockIdx.x * gpb + threadIdx.x / LPR;
+  const int ch4 = (threadIdx.x % LPR) * 4;
+  const int64_t n = a.off[a.n_sources];
+  if (i >= n) return;
+  int p = 0;
+  while (p + 1 < a.n_sources && i >= a.off[p + 1]) ++p;
+  const int32_t r = rows[i];
+  for (int q = 0; q < p; ++q) {            // an earlier source names the row: that slot sums it
+    const int64_t j = acc_find(rows, a.off[q], a.off[q + 1], r);
+    if (j < a.off[q + 1] && rows[j] == r) return;
+  }
+  if (ch4 >= D) return;
+  float4 v = ld4(src + i * D + ch4);
+  for (int q = p + 1; q < a.n_sources; ++q) {
+    const int64_t j = acc_find(rows, a.off[q], a.off[q + 1], r);
+    if (j < a.off[q + 1] && rows[j] == r) v = add4(v, ld4(src + j * D + ch4));
+  }
+  const uint8_t f = flags[r];
+  if (f == 2) v = add4(ld4(out + (int64_t)r * D + ch4), v);      // (a row already written this step by an earlier call)
+  st4(out + (int64_t)r * D + ch4, v);
+  if (ch4 == 0 && f != 2) flags[r] = 2;
+}
+
+extern "C" int score_rows_accumulate_multi(const int32_t* rows, const float* src, const int64_t* offsets, int32_t n_sources,
+                                           int32_t D, int64_t n_out_rows, float* out, uint8_t* row_flags, void* stream) {
+  if (!rows || !src || !offsets || !out || !row_flags || n_sources < 1 || n_sources > ACC_MAX_SOURCES || D <= 0 || (D & 3) ||
+      D > 256 || n_out_rows <= 0)
+    return SCORE_E_BADARG;
+  AccMultiArgs a;
+  for (int p = 0; p <= n_sources; ++p) {
+    a.off[p] = offsets[p];
+    if (p && offsets[p] < offsets[p - 1]) return SCORE_E_BADARG;
+  }
+  if (a.off[0] != 0) return SCORE_E_BADARG;
+  a.n_sources = n_sources;
+  const int64_t n = a.off[n_sources];
+  if (n == 0) return 0;
+  int LPR = 1;
+  while (LPR < D / 4) LPR <<= 1;
+  const int gpb = 256 / LPR;
+  hipLaunchKernelGGL(rows_accumulate_multi_kernel, dim3((unsigned)cdiv64(n, gpb)), dim3(256), 0, (hipStream_t)stream, a, rows,
+                     src, D, LPR, out, row_flags);
+  SCORE_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int64_t score_segment_sum_scratch_bytes(int64_t n, int32_t D) {
   size_t sort_bytes = 0;
   if (score_plan_temp_bytes(n > 0 ? n : 1, 32, &sort_bytes) != 0) return -1;

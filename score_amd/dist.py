@@ -373,6 +373,15 @@ class HipBackend(object):
         m._begin_row_grads()
         if counts is None:
             counts = [req_rows.numel()]
+        if len(counts) > 1 and len(counts) <= 64 and not os.environ.get("SCORE_ACCUMULATE_PER_SOURCE"):
+            # every source rank's list in one launch (the lists are unique and ascending: segments of the plans' unique-row
+            # lists); the same bits as one launch per source in rank order, which at eight ranks were eight small launches
+            # in a row on the chain the next step's rows wait for
+            offs = (C.c_int64 * (len(counts) + 1))(*np.concatenate([[0], np.cumsum([int(c) for c in counts])]).tolist())
+            rc = self.lib.score_rows_accumulate_multi(_ptr(req_rows), _ptr(grads_in), offs, len(counts), self.D,
+                                                      m._tbl.shape[0], _ptr(m.table_g), _ptr(m.table_flags), m._stream())
+            _lib.check(rc, "score_rows_accumulate_multi")
+            return
         off = 0
         for c in counts:
             c = int(c)

@@ -253,6 +253,50 @@ def test_rows_accumulate_op():
     assert lib.score_rows_accumulate(p(drows), p(src), 4, 6, R, p(out), p(flags), st) != 0   # D % 4
 
 
+@pytest.mark.parametrize("G,D", [(2, 16), (3, 24), (8, 64), (5, 128)])
+def test_rows_accumulate_multi_equals_per_source_calls(G, D):
+    """score_rows_accumulate_multi -- every source rank's (unique, ascending) row list in ONE launch -- against one
+    score_rows_accumulate per source in rank order: the same bits in the rows, the same state bytes; rows nobody names
+    untouched; an empty source and a row named by every source included"""
+    import ctypes as C
+    from score_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(G * 100 + D)
+    R = 5000
+    p = lambda t: C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    lists = []
+    for q in range(G):
+        n = 0 if (G > 2 and q == 1) else int(rng.integers(200, 1800))
+        rows = np.sort(rng.choice(R - 1, n, replace=False) + 1).astype(np.int32)
+        if n:
+            rows = np.unique(np.concatenate([rows, [R - 1]])).astype(np.int32)        # a row every (non-empty) source names
+        lists.append(rows)
+    rows_all = torch.from_numpy(np.concatenate(lists)).cuda()
+    src = torch.from_numpy(rng.standard_normal((rows_all.numel(), D)).astype(np.float32)).cuda()
+    offs = np.concatenate([[0], np.cumsum([len(l) for l in lists])])
+    outs, flagss = [], []
+    for mode in ("per-source", "multi"):
+        out = torch.full((R, D), 7.0, device="cuda")
+        flags = torch.zeros((R,), dtype=torch.uint8, device="cuda")
+        flags[::3] = 1
+        if mode == "per-source":
+            for q in range(G):
+                a, b = int(offs[q]), int(offs[q + 1])
+                if b > a:
+                    assert lib.score_rows_accumulate(p(rows_all[a:b]), p(src[a:b]), b - a, D, R, p(out), p(flags), st) == 0
+        else:
+            o = (C.c_int64 * (G + 1))(*offs.tolist())
+            assert lib.score_rows_accumulate_multi(p(rows_all), p(src), o, G, D, R, p(out), p(flags), st) == 0
+        torch.cuda.synchronize()
+        outs.append(out); flagss.append(flags)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(flagss[0], flagss[1])
+    named = np.zeros(R, bool); named[np.concatenate(lists)] = True
+    assert bool((outs[1][torch.from_numpy(~named).cuda()] == 7.0).all()) and int((flagss[1] == 2).sum()) == int(named.sum())
+    bad = (C.c_int64 * 3)(0, 5, 3)
+    assert lib.score_rows_accumulate_multi(p(rows_all), p(src), bad, 2, D, R, p(outs[1]), p(flagss[1]), st) != 0     # offsets must ascend
+
+
 def test_segment_sum_rows_op():
     import ctypes as C
     from score_amd import _lib
