@@ -24,6 +24,7 @@ import torch
 from . import _lib
 
 ADAM_B1, ADAM_B2, ADAM_EPS = 0.9, 0.999, 1e-8      # tf.train.AdamOptimizer defaults
+_NO_PIN = bool(os.environ.get("SCORE_NO_STREAM_PIN"))       # A/B: look the current stream up at every use again
 BATCH_FIELDS = ("user_1hop", "user_2hop", "item_1hop", "item_2hop",
                 "target_user", "target_item", "label", "length")
 
@@ -199,6 +200,7 @@ class SCOREBASE(object):
         self._ev_stage = None        # a stage boundary of the backward pass (where the window slice starts)
         self.catchup_events = None   # optional (start, end) torch events around score_adam_catchup_ids (bench.py)
         self._ev_sweep = None
+        self._pinned_stream = self._pinned_handle = None
         self._row_list = None
         self.w = torch.zeros((self.n_w,), **f32)
         self._alloc_optimizer()
@@ -526,8 +528,49 @@ class SCOREBASE(object):
         for e in self.fwd_events + self.bwd_events:
             e.record()          # forces creation of the underlying hipEvent_t
 
+    def _cur(self):
+        """torch.cuda.current_stream(self.device), looked up once per public call: the query costs ~4 us of Python and a
+        training step asked for it eleven times (the small shapes are host-bound).  `_pinned_stream` is set by the
+        entry points below for the duration of one call; a `with torch.cuda.stream(...)` block inside clears it."""
+        c = self._pinned_stream
+        return c if c is not None else torch.cuda.current_stream(self.device)
+
     def _stream(self):
+        c = self._pinned_stream
+        if c is not None:
+            return self._pinned_handle
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    class _Pin(object):
+        """context: look the current stream up once and hold it for the calls inside"""
+
+        def __init__(self, m):
+            self.m = m
+
+        def __enter__(self):
+            m = self.m
+            self.prev = (m._pinned_stream, m._pinned_handle)
+            if m._pinned_stream is None and not _NO_PIN:
+                cur = torch.cuda.current_stream(m.device)
+                m._pinned_stream, m._pinned_handle = cur, C.c_void_p(cur.cuda_stream)
+            return m
+
+        def __exit__(self, *a):
+            self.m._pinned_stream, self.m._pinned_handle = self.prev
+
+    class _Unpin(object):
+        """context: inside a `with torch.cuda.stream(other)` block the current stream is the other one"""
+
+        def __init__(self, m):
+            self.m = m
+
+        def __enter__(self):
+            m = self.m
+            self.prev = (m._pinned_stream, m._pinned_handle)
+            m._pinned_stream = m._pinned_handle = None
+
+        def __exit__(self, *a):
+            self.m._pinned_stream, self.m._pinned_handle = self.prev
 
     def device_batch(self, batch_data):
         return batch_data if isinstance(batch_data, DeviceBatch) else DeviceBatch(self, batch_data)
@@ -567,9 +610,13 @@ class SCOREBASE(object):
     def forward_backward(self, batch_data, reg_lambda, keep_prob=1.0, dropout_masks=None):
         """Forward + backward; gradients land in self.w_g (without the L2 term) and
         self.table_g (dense [N,D]).  Returns the device workspace layout/buffer."""
+        with self._Pin(self):
+            return self._forward_backward(batch_data, reg_lambda, keep_prob, dropout_masks)
+
+    def _forward_backward(self, batch_data, reg_lambda, keep_prob, dropout_masks):
         db = self.device_batch(batch_data)
         plan_done = None
-        cur = torch.cuda.current_stream(self.device)
+        cur = self._cur()
         if self.scatter_mode == 0:
             if self._side is None:
                 self._side = torch.cuda.Stream(device=self.device)
@@ -592,7 +639,7 @@ class SCOREBASE(object):
             # (its workspace regions are its own; the previous step's scatter, their last reader, is behind
             # the event the side stream waits for)
             self._side.wait_event(ev_start if early else self._ev_gather)
-            with torch.cuda.stream(self._side):
+            with torch.cuda.stream(self._side), self._Unpin(self):
                 # (dedup = 2: also the list of the batch's unique rows, for score_adam_touched_rows -- the touched-row update
                 #  driven by that list instead of a scan of the table's state bytes.  OFF by default: measured on one box,
                 #  alternating runs (tools/ab_env.sh), the update itself is 8 - 10 us shorter but the three extra plan kernels
@@ -649,12 +696,13 @@ class SCOREBASE(object):
     def apply_adam(self, lr, reg_lambda):
         """tf.train.AdamOptimizer(lr).minimize(loss) update (score.py:96-99): dense over the
         whole table (the emb_mtx*mask gradient is dense) and over every dense variable."""
-        if self._tiled_on() and self._row_grads:
-            self._adam_table_tiled(lr)
-        else:
-            self.adam_table(lr)
-        self.adam_dense(lr, reg_lambda)
-        self.adam_advance()
+        with self._Pin(self):
+            if self._tiled_on() and self._row_grads:
+                self._adam_table_tiled(lr)
+            else:
+                self.adam_table(lr)
+            self.adam_dense(lr, reg_lambda)
+            self.adam_advance()
 
     # ------------------------------------------------------------------ time-tiled table optimizer
     _tiled_supported = True          # (a subclass may opt out)
@@ -694,7 +742,7 @@ class SCOREBASE(object):
             if ev:
                 ev[0].record(); ev[1].record()
             return
-        cur = torch.cuda.current_stream(self.device)
+        cur = self._cur()
         self._join_sweep(cur)
         if self._flags_marked:
             self._drop_row_marks()        # (a backward nobody applied left state-2 marks)
@@ -722,7 +770,7 @@ class SCOREBASE(object):
         lo, hi, upto, after = self._pending_sweep
         self._pending_sweep = None
         _, _, T = self._tiled
-        cur = torch.cuda.current_stream(self.device)
+        cur = self._cur()
         other = stream.cuda_stream != cur.cuda_stream       # (current_stream() returns a new wrapper object every call)
         if other:
             stream.wait_event(after)
@@ -736,7 +784,7 @@ class SCOREBASE(object):
         (On the main stream: behind the row-gradient event on the side stream, beside the weight-gradient products,
         it slowed those by what it saved -- bwd_weight_grads 0.180 -> 0.246 ms, profiles/r02_probes.md.)"""
         row_step, ring, T = self._tiled_table()
-        cur = torch.cuda.current_stream(self.device)
+        cur = self._cur()
         # this step's window slice first: it must not see a row half-way through its first update (state 0 -> 2 -> 1
         # with row_step still unset); it finished long ago (it runs beside the forward)
         self._join_sweep(cur)
@@ -767,7 +815,7 @@ class SCOREBASE(object):
         self._adam_dirty = False
         self._pending_sweep = None
         _, ring, T = self._tiled
-        cur = torch.cuda.current_stream(self.device)
+        cur = self._cur()
         self._join_sweep(cur)
         # (rows in state 2 -- a gradient not applied yet -- are left alone, marks and all: they were brought up to
         #  date before the forward that produced the gradient, and the update that follows still needs the marks)
@@ -822,8 +870,9 @@ class SCOREBASE(object):
         """One training step; returns the loss as a 0-d device tensor (no host sync)."""
         if self._graph_on and dropout_masks is None and self.scatter_mode == 0 and not self.fwd_events:
             return self._train_captured(batch_data, lr, reg_lambda, keep_prob)
-        lay, ws = self.forward_backward(batch_data, reg_lambda, keep_prob, dropout_masks)
-        self.apply_adam(lr, reg_lambda)
+        with self._Pin(self):
+            lay, ws = self.forward_backward(batch_data, reg_lambda, keep_prob, dropout_masks)
+            self.apply_adam(lr, reg_lambda)
         return ws[lay.loss]
 
     # ------------------------------------------------------------------ captured step (hipGraph)
@@ -927,12 +976,14 @@ class SCOREBASE(object):
         """eval without the host round trip: (y_pred [B] device view of the workspace -- copy it before the next
         forward --, labels [B] device int32, loss 0-d device tensor)."""
         db = self.device_batch(batch_data)
-        lay, ws, _ = self._forward(db, reg_lambda, 1.0, None)
+        with self._Pin(self):
+            lay, ws, _ = self._forward(db, reg_lambda, 1.0, None)
         return ws[lay.y_pred:lay.y_pred + db.B], db.tensors[6], ws[lay.loss]
 
     def eval(self, sess, batch_data, reg_lambda):
         db = self.device_batch(batch_data)
-        lay, ws, _ = self._forward(db, reg_lambda, 1.0, None)
+        with self._Pin(self):
+            lay, ws, _ = self._forward(db, reg_lambda, 1.0, None)
         B = db.B
         pred = ws[lay.y_pred:lay.y_pred + B].cpu().numpy()
         label = db.tensors[6].cpu().numpy()
