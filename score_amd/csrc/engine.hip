@@ -766,6 +766,10 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
       G(colsum_queue_add(&cq, ws + w.dq, B, d.Dk, d.Dk, gw + P.at_b[0], 0));
       G(gemm_mode_call(x3, 1, B, d.Dq, d.Dk, ws + w.dq, d.Dk, W + P.at_w[0], d.Dk, ws + w.dquery, d.Dq, nullptr, 0, 1.f,
                        nullptr, 0, scratch2, SF, qs));
+      // d query is what the main stream needs from here (target_bwd_kernel): its own event, so that the wait there does not
+      // also sit behind the weight-gradient products and column sums that follow on this stream (at the small shapes the
+      // side chain is as long as the main one: the scatter stage waited ~30 us for it)
+      if (q_on_side) HIPTRY(hipEventRecord(side->wx, side->st));
       if (!q_on_side) {       // dq is final on the main stream: the side stream (its weight-gradient product) follows it
         HIPTRY(hipEventRecord(side->fork, s));
         HIPTRY(hipStreamWaitEvent(side->st, side->fork, 0));
@@ -863,7 +867,7 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
     if (atomic || d.coattn)   // RCA in pull mode has nothing to prepare: every row gradient is G itself
       G(score_coattn_bwd_multi(ca, 2, d.D, B, dWs, ws + w.ca_slab, w.ca_slab_floats, atomic ? 1 : 0, &cq, s));
   }
-  if (side && d.attn && st->scatter_mode != 2) HIPTRY(hipStreamWaitEvent(s, side->join, 0));   // d query comes from the side stream
+  if (side && d.attn && st->scatter_mode != 2) HIPTRY(hipStreamWaitEvent(s, side->wx, 0));     // d query comes from the side stream
   G(score_launch_target_bwd(grad_table, d.D, d.Fu, d.Fi, B, T, bt->target_user, bt->target_item,
                             d.attn ? ws + w.dquery : nullptr, d.Dq, ws + w.dhead, d.Dhead, d.off_ti, d.off_tu,
                             ws + w.query, d.coattn ? W + P.ca_w[0] : nullptr, d.coattn ? W + P.ca_w[1] : nullptr,
