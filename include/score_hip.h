@@ -191,6 +191,17 @@ int score_gemm(int32_t trans, int32_t M, int32_t N, int32_t K,
                float keep_prob, const uint8_t* drop_mask, uint64_t drop_seed,
                float* scratch, int64_t scratch_floats, void* stream);
 
+/* The same-shape products of `ngroups` (<= 4) independent problems C_i[M,N] = A_i[M,K] . op(B_i) (+ bias_i[N]) in ONE launch
+ * on the bf16 matrix cores, fp32-accurate (bf16x3), with a whole-N output panel per workgroup: the form the GRU input
+ * projections of the two sides (score.py:205-208) and their input gradients take at cfg-3's sizes (csrc/gemm_panel.hip).
+ * trans_b: 0 = B_i[K,N], 1 = B_i[N,K] (C = A . B^T).  `images` is scratch for the weights' MFMA-fragment images,
+ * ngroups * K/32 * 8*ceil(N/128) * 768 floats.  Shapes it does not cover (N % 16, N <= 256 or > 512, K % 32, ld % 4, too few
+ * rows to fill the chip) return SCORE_E_SHAPE: use score_gemm. */
+int score_gemm_panel_products(int32_t trans_b, int32_t ngroups, int32_t M, int32_t N, int32_t K,
+                              const float* const* A, int32_t lda, const float* const* Bm, int32_t ldb,
+                              float* const* C, int32_t ldc, const float* const* bias,
+                              float* images, int64_t image_floats, void* stream);
+
 /* tf.nn.dynamic_rnn(GRUCell(H), sequence_length) recurrence (score.py:205-208)
  * given the hoisted input projection xproj [B*T,3H] = x.[Wx_gates|Wx_cand]+bias.
  * Wg/Wc point at the h-rows of gates/kernel [H,2H] and candidate/kernel [H,H].

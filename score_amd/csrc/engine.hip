@@ -145,6 +145,7 @@ struct WS {
   int64_t n_occ, sort_temp_bytes, partial_floats;
   int64_t uid, unique_rows, meta, remap[6];
   int64_t ca_slab, ca_slab_floats, cs_part, cs_part_floats, wxcat;
+  int64_t pimg_x[2], pimg_d[2];      // weight fragment images of the panel GEMMs (gemm_panel.hip): projection, input gradient
   int64_t scratch_floats, total;
 };
 
@@ -195,6 +196,10 @@ void build_ws(const Dims& d, int B, WS* w) {
   w->cs_part_floats = 1 << 21;
   w->cs_part = take(w->cs_part_floats);
   w->wxcat = take(2 * (int64_t)(d.I + 1) * 3 * d.H);
+  for (int sd = 0; sd < 2; ++sd) {
+    w->pimg_x[sd] = take(score_gemm_panel_image_floats(3 * d.H, d.Is[sd]));
+    w->pimg_d[sd] = take(score_gemm_panel_image_floats(d.Is[sd], 3 * d.H));
+  }
   w->dgstage = take((int64_t)B * d.Dhead);
   w->scratch2 = take(w->scratch_floats);           // split-K scratch of the side stream's products
   // scratch of the recurrences without a register-resident kernel: MFMA-fragment weight copies (H = 256) or the
@@ -280,11 +285,11 @@ static int side_stream(const score_state_t* st, SideStream** out) {
   return 0;
 }
 // A/B switches of the launch sequence, read from the environment ONCE (first call), not per step
-struct EnvFlags { bool head_unfused, attn_tail_unfused, wgrad_side, gru_stepwise, attn_fwd_unfused, gru_bias_colsum; };
+struct EnvFlags { bool head_unfused, attn_tail_unfused, wgrad_side, gru_stepwise, attn_fwd_unfused, gru_bias_colsum, gemm_tiled, wgrad_late, panel_dx; };
 static bool env_on(const char* name) { const char* v = getenv(name); return v && *v && !(v[0] == '0' && !v[1]); }   // (set, not empty, not "0")
 static const EnvFlags& env_flags() {
   static const EnvFlags f = {env_on("SCORE_HEAD_UNFUSED"), env_on("SCORE_ATTN_TAIL_UNFUSED"), env_on("SCORE_WGRAD_SIDE"),
-                             env_on("SCORE_GRU_STEPWISE"), env_on("SCORE_ATTN_FWD_UNFUSED"), env_on("SCORE_GRU_BIAS_COLSUM")};
+                             env_on("SCORE_GRU_STEPWISE"), env_on("SCORE_ATTN_FWD_UNFUSED"), env_on("SCORE_GRU_BIAS_COLSUM"), env_on("SCORE_GEMM_TILED"), env_on("SCORE_WGRAD_LATE"), env_on("SCORE_PANEL_DX")};
   return f;
 }
 #define HIPTRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return (int)e_; } while (0)
@@ -428,6 +433,19 @@ extern "C" int score_index_plan(const score_config_t* cfg, const score_state_t* 
   return 0;
 }
 
+// do the two sides' GRU input projections (which = 0) / their input gradients (which = 1) take the panel form?  Same
+// answer in the forward pass (which writes the weight images) and in the backward pass (which uses them).
+// The input gradients: only with SCORE_PANEL_DX=1.  The kernel itself is 30 % faster there too (71 vs 101 us), but a panel
+// workgroup owns its CU (8 waves x 256 registers), and the backward pass has ~350 us of other streams' work to place --
+// the side stream's query branch and early weight gradients, the optimizer's window slice -- which the tiled kernel lets
+// run beside it and the panel kernel pushes into the co-attention backward and the scatter (0.254 -> 0.329 ms), or, with the
+// recurrences' weight gradients moved in front of those, into them (1.287 -> 1.285 ms/step; forward only: 1.273).
+static bool panel_gemms(const Dims& d, const score_state_t* st, int BT, int which) {
+  if (st->gemm_mode != 1 || env_flags().gemm_tiled || d.Is[0] != d.Is[1]) return false;
+  return which == 0 ? score_gemm_panel_ok(2, BT, 3 * d.H, d.Is[0], d.I, 3 * d.H, nullptr)
+                    : env_flags().panel_dx && score_gemm_panel_ok(2, BT, d.Is[0], 3 * d.H, 3 * d.H, d.I, nullptr);
+}
+
 extern "C" int score_forward(const score_config_t* cfg, const score_state_t* st, const score_batch_t* bt,
                              float reg_lambda, float keep_prob, const uint8_t* drop_mask0,
                              const uint8_t* drop_mask1, uint64_t drop_seed, void* const* stage_events,
@@ -463,6 +481,16 @@ extern "C" int score_forward(const score_config_t* cfg, const score_state_t* st,
   // [Wx_gates | Wx_cand] copies for the hoisted GRU input projections: weights only, off the main stream
   G(score_launch_gru_wxcat(W + P.gk[0], W + P.ck[0], W + P.gb[0], W + P.cb[0], W + P.gk[1], W + P.ck[1], W + P.gb[1],
                            W + P.cb[1], d.Is[0], d.Is[1], d.I, H, ws + w.wxcat, sd->st));
+  // the panel form of the projections and of their input gradients (gemm_panel.hip) takes the weights as fragment images:
+  // written here, once per step, behind the concatenated copies (the backward pass reuses them as it reuses the copies)
+  const bool panel_x = panel_gemms(d, st, BT, 0), panel_d = panel_gemms(d, st, BT, 1);
+  {
+    const float* cats[2] = {ws + w.wxcat, ws + w.wxcat + (int64_t)(d.I + 1) * 3 * H};
+    float* ix[2] = {ws + w.pimg_x[0], ws + w.pimg_x[1]};
+    float* id[2] = {ws + w.pimg_d[0], ws + w.pimg_d[1]};
+    if (panel_x) G(score_gemm_panel_prep(2, cats, 3 * H, 1, 3 * H, d.Is[0], ix, sd->st));
+    if (panel_d) G(score_gemm_panel_prep(2, cats, 3 * H, 0, d.Is[0], 3 * H, id, sd->st));
+  }
   hipEvent_t wx_ev = sd->wx;
   HIPTRY(hipEventRecord(wx_ev, sd->st));
   const bool head_fused = !env_flags().head_unfused;
@@ -517,8 +545,13 @@ extern "C" int score_forward(const score_config_t* cfg, const score_state_t* st,
       const float* Bx[2] = {c0, c1};
       float* Cx[2] = {ws + w.xproj[0], ws + w.xproj[1]};
       const float* bx[2] = {c0 + (int64_t)d.Is[0] * 3 * H, c1 + (int64_t)d.Is[1] * 3 * H};
-      G(score_gemm_same_shape(0, 2, BT, 3 * H, d.Is[0], Ax, d.I, Bx, 3 * H, Cx, 3 * H, GF_BIAS, x3 != 0, scratch,
-                              w.scratch_floats, s, bx));
+      if (panel_x) {
+        const PanelGroup pg[2] = {{Ax[0], ws + w.pimg_x[0], Cx[0], bx[0]}, {Ax[1], ws + w.pimg_x[1], Cx[1], bx[1]}};
+        G(score_gemm_panel(2, pg, BT, 3 * H, d.Is[0], d.I, 3 * H, s));
+      } else {
+        G(score_gemm_same_shape(0, 2, BT, 3 * H, d.Is[0], Ax, d.I, Bx, 3 * H, Cx, 3 * H, GF_BIAS, x3 != 0, scratch,
+                                w.scratch_floats, s, bx));
+      }
     }
     for (int sd = 0; sd < 2; ++sd) {
       float* xp = ws + w.xproj[sd];
@@ -831,11 +864,26 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
     const float* Ad[2] = {ws + w.dxproj[0], ws + w.dxproj[1]};
     const float* Bd[2] = {ws + w.wxcat, ws + w.wxcat + (int64_t)(d.I + 1) * 3 * H};
     float* Cd[2] = {ws + w.dxside[0], ws + w.dxside[1]};
-    G(score_gemm_same_shape(1, 2, BT, d.Is[0], 3 * H, Ad, 3 * H, Bd, 3 * H, Cd, d.I, 0, x3 != 0, scratch, SF, s));
+    if (panel_gemms(d, st, BT, 1)) {      // (the images were written by the forward pass, like the concatenated copies)
+      const PanelGroup pg[2] = {{Ad[0], ws + w.pimg_d[0], Cd[0], nullptr}, {Ad[1], ws + w.pimg_d[1], Cd[1], nullptr}};
+      G(score_gemm_panel(2, pg, BT, d.Is[0], 3 * H, 3 * H, d.I, s));
+    } else {
+      G(score_gemm_same_shape(1, 2, BT, d.Is[0], 3 * H, Ad, 3 * H, Bd, 3 * H, Cd, d.I, 0, x3 != 0, scratch, SF, s));
+    }
   }
 
   // ---- co-attention + embedding rows (score.py:147-167, 196-201, 51-66)
   int64_t slab_used = slab_half;
+  // With the panel form of d x the main stream reaches this point ~50 us earlier than the side stream's chain (query branch,
+  // the head's and the attention's weight gradients, their slab reduce and column sums) was sized for: its tail then runs
+  // beside the co-attention backward, and both crawl (kernel trace: the reduce 22 -> 110 us, the co-attention backward
+  // 112 -> 184).  The recurrences' weight-gradient products -- matrix-bound, everything they need is final -- go here instead
+  // of the end of the pass: the side stream's tail and the optimizer's window slice run beside THEM.
+  const bool wgrad_early = panel_gemms(d, st, BT, 1) && !env_flags().wgrad_late && !wgrad_side;
+  if (wgrad_early && gq.n > 0) {
+    G(gemm_queue_flush(&gq, x3 != 0, ws + w.dwslab + slab_half, slab_third, s));
+    slab_used = slab_half + slab_third;
+  }
   if (wgrad_side && gq.n > 0) {     // the GRU kernels' weight gradients: beside the co-attention backward and the scatter
     HIPTRY(hipEventRecord(side->fork, s));
     HIPTRY(hipStreamWaitEvent(side->st, side->fork, 0));

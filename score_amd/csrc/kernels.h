@@ -200,6 +200,14 @@ struct GruArgs {
 int score_gemm_same_shape(int trans, int nprob, int M, int N, int K, const float* const* A, int lda,
                           const float* const* B, int ldb, float* const* C, int ldc, int flags, int x3, float* scratch,
                           int64_t scratch_floats, hipStream_t s, const float* const* bias = nullptr);   // flags: 1 = + bias[i][N]
+// gemm_panel.hip: bf16x3 products C = A . Bt^T (+ bias) with a whole-N output panel per workgroup (the GRU input projections
+// and their input gradients at cfg-3's sizes): A is read once, the weights come as fragment images written once per step
+struct PanelGroup { const float* A; const float* img; float* C; const float* bias; };
+bool score_gemm_panel_ok(int ngroups, int M, int N, int K, int lda, int ldc, int* mt_out);      // false: use the tiled kernels
+int64_t score_gemm_panel_image_floats(int N, int K);                                          // 0: shape not covered
+// images of nimg weight matrices of one shape; Bt(n, k) = trans ? B[k * ldb + n] : B[n * ldb + k]
+int score_gemm_panel_prep(int nimg, const float* const* B, int ldb, int trans, int N, int K, float* const* img, hipStream_t s);
+int score_gemm_panel(int ngroups, const PanelGroup* g, int M, int N, int K, int lda, int ldc, hipStream_t s);
 // gru_stream.hip: H = 256 (weights streamed from L2 in MFMA fragment order; tmp holds the fragment copies)
 bool score_gru_stream_ok(int H);
 int64_t score_gru_stream_tmp_floats(int H, int nsides);

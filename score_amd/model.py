@@ -200,6 +200,8 @@ class SCOREBASE(object):
         self._ev_stage = None        # a stage boundary of the backward pass (where the window slice starts)
         self.catchup_events = None   # optional (start, end) torch events around score_adam_catchup_ids (bench.py)
         self._ev_sweep = None
+        self._sweep_st = None        # stream of the window slice when it runs beside the forward pass (SCORE_ADAM_SWEEP_AT=f1)
+        self._fwd_stage_event = None
         self._pinned_stream = self._pinned_handle = None
         self._row_list = None
         self.w = torch.zeros((self.n_w,), **f32)
@@ -584,7 +586,7 @@ class SCOREBASE(object):
         return buf[off:off + n].view(*shape)
 
     # ------------------------------------------------------------------ forward / backward / update
-    def _forward(self, db, reg_lambda, keep_prob, masks, gather_event=None, sweep=False):
+    def _forward(self, db, reg_lambda, keep_prob, masks, gather_event=None, sweep=False, stage_event=None):
         lay, ws = self._workspace(db.B)
         st = self._state(ws)
         if self._tiled_on():
@@ -600,9 +602,15 @@ class SCOREBASE(object):
             if tuple(m0.shape) != (db.B, 200) or tuple(m1.shape) != (db.B, 80):
                 raise ValueError("dropout masks must be [B,200] and [B,80]")
         seed = (self._drop_seed * 0x9E3779B1 + self.step * 0x85EBCA77) & 0xFFFFFFFFFFFFFFFF
+        events = self.fwd_events
+        if stage_event is not None:          # (k, event): score_forward records it at its stage boundary k
+            events = list(events) if events else [None] * 5
+            if events[stage_event[0]] is None:
+                events[stage_event[0]] = stage_event[1]
+            self._fwd_stage_event = events[stage_event[0]]
         rc = self.lib.score_forward(C.byref(self.cfg), C.byref(st), C.byref(db.struct), float(reg_lambda),
                                     float(keep_prob), _ptr(m0), _ptr(m1), C.c_uint64(seed),
-                                    self._event_array(self.fwd_events), self._stream())
+                                    self._event_array(events), self._stream())
         _lib.check(rc, "score_forward")
         self._keep = (m0, m1)
         return lay, ws, st
@@ -629,9 +637,26 @@ class SCOREBASE(object):
         early = self.scatter_mode == 0 and not os.environ.get("SCORE_PLAN_BEHIND_GATHER")
         if early:
             ev_start = cur.record_event()
+        # time-tiled optimizer: this step's slice of the table (rows nobody in the batch touches: any time between the
+        # batch rows' catch-up and the touched-row update will do).  "f1": behind the fused gather, i.e. beside the forward
+        # recurrence, which is matrix-bound and fills half the CUs; 1 .. 4: at that stage boundary of the backward pass
+        sweep_at = os.environ.get("SCORE_ADAM_SWEEP_AT", "2")
+        if sweep_at not in ("plan", "f1", "1", "2", "3", "4"):
+            sweep_at = "2"                  # (an unknown value must not leave the window slice unlaunched)
+        fwd_stage = None
+        if sweep_at == "f1" and self._tiled_on():
+            if self._ev_stage is None:
+                self._ev_stage = torch.cuda.Event()
+                self._ev_stage.record(cur)              # materialise the hipEvent_t
+            fwd_stage = (1, self._ev_stage)
         lay, ws, st = self._forward(db, reg_lambda, keep_prob, dropout_masks,
                                     gather_event=self._ev_gather if (self.scatter_mode == 0 and not early) else None,
-                                    sweep=True)
+                                    sweep=True, stage_event=fwd_stage)
+        if fwd_stage is not None and self._pending_sweep is not None:
+            if self._sweep_st is None:
+                self._sweep_st = torch.cuda.Stream(device=self.device)      # (its own stream: the occurrence sort must not queue behind it)
+            self._sweep_st.wait_event(self._fwd_stage_event)
+            self._launch_sweep(self._sweep_st)
         if self.scatter_mode == 0:
             # occurrence sort for the pull-form scatter: depends on the indices only.  It runs on a side
             # stream from the start of the forward (see above), under the gather / GRUs / attention / head and
@@ -657,9 +682,8 @@ class SCOREBASE(object):
         # costs the step 0.02 ms; behind the occurrence sort -- beside the fused attention forward, whose 8-wave, 232-
         # register workgroups cannot share a CU with it -- 0.06; boundaries 1 / 3 / 4: 0.03 / 0.03 / 0.2
         # (SCORE_ADAM_SWEEP_AT=plan|1|2|3|4, profiles/r02_probes.md)
-        sweep_at = os.environ.get("SCORE_ADAM_SWEEP_AT", "2") if self._pending_sweep is not None else ""
-        if sweep_at not in ("", "plan", "1", "2", "3", "4"):
-            sweep_at = "2"                  # (an unknown value must not leave the window slice unlaunched)
+        if self._pending_sweep is None:
+            sweep_at = ""
         if sweep_at == "plan":
             self._launch_sweep(self._side)
         if self.scatter_mode == 0:

@@ -119,6 +119,58 @@ def test_gemm_bf16x3_is_fp32_accurate(trans, shape):
         assert bool((err <= tol).all()), float((err / tol).max())
 
 
+@pytest.mark.parametrize("trans_b,G,M,N,K,with_bias", [
+    (0, 2, 18432, 384, 448, True),      # cfg-3's GRU input projections (18 active slices): 256 panels of 144 rows
+    (1, 2, 18432, 448, 384, False),     # their input gradients: N = 448 leaves the eighth wave's columns as padding
+    (0, 2, 20480, 384, 448, True),      # all 20 slices: 160-row panels
+    (1, 2, 19000, 448, 384, False),     # a ragged last panel (rows past M are copies of row M - 1)
+    (0, 1, 33000, 320, 64, True),       # one group, N not a multiple of 128, two k-tiles
+    (1, 3, 12345, 512, 96, True),       # three groups, the widest N, odd number of k-tiles
+])
+def test_gemm_panel_products_match_fp64_within_the_fp32_bound(trans_b, G, M, N, K, with_bias):
+    # csrc/gemm_panel.hip: whole-N output panels, weights as MFMA-fragment images; same bound as the tiled bf16x3 kernel
+    lib = _lib.load()
+    g = torch.Generator(device="cuda").manual_seed(M + N + K + trans_b)
+    abuf = [torch.randn((M, K + 4), device="cuda", generator=g) for _ in range(G)]      # rows K + 4 apart: lda > K
+    for x in abuf:
+        x[:, :K] *= torch.logspace(-3, 3, K, device="cuda")                               # wide dynamic range
+    a = [x[:, :K] for x in abuf]
+    b = [torch.randn((K, N), device="cuda", generator=g) for _ in range(G)]
+    bias = [torch.randn((N,), device="cuda", generator=g) for _ in range(G)]
+    Bm = [x if trans_b == 0 else x.t().contiguous() for x in b]
+    c0 = [torch.randn((M, N + 4), device="cuda", generator=g) for _ in range(G)]
+    c = [x.clone() for x in c0]
+    images = torch.empty((G * (K // 32) * 8 * ((N + 127) // 128) * 768,), device="cuda")
+    arr = lambda ts: (C.c_void_p * G)(*[t.data_ptr() for t in ts])
+    rc = lib.score_gemm_panel_products(trans_b, G, M, N, K, arr(a), K + 4, arr(Bm), Bm[0].shape[1], arr(c), N + 4,
+                                       arr(bias) if with_bias else None, P(images), images.numel(), stream())
+    _lib.check(rc, "gemm_panel_products")
+    torch.cuda.synchronize()
+    for i in range(G):
+        want = a[i].double() @ b[i].double()
+        if with_bias:
+            want = want + bias[i].double()
+        tol = 2e-6 * (a[i].abs().double() @ b[i].abs().double()) + 1e-6
+        assert torch.equal(c[i][:, N:], c0[i][:, N:])          # nothing written past column N
+        err = (c[i][:, :N].double() - want).abs()
+        assert bool((err <= tol).all()), (i, float((err / tol).max()))
+
+
+def test_gemm_panel_products_refuse_what_they_do_not_cover():
+    lib = _lib.load()
+    a = torch.zeros((64, 64), device="cuda"); b = torch.zeros((64, 384), device="cuda"); c = torch.zeros((64, 384), device="cuda")
+    img = torch.zeros((1 << 20,), device="cuda")
+    one = lambda t: (C.c_void_p * 1)(t.data_ptr())
+    # too few rows to fill the chip, N too small, K not a multiple of 32: SCORE_E_SHAPE (-2), nothing launched
+    assert lib.score_gemm_panel_products(0, 1, 64, 384, 64, one(a), 64, one(b), 384, one(c), 384, None, P(img), img.numel(), stream()) == -2
+    big = torch.zeros((40000, 64), device="cuda"); cb = torch.zeros((40000, 384), device="cuda")
+    assert lib.score_gemm_panel_products(0, 1, 40000, 128, 64, one(big), 64, one(b), 384, one(cb), 384, None, P(img), img.numel(), stream()) == -2
+    assert lib.score_gemm_panel_products(0, 1, 40000, 384, 48, one(big), 64, one(b), 384, one(cb), 384, None, P(img), img.numel(), stream()) == -2
+    # scratch for the images too small: SCORE_E_WORKSPACE
+    assert lib.score_gemm_panel_products(0, 1, 40000, 384, 64, one(big), 64, one(b), 384, one(cb), 384, None, P(img), 100, stream()) == -3
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("force", [0, 32])
 def test_gemm_row_grouped_bias(force):
     # flags bits 16+: bias row group g -> output row r adds bias[r // g, :]  (folded attention layer)
