@@ -309,7 +309,9 @@ typedef struct {
   int32_t debug_flags;  /* A/B switches (0 in production): bit 0 = run the H = 256 recurrence step by step (grouped GEMMs +
                            pointwise launches per time slice) instead of the persistent streaming kernel; bit 1 = the
                            head's forward in one launch at every batch size; bit 2 = the H = 128 recurrences on the
-                           f32-input MFMA kernels instead of the bf16x3 form                                    */
+                           f32-input MFMA kernels instead of the bf16x3 form; bit 3 = the GRU input projections (and
+                           their input gradients) on the tiled bf16x3 kernel instead of the whole-N panel form
+                           (csrc/gemm_panel.hip); bit 4 = the input gradients in the panel form at every size       */
   uint8_t* row_flags;   /* optional [n_table_rows] row state of the dense table optimizer (see
                            score_adam_rows): score_backward (scatter_mode 0) marks every row it
                            writes into grad_table with 2 and leaves all other rows of grad_table

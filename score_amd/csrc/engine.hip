@@ -149,6 +149,10 @@ struct WS {
   int64_t scratch_floats, total;
 };
 
+// the projections' 3H output columns as one panel (3H <= 512) or as two column halves, each a panel group of its own
+// (H = 256: 768 columns; A is then read twice); 0: no panel form
+static int panel_x_splits(int H) { return 3 * H <= 512 ? 1 : ((3 * H) % 32 == 0 && 3 * H <= 1024 ? 2 : 0); }
+
 void build_ws(const Dims& d, int B, WS* w) {
   int64_t cur = 0;
   auto take = [&](int64_t n) { int64_t o = cur; cur = align_up64(cur + (n > 0 ? n : 4), 4); return o; };
@@ -197,7 +201,8 @@ void build_ws(const Dims& d, int B, WS* w) {
   w->cs_part = take(w->cs_part_floats);
   w->wxcat = take(2 * (int64_t)(d.I + 1) * 3 * d.H);
   for (int sd = 0; sd < 2; ++sd) {
-    w->pimg_x[sd] = take(score_gemm_panel_image_floats(3 * d.H, d.Is[sd]));
+    const int ns = panel_x_splits(d.H);
+    w->pimg_x[sd] = take(ns ? ns * score_gemm_panel_image_floats(3 * d.H / ns, d.Is[sd]) : 0);
     w->pimg_d[sd] = take(score_gemm_panel_image_floats(d.Is[sd], 3 * d.H));
   }
   w->dgstage = take((int64_t)B * d.Dhead);
@@ -285,11 +290,11 @@ static int side_stream(const score_state_t* st, SideStream** out) {
   return 0;
 }
 // A/B switches of the launch sequence, read from the environment ONCE (first call), not per step
-struct EnvFlags { bool head_unfused, attn_tail_unfused, wgrad_side, gru_stepwise, attn_fwd_unfused, gru_bias_colsum, gemm_tiled, wgrad_late, panel_dx; };
+struct EnvFlags { bool head_unfused, attn_tail_unfused, wgrad_side, gru_stepwise, attn_fwd_unfused, gru_bias_colsum, gemm_tiled, wgrad_early, panel_dx; };
 static bool env_on(const char* name) { const char* v = getenv(name); return v && *v && !(v[0] == '0' && !v[1]); }   // (set, not empty, not "0")
 static const EnvFlags& env_flags() {
   static const EnvFlags f = {env_on("SCORE_HEAD_UNFUSED"), env_on("SCORE_ATTN_TAIL_UNFUSED"), env_on("SCORE_WGRAD_SIDE"),
-                             env_on("SCORE_GRU_STEPWISE"), env_on("SCORE_ATTN_FWD_UNFUSED"), env_on("SCORE_GRU_BIAS_COLSUM"), env_on("SCORE_GEMM_TILED"), env_on("SCORE_WGRAD_LATE"), env_on("SCORE_PANEL_DX")};
+                             env_on("SCORE_GRU_STEPWISE"), env_on("SCORE_ATTN_FWD_UNFUSED"), env_on("SCORE_GRU_BIAS_COLSUM"), env_on("SCORE_GEMM_TILED"), env_on("SCORE_WGRAD_EARLY"), env_on("SCORE_PANEL_DX")};
   return f;
 }
 #define HIPTRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return (int)e_; } while (0)
@@ -435,15 +440,18 @@ extern "C" int score_index_plan(const score_config_t* cfg, const score_state_t* 
 
 // do the two sides' GRU input projections (which = 0) / their input gradients (which = 1) take the panel form?  Same
 // answer in the forward pass (which writes the weight images) and in the backward pass (which uses them).
-// The input gradients: only with SCORE_PANEL_DX=1.  The kernel itself is 30 % faster there too (71 vs 101 us), but a panel
-// workgroup owns its CU (8 waves x 256 registers), and the backward pass has ~350 us of other streams' work to place --
-// the side stream's query branch and early weight gradients, the optimizer's window slice -- which the tiled kernel lets
-// run beside it and the panel kernel pushes into the co-attention backward and the scatter (0.254 -> 0.329 ms), or, with the
-// recurrences' weight gradients moved in front of those, into them (1.287 -> 1.285 ms/step; forward only: 1.273).
+// The input gradients: from 64 K rows per side (cfg-5), or with SCORE_PANEL_DX=1.  The kernel itself is 30 % faster there
+// too (71 vs 101 us at cfg-3), but a panel workgroup owns its CU (8 waves x 256 registers), and the backward pass has
+// ~350 us of other streams' work to place -- the side stream's query branch and early weight gradients, the optimizer's
+// window slice -- which the tiled kernel lets run beside it and a one-round panel kernel pushes into the co-attention
+// backward and the scatter (cfg-3: 0.254 -> 0.329 ms), or, with the recurrences' weight gradients moved in front of those
+// (SCORE_WGRAD_EARLY=1), into them (1.287 -> 1.285 ms/step; projections only: 1.273).  At cfg-5's sizes the other
+// streams' work is small beside these products: 20.3 -> 19.8 ms/step with both.
 static bool panel_gemms(const Dims& d, const score_state_t* st, int BT, int which) {
-  if (st->gemm_mode != 1 || env_flags().gemm_tiled || d.Is[0] != d.Is[1]) return false;
-  return which == 0 ? score_gemm_panel_ok(2, BT, 3 * d.H, d.Is[0], d.I, 3 * d.H, nullptr)
-                    : env_flags().panel_dx && score_gemm_panel_ok(2, BT, d.Is[0], 3 * d.H, 3 * d.H, d.I, nullptr);
+  if (st->gemm_mode != 1 || env_flags().gemm_tiled || (st->debug_flags & 8) || d.Is[0] != d.Is[1]) return false;
+  const int ns = panel_x_splits(d.H);
+  return which == 0 ? ns > 0 && score_gemm_panel_ok(2 * ns, BT, 3 * d.H / ns, d.Is[0], d.I, 3 * d.H, nullptr)
+                    : (env_flags().panel_dx || (st->debug_flags & 16) || (int64_t)BT >= 65536) && score_gemm_panel_ok(2, BT, d.Is[0], 3 * d.H, 3 * d.H, d.I, nullptr);
 }
 
 extern "C" int score_forward(const score_config_t* cfg, const score_state_t* st, const score_batch_t* bt,
@@ -486,9 +494,15 @@ extern "C" int score_forward(const score_config_t* cfg, const score_state_t* st,
   const bool panel_x = panel_gemms(d, st, BT, 0), panel_d = panel_gemms(d, st, BT, 1);
   {
     const float* cats[2] = {ws + w.wxcat, ws + w.wxcat + (int64_t)(d.I + 1) * 3 * H};
-    float* ix[2] = {ws + w.pimg_x[0], ws + w.pimg_x[1]};
     float* id[2] = {ws + w.pimg_d[0], ws + w.pimg_d[1]};
-    if (panel_x) G(score_gemm_panel_prep(2, cats, 3 * H, 1, 3 * H, d.Is[0], ix, sd->st));
+    if (panel_x) {
+      const int ns = panel_x_splits(H), Nh = 3 * H / ns;
+      const int64_t per = score_gemm_panel_image_floats(Nh, d.Is[0]);
+      const float* bs[4];
+      float* ix[4];
+      for (int g = 0; g < 2 * ns; ++g) { bs[g] = cats[g / ns] + (g % ns) * Nh; ix[g] = ws + w.pimg_x[g / ns] + (g % ns) * per; }
+      G(score_gemm_panel_prep(2 * ns, bs, 3 * H, 1, Nh, d.Is[0], ix, sd->st));
+    }
     if (panel_d) G(score_gemm_panel_prep(2, cats, 3 * H, 0, d.Is[0], 3 * H, id, sd->st));
   }
   hipEvent_t wx_ev = sd->wx;
@@ -546,8 +560,14 @@ extern "C" int score_forward(const score_config_t* cfg, const score_state_t* st,
       float* Cx[2] = {ws + w.xproj[0], ws + w.xproj[1]};
       const float* bx[2] = {c0 + (int64_t)d.Is[0] * 3 * H, c1 + (int64_t)d.Is[1] * 3 * H};
       if (panel_x) {
-        const PanelGroup pg[2] = {{Ax[0], ws + w.pimg_x[0], Cx[0], bx[0]}, {Ax[1], ws + w.pimg_x[1], Cx[1], bx[1]}};
-        G(score_gemm_panel(2, pg, BT, 3 * H, d.Is[0], d.I, 3 * H, s));
+        const int ns = panel_x_splits(H), Nh = 3 * H / ns;
+        const int64_t per = score_gemm_panel_image_floats(Nh, d.Is[0]);
+        PanelGroup pg[4];
+        for (int g = 0; g < 2 * ns; ++g) {
+          const int side = g / ns, h = g % ns;
+          pg[g].A = Ax[side]; pg[g].img = ws + w.pimg_x[side] + h * per; pg[g].C = Cx[side] + h * Nh; pg[g].bias = bx[side] + h * Nh;
+        }
+        G(score_gemm_panel(2 * ns, pg, BT, Nh, d.Is[0], d.I, 3 * H, s));
       } else {
         G(score_gemm_same_shape(0, 2, BT, 3 * H, d.Is[0], Ax, d.I, Bx, 3 * H, Cx, 3 * H, GF_BIAS, x3 != 0, scratch,
                                 w.scratch_floats, s, bx));
@@ -874,12 +894,12 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
 
   // ---- co-attention + embedding rows (score.py:147-167, 196-201, 51-66)
   int64_t slab_used = slab_half;
-  // With the panel form of d x the main stream reaches this point ~50 us earlier than the side stream's chain (query branch,
+  // A/B (SCORE_WGRAD_EARLY=1): the recurrences' weight-gradient products here instead of at the end of the pass.  With the
+  // panel form of d x at cfg-3 the main stream reaches this point ~50 us earlier than the side stream's chain (query branch,
   // the head's and the attention's weight gradients, their slab reduce and column sums) was sized for: its tail then runs
   // beside the co-attention backward, and both crawl (kernel trace: the reduce 22 -> 110 us, the co-attention backward
-  // 112 -> 184).  The recurrences' weight-gradient products -- matrix-bound, everything they need is final -- go here instead
-  // of the end of the pass: the side stream's tail and the optimizer's window slice run beside THEM.
-  const bool wgrad_early = panel_gemms(d, st, BT, 1) && !env_flags().wgrad_late && !wgrad_side;
+  // 112 -> 184); moved here, the products take that company instead and lose what the scatter regains.
+  const bool wgrad_early = env_flags().wgrad_early && !wgrad_side;
   if (wgrad_early && gq.n > 0) {
     G(gemm_queue_flush(&gq, x3 != 0, ws + w.dwslab + slab_half, slab_third, s));
     slab_used = slab_half + slab_third;

@@ -231,7 +231,7 @@ class SCOREBASE(object):
         self._scalars_slot = 0
         self._use_dev_scalars = False
         self._graph_on, self._graphs = False, {}
-        self.debug_flags = 0       # score_state_t.debug_flags (A/B switches; bit 0: step-by-step H = 256 recurrence, bit 1: head forward in one launch, bit 2: f32-MFMA H = 128 recurrence)
+        self.debug_flags = 0       # score_state_t.debug_flags (A/B switches; bit 0: step-by-step H = 256 recurrence, bit 1: head forward in one launch, bit 2: f32-MFMA H = 128 recurrence, bit 3: tiled instead of panel GEMMs for the GRU projections, bit 4: panel form for their input gradients too)
         self.gemm_mode = 1         # 1: bf16x3 split (fp32-accurate) on the shapes where it measured faster, 0: f32 MFMA only
         # host feed path (nested lists / arrays -> pinned staging -> device): native threads of the list walk, and a ring
         # of pinned staging buffers per batch size (a buffer is reused once the H2D copy that read it has run)

@@ -123,3 +123,32 @@ def test_one_step_vs_oracle_full_size(cfg3):
     assert np.median(d) < 1e-4 and d.max() < 2e-3, (np.median(d), d.max())
     assert abs(lg2 - lo2) < 1e-4 * max(1.0, abs(lo2))
     assert round(roc_auc_score(lab, pg2), 3) == round(roc_auc_score(lab, po2), 3)
+
+
+def test_panel_and_tiled_projections_agree_full_size(cfg3):
+    # csrc/gemm_panel.hip: at this size the GRU input projections of both sides run as ONE launch of 256 whole-N panels
+    # (weights as MFMA-fragment images); score_state_t.debug_flags bit 3 puts them back on the tiled bf16x3 kernel, bit 4
+    # moves their input gradients to the panel form as well.  Same fp32-accurate products, different summation trees:
+    # predictions and gradients agree to fp32 rounding (the op test bounds each form against fp64).
+    w, kw, B, m = cfg3
+    b = w.batch(B, 5)
+    m.scatter_mode, m.global_batch = 0, 0
+    out = {}
+    try:
+        for flags in (0, 8, 16):
+            m.debug_flags = flags
+            p, _, loss = m.eval(None, b, 1e-4)
+            m.forward_backward(b, 1e-4, 1.0)
+            out[flags] = (np.asarray(p), loss, m.w_g.clone(), m.dense_table_grad().clone())
+    finally:
+        m.debug_flags = 0
+    p0, l0, w0, g0 = out[0]
+    assert float(w0.abs().max()) > 0 and float(g0.abs().max()) > 0
+    for flags in (8, 16):
+        p1, l1, w1, g1 = out[flags]
+        assert np.abs(p1 - p0).max() < 2e-6 and abs(l1 - l0) < 1e-6
+        assert float((w1 - w0).abs().max()) <= 2e-5 * float(w0.abs().max())
+        assert float((g1 - g0).abs().max()) <= 2e-5 * float(g0.abs().max())
+    # the tiled form differs from the panel form somewhere (the switch did switch), the forward of flags 16 is flags 0's
+    assert not np.array_equal(out[8][0], p0) or not torch.equal(out[8][2], w0)
+    assert np.array_equal(out[16][0], p0)
