@@ -39,6 +39,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 matrix peak (MI355X_MICROARCH.md; AMD's headline doubles it with sparsity)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable (float4 copy)
 PROFILE_ROUND = "r03"
 
@@ -193,6 +194,46 @@ def gather_probe(model, kw, B, n_probe_rows, iters, seed=0):
     uniq = n_probe_rows * (1.0 - np.exp(-uses / float(n_probe_rows)))
     return {"ms": float(np.mean(times)), "ms_min": float(np.min(times)), "alg_bytes": ab * B, "row_uses": uses,
             "expected_distinct_rows": int(uniq), "compulsory_row_bytes": int(uniq) * 4 * D, "probe_rows": n_probe_rows}
+
+
+def panel_gemm_probe(model, kw, B, A, iters=20):
+    """The GRU input projections of both sides as the step runs them (csrc/gemm_panel.hip through its C-ABI op,
+    score_gemm_panel_run: weights as prepared fragment images) on synthetic operands of the workload's shape:
+    2 x [B*A, I] . [I, 3H] + bias, A = the active time slices.  Duration by HIP events on the launch stream."""
+    import ctypes as C
+    from score_amd import _lib
+    D, H, Fu, Fi = kw["eb_dim"], kw["hidden_size"], kw["user_fnum"], kw["item_fnum"]
+    M, N, K = B * A, 3 * H, D * (Fu + Fi)
+    dev = model.device
+    a = [torch.randn((M, K), device=dev) for _ in range(2)]
+    w = [torch.randn((K, N), device=dev) * 0.05 for _ in range(2)]
+    bias = [torch.randn((N,), device=dev) for _ in range(2)]
+    c = [torch.empty((M, N), device=dev) for _ in range(2)]
+    images = torch.empty((2 * (K // 32) * 8 * ((N + 127) // 128) * 768,), device=dev)
+    arr = lambda ts: (C.c_void_p * 2)(*[t.data_ptr() for t in ts])
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rc = model.lib.score_gemm_panel_images(0, 2, N, K, arr(w), N, C.c_void_p(images.data_ptr()), images.numel(), st)
+    if rc != 0:
+        return None                         # (shape not covered: the tiled kernels run it)
+    Aa, Ca, Ba = arr(a), arr(c), arr(bias)
+    run = lambda: model.lib.score_gemm_panel_run(2, M, N, K, Aa, K, Ca, N, Ba, C.c_void_p(images.data_ptr()), images.numel(), st)
+    if run() != 0:
+        return None
+    torch.cuda.synchronize()
+    best, tot = 1e9, 0.0
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        t = e0.elapsed_time(e1) / iters
+        best, tot = min(best, t), tot + t
+    ref = a[0][:256].double() @ w[0].double() + bias[0].double()
+    err = float((c[0][:256].double() - ref).abs().max() / ref.abs().max())
+    return {"ms": tot / 3, "ms_min": best, "M": M, "N": N, "K": K, "max_rel_err_vs_fp64": err,
+            "flops": 2.0 * 2 * M * N * K, "a_bytes": 2 * M * K * 4, "c_bytes": 2 * M * N * 4, "w_bytes": 2 * K * N * 4}
 
 
 def spawn_ranks(n):
@@ -544,6 +585,28 @@ def main():
                 "compulsory_row_bytes": pr["compulsory_row_bytes"]}
         except Exception as e:          # an optional leg never takes the headline down
             side["roofline_lowdup"] = {"error": repr(e)}
+        # (c2) the largest matrix product of the forward pass, alone
+        try:
+            gp = panel_gemm_probe(model, kw, B, A)
+            if gp is not None:
+                g_tr, g_src = committed_traffic(args.config, "bench_workload", "gemm_panel_kernel", sources=("gemm_panel.hip",))
+                s_ = gp["ms"] * 1e-3
+                side["roofline_gemm_panel"] = {
+                    "kernel": "gemm_panel_kernel: the GRU input projections of both sides in one launch, 2 x [%d, %d] . [%d, %d] + "
+                              "bias, fp32-accurate on the bf16 matrix cores (bf16x3: six v_mfma_f32_16x16x32_bf16 per product)"
+                              % (gp["M"], gp["K"], gp["K"], gp["N"]),
+                    "bound": "mfma", "achieved": 6 * gp["flops"] / s_ / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": 6 * gp["flops"] / s_ / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                    "fp32_equivalent_tflops": gp["flops"] / s_ / 1e12,
+                    "algorithmic_bytes_per_launch": gp["a_bytes"] + gp["c_bytes"] + gp["w_bytes"],
+                    "traffic": g_tr, "traffic_source": g_src, "avg_launch_ms": gp["ms"], "min_launch_ms": gp["ms_min"],
+                    "max_rel_err_vs_fp64": gp["max_rel_err_vs_fp64"],
+                    "note": "achieved counts the six bf16 MFMAs each fp32-accurate product costs (the work the pipe does); "
+                            "fp32_equivalent_tflops counts the product once.  Measured alone on synthetic operands of the bench "
+                            "workload's shape through score_gemm_panel_run (include/score_hip.h); in the step it is the first "
+                            "kernel of the fwd_gru stage"}
+        except Exception as e:
+            side["roofline_gemm_panel"] = {"error": repr(e)}
         # (d) host ingestion included
         try:
             from score_amd.synth import make_graph
@@ -685,6 +748,7 @@ def main():
         "roofline": roofline,
         "roofline_bench_workload": bench_block,
         "roofline_other": {
+            **({"gru input projections (gemm_panel_kernel)": side.pop("roofline_gemm_panel")} if "roofline_gemm_panel" in side else {}),
             adam_name: {
                 "live_row_frac": headline_live_frac, "rows_with_gradient_per_step": touched,
                 "bound": "hbm", "achieved": adam_bytes / (stages["adam_table_and_dense"] * 1e-3) / 1e9 if adam_timed else None,

@@ -201,6 +201,13 @@ int score_gemm_panel_products(int32_t trans_b, int32_t ngroups, int32_t M, int32
                               const float* const* A, int32_t lda, const float* const* Bm, int32_t ldb,
                               float* const* C, int32_t ldc, const float* const* bias,
                               float* images, int64_t image_floats, void* stream);
+/* The two halves of score_gemm_panel_products: the images of the weights (once per set of weights), and the products
+ * from prepared images (as the engine runs them: the images are written once per step, beside the gather). */
+int score_gemm_panel_images(int32_t trans_b, int32_t ngroups, int32_t N, int32_t K, const float* const* Bm, int32_t ldb,
+                            float* images, int64_t image_floats, void* stream);
+int score_gemm_panel_run(int32_t ngroups, int32_t M, int32_t N, int32_t K, const float* const* A, int32_t lda,
+                         float* const* C, int32_t ldc, const float* const* bias, const float* images,
+                         int64_t image_floats, void* stream);
 
 /* tf.nn.dynamic_rnn(GRUCell(H), sequence_length) recurrence (score.py:205-208)
  * given the hoisted input projection xproj [B*T,3H] = x.[Wx_gates|Wx_cand]+bias.

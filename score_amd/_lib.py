@@ -88,6 +88,9 @@ _SIGS = {
                          C.c_int32, C.c_void_p],
     "score_gemm": [C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_f, C.c_int32, c_f, C.c_int32, c_f, C.c_int32,
                    c_f, C.c_int32, C.c_float, C.c_void_p, C.c_uint64, c_f, C.c_int64, C.c_void_p],
+    "score_gemm_panel_images": [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, c_f, C.c_int64, C.c_void_p],
+    "score_gemm_panel_run": [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
+                             c_f, C.c_int64, C.c_void_p],
     "score_gemm_panel_products": [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
                                   C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, c_f, C.c_int64, C.c_void_p],
     "score_gru_fwd": [C.c_int32, C.c_int32, C.c_int32, c_f, c_f, C.c_int32, c_f, C.c_int32, c_i, c_f, C.c_int32,

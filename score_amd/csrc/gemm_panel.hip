@@ -201,51 +201,69 @@ __global__ __launch_bounds__(512, 1) void gemm_panel_kernel(const PanelArgs a) {
   //  compiler derives at the loop head are the steady state's, not a conservative merge)
   a_load(0);
   a_store(0);
-  a_load(min(1, nt - 1));
+  {
+    a_load(min(1, nt - 1));
 #pragma unroll
-  for (int n = 0; n < NBW; ++n) b_load(n, 0);
-  for (int t = 0; t < nt; ++t) {
-    const int t1 = min(t + 1, nt - 1), t2 = min(t + 2, nt - 1);
-    __syncthreads();                 // stage t & 1 is complete; nobody reads stage (t + 1) & 1 any more
-    a_store((t + 1) & 1);
-    a_load(t2);
-    mma_group(t, I0(), I1());
+    for (int n = 0; n < NBW; ++n) b_load(n, 0);
+    for (int t = 0; t < nt; ++t) {
+      const int t1 = min(t + 1, nt - 1), t2 = min(t + 2, nt - 1);
+      __syncthreads();                 // stage t & 1 is complete; nobody reads stage (t + 1) & 1 any more
+      a_store((t + 1) & 1);
+      a_load(t2);
+      mma_group(t, I0(), I1());
 #pragma unroll
-    for (int n = 0; n < NG0; ++n) b_load(n, t1);        // behind their last use of this k-tile
-    mma_group(t, I1(), I2());
+      for (int n = 0; n < NG0; ++n) b_load(n, t1);        // behind their last use of this k-tile
+      mma_group(t, I1(), I2());
 #pragma unroll
-    for (int n = NG0; n < NBW; ++n) b_load(n, t1);
+      for (int n = NG0; n < NBW; ++n) b_load(n, t1);
+    }
   }
 
-  // C^T in the accumulators: lane = row lc of the m-block, columns 4*lq .. +4 of the n-block
-  const int nvalid = min(NBW, a.N / 16 - jb0);          // wave-uniform (N % 16 == 0)
+  // C^T in the accumulators: lane = row lc of the m-block, columns 4*lq .. +4 of the n-block.  Stored from there, a wave
+  // instruction writes 16 rows x 64 B, half a cache line per row: measured (PMC WRITE_SIZE) 110 MB leave the chip for
+  // 56.6 MB of C.  So the panel goes out one m-block (16 rows x N) at a time through LDS -- the stages are free now --:
+  // every wave drops its columns (+ bias) into a [16][N + 4] buffer, one barrier, then the 512 threads store whole rows,
+  // 512 contiguous bytes per half-wave.  Two buffers, so one barrier per m-block.
+  constexpr int NCOL = 8 * NBW * 16, CS = NCOL + 4;          // row stride in floats: rows 4 banks apart (conflict-free b128)
+  float* cbuf = reinterpret_cast<float*>(lds);
   f32x4 bias[NBW];
 #pragma unroll
   for (int n = 0; n < NBW; ++n) {
     bias[n] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (BIAS) bias[n] = *(const gfloat4*)(uni64(G.bias) + (uint64_t)(min((jb0 + n) * 16, a.N - 16) + 4 * lq) * 4);
   }
-  uint32_t coff[MT];
+  constexpr int RND = NCOL / 128;                             // float4 per row / 32 lanes
+  const int srow = tid >> 5, sc4 = tid & 31;                  // this thread's row of the m-block and first float4 of it
+  const int nq = a.N >> 2;                                    // float4 per row that exist (the rest is padding: the
+  uint32_t scol[RND];                                         //  lanes there store the last real one again)
 #pragma unroll
-  for (int m = 0; m < MT; ++m) coff[m] = (uint32_t)((min(m * 16 + lc, rows_here - 1) * a.ldc + jb0 * 16 + 4 * lq) * 4);
+  for (int i = 0; i < RND; ++i) scol[i] = (uint32_t)min(sc4 + 32 * i, nq - 1) * 4;
   const uint64_t cbase = uni64(G.C + (int64_t)bm * a.ldc);
+  const uint32_t wofs = (uint32_t)(lc * CS + jb0 * 16 + 4 * lq);
+  __syncthreads();                                            // every wave is done with the stages
 #pragma unroll
-  for (int n = 0; n < NBW; ++n) {
-    if (n < nvalid) {
+  for (int m = 0; m < MT; ++m) {
+    float* cb = cbuf + (m & 1) * 16 * CS;
 #pragma unroll
-      for (int m = 0; m < MT; ++m) {
+    for (int n = 0; n < NBW; ++n) *reinterpret_cast<f32x4*>(cb + wofs + n * 16) = acc[n][m] + bias[n];
+    __syncthreads();
+    const uint32_t roff = (uint32_t)(min(m * 16 + srow, rows_here - 1) * a.ldc) * 4;
+#pragma unroll
+    for (int i = 0; i < RND; ++i) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(cb + srow * CS + scol[i]);
 #ifdef PANEL_PROBE_NOCSTORE
-        if (acc[n][m][0] == 123.456f)
+      if (v[0] == 123.456f)
 #endif
-        *(gfloat4*)(cbase + coff[m] + n * 64) = acc[n][m] + bias[n];
-      }
+      *(gfloat4*)(cbase + roff + scol[i] * 4) = v;
     }
   }
 }
 
 template <int MT, int NBW>
 int launch_panel(const PanelArgs& a, int ngroups, bool bias, hipStream_t s) {
-  constexpr int bytes = 2 * 3 * MT * 16 * 64 + 512 * 8 + 2 * MT * 16 * 64;     // two stages + the dummy slots (three planes apart)
+  constexpr int stage_bytes = 2 * 3 * MT * 16 * 64 + 512 * 8 + 2 * MT * 16 * 64;     // two stages + the dummy slots (three planes apart)
+  constexpr int cbuf_bytes = 2 * 16 * (8 * NBW * 16 + 4) * 4;                          // the epilogue's two row buffers
+  constexpr int bytes = stage_bytes > cbuf_bytes ? stage_bytes : cbuf_bytes;
   hipError_t e;
   if (bias) {
     static const hipError_t once = hipFuncSetAttribute((const void*)gemm_panel_kernel<MT, NBW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -324,23 +342,39 @@ int score_gemm_panel(int ngroups, const PanelGroup* g, int M, int N, int K, int 
   return launch_panel<10, 4>(a, ngroups, bias, s);
 }
 
-// C-ABI op (include/score_hip.h): images + products in one call
+// C-ABI ops (include/score_hip.h): the weights' fragment images, the products from prepared images, and both in one call
+extern "C" int score_gemm_panel_images(int32_t trans_b, int32_t ngroups, int32_t N, int32_t K, const float* const* Bm, int32_t ldb,
+                                       float* images, int64_t image_floats, void* stream) {
+  if (!Bm || !images || ngroups < 1 || ngroups > 4 || N <= 0 || K <= 0 || trans_b < 0 || trans_b > 1) return SCORE_E_BADARG;
+  const int64_t per = score_gemm_panel_image_floats(N, K);
+  if (per == 0) return SCORE_E_SHAPE;
+  if (per * ngroups > image_floats) return SCORE_E_WORKSPACE;
+  float* img[4];
+  for (int i = 0; i < ngroups; ++i) img[i] = images + (int64_t)i * per;
+  // Bt(n, k): trans_b = 0 means Bm is [K, N] (C = A . Bm), 1 means Bm is [N, K] (C = A . Bm^T)
+  return score_gemm_panel_prep(ngroups, Bm, ldb, trans_b == 0 ? 1 : 0, N, K, img, (hipStream_t)stream);
+}
+
+extern "C" int score_gemm_panel_run(int32_t ngroups, int32_t M, int32_t N, int32_t K, const float* const* A, int32_t lda,
+                                    float* const* C, int32_t ldc, const float* const* bias, const float* images,
+                                    int64_t image_floats, void* stream) {
+  if (!A || !C || !images || ngroups < 1 || ngroups > 4 || M <= 0 || N <= 0 || K <= 0) return SCORE_E_BADARG;
+  if (!score_gemm_panel_ok(ngroups, M, N, K, lda, ldc, nullptr)) return SCORE_E_SHAPE;
+  const int64_t per = score_gemm_panel_image_floats(N, K);
+  if (per * ngroups > image_floats) return SCORE_E_WORKSPACE;
+  PanelGroup g[4];
+  for (int i = 0; i < ngroups; ++i) {
+    g[i].A = A[i]; g[i].img = images + (int64_t)i * per; g[i].C = C[i]; g[i].bias = bias ? bias[i] : nullptr;
+  }
+  return score_gemm_panel(ngroups, g, M, N, K, lda, ldc, (hipStream_t)stream);
+}
+
 extern "C" int score_gemm_panel_products(int32_t trans_b, int32_t ngroups, int32_t M, int32_t N, int32_t K, const float* const* A,
                                          int32_t lda, const float* const* Bm, int32_t ldb, float* const* C, int32_t ldc,
                                          const float* const* bias, float* images, int64_t image_floats, void* stream) {
   if (!A || !Bm || !C || !images || ngroups < 1 || ngroups > 4 || M <= 0 || N <= 0 || K <= 0 || trans_b < 0 || trans_b > 1)
     return SCORE_E_BADARG;
   if (!score_gemm_panel_ok(ngroups, M, N, K, lda, ldc, nullptr)) return SCORE_E_SHAPE;
-  const int64_t per = score_gemm_panel_image_floats(N, K);
-  if (per * ngroups > image_floats) return SCORE_E_WORKSPACE;
-  float* img[4];
-  PanelGroup g[4];
-  for (int i = 0; i < ngroups; ++i) {
-    img[i] = images + (int64_t)i * per;
-    g[i].A = A[i]; g[i].img = img[i]; g[i].C = C[i]; g[i].bias = bias ? bias[i] : nullptr;
-  }
-  hipStream_t s = (hipStream_t)stream;
-  // Bt(n, k): trans_b = 0 means Bm is [K, N] (C = A . Bm), 1 means Bm is [N, K] (C = A . Bm^T)
-  SCORE_TRY(score_gemm_panel_prep(ngroups, Bm, ldb, trans_b == 0 ? 1 : 0, N, K, img, s));
-  return score_gemm_panel(ngroups, g, M, N, K, lda, ldc, s);
+  SCORE_TRY(score_gemm_panel_images(trans_b, ngroups, N, K, Bm, ldb, images, image_floats, stream));
+  return score_gemm_panel_run(ngroups, M, N, K, A, lda, C, ldc, bias, images, image_floats, stream);
 }

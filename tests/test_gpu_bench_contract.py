@@ -38,11 +38,23 @@ def test_default_line_carries_the_contract():
     lo = j["roofline"]                  # the headline block is the low-duplication probe
     assert "low-duplication" in lo["kernel"] and lo["frac"] <= 1.0 and lo["expected_distinct_rows"] <= lo["row_uses"]
     for v in j["roofline_other"].values():
-        assert "traffic" in v and v["algorithmic_bytes_per_step"] > 0
+        assert "traffic" in v and (v.get("algorithmic_bytes_per_step") or v.get("algorithmic_bytes_per_launch")) > 0
+    assert "gru input projections (gemm_panel_kernel)" not in j["roofline_other"]      # (cfg-2's 96 columns: tiled kernels)
     ing = j["ingestion"]
     assert ing["device_assembly_samples_per_s"] > 0 and ing["nested_python_lists_samples_per_s"] > 0
     assert j["cpu_baseline_literal_tile"]["value"] > 0 and "materialised" in j["cpu_baseline_literal_tile"]["sample"]
     assert set(j["stages_ms"]) >= {"fwd_gather_coattn", "bwd_coattn_scatter", "adam_table_and_dense"}
+
+
+def test_cfg3_line_carries_the_panel_gemm_block():
+    # the headline workload: the GRU input projections run as whole-N panels (csrc/gemm_panel.hip); the line prices the
+    # kernel against the dense bf16 matrix peak, measured alone through the C-ABI op on operands of the workload's shape
+    j = _run("--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--probe-rows", "2000000")
+    gp = j["roofline_other"]["gru input projections (gemm_panel_kernel)"]
+    assert gp["bound"] == "mfma" and gp["unit"] == "TFLOP/s" and gp["peak"] == 2500.0 and 0 < gp["frac"] <= 1.0
+    assert abs(gp["frac"] - gp["achieved"] / gp["peak"]) < 1e-9 and abs(gp["achieved"] - 6 * gp["fp32_equivalent_tflops"]) < 1e-6 * gp["achieved"]
+    assert gp["max_rel_err_vs_fp64"] < 5e-6 and "traffic" in gp and gp["avg_launch_ms"] > 0
+    assert j["metric"] == "train samples/sec @ batch=1024" and j["config"]["workload"].startswith("cfg3")
 
 
 def test_flags_change_what_they_say():
