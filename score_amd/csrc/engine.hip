@@ -152,6 +152,8 @@ struct WS {
 // the projections' 3H output columns as one panel (3H <= 512) or as two column halves, each a panel group of its own
 // (H = 256: 768 columns; A is then read twice); 0: no panel form
 static int panel_x_splits(int H) { return 3 * H <= 512 ? 1 : ((3 * H) % 32 == 0 && 3 * H <= 1024 ? 2 : 0); }
+// ... and the input gradients' I output columns likewise (cfg-5, Tmall-shaped: 896)
+static int panel_d_splits(int I) { return I <= 512 ? 1 : (I % 32 == 0 && I <= 1024 ? 2 : 0); }
 
 void build_ws(const Dims& d, int B, WS* w) {
   int64_t cur = 0;
@@ -203,7 +205,8 @@ void build_ws(const Dims& d, int B, WS* w) {
   for (int sd = 0; sd < 2; ++sd) {
     const int ns = panel_x_splits(d.H);
     w->pimg_x[sd] = take(ns ? ns * score_gemm_panel_image_floats(3 * d.H / ns, d.Is[sd]) : 0);
-    w->pimg_d[sd] = take(score_gemm_panel_image_floats(d.Is[sd], 3 * d.H));
+    const int nd = panel_d_splits(d.Is[sd]);
+    w->pimg_d[sd] = take(nd ? nd * score_gemm_panel_image_floats(d.Is[sd] / nd, 3 * d.H) : 0);
   }
   w->dgstage = take((int64_t)B * d.Dhead);
   w->scratch2 = take(w->scratch_floats);           // split-K scratch of the side stream's products
@@ -451,7 +454,8 @@ static bool panel_gemms(const Dims& d, const score_state_t* st, int BT, int whic
   if (st->gemm_mode != 1 || env_flags().gemm_tiled || (st->debug_flags & 8) || d.Is[0] != d.Is[1]) return false;
   const int ns = panel_x_splits(d.H);
   return which == 0 ? ns > 0 && score_gemm_panel_ok(2 * ns, BT, 3 * d.H / ns, d.Is[0], d.I, 3 * d.H, nullptr)
-                    : (env_flags().panel_dx || (st->debug_flags & 16) || (int64_t)BT >= 65536) && score_gemm_panel_ok(2, BT, d.Is[0], 3 * d.H, 3 * d.H, d.I, nullptr);
+                    : (env_flags().panel_dx || (st->debug_flags & 16) || (int64_t)BT >= 65536) && panel_d_splits(d.Is[0]) > 0 &&
+                          score_gemm_panel_ok(2 * panel_d_splits(d.Is[0]), BT, d.Is[0] / panel_d_splits(d.Is[0]), 3 * d.H, 3 * d.H, d.I, nullptr);
 }
 
 extern "C" int score_forward(const score_config_t* cfg, const score_state_t* st, const score_batch_t* bt,
@@ -494,7 +498,6 @@ extern "C" int score_forward(const score_config_t* cfg, const score_state_t* st,
   const bool panel_x = panel_gemms(d, st, BT, 0), panel_d = panel_gemms(d, st, BT, 1);
   {
     const float* cats[2] = {ws + w.wxcat, ws + w.wxcat + (int64_t)(d.I + 1) * 3 * H};
-    float* id[2] = {ws + w.pimg_d[0], ws + w.pimg_d[1]};
     if (panel_x) {
       const int ns = panel_x_splits(H), Nh = 3 * H / ns;
       const int64_t per = score_gemm_panel_image_floats(Nh, d.Is[0]);
@@ -503,7 +506,14 @@ extern "C" int score_forward(const score_config_t* cfg, const score_state_t* st,
       for (int g = 0; g < 2 * ns; ++g) { bs[g] = cats[g / ns] + (g % ns) * Nh; ix[g] = ws + w.pimg_x[g / ns] + (g % ns) * per; }
       G(score_gemm_panel_prep(2 * ns, bs, 3 * H, 1, Nh, d.Is[0], ix, sd->st));
     }
-    if (panel_d) G(score_gemm_panel_prep(2, cats, 3 * H, 0, d.Is[0], 3 * H, id, sd->st));
+    if (panel_d) {
+      const int ns = panel_d_splits(d.Is[0]), Nh = d.Is[0] / ns;
+      const int64_t per = score_gemm_panel_image_floats(Nh, 3 * H);
+      const float* bs[4];
+      float* id[4];
+      for (int g = 0; g < 2 * ns; ++g) { bs[g] = cats[g / ns] + (int64_t)(g % ns) * Nh * 3 * H; id[g] = ws + w.pimg_d[g / ns] + (g % ns) * per; }
+      G(score_gemm_panel_prep(2 * ns, bs, 3 * H, 0, Nh, 3 * H, id, sd->st));
+    }
   }
   hipEvent_t wx_ev = sd->wx;
   HIPTRY(hipEventRecord(wx_ev, sd->st));
@@ -885,8 +895,14 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
     const float* Bd[2] = {ws + w.wxcat, ws + w.wxcat + (int64_t)(d.I + 1) * 3 * H};
     float* Cd[2] = {ws + w.dxside[0], ws + w.dxside[1]};
     if (panel_gemms(d, st, BT, 1)) {      // (the images were written by the forward pass, like the concatenated copies)
-      const PanelGroup pg[2] = {{Ad[0], ws + w.pimg_d[0], Cd[0], nullptr}, {Ad[1], ws + w.pimg_d[1], Cd[1], nullptr}};
-      G(score_gemm_panel(2, pg, BT, d.Is[0], 3 * H, 3 * H, d.I, s));
+      const int ns = panel_d_splits(d.Is[0]), Nh = d.Is[0] / ns;
+      const int64_t per = score_gemm_panel_image_floats(Nh, 3 * H);
+      PanelGroup pg[4];
+      for (int g = 0; g < 2 * ns; ++g) {
+        const int side_ = g / ns, h = g % ns;
+        pg[g].A = Ad[side_]; pg[g].img = ws + w.pimg_d[side_] + h * per; pg[g].C = Cd[side_] + h * Nh; pg[g].bias = nullptr;
+      }
+      G(score_gemm_panel(2 * ns, pg, BT, Nh, 3 * H, 3 * H, d.I, s));
     } else {
       G(score_gemm_same_shape(1, 2, BT, d.Is[0], 3 * H, Ad, 3 * H, Bd, 3 * H, Cd, d.I, 0, x3 != 0, scratch, SF, s));
     }
