@@ -44,14 +44,14 @@ struct TnArgs { TnJob j[8]; int njobs, K; };
 constexpr int TM = 192;
 
 template <int NW>
-__device__ __forceinline__ void tnp_body(const TnArgs& a, const TnJob& J, unsigned char* lds) {
+__device__ __forceinline__ void tnp_body(const TnArgs& a, const TnJob& J, unsigned char* lds, int wgid) {
   constexpr int TN = 64 * NW, ROWS = TM + TN, PLANE = ROWS * 64;
   constexpr int NBLK = ROWS / 4 * 8;                 // 4 x 4 blocks of a k-tile: (rows / 4) x (32 / 4)
   constexpr int NRD = (NBLK + 511) / 512;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int M = J.Ix + J.Ih;
   const int mt = (M + TM - 1) / TM;
-  const int local = (int)blockIdx.x - J.first_wg;
+  const int local = wgid - J.first_wg;
   const int tile_m = local % mt, chunk_i = local / mt;
   const int i0 = tile_m * TM;
   const int k0 = chunk_i * J.chunk, k1 = min(a.K, k0 + J.chunk);
@@ -168,10 +168,20 @@ __device__ __forceinline__ void tnp_body(const TnArgs& a, const TnJob& J, unsign
 // one launch for jobs of both widths: N > 128 -> 256-column tiles, else 128-column tiles (wave-uniform per workgroup)
 __global__ __launch_bounds__(512, 1) void tnp_kernel(const TnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+#ifdef TNP_XCD      // workgroups are dealt round-robin over the 8 XCDs: give every XCD a contiguous run, so that the row tiles of
+  int wgid;        // one K-chunk (consecutive ids) share an L2 for the dY rows they all read
+  {
+    const int nwg = (int)gridDim.x, orig = (int)blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+    wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+  }
+#else
+  const int wgid = (int)blockIdx.x;
+#endif
   int ji = 0;
-  while (ji + 1 < a.njobs && (int)blockIdx.x >= a.j[ji + 1].first_wg) ++ji;
+  while (ji + 1 < a.njobs && wgid >= a.j[ji + 1].first_wg) ++ji;
   const TnJob& J = a.j[ji];
-  if (J.N > 128) tnp_body<4>(a, J, lds); else tnp_body<2>(a, J, lds);
+  if (J.N > 128) tnp_body<4>(a, J, lds, wgid); else tnp_body<2>(a, J, lds, wgid);
 }
 
 __global__ void tnp_reduce_kernel(const float* __restrict__ slab, int ns, int64_t n, float* __restrict__ C) {
