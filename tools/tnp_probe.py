@@ -9,7 +9,7 @@ from score_amd import _lib
 lib = _lib.load()
 so = os.path.join(tempfile.mkdtemp(), "tnp.so")
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-result"] +
-                      [a for a in sys.argv[1:] if a.startswith("-D")] + [os.path.join(root, "tools", "tnp", "tnp_probe.hip"), "-o", so])
+                      [a for a in sys.argv[1:] if a.startswith("-D")] + [os.path.join(root, "tools", "tnp", "tnp2_probe.hip" if os.environ.get("TNP2") else "tnp_probe.hip"), "-o", so])
 x = C.CDLL(so)
 P = lambda t: C.c_void_p(t.data_ptr())
 st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -25,14 +25,14 @@ def timeit(fn, n=20):
     return best * 1e3
 stripped = any(a_.startswith("-DTNP_NO") for a_ in sys.argv[1:])
 K, I, H = int(os.environ.get("TNP_K", 18432)), 448, 128
-NS_G = int(os.environ.get("TNP_NS", 28))
+NS_G = int(os.environ.get("TNP_NS", 16 if os.environ.get("TNP2") else 28))
 for sides in (2,):
     xs = [torch.randn((K, I), device="cuda") for _ in range(sides)]
     hp = [torch.randn((K, H), device="cuda") for _ in range(sides)]
     rh = [torch.randn((K, H), device="cuda") for _ in range(sides)]
     dy = [torch.randn((K, 3 * H), device="cuda") * 0.1 for _ in range(sides)]
     M = I + H
-    ns_g, ns_c = NS_G, NS_G // 2
+    ns_g, ns_c = NS_G, int(os.environ.get('TNP_NSC', (NS_G + 1) // 2))
     ch = lambda ns: ((K + ns - 1) // ns + 31) // 32 * 32
     ch_g, ch_c = ch(ns_g), ch(ns_c)
     ns_g, ns_c = (K + ch_g - 1) // ch_g, (K + ch_c - 1) // ch_c
