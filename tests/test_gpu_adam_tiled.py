@@ -350,3 +350,22 @@ def test_row_list_and_state_scan_forms_of_the_touched_update_agree(monkeypatch):
             b.forward_backward(bs[0], 1e-4, 1.0)
             assert b._row_list is None
     assert same_state(a, b)
+
+
+@pytest.mark.parametrize("where", ["f1", "plan", "4"])
+def test_window_slice_placement_does_not_change_the_tables(monkeypatch, where):
+    """SCORE_ADAM_SWEEP_AT: the step's window slice beside the forward recurrence on its own stream (f1), behind the
+    occurrence sort (plan) or at the last stage boundary of the backward pass (4) instead of boundary 2 -- rows nobody in the
+    batch touches, any time between the batch rows' catch-up and the touched-row update: bit-identical tables and losses"""
+    cfg = so.Cfg(6000, 32, 32, 6, 4, 2, 3, "SCORE")
+    a, b = make(cfg, 5), make(cfg, 5)
+    bs = batches(cfg, 16, 24, seed=13, hot_rows=400)
+    for i, bt in enumerate(bs):
+        monkeypatch.setenv("SCORE_ADAM_SWEEP_AT", where)
+        la = a.train(None, bt, 1e-2, 1e-4, keep_prob=0.8)
+        monkeypatch.delenv("SCORE_ADAM_SWEEP_AT", raising=False)
+        lb = b.train(None, bt, 1e-2, 1e-4, keep_prob=0.8)
+        assert la == lb, (i, la, lb)
+    if where == "f1":
+        assert a._sweep_st is not None              # (the slice did run on its own stream)
+    assert same_state(a, b)
