@@ -141,6 +141,13 @@ def load():
     if path == LIB_PATH and not os.path.exists(LIB_PATH):
         from . import build as _build
         _build.build()
+    # torch first: it ships its own HIP runtime (torch/lib/libamdhip64.so).  Loaded before torch, this library would bind
+    # the system's copy, and the process would hold two runtimes -- torch's streams and device state on one, these kernels'
+    # launches on the other (seen as `score_context_create failed` when build() and smoke() shared a process)
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(path)
     for name, args in _SIGS.items():
         fn = getattr(lib, name)      # AttributeError if a declared symbol is missing
