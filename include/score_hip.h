@@ -353,6 +353,14 @@ typedef struct {
  * InvalidArgumentError "indices[...] is not in [0, N)" corresponds to (score.py:51-66). */
 int score_id_status(int32_t* id_status, int32_t* bits, int32_t clear, void* stream);
 
+/* Which kernel form the two sides' GRU input projections (score.py:205-208; *x_form) and their input gradients
+ * (*dx_form) take in score_forward / score_backward for a batch of B samples with `active_slices` computed time slices
+ * (0 = all T) under st->gemm_mode / st->debug_flags: 0 = the tiled kernels (gemm_bf16x3.hip / gemm.hip), n > 0 = the
+ * whole-N panel form (gemm_panel.hip) with each side's output columns as n panel groups (2 = column halves: H = 256).
+ * Host-only query, nothing is launched: what the parity tests assert before they compare the two forms. */
+int score_gemm_forms(const score_config_t* cfg, const score_state_t* st, int32_t B, int32_t active_slices,
+                     int32_t* x_form, int32_t* dx_form);
+
 /* Index plan of a batch (depends on the indices only; run it before score_backward, on
  * any stream ordered before it).  Radix-sorts all R*B row uses by (owner shard, row).
  * n_shards > 1 (table row-sharded, owner = row % n_shards) or dedup != 0 additionally

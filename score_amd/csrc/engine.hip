@@ -458,6 +458,19 @@ static bool panel_gemms(const Dims& d, const score_state_t* st, int BT, int whic
                           score_gemm_panel_ok(2 * panel_d_splits(d.Is[0]), BT, d.Is[0] / panel_d_splits(d.Is[0]), 3 * d.H, 3 * d.H, d.I, nullptr);
 }
 
+extern "C" int score_gemm_forms(const score_config_t* cfg, const score_state_t* st, int32_t B, int32_t active_slices,
+                                int32_t* x_form, int32_t* dx_form) {
+  Dims d;
+  SCORE_TRY(make_dims(cfg, &d));
+  if (!st || B <= 0 || active_slices < 0) return SCORE_E_BADARG;
+  const int T = (active_slices > 0 && active_slices < d.T) ? active_slices : d.T;
+  const int64_t BT = (int64_t)B * T;
+  if (BT > (1ll << 30)) return SCORE_E_SHAPE;
+  if (x_form) *x_form = panel_gemms(d, st, (int)BT, 0) ? panel_x_splits(d.H) : 0;
+  if (dx_form) *dx_form = panel_gemms(d, st, (int)BT, 1) ? panel_d_splits(d.Is[0]) : 0;
+  return 0;
+}
+
 extern "C" int score_forward(const score_config_t* cfg, const score_state_t* st, const score_batch_t* bt,
                              float reg_lambda, float keep_prob, const uint8_t* drop_mask0,
                              const uint8_t* drop_mask1, uint64_t drop_seed, void* const* stage_events,

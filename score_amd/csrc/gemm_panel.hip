@@ -21,6 +21,7 @@
 // 256 panels of cfg-3's two sides are one round of the chip.  Measured (tools/x3n_probe.py, both sides, 18,432 rows each):
 // projection 68 us (101 with gemm_bf16x3.hip), input gradient 71 us (101).
 #include "kernels.h"
+#include <atomic>
 #include <stdint.h>
 #include <stdlib.h>
 #include <type_traits>
@@ -265,15 +266,22 @@ int launch_panel(const PanelArgs& a, int ngroups, bool bias, hipStream_t s) {
   constexpr int cbuf_bytes = 2 * 16 * (8 * NBW * 16 + 4) * 4;                          // the epilogue's two row buffers
   constexpr int bytes = stage_bytes > cbuf_bytes ? stage_bytes : cbuf_bytes;
   hipError_t e;
-  if (bias) {
-    static const hipError_t once = hipFuncSetAttribute((const void*)gemm_panel_kernel<MT, NBW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    if (once != hipSuccess) return (int)once;
-    hipLaunchKernelGGL((gemm_panel_kernel<MT, NBW, true>), dim3(a.tiles * ngroups), dim3(512), bytes, s, a);
-  } else {
-    static const hipError_t once = hipFuncSetAttribute((const void*)gemm_panel_kernel<MT, NBW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    if (once != hipSuccess) return (int)once;
-    hipLaunchKernelGGL((gemm_panel_kernel<MT, NBW, false>), dim3(a.tiles * ngroups), dim3(512), bytes, s, a);
+  // more than 64 KB of dynamic LDS needs the attribute, and the attribute is per DEVICE: set once per device and kernel
+  // (a process may drive several GPUs: SideStream keeps per-device contexts too)
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return SCORE_E_BADARG;
+  static std::atomic<bool> set_[2][64];
+  const int bi = bias ? 1 : 0;
+  if (!set_[bi][dev].load(std::memory_order_acquire)) {
+    e = bias ? hipFuncSetAttribute((const void*)gemm_panel_kernel<MT, NBW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)
+             : hipFuncSetAttribute((const void*)gemm_panel_kernel<MT, NBW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return (int)e;
+    set_[bi][dev].store(true, std::memory_order_release);
   }
+  if (bias)
+    hipLaunchKernelGGL((gemm_panel_kernel<MT, NBW, true>), dim3(a.tiles * ngroups), dim3(512), bytes, s, a);
+  else
+    hipLaunchKernelGGL((gemm_panel_kernel<MT, NBW, false>), dim3(a.tiles * ngroups), dim3(512), bytes, s, a);
   e = hipGetLastError();
   return (int)e;
 }

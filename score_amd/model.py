@@ -577,6 +577,16 @@ class SCOREBASE(object):
     def device_batch(self, batch_data):
         return batch_data if isinstance(batch_data, DeviceBatch) else DeviceBatch(self, batch_data)
 
+    def gemm_forms(self, B, active_slices=0):
+        """(x_form, dx_form) of include/score_hip.h score_gemm_forms: how the GRU input projections / their input gradients
+        of a batch of B samples run under this model's gemm_mode and debug_flags (0 = tiled kernels, n = panel groups per side)"""
+        _, ws = self._workspace(B)
+        st = self._state(ws)
+        xf, df = C.c_int32(0), C.c_int32(0)
+        _lib.check(self.lib.score_gemm_forms(C.byref(self.cfg), C.byref(st), int(B), int(active_slices), C.byref(xf),
+                                             C.byref(df)), "score_gemm_forms")
+        return xf.value, df.value
+
     def ws_tensor(self, B, field, shape):
         """View of a named workspace region (tests / introspection).  Per-slice regions hold
         [B * A, .] rows when the batch ran with A = active_slices < T: pass A in place of T."""

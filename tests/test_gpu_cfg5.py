@@ -52,12 +52,16 @@ def compact_oracle(m, kw, batch):
     return om, remapped, uniq
 
 
-def _check_vs_oracle(world, kw, m, B, ragged):
+def _check_vs_oracle(world, kw, m, B, ragged, forms=None):
+    """forms: the (x_form, dx_form) of score_gemm_forms the run must take (None: whatever the size selects)"""
     b = list(world.batch(B, 11))
     if ragged:                     # lengths below T, different per sample (the synthetic default is T-2 for all)
         rng = np.random.default_rng(3)
         b[7] = rng.integers(1, kw["max_time_len"] + 1, B).astype(np.int32)
     b = tuple(b)
+    if forms is not None:
+        A = int(np.asarray(b[7]).max())
+        assert m.gemm_forms(B, 0 if A >= kw["max_time_len"] else A) == forms
     om, rb, uniq = compact_oracle(m, kw, b)
     rows = torch.from_numpy(uniq).to(m.device).long()
     lam = 1e-4
@@ -121,6 +125,58 @@ def test_taobao_shape_vs_oracle_ragged_lengths(taobao):
 def test_tmall_shape_vs_oracle(tmall):
     w, kw, B, m = tmall
     _check_vs_oracle(w, kw, m, 32, ragged=False)
+
+
+# ---- the H = 256 column-halves panel path (csrc/gemm_panel.hip through csrc/engine.hip) against the oracle ------------
+# score.py:205-208 at H = 2 * D scaled to cfg-5: the GRU input projections are 3H = 768 columns wide, i.e. TWO panel
+# groups per side (weights at column offset 384 of a [I + 1, 768] matrix, C at column offset 384 of a [B*T, 768] one),
+# and the Tmall-shaped input gradients (I = 896) two halves of 448 likewise.  score_gemm_panel_ok refuses the panel form
+# below ~23 k group-rows, so the B = 32 .. 64 comparisons above run the tiled kernels: these run B = 512
+# (4 groups x 24,576 rows) with debug_flags bit 4 (input gradients in panel form at every size), and assert the form.
+@pytest.mark.parametrize("name,forms", [("cfg5_taobao", (2, 1)), ("cfg5_tmall", (2, 2))])
+def test_panel_halves_vs_oracle_b512(name, forms):
+    w, kw, _, m = _model(name)
+    try:
+        m.debug_flags = 16
+        _check_vs_oracle(w, kw, m, 512, ragged=False, forms=forms)
+    finally:
+        del m
+        torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("which,forms", [("taobao", (2, 1)), ("tmall", (2, 2))])
+def test_panel_and_tiled_products_agree_full_batch(which, forms, request):
+    """B = 4096: debug_flags 0 (what the size selects: projections and input gradients in panel form, as column halves
+    where N > 512), 8 (both on the tiled bf16x3 kernel) and 16 must agree to fp32 rounding -- same fp32-accurate products,
+    different summation trees -- and the forms must be the ones claimed."""
+    w, kw, B, m = request.getfixturevalue(which)
+    db = m.device_batch(w.batch(B, 23))
+    A = db.active_slices
+    m.scatter_mode, m.global_batch = 0, 0
+    out = {}
+    try:
+        for flags in (0, 8, 16):
+            m.debug_flags = flags
+            assert m.gemm_forms(B, A) == ((0, 0) if flags == 8 else forms)
+            p, _, loss = m.eval(None, db, 1e-4)
+            m.forward_backward(db, 1e-4, 1.0)
+            rows = (m.table_flags == 2).nonzero().reshape(-1)
+            out[flags] = (np.asarray(p), loss, m.w_g.clone(), m.table_g[rows].clone(), rows)
+    finally:
+        m.debug_flags = 0
+        m._drop_row_marks()
+    p0, l0, w0, g0, r0 = out[0]
+    assert float(w0.abs().max()) > 0 and float(g0.abs().max()) > 0
+    for flags in (8, 16):
+        p1, l1, w1, g1, r1 = out[flags]
+        assert torch.equal(r0, r1)
+        assert np.abs(p1 - p0).max() < 5e-6 and abs(l1 - l0) < 1e-6, (flags, float(np.abs(p1 - p0).max()))
+        assert float((w1 - w0).abs().max()) <= 5e-5 * float(w0.abs().max()), (flags, float((w1 - w0).abs().max() / w0.abs().max()))
+        assert float((g1 - g0).abs().max()) <= 5e-5 * float(g0.abs().max()), (flags, float((g1 - g0).abs().max() / g0.abs().max()))
+    # the tiled form differs from the panel form somewhere (the switch did switch); flags 16 is flags 0 at this size
+    assert not np.array_equal(out[8][0], p0) or not torch.equal(out[8][2], w0)
+    assert np.array_equal(out[16][0], p0) and torch.equal(out[16][2], w0) and torch.equal(out[16][3], g0)
+    del out
 
 
 @pytest.mark.parametrize("which", ["taobao", "tmall"])

@@ -156,6 +156,53 @@ def test_gemm_panel_products_match_fp64_within_the_fp32_bound(trans_b, G, M, N, 
         assert bool((err <= tol).all()), (i, float((err / tol).max()))
 
 
+@pytest.mark.parametrize("trans_b,M,Nh,K,with_bias", [
+    (0, 24576, 384, 384, True),       # cfg-5 Taobao-shaped projections at B = 512: 3H = 768 columns as two halves, I = 384
+    (0, 24576, 384, 896, True),       # cfg-5 Tmall-shaped projections: I = 896 (28 k-tiles)
+    (1, 24576, 448, 768, False),      # cfg-5 Tmall-shaped input gradients: I = 896 output columns as two halves of 448, K = 3H
+    (1, 24000, 384, 768, True),       # ragged last panel, transposed weights inside a wider matrix
+])
+def test_gemm_panel_column_halves_of_one_matrix_match_fp64(trans_b, M, Nh, K, with_bias):
+    """The H = 256 form of csrc/engine.hip: each side's weights are ONE matrix whose output columns are split into two panel
+    groups -- B_h = a column range of a [K, 2Nh] matrix (trans_b 0: ldb = 2Nh > N) or a row range of a [2Nh, K] one inside a
+    wider allocation (trans_b 1: ldb > K) -- and both halves write column ranges of ONE C (ldc = 2Nh + 4, column offset Nh),
+    with the matching halves of one bias row.  Two sides = four groups, as the engine launches them."""
+    lib = _lib.load()
+    g = torch.Generator(device="cuda").manual_seed(M + Nh + K + trans_b)
+    G, N2 = 4, 2 * Nh
+    a = [torch.randn((M, K), device="cuda", generator=g) * torch.logspace(-2, 2, K, device="cuda") for _ in range(2)]
+    if trans_b == 0:
+        wbuf = [torch.randn((K, N2), device="cuda", generator=g) for _ in range(2)]        # C = A . W
+        Bh = [wbuf[s_][:, h * Nh:] for s_ in range(2) for h in range(2)]                   # views: column offset, ldb = N2
+        ldb = N2
+        wfull = wbuf
+    else:
+        wbuf = [torch.randn((N2, K + 8), device="cuda", generator=g) for _ in range(2)]    # C = A . W^T, rows K + 8 apart
+        Bh = [wbuf[s_][h * Nh:, :K] for s_ in range(2) for h in range(2)]
+        ldb = K + 8
+        wfull = [x[:, :K].t() for x in wbuf]
+    bias = [torch.randn((N2,), device="cuda", generator=g) for _ in range(2)]
+    c0 = [torch.randn((M, N2 + 4), device="cuda", generator=g) for _ in range(2)]
+    c = [x.clone() for x in c0]
+    Ah = [a[s_] for s_ in range(2) for h in range(2)]
+    Ch = [c[s_][:, h * Nh:] for s_ in range(2) for h in range(2)]
+    bh = [bias[s_][h * Nh:] for s_ in range(2) for h in range(2)]
+    images = torch.empty((G * (K // 32) * 8 * ((Nh + 127) // 128) * 768,), device="cuda")
+    arr = lambda ts: (C.c_void_p * G)(*[t.data_ptr() for t in ts])
+    rc = lib.score_gemm_panel_products(trans_b, G, M, Nh, K, arr(Ah), K, arr(Bh), ldb, arr(Ch), N2 + 4,
+                                       arr(bh) if with_bias else None, P(images), images.numel(), stream())
+    _lib.check(rc, "gemm_panel_products")
+    torch.cuda.synchronize()
+    for s_ in range(2):
+        want = a[s_].double() @ wfull[s_].double()
+        if with_bias:
+            want = want + bias[s_].double()
+        tol = 2e-6 * (a[s_].abs().double() @ wfull[s_].abs().double()) + 1e-6
+        assert torch.equal(c[s_][:, N2:], c0[s_][:, N2:])          # nothing written past column 2 Nh
+        err = (c[s_][:, :N2].double() - want).abs()
+        assert bool((err <= tol).all()), (s_, float((err / tol).max()))
+
+
 def test_gemm_panel_products_refuse_what_they_do_not_cover():
     lib = _lib.load()
     a = torch.zeros((64, 64), device="cuda"); b = torch.zeros((64, 384), device="cuda"); c = torch.zeros((64, 384), device="cuda")
