@@ -41,7 +41,7 @@ sys.path.insert(0, ROOT)
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 matrix peak (MI355X_MICROARCH.md; AMD's headline doubles it with sparsity)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable (float4 copy)
-PROFILE_ROUND = "r03"
+PROFILE_ROUND = os.environ.get("SCORE_PROFILE_ROUND", "r04")
 
 
 def alg_bytes_per_sample(T, K, D, Fu, Fi):
@@ -238,16 +238,118 @@ def panel_gemm_probe(model, kw, B, A, iters=20):
             "flops": 2.0 * 2 * M * N * K, "a_bytes": 2 * M * K * 4, "c_bytes": 2 * M * N * 4, "w_bytes": 2 * K * N * 4}
 
 
+def stream_copy_ceiling(model, n_bytes=1 << 30, iters=10):
+    """SURVEY.md 8(d)'s second roofline denominator, measured on THIS box in THIS run: a plain float4 stream copy
+    (score_stream_copy, include/score_hip.h) between two buffers of n_bytes each -- far beyond the 256 MiB Infinity Cache --,
+    timed with HIP events on the launch stream.  GB/s of read + write traffic."""
+    import ctypes as C
+    from score_amd import _lib
+    n = n_bytes // 4
+    src = torch.empty((n,), dtype=torch.float32, device=model.device).normal_()
+    dst = torch.empty_like(src)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    run = lambda: _lib.check(model.lib.score_stream_copy(C.c_void_p(dst.data_ptr()), C.c_void_p(src.data_ptr()), n, st),
+                             "score_stream_copy")
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    times = []
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        times.append(e0.elapsed_time(e1) / iters)
+    ok = bool(torch.equal(dst[:4096], src[:4096]) and torch.equal(dst[-4096:], src[-4096:]))
+    del src, dst
+    torch.cuda.empty_cache()
+    ms = float(np.median(times))
+    return {"GBs": 2.0 * n_bytes / (ms * 1e-3) / 1e9, "ms": ms, "bytes_each_way": n_bytes, "copy_verified": ok,
+            "what": "float4 grid-stride copy kernel (score_stream_copy), %d MiB read + %d MiB written per launch, median of "
+                    "3 x %d launches by HIP events" % (n_bytes >> 20, n_bytes >> 20, iters)}
+
+
+class Heartbeat(object):
+    """Several ranks: a hung collective must not eat the driver's whole timeout in silence.  A daemon thread prints one
+    line per rank to stderr every `every` seconds (phase, step, the communicator's last collective) and, when the main
+    thread has made no progress for `stall` seconds, says which rank hangs where and ends the process with exit code 3 --
+    the launcher (torch.distributed.run) then takes the other ranks down.  (The process exits; nothing is re-executed.)"""
+
+    def __init__(self, rank, comm_of, every=20.0, stall=150.0):
+        import threading
+        self.rank, self.comm_of, self.every, self.stall = rank, comm_of, every, stall
+        self.phase, self.count, self._seen, self._t_seen = "start", 0, None, time.time()
+        self._stop = threading.Event()
+        self._t = threading.Thread(target=self._run, name="bench-heartbeat", daemon=True)
+        self._t.start()
+
+    def tick(self, phase=None):
+        if phase is not None:
+            self.phase = phase
+        self.count += 1
+
+    def stop(self):
+        self._stop.set()
+
+    def _run(self):
+        last_print = time.time()
+        while not self._stop.wait(1.0):
+            now = time.time()
+            state = (self.phase, self.count)
+            if state != self._seen:
+                self._seen, self._t_seen = state, now
+            cm = self.comm_of()
+            coll = getattr(cm, "last", None) if cm is not None else None
+            if now - last_print >= self.every:
+                last_print = now
+                sys.stderr.write("bench.py heartbeat: rank %d phase=%s ticks=%d last_collective=%s idle=%.0fs\n"
+                                 % (self.rank, self.phase, self.count, coll, now - self._t_seen))
+                sys.stderr.flush()
+            if now - self._t_seen > self.stall:
+                sys.stderr.write("bench.py: rank %d made no progress for %.0f s in phase '%s' (tick %d), last collective "
+                                 "entered: %s -- giving up (exit 3)\n" % (self.rank, now - self._t_seen, self.phase,
+                                                                           self.count, coll))
+                sys.stderr.flush()
+                os._exit(3)
+
+
+def visible_gpus():
+    """GPUs this process could use, counted WITHOUT touching the HIP runtime: the KFD topology in sysfs (a node with
+    simd_count > 0 is a GPU), narrowed by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES when set.  0 without a KFD driver; None if the topology cannot be read."""
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    if not os.path.isdir(base):
+        return 0                      # no KFD driver: no ROCm device can be opened
+    try:
+        n = 0
+        for d in os.listdir(base):
+            try:
+                props = dict(line.split()[:2] for line in open(os.path.join(base, d, "properties")) if len(line.split()) >= 2)
+            except Exception:
+                continue
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+    except Exception:
+        return None
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
     --master-addr 127.0.0.1 --master-port <free port> bench.py <same arguments>` as a child process (one rank per GPU
-    over RCCL; rank 0 prints the one JSON line to the inherited stdout) and return its exit code.  Called before
-    anything in this process has initialised the GPU; torch.cuda.device_count() only counts."""
+    over RCCL; rank 0 prints the one JSON line to the inherited stdout) and return its exit code.  This process never
+    touches the GPU: the devices are counted from the KFD topology in sysfs (visible_gpus; when that is unavailable the
+    count is left to the ranks themselves, which refuse a missing device)."""
     import socket
     import subprocess
     rehearsal = os.environ.get("SCORE_BENCH_DEVICE") is not None      # several ranks on ONE device (gloo rehearsal)
-    n_dev = torch.cuda.device_count()
-    if n_dev < n and not rehearsal:
+    n_dev = visible_gpus()
+    if n_dev is not None and n_dev < n and not rehearsal:
         sys.stderr.write("bench.py: --gpus %d asked for, %d GPU(s) visible on this box: not started (nothing has touched the "
                          "GPU).  To rehearse N ranks on one device: SCORE_BENCH_DEVICE=0 SCORE_DIST_BACKEND=gloo "
                          "python bench.py --gpus %d\n" % (n, n_dev, n))
@@ -339,14 +441,23 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # a collective that never completes must fail within minutes, not at the default 10 (= the driver's whole limit)
+        from datetime import timedelta
+        tmo = timedelta(seconds=int(os.environ.get("SCORE_DIST_TIMEOUT_S", "120")))
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world_size,
+            dist.init_process_group("nccl", rank=rank, world_size=world_size, timeout=tmo,
                                     device_id=torch.device("cuda", local_rank))
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world_size)
+            dist.init_process_group(backend, rank=rank, world_size=world_size, timeout=tmo)
 
     from score_amd.synth import make_world
     from score_amd.model import SCORE
+    hb = None
+    model = None
+    if dist is not None and world_size > 1:
+        hb = Heartbeat(rank, lambda: getattr(model, "comm", None))
+    beat = (lambda phase=None: hb.tick(phase)) if hb is not None else (lambda phase=None: None)
+    beat("setup")
     world, kw = make_world(args.config)
     B = kw.pop("batch")
     strong = args.global_batch > 0
@@ -385,13 +496,21 @@ def main():
         model.enable_graph(True)
     last_loss = [None]
 
-    def run_steps(n, first=0, events=None):
+    def run_steps(n, first=0, events=None, step_marks=None):
+        """step_marks: a list of n + 1 timing events -- [i] is recorded on the launch stream before step i, [n] after the last"""
         fb = None
         if graph and events is None:
             for i in range(first, first + n):
+                if step_marks is not None:
+                    step_marks[i - first].record()
                 last_loss[0] = model.train_async(batches[i % len(batches)], args.lr, args.reg_lambda)
+            if step_marks is not None:
+                step_marks[n].record()
             return None
         for i in range(first, first + n):
+            beat()
+            if step_marks is not None:
+                step_marks[i - first].record()
             e_a0 = e_a1 = None
             if events is not None and i in events:
                 model.fwd_events, model.bwd_events, e_a0, e_a1 = events[i][:4]
@@ -410,6 +529,8 @@ def main():
             model.apply_adam(args.lr, args.reg_lambda)
             if e_a1 is not None:
                 e_a1.record()
+        if step_marks is not None:
+            step_marks[n].record()
         return fb
 
     def finish_adam():
@@ -422,7 +543,6 @@ def main():
     # ---------------------------------------------------------------- headline: steady state
     if not args.fresh_state:
         inner.table_flags.fill_(1)      # every row carries Adam moments: the state a long run converges to
-    run_steps(max(args.warmup - 1, 0))
     events = {}
     every = max(1, args.event_every)
     for i in range(args.steps):
@@ -430,6 +550,20 @@ def main():
             continue
         model.enable_stage_events(True)
         events[i] = (model.fwd_events, model.bwd_events) + tuple(torch.cuda.Event(enable_timing=True) for _ in range(4))
+    step_marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]     # one record per step: ms_per_step_p50
+    # The interpreter's cyclic garbage collector: a generation-2 pass over the ~10^6 objects torch has alive takes 50 - 70
+    # ms, and when one lands inside a host-bound timed loop (the small shapes: 300 steps of 0.38 ms) it alone adds 0.13 -
+    # 0.2 ms per step to the mean (measured: bench line 0.53 vs 0.385 ms/step at the reference's own shape; which run gets
+    # one depends on how many container objects the set-up happened to allocate).  Everything alive now is moved to the
+    # permanent generation, as a long-running training process does after start-up; the collector itself stays on.
+    # BEFORE the warm-up steps (round 4): between them and the timed region it left the GPU idle for those 50 - 70 ms, the
+    # clocks dropped, and a 20-step timed region (27 ms) ran its first steps on the way back up -- the driver's protocol
+    # measured 5 % below a 200-step run of the same build on the same box.  Warm-up now ends where the timing starts.
+    import gc
+    gc.collect()
+    gc.freeze()
+    beat("warmup")
+    run_steps(max(args.warmup - 1, 0))
     if args.warmup > 0 and not graph:
         # the last warm-up step carries stage events like every `every`-th timed step does: the first step that records
         # timing events pays a one-time 15 ms in the HIP runtime (measured), which is warm-up, not a step
@@ -438,20 +572,15 @@ def main():
         run_steps(1, -1, warm_ev)
     elif args.warmup > 0:
         run_steps(1)
-    # The interpreter's cyclic garbage collector: a generation-2 pass over the ~10^6 objects torch has alive takes 50 - 70
-    # ms, and when one lands inside a host-bound timed loop (the small shapes: 300 steps of 0.38 ms) it alone adds 0.13 -
-    # 0.2 ms per step to the mean (measured: bench line 0.53 vs 0.385 ms/step at the reference's own shape; which run gets
-    # one depends on how many container objects the set-up happened to allocate).  Everything alive now is moved to the
-    # permanent generation, as a long-running training process does after start-up; the collector itself stays on.
-    import gc
-    gc.collect()
-    gc.freeze()
+    beat("timed")
     barrier()
     t0 = time.perf_counter()
-    fb = run_steps(args.steps, 0, None if graph else events)
+    fb = run_steps(args.steps, 0, None if graph else events, step_marks)
     finish_adam()                  # inside the timed region: no update is left owing when the clock stops
     barrier()
     dt = time.perf_counter() - t0
+    beat("after")
+    per_step_ms = [step_marks[i].elapsed_time(step_marks[i + 1]) for i in range(args.steps)]
     tiled = tiled and bool(inner._tiled_on())       # (a shard may have gone back to the sweep: HipBackend.note_requests)
     if graph:                      # stage timings from eager steps, outside the timed region
         model.enable_graph(False)
@@ -529,6 +658,36 @@ def main():
         stages["adam_table_and_dense"] = None
     scat_bytes = R * (4 + 4 * D) * B
     headline_live_frac = live_rows / float(rows_local)
+
+    # ---------------------------------------------------------------- the reference's own call, synchronous
+    # loss = model.train(sess, batch_data, lr, reg_lambda) (score.py:101-116: one sess.run per step, the loss read back
+    # every step) on the same device-resident batches and the same state as the headline: the host waits for every step,
+    # so the queue drains each time and nothing of step t+1 is enqueued under step t
+    beat("sync_train")
+    n_sync = max(10, min(args.steps, 100))
+    sync_losses = []
+
+    def sync_steps(n):
+        for i in range(n):
+            beat()
+            b_ = batches[i % len(batches)]
+            if sharded:
+                nxt_ = batches[(i + 1) % len(batches)] if (args.prefetch and i + 1 < n) else None
+                sync_losses.append(model.train(None, b_, args.lr, args.reg_lambda, next_batch=nxt_))
+            else:
+                sync_losses.append(model.train(None, b_, args.lr, args.reg_lambda))
+    sync_steps(2)
+    barrier()
+    t_sync = time.perf_counter()
+    sync_steps(n_sync)
+    finish_adam()
+    barrier()
+    dt_sync = time.perf_counter() - t_sync
+    if dist is not None:
+        t_ = torch.tensor([dt_sync], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(t_, op=dist.ReduceOp.MAX)
+        dt_sync = float(t_.item())
+    beat("side")
 
     # ---------------------------------------------------------------- side measurements (one GPU, unsharded)
     side = {}
@@ -672,9 +831,16 @@ def main():
             side["ingestion"] = {"error": repr(e)}
 
     if rank != 0:
+        if hb is not None:
+            hb.stop()
         if dist is not None:
             dist.destroy_process_group()
         return
+    beat("report")
+    try:
+        ceiling = stream_copy_ceiling(inner)
+    except Exception as e:          # (a measurement aid never takes the headline down)
+        ceiling = {"error": repr(e)}
     traffic, tsrc = committed_traffic(args.config, "bench_workload", "coattn_fwd_kernel")
     scat_tr, scat_src = committed_traffic(args.config, "bench_workload",
                                           ("coattn_bwd_kernel_t", "pull_kernel", "pull_fixup_kernel", "pull_long_kernel",
@@ -709,6 +875,14 @@ def main():
         roofline["note"] = ("low-duplication probe not run in this invocation (%s): this is the loader-shaped bench workload, "
                             "whose algorithmic bytes exceed its memory traffic -- see roofline_bench_workload.note"
                             % ("--no-side / sharded / non-default state" if lowdup is None else lowdup.get("error")))
+    if "GBs" in ceiling:     # both denominators -- the spec peak and the copy ceiling measured in this run
+        for blk in (roofline, bench_block):
+            blk["peak_measured"] = ceiling["GBs"]
+            blk["frac_of_peak_measured"] = blk["achieved"] / ceiling["GBs"]
+        roofline["peak_measured_what"] = ceiling["what"] + " (%.3f ms per launch)" % ceiling["ms"]
+    else:
+        roofline["peak_measured"] = None
+        roofline["peak_measured_error"] = ceiling.get("error")
     out = {
         "metric": "train samples/sec @ batch=1024",
         "value": B * world_size * args.steps / dt,
@@ -717,6 +891,17 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3,
+        "ms_per_step_p50": float(np.median(per_step_ms)),
+        "ms_per_step_p10_p90": [float(np.percentile(per_step_ms, 10)), float(np.percentile(per_step_ms, 90))],
+        "ms_per_step_what": "ms_per_step = wall clock of the timed region (barrier to barrier, the optimizer's flush included) "
+                            "/ steps: the figure `value` is computed from.  p50 / p10 / p90: per-step durations from one HIP "
+                            "event per step on the launch stream (rank 0)",
+        "value_sync_train": B * world_size * n_sync / dt_sync,
+        "value_sync_train_what": "the reference's own call, one after the other: loss = model.train(sess, batch_data, lr, "
+                                 "reg_lambda) (score.py:101-116) with its per-step loss read-back, %d steps on the same "
+                                 "device-resident batches and optimizer state as `value` (which enqueues forward_backward + "
+                                 "apply_adam without reading the loss back: the asynchronous form); ms_per_step %.4f, last loss %.6f"
+                                 % (n_sync, dt_sync / n_sync * 1e3, sync_losses[-1]),
         "ms_per_step_ranks": {"min": min(dt_ranks) / args.steps * 1e3, "max": max(dt_ranks) / args.steps * 1e3},
         "rccl_ranks": ranks_seen if (dist is not None and backend == "nccl") else 0,
         "dist": ({"backend": backend, "world_size": ranks_seen} if dist is not None else None),
@@ -787,6 +972,8 @@ def main():
                                                                        budget_s=8.0, max_steps=3)
     else:
         out["cpu_baseline"] = None
+    if hb is not None:
+        hb.stop()
     if dist is not None:
         dist.destroy_process_group()
     # RCCL prints its version banner through C stdio: flush it first so the JSON is the LAST line

@@ -136,6 +136,11 @@ int score_workspace_layout(const score_config_t* cfg, int32_t B, score_workspace
 
 /* ---- per-op entry points (each is also a stage of score_forward/backward) ---- */
 
+/* Measurement helper (bench.py's `roofline.peak_measured`, SURVEY.md 8d "the measured stream-copy ceiling as a second
+ * denominator"): dst[i] = src[i] for n_floats floats (a multiple of 4; both 16-byte aligned) as a plain float4 grid-stride
+ * copy -- the HBM bandwidth a trivially coalesced kernel reaches on this box (n_floats * 8 bytes move per call). */
+int score_stream_copy(float* dst, const float* src, int64_t n_floats, void* stream);
+
 /* tf.truncated_normal_initializer (defaults: mean 0, stddev 1, resampled outside 2 sigma; score.py:44) for a
  * row shard of emb_mtx: local row i holds global row i * row_stride + row_first (row_stride = number of shards,
  * row_first = this shard's rank; 1 / 0 for the whole table).  Every element is a pure function of
@@ -227,17 +232,32 @@ int score_gru_bwd(int32_t B, int32_t T, int32_t H, const float* Wg, int32_t ldwg
                   const float* gates_save, const float* dout, int32_t lddo, const float* dfinal,
                   float* dxproj, float* rh, float* hprev, void* stream);
 
+/* Guard of the optimizer entry points.  tf.nn.embedding_lookup raises inside sess.run for an id outside the table and
+ * NO variable is updated by that call (score.py:51-66, 101-116).  The kernels that read the ids report such a batch in
+ * the device word score_state_t.id_status; an optimizer call that is handed the same word reads it when it EXECUTES
+ * (one uniform load) and, if it is non-zero, leaves the variable and both Adam slots untouched.  `skipped` (optional
+ * device counter) gets +1 from each suppressed call it is passed to: the caller hands it to ONE call per step (the dense
+ * variables') and learns how many steps to take off its own step count / beta powers when it sees the word.  The word
+ * is sticky: every later guarded call is suppressed too until the caller clears it.  NULL guard / NULL id_status =
+ * unguarded (a row shard's optimizer: the sharded path rejects such a batch on the host before the step starts). */
+typedef struct {
+  const int32_t* id_status;
+  int32_t* skipped;
+} score_guard_t;
+
 /* tf.train.AdamOptimizer ApplyAdam (score.py:96-99), dense over n floats:
  * g' = g + l2*p (first n_reg floats); m += (g'-m)(1-b1); v += (g'^2-v)(1-b2);
  * p -= m*alpha/(sqrt(v)+eps).  alpha = lr*sqrt(1-b2^t)/(1-b1^t) from the host. */
 int score_adam(float* p, float* m, float* v, const float* g, int64_t n, int64_t n_reg,
-               float l2, float alpha, float beta1, float beta2, float eps, void* stream);
+               float l2, float alpha, float beta1, float beta2, float eps, const score_guard_t* guard, void* stream);
 
 /* score_adam / score_adam_rows with alpha read from device memory (sc->adam_alpha) at execution time. */
 int score_adam_dev(float* p, float* m, float* v, const float* g, int64_t n, int64_t n_reg, float l2,
-                   const score_step_scalars_t* sc, float beta1, float beta2, float eps, void* stream);
+                   const score_step_scalars_t* sc, float beta1, float beta2, float eps, const score_guard_t* guard,
+                   void* stream);
 int score_adam_rows_dev(float* p, float* m, float* v, const float* g, int64_t n_rows, int32_t D, uint8_t* row_flags,
-                        const score_step_scalars_t* sc, float beta1, float beta2, float eps, void* stream);
+                        const score_step_scalars_t* sc, float beta1, float beta2, float eps, const score_guard_t* guard,
+                        void* stream);
 
 /* The same update over the [n_rows, D] embedding table, driven by a per-row state byte so the
  * dense sweep only moves the rows dense ApplyAdam actually changes (bit-identical result):
@@ -246,9 +266,11 @@ int score_adam_rows_dev(float* p, float* m, float* v, const float* g, int64_t n_
  *   2  gradient written this step (score_backward / score_segment_sum_rows set it) -> full
  *      update from g, then the state becomes 1
  *   (3 exists only inside score_adam_catchup_ids: a live row the batch is about to read, see below)
- * g rows in state 0/1 are never read, so grad_table needs no zero fill between steps. */
+ * g rows in state 0/1 are never read, so grad_table needs no zero fill between steps.
+ * A suppressed call (guard) leaves the state bytes as they are: the caller clamps the 2s back to 1. */
 int score_adam_rows(float* p, float* m, float* v, const float* g, int64_t n_rows, int32_t D,
-                    uint8_t* row_flags, float alpha, float beta1, float beta2, float eps, void* stream);
+                    uint8_t* row_flags, float alpha, float beta1, float beta2, float eps, const score_guard_t* guard,
+                    void* stream);
 
 /* ---- time-tiled ApplyAdam over the table ----------------------------------------------------------------------
  * Dense ApplyAdam moves every live row every step, but the update of a row WITHOUT a gradient (m *= b1, v *= b2,
@@ -281,8 +303,20 @@ typedef struct {
   uint32_t* row_step;             /* [n_rows]                                              */
   float* alpha_ring;              /* [SCORE_ADAM_RING + 1]                                 */
   float beta1, beta2, eps;
+  int32_t reserved2;
+  const int32_t* id_status;       /* optional guard word (score_guard_t.id_status).  While it is non-zero:
+                                     score_adam_touched(_rows) applies nothing -- its rows go back to state 1 with
+                                     row_step = step - 1 (they were current up to there), alpha_ring is not written --
+                                     and the catch-up entry points replay nothing (the steps they would replay may be
+                                     ones that were suppressed): the table, m and v stay as the last applied step left them */
+  const int32_t* skipped_steps;   /* optional DEVICE counter (score_guard_t.skipped of the same caller): steps suppressed so
+                                     far, i.e. by how much the `step` arguments run ahead of what was really applied   */
 } score_adam_table_t;
 int score_adam_touched(const score_adam_table_t* t, uint32_t step, float alpha, void* stream);
+/* A backward pass whose gradient nobody applies: every state-2 row back to state 1.  A row that was live keeps its
+ * row_step (the batch's rows were brought up to `upto` before that pass); a row that was in state 0 -- m = v = 0: its owed
+ * updates are identities and any count is right for it -- gets row_step = upto, which keeps it inside the ring. */
+int score_adam_unmark(const score_adam_table_t* t, uint32_t upto, void* stream);
 /* score_adam_touched driven by a row LIST instead of a scan of the state bytes: rows[0 .. *n_rows_dev) (device int32,
  * the count is read on the device; max_rows bounds it for the launch) names every row that may be in state 2 -- what
  * score_index_plan(dedup = 2) leaves in the workspace (plan_unique_rows / plan_meta[0]).  Entries not in state 2 are

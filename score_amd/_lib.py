@@ -64,7 +64,13 @@ class AdamTable(C.Structure):
     """score_adam_table_t"""
     _fields_ = [("p", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("g", C.c_void_p), ("n_rows", C.c_int64),
                 ("D", C.c_int32), ("reserved", C.c_int32), ("row_flags", C.c_void_p), ("row_step", C.c_void_p),
-                ("alpha_ring", C.c_void_p), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float)]
+                ("alpha_ring", C.c_void_p), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("reserved2", C.c_int32), ("id_status", C.c_void_p), ("skipped_steps", C.c_void_p)]
+
+
+class Guard(C.Structure):
+    """score_guard_t"""
+    _fields_ = [("id_status", C.c_void_p), ("skipped", C.c_void_p)]
 
 
 ADAM_RING = 64          # SCORE_ADAM_RING
@@ -73,6 +79,7 @@ _SIGS = {
     "score_context_create": [C.POINTER(C.c_void_p)],
     "score_context_destroy": [C.c_void_p],
     "score_id_status": [C.c_void_p, C.POINTER(C.c_int32), C.c_int32, C.c_void_p],
+    "score_stream_copy": [c_f, c_f, C.c_int64, C.c_void_p],
     "score_table_init": [c_f, C.c_int64, C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_uint64, C.c_void_p],
     "score_batch_assemble": [C.POINTER(Graph), c_i, c_i, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                              C.c_int32, C.c_uint64, C.POINTER(BatchOut), C.c_void_p],
@@ -98,14 +105,15 @@ _SIGS = {
     "score_gru_bwd": [C.c_int32, C.c_int32, C.c_int32, c_f, C.c_int32, c_f, C.c_int32, c_i, c_f, C.c_int32, c_f,
                       c_f, C.c_int32, c_f, c_f, c_f, c_f, C.c_void_p],
     "score_adam": [c_f, c_f, c_f, c_f, C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,
-                   C.c_float, C.c_void_p],
+                   C.c_float, C.POINTER(Guard), C.c_void_p],
     "score_adam_dev": [c_f, c_f, c_f, c_f, C.c_int64, C.c_int64, C.c_float, C.c_void_p, C.c_float, C.c_float, C.c_float,
-                       C.c_void_p],
+                       C.POINTER(Guard), C.c_void_p],
     "score_adam_rows_dev": [c_f, c_f, c_f, c_f, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_float, C.c_float,
-                            C.c_float, C.c_void_p],
+                            C.c_float, C.POINTER(Guard), C.c_void_p],
     "score_adam_rows": [c_f, c_f, c_f, c_f, C.c_int64, C.c_int32, C.c_void_p, C.c_float, C.c_float, C.c_float,
-                        C.c_float, C.c_void_p],
+                        C.c_float, C.POINTER(Guard), C.c_void_p],
     "score_adam_touched": [C.POINTER(AdamTable), C.c_uint32, C.c_float, C.c_void_p],
+    "score_adam_unmark": [C.POINTER(AdamTable), C.c_uint32, C.c_void_p],
     "score_adam_touched_rows": [C.POINTER(AdamTable), c_i, c_i, C.c_int64, C.c_uint32, C.c_float, C.c_void_p],
     "score_adam_catchup_ids": [C.POINTER(AdamTable), c_i, C.c_int64, C.c_uint32, C.c_void_p],
     "score_adam_catchup_rows": [C.POINTER(AdamTable), C.c_int64, C.c_int64, C.c_uint32, C.c_void_p],

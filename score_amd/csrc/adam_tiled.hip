@@ -23,7 +23,10 @@ struct TiledArgs {
   uint8_t* flags; uint32_t* step; float* ring;
   int64_t n_rows; int D; int LPR;
   float omb1, omb2, eps;
+  const int32_t* guard;        // score_adam_table_t.id_status: non-zero -> nothing is applied or replayed
+  const int32_t* skipped;      // score_adam_table_t.skipped_steps: optimizer steps suppressed so far (the caller's step count runs ahead by it)
 };
+__device__ __forceinline__ bool tiled_guarded(const TiledArgs& a) { return a.guard && *a.guard; }
 
 __device__ __forceinline__ int tiled_lane() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
@@ -100,10 +103,36 @@ __device__ __forceinline__ void tiled_rows(const TiledArgs& a, uint64_t mask, in
 }
 
 // rows whose state byte is 2: the step's ApplyAdam from their gradient.  One lane per row scans the state bytes.
-__global__ __launch_bounds__(256) void adam_touched_kernel(const TiledArgs a, uint32_t step, float alpha) {
+// A state-2 row whose gradient is NOT applied goes back to state 1.  Its row_step: a row that was live before the pass keeps
+// its count (it was brought up to date before the forward, or -- in a step queued behind a suppressed one -- still owes what
+// it owed); a row that was in state 0 has never had one, and m = v = 0 there, so every update it "owes" is the identity and
+// any count is right for it: it gets `applied`, the number of steps really applied so far, which keeps it inside the ring.
+// The two cannot be told apart by the state byte, but by the moments they can: all-zero m and v <=> the count is free.
+__device__ __forceinline__ void tiled_unmark_row(const TiledArgs& a, int64_t r, uint32_t applied) {
+  bool zero = true;
+  const float* m = a.m + r * a.D;
+  const float* v = a.v + r * a.D;
+  for (int c = 0; c < a.D && zero; ++c) zero = m[c] == 0.f && v[c] == 0.f;
+  a.flags[r] = 1;
+  if (zero) a.step[r] = applied;
+}
+// steps the device has really applied when the caller says `step` is being applied: the caller's count runs ahead by the
+// steps suppressed so far (score_guard_t.skipped; error path only)
+__device__ __forceinline__ uint32_t tiled_applied(const TiledArgs& a, uint32_t step) {
+  const uint32_t sk = a.skipped ? (uint32_t)*a.skipped : 0u;
+  return step - 1 > sk ? step - 1 - sk : 0u;
+}
+// `drop` (score_adam_unmark) or a set guard word: nothing is applied (tiled_unmark_row)
+__global__ __launch_bounds__(256) void adam_touched_kernel(const TiledArgs a, uint32_t step, float alpha, int drop) {
   const int lane = tiled_lane();
-  if (blockIdx.x == 0 && threadIdx.x == 0) a.ring[step % SCORE_ADAM_RING] = alpha;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  if (drop || tiled_guarded(a)) {
+    const uint32_t applied = drop ? step - 1 : tiled_applied(a, step);
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < a.n_rows; r += stride)
+      if (a.flags[r] == 2) tiled_unmark_row(a, r, applied);
+    return;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) a.ring[step % SCORE_ADAM_RING] = alpha;
   for (int64_t base = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) - lane; base < a.n_rows; base += stride) {
     const int64_t r = base + lane;
     const bool hit = r < a.n_rows && a.flags[r] == 2;
@@ -119,8 +148,16 @@ __global__ __launch_bounds__(256) void adam_touched_kernel(const TiledArgs a, ui
 __global__ __launch_bounds__(256) void adam_touched_rows_kernel(const TiledArgs a, const int32_t* __restrict__ rows,
                                                                 const int32_t* __restrict__ n_rows_dev, uint32_t step,
                                                                 float alpha) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) a.ring[step % SCORE_ADAM_RING] = alpha;
   const int n = *n_rows_dev;
+  if (tiled_guarded(a)) {                   // (as adam_touched_kernel)
+    const uint32_t applied = tiled_applied(a, step);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+      const int r = rows[i];
+      if (a.flags[r] == 2) tiled_unmark_row(a, r, applied);
+    }
+    return;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) a.ring[step % SCORE_ADAM_RING] = alpha;
   const int gpb = blockDim.x / a.LPR;
   const int ch4 = ((int)threadIdx.x % a.LPR) * 4;
   const int64_t ngroups = (int64_t)gridDim.x * gpb;
@@ -156,6 +193,7 @@ __global__ __launch_bounds__(256) void adam_touched_rows_kernel(const TiledArgs 
 // they belong to the step in flight (score_adam_touched), and are current up to the step before by construction.
 __global__ __launch_bounds__(256) void adam_catchup_rows_kernel(const TiledArgs a, int64_t row_begin, int64_t row_end,
                                                                 uint32_t upto) {
+  if (tiled_guarded(a)) return;
   const int lane = tiled_lane();
   const float areg = a.ring[(upto - (uint32_t)lane) % SCORE_ADAM_RING];
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -180,6 +218,7 @@ __global__ __launch_bounds__(256) void adam_catchup_rows_kernel(const TiledArgs 
 // in it name low rows: catching a row up early is always valid).
 __global__ __launch_bounds__(256) void adam_mark_ids_kernel(const TiledArgs a, const int32_t* __restrict__ ids, int64_t n,
                                                             uint32_t upto) {
+  if (tiled_guarded(a)) return;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     const int row = ids[i];
@@ -188,6 +227,11 @@ __global__ __launch_bounds__(256) void adam_mark_ids_kernel(const TiledArgs a, c
 }
 // second half: the rows in state 3 are replayed up to `upto` and return to state 1 (the scan of score_adam_touched)
 __global__ __launch_bounds__(256) void adam_catchup_marked_kernel(const TiledArgs a, uint32_t upto) {
+  if (tiled_guarded(a)) {                   // (the word was raised between the two halves: the marks go, nothing is replayed)
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < a.n_rows; r += (int64_t)gridDim.x * blockDim.x)
+      if (a.flags[r] == 3) a.flags[r] = 1;
+    return;
+  }
   const int lane = tiled_lane();
   const float areg = a.ring[(upto - (uint32_t)lane) % SCORE_ADAM_RING];
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -215,6 +259,8 @@ static int tiled_args(const score_adam_table_t* t, TiledArgs* a, bool need_g) {
   while (LPR < t->D / 4) LPR <<= 1;
   a->LPR = LPR;
   a->omb1 = 1.0f - t->beta1; a->omb2 = 1.0f - t->beta2; a->eps = t->eps;
+  a->guard = t->id_status;
+  a->skipped = t->skipped_steps;
   return 0;
 }
 static int tiled_blocks(int64_t n) {
@@ -226,7 +272,15 @@ extern "C" int score_adam_touched(const score_adam_table_t* t, uint32_t step, fl
   TiledArgs a;
   SCORE_TRY(tiled_args(t, &a, true));
   if (step == 0) return SCORE_E_BADARG;
-  hipLaunchKernelGGL(adam_touched_kernel, dim3(tiled_blocks(a.n_rows)), dim3(256), 0, (hipStream_t)stream, a, step, alpha);
+  hipLaunchKernelGGL(adam_touched_kernel, dim3(tiled_blocks(a.n_rows)), dim3(256), 0, (hipStream_t)stream, a, step, alpha, 0);
+  SCORE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int score_adam_unmark(const score_adam_table_t* t, uint32_t upto, void* stream) {
+  TiledArgs a;
+  SCORE_TRY(tiled_args(t, &a, false));
+  hipLaunchKernelGGL(adam_touched_kernel, dim3(tiled_blocks(a.n_rows)), dim3(256), 0, (hipStream_t)stream, a, upto + 1, 0.f, 1);
   SCORE_CHECK_LAUNCH();
   return 0;
 }

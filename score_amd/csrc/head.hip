@@ -586,7 +586,13 @@ int score_launch_gru_wxcat(const float* gk0, const float* ck0, const float* gb0,
 #define adam1 score_adam1     /* common.h */
 __global__ void adam_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
                             const float* __restrict__ g, int64_t n4, int64_t n, int64_t n_reg, float l2, float alpha,
-                            float omb1, float omb2, float eps, const float* __restrict__ alpha_dev) {
+                            float omb1, float omb2, float eps, const float* __restrict__ alpha_dev,
+                            const int32_t* __restrict__ guard, int32_t* __restrict__ skipped) {
+  // score_guard_t: a fed id outside the table -> the variables stay as they are (TF raises inside sess.run, score.py:51-66)
+  if (guard && *guard) {
+    if (skipped && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(skipped, 1);
+    return;
+  }
   if (alpha_dev) alpha = *alpha_dev;          // score_step_scalars_t.adam_alpha (captured steps)
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -647,7 +653,12 @@ __global__ __launch_bounds__(256) void adam_rows_kernel(float* __restrict__ p, f
                                                         float* __restrict__ v, const float* __restrict__ g,
                                                         int64_t n_rows, int D, int LPR, uint8_t* __restrict__ flags,
                                                         float alpha, float omb1, float omb2, float eps,
-                                                        const float* __restrict__ alpha_dev) {
+                                                        const float* __restrict__ alpha_dev,
+                                                        const int32_t* __restrict__ guard, int32_t* __restrict__ skipped) {
+  if (guard && *guard) {                       // score_guard_t (the state bytes stay: the caller clamps them)
+    if (skipped && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(skipped, 1);
+    return;
+  }
   if (alpha_dev) alpha = *alpha_dev;
   const int gpb = blockDim.x / LPR;
   const int ch4 = (threadIdx.x % LPR) * 4;
@@ -689,7 +700,7 @@ __global__ __launch_bounds__(256) void adam_rows_kernel(float* __restrict__ p, f
 
 static int adam_rows_impl(float* p, float* m, float* v, const float* g, int64_t n_rows, int32_t D,
                           uint8_t* row_flags, float alpha, const float* alpha_dev, float beta1, float beta2, float eps,
-                          void* stream) {
+                          const score_guard_t* guard, void* stream) {
   if (!p || !m || !v || !g || !row_flags || n_rows <= 0 || D <= 0) return SCORE_E_BADARG;
   if ((D & 3) || D > 256) return SCORE_E_SHAPE;
   if ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v) |
@@ -702,23 +713,26 @@ static int adam_rows_impl(float* p, float* m, float* v, const float* g, int64_t 
   int blocks = (int)(want < 16384 ? want : 16384);
   { static const char* e_ = getenv("SCORE_ADAM_BLOCKS"); if (e_ && atoi(e_) > 0 && atoi(e_) < blocks) blocks = atoi(e_); }   // EXPERIMENT
   hipLaunchKernelGGL(adam_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, m, v, g, n_rows, D, LPR,
-                     row_flags, alpha, 1.0f - beta1, 1.0f - beta2, eps, alpha_dev);
+                     row_flags, alpha, 1.0f - beta1, 1.0f - beta2, eps, alpha_dev, guard ? guard->id_status : nullptr,
+                     guard ? guard->skipped : nullptr);
   SCORE_CHECK_LAUNCH();
   return 0;
 }
 extern "C" int score_adam_rows(float* p, float* m, float* v, const float* g, int64_t n_rows, int32_t D,
-                               uint8_t* row_flags, float alpha, float beta1, float beta2, float eps, void* stream) {
-  return adam_rows_impl(p, m, v, g, n_rows, D, row_flags, alpha, nullptr, beta1, beta2, eps, stream);
+                               uint8_t* row_flags, float alpha, float beta1, float beta2, float eps,
+                               const score_guard_t* guard, void* stream) {
+  return adam_rows_impl(p, m, v, g, n_rows, D, row_flags, alpha, nullptr, beta1, beta2, eps, guard, stream);
 }
 extern "C" int score_adam_rows_dev(float* p, float* m, float* v, const float* g, int64_t n_rows, int32_t D,
                                    uint8_t* row_flags, const score_step_scalars_t* sc, float beta1, float beta2,
-                                   float eps, void* stream) {
+                                   float eps, const score_guard_t* guard, void* stream) {
   if (!sc) return SCORE_E_BADARG;
-  return adam_rows_impl(p, m, v, g, n_rows, D, row_flags, 0.f, &sc->adam_alpha, beta1, beta2, eps, stream);
+  return adam_rows_impl(p, m, v, g, n_rows, D, row_flags, 0.f, &sc->adam_alpha, beta1, beta2, eps, guard, stream);
 }
 
 static int adam_impl(float* p, float* m, float* v, const float* g, int64_t n, int64_t n_reg, float l2,
-                     float alpha, const float* alpha_dev, float beta1, float beta2, float eps, void* stream) {
+                     float alpha, const float* alpha_dev, float beta1, float beta2, float eps, const score_guard_t* guard,
+                     void* stream) {
   if (!p || !m || !v || !g || n <= 0) return SCORE_E_BADARG;
   if ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v) |
        reinterpret_cast<uintptr_t>(g)) & 15)
@@ -727,18 +741,43 @@ static int adam_impl(float* p, float* m, float* v, const float* g, int64_t n, in
   int64_t want = cdiv64(n4 > 0 ? n4 : 1, 256);
   int blocks = (int)(want < 8192 ? want : 8192);
   hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, m, v, g, n4, n, n_reg, l2,
-                     alpha, 1.0f - beta1, 1.0f - beta2, eps, alpha_dev);
+                     alpha, 1.0f - beta1, 1.0f - beta2, eps, alpha_dev, guard ? guard->id_status : nullptr,
+                     guard ? guard->skipped : nullptr);
   SCORE_CHECK_LAUNCH();
   return 0;
 }
 extern "C" int score_adam(float* p, float* m, float* v, const float* g, int64_t n, int64_t n_reg, float l2,
-                          float alpha, float beta1, float beta2, float eps, void* stream) {
-  return adam_impl(p, m, v, g, n, n_reg, l2, alpha, nullptr, beta1, beta2, eps, stream);
+                          float alpha, float beta1, float beta2, float eps, const score_guard_t* guard, void* stream) {
+  return adam_impl(p, m, v, g, n, n_reg, l2, alpha, nullptr, beta1, beta2, eps, guard, stream);
 }
 extern "C" int score_adam_dev(float* p, float* m, float* v, const float* g, int64_t n, int64_t n_reg, float l2,
-                              const score_step_scalars_t* sc, float beta1, float beta2, float eps, void* stream) {
+                              const score_step_scalars_t* sc, float beta1, float beta2, float eps,
+                              const score_guard_t* guard, void* stream) {
   if (!sc) return SCORE_E_BADARG;
-  return adam_impl(p, m, v, g, n, n_reg, l2, 0.f, &sc->adam_alpha, beta1, beta2, eps, stream);
+  return adam_impl(p, m, v, g, n, n_reg, l2, 0.f, &sc->adam_alpha, beta1, beta2, eps, guard, stream);
+}
+
+// ---------------------------------------------------------------- stream copy (measurement helper, score_hip.h)
+__global__ __launch_bounds__(256) void stream_copy_kernel(float4* __restrict__ dst, const float4* __restrict__ src, int64_t n4) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // four independent 16-byte loads in flight per lane before the first store
+  for (; i + 3 * stride < n4; i += 4 * stride) {
+    const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+    dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+  }
+  for (; i < n4; i += stride) dst[i] = src[i];
+}
+extern "C" int score_stream_copy(float* dst, const float* src, int64_t n_floats, void* stream) {
+  if (!dst || !src || n_floats <= 0) return SCORE_E_BADARG;
+  if ((n_floats & 3) || ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15)) return SCORE_E_SHAPE;
+  const int64_t n4 = n_floats / 4;
+  const int64_t want = cdiv64(n4, 256 * 4);
+  const int blocks = (int)(want < 1 ? 1 : want < 16384 ? want : 16384);
+  hipLaunchKernelGGL(stream_copy_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<float4*>(dst),
+                     reinterpret_cast<const float4*>(src), n4);
+  SCORE_CHECK_LAUNCH();
+  return 0;
 }
 
 // ---------------------------------------------------------------- table initialiser (score.py:44)

@@ -96,6 +96,12 @@ class TorchDistComm(object):
         self.world = dist.get_world_size(group)
         self._gloo = dist.get_backend(group) == "gloo"
         self._index = None
+        self.last = None       # ("name", sequence number) of the collective this rank entered last (bench.py's heartbeat)
+        self._seq = 0
+
+    def _note(self, name):
+        self._seq += 1
+        self.last = (name, self._seq)
 
     def index_comm(self):
         """The communicator of the index-only collectives (split sizes, row requests) and, in the pipelined step,
@@ -131,6 +137,7 @@ class TorchDistComm(object):
         return [int(r[0]) for r in got], [int(r[1]) for r in got]
 
     def all_to_all(self, out, inp, out_splits, in_splits):
+        self._note("all_to_all[%s x %d]" % (str(inp.dtype).replace("torch.", ""), int(inp.shape[0]) if inp.dim() else 1))
         if not self._gloo:
             self.dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)
             return
@@ -156,6 +163,7 @@ class TorchDistComm(object):
             r.wait()
 
     def all_reduce_sum(self, t):
+        self._note("all_reduce[%d]" % t.numel())
         if self._gloo and t.device.type != "cpu":
             h = t.cpu()
             self.dist.all_reduce(h, op=self.dist.ReduceOp.SUM, group=self.group)
@@ -169,6 +177,9 @@ class _ShardModel(SCOREBASE):
     model_type = "SCORE"
     # (the time-tiled table optimizer works on a shard as on the whole table: the rows other ranks ask for are the
     #  "batch", HipBackend.gather catches them up before it reads them; on from 256 MB of sweep traffic per shard)
+    # No device-side guard on a shard's optimizer (SCOREBASE._guard_on): a batch with an id outside the table is known to
+    # every rank BEFORE its step starts (its index plan's status word rides with the row counts) and is rejected there
+    _guard_on = False
 
     def __init__(self, rank, world, model_type, feature_size, *args, **kw):
         self.model_type = model_type
@@ -228,6 +239,9 @@ class HipBackend(object):
         self.auto_sweep = True
         self._req_seen, self._want_sweep = [], False
         self.defer_sweep = False         # gather(): leave the optimizer's window slice to the next backward pass
+        # one id-status word per plan slot (score_state_t.id_status of THAT plan only: plans run a step ahead of the
+        # compute, a shared sticky word would blame the step in flight for the next batch's ids)
+        self._plan_status = torch.zeros((4,), dtype=torch.int32, device=self.device)
 
     # -- index plan ---------------------------------------------------------------------
     def plan_launch(self, batch_data, slot=0):
@@ -236,11 +250,15 @@ class HipBackend(object):
         db = m.device_batch(batch_data)
         lay, ws = m._workspace(db.B, slot)
         st = m._state(ws)
+        word = self._plan_status[slot % 4:slot % 4 + 1]
+        word.zero_()
+        st.id_status = _ptr(word)
         _lib.check(self.lib.score_index_plan(C.byref(m.cfg), C.byref(st), C.byref(db.struct), self.world, 1,
                                              m._stream()), "score_index_plan")
         meta = ws[lay.plan_meta:lay.plan_meta + 2 + self.world].view(torch.int32)
-        host = torch.empty(meta.shape, dtype=meta.dtype, pin_memory=True)
-        host.copy_(meta, non_blocking=True)
+        host = torch.empty((meta.numel() + 1,), dtype=meta.dtype, pin_memory=True)
+        host[:meta.numel()].copy_(meta, non_blocking=True)
+        host[meta.numel():].copy_(word, non_blocking=True)        # (the plan's occurrence fill saw every id as fed)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.device))
         return dict(db=db, lay=lay, ws=ws, host=host, event=ev, slot=slot)
@@ -250,7 +268,7 @@ class HipBackend(object):
         h["event"].synchronize()
         db, lay, ws = h["db"], h["lay"], h["ws"]
         meta = h["host"].tolist()
-        U, offs = meta[0], meta[1:2 + self.world]
+        U, offs, bad_ids = meta[0], meta[1:2 + self.world], meta[2 + self.world]
         uniq = ws[lay.plan_unique_rows:lay.plan_unique_rows + U].view(torch.int32)
         # batch struct over the remapped (unique-position) index tensors
         sizes = [t.numel() for t in (db.tensors[0], db.tensors[3], db.tensors[1], db.tensors[2], db.tensors[4],
@@ -262,7 +280,7 @@ class HipBackend(object):
         # the record keeps (lay, ws): the step that consumes the plan must use THIS buffer -- the sort output, the
         # unique-row list and the remapped indices live in it -- whatever the workspace cache does in between
         return dict(db=db, remapped=remapped, keep=rm, U=U, offsets=offs, unique_rows=uniq, slot=h["slot"],
-                    event=h["event"], lay=lay, ws=ws)
+                    event=h["event"], lay=lay, ws=ws, bad_ids=bad_ids & 63)
 
     def plan(self, batch_data, slot=0):
         return self.plan_finish(self.plan_launch(batch_data, slot))
@@ -292,7 +310,7 @@ class HipBackend(object):
         return lay, ws, _lib.State(table=_ptr(mini), n_table_rows=mini.shape[0], w=_ptr(m.w), workspace=_ptr(ws),
                                    workspace_bytes=ws.numel() * 4, scatter_mode=2, global_batch=int(m.global_batch),
                                    gemm_mode=int(m.gemm_mode), debug_flags=int(m.debug_flags), context=m._ctx,
-                                   id_status=_ptr(m._id_status))     # (set by this batch's score_index_plan)
+                                   id_status=None)     # (the ids were checked by this batch's score_index_plan: plan["bad_ids"])
 
     def forward(self, plan, mini, reg_lambda, keep_prob, masks):
         m = self.m
@@ -497,10 +515,13 @@ class ShardedSCORE(object):
         B_local = plan["B"] if "B" in plan else plan["db"].B
         # rows shard-me must serve to rank p; every rank's batch size rides along: the loss is the mean over the
         # GLOBAL batch (sum of the local ones -- per-rank loaders end with short last batches of different sizes)
-        recv, sizes = cm.exchange_counts(send, self.device, extra=B_local)
+        # ... and so does the status word of the batch's index plan (six bits, one per id tensor of the feed tuple): every
+        # rank knows which ranks fed an id outside the table before anybody starts the step (_reject_bad_ids)
+        recv, extras = cm.exchange_counts(send, self.device, extra=int(B_local) | (int(plan.get("bad_ids", 0)) << 32))
+        sizes = [e & 0xFFFFFFFF for e in extras]
         req = torch.empty((sum(recv),), dtype=torch.int32, device=self.device)
         cm.all_to_all(req, plan["unique_rows"], recv, send)
-        plan.update(send=send, recv=recv, req=req, global_B=sum(sizes))
+        plan.update(send=send, recv=recv, req=req, global_B=sum(sizes), bad_by_rank=[e >> 32 for e in extras])
         if hasattr(self.backend, "note_requests"):
             self.backend.note_requests(sum(recv))
         return plan
@@ -582,6 +603,24 @@ class ShardedSCORE(object):
         self._prefetched = None
         return plan, self._rows(plan)
 
+    def _reject_bad_ids(self, plan):
+        """ValueError on EVERY rank, before anything of the step has run, if any rank's batch holds a feature id outside
+        [0, feature_size): tf.nn.embedding_lookup raises inside sess.run and no variable is updated (score.py:51-66,
+        101-116).  The index plan of each rank's batch reported its tensors (score_state_t.id_status of that plan), the
+        words were exchanged with the row counts: no extra collective, no device read-back, the same decision on every
+        rank.  Rows fetched ahead for the rejected batch are dropped; the next call plans afresh."""
+        bad = plan.get("bad_by_rank")
+        if not bad or not any(bad):
+            return
+        self._ready = self._prefetched = None
+        from .model import BATCH_FIELDS
+        msgs = ["rank %d: %s" % (r, ", ".join("batch_data[%d] (%s)" % (i, BATCH_FIELDS[i]) for i in range(6) if b >> i & 1))
+                for r, b in enumerate(bad) if b]
+        m = getattr(self.backend, "m", None)
+        raise ValueError("feature id outside [0, %s) -- %s (tf.nn.embedding_lookup would raise: score.py:51-66); the batch "
+                         "was rejected before its step started: no variable was updated on any rank"
+                         % (m.N_global if m is not None else "feature_size", "; ".join(msgs)))
+
     def _mark_step_end(self):
         if self.device.type == "cuda":
             self._slot_done[self._slot] = torch.cuda.current_stream(self.device).record_event()
@@ -598,6 +637,7 @@ class ShardedSCORE(object):
         if hasattr(be, "defer_sweep"):
             be.defer_sweep = self.device.type == "cuda"
         plan, mini = self._fetch(batch_data)
+        self._reject_bad_ids(plan)
         if next_batch is not None:
             self._prefetch_launch(next_batch)     # its kernels run under this step's forward
         be.set_global_batch(plan["global_B"])         # sum of every rank's batch size (exchanged with the row counts)
@@ -672,37 +712,13 @@ class ShardedSCORE(object):
         return loss[1] + float(reg_lambda) * loss[2]
 
     def train(self, sess, batch_data, lr, reg_lambda, keep_prob=0.8, dropout_masks=None, next_batch=None):
-        loss = float(self.train_async(batch_data, lr, reg_lambda, keep_prob, dropout_masks, next_batch).item())
-        if loss != loss:
-            self.check_ids()
-        return loss
+        return float(self.train_async(batch_data, lr, reg_lambda, keep_prob, dropout_masks, next_batch).item())
 
     def check_ids(self, collective=True):
-        """ValueError on EVERY rank if any rank fed an id outside [0, feature_size) (SCOREBASE.check_ids; the index
-        plan of the offending batch reported it and routed the id to the dummy row).  The global loss is NaN on
-        all ranks then (it is all-reduced), so all of them arrive here together: one small all-reduce of the
-        status words keeps them in step.  collective=False checks the local word only."""
-        m = getattr(self.backend, "m", None)
-        if m is None:
-            return
-        word = m._id_status.clone()
-        if collective and self.world > 1:
-            w64 = word.to(torch.int64) << (6 * self.rank) if self.world <= 10 else word.to(torch.int64)
-            self.comm.all_reduce_sum(w64)          # disjoint bit fields per rank: the sum is their union
-            allbits = int(w64.item())
-        else:
-            allbits = int(word.item()) << (6 * self.rank if self.world <= 10 else 0)
-        if allbits:
-            m._id_status.zero_()
-            from .model import BATCH_FIELDS
-            msgs = []
-            for r in range(self.world if self.world <= 10 else 1):
-                b = allbits >> (6 * r) & 63
-                if b:
-                    msgs.append("rank %d: %s" % (r, ", ".join("batch_data[%d] (%s)" % (i, BATCH_FIELDS[i])
-                                                                for i in range(6) if b >> i & 1)))
-            raise ValueError("feature id outside [0, %d) -- %s (tf.nn.embedding_lookup would raise: score.py:51-66)"
-                             % (m.N_global, "; ".join(msgs) or "some rank"))
+        """Kept for callers of train_async / eval_async written against SCOREBASE.check_ids: nothing can be pending
+        here.  A batch with a feature id outside the table is rejected when its step (or eval) STARTS -- ValueError on
+        every rank, before any kernel of it has run (_reject_bad_ids) -- so no later sync point has anything to report."""
+        return None
 
     # -- checkpoint (score.py:135-142), one file per rank ---------------------------------------
     def _shard_path(self, path):
@@ -734,6 +750,7 @@ class ShardedSCORE(object):
         if hasattr(be, "defer_sweep"):
             be.defer_sweep = False
         plan, mini = self._fetch(batch_data)
+        self._reject_bad_ids(plan)
         B = plan["B"] if "B" in plan else plan["db"].B
         be.set_global_batch(B)             # eval reports the local batch's loss, as the reference does
         fw = be.forward(plan, mini, reg_lambda, 1.0, None)
@@ -742,6 +759,4 @@ class ShardedSCORE(object):
         label = be.labels(plan).cpu().numpy().reshape([-1, ]).tolist()
         loss = fw["loss"]
         val = float((loss[1] + float(reg_lambda) * loss[2]).item())
-        if val != val:
-            self.check_ids(collective=False)      # (eval reports the local batch's loss: only this rank knows)
         return pred, label, val

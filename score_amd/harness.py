@@ -162,8 +162,25 @@ def train_loop(model, train_batches, vali_batches, lr, reg_lambda, train_batch_s
             cur = nxt
         yield cur, None
 
-    def in_step(pairs):
-        """several ranks: stop together -- a step is taken only if EVERY rank still has a batch for it (one small
+    def steps_agreed(source):
+        """several ranks, once per EPOCH: if every rank's loader has a length, the ranks agree on min(length) with one small
+        all-reduce (each rank writes its length into its own slot) and the epoch then needs no per-step agreement -- an
+        all-reduce plus a host read-back ahead of every step drains the stream each time, and the host could no longer run
+        ahead of the GPU (which is what train_async, feed() and next_batch= are for).  None: some loader has no length"""
+        if not multi:
+            return None
+        n = len(source) if hasattr(source, "__len__") else -1
+        slots = [0.0] * (2 * comm.world)
+        slots[comm.rank] = 1.0 if n >= 0 else 0.0
+        slots[comm.world + comm.rank] = float(max(n, 0))
+        got = across_ranks(slots, op="sum")
+        if sum(got[:comm.world]) < comm.world:
+            return None
+        return int(min(got[comm.world:]))
+
+    def in_step(pairs, n_steps=None):
+        """several ranks: stop together.  n_steps (steps_agreed): exactly that many steps, the look-ahead batch of the last
+        one dropped, no collective.  Otherwise a step is taken only if EVERY rank still has a batch for it (one small
         all-reduce per step, ahead of the step's own collectives); the look-ahead batch is dropped when some rank has
         none, so nobody prefetches for a step that will not happen"""
         if not multi:
@@ -171,6 +188,11 @@ def train_loop(model, train_batches, vali_batches, lr, reg_lambda, train_batch_s
                 yield p
             return
         it = iter(pairs)
+        if n_steps is not None:
+            for i in range(n_steps):
+                p = next(it)
+                yield (p[0], p[1] if i + 1 < n_steps else None)
+            return
         while True:
             p = next(it, None)
             have = across_ranks((0.0 if p is None else 1.0, 0.0 if (p is None or p[1] is None) else 1.0), op="sum")
@@ -183,9 +205,10 @@ def train_loop(model, train_batches, vali_batches, lr, reg_lambda, train_batch_s
         # host feed tuples (nested lists, as GraphLoader yields them) are converted and uploaded a batch or two ahead on a
         # worker thread (SCOREBASE.feed), under the step that is running
         source = train_batches()
+        n_agreed = steps_agreed(source)
         if hasattr(model, "feed") and feed_ahead:
             source = model.feed(source)
-        for batch_data, next_data in in_step(with_next(source)):
+        for batch_data, next_data in in_step(with_next(source), n_agreed):
             if early_stop:
                 break
             if ahead:
@@ -285,4 +308,6 @@ def evaluate_device(model, batches, reg_lambda, neg_sample_num=TEST_NEG_SAMPLE_N
     ndcg_5, ndcg_10, hr_1, hr_5, hr_10, mrr = ranking_quality_device(preds, iids, neg_sample_num)
     auc, logloss = auc_logloss_device(preds, labels)
     loss = float(torch.stack(losses).mean().item())
+    if loss != loss and hasattr(model, "check_ids"):
+        model.check_ids()       # (a NaN loss is how an id outside the table shows: raised HERE, not blamed on the next train step)
     return (logloss, auc, ndcg_5, ndcg_10, hr_1, hr_5, hr_10, mrr, loss)

@@ -223,7 +223,14 @@ class SCOREBASE(object):
         self.skip_masked_slices = True   # batches carry active_slices = max(length): slices every sample masks are skipped
         # per-step scalars in device memory (score_step_scalars_t): what a captured step reads its alpha / dropout seed from
         # sticky device word the kernels OR a bit into when a fed id lies outside the table (score_state_t.id_status)
-        self._id_status = torch.zeros((1,), dtype=torch.int32, device=self.device)
+        # word 0: the bits; word 1: optimizer steps the device suppressed because of it (score_guard_t.skipped)
+        self._id_status = torch.zeros((2,), dtype=torch.int32, device=self.device)
+        if self._guard_on:
+            a = self._id_status.data_ptr()
+            self._guard_dense = _lib.Guard(id_status=a, skipped=a + 4)      # ONE counted call per step: the dense variables'
+            self._guard_table = _lib.Guard(id_status=a, skipped=None)
+        else:
+            self._guard_dense = self._guard_table = None
         self._scalars = torch.zeros((4,), dtype=torch.int32, device=self.device)
         # pinned staging ring for them: with a captured step the host runs many steps ahead of the GPU, so the slot a
         # queued H2D copy reads from must not be rewritten before that copy has run (one event per slot says when)
@@ -242,6 +249,10 @@ class SCOREBASE(object):
         self._init_params(seed)
 
     STAGING_SLOTS = 4
+    # the optimizer kernels read score_state_t.id_status and apply nothing while it is set (score_guard_t: TF raises inside
+    # sess.run for an id outside the table and no variable is updated, score.py:51-66,101-116).  Off for a row shard: the
+    # sharded path rejects such a batch on the host, on every rank, before the step starts (score_amd/dist.py)
+    _guard_on = True
 
     def _staging(self, B, n_flat):
         """-> (pinned int32 [n_flat] whose padding words are zero, its ring slot [tensor, copy-done event, busy])"""
@@ -456,6 +467,11 @@ class SCOREBASE(object):
     def _drop_row_marks(self):
         # rows a previous backward marked (state 2) that no optimizer step consumed: back to "live"
         if self._flags_marked:
+            if self._tiled is not None and self._tiled_ready:
+                # (with row_step = the step they were brought up to before that pass: a row that had been in state 0 would
+                #  otherwise keep a stale count and look more steps behind than the alpha ring remembers)
+                _lib.check(self.lib.score_adam_unmark(C.byref(self._tiled[2]), int(self.step), self._stream()),
+                           "score_adam_unmark")
             self.table_flags.clamp_(max=1)
         self._flags_marked = False
         self._row_grads = False
@@ -753,7 +769,9 @@ class SCOREBASE(object):
             ring = torch.zeros((_lib.ADAM_RING + 1,), dtype=torch.float32, device=self.device)
             T = _lib.AdamTable(p=_ptr(self._tbl), m=_ptr(self._tbl_m), v=_ptr(self._tbl_v), g=_ptr(self.table_g),
                                n_rows=self._tbl.shape[0], D=self._tbl.shape[1], row_flags=_ptr(self.table_flags),
-                               row_step=_ptr(row_step), alpha_ring=_ptr(ring), beta1=ADAM_B1, beta2=ADAM_B2, eps=ADAM_EPS)
+                               row_step=_ptr(row_step), alpha_ring=_ptr(ring), beta1=ADAM_B1, beta2=ADAM_B2, eps=ADAM_EPS,
+                               id_status=_ptr(self._id_status) if self._guard_on else None,
+                               skipped_steps=C.c_void_p(self._id_status.data_ptr() + 4) if self._guard_on else None)
             self._tiled = (row_step, ring, T)
             self._tiled_ready = False
         return self._tiled
@@ -857,6 +875,8 @@ class SCOREBASE(object):
                    "score_adam_catchup_rows")
         if int(ring[_lib.ADAM_RING].view(torch.int32).item()) != 0:
             raise RuntimeError("time-tiled Adam: a row lagged more steps than the alpha ring holds")
+        if self._guard_on:
+            self.check_ids()     # (a set word suppressed the catch-up above: the caller must not read a stale table unawares)
 
     def adam_table(self, lr):
         """ApplyAdam over the table (shard) on the current stream: needs the row gradients only."""
@@ -868,16 +888,17 @@ class SCOREBASE(object):
             if self._use_dev_scalars:
                 rc = self.lib.score_adam_rows_dev(_ptr(self._tbl), _ptr(self._tbl_m), _ptr(self._tbl_v),
                                                   _ptr(self.table_g), self._tbl.shape[0], self._tbl.shape[1],
-                                                  _ptr(self.table_flags), _ptr(self._scalars), ADAM_B1, ADAM_B2, ADAM_EPS, s)
+                                                  _ptr(self.table_flags), _ptr(self._scalars), ADAM_B1, ADAM_B2, ADAM_EPS,
+                                                  self._guard_table, s)
             else:
                 rc = self.lib.score_adam_rows(_ptr(self._tbl), _ptr(self._tbl_m), _ptr(self._tbl_v),
                                               _ptr(self.table_g), self._tbl.shape[0], self._tbl.shape[1],
-                                              _ptr(self.table_flags), a, ADAM_B1, ADAM_B2, ADAM_EPS, s)
+                                              _ptr(self.table_flags), a, ADAM_B1, ADAM_B2, ADAM_EPS, self._guard_table, s)
             self._row_grads = False
             self._flags_marked = False
         else:
             rc = self.lib.score_adam(_ptr(self._tbl), _ptr(self._tbl_m), _ptr(self._tbl_v), _ptr(self.table_g),
-                                     self._tbl.numel(), 0, 0.0, a, ADAM_B1, ADAM_B2, ADAM_EPS, s)
+                                     self._tbl.numel(), 0, 0.0, a, ADAM_B1, ADAM_B2, ADAM_EPS, self._guard_table, s)
             self.table_flags.fill_(1)       # dense sweep: any row may carry moments now
             self._flags_marked = False
         _lib.check(rc, "score_adam(table)")
@@ -887,11 +908,11 @@ class SCOREBASE(object):
         if self._use_dev_scalars:
             rc = self.lib.score_adam_dev(_ptr(self.w), _ptr(self.w_m), _ptr(self.w_v), _ptr(self.w_g), self.n_w,
                                          self.n_reg, float(reg_lambda), _ptr(self._scalars), ADAM_B1, ADAM_B2, ADAM_EPS,
-                                         self._stream())
+                                         self._guard_dense, self._stream())
         else:
             rc = self.lib.score_adam(_ptr(self.w), _ptr(self.w_m), _ptr(self.w_v), _ptr(self.w_g), self.n_w,
                                      self.n_reg, float(reg_lambda), self._alpha(lr), ADAM_B1, ADAM_B2, ADAM_EPS,
-                                     self._stream())
+                                     self._guard_dense, self._stream())
         _lib.check(rc, "score_adam(dense)")
 
     def adam_advance(self):
@@ -997,14 +1018,35 @@ class SCOREBASE(object):
         where tf.nn.embedding_lookup raises InvalidArgumentError (score.py:51-66).  The kernels that read the ids
         report into a sticky device word (score_state_t.id_status) and treat such an id as the dummy row 0, so
         nothing is ever read or written out of bounds; the loss of such a step is NaN, which is how train() / eval()
-        learn of it without an extra read-back.  Callers of train_async / eval_async call this at their own sync
-        points.  The offending step has been applied with those ids read as padding."""
-        bits = int(self._id_status.item())
+        learn of it without an extra read-back.  As in TF, where the exception leaves sess.run before any assign op has run
+        (score.py:101-116), NO variable has been updated by the offending step: the optimizer kernels read the same
+        word when they execute and apply nothing while it is set (score_guard_t); the device counts the steps it
+        suppressed -- with train_async the host may have queued several more behind the offending one -- and this
+        call takes them off the step count and the beta powers again.  Parameters, Adam slots, step and beta powers
+        are then bit for bit what they were before the offending call.  Callers of train_async / eval_async call
+        this at their own sync points."""
+        bits, skipped = [int(x) for x in self._id_status.tolist()]
         if bits:
             self._id_status.zero_()
+            if skipped:
+                self._rollback_steps(skipped)
+            self._pending_sweep = None          # (a window slice scheduled for a step that was not applied)
+            self._adam_dirty = self._tiled is not None and self._tiled_ready     # (a suppressed flush left rows behind)
+            self._flags_marked = True           # state-2 marks of the suppressed steps: gone before the next backward
+            self._drop_row_marks()
             names = ["batch_data[%d] (%s)" % (i, BATCH_FIELDS[i]) for i in range(6) if bits >> i & 1]
-            raise ValueError("feature id outside [0, %d) in %s (tf.nn.embedding_lookup would raise: score.py:51-66)"
-                             % (int(self.cfg.feature_size), ", ".join(names)))
+            raise ValueError("feature id outside [0, %d) in %s (tf.nn.embedding_lookup would raise: score.py:51-66); "
+                             "no variable was updated%s"
+                             % (int(self.cfg.feature_size), ", ".join(names),
+                                "" if skipped <= 1 else " by that step or the %d queued behind it" % (skipped - 1)))
+
+    def _rollback_steps(self, k):
+        """the host's step count and beta powers, k optimizer steps back (the device applied none of them)"""
+        self.step = max(0, int(self.step) - int(k))
+        f = np.float32
+        # beta^(step+1) as adam_advance computes it: a chain of fp32 products (not a closed form: the bits must match)
+        self.beta1_power = f(np.multiply.accumulate(np.full((self.step + 1,), ADAM_B1, dtype=f))[-1])
+        self.beta2_power = f(np.multiply.accumulate(np.full((self.step + 1,), ADAM_B2, dtype=f))[-1])
 
     def eval_async(self, batch_data, reg_lambda):
         """eval without the host round trip: (y_pred [B] device view of the workspace -- copy it before the next

@@ -31,7 +31,15 @@ class CpuBackend(object):
         self._wg = None
 
     def plan(self, batch_data, slot=0):
-        b = so.batch_to_arrays(batch_data)
+        b = dict(so.batch_to_arrays(batch_data))
+        # what score_index_plan's occurrence fill does (score_state_t.id_status): an id outside [0, N) is reported -- bit i =
+        # position of the tensor in the feed tuple -- and read as the dummy row 0
+        bad_ids = 0
+        for i, n in enumerate(NAMES[:6]):
+            out = (b[n] < 0) | (b[n] >= self.cfg.N)
+            if out.any():
+                bad_ids |= 1 << i
+                b[n] = np.where(out, 0, b[n]).astype(b[n].dtype)
         G = self.world
         rows_local = (self.cfg.N + G - 1) // G
         shift = 1
@@ -50,7 +58,7 @@ class CpuBackend(object):
             pos += sz
         remapped["label"], remapped["length"] = b["label"], b["length"]
         return dict(B=b["label"].shape[0], U=U, offsets=offs, remapped=remapped,
-                    unique_rows=torch.from_numpy((uniq & ((1 << shift) - 1)).astype(np.int32)), batch=b)
+                    unique_rows=torch.from_numpy((uniq & ((1 << shift) - 1)).astype(np.int32)), batch=b, bad_ids=bad_ids)
 
     def gather(self, req_rows):
         return torch.from_numpy(self.table["t"][req_rows.numpy().astype(np.int64)])

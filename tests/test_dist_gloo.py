@@ -97,8 +97,71 @@ def test_two_rank_sharded_training_matches_single_model(tmp_path, model_type):
         assert abs(float(z[r]["eloss"]) - lref) < 1e-5
 
 
+# ---- an id outside the table on ONE rank: rejected on EVERY rank before the step starts (score.py:51-66) -------------
+def _badid_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    import torch.distributed as dist
+    from oracle import score_oracle as so
+    from score_amd.dist import ShardedSCORE, TorchDistComm
+    from cpu_backend import CpuBackend
+    from helpers import random_batch, batch_tuple
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    cfg_args = (203, 4, 8, 3, 3, 3, 4)
+    cfg = so.Cfg(*cfg_args, model_type="SCORE")
+    params = so.init_params(cfg, 5)
+    rng = np.random.default_rng(300 + rank)
+    good = [random_batch(rng, cfg, 6) for _ in range(3)]
+    bad = {k: v.copy() for k, v in good[1].items()}
+    if rank == 1:                                   # only rank 1 feeds it
+        bad["item_1hop"][2, 1, 0, 1] = cfg_args[0] + 9
+        bad["target_user"][0, 0] = -3
+
+    def run(with_bad):
+        be = CpuBackend(rank, world, "SCORE", cfg_args, params)
+        model = ShardedSCORE(*cfg_args, comm=TorchDistComm(), backend=be)
+        out, msg = [], ""
+        # the bad batch is ALSO the look-ahead batch of the step before it: that step must run and report normally
+        out.append(model.train(None, batch_tuple(good[0]), 1e-3, 1e-3, keep_prob=1.0,
+                               next_batch=batch_tuple(bad) if with_bad else batch_tuple(good[2])))
+        if with_bad:
+            before = (be.table["t"].copy(), {k: v.copy() for k, v in be.dense.items()})
+            try:
+                model.train(None, batch_tuple(bad), 1e-3, 1e-3, keep_prob=1.0)
+            except ValueError as e:
+                msg = str(e)
+            assert np.array_equal(before[0], be.table["t"]) and all(np.array_equal(before[1][k], be.dense[k]) for k in be.dense)
+            try:
+                model.eval(None, batch_tuple(bad), 1e-3)
+                msg += " | eval: no error"
+            except ValueError:
+                pass
+        out.append(model.train(None, batch_tuple(good[2]), 1e-3, 1e-3, keep_prob=1.0))
+        return out, msg, be.table["t"].copy()
+    l_bad, msg, t_bad = run(True)
+    l_ref, _, t_ref = run(False)
+    np.savez(os.path.join(out_dir, "bad%d.npz" % rank), l_bad=np.asarray(l_bad), l_ref=np.asarray(l_ref), msg=np.asarray(msg),
+             same_table=bool(np.array_equal(t_bad, t_ref)))
+    dist.destroy_process_group()
+
+
+def test_bad_id_on_one_rank_is_rejected_on_every_rank_before_the_step(tmp_path):
+    world = 2
+    mp.spawn(_badid_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    z = [np.load(str(tmp_path / ("bad%d.npz" % r))) for r in range(world)]
+    for r in range(world):
+        msg = str(z[r]["msg"])
+        assert "rank 1" in msg and "(item_1hop)" in msg and "(target_user)" in msg and "rank 0:" not in msg, (r, msg)
+        assert "no error" not in msg
+        # the run with the rejected batch in the middle == the run that never saw it (losses and shard, bit for bit)
+        assert np.array_equal(z[r]["l_bad"], z[r]["l_ref"]) and bool(z[r]["same_table"])
+
+
 # ---- harness.train_loop with several ranks: every rank must take the same branches -----------------
-def _loop_worker(rank, world, port, out_dir):
+def _loop_worker(rank, world, port, out_dir, with_len):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     from score_amd import harness as h
@@ -137,17 +200,30 @@ def _loop_worker(rank, world, port, out_dir):
         model.n_eval += 1
         return 0.0, 0.5, v, v, v, v, v, v, 0.25 + rank
     n_batches = 5 if rank == 0 else 3                          # rank 1's loader ends first: everybody stops there
-    out = h.train_loop(m, lambda: list(range(10 * rank, 10 * rank + n_batches)), lambda: [], 1e-3, 1e-4, 4, 18, epochs=2,
+    # with_len: loaders with a length (one agreement per EPOCH, no per-step collective); else plain iterators (one per step)
+    mk = (lambda: list(range(10 * rank, 10 * rank + n_batches))) if with_len else \
+         (lambda: iter(range(10 * rank, 10 * rank + n_batches)))
+    n_coll = [0]
+    orig = m.comm.all_reduce_sum
+
+    def counted(t):
+        n_coll[0] += 1
+        return orig(t)
+    m.comm.all_reduce_sum = counted
+    out = h.train_loop(m, mk, lambda: [], 1e-3, 1e-4, 4, 18, epochs=2,
                        save_path="ckpt", evaluate_fn=ev, log=lambda s: None)
+    # collectives of the loop itself: 6 train + 3 eval (the scripted model's own) + 3 metric means + the agreement
+    assert n_coll[0] == 6 + 3 + 3 + (2 if with_len else 10), n_coll[0]      # (no length: the per-epoch probe + 4 per epoch)
     np.savez(os.path.join(out_dir, "loop%d.npz" % rank), steps=out["steps"], mrrs=np.asarray(out["vali_mrrs"]),
              vloss=np.asarray(out["vali_losses"]), saved=np.asarray(m.saved), n_eval=m.n_eval,
              last_next=np.asarray([-1 if p[1] is None else p[1] for p in m.pairs]))
     dist.destroy_process_group()
 
 
-def test_train_loop_two_ranks_take_the_same_branches(tmp_path):
+@pytest.mark.parametrize("with_len", [True, False])
+def test_train_loop_two_ranks_take_the_same_branches(tmp_path, with_len):
     world = 2
-    mp.spawn(_loop_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_loop_worker, args=(world, _free_port(), str(tmp_path), with_len), nprocs=world, join=True)
     z = [np.load(str(tmp_path / ("loop%d.npz" % r))) for r in range(world)]
     # 3 steps per epoch (the shorter loader), eval_iter_num = 3: evaluations at steps 0, 3, 6
     assert int(z[0]["steps"]) == int(z[1]["steps"]) == 6 and int(z[0]["n_eval"]) == int(z[1]["n_eval"]) == 3

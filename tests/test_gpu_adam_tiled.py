@@ -170,7 +170,7 @@ def test_entry_points_bitwise_against_the_row_sweep(n_rows, D, window):
         alpha = float(np.float32(np.float32(1e-2) * np.sqrt(np.float32(1) - np.float32(b2p)) / (np.float32(1) - np.float32(b1p))))
         assert lib.score_adam_touched(C.byref(T), step, alpha, st) == 0
         assert lib.score_adam_rows(P(ref[0]), P(ref[1]), P(ref[2]), P(ref[3]), n_rows, D, P(flags_ref), alpha, 0.9, 0.999,
-                                   1e-8, st) == 0
+                                   1e-8, None, st) == 0
         if step % 6 == 0 or step == 25:
             assert lib.score_adam_catchup_rows(C.byref(T), 0, n_rows, step, st) == 0
             assert torch.equal(blk[:3], ref[:3]), step

@@ -98,6 +98,105 @@ def test_bad_id_equals_dummy_row_semantics_and_async_check():
         _lib.check(-4, "score_id_status")
 
 
+def _snapshot(m):
+    return dict(table=m.table.clone(), tm=m.table_m.clone(), tv=m.table_v.clone(), w=m.w.clone(), wm=m.w_m.clone(),
+                wv=m.w_v.clone(), step=int(m.step), b1=np.float32(m.beta1_power), b2=np.float32(m.beta2_power))
+
+
+def _same(m, snap):
+    now = _snapshot(m)
+    return all(torch.equal(now[k], snap[k]) for k in ("table", "tm", "tv", "w", "wm", "wv")) and \
+        now["step"] == snap["step"] and now["b1"] == snap["b1"] and now["b2"] == snap["b2"]
+
+
+@pytest.mark.parametrize("mode", ["sweep", "tiled", "graph"])
+def test_no_variable_is_updated_by_a_step_that_raises(mode):
+    """score.py:51-66 + :101-116: tf.nn.embedding_lookup raises inside sess.run, so train_step's assigns never run -- the
+    embedding table, every dense variable, both Adam slots of each and beta1_power / beta2_power are what they were before
+    the call.  Here the optimizer kernels read score_state_t.id_status when they execute and apply nothing while it is set
+    (score_guard_t), the host takes the step off its count again: bit for bit the state before the call, and training
+    then continues exactly like a twin model that never saw the bad batch (dropout on: the per-step seed too)."""
+    cfg = so.Cfg(*CFG, model_type="SCORE")
+    rng = np.random.default_rng(17)
+    goods = []
+    for _ in range(7):
+        g = random_batch(rng, cfg, 12)
+        g["length"][:] = cfg.T
+        goods.append(batch_tuple(g))
+    bad = {k: v.copy() for k, v in zip(NAMES, goods[3])}
+    bad["user_2hop"][5, 2, 1, 0] = CFG[0] + 3
+    bad["target_item"][7, 2] = -9
+    m, twin = _model(), _model()
+    for x in (m, twin):
+        if mode == "tiled":
+            x.adam_tiled_min_bytes = 0
+        if mode == "graph":
+            x.enable_graph(True)
+    for i in range(5):                               # (graph: eager, eager, captured, replays)
+        assert m.train(None, goods[i % 3], 1e-3, 1e-4) == twin.train(None, goods[i % 3], 1e-3, 1e-4)
+    if mode == "tiled":
+        assert m._tiled_on() and m._adam_dirty
+    snap = _snapshot(m)
+    with pytest.raises(ValueError) as ei:
+        m.train(None, batch_tuple(bad), 1e-3, 1e-4)
+    assert "(user_2hop)" in str(ei.value) and "(target_item)" in str(ei.value) and "no variable was updated" in str(ei.value)
+    assert _same(m, snap)
+    assert int(m._id_status.sum().item()) == 0
+    # ... and the run goes on as if the call had never been made
+    for i in range(5, 9):
+        assert m.train(None, goods[i % 7], 1e-3, 1e-4) == twin.train(None, goods[i % 7], 1e-3, 1e-4), i
+    assert _same(m, _snapshot(twin))
+
+
+@pytest.mark.parametrize("mode", ["sweep", "tiled"])
+def test_async_steps_queued_behind_a_bad_batch_are_not_applied_either(mode):
+    """train_async: the host has queued more steps by the time anybody looks.  The word is sticky, so the device applies
+    none of them and counts them; check_ids() takes exactly that many off the host's step count."""
+    cfg = so.Cfg(*CFG, model_type="SCORE")
+    rng = np.random.default_rng(23)
+    goods = []
+    for _ in range(4):
+        g = random_batch(rng, cfg, 10)
+        g["length"][:] = cfg.T
+        goods.append(batch_tuple(g))
+    bad = {k: v.copy() for k, v in zip(NAMES, goods[1])}
+    bad["item_2hop"][0, 0, 0, 0] = 2 ** 30
+    m, twin = _model(), _model()
+    for x in (m, twin):
+        if mode == "tiled":
+            x.adam_tiled_min_bytes = 0
+    for i in range(3):
+        m.train_async(goods[i], 1e-3, 1e-4)
+        twin.train_async(goods[i], 1e-3, 1e-4)
+    snap = _snapshot(m)
+    losses = [m.train_async(batch_tuple(bad), 1e-3, 1e-4).clone()]
+    losses += [m.train_async(goods[i], 1e-3, 1e-4).clone() for i in (3, 0)]
+    assert all(bool(torch.isnan(x)) for x in losses)           # every queued step reports it
+    with pytest.raises(ValueError) as ei:
+        m.check_ids()
+    assert "(item_2hop)" in str(ei.value) and "2 queued behind it" in str(ei.value)
+    assert _same(m, snap)
+    for i in (3, 0, 1):
+        assert float(m.train_async(goods[i], 1e-3, 1e-4)) == float(twin.train_async(goods[i], 1e-3, 1e-4))
+    assert _same(m, _snapshot(twin))
+
+
+def test_a_flush_with_the_word_set_raises_instead_of_returning_a_stale_table():
+    cfg = so.Cfg(*CFG, model_type="SCORE")
+    m = _model()
+    m.adam_tiled_min_bytes = 0
+    g = random_batch(np.random.default_rng(2), cfg, 10)
+    g["length"][:] = cfg.T
+    for _ in range(3):
+        m.train_async(batch_tuple(g), 1e-3, 1e-4)
+    bad = {k: v.copy() for k, v in g.items()}
+    bad["user_1hop"][1, 1, 1, 1] = CFG[0]
+    m.train_async(batch_tuple(bad), 1e-3, 1e-4)
+    with pytest.raises(ValueError):
+        m.table                                               # (save / get_params / tests read it through the same property)
+    assert torch.isfinite(m.table).all() and int(m.step) == 3
+
+
 def test_masked_slices_are_not_dereferenced():
     """ids of slices every sample masks (t >= max length) are never turned into addresses: garbage there is harmless
     and -- documented in include/score_hip.h -- not reported"""
@@ -144,5 +243,14 @@ def test_tiled_optimizer_and_sharded_plan_report():
     assert np.isfinite(s.train(None, batch_tuple(good), 1e-3, 1e-4))
     with pytest.raises(ValueError) as ei:
         s.train(None, batch_tuple(bad), 1e-3, 1e-4)
-    assert "(user_1hop)" in str(ei.value) and "rank 0" in str(ei.value)
+    assert "(user_1hop)" in str(ei.value) and "rank 0" in str(ei.value) and "before its step started" in str(ei.value)
     assert np.isfinite(s.train(None, batch_tuple(good), 1e-3, 1e-4))
+    # rejected on the host before anything ran: a twin that never saw the bad batch holds the same bits
+    t = ShardedSCORE(*CFG, comm=OneRank())
+    for _ in range(2):
+        t.train(None, batch_tuple(good), 1e-3, 1e-4)
+    assert torch.equal(s.backend.m.table, t.backend.m.table) and torch.equal(s.backend.m.w, t.backend.m.w)
+    with pytest.raises(ValueError):
+        s.eval(None, batch_tuple(bad), 1e-4)
+    pe, _, le = s.eval(None, batch_tuple(good), 1e-4)
+    assert np.isfinite(le) and np.isfinite(np.asarray(pe)).all()

@@ -418,7 +418,7 @@ def test_adam_matches_tf_form():
         a = float(opt.alpha(1e-3))
         opt.step(params, {"p": geff}, 1e-3)
         dg = dev(np.concatenate([g, np.zeros(pad, np.float32)]))
-        _lib.check(lib.score_adam(P(dp), P(dm), P(dv), P(dg), n, n_reg, lam, a, 0.9, 0.999, 1e-8, stream()), "adam")
+        _lib.check(lib.score_adam(P(dp), P(dm), P(dv), P(dg), n, n_reg, lam, a, 0.9, 0.999, 1e-8, None, stream()), "adam")
         torch.cuda.synchronize()
         assert np.allclose(dp.cpu().numpy()[:n], params["p"], rtol=1e-6, atol=1e-7)
         assert np.allclose(dm.cpu().numpy()[:n], opt.m["p"], rtol=1e-6, atol=1e-7)   # fma contraction: <= 1 ulp of the operands
