@@ -577,10 +577,13 @@ def main():
     t0 = time.perf_counter()
     fb = run_steps(args.steps, 0, None if graph else events, step_marks)
     finish_adam()                  # inside the timed region: no update is left owing when the clock stops
+    ev_tail = torch.cuda.Event(enable_timing=True)
+    ev_tail.record()
     barrier()
     dt = time.perf_counter() - t0
     beat("after")
     per_step_ms = [step_marks[i].elapsed_time(step_marks[i + 1]) for i in range(args.steps)]
+    flush_ms = step_marks[args.steps].elapsed_time(ev_tail)
     tiled = tiled and bool(inner._tiled_on())       # (a shard may have gone back to the sweep: HipBackend.note_requests)
     if graph:                      # stage timings from eager steps, outside the timed region
         model.enable_graph(False)
@@ -893,6 +896,8 @@ def main():
         "ms_per_step": dt / args.steps * 1e3,
         "ms_per_step_p50": float(np.median(per_step_ms)),
         "ms_per_step_p10_p90": [float(np.percentile(per_step_ms, 10)), float(np.percentile(per_step_ms, 90))],
+        "timed_region_ms": {"wall": dt * 1e3, "steps_by_events": float(np.sum(per_step_ms)), "optimizer_flush_by_events": flush_ms,
+                            "first_steps": [round(x, 4) for x in per_step_ms[:6]]},
         "ms_per_step_what": "ms_per_step = wall clock of the timed region (barrier to barrier, the optimizer's flush included) "
                             "/ steps: the figure `value` is computed from.  p50 / p10 / p90: per-step durations from one HIP "
                             "event per step on the launch stream (rank 0)",

@@ -125,6 +125,8 @@ class TorchDistComm(object):
     def exchange_counts(self, send_counts, device, extra=None):
         """all_to_all of one count per peer.  `extra` (an int): sent to every peer beside its count -- the reply is
         (counts, extras), one extra per rank (the local batch sizes ride here, no second collective)."""
+        if self.world == 1:            # nobody to tell: no collective, no read-back
+            return list(send_counts) if extra is None else (list(send_counts), [int(extra)])
         if extra is None:
             t = torch.tensor(send_counts, dtype=torch.int64, device=device)
             out = torch.empty_like(t)
@@ -161,6 +163,25 @@ class TorchDistComm(object):
             outs[p].copy_(buf)
         for r in reqs:
             r.wait()
+
+    def all_to_all_remote(self, out, inp, out_splits, in_splits):
+        """all_to_all of the segments that belong to OTHER ranks only; this rank's own segment is a device-side copy (or,
+        for callers that pass out / inp whose own segments are the same memory, nothing).  What a rank owns never goes
+        through RCCL: one rank = no collective at all, G ranks = (G - 1) / G of the bytes in the collective's kernels."""
+        r = self.rank
+        outs = list(out.split(out_splits, 0))
+        ins = list(inp.split(in_splits, 0))
+        if outs[r].numel() and outs[r].data_ptr() != ins[r].data_ptr():
+            outs[r].copy_(ins[r])
+        if self.world == 1:
+            return
+        if self._gloo:                 # (the pairwise host-staged exchange below already leaves the own segment out)
+            self.all_to_all(out, inp, out_splits, in_splits)
+            return
+        self._note("all_to_all_remote[%s x %d]" % (str(inp.dtype).replace("torch.", ""), int(inp.shape[0]) - int(ins[r].shape[0])))
+        outs[r] = out.new_empty((0,) + tuple(out.shape[1:]))
+        ins[r] = inp.new_empty((0,) + tuple(inp.shape[1:]))
+        self.dist.all_to_all(outs, ins, group=self.group)
 
     def all_reduce_sum(self, t):
         self._note("all_reduce[%d]" % t.numel())
@@ -519,8 +540,11 @@ class ShardedSCORE(object):
         # rank knows which ranks fed an id outside the table before anybody starts the step (_reject_bad_ids)
         recv, extras = cm.exchange_counts(send, self.device, extra=int(B_local) | (int(plan.get("bad_ids", 0)) << 32))
         sizes = [e & 0xFFFFFFFF for e in extras]
-        req = torch.empty((sum(recv),), dtype=torch.int32, device=self.device)
-        cm.all_to_all(req, plan["unique_rows"], recv, send)
+        if self.world == 1:
+            req = plan["unique_rows"]           # (the one owner is this rank: its request list IS the plan's unique rows)
+        else:
+            req = torch.empty((sum(recv),), dtype=torch.int32, device=self.device)
+            getattr(cm, "all_to_all_remote", cm.all_to_all)(req, plan["unique_rows"], recv, send)
         plan.update(send=send, recv=recv, req=req, global_B=sum(sizes), bad_by_rank=[e >> 32 for e in extras])
         if hasattr(self.backend, "note_requests"):
             self.backend.note_requests(sum(recv))
@@ -536,8 +560,10 @@ class ShardedSCORE(object):
         """Parameter phase: owners gather the requested rows from their (up-to-date) shard."""
         be, cm = self.backend, self.comm
         rows = be.gather(plan["req"])
+        if self.world == 1:
+            return rows                         # (gathered in the plan's unique-row order: it IS the mini-table)
         mini = torch.empty((plan["U"], self.D), dtype=torch.float32, device=self.device)
-        cm.all_to_all(mini, rows, plan["send"], plan["recv"])
+        getattr(cm, "all_to_all_remote", cm.all_to_all)(mini, rows, plan["send"], plan["recv"])
         return mini
 
     def prefetch(self, batch_data):
@@ -650,7 +676,9 @@ class ShardedSCORE(object):
             cur = torch.cuda.current_stream(self.device)
             mini_g, ev = be.backward(plan, mini, fw, keep_prob, scatter_event=self._ev_scatter)
             be.launch_sweep(self._gside)      # (first on that stream: it is through before the row gradients are)
-            grads_in = torch.empty((plan["req"].numel(), self.D), dtype=torch.float32, device=self.device)
+            # (one rank: the gradient rows of the mini-table ARE the owner's input, in request order: no exchange, no copy)
+            grads_in = mini_g if self.world == 1 else \
+                torch.empty((plan["req"].numel(), self.D), dtype=torch.float32, device=self.device)
             pipelined = lr is not None and next_batch is not None and self._prefetched is not None \
                 and self._prefetched[1] is not None and not os.environ.get("SCORE_NO_PIPELINE")
             nxt = None
@@ -661,7 +689,9 @@ class ShardedSCORE(object):
             icm = self.comm.index_comm() if hasattr(self.comm, "index_comm") else cm
             self._gside.wait_event(ev)
             with torch.cuda.stream(self._gside):
-                cm.all_to_all(grads_in, mini_g, plan["recv"], plan["send"])
+                if self.world > 1:
+                    getattr(cm, "all_to_all_remote", cm.all_to_all)(grads_in, mini_g, plan["recv"], plan["send"])
+                mini_g.record_stream(self._gside)
                 be.accumulate(plan["req"], grads_in, plan["recv"])
                 if pipelined:
                     be.adam_table(lr)
@@ -691,8 +721,11 @@ class ShardedSCORE(object):
         mini_g = be.backward(plan, mini, fw, keep_prob)
         if hasattr(be, "launch_sweep"):
             be.launch_sweep(None)
-        grads_in = torch.empty((plan["req"].numel(), self.D), dtype=torch.float32, device=self.device)
-        cm.all_to_all(grads_in, mini_g, plan["recv"], plan["send"])
+        if self.world == 1:
+            grads_in = mini_g
+        else:
+            grads_in = torch.empty((plan["req"].numel(), self.D), dtype=torch.float32, device=self.device)
+            getattr(cm, "all_to_all_remote", cm.all_to_all)(grads_in, mini_g, plan["recv"], plan["send"])
         cm.all_reduce_sum(be.dense_grad())
         be.accumulate(plan["req"], grads_in, plan["recv"])
         loss = fw["loss"].clone()          # [loss, log_loss (local share of the global mean), l2]

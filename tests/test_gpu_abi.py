@@ -94,3 +94,20 @@ def test_workspace_cache_evicts_one_entry_at_a_time():
     rng = np.random.default_rng(0)
     losses = [m.train(None, batch_tuple(random_batch(rng, cfg, B)), 1e-3, 1e-4) for B in (3, 5, 7, 9, 11, 13, 3, 5)]
     assert all(np.isfinite(l) for l in losses)
+
+
+def test_stream_copy_helper_copies_exactly():
+    """score_stream_copy (bench.py's measured bandwidth ceiling): a plain copy, any multiple of four floats"""
+    import ctypes as C
+    import torch
+    from score_amd import _lib
+    lib = _lib.load()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for n in (4, 1024, 4 * 100003, 1 << 24):
+        src = torch.randn((n,), device="cuda")
+        dst = torch.zeros((n + 8,), device="cuda")
+        assert lib.score_stream_copy(C.c_void_p(dst.data_ptr()), C.c_void_p(src.data_ptr()), n, st) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(dst[:n], src) and not bool(dst[n:].any())
+    assert lib.score_stream_copy(C.c_void_p(dst.data_ptr()), C.c_void_p(src.data_ptr()), 6, st) == -2
+    assert lib.score_stream_copy(None, C.c_void_p(src.data_ptr()), 8, st) == -1
