@@ -393,12 +393,20 @@ def main():
     ap.add_argument("--event-every", type=int, default=4,
                     help="record the HIP stage events (live kernel timing for `roofline`) on every E-th timed step: "
                          "eleven timing events per step cost ~3 %% of a 1.8 ms step")
+    ap.add_argument("--stage-events-timed", action="store_true",
+                    help="record ALL stage boundary events inside the timed region (every E-th step) instead of on extra steps "
+                         "behind it: the round-1..3 protocol (costs ~0.07 ms on each step that carries them)")
     ap.add_argument("--fresh-state", action="store_true",
                     help="headline from a FRESH optimizer state (only rows touched during the run carry moments): the "
                          "best case; default is the steady state with every table row live")
     ap.add_argument("--no-skip-masked", action="store_true",
                     help="gather and compute all T time slices, also those past every sample's length (whose "
                          "results the model masks): A/B for score_batch_t.active_slices")
+    ap.add_argument("--no-look-ahead", dest="look_ahead", action="store_false",
+                    help="do NOT tell apply_adam which batch comes next (SCOREBASE.apply_adam(next_batch=): with the time-tiled "
+                         "table optimizer the next batch's rows are brought up to date beside this step's weight-gradient "
+                         "products instead of in front of the next forward pass)")
+    ap.add_argument("--debug-flags", type=int, default=0, help="score_state_t.debug_flags (A/B switches of the launch sequence)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step as one captured hipGraph (SCOREBASE.enable_graph: launch-bound small shapes); "
                          "the timed loop then carries no stage events -- stages_ms come from a few eager steps after it")
@@ -483,6 +491,8 @@ def main():
 
     if args.no_skip_masked:
         inner.skip_masked_slices = False
+    if args.debug_flags:
+        inner.debug_flags = args.debug_flags
     # every rank trains on its own batches (weak: B each, global B * N; strong: global_batch / N each)
     batches = [model.device_batch(world.batch(B, rank * 1000 + i)) for i in range(args.batches)]
 
@@ -492,6 +502,7 @@ def main():
         torch.cuda.synchronize()
 
     graph = args.graph and not sharded
+    look_ahead = args.look_ahead and not sharded and not graph
     if graph:
         model.enable_graph(True)
     last_loss = [None]
@@ -514,7 +525,7 @@ def main():
             e_a0 = e_a1 = None
             if events is not None and i in events:
                 model.fwd_events, model.bwd_events, e_a0, e_a1 = events[i][:4]
-                inner.catchup_events = events[i][4:6]
+                inner.catchup_events = events[i][4:6] if events[i][4] is not None else None
             elif events is not None:
                 model.fwd_events = model.bwd_events = inner.catchup_events = None
             if sharded:   # optionally run the next batch's index-only phase (plan + row requests) inside this step
@@ -526,7 +537,10 @@ def main():
                 fb = model.forward_backward(batches[i % len(batches)], args.reg_lambda, 0.8)
             if e_a0 is not None:
                 e_a0.record()
-            model.apply_adam(args.lr, args.reg_lambda)
+            if look_ahead:      # the next batch is known (the loader's queue): its rows are caught up beside this step's tail
+                model.apply_adam(args.lr, args.reg_lambda, next_batch=batches[(i + 1) % len(batches)])
+            else:
+                model.apply_adam(args.lr, args.reg_lambda)
             if e_a1 is not None:
                 e_a1.record()
         if step_marks is not None:
@@ -545,11 +559,21 @@ def main():
         inner.table_flags.fill_(1)      # every row carries Adam moments: the state a long run converges to
     events = {}
     every = max(1, args.event_every)
+
+    def full_event_set():
+        model.enable_stage_events(True)
+        return (model.fwd_events, model.bwd_events) + tuple(torch.cuda.Event(enable_timing=True) for _ in range(4))
+    # Inside the timed region only the dominant kernel is bracketed (the fused gather: two events on every E-th step,
+    # `roofline_bench_workload`'s live launch duration); the full stage table -- eleven events per step, +0.07 ms on a step that
+    # carries them (round 4: per-step marks, 1.35 vs 1.27 ms) -- comes from a few extra steps right behind the timed region
     for i in range(args.steps):
         if i % every:
             continue
-        model.enable_stage_events(True)
-        events[i] = (model.fwd_events, model.bwd_events) + tuple(torch.cuda.Event(enable_timing=True) for _ in range(4))
+        if args.stage_events_timed:
+            events[i] = full_event_set()
+        else:
+            model.enable_stage_events(True)
+            events[i] = (model.fwd_events[:2] + [None, None, None], None, None, None, None, None)
     step_marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]     # one record per step: ms_per_step_p50
     # The interpreter's cyclic garbage collector: a generation-2 pass over the ~10^6 objects torch has alive takes 50 - 70
     # ms, and when one lands inside a host-bound timed loop (the small shapes: 300 steps of 0.38 ms) it alone adds 0.13 -
@@ -567,8 +591,7 @@ def main():
     if args.warmup > 0 and not graph:
         # the last warm-up step carries stage events like every `every`-th timed step does: the first step that records
         # timing events pays a one-time 15 ms in the HIP runtime (measured), which is warm-up, not a step
-        model.enable_stage_events(True)
-        warm_ev = {-1: (model.fwd_events, model.bwd_events) + tuple(torch.cuda.Event(enable_timing=True) for _ in range(4))}
+        warm_ev = {-1: full_event_set()}
         run_steps(1, -1, warm_ev)
     elif args.warmup > 0:
         run_steps(1)
@@ -588,10 +611,20 @@ def main():
     if graph:                      # stage timings from eager steps, outside the timed region
         model.enable_graph(False)
         graph = False
-        fb = run_steps(4 * every, 0, {k: v for k, v in events.items() if k < 4 * every})
-        events = {k: v for k, v in events.items() if k < 4 * every}
+        events = {i: full_event_set() for i in range(0, 4 * every, every)}
+        fb = run_steps(4 * every, 0, events)
         torch.cuda.synchronize()
         graph = True
+    if not args.stage_events_timed and not graph:
+        gather_ms = [v[0][0].elapsed_time(v[0][1]) for v in events.values()]      # live, inside the timed region
+        # the stage table: eager steps with every boundary event, right behind the timed region (same state, same batches)
+        n_st = max(3 * every, 12)
+        events = {i: full_event_set() for i in range(0, n_st, every)}
+        fb2 = run_steps(n_st, 0, events)
+        fb = fb2 if fb is None else fb
+        torch.cuda.synchronize()
+    else:
+        gather_ms = [v[0][0].elapsed_time(v[0][1]) for v in events.values()]
     model.enable_stage_events(False)
     dt_ranks = [dt]
     ranks_seen = 1
@@ -613,7 +646,7 @@ def main():
     def avg(fn):
         return float(np.mean([fn(s) for s in ev_sets]))
     stages = {
-        "fwd_gather_coattn": avg(lambda s: s[0][0].elapsed_time(s[0][1])),
+        "fwd_gather_coattn": float(np.mean(gather_ms)),
         "fwd_gru": avg(lambda s: s[0][1].elapsed_time(s[0][2])),
         "fwd_attention": avg(lambda s: s[0][2].elapsed_time(s[0][3])),
         "fwd_head_loss": avg(lambda s: s[0][3].elapsed_time(s[0][4])),

@@ -326,6 +326,15 @@ int score_adam_touched_rows(const score_adam_table_t* t, const int32_t* rows, co
 /* every value of ids[0..n_ids) that names a live row (values outside [0, n_rows) are ignored, so a whole flat batch
  * buffer may be passed): replay the zero-gradient steps row_step+1 .. upto of that row */
 int score_adam_catchup_ids(const score_adam_table_t* t, const int32_t* ids, int64_t n_ids, uint32_t upto, void* stream);
+/* The NEXT batch's rows, one step early.  Between score_backward's row scatter of step `step` (its stage boundary 4: every
+ * row that gets this step's gradient is in state 2 by then) and the next step's score_forward, on any stream: every id that
+ * names a live row NOT in state 2 is replayed through `step` itself -- its gradient in this step is zero, so its update
+ * needs nothing but alpha (= the alpha score_adam_touched(step) is called with; written to the ring here too).  Rows in
+ * state 2 are left to score_adam_touched.  Afterwards every row the next batch reads is current up to `step`, and the
+ * next step needs no score_adam_catchup_ids: its 0.07 ms (cfg-3) run beside this step's weight-gradient products instead
+ * of in front of the next forward.  Must not overlap score_adam_catchup_rows on another stream (same rows). */
+int score_adam_catchup_ids_through(const score_adam_table_t* t, const int32_t* ids, int64_t n_ids, uint32_t step, float alpha,
+                                   void* stream);
 /* the same for every state-1 row of [row_begin, row_end) */
 int score_adam_catchup_rows(const score_adam_table_t* t, int64_t row_begin, int64_t row_end, uint32_t upto, void* stream);
 

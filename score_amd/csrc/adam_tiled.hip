@@ -217,8 +217,11 @@ __global__ __launch_bounds__(256) void adam_catchup_rows_kernel(const TiledArgs 
 // Values outside [0, n_rows) are ignored, so the caller may pass a whole flat batch buffer (the lengths and labels
 // in it name low rows: catching a row up early is always valid).
 __global__ __launch_bounds__(256) void adam_mark_ids_kernel(const TiledArgs a, const int32_t* __restrict__ ids, int64_t n,
-                                                            uint32_t upto) {
+                                                            uint32_t upto, int set_alpha, float alpha_upto) {
   if (tiled_guarded(a)) return;
+  // score_adam_catchup_ids_through: the replay that follows reads alpha of step `upto` from the ring before the step's own
+  // score_adam_touched has written it (the same value)
+  if (set_alpha && blockIdx.x == 0 && threadIdx.x == 0) a.ring[upto % SCORE_ADAM_RING] = alpha_upto;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     const int row = ids[i];
@@ -319,9 +322,23 @@ extern "C" int score_adam_catchup_ids(const score_adam_table_t* t, const int32_t
   if (n_ids == 0) return 0;
   if (upto == 0) return 0;         // nothing has been applied yet: nothing can lag
   hipLaunchKernelGGL(adam_mark_ids_kernel, dim3(tiled_blocks(cdiv64(n_ids, 4))), dim3(256), 0, (hipStream_t)stream, a, ids,
-                     n_ids, upto);
+                     n_ids, upto, 0, 0.f);
   SCORE_CHECK_LAUNCH();
   hipLaunchKernelGGL(adam_catchup_marked_kernel, dim3(tiled_blocks(a.n_rows)), dim3(256), 0, (hipStream_t)stream, a, upto);
+  SCORE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int score_adam_catchup_ids_through(const score_adam_table_t* t, const int32_t* ids, int64_t n_ids, uint32_t step,
+                                              float alpha, void* stream) {
+  TiledArgs a;
+  SCORE_TRY(tiled_args(t, &a, false));
+  if (!ids || n_ids < 0 || step == 0) return SCORE_E_BADARG;
+  if (n_ids == 0) return 0;
+  hipLaunchKernelGGL(adam_mark_ids_kernel, dim3(tiled_blocks(cdiv64(n_ids, 4))), dim3(256), 0, (hipStream_t)stream, a, ids,
+                     n_ids, step, 1, alpha);
+  SCORE_CHECK_LAUNCH();
+  hipLaunchKernelGGL(adam_catchup_marked_kernel, dim3(tiled_blocks(a.n_rows)), dim3(256), 0, (hipStream_t)stream, a, step);
   SCORE_CHECK_LAUNCH();
   return 0;
 }

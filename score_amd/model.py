@@ -200,6 +200,8 @@ class SCOREBASE(object):
         self._ev_stage = None        # a stage boundary of the backward pass (where the window slice starts)
         self.catchup_events = None   # optional (start, end) torch events around score_adam_catchup_ids (bench.py)
         self._ev_sweep = None
+        self._ev_b4 = None           # stage boundary 4 of the backward pass (row scatter done): where the look-ahead catch-up starts
+        self._ahead = None           # (DeviceBatch, event): its rows were brought up to date through the step in flight
         self._sweep_st = None        # stream of the window slice when it runs beside the forward pass (SCORE_ADAM_SWEEP_AT=f1)
         self._fwd_stage_event = None
         self._pinned_stream = self._pinned_handle = None
@@ -730,6 +732,17 @@ class SCOREBASE(object):
             if events[k] is None:
                 events[k] = self._ev_stage
             ev_sweep_start = events[k]
+        self._b4_recorded = None
+        if self._look_ahead and self.scatter_mode == 0 and self._tiled_on():
+            # boundary 4 (the row scatter has marked every row that gets this step's gradient): apply_adam(next_batch=)
+            # starts the next batch's catch-up there, on the side stream
+            if self._ev_b4 is None:
+                self._ev_b4 = torch.cuda.Event()
+                self._ev_b4.record(cur)
+            events = list(events) if events else [None] * 6
+            if events[4] is None:
+                events[4] = self._ev_b4
+            self._b4_recorded = events[4]
         rc = self.lib.score_backward(C.byref(self.cfg), C.byref(st), C.byref(db.struct), float(keep_prob),
                                      _ptr(self.w_g), _ptr(self.table_g), self._event_array(events),
                                      self._stream())
@@ -743,11 +756,18 @@ class SCOREBASE(object):
         f = np.float32
         return float(f(f(lr) * np.sqrt(f(1) - self.beta2_power) / (f(1) - self.beta1_power)))
 
-    def apply_adam(self, lr, reg_lambda):
+    def apply_adam(self, lr, reg_lambda, next_batch=None):
         """tf.train.AdamOptimizer(lr).minimize(loss) update (score.py:96-99): dense over the
-        whole table (the emb_mtx*mask gradient is dense) and over every dense variable."""
+        whole table (the emb_mtx*mask gradient is dense) and over every dense variable.
+        next_batch (a DeviceBatch, optional): the batch the NEXT step will train on, when the caller already holds it (the
+        reference's loader keeps a queue of ten, graph_loader.py:280-281).  With the time-tiled table optimizer its rows
+        are then brought up to date -- through this very step -- on the side stream beside this step's weight-gradient
+        products, instead of in front of the next forward pass (score_adam_catchup_ids_through).  Same updates, same order
+        per row: the same bits.  A different batch next is fine (it is caught up the usual way)."""
         with self._Pin(self):
             if self._tiled_on() and self._row_grads:
+                if next_batch is not None:
+                    self._catchup_ahead(next_batch, lr)
                 self._adam_table_tiled(lr)
             else:
                 self.adam_table(lr)
@@ -780,10 +800,23 @@ class SCOREBASE(object):
         if self._ev_sweep is not None:
             cur.wait_event(self._ev_sweep)
             self._ev_sweep = None
+        if self._ahead is not None:          # (a look-ahead catch-up replays rows on the side stream: nothing else may meanwhile)
+            cur.wait_event(self._ahead[1])
 
     def _catchup(self, db, sweep):
         """Before a forward: the rows this batch reads are brought up to self.step (score_adam_catchup_ids); in a
         training step the window's slice of the table follows on its own stream, beside the step."""
+        ah, self._ahead = self._ahead, None
+        if ah is not None:
+            self._cur().wait_event(ah[1])
+            if ah[0] is db and db.flat is not None:
+                # apply_adam(next_batch=db) of the previous step has brought these rows up to date through that step
+                # (score_adam_catchup_ids_through, beside its weight-gradient products): nothing to replay here
+                ev = self.catchup_events
+                if ev:
+                    ev[0].record(); ev[1].record()
+                self._catchup_ids([], sweep)
+                return
         self._catchup_ids([db.flat] if db.flat is not None else list(db.tensors[:6]), sweep)
 
     def _catchup_ids(self, spans, sweep, inline_sweep=False):
@@ -791,7 +824,7 @@ class SCOREBASE(object):
         ev = self.catchup_events
         _, _, T = self._tiled_table()     # (created here, on the main stream, well before the side stream first uses it)
         if not self._adam_dirty:
-            if ev:
+            if ev and spans:
                 ev[0].record(); ev[1].record()
             return
         cur = self._cur()
@@ -799,12 +832,12 @@ class SCOREBASE(object):
         if self._flags_marked:
             self._drop_row_marks()        # (a backward nobody applied left state-2 marks)
         upto = int(self.step)
-        if ev:
+        if ev and spans:
             ev[0].record()
         for t in spans:
             _lib.check(self.lib.score_adam_catchup_ids(C.byref(T), _ptr(t), t.numel(), upto, self._stream()),
                        "score_adam_catchup_ids")
-        if ev:
+        if ev and spans:
             ev[1].record()
         if sweep:
             # the window's slice of the table: must start after the rows above are done (it would take them for lagging
@@ -830,6 +863,26 @@ class SCOREBASE(object):
                    "score_adam_catchup_rows")
         if other:
             self._ev_sweep = stream.record_event()
+
+    _look_ahead = True               # score_backward records its stage boundary 4 for apply_adam(next_batch=)
+
+    def _catchup_ahead(self, nxt, lr):
+        ev4 = getattr(self, "_b4_recorded", None)
+        if (not isinstance(nxt, DeviceBatch) or nxt.flat is None or ev4 is None or not self._tiled_ready
+                or self._tiled is None or self._side is None):
+            return
+        _, _, T = self._tiled
+        side = self._side
+        side.wait_event(ev4)
+        if self._ev_sweep is not None:       # (a window slice on a stream of its own: behind it)
+            side.wait_event(self._ev_sweep)
+        # (the side stream has run this step's window slice before -- it was started at boundary 2 --, so the two replays
+        #  never meet on a row; rows in state 2 are skipped here and updated by score_adam_touched on the main stream)
+        _lib.check(self.lib.score_adam_catchup_ids_through(C.byref(T), _ptr(nxt.flat), nxt.flat.numel(), int(self.step) + 1,
+                                                           self._alpha(lr), C.c_void_p(side.cuda_stream)),
+                   "score_adam_catchup_ids_through")
+        self._ahead = (nxt, side.record_event())
+        self._b4_recorded = None
 
     def _adam_table_tiled(self, lr):
         """ApplyAdam of step self.step + 1 on the rows that have a gradient; every other live row owes it.
@@ -921,13 +974,13 @@ class SCOREBASE(object):
         self.beta2_power = np.float32(self.beta2_power * np.float32(ADAM_B2))
         self.step += 1
 
-    def train_async(self, batch_data, lr, reg_lambda, keep_prob=0.8, dropout_masks=None):
-        """One training step; returns the loss as a 0-d device tensor (no host sync)."""
+    def train_async(self, batch_data, lr, reg_lambda, keep_prob=0.8, dropout_masks=None, next_batch=None):
+        """One training step; returns the loss as a 0-d device tensor (no host sync).  next_batch: see apply_adam."""
         if self._graph_on and dropout_masks is None and self.scatter_mode == 0 and not self.fwd_events:
             return self._train_captured(batch_data, lr, reg_lambda, keep_prob)
         with self._Pin(self):
             lay, ws = self.forward_backward(batch_data, reg_lambda, keep_prob, dropout_masks)
-            self.apply_adam(lr, reg_lambda)
+            self.apply_adam(lr, reg_lambda, next_batch)
         return ws[lay.loss]
 
     # ------------------------------------------------------------------ captured step (hipGraph)
@@ -1031,6 +1084,9 @@ class SCOREBASE(object):
             if skipped:
                 self._rollback_steps(skipped)
             self._pending_sweep = None          # (a window slice scheduled for a step that was not applied)
+            if self._ahead is not None:         # (a look-ahead catch-up that the set word suppressed)
+                self._cur().wait_event(self._ahead[1])
+                self._ahead = None
             self._adam_dirty = self._tiled is not None and self._tiled_ready     # (a suppressed flush left rows behind)
             self._flags_marked = True           # state-2 marks of the suppressed steps: gone before the next backward
             self._drop_row_marks()

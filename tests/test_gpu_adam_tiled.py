@@ -369,3 +369,37 @@ def test_window_slice_placement_does_not_change_the_tables(monkeypatch, where):
     if where == "f1":
         assert a._sweep_st is not None              # (the slice did run on its own stream)
     assert same_state(a, b)
+
+
+def test_look_ahead_catchup_of_the_next_batch_is_bitwise_the_same():
+    """apply_adam(next_batch=) / train_async(next_batch=): the next batch's rows are brought up to date THROUGH the step in
+    flight on the side stream (score_adam_catchup_ids_through, behind the row scatter) instead of in front of the next
+    forward.  Every (row, step) update still runs exactly once, in step order: losses and state equal the plain run's bit
+    for bit -- with right hints, wrong hints (another batch comes next), no hint, an eval or a table read in between, an lr
+    change, and dropout on."""
+    cfg = so.Cfg(3000, 16, 16, 4, 3, 2, 3, "SCORE")
+    plain, ahead = make(cfg, 5), make(cfg, 5)
+    bs = batches(cfg, 16, 6, seed=9, hot_rows=150)
+    dbs_p = [plain.device_batch(b) for b in bs]
+    dbs_a = [ahead.device_batch(b) for b in bs]
+    order = [0, 1, 2, 3, 4, 5, 0, 2, 4, 1, 3, 5, 5, 0, 1, 1, 2, 3, 4, 0, 5, 2, 3, 1, 4, 0, 1, 2, 3, 4]
+    for i, bi in enumerate(order):
+        lr = 1e-2 if i < 17 else 3e-3
+        nxt = order[i + 1] if i + 1 < len(order) else 0
+        if i % 7 == 3:
+            hint = dbs_a[(nxt + 1) % len(bs)]          # a WRONG hint: some other batch comes next
+        elif i % 5 == 4:
+            hint = None
+        else:
+            hint = dbs_a[nxt]
+        lp = plain.train_async(dbs_p[bi], lr, 1e-4)
+        la = ahead.train_async(dbs_a[bi], lr, 1e-4, next_batch=hint)
+        assert float(lp) == float(la), i
+        if i > 2:
+            assert ahead._tiled_on() and ahead._adam_dirty
+        if i == 9:                                     # an evaluation of another batch between two steps
+            assert plain.eval(None, dbs_p[4], 1e-4)[0] == ahead.eval(None, dbs_a[4], 1e-4)[0]
+        if i in (13, 22):                              # somebody reads the table (flush) while a look-ahead is pending
+            assert same_state(plain, ahead), i
+    assert same_state(plain, ahead)
+    assert ahead._ahead is None or ahead._ahead[0] is not None
