@@ -361,7 +361,11 @@ typedef struct {
                            head's forward in one launch at every batch size; bit 2 = the H = 128 recurrences on the
                            f32-input MFMA kernels instead of the bf16x3 form; bit 3 = the GRU input projections (and
                            their input gradients) on the tiled bf16x3 kernel instead of the whole-N panel form
-                           (csrc/gemm_panel.hip); bit 4 = the input gradients in the panel form at every size       */
+                           (csrc/gemm_panel.hip); bit 4 = the input gradients in the panel form at every size; bit 6 =
+                           build_fc_net layer by layer instead of the fused head kernels; bit 7 = the temporal attention
+                           layer by layer instead of its fused kernels (the paths shapes outside the fused kernels'
+                           instantiated widths take anyway).  The ONLY switches of the launch sequence: the library reads
+                           no environment variable                                                                   */
   uint8_t* row_flags;   /* optional [n_table_rows] row state of the dense table optimizer (see
                            score_adam_rows): score_backward (scatter_mode 0) marks every row it
                            writes into grad_table with 2 and leaves all other rows of grad_table

@@ -292,12 +292,16 @@ static int side_stream(const score_state_t* st, SideStream** out) {
   *out = &sd;
   return 0;
 }
-// A/B switches of the launch sequence, read from the environment ONCE (first call), not per step
-struct EnvFlags { bool head_unfused, attn_tail_unfused, wgrad_side, gru_stepwise, attn_fwd_unfused, gru_bias_colsum, gemm_tiled, wgrad_early, panel_dx; };
-static bool env_on(const char* name) { const char* v = getenv(name); return v && *v && !(v[0] == '0' && !v[1]); }   // (set, not empty, not "0")
-static const EnvFlags& env_flags() {
-  static const EnvFlags f = {env_on("SCORE_HEAD_UNFUSED"), env_on("SCORE_ATTN_TAIL_UNFUSED"), env_on("SCORE_WGRAD_SIDE"),
-                             env_on("SCORE_GRU_STEPWISE"), env_on("SCORE_ATTN_FWD_UNFUSED"), env_on("SCORE_GRU_BIAS_COLSUM"), env_on("SCORE_GEMM_TILED"), env_on("SCORE_WGRAD_EARLY"), env_on("SCORE_PANEL_DX")};
+// A/B switches of the launch sequence: score_state_t.debug_flags only (round 4: the environment switches of rounds 1 - 3 --
+// SCORE_WGRAD_SIDE / _EARLY, SCORE_PANEL_DX, SCORE_GEMM_TILED, SCORE_GRU_STEPWISE, SCORE_GRU_BIAS_COLSUM, SCORE_HEAD_UNFUSED,
+// SCORE_ATTN_*_UNFUSED -- were decided A/Bs or duplicates of a flag bit, and a process-wide switch read once cannot be
+// flipped by the test that wants to compare the two paths)
+struct Flags { bool head_unfused, attn_unfused, gru_stepwise; };
+static inline Flags flags_of(const score_state_t* st) {
+  Flags f;
+  f.head_unfused = (st->debug_flags & 64) != 0;
+  f.attn_unfused = (st->debug_flags & 128) != 0;
+  f.gru_stepwise = (st->debug_flags & 1) != 0;
   return f;
 }
 #define HIPTRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return (int)e_; } while (0)
@@ -443,18 +447,20 @@ extern "C" int score_index_plan(const score_config_t* cfg, const score_state_t* 
 
 // do the two sides' GRU input projections (which = 0) / their input gradients (which = 1) take the panel form?  Same
 // answer in the forward pass (which writes the weight images) and in the backward pass (which uses them).
-// The input gradients: from 64 K rows per side (cfg-5), or with SCORE_PANEL_DX=1.  The kernel itself is 30 % faster there
+// The input gradients: from 64 K rows per side (cfg-5), or with debug_flags bit 4.  The kernel itself is 30 % faster there
 // too (71 vs 101 us at cfg-3), but a panel workgroup owns its CU (8 waves x 256 registers), and the backward pass has
 // ~350 us of other streams' work to place -- the side stream's query branch and early weight gradients, the optimizer's
 // window slice -- which the tiled kernel lets run beside it and a one-round panel kernel pushes into the co-attention
 // backward and the scatter (cfg-3: 0.254 -> 0.329 ms), or, with the recurrences' weight gradients moved in front of those
-// (SCORE_WGRAD_EARLY=1), into them (1.287 -> 1.285 ms/step; projections only: 1.273).  At cfg-5's sizes the other
+// (round 3's SCORE_WGRAD_EARLY), into them (1.287 -> 1.285 ms/step; projections only: 1.273; round 4: with the head's and the
+// attention's products folded into the end-of-pass launch, or the side stream joined before the co-attention backward, the
+// same: profiles/r04_probes.md).  At cfg-5's sizes the other
 // streams' work is small beside these products: 20.3 -> 19.8 ms/step with both.
 static bool panel_gemms(const Dims& d, const score_state_t* st, int BT, int which) {
-  if (st->gemm_mode != 1 || env_flags().gemm_tiled || (st->debug_flags & 8) || d.Is[0] != d.Is[1]) return false;
+  if (st->gemm_mode != 1 || (st->debug_flags & 8) || d.Is[0] != d.Is[1]) return false;
   const int ns = panel_x_splits(d.H);
   return which == 0 ? ns > 0 && score_gemm_panel_ok(2 * ns, BT, 3 * d.H / ns, d.Is[0], d.I, 3 * d.H, nullptr)
-                    : (env_flags().panel_dx || (st->debug_flags & 16) || (int64_t)BT >= 65536) && panel_d_splits(d.Is[0]) > 0 &&
+                    : ((st->debug_flags & 16) || (int64_t)BT >= 65536) && panel_d_splits(d.Is[0]) > 0 &&
                           score_gemm_panel_ok(2 * panel_d_splits(d.Is[0]), BT, d.Is[0] / panel_d_splits(d.Is[0]), 3 * d.H, 3 * d.H, d.I, nullptr);
 }
 
@@ -530,7 +536,8 @@ extern "C" int score_forward(const score_config_t* cfg, const score_state_t* st,
   }
   hipEvent_t wx_ev = sd->wx;
   HIPTRY(hipEventRecord(wx_ev, sd->st));
-  const bool head_fused = !env_flags().head_unfused;
+  const Flags fl = flags_of(st);
+  const bool head_fused = !fl.head_unfused;
   const int64_t weff_stride = align_up64(2 * (int64_t)d.Dk * AT1 + 48, 4);     // replicas of the folded attention weight (build_ws)
   G(score_launch_l2_partials(W, P.n_reg, ws + w.part, sd->st));
   if (!d.attn) HIPTRY(hipEventRecord(sd->join, sd->st));
@@ -573,7 +580,7 @@ extern "C" int score_forward(const score_config_t* cfg, const score_state_t* st,
     GruArgs ga;
     memset(&ga, 0, sizeof(ga));
     ga.B = B; ga.T = T; ga.H = H; ga.length = bt->length; ga.nw8 = 1;
-    ga.tmp = ws + w.gru_tmp; ga.tmp_floats = w.gru_tmp_floats; ga.x3 = x3 != 0; ga.x3_rec = ga.x3 && !(st->debug_flags & 4); ga.stepwise = env_flags().gru_stepwise || (st->debug_flags & 1);   // H = 128: two waves per SIMD hide the LDS/epilogue latency (measured -0.08 ms/step)
+    ga.tmp = ws + w.gru_tmp; ga.tmp_floats = w.gru_tmp_floats; ga.x3 = x3 != 0; ga.x3_rec = ga.x3 && !(st->debug_flags & 4); ga.stepwise = fl.gru_stepwise;   // H = 128: two waves per SIMD hide the LDS/epilogue latency (measured -0.08 ms/step)
     HIPTRY(hipStreamWaitEvent(s, wx_ev, 0));
     if (d.Is[0] == d.Is[1]) {    // both sides' projections in ONE grouped launch (each with its own bias row)
       const float* c0 = ws + w.wxcat;
@@ -615,7 +622,7 @@ extern "C" int score_forward(const score_config_t* cfg, const score_state_t* st,
     // temporal attention (:169-186, 210-215); q, Weff/Wq and qz come from the side stream
     HIPTRY(hipStreamWaitEvent(s, sd->join, 0));
     // all of it in one launch (head_fused.hip) where the shape allows ...
-    int frc = (env_flags().attn_fwd_unfused || env_flags().attn_tail_unfused) ? SCORE_E_SHAPE
+    int frc = fl.attn_unfused ? SCORE_E_SHAPE
                   : score_launch_attn_fwd_fused(B, T, H, d.NI, AT1, AT2, ws + w.q, ws + w.gru_out[0], ws + w.gru_out[1],
                                                 ws + w.info, ws + w.weff, ws + w.qz, W + P.at_w[2], W + P.at_b[2],
                                                 W + P.at_w[3], W + P.at_b[3], bt->length, ws + w.ainp, ws + w.a1, ws + w.a2,
@@ -628,7 +635,7 @@ extern "C" int score_forward(const score_config_t* cfg, const score_state_t* st,
     G(gemm_mode_call(x3, 0, BT, AT1, 2 * d.Dk, ws + w.ainp, 2 * d.Dk, ws + w.weff, AT1, ws + w.a1, AT1, ws + w.qz,
                      GF_BIAS | GF_RELU | (T << 16), 1.f, nullptr, 0, scratch, w.scratch_floats, s));
     // dense_4, dense_5, mask, softmax over T and the pooling: one launch, a block per sample (head.hip)
-    int trc = env_flags().attn_tail_unfused ? SCORE_E_SHAPE
+    int trc = fl.attn_unfused ? SCORE_E_SHAPE
                   : score_launch_attn_tail_fwd(B, T, H, AT1, AT2, ws + w.a1, W + P.at_w[2], W + P.at_b[2], W + P.at_w[3],
                                                W + P.at_b[3], bt->length, ws + w.gru_out[0], ws + w.gru_out[1], ws + w.a2,
                                                ws + w.att_score, ws + w.head_inp, d.Dhead, d.off_u, d.off_i, s);
@@ -700,6 +707,7 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
   float* scratch = ws + w.scratch;
   const int64_t SF = w.scratch_floats;
   const int x3 = st->gemm_mode == 1 ? GF_X3 : 0;
+  const Flags fl = flags_of(st);
   ColsumJobs cq;
   cq.n = 0; cq.part_used = 0;
   // weight gradients C = X^T dY have no consumer inside the pass: queued, issued together at its end
@@ -720,14 +728,14 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
   // fc3: dW = f2^T dlogit, db = sum dlogit, dz2 = [f2>0] dlogit w3 / keep
   G(gemm_queue_add(&gq, FC2, 1, B, ws + w.f2, FC2, ws + w.dlogit, 1, gw + P.fc_w[2], 1));
   G(colsum_queue_add(&cq, ws + w.dlogit, B, 1, 1, gw + P.fc_b[2], 0));
-  if (env_flags().head_unfused || !score_head_fwd_fused_fits(B, d.Dhead, FC1, FC2))     // (else score_forward's fused head wrote dz2)
+  if (fl.head_unfused || !score_head_fwd_fused_fits(B, d.Dhead, FC1, FC2))     // (else score_forward's fused head wrote dz2)
     G(score_launch_outer_relu_bwd(B, FC2, ws + w.dlogit, W + P.fc_w[2], ws + w.f2, keep_prob, ws + w.dz2, s));
   // fc2
   G(gemm_queue_add(&gq, FC1, FC2, B, ws + w.f1, FC1, ws + w.dz2, FC2, gw + P.fc_w[1], FC2));
   G(colsum_queue_add(&cq, ws + w.dz2, B, FC2, FC2, gw + P.fc_b[1], 0));
   const float rs = (float)(1.0 / sqrt(1.0 + 1e-3));
   // dz1, d bn1, d head input and bn1's d gamma terms: one launch (head_fused.hip) ...
-  int hbrc = env_flags().head_unfused ? SCORE_E_SHAPE
+  int hbrc = fl.head_unfused ? SCORE_E_SHAPE
                  : score_launch_head_bwd_fused(B, d.Dhead, FC1, FC2, ws + w.dz2, W + P.fc_w[1], ws + w.f1, keep_prob,
                                                W + P.fc_w[0], ws + w.head_inp, W + P.bn_g, rs, ws + w.dz1, ws + w.dbn,
                                                ws + w.dhead, ws + w.dgstage, s);
@@ -756,9 +764,9 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
     // (on small batches the fused attention backward below does this part too -- one launch less: 0.0218 -> 0.0183 ms for
     //  the stage at the reference's own shape; at cfg-3, where a workgroup per four samples serialises what 1024 small
     //  workgroups do side by side, the separate launch stays: 0.0613 vs 0.0629)
-    const bool pool_in_fused = !env_flags().attn_fwd_unfused && !env_flags().attn_tail_unfused && (int64_t)B * T < 8192 &&
+    const bool pool_in_fused = !fl.attn_unfused && (int64_t)B * T < 8192 &&
                                score_attn_inp_bwd_fused_fits(B, T, H, d.NI, AT1, AT2, d.Dhead, d.off_u, d.off_i, true);
-    int prc = pool_in_fused ? 0 : env_flags().attn_tail_unfused ? SCORE_E_SHAPE
+    int prc = pool_in_fused ? 0 : fl.attn_unfused ? SCORE_E_SHAPE
                   : score_launch_attn_pool_bwd(B, T, H, AT2, ws + w.a2, W + P.at_w[3], bt->length, ws + w.gru_out[0],
                                                ws + w.gru_out[1], ws + w.att_score, ws + w.dhead, d.Dhead, d.off_u,
                                                d.off_i, ws + w.ds, ws + w.da2, s, AT1, W + P.at_w[2], ws + w.a1, ws + w.da1);
@@ -786,7 +794,7 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
     // d inp = da1 . Weff^T and its way into d (states, atten_info, q): one launch where the shape allows (head_fused.hip).
     // dq = sum_t d(q*k).k here; the per-sample q-term gradient dzsum . Wq^T is added, and the query projection's
     // backward runs, on the side stream below (beside the recurrence: only the target rows consume them)
-    int brc = env_flags().attn_fwd_unfused ? SCORE_E_SHAPE
+    int brc = fl.attn_unfused ? SCORE_E_SHAPE
               : pool_in_fused
                   ? score_launch_attn_inp_bwd_fused(B, T, H, d.NI, AT1, nullptr, ws + w.weff, ws + w.q, ws + w.gru_out[0],
                                                     ws + w.gru_out[1], ws + w.info, ws + w.att_score, ws + w.dhead, d.Dhead,
@@ -821,8 +829,6 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
   int gru_bias_rows = 0;
   // ---- GRUs (score.py:205-208)
   // the weight gradients queued so far (head, attention) have everything they need: beside the recurrence
-  const bool wgrad_side = env_flags().wgrad_side;   // A/B: the recurrences' weight gradients beside the scatter
-  const int64_t slab_third = (w.dwslab_floats / 2) & ~(int64_t)3;      // region of the second side flush
   const int64_t slab_half = (w.dwslab_floats / 4) & ~(int64_t)3;        // region of the first one
   {
     HIPTRY(hipEventRecord(side->fork, s));
@@ -860,7 +866,7 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
     GruArgs ga;
     memset(&ga, 0, sizeof(ga));
     ga.B = B; ga.T = T; ga.H = H; ga.length = bt->length; ga.nw8 = 1;
-    ga.tmp = ws + w.gru_tmp; ga.tmp_floats = w.gru_tmp_floats; ga.x3 = x3 != 0; ga.x3_rec = ga.x3 && !(st->debug_flags & 4); ga.stepwise = env_flags().gru_stepwise || (st->debug_flags & 1);   // H = 128: two waves per SIMD hide the LDS/epilogue latency (measured -0.08 ms/step)
+    ga.tmp = ws + w.gru_tmp; ga.tmp_floats = w.gru_tmp_floats; ga.x3 = x3 != 0; ga.x3_rec = ga.x3 && !(st->debug_flags & 4); ga.stepwise = fl.gru_stepwise;   // H = 128: two waves per SIMD hide the LDS/epilogue latency (measured -0.08 ms/step)
     for (int sd = 0; sd < 2; ++sd) {
       GruSide& g = ga.s[sd];
       g.Wg = W + P.gk[sd] + (int64_t)d.Is[sd] * 2 * H; g.ldwg = 2 * H;
@@ -870,7 +876,7 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
       g.dxproj = ws + w.dxproj[sd]; g.rh = ws + w.rh[sd]; g.hprev = ws + w.hprev[sd];
       // per-workgroup column sums of dxproj (the recurrence's bias gradients), where the kernel that runs provides them;
       // one row per 16 samples at most: far inside the scratch that only the other recurrence kernels use
-      g.bias_slab = (!env_flags().gru_bias_colsum && 2 * ((int64_t)B / 16 + 1) * 3 * H <= w.gru_tmp_floats) ? ws + w.gru_tmp + (int64_t)sd * (B / 16 + 1) * 3 * H
+      g.bias_slab = (2 * ((int64_t)B / 16 + 1) * 3 * H <= w.gru_tmp_floats) ? ws + w.gru_tmp + (int64_t)sd * (B / 16 + 1) * 3 * H
                                                                           : nullptr;
     }
     G(score_gru_bwd_multi(ga, 2, s));
@@ -922,24 +928,10 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
   }
 
   // ---- co-attention + embedding rows (score.py:147-167, 196-201, 51-66)
-  int64_t slab_used = slab_half;
-  // A/B (SCORE_WGRAD_EARLY=1): the recurrences' weight-gradient products here instead of at the end of the pass.  With the
-  // panel form of d x at cfg-3 the main stream reaches this point ~50 us earlier than the side stream's chain (query branch,
-  // the head's and the attention's weight gradients, their slab reduce and column sums) was sized for: its tail then runs
-  // beside the co-attention backward, and both crawl (kernel trace: the reduce 22 -> 110 us, the co-attention backward
-  // 112 -> 184); moved here, the products take that company instead and lose what the scatter regains.
-  const bool wgrad_early = env_flags().wgrad_early && !wgrad_side;
-  if (wgrad_early && gq.n > 0) {
-    G(gemm_queue_flush(&gq, x3 != 0, ws + w.dwslab + slab_half, slab_third, s));
-    slab_used = slab_half + slab_third;
-  }
-  if (wgrad_side && gq.n > 0) {     // the GRU kernels' weight gradients: beside the co-attention backward and the scatter
-    HIPTRY(hipEventRecord(side->fork, s));
-    HIPTRY(hipStreamWaitEvent(side->st, side->fork, 0));
-    G(gemm_queue_flush(&gq, x3 != 0, ws + w.dwslab + slab_half, slab_third, side->st));
-    HIPTRY(hipEventRecord(side->join, side->st));
-    slab_used = slab_half + slab_third;
-  }
+  const int64_t slab_used = slab_half;
+  // (round 3 measured the recurrences' weight-gradient products HERE instead of at the end of the pass, on the main stream
+  //  and on the side stream beside the co-attention backward and the scatter: each moves the cost somewhere else,
+  //  profiles/r03_probes.md)
   EV(3);
   const bool atomic = st->scatter_mode == 1;
   uint32_t* keys_out = reinterpret_cast<uint32_t*>(ws + w.keys_out);

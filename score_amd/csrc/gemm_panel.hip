@@ -304,10 +304,6 @@ bool score_gemm_panel_ok(int ngroups, int M, int N, int K, int lda, int ldc, int
   }
   // (rows the chip could have done in the rounds it runs) vs (rows there are): below 0.7 the 128 x 128 tiles fill it better
   if ((double)ngroups * M < 0.7 * best_cost * 16.0 * 256.0) return false;
-  {      // (probe: SCORE_PANEL_MT=8|9|10 forces the panel height, e.g. 10 on 18,432 rows leaves 24 CUs to other streams)
-    static const int forced = [] { const char* v = getenv("SCORE_PANEL_MT"); return v ? atoi(v) : 0; }();
-    if (forced >= 8 && forced <= 10) best = forced;
-  }
   if (mt_out) *mt_out = best;
   return true;
 }

@@ -829,11 +829,8 @@ static int gru_bwd_steps(GruArgs& a, int nsides, hipStream_t s) {
 }
 
 static bool gru_reg_ok(int H) { return H == 16 || H == 32 || H == 64 || H == 128; }
-// SCORE_GRU_F32 (set, not empty, not "0"; read once): keep the H = 128 recurrences on the f32-input MFMA (A/B)
-static bool gru_x3_allowed() {
-  static const bool off = [] { const char* v = getenv("SCORE_GRU_F32"); return v && *v && !(v[0] == '0' && !v[1]); }();
-  return !off;
-}
+// (the H = 128 recurrences on the f32-input MFMA instead of the bf16x3 form: score_state_t.debug_flags bit 2 -> GruArgs.x3_rec)
+static bool gru_x3_allowed() { return true; }
 
 int score_gru_fwd_multi(GruArgs& a, int nsides, hipStream_t s) {
   const int H = a.H;

@@ -711,7 +711,6 @@ static int adam_rows_impl(float* p, float* m, float* v, const float* g, int64_t 
   const int gpb = 256 / LPR;
   int64_t want = cdiv64(n_rows, gpb);
   int blocks = (int)(want < 16384 ? want : 16384);
-  { static const char* e_ = getenv("SCORE_ADAM_BLOCKS"); if (e_ && atoi(e_) > 0 && atoi(e_) < blocks) blocks = atoi(e_); }   // EXPERIMENT
   hipLaunchKernelGGL(adam_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, m, v, g, n_rows, D, LPR,
                      row_flags, alpha, 1.0f - beta1, 1.0f - beta2, eps, alpha_dev, guard ? guard->id_status : nullptr,
                      guard ? guard->skipped : nullptr);

@@ -898,9 +898,8 @@ int score_launch_head_fwd_fused(int B, int Dh, int N1, int N2, const float* x, c
   a.label = label; a.bn = bn; a.f1 = f1; a.f2 = f2; a.logit = logit; a.y = y; a.lossb = lossb; a.dlogit = dlogit;
   a.dz2 = dz2;
   const int mt = (B + HF_ROWS - 1) / HF_ROWS, nt1 = (N1 + 15) >> 4;
-  // SCORE_HEAD_SPLIT=0 / 1 forces one launch / two (read once); default: two from 32 row tiles up
-  static const int split_env = [] { const char* v = getenv("SCORE_HEAD_SPLIT"); return (v && *v) ? (v[0] == '0' ? 0 : 1) : -1; }();
-  const bool split = !single_launch && nt1 >= 4 && (split_env < 0 ? mt >= 32 : split_env == 1);
+  // two launches from 32 row tiles up (one launch: score_state_t.debug_flags bit 1)
+  const bool split = !single_launch && nt1 >= 4 && mt >= 32;
   if (!split) {
     a.phase = 0;
     hipLaunchKernelGGL(head_fwd_fused_kernel, dim3(mt), dim3(64 * HF_NW), lds, s, a);

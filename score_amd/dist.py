@@ -74,10 +74,6 @@ def _concurrent_stream(device, candidates=8, cycles=1500000):
             torch.cuda.synchronize(device)
             spans.append((e0.elapsed_time(e1), e0.elapsed_time(f1)))
         single, span = spans[-1]
-        if os.environ.get("SCORE_STREAM_PROBE_DEBUG"):
-            import sys
-            print("stream probe: candidate %d spans %s -> %s" % (_, spans, "taken" if span < 1.4 * single else "serialises"),
-                  file=sys.stderr, flush=True)
         if best is None:
             best = st
         if span < 1.4 * single:
@@ -95,7 +91,6 @@ class TorchDistComm(object):
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self._gloo = dist.get_backend(group) == "gloo"
-        self._index = None
         self.last = None       # ("name", sequence number) of the collective this rank entered last (bench.py's heartbeat)
         self._seq = 0
 
@@ -104,23 +99,13 @@ class TorchDistComm(object):
         self.last = (name, self._seq)
 
     def index_comm(self):
-        """The communicator of the index-only collectives (split sizes, row requests) and, in the pipelined step,
-        of the dense all-reduce.  DEFAULT: this communicator itself -- every collective of a rank then goes through
-        one process group in host program order, which is the same on every rank, so no cross-rank ordering hazard
-        exists by construction.
-        SCORE_DUAL_COMM=1 (opt-in, UNVERIFIED beyond one rank): a second communicator over the same ranks, so the
-        index collectives are not queued behind the previous step's gradient exchange.  Two communicators in
-        flight on different streams are only safe if their kernels can always run side by side on every GPU: RCCL
-        kernels block until their peers arrive, and if two ranks' hardware queues ever serialise the two
-        communicators' kernels in opposite orders the step hangs.  Measure on a real multi-GPU node before
-        enabling it (one rank through RCCL: 1.712 vs 1.752 ms/step at cfg-3)."""
-        if not os.environ.get("SCORE_DUAL_COMM") or self.world == 1 and self._gloo:
-            return self
-        if self._index is None:
-            ranks = self.dist.get_process_group_ranks(self.group) if self.group is not None else None
-            self._index = TorchDistComm(self.dist.new_group(ranks=ranks))
-            self._index._index = self._index
-        return self._index
+        """The communicator of the index-only collectives (split sizes, row requests) and of the dense all-reduce: this
+        communicator itself.  Every collective of a rank goes through ONE process group in host program order, which is
+        the same on every rank, so no cross-rank ordering hazard exists by construction.  (Rounds 1 - 3 kept a second,
+        opt-in communicator for the index traffic, SCORE_DUAL_COMM: two communicators in flight on different streams hang
+        if two ranks' hardware queues ever serialise their kernels in opposite orders, it bought 2 % with one rank and could
+        never be verified on more: removed.)"""
+        return self
 
     def exchange_counts(self, send_counts, device, extra=None):
         """all_to_all of one count per peer.  `extra` (an int): sent to every peer beside its count -- the reply is
@@ -412,7 +397,7 @@ class HipBackend(object):
         m._begin_row_grads()
         if counts is None:
             counts = [req_rows.numel()]
-        if len(counts) > 1 and len(counts) <= 64 and not os.environ.get("SCORE_ACCUMULATE_PER_SOURCE"):
+        if len(counts) > 1 and len(counts) <= 64:
             # every source rank's list in one launch (the lists are unique and ascending: segments of the plans' unique-row
             # lists); the same bits as one launch per source in rank order, which at eight ranks were eight small launches
             # in a row on the chain the next step's rows wait for
@@ -668,7 +653,7 @@ class ShardedSCORE(object):
             self._prefetch_launch(next_batch)     # its kernels run under this step's forward
         be.set_global_batch(plan["global_B"])         # sum of every rank's batch size (exchanged with the row counts)
         fw = be.forward(plan, mini, reg_lambda, keep_prob, dropout_masks)
-        if self.device.type == "cuda" and hasattr(be, "dense_grad_with_loss") and not os.environ.get("SCORE_LATE_GRADS"):
+        if self.device.type == "cuda" and hasattr(be, "dense_grad_with_loss"):
             # The row gradients are complete before the weight-gradient products of the backward pass
             # (score_backward's stage boundary 4): their all-to-all and the owner-side accumulate start there, on a
             # side stream, under those products.  The dense gradient goes out at the end of the pass in ONE
@@ -680,7 +665,7 @@ class ShardedSCORE(object):
             grads_in = mini_g if self.world == 1 else \
                 torch.empty((plan["req"].numel(), self.D), dtype=torch.float32, device=self.device)
             pipelined = lr is not None and next_batch is not None and self._prefetched is not None \
-                and self._prefetched[1] is not None and not os.environ.get("SCORE_NO_PIPELINE")
+                and self._prefetched[1] is not None
             nxt = None
             if pipelined:       # the next batch's plan was launched a forward + backward ago: sizes and requests now
                 self._prefetch_finish()
@@ -697,8 +682,7 @@ class ShardedSCORE(object):
                     be.adam_table(lr)
             # Host order = execution order on a communicator, identical on every rank: row gradients, then the dense
             # all-reduce (on the critical path: the dense ApplyAdam and the next forward wait for it), then the next
-            # batch's rows (their all-to-all overlaps the dense ApplyAdam; with SCORE_DUAL_COMM the all-reduce has
-            # the index communicator to itself)
+            # batch's rows (their all-to-all overlaps the dense ApplyAdam)
             buf = be.dense_grad_with_loss(fw)
             (icm if pipelined else cm).all_reduce_sum(buf)
             if pipelined:

@@ -24,7 +24,6 @@ import torch
 from . import _lib
 
 ADAM_B1, ADAM_B2, ADAM_EPS = 0.9, 0.999, 1e-8      # tf.train.AdamOptimizer defaults
-_NO_PIN = bool(os.environ.get("SCORE_NO_STREAM_PIN"))       # A/B: look the current stream up at every use again
 BATCH_FIELDS = ("user_1hop", "user_2hop", "item_1hop", "item_2hop",
                 "target_user", "target_item", "label", "length")
 
@@ -202,7 +201,7 @@ class SCOREBASE(object):
         self._ev_sweep = None
         self._ev_b4 = None           # stage boundary 4 of the backward pass (row scatter done): where the look-ahead catch-up starts
         self._ahead = None           # (DeviceBatch, event): its rows were brought up to date through the step in flight
-        self._sweep_st = None        # stream of the window slice when it runs beside the forward pass (SCORE_ADAM_SWEEP_AT=f1)
+        self._sweep_st = None        # stream of the window slice when it runs beside the forward pass (adam_sweep_at = "f1")
         self._fwd_stage_event = None
         self._pinned_stream = self._pinned_handle = None
         self._row_list = None
@@ -240,12 +239,18 @@ class SCOREBASE(object):
         self._scalars_slot = 0
         self._use_dev_scalars = False
         self._graph_on, self._graphs = False, {}
-        self.debug_flags = 0       # score_state_t.debug_flags (A/B switches; bit 0: step-by-step H = 256 recurrence, bit 1: head forward in one launch, bit 2: f32-MFMA H = 128 recurrence, bit 3: tiled instead of panel GEMMs for the GRU projections, bit 4: panel form for their input gradients too)
+        self.debug_flags = 0       # score_state_t.debug_flags (A/B switches; bit 0: step-by-step H = 256 recurrence, bit 1: head forward in one launch, bit 2: f32-MFMA H = 128 recurrence, bit 3: tiled instead of panel GEMMs for the GRU projections, bit 4: panel form for their input gradients too, bit 6: the head layer by layer, bit 7: the temporal attention layer by layer)
         self.gemm_mode = 1         # 1: bf16x3 split (fp32-accurate) on the shapes where it measured faster, 0: f32 MFMA only
         # host feed path (nested lists / arrays -> pinned staging -> device): native threads of the list walk, and a ring
         # of pinned staging buffers per batch size (a buffer is reused once the H2D copy that read it has run)
         # (threads: the walk is one cache miss per boxed int, so it scales with cores until the memory system is busy --
         #  cfg-3 batch on the GPU box's host: 8.9 ms with 1 thread, 2.5 with 4, 1.6 with 8, 1.35 with 16)
+        # where the time-tiled optimizer's window slice starts: "2" (stage boundary 2 of the backward pass, beside the
+        # recurrence: the measured best), "1" / "3" / "4", "plan" (behind the occurrence sort), "f1" (behind the fused gather,
+        # on a stream of its own); the touched-row update from the plan's unique-row list instead of a state-byte scan
+        # (measured +8 us net: off).  Both change WHERE work runs, never a result (tests/test_gpu_adam_tiled.py)
+        self.adam_sweep_at = "2"
+        self.adam_touched_list = False
         self.feed_threads = int(os.environ.get("SCORE_FEED_THREADS", str(max(1, min(16, _usable_cpus())))))
         self._stage, self._stage_lock = {}, threading.Lock()
         self._init_params(seed)
@@ -570,7 +575,7 @@ class SCOREBASE(object):
         def __enter__(self):
             m = self.m
             self.prev = (m._pinned_stream, m._pinned_handle)
-            if m._pinned_stream is None and not _NO_PIN:
+            if m._pinned_stream is None:
                 cur = torch.cuda.current_stream(m.device)
                 m._pinned_stream, m._pinned_handle = cur, C.c_void_p(cur.cuda_stream)
             return m
@@ -660,15 +665,14 @@ class SCOREBASE(object):
                 self._ev_gather.record(cur)          # materialise the hipEvent_t
         # the occurrence sort starts together with the forward (an event recorded here, not between the gather and
         # the input projections: a record between two launches costs ~5 us of bubble on the main stream, and the
-        # latency-bound gather hardly notices the sort beside it: 1.489 -> 1.476 ms/step); SCORE_PLAN_BEHIND_GATHER=1
-        # restores the old placement (score_state_t.gather_done_event)
-        early = self.scatter_mode == 0 and not os.environ.get("SCORE_PLAN_BEHIND_GATHER")
+        # latency-bound gather hardly notices the sort beside it: 1.489 -> 1.476 ms/step)
+        early = self.scatter_mode == 0
         if early:
             ev_start = cur.record_event()
         # time-tiled optimizer: this step's slice of the table (rows nobody in the batch touches: any time between the
         # batch rows' catch-up and the touched-row update will do).  "f1": behind the fused gather, i.e. beside the forward
         # recurrence, which is matrix-bound and fills half the CUs; 1 .. 4: at that stage boundary of the backward pass
-        sweep_at = os.environ.get("SCORE_ADAM_SWEEP_AT", "2")
+        sweep_at = str(self.adam_sweep_at)
         if sweep_at not in ("plan", "f1", "1", "2", "3", "4"):
             sweep_at = "2"                  # (an unknown value must not leave the window slice unlaunched)
         fwd_stage = None
@@ -697,8 +701,8 @@ class SCOREBASE(object):
                 #  driven by that list instead of a scan of the table's state bytes.  OFF by default: measured on one box,
                 #  alternating runs (tools/ab_env.sh), the update itself is 8 - 10 us shorter but the three extra plan kernels
                 #  on the side stream cost the input projections / recurrence beside them 16 - 18 us: 1.306 vs 1.298 ms/step.
-                #  SCORE_ADAM_TOUCHED_LIST=1 turns it on.)
-                want_list = self._tiled_on() and bool(os.environ.get("SCORE_ADAM_TOUCHED_LIST"))
+                #  model.adam_touched_list = True turns it on.)
+                want_list = self._tiled_on() and bool(self.adam_touched_list)
                 _lib.check(self.lib.score_index_plan(C.byref(self.cfg), C.byref(st), C.byref(db.struct), 1,
                                                      2 if want_list else 0, self._stream()), "score_index_plan")
                 row_list = (lay, ws) if want_list else None
@@ -709,7 +713,7 @@ class SCOREBASE(object):
         # boundary 2 of score_backward: a 140-us VALU-bound kernel next to a matrix-bound one that fills half the CUs)
         # costs the step 0.02 ms; behind the occurrence sort -- beside the fused attention forward, whose 8-wave, 232-
         # register workgroups cannot share a CU with it -- 0.06; boundaries 1 / 3 / 4: 0.03 / 0.03 / 0.2
-        # (SCORE_ADAM_SWEEP_AT=plan|1|2|3|4, profiles/r02_probes.md)
+        # (model.adam_sweep_at = plan|1|2|3|4, profiles/r02_probes.md)
         if self._pending_sweep is None:
             sweep_at = ""
         if sweep_at == "plan":
@@ -842,11 +846,11 @@ class SCOREBASE(object):
         if sweep:
             # the window's slice of the table: must start after the rows above are done (it would take them for lagging
             # ones) and finish before the next step's catch-up; forward_backward starts it on the side stream beside
-            # the backward recurrence (SCORE_ADAM_SWEEP_INLINE=1 runs it here on the main stream instead)
+            # the backward recurrence (inline_sweep: here on the main stream instead -- a row shard's gather, score_amd/dist.py)
             rows, K = self._tbl.shape[0], self.adam_window
             j = (upto + 1) % K
             self._pending_sweep = (rows * j // K, rows * (j + 1) // K, upto, cur.record_event())
-            if inline_sweep or os.environ.get("SCORE_ADAM_SWEEP_INLINE"):
+            if inline_sweep:
                 self._launch_sweep(cur)
 
     def _launch_sweep(self, stream):

@@ -328,42 +328,38 @@ def test_g6_optimizer_alone_on_the_oracles_gradients(window):
         assert e <= (5e-7 if k == "emb_mtx" else 1e-6), (step, k, e)
 
 
-def test_row_list_and_state_scan_forms_of_the_touched_update_agree(monkeypatch):
-    """score_adam_touched_rows (driven by the plan's unique-row list, SCORE_ADAM_TOUCHED_LIST=1) against score_adam_touched
-    (scan of the state bytes, the default): the same rows get the same update -- bit-identical tables -- also when a
-    backward pass nobody applied sits between two steps"""
+def test_row_list_and_state_scan_forms_of_the_touched_update_agree():
+    """score_adam_touched_rows (driven by the plan's unique-row list, model.adam_touched_list = True) against
+    score_adam_touched (scan of the state bytes, the default): the same rows get the same update -- bit-identical tables --
+    also when a backward pass nobody applied sits between two steps"""
     cfg = so.Cfg(6000, 32, 32, 6, 4, 2, 3, "SCORE")
     a, b = make(cfg, 5), make(cfg, 5)
+    a.adam_touched_list = True
     bs = batches(cfg, 14, 24, seed=11, hot_rows=400)
     for i, bt in enumerate(bs):
-        monkeypatch.setenv("SCORE_ADAM_TOUCHED_LIST", "1")
         la = a.train(None, bt, 1e-2, 1e-4)
         assert a._row_list is None                       # consumed by the step
-        monkeypatch.delenv("SCORE_ADAM_TOUCHED_LIST", raising=False)
         lb = b.train(None, bt, 1e-2, 1e-4)
         assert la == lb
         if i == 6:
-            monkeypatch.setenv("SCORE_ADAM_TOUCHED_LIST", "1")
             a.forward_backward(bs[0], 1e-4, 1.0)         # marks + a row list that no optimizer step consumes
             assert a._row_list is not None
-            monkeypatch.delenv("SCORE_ADAM_TOUCHED_LIST", raising=False)
             b.forward_backward(bs[0], 1e-4, 1.0)
             assert b._row_list is None
     assert same_state(a, b)
 
 
 @pytest.mark.parametrize("where", ["f1", "plan", "4"])
-def test_window_slice_placement_does_not_change_the_tables(monkeypatch, where):
-    """SCORE_ADAM_SWEEP_AT: the step's window slice beside the forward recurrence on its own stream (f1), behind the
+def test_window_slice_placement_does_not_change_the_tables(where):
+    """model.adam_sweep_at: the step's window slice beside the forward recurrence on its own stream (f1), behind the
     occurrence sort (plan) or at the last stage boundary of the backward pass (4) instead of boundary 2 -- rows nobody in the
     batch touches, any time between the batch rows' catch-up and the touched-row update: bit-identical tables and losses"""
     cfg = so.Cfg(6000, 32, 32, 6, 4, 2, 3, "SCORE")
     a, b = make(cfg, 5), make(cfg, 5)
+    a.adam_sweep_at = where
     bs = batches(cfg, 16, 24, seed=13, hot_rows=400)
     for i, bt in enumerate(bs):
-        monkeypatch.setenv("SCORE_ADAM_SWEEP_AT", where)
         la = a.train(None, bt, 1e-2, 1e-4, keep_prob=0.8)
-        monkeypatch.delenv("SCORE_ADAM_SWEEP_AT", raising=False)
         lb = b.train(None, bt, 1e-2, 1e-4, keep_prob=0.8)
         assert la == lb, (i, la, lb)
     if where == "f1":

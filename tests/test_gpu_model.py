@@ -247,7 +247,7 @@ def test_masked_slices_skipped_vs_oracle(mt):
     assert np.array_equal(m_all.get_params()["emb_mtx"][dead_only], P["emb_mtx"][dead_only])
 
 
-def test_fused_and_layerwise_paths_agree(monkeypatch):
+def test_fused_and_layerwise_paths_agree():
     # the one-launch head (head_fused.hip) and attention tail against the layer-by-layer paths they replace (still
     # taken for shapes the fused kernels do not cover): same predictions, loss and gradients
     cfg = so.Cfg(3000, 16, 32, 6, 5, 3, 4, "SCORE")
@@ -260,14 +260,18 @@ def test_fused_and_layerwise_paths_agree(monkeypatch):
     y0 = ws[lay.y_pred:lay.y_pred + 80].clone()
     l0 = float(ws[lay.loss].item())
     g0 = m.get_grads()
-    monkeypatch.setenv("SCORE_HEAD_UNFUSED", "1")
-    monkeypatch.setenv("SCORE_ATTN_TAIL_UNFUSED", "1")
+    # score_state_t.debug_flags bits 6 / 7: the head / the temporal attention layer by layer (rounds 1 - 3 switched these
+    # through the environment, which the library reads ONCE per process: set after the first call it compared the fused
+    # path with itself)
+    m.debug_flags = 64 | 128
     lay, ws = m.forward_backward(batch_tuple(b), 1e-4, 1.0)
     torch.cuda.synchronize()
     y1 = ws[lay.y_pred:lay.y_pred + 80].clone()
     l1 = float(ws[lay.loss].item())
     g1 = m.get_grads()
+    m.debug_flags = 0
     assert float((y0 - y1).abs().max()) < 2e-6 and abs(l0 - l1) < 2e-6
+    assert not torch.equal(y0, y1) or any(not np.array_equal(g0[k], g1[k]) for k in g0)     # (the switch did switch)
     for k in g0:
         ok, err = close(g1[k], g0[k], rtol=2e-5, atol=1e-9)
         assert ok, (k, err)
