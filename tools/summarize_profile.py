@@ -74,8 +74,11 @@ def pmc_round(bench_fetch, bench_write, probe_fetch, probe_write, out, config="c
         pmc(fd, wd, tmp, wl)
         sec = json.load(open(tmp))
         os.unlink(tmp)
+        # steps the profiled run took: the fused gather runs exactly once per forward pass (round 4: bench.py also runs stage-table
+        # and synchronous-train steps behind the timed region, so the count is read off the trace, not assumed)
+        n_fwd = [v["dispatches"] for k, v in sec["kernels"].items() if "coattn_fwd_kernel" in k]
         sec.update(commit=commit, embed_hip_sha16=sha, source_sha16=shas, workload=wl,
-                   steps_profiled=(8 if key == "bench_workload" else None))      # bench.py --steps 6 --warmup 2
+                   steps_profiled=(n_fwd[0] if (key == "bench_workload" and n_fwd) else None))
         res[key] = sec
     json.dump(res, open(out, "w"), indent=1)
 
