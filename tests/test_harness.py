@@ -134,3 +134,22 @@ def test_train_loop_feeds_lookahead_models_one_batch_ahead():
     ev = lambda model, batches, reg: (0.0, 0.5, 0, 0, 0, 0, 0, model.mrrs[min(len(model.pairs) // 3, 6)], 0.1)
     h.train_loop(m, lambda: iter([10, 11, 12]), lambda: [], 1e-3, 1e-4, 4, 18, epochs=2, evaluate_fn=ev, log=lambda s: None)
     assert m.pairs == [(10, 11), (11, 12), (12, None)] * 2        # the last batch of an epoch has no successor
+
+
+def test_step_rollback_restores_the_beta_powers_bit_for_bit():
+    """SCOREBASE._rollback_steps (check_ids after suppressed optimizer steps, score.py:51-66 / 101-116): beta1_power and
+    beta2_power are chains of fp32 products (adam_advance); k steps back they must be the very bits they were then"""
+    import types
+    import numpy as np
+    from score_amd.model import SCOREBASE, ADAM_B1, ADAM_B2
+    m = types.SimpleNamespace(step=0, beta1_power=np.float32(ADAM_B1), beta2_power=np.float32(ADAM_B2))
+    hist = {}
+    for _ in range(700):
+        hist[m.step] = (m.beta1_power, m.beta2_power)
+        SCOREBASE.adam_advance(m)
+    for k in (1, 3, 64, 699, 700):
+        c = types.SimpleNamespace(step=m.step, beta1_power=m.beta1_power, beta2_power=m.beta2_power)
+        SCOREBASE._rollback_steps(c, k)
+        assert c.step == 700 - k
+        assert c.beta1_power == hist[c.step][0] and c.beta2_power == hist[c.step][1]
+        assert c.beta1_power.dtype == np.float32 and c.beta2_power.dtype == np.float32
