@@ -150,6 +150,13 @@ def train_loop(model, train_batches, vali_batches, lr, reg_lambda, train_batch_s
         ahead = False
 
     use_async = not ahead and hasattr(model, "train_async") and hasattr(model, "device")
+    # ... and the single-device model's train_async takes the upcoming batch as a hint (SCOREBASE.apply_adam(next_batch=): with
+    # the time-tiled table optimizer its rows are brought up to date beside this step's tail instead of in front of the next
+    # forward pass).  Only device-resident batches qualify -- what model.feed() yields
+    try:
+        async_hint = use_async and "next_batch" in inspect.signature(model.train_async).parameters
+    except (TypeError, ValueError):
+        async_hint = False
 
     def with_next(it):
         it = iter(it)
@@ -216,7 +223,10 @@ def train_loop(model, train_batches, vali_batches, lr, reg_lambda, train_batch_s
             elif use_async:
                 # the loss stays on the device until the next evaluation needs the mean: the host does not wait for the
                 # GPU every step, so preparing batch t+1 (list flattening, loader work) overlaps step t
-                loss = model.train_async(batch_data, lr, reg_lambda).clone()
+                if async_hint and next_data is not None and hasattr(next_data, "flat"):
+                    loss = model.train_async(batch_data, lr, reg_lambda, next_batch=next_data).clone()
+                else:
+                    loss = model.train_async(batch_data, lr, reg_lambda).clone()
             else:
                 loss = model.train(sess, batch_data, lr, reg_lambda)
             step += 1
