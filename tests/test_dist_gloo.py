@@ -97,6 +97,25 @@ def test_two_rank_sharded_training_matches_single_model(tmp_path, model_type):
         assert abs(float(z[r]["eloss"]) - lref) < 1e-5
 
 
+# ---- the branch RCCL takes, with three and four ranks (threads of one process: torch's "threaded" process group) ---------
+@pytest.mark.parametrize("world", [3, 4])
+def test_ranks_on_the_rccl_code_path(world):
+    """score_amd/dist.py under a backend that is not gloo: all_to_all_single for the counts, all_to_all_remote = the own
+    segment copied locally + ONE list all_to_all with empty own slots, all_reduce.  No multi-GPU node has been available to any
+    round; tests/threaded_pg_worker.py runs that branch's index arithmetic with `world` ranks of unequal batch sizes (oracle
+    backend) against one oracle model on the concatenated batch."""
+    import json
+    import subprocess
+    out = subprocess.run([sys.executable, os.path.join(HERE, "threaded_pg_worker.py"), str(world)], capture_output=True,
+                         text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    j = json.loads(out.stdout.strip().splitlines()[-1])
+    assert j["ok"] and j["loss_rel_err"] < 1e-5 and j["table_max_err"] < 2e-6 and j["dense_identical_across_ranks"]
+    assert j["own_slot_sizes"] == [[0, 0]]                       # what a rank owns never went through the collective
+    assert len(set(j["list_collectives_per_rank"])) == 1 and j["list_collectives_per_rank"][0] >= 6
+    assert len({tuple(x) for x in j["last"]}) == 1               # every rank entered the same last collective (same sequence number)
+
+
 # ---- an id outside the table on ONE rank: rejected on EVERY rank before the step starts (score.py:51-66) -------------
 def _badid_worker(rank, world, port, out_dir):
     sys.path.insert(0, ROOT)
