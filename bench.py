@@ -393,6 +393,9 @@ def main():
     ap.add_argument("--event-every", type=int, default=4,
                     help="record the HIP stage events (live kernel timing for `roofline`) on every E-th timed step: "
                          "eleven timing events per step cost ~3 %% of a 1.8 ms step")
+    ap.add_argument("--step-marks-timed", action="store_true",
+                    help="one event mark per step INSIDE the timed region (default: only its first and last step; ms_per_step_p50 "
+                         "from a separate stretch of steps behind it)")
     ap.add_argument("--stage-events-timed", action="store_true",
                     help="record ALL stage boundary events inside the timed region (every E-th step) instead of on extra steps "
                          "behind it: the round-1..3 protocol (costs ~0.07 ms on each step that carries them)")
@@ -507,6 +510,8 @@ def main():
         model.enable_graph(True)
     last_loss = [None]
 
+    mark_every_step = True
+
     def run_steps(n, first=0, events=None, step_marks=None):
         """step_marks: a list of n + 1 timing events -- [i] is recorded on the launch stream before step i, [n] after the last"""
         fb = None
@@ -520,7 +525,7 @@ def main():
             return None
         for i in range(first, first + n):
             beat()
-            if step_marks is not None:
+            if step_marks is not None and (mark_every_step or i == first):
                 step_marks[i - first].record()
             e_a0 = e_a1 = None
             if events is not None and i in events:
@@ -595,9 +600,17 @@ def main():
         run_steps(1, -1, warm_ev)
     elif args.warmup > 0:
         run_steps(1)
+    # the time-tiled optimizer applies a row's zero-gradient updates late; what the WARM-UP steps still owe is applied here,
+    # before the clock starts, as what the timed steps still owe is applied before it stops: the region pays for exactly its
+    # own steps (round 4; before, it also paid the warm-up's share of the replay arithmetic)
+    finish_adam()
     beat("timed")
     barrier()
     t0 = time.perf_counter()
+    # (per-step marks cost the timed region 0.008 ms per step -- four alternating pairs at 20 steps, two at 200,
+    #  profiles/r04_probes.md --: inside it only its first and last step are marked; the per-step distribution comes from a
+    #  separate stretch of steps right behind it.  --step-marks-timed restores a mark per timed step)
+    mark_every_step = args.step_marks_timed
     fb = run_steps(args.steps, 0, None if graph else events, step_marks)
     finish_adam()                  # inside the timed region: no update is left owing when the clock stops
     ev_tail = torch.cuda.Event(enable_timing=True)
@@ -605,7 +618,20 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     beat("after")
-    per_step_ms = [step_marks[i].elapsed_time(step_marks[i + 1]) for i in range(args.steps)]
+    steps_by_events_ms = step_marks[0].elapsed_time(step_marks[args.steps])
+    if mark_every_step:
+        per_step_ms = [step_marks[i].elapsed_time(step_marks[i + 1]) for i in range(args.steps)]
+        p50_what = "one HIP event per step inside the timed region (--step-marks-timed)"
+    else:
+        n_p = max(8, min(args.steps, 40))
+        marks2 = [torch.cuda.Event(enable_timing=True) for _ in range(n_p + 1)]
+        mark_every_step = True
+        fb_p = run_steps(n_p, 0, None, marks2)
+        fb = fb_p if fb is None else fb
+        torch.cuda.synchronize()
+        mark_every_step = False
+        per_step_ms = [marks2[i].elapsed_time(marks2[i + 1]) for i in range(n_p)]
+        p50_what = "one HIP event per step over %d steps right BEHIND the timed region (a mark per step costs it 0.008 ms/step)" % n_p
     flush_ms = step_marks[args.steps].elapsed_time(ev_tail)
     tiled = tiled and bool(inner._tiled_on())       # (a shard may have gone back to the sweep: HipBackend.note_requests)
     if graph:                      # stage timings from eager steps, outside the timed region
@@ -929,11 +955,10 @@ def main():
         "ms_per_step": dt / args.steps * 1e3,
         "ms_per_step_p50": float(np.median(per_step_ms)),
         "ms_per_step_p10_p90": [float(np.percentile(per_step_ms, 10)), float(np.percentile(per_step_ms, 90))],
-        "timed_region_ms": {"wall": dt * 1e3, "steps_by_events": float(np.sum(per_step_ms)), "optimizer_flush_by_events": flush_ms,
-                            "first_steps": [round(x, 4) for x in per_step_ms[:6]]},
+        "timed_region_ms": {"wall": dt * 1e3, "steps_by_events": steps_by_events_ms, "optimizer_flush_by_events": flush_ms,
+                            "first_steps_of_the_marked_stretch": [round(x, 4) for x in per_step_ms[:6]]},
         "ms_per_step_what": "ms_per_step = wall clock of the timed region (barrier to barrier, the optimizer's flush included) "
-                            "/ steps: the figure `value` is computed from.  p50 / p10 / p90: per-step durations from one HIP "
-                            "event per step on the launch stream (rank 0)",
+                            "/ steps: the figure `value` is computed from.  p50 / p10 / p90: per-step durations, " + p50_what + " (rank 0)",
         "value_sync_train": B * world_size * n_sync / dt_sync,
         "value_sync_train_what": "the reference's own call, one after the other: loss = model.train(sess, batch_data, lr, "
                                  "reg_lambda) (score.py:101-116) with its per-step loss read-back, %d steps on the same "
