@@ -364,8 +364,10 @@ typedef struct {
                            (csrc/gemm_panel.hip); bit 4 = the input gradients in the panel form at every size; bit 6 =
                            build_fc_net layer by layer instead of the fused head kernels; bit 7 = the temporal attention
                            layer by layer instead of its fused kernels (the paths shapes outside the fused kernels'
-                           instantiated widths take anyway).  The ONLY switches of the launch sequence: the library reads
-                           no environment variable                                                                   */
+                           instantiated widths take anyway); bit 5 = the index plan sorts with the library's radix sort at
+                           every size, bit 8 = with csrc/sort.hip's at every size (default: by the number of occurrences;
+                           both are stable, the plan is the same bits).  The ONLY switches of the launch sequence: the
+                           library reads no environment variable                                                     */
   uint8_t* row_flags;   /* optional [n_table_rows] row state of the dense table optimizer (see
                            score_adam_rows): score_backward (scatter_mode 0) marks every row it
                            writes into grad_table with 2 and leaves all other rows of grad_table
@@ -418,6 +420,15 @@ int score_gemm_forms(const score_config_t* cfg, const score_state_t* st, int32_t
  * it is the index-routing step BASELINE.json's north_star asks for. */
 int score_index_plan(const score_config_t* cfg, const score_state_t* st, const score_batch_t* batch,
                      int32_t n_shards, int32_t dedup, void* stream);
+
+/* The small-batch sort behind score_index_plan as an op of its own (csrc/sort.hip): a STABLE least-significant-digit radix
+ * sort of n (key, value) pairs of 32-bit words by the low key_bits bits of the key (all higher bits must be zero), 11 - 12 bits
+ * per pass (key_bits 21: two passes; 32: three), six launches for two passes whatever n.  keys / vals and keys_alt / vals_alt
+ * are the two buffers the passes alternate between; *result_in_alt says where the sorted pairs are (1: the alt buffers -- an
+ * odd number of passes --, 0: keys / vals); the other pair holds an intermediate pass.  temp: score_sort_pairs_temp_bytes(n). */
+int score_sort_pairs(uint32_t* keys, uint32_t* vals, uint32_t* keys_alt, uint32_t* vals_alt, int64_t n, int32_t key_bits,
+                     void* temp, int64_t temp_bytes, int32_t* result_in_alt, void* stream);
+int64_t score_sort_pairs_temp_bytes(int64_t n);
 
 /* out[rows[j], :] = sum over slots j with equal rows[j] of src[j, :] (slot order; rows never
  * named keep their value).  The shard owner uses it to combine the row gradients received

@@ -119,6 +119,9 @@ _SIGS = {
     "score_adam_catchup_ids_through": [C.POINTER(AdamTable), c_i, C.c_int64, C.c_uint32, C.c_float, C.c_void_p],
     "score_adam_catchup_rows": [C.POINTER(AdamTable), C.c_int64, C.c_int64, C.c_uint32, C.c_void_p],
     "score_index_plan": [C.POINTER(Config), C.POINTER(State), C.POINTER(Batch), C.c_int32, C.c_int32, C.c_void_p],
+    "score_sort_pairs": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64,
+                         C.POINTER(C.c_int32), C.c_void_p],
+    "score_sort_pairs_temp_bytes": [C.c_int64],
     "score_segment_sum_rows": [c_i, c_f, C.c_int64, C.c_int32, C.c_int64, c_f, C.c_void_p, C.c_void_p, C.c_int64,
                                C.c_void_p],
     "score_segment_sum_scratch_bytes": [C.c_int64, C.c_int32],

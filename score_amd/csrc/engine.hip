@@ -239,6 +239,7 @@ void build_ws(const Dims& d, int B, WS* w) {
   score_plan_temp_bytes(np, 32, &tb);
   score_scan_temp_bytes(np, &tb2);
   if (tb2 > tb) tb = tb2;
+  if (score_sort_temp_bytes(np) > tb) tb = score_sort_temp_bytes(np);       // (sort.hip's histogram matrix)
   w->sort_temp_bytes = (int64_t)tb;
   w->sort_temp = take((int64_t)(tb + 3) / 4 + 4);
   {
@@ -430,7 +431,7 @@ extern "C" int score_index_plan(const score_config_t* cfg, const score_state_t* 
   uint32_t* keys_out = reinterpret_cast<uint32_t*>(ws + w.keys_out);
   uint32_t* vals_out = reinterpret_cast<uint32_t*>(ws + w.vals_out);
   G(score_launch_plan(pf, key_bits, keys_in, vals_in, keys_out, vals_out, ws + w.sort_temp,
-                      (size_t)w.sort_temp_bytes, s));
+                      (size_t)w.sort_temp_bytes, s, (st->debug_flags & 32) ? 1 : (st->debug_flags & 256) ? 2 : 0));
   if (n_shards > 1 || dedup) {
     PlanRemapArgs ra;
     memset(&ra, 0, sizeof(ra));

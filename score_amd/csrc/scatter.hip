@@ -70,10 +70,17 @@ int score_plan_temp_bytes(int64_t n, int end_bit, size_t* bytes) {
   return e == hipSuccess ? 0 : (int)e;
 }
 
-// keys_out/vals_out <- occurrences of the batch sorted by (owner, row)
+// keys_out/vals_out <- occurrences of the batch sorted by (owner, row), equal keys in occurrence order.
+// which = 0: by size -- sort.hip's six-launch sort below SCORE_OWN_SORT_MAX_N occurrences (the reference's own batch sizes:
+// the library takes 19 launches there and the step is bound by the host's launch calls), rocPRIM's onesweep above (cfg-3's
+// 2.9 M: the device side decides, and there the library's 8-bit passes coalesce better); 1 / 2 force the library / sort.hip.
+// Both sorts are stable: the plan is the same bits either way.
+#define SCORE_OWN_SORT_MAX_N (1 << 21)
 int score_launch_plan(const PlanFillArgs& a, int key_bits, uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys_out,
-                      uint32_t* vals_out, void* temp, size_t temp_bytes, hipStream_t s) {
+                      uint32_t* vals_out, void* temp, size_t temp_bytes, hipStream_t s, int which) {
   int64_t n = a.off[6] + 1;   // + sentinel
+  if (which == 2 || (which == 0 && n < SCORE_OWN_SORT_MAX_N))
+    return score_launch_plan_own(a, key_bits, keys_in, vals_in, keys_out, vals_out, temp, temp_bytes, s);
   hipLaunchKernelGGL(plan_fill_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, s, a, keys_in, vals_in);
   SCORE_CHECK_LAUNCH();
   size_t need = 0;

@@ -1,14 +1,20 @@
-// PROBE (round 4; built, correct, measured, NOT kept: tools/sort_probe.py, profiles/r04_probes.md).
-// The occurrence sort of the index plan, by hand: a stable LSD radix sort of (key, value) pairs of 32-bit words,
-// specialised to what score_index_plan sorts -- 2.6 - 57 M occurrences keyed by a table row id of 18 - 23 bits (32 with an
-// owner shard in front) -- and to this chip.
+// The occurrence sort of the index plan, by hand, for SMALL batches (round 4): a stable LSD radix sort of (key, value) pairs
+// of 32-bit words with 11- / 12-bit digits.
 //
-// Why not the library's: rocPRIM's onesweep takes 8 bits per pass (256 bins: what its one-size-fits-all tile ranking holds in
-// LDS), i.e. THREE passes over a 21-bit key, each reading and writing both arrays, plus a histogram kernel and seven counter
-// clears: 208 us of kernel time and 227 MB of traffic per cfg-3 step (profiles/r03_cfg3_kernel_stats.csv), the largest
-// kernel family of the step after the matrix products.  160 KB of LDS per CU hold a 2,048- or 4,096-bin ranking of an
-// 8,192-pair tile, so a 21-bit key needs TWO passes of 11 bits (23 bits: 12 + 11), and the first pass's histogram comes out
-// of the kernel that writes the keys in the first place (plan_fill): six launches, no clears.
+// Where it is used, and why only there.  For the reference's own batch sizes (B = 100 / 200: 0.15 - 1 M occurrences) rocPRIM
+// sorts with NINETEEN kernels (block sort + a chain of merge passes), and the step is bound by the host's launch calls (~6 us
+// each, ~57 per step): in the kernel trace the launch stream idles 140 us between the forward and the backward pass while
+// the host queues the sort.  This sort is SIX launches whatever n (fill + histogram fused, column scan, scatter; histogram,
+// column scan, scatter).  For cfg-3's 2.9 M occurrences the library switches to onesweep (three passes of 8 bits, 12
+// launches) and the device side decides: there this sort is no faster alone (139 vs ~145 us) and 1.5 % SLOWER inside the
+// step -- 2,048 bins leave four-pair runs per tile and bin, so its stores are 16-byte pieces, and its 78-KB-LDS workgroups
+// crowd the gather and the recurrence beside it (profiles/r04_probes.md); at cfg-5's 23.6 / 57 M it ties (965 / 2,170 us).
+// So score_launch_plan (scatter.hip) takes it below SCORE_OWN_SORT_MAX_N occurrences and the library above; both are stable,
+// so the plan -- and every sum the pull scatter builds from it -- is bit for bit the same either way
+// (score_state_t.debug_flags bits 5 / 8 force one or the other: tests/test_gpu_ops.py, test_gpu_model.py).
+//
+// 160 KB of LDS per CU hold a 2,048- or 4,096-bin ranking of an 8,192-pair tile, so a 21-bit key needs TWO passes of 11 bits
+// (23 bits: 12 + 11), and the first pass's histogram comes out of the kernel that writes the keys in the first place.
 //
 // One pass = three kernels.
 //   hist     M[tile][bin] = how many of the tile's 8,192 keys have that digit (LDS counters; for pass 1 fused into the fill)
@@ -16,14 +22,13 @@
 //   scatter  per tile: stable rank of every key among the tile's keys of the same digit -- eight waves, each ranking its
 //            1,024 consecutive keys in 16 rounds of 64 by wave-wide digit matching (dbits ballots: deterministic, no LDS
 //            atomics, so equal keys keep their order) into per-(digit, wave) counters --, then the tile is put in digit order
-//            in LDS and written out in that order: a run of equal digits goes to consecutive addresses, lanes are coalesced
-//            wherever runs are longer than a few pairs (the hot categorical rows), and every pair moves exactly once.
+//            in LDS and written out in that order: a run of equal digits goes to consecutive addresses.
 // Destination of the pair at tile-local sorted position i with digit d:
 //   binbase[d] (keys with a smaller digit, all tiles) + M[tile][d] (same digit, earlier tiles) + i - dpre[d] (same digit,
 //   this tile, before it).
 #include <atomic>
-#include "../../score_amd/csrc/common.h"
-#include "../../score_amd/csrc/kernels.h"
+#include "common.h"
+#include "kernels.h"
 
 namespace {
 
@@ -389,7 +394,7 @@ size_t score_sort_temp_bytes(int64_t n) {
 
 // keys_out / vals_out <- the occurrences of the batch sorted by (owner, row), equal keys in occurrence order (stable).
 // keys_in / vals_in are scratch (they hold an intermediate pass afterwards).
-int score_launch_plan(const PlanFillArgs& a, int key_bits, uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys_out,
+int score_launch_plan_own(const PlanFillArgs& a, int key_bits, uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys_out,
                       uint32_t* vals_out, void* temp, size_t temp_bytes, hipStream_t s) {
   const int64_t n = a.off[6] + 1;   // + sentinel
   if (n >= (1ll << 31)) return SCORE_E_SHAPE;

@@ -152,3 +152,24 @@ def test_panel_and_tiled_projections_agree_full_size(cfg3):
     # the tiled form differs from the panel form somewhere (the switch did switch), the forward of flags 16 is flags 0's
     assert not np.array_equal(out[8][0], p0) or not torch.equal(out[8][2], w0)
     assert np.array_equal(out[16][0], p0)
+
+
+def test_plan_sorts_give_the_same_bits_full_size(cfg3):
+    # 2.87 M occurrences: the plan takes the library's onesweep here (csrc/scatter.hip score_launch_plan); sort.hip's
+    # two-pass sort (debug_flags bit 8) must produce the very same plan -- both are stable
+    w, kw, B, m = cfg3
+    b = m.device_batch(w.batch(B, 6))
+    m.scatter_mode, m.global_batch = 0, 0
+    out = {}
+    try:
+        for flags in (0, 256, 32):
+            m.debug_flags = flags
+            m.forward_backward(b, 1e-4, 1.0)
+            rows = (m.table_flags == 2).nonzero().reshape(-1)
+            out[flags] = (rows, m.table_g[rows].clone(), m.w_g.clone())
+    finally:
+        m.debug_flags = 0
+        m._drop_row_marks()
+    for flags in (256, 32):
+        assert torch.equal(out[flags][0], out[0][0]) and torch.equal(out[flags][1], out[0][1]) and torch.equal(out[flags][2], out[0][2])
+

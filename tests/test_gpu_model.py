@@ -277,6 +277,27 @@ def test_fused_and_layerwise_paths_agree():
         assert ok, (k, err)
 
 
+@pytest.mark.parametrize("B,T", [(64, 6), (200, 11)])
+def test_plan_sorts_are_interchangeable_bit_for_bit(B, T):
+    """score_index_plan sorts the occurrences with csrc/sort.hip below 2 M occurrences and with the library's radix sort
+    above; both are stable, so the plan -- and every sum the pull scatter builds from it -- must be the same BITS either way
+    (debug_flags bit 5 forces the library, bit 8 sort.hip)"""
+    cfg = so.Cfg(3000, 16, 32, T, 10, 3, 4, "SCORE")
+    rng = np.random.default_rng(B)
+    m = make_model(cfg, so.init_params(cfg, 3))
+    b = random_batch(rng, cfg, B)
+    out = {}
+    for flags in (32, 256, 0):
+        m.debug_flags = flags
+        m.forward_backward(batch_tuple(b), 1e-4, 1.0)
+        torch.cuda.synchronize()
+        out[flags] = (m.dense_table_grad().clone(), m.w_g.clone())
+    m.debug_flags = 0
+    assert float(out[0][0].abs().max()) > 0
+    for flags in (256, 0):
+        assert torch.equal(out[flags][0], out[32][0]) and torch.equal(out[flags][1], out[32][1]), flags
+
+
 @pytest.mark.parametrize("H,B", [(48, 96), (256, 4096)])
 def test_stepwise_recurrence_hidden_sizes(H, B):
     # hidden sizes without a register-resident GRU kernel run the recurrence step by step on grouped

@@ -422,3 +422,47 @@ def test_adam_matches_tf_form():
         torch.cuda.synchronize()
         assert np.allclose(dp.cpu().numpy()[:n], params["p"], rtol=1e-6, atol=1e-7)
         assert np.allclose(dm.cpu().numpy()[:n], opt.m["p"], rtol=1e-6, atol=1e-7)   # fma contraction: <= 1 ulp of the operands
+
+
+@pytest.mark.parametrize("n,key_bits,dist", [
+    (1, 5, "uniform"), (63, 11, "uniform"), (8192, 11, "uniform"), (8193, 21, "uniform"), (100_000, 18, "uniform"),
+    (309_401, 21, "hot"),            # the reference's own batch (B = 200, T = 11, K = 10): where the plan uses this sort
+    (2_874_369, 21, "hot"),          # cfg-3's occurrence count: two passes of 11 + 10 bits, hot categorical rows and the dummy row
+    (1_000_003, 23, "hot"),          # 12 + 11 bits (the 5 M-row tables)
+    (600_001, 32, "uniform"),        # three passes (an owner shard in front of the row)
+    (300_000, 12, "uniform"),        # one pass of 12 bits
+    (70_000, 21, "equal"),           # every key equal: the order of the values must be the input order
+    (50_000, 1, "uniform"),
+])
+def test_sort_pairs_is_a_stable_sort(n, key_bits, dist):
+    """csrc/sort.hip (score_sort_pairs): the occurrence sort of the index plan for small batches against torch's stable sort --
+    keys ascending, equal keys in input order (what makes the pull scatter's sums reproducible)"""
+    lib = _lib.load()
+    g = torch.Generator(device="cuda").manual_seed(n + key_bits)
+    hi = 1 << key_bits
+    if dist == "uniform":
+        keys = torch.randint(0, hi, (n,), device="cuda", generator=g, dtype=torch.int64)
+    elif dist == "equal":
+        keys = torch.full((n,), min(hi - 1, 12345), device="cuda", dtype=torch.int64)
+    else:       # 30 % dummy row 0, 40 % twelve hot rows, the rest uniform
+        u = torch.rand((n,), device="cuda", generator=g)
+        keys = torch.randint(0, hi, (n,), device="cuda", generator=g, dtype=torch.int64)
+        hot = hi - 1 - torch.randint(0, 12, (n,), device="cuda", generator=g, dtype=torch.int64)
+        keys = torch.where(u < 0.3, torch.zeros_like(keys), torch.where(u < 0.7, hot, keys))
+    vals = torch.arange(n, device="cuda", dtype=torch.int64)
+    want_k, order = torch.sort(keys, stable=True)
+    k0 = torch.where(keys >= (1 << 31), keys - (1 << 32), keys).to(torch.int32)         # the same 32 bits as signed words
+    v0 = vals.to(torch.int32)
+    k1, v1 = torch.empty_like(k0), torch.empty_like(v0)
+    tb = int(lib.score_sort_pairs_temp_bytes(n))
+    temp = torch.empty((tb,), dtype=torch.uint8, device="cuda")
+    where = C.c_int32(-1)
+    rc = lib.score_sort_pairs(P(k0), P(v0), P(k1), P(v1), n, key_bits, P(temp), tb, C.byref(where), stream())
+    _lib.check(rc, "score_sort_pairs")
+    torch.cuda.synchronize()
+    ko, vo = (k1, v1) if where.value == 1 else (k0, v0)
+    assert torch.equal(ko.to(torch.int64) & 0xFFFFFFFF, want_k)
+    assert torch.equal(vo.to(torch.int64), order)
+    # too little scratch / bad arguments
+    assert lib.score_sort_pairs(P(k0), P(v0), P(k1), P(v1), n, key_bits, P(temp), 16, C.byref(where), stream()) == -3
+    assert lib.score_sort_pairs(P(k0), P(v0), P(k1), P(v1), n, 33, P(temp), tb, C.byref(where), stream()) == -1

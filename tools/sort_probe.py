@@ -1,18 +1,11 @@
-"""tools/sortx/sort_lsd11.hip (a hand-written two-pass 11-bit LSD radix sort for the index plan: built, correct, NOT kept) alone:
-score_sort_pairs on cfg-3-shaped keys (2.87 M occurrences, 21-bit row ids: 30 % dummy row, 40 % a dozen
-hot rows at the top of the id space + 15 k categorical rows, the rest uniform), against torch.sort.  Run under
-`rocprofv3 --kernel-trace --stats` for the per-kernel split.   python tools/sort_probe.py [n] [key_bits]"""
-import ctypes as C, os, subprocess, sys, tempfile
+"""csrc/sort.hip alone (the index plan's sort for small batches): score_sort_pairs on cfg-3-shaped keys (2.87 M occurrences, 21-bit
+row ids: 30 % dummy row, 20 % a dozen hot rows at the top of the id space, 30 % 15 k categorical rows, the rest uniform), against
+torch.sort.  Run under `rocprofv3 --kernel-trace --stats` for the per-kernel split.   python tools/sort_probe.py [n] [key_bits]"""
+import ctypes as C, os, sys
 import torch
-root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-so = os.path.join(tempfile.mkdtemp(), "sortx.so")
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-result",
-                       os.path.join(root, "tools", "sortx", "sort_lsd11.hip"), "-o", so])
-lib = C.CDLL(so)
-lib.score_sort_pairs_temp_bytes.restype = C.c_int64
-lib.score_sort_pairs_temp_bytes.argtypes = [C.c_int64]
-lib.score_sort_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64,
-                                 C.POINTER(C.c_int32), C.c_void_p]
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from score_amd import _lib
+lib = _lib.load()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2_874_369
 bits = int(sys.argv[2]) if len(sys.argv) > 2 else 21
 g = torch.Generator(device="cuda").manual_seed(1)
