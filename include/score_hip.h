@@ -313,6 +313,13 @@ typedef struct {
                                      far, i.e. by how much the `step` arguments run ahead of what was really applied   */
 } score_adam_table_t;
 int score_adam_touched(const score_adam_table_t* t, uint32_t step, float alpha, void* stream);
+/* score_adam_touched(t, step, alpha) and score_adam(p, m, v, g, n, n_reg, l2, alpha, t->beta1, t->beta2, t->eps, guard) --
+ * the step's whole ApplyAdam, table rows with a gradient and the flat dense variables -- in ONE launch: the two touch disjoint
+ * memory and were two dependent launches at the end of every step (the reference's own batch sizes are bound by the host's
+ * launch calls).  The guard is t->id_status; `skipped` (optional) counts the step when it is suppressed.  Same arithmetic in
+ * the same order per element as the two calls: the same bits. */
+int score_adam_touched_and_dense(const score_adam_table_t* t, uint32_t step, float alpha, float* p, float* m, float* v,
+                                 const float* g, int64_t n, int64_t n_reg, float l2, int32_t* skipped, void* stream);
 /* A backward pass whose gradient nobody applies: every state-2 row back to state 1.  A row that was live keeps its
  * row_step (the batch's rows were brought up to `upto` before that pass); a row that was in state 0 -- m = v = 0: its owed
  * updates are identities and any count is right for it -- gets row_step = upto, which keeps it inside the ring. */

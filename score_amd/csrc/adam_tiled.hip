@@ -122,23 +122,45 @@ __device__ __forceinline__ uint32_t tiled_applied(const TiledArgs& a, uint32_t s
   const uint32_t sk = a.skipped ? (uint32_t)*a.skipped : 0u;
   return step - 1 > sk ? step - 1 - sk : 0u;
 }
-// `drop` (score_adam_unmark) or a set guard word: nothing is applied (tiled_unmark_row)
-__global__ __launch_bounds__(256) void adam_touched_kernel(const TiledArgs a, uint32_t step, float alpha, int drop) {
+// `drop` (score_adam_unmark) or a set guard word: nothing is applied (tiled_unmark_row).  Virtual block blk of nblk.
+__device__ __forceinline__ void adam_touched_body(const TiledArgs& a, uint32_t step, float alpha, int drop, int blk, int nblk) {
   const int lane = tiled_lane();
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t stride = (int64_t)nblk * blockDim.x;
   if (drop || tiled_guarded(a)) {
     const uint32_t applied = drop ? step - 1 : tiled_applied(a, step);
-    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < a.n_rows; r += stride)
+    for (int64_t r = (int64_t)blk * blockDim.x + threadIdx.x; r < a.n_rows; r += stride)
       if (a.flags[r] == 2) tiled_unmark_row(a, r, applied);
     return;
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) a.ring[step % SCORE_ADAM_RING] = alpha;
-  for (int64_t base = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) - lane; base < a.n_rows; base += stride) {
+  if (blk == 0 && threadIdx.x == 0) a.ring[step % SCORE_ADAM_RING] = alpha;
+  for (int64_t base = ((int64_t)blk * blockDim.x + threadIdx.x) - lane; base < a.n_rows; base += stride) {
     const int64_t r = base + lane;
     const bool hit = r < a.n_rows && a.flags[r] == 2;
     const uint64_t mask = __ballot(hit);
     tiled_rows<0>(a, mask, (int)r, 0u, step, alpha, 0.f, lane);
   }
+}
+// rows whose state byte is 2: the step's ApplyAdam from their gradient.  One lane per row scans the state bytes.
+__global__ __launch_bounds__(256) void adam_touched_kernel(const TiledArgs a, uint32_t step, float alpha, int drop) {
+  adam_touched_body(a, step, alpha, drop, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// The step's whole ApplyAdam in ONE launch (round 4): blocks [0, nb_t) the touched rows of the table, blocks [nb_t, nb_t + nb_d)
+// the flat dense variables (what score_adam does: the L2 term folded in for the regularised range) -- the two touch disjoint
+// memory and were two dependent launches at the end of every step.  The guard is the table's (score_adam_table_t.id_status):
+// set, neither half applies anything and the dense half counts the suppressed step.
+struct DenseAdamArgs { float* p; float* m; float* v; const float* g; int64_t n4, n, n_reg; float l2; int32_t* skipped; };
+__global__ __launch_bounds__(256) void adam_step_kernel(const TiledArgs a, uint32_t step, float alpha, const DenseAdamArgs d,
+                                                        int nb_t, int nb_d) {
+  if ((int)blockIdx.x < nb_t) {
+    adam_touched_body(a, step, alpha, 0, (int)blockIdx.x, nb_t);
+    return;
+  }
+  if (tiled_guarded(a)) {
+    if (d.skipped && (int)blockIdx.x == nb_t && threadIdx.x == 0) atomicAdd(d.skipped, 1);
+    return;
+  }
+  score_adam_dense_body(d.p, d.m, d.v, d.g, d.n4, d.n, d.n_reg, d.l2, alpha, a.omb1, a.omb2, a.eps, (int)blockIdx.x - nb_t, nb_d);
 }
 
 // The same update driven by a LIST of rows (the unique rows of the batch, score_index_plan with dedup == 2) instead of a
@@ -276,6 +298,24 @@ extern "C" int score_adam_touched(const score_adam_table_t* t, uint32_t step, fl
   SCORE_TRY(tiled_args(t, &a, true));
   if (step == 0) return SCORE_E_BADARG;
   hipLaunchKernelGGL(adam_touched_kernel, dim3(tiled_blocks(a.n_rows)), dim3(256), 0, (hipStream_t)stream, a, step, alpha, 0);
+  SCORE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int score_adam_touched_and_dense(const score_adam_table_t* t, uint32_t step, float alpha, float* p, float* m, float* v,
+                                            const float* g, int64_t n, int64_t n_reg, float l2, int32_t* skipped, void* stream) {
+  TiledArgs a;
+  SCORE_TRY(tiled_args(t, &a, true));
+  if (step == 0 || !p || !m || !v || !g || n <= 0) return SCORE_E_BADARG;
+  if ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v) |
+       reinterpret_cast<uintptr_t>(g)) & 15)
+    return SCORE_E_SHAPE;
+  DenseAdamArgs d;
+  d.p = p; d.m = m; d.v = v; d.g = g; d.n4 = n / 4; d.n = n; d.n_reg = n_reg; d.l2 = l2; d.skipped = skipped;
+  const int nb_t = tiled_blocks(a.n_rows);
+  const int64_t want = cdiv64(d.n4 > 0 ? d.n4 : 1, 256);
+  const int nb_d = (int)(want < 8192 ? want : 8192);
+  hipLaunchKernelGGL(adam_step_kernel, dim3(nb_t + nb_d), dim3(256), 0, (hipStream_t)stream, a, step, alpha, d, nb_t, nb_d);
   SCORE_CHECK_LAUNCH();
   return 0;
 }

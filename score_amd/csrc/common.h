@@ -59,6 +59,43 @@ __device__ __forceinline__ void score_adam1(float& p, float& m, float& v, float 
   p = p - (m * alpha) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v) + eps);
 #endif
 }
+// ApplyAdam over a flat range of floats (the dense variables; score.py:96-99) by virtual block `blk` of `nblk`: the body of
+// adam_kernel (head.hip) and of the dense half of adam_step_kernel (adam_tiled.hip), so both round alike.
+__device__ __forceinline__ void score_adam_dense_body(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
+                                                      const float* __restrict__ g, int64_t n4, int64_t n, int64_t n_reg, float l2,
+                                                      float alpha, float omb1, float omb2, float eps, int blk, int nblk) {
+  int64_t i = (int64_t)blk * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)nblk * blockDim.x;
+  for (; i < n4; i += stride) {
+    float4 mm = ld4(m + i * 4), vv = ld4(v + i * 4), gg = ld4(g + i * 4);
+    int64_t e = i * 4;
+    // exact shortcut: with g = m = v = 0 (a row no batch has touched yet, no L2 term on it) ApplyAdam
+    // leaves m, v and the variable bit-identical -- skip the variable's read and all three writes
+    if (e >= n_reg && gg.x == 0.f && gg.y == 0.f && gg.z == 0.f && gg.w == 0.f && mm.x == 0.f && mm.y == 0.f &&
+        mm.z == 0.f && mm.w == 0.f && vv.x == 0.f && vv.y == 0.f && vv.z == 0.f && vv.w == 0.f)
+      continue;
+    float4 pp = ld4(p + i * 4);
+    if (e < n_reg) {  // d/dw of lambda * sum(w^2)/2   (build_l2norm, score.py:91-94)
+      gg.x = e + 0 < n_reg ? fmaf(l2, pp.x, gg.x) : gg.x;
+      gg.y = e + 1 < n_reg ? fmaf(l2, pp.y, gg.y) : gg.y;
+      gg.z = e + 2 < n_reg ? fmaf(l2, pp.z, gg.z) : gg.z;
+      gg.w = e + 3 < n_reg ? fmaf(l2, pp.w, gg.w) : gg.w;
+    }
+    score_adam1(pp.x, mm.x, vv.x, gg.x, omb1, omb2, alpha, eps);
+    score_adam1(pp.y, mm.y, vv.y, gg.y, omb1, omb2, alpha, eps);
+    score_adam1(pp.z, mm.z, vv.z, gg.z, omb1, omb2, alpha, eps);
+    score_adam1(pp.w, mm.w, vv.w, gg.w, omb1, omb2, alpha, eps);
+    st4(p + i * 4, pp); st4(m + i * 4, mm); st4(v + i * 4, vv);
+  }
+  // tail (n not a multiple of 4)
+  if (blk == 0 && threadIdx.x < (unsigned)(n - n4 * 4)) {
+    int64_t e = n4 * 4 + threadIdx.x;
+    float pp = p[e], mm = m[e], vv = v[e], gg = g[e];
+    if (e < n_reg) gg = fmaf(l2, pp, gg);
+    score_adam1(pp, mm, vv, gg, omb1, omb2, alpha, eps);
+    p[e] = pp; m[e] = mm; v[e] = vv;
+  }
+}
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // sum over the `gs` (power of two <= 64) consecutive lanes of a group; every lane gets the sum

@@ -510,9 +510,13 @@ extern "C" int score_forward(const score_config_t* cfg, const score_state_t* st,
   G(side_stream(st, &sd));
   HIPTRY(hipEventRecord(sd->fork, s));
   HIPTRY(hipStreamWaitEvent(sd->st, sd->fork, 0));
-  // [Wx_gates | Wx_cand] copies for the hoisted GRU input projections: weights only, off the main stream
-  G(score_launch_gru_wxcat(W + P.gk[0], W + P.ck[0], W + P.gb[0], W + P.cb[0], W + P.gk[1], W + P.ck[1], W + P.gb[1],
-                           W + P.cb[1], d.Is[0], d.Is[1], d.I, H, ws + w.wxcat, sd->st));
+  // what the step derives from the weights alone, in ONE launch off the main stream: the [Wx_gates | Wx_cand] copies for the
+  // hoisted GRU input projections, the folded first attention layer (dense_3 on [q, k, q-k, q*k], head.hip) and the L2 norm's
+  // partial sums (three launches before round 4: the reference's own batch sizes are bound by the host's launch calls)
+  const int64_t weff_stride = align_up64(2 * (int64_t)d.Dk * AT1 + 48, 4);     // replicas of the folded attention weight (build_ws)
+  G(score_launch_weight_prep(W + P.gk[0], W + P.ck[0], W + P.gb[0], W + P.cb[0], W + P.gk[1], W + P.ck[1], W + P.gb[1],
+                             W + P.cb[1], d.Is[0], d.Is[1], d.I, H, ws + w.wxcat, d.Dk, AT1, d.attn ? W + P.at_w[1] : nullptr,
+                             ws + w.weff, ws + w.wq, SCORE_WEFF_COPIES, weff_stride, W, P.n_reg, ws + w.part, sd->st));
   // the panel form of the projections and of their input gradients (gemm_panel.hip) takes the weights as fragment images:
   // written here, once per step, behind the concatenated copies (the backward pass reuses them as it reuses the copies)
   const bool panel_x = panel_gemms(d, st, BT, 0), panel_d = panel_gemms(d, st, BT, 1);
@@ -539,15 +543,13 @@ extern "C" int score_forward(const score_config_t* cfg, const score_state_t* st,
   HIPTRY(hipEventRecord(wx_ev, sd->st));
   const Flags fl = flags_of(st);
   const bool head_fused = !fl.head_unfused;
-  const int64_t weff_stride = align_up64(2 * (int64_t)d.Dk * AT1 + 48, 4);     // replicas of the folded attention weight (build_ws)
-  G(score_launch_l2_partials(W, P.n_reg, ws + w.part, sd->st));
   if (!d.attn) HIPTRY(hipEventRecord(sd->join, sd->st));
   if (d.attn) {
     float* scratch2 = ws + w.scratch2;
     G(gemm_mode_call(x3, 0, B, d.Dk, d.Dq, ws + w.query, d.Dq, W + P.at_w[0], d.Dk, ws + w.q, d.Dk, W + P.at_b[0], GF_BIAS,
                      1.f, nullptr, 0, scratch2, w.scratch_floats, sd->st));
-    // dense_3 on [q, k, q-k, q*k], folded (head.hip): a1 = relu([k, q*k] . Weff + (q . Wq + b)[sample])
-    G(score_launch_attn_fold_w1(d.Dk, AT1, W + P.at_w[1], ws + w.weff, ws + w.wq, sd->st, SCORE_WEFF_COPIES, weff_stride));
+    // dense_3 on [q, k, q-k, q*k], folded (head.hip; Weff / Wq come from the weight-prep launch above):
+    // a1 = relu([k, q*k] . Weff + (q . Wq + b)[sample])
     G(gemm_mode_call(x3, 0, B, AT1, d.Dk, ws + w.q, d.Dk, ws + w.wq, AT1, ws + w.qz, AT1, W + P.at_b[1], GF_BIAS, 1.f,
                      nullptr, 0, scratch2, w.scratch_floats, sd->st));
     HIPTRY(hipEventRecord(sd->join, sd->st));

@@ -14,9 +14,9 @@
 // `copies` replicas of Weff, `copy_stride` floats apart: the fused attention forward (head_fused.hip) has every workgroup
 // read all of Weff at its start, and 32 CUs of an XCD asking one L2 channel for the same line at the same moment took
 // 34 us for 189 KB; neighbouring workgroups read different replicas (different lines, different channels).
-__global__ void attn_fold_w1_kernel(int Dk, int NA, const float* __restrict__ W1, float* __restrict__ weff,
-                                    float* __restrict__ wq, int copies, int64_t copy_stride) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void attn_fold_w1_body(int blk, int Dk, int NA, const float* __restrict__ W1, float* __restrict__ weff,
+                                                  float* __restrict__ wq, int copies, int64_t copy_stride) {
+  int i = blk * 256 + threadIdx.x;
   if (i >= Dk * NA) return;
   const float wa = W1[i], wb = W1[Dk * NA + i], wc = W1[2 * Dk * NA + i], wd = W1[3 * Dk * NA + i];
   for (int c = 0; c < copies; ++c) {
@@ -24,6 +24,10 @@ __global__ void attn_fold_w1_kernel(int Dk, int NA, const float* __restrict__ W1
     weff[c * copy_stride + Dk * NA + i] = wd;
   }
   wq[i] = wa + wc;
+}
+__global__ __launch_bounds__(256) void attn_fold_w1_kernel(int Dk, int NA, const float* __restrict__ W1, float* __restrict__ weff,
+                                                           float* __restrict__ wq, int copies, int64_t copy_stride) {
+  attn_fold_w1_body(blockIdx.x, Dk, NA, W1, weff, wq, copies, copy_stride);
 }
 
 int score_launch_attn_fold_w1(int Dk, int NA, const float* W1, float* weff, float* wq, hipStream_t s, int copies,
@@ -444,22 +448,25 @@ __global__ void head_out_kernel(int B, int NF, const float* __restrict__ f2, con
 
 #define L2_PARTS 256
 // partial sums of squares of the regularised range (build_l2norm, score.py:91-94): 256 blocks, float4 loads
-__global__ __launch_bounds__(256) void sumsq_stage1(const float* __restrict__ x, int64_t n, float* __restrict__ part) {
+__device__ __forceinline__ void sumsq_stage1_body(int blk, int nblk, const float* __restrict__ x, int64_t n, float* __restrict__ part) {
   __shared__ float sh[256];
   const int64_t n4 = n >> 2;
   float s = 0.f;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+  for (int64_t i = (int64_t)blk * 256 + threadIdx.x; i < n4; i += (int64_t)nblk * 256) {
     const float4 v = ld4(x + i * 4);
     s = fmaf(v.x, v.x, s); s = fmaf(v.y, v.y, s); s = fmaf(v.z, v.z, s); s = fmaf(v.w, v.w, s);
   }
-  if (blockIdx.x == 0 && threadIdx.x < (unsigned)(n - n4 * 4)) { const float v = x[n4 * 4 + threadIdx.x]; s = fmaf(v, v, s); }
+  if (blk == 0 && threadIdx.x < (unsigned)(n - n4 * 4)) { const float v = x[n4 * 4 + threadIdx.x]; s = fmaf(v, v, s); }
   sh[threadIdx.x] = s;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
     if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
     __syncthreads();
   }
-  if (threadIdx.x == 0) part[blockIdx.x] = sh[0];
+  if (threadIdx.x == 0) part[blk] = sh[0];
+}
+__global__ __launch_bounds__(256) void sumsq_stage1(const float* __restrict__ x, int64_t n, float* __restrict__ part) {
+  sumsq_stage1_body(blockIdx.x, gridDim.x, x, n, part);
 }
 int score_launch_l2_partials(const float* wreg, int64_t n_reg, float* part /* L2_PARTS floats */, hipStream_t s) {
   hipLaunchKernelGGL(sumsq_stage1, dim3(L2_PARTS), dim3(256), 0, s, wreg, n_reg, part);
@@ -551,33 +558,66 @@ int score_launch_copy2d(int64_t rows, int cols, const float* src, int lds_, floa
 
 // [Wx_gates | Wx_cand] and [b_gates | b_cand] of both GRUs side by side, so the hoisted input projection
 // (and its two backward products) is ONE GEMM per side.  cat: [2][I+1][3H] (row I holds the bias).
-__global__ void gru_wxcat_kernel(const float* __restrict__ gk0, const float* __restrict__ ck0,
-                                 const float* __restrict__ gb0, const float* __restrict__ cb0,
-                                 const float* __restrict__ gk1, const float* __restrict__ ck1,
-                                 const float* __restrict__ gb1, const float* __restrict__ cb1, int I0, int I1, int Imax,
-                                 int H, float* __restrict__ cat) {
+struct WxcatArgs {
+  const float* gk0; const float* ck0; const float* gb0; const float* cb0;
+  const float* gk1; const float* ck1; const float* gb1; const float* cb1;
+  int I0, I1, Imax, H; float* cat;
+};
+__device__ __forceinline__ void gru_wxcat_body(int blk, const WxcatArgs& a) {
   // side sd's block is [(Imax+1)][3H]: rows [0, I_sd) the x rows of both kernels, row I_sd the biases
-  const int64_t per = (int64_t)(Imax + 1) * 3 * H;
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int H = a.H;
+  const int64_t per = (int64_t)(a.Imax + 1) * 3 * H;
+  int64_t i = (int64_t)blk * 256 + threadIdx.x;
   if (i >= 2 * per) return;
   const int sd = i >= per;
   const int64_t l = i - sd * per;
   const int r = (int)(l / (3 * H)), j = (int)(l - (int64_t)r * 3 * H);
-  const int I = sd ? I1 : I0;
+  const int I = sd ? a.I1 : a.I0;
   if (r > I) return;
-  const float* gk = sd ? gk1 : gk0; const float* ck = sd ? ck1 : ck0;
-  const float* gb = sd ? gb1 : gb0; const float* cb = sd ? cb1 : cb0;
+  const float* gk = sd ? a.gk1 : a.gk0; const float* ck = sd ? a.ck1 : a.ck0;
+  const float* gb = sd ? a.gb1 : a.gb0; const float* cb = sd ? a.cb1 : a.cb0;
   float v;
   if (r < I) v = j < 2 * H ? gk[(int64_t)r * 2 * H + j] : ck[(int64_t)r * H + (j - 2 * H)];
   else v = j < 2 * H ? gb[j] : cb[j - 2 * H];
-  cat[i] = v;
+  a.cat[i] = v;
+}
+__global__ __launch_bounds__(256) void gru_wxcat_kernel(const WxcatArgs a) { gru_wxcat_body(blockIdx.x, a); }
+
+// The per-step transforms of the WEIGHTS -- the concatenated [Wx_gates | Wx_cand] copies, the folded first attention layer
+// (optional) and the partial sums of squares of the regularised range -- in ONE launch (round 4: three launches before; the
+// reference's own batch sizes are bound by the host's launch calls, ~6 us each).  Blocks [0, b_wx) copy, [b_wx, b_wx + b_fold)
+// fold, the last L2_PARTS sum.
+struct WeightPrepArgs {
+  WxcatArgs wx; int b_wx;
+  int Dk, NA; const float* W1; float* weff; float* wq; int copies; int64_t copy_stride; int b_fold;
+  const float* wreg; int64_t n_reg; float* part;
+};
+__global__ __launch_bounds__(256) void weight_prep_kernel(const WeightPrepArgs a) {
+  const int b = blockIdx.x;
+  if (b < a.b_wx) gru_wxcat_body(b, a.wx);
+  else if (b < a.b_wx + a.b_fold) attn_fold_w1_body(b - a.b_wx, a.Dk, a.NA, a.W1, a.weff, a.wq, a.copies, a.copy_stride);
+  else sumsq_stage1_body(b - a.b_wx - a.b_fold, L2_PARTS, a.wreg, a.n_reg, a.part);
+}
+int score_launch_weight_prep(const float* gk0, const float* ck0, const float* gb0, const float* cb0, const float* gk1,
+                             const float* ck1, const float* gb1, const float* cb1, int I0, int I1, int Imax, int H, float* cat,
+                             int Dk, int NA, const float* W1, float* weff, float* wq, int copies, int64_t copy_stride,
+                             const float* wreg, int64_t n_reg, float* part, hipStream_t s) {
+  WeightPrepArgs a;
+  a.wx = WxcatArgs{gk0, ck0, gb0, cb0, gk1, ck1, gb1, cb1, I0, I1, Imax, H, cat};
+  a.b_wx = (int)cdiv64(2 * (int64_t)(Imax + 1) * 3 * H, 256);
+  a.Dk = Dk; a.NA = NA; a.W1 = W1; a.weff = weff; a.wq = wq; a.copies = copies; a.copy_stride = copy_stride;
+  a.b_fold = W1 ? (Dk * NA + 255) / 256 : 0;
+  a.wreg = wreg; a.n_reg = n_reg; a.part = part;
+  hipLaunchKernelGGL(weight_prep_kernel, dim3(a.b_wx + a.b_fold + L2_PARTS), dim3(256), 0, s, a);
+  SCORE_CHECK_LAUNCH();
+  return 0;
 }
 int score_launch_gru_wxcat(const float* gk0, const float* ck0, const float* gb0, const float* cb0, const float* gk1,
                            const float* ck1, const float* gb1, const float* cb1, int I0, int I1, int Imax, int H,
                            float* cat, hipStream_t s) {
   int64_t n = 2 * (int64_t)(Imax + 1) * 3 * H;
-  hipLaunchKernelGGL(gru_wxcat_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, s, gk0, ck0, gb0, cb0, gk1, ck1,
-                     gb1, cb1, I0, I1, Imax, H, cat);
+  hipLaunchKernelGGL(gru_wxcat_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, s,
+                     WxcatArgs{gk0, ck0, gb0, cb0, gk1, ck1, gb1, cb1, I0, I1, Imax, H, cat});
   SCORE_CHECK_LAUNCH();
   return 0;
 }
@@ -594,37 +634,7 @@ __global__ void adam_kernel(float* __restrict__ p, float* __restrict__ m, float*
     return;
   }
   if (alpha_dev) alpha = *alpha_dev;          // score_step_scalars_t.adam_alpha (captured steps)
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (; i < n4; i += stride) {
-    float4 mm = ld4(m + i * 4), vv = ld4(v + i * 4), gg = ld4(g + i * 4);
-    int64_t e = i * 4;
-    // exact shortcut: with g = m = v = 0 (a row no batch has touched yet, no L2 term on it) ApplyAdam
-    // leaves m, v and the variable bit-identical -- skip the variable's read and all three writes
-    if (e >= n_reg && gg.x == 0.f && gg.y == 0.f && gg.z == 0.f && gg.w == 0.f && mm.x == 0.f && mm.y == 0.f &&
-        mm.z == 0.f && mm.w == 0.f && vv.x == 0.f && vv.y == 0.f && vv.z == 0.f && vv.w == 0.f)
-      continue;
-    float4 pp = ld4(p + i * 4);
-    if (e < n_reg) {  // d/dw of lambda * sum(w^2)/2   (build_l2norm, score.py:91-94)
-      gg.x = e + 0 < n_reg ? fmaf(l2, pp.x, gg.x) : gg.x;
-      gg.y = e + 1 < n_reg ? fmaf(l2, pp.y, gg.y) : gg.y;
-      gg.z = e + 2 < n_reg ? fmaf(l2, pp.z, gg.z) : gg.z;
-      gg.w = e + 3 < n_reg ? fmaf(l2, pp.w, gg.w) : gg.w;
-    }
-    adam1(pp.x, mm.x, vv.x, gg.x, omb1, omb2, alpha, eps);
-    adam1(pp.y, mm.y, vv.y, gg.y, omb1, omb2, alpha, eps);
-    adam1(pp.z, mm.z, vv.z, gg.z, omb1, omb2, alpha, eps);
-    adam1(pp.w, mm.w, vv.w, gg.w, omb1, omb2, alpha, eps);
-    st4(p + i * 4, pp); st4(m + i * 4, mm); st4(v + i * 4, vv);
-  }
-  // tail (n not a multiple of 4)
-  if (blockIdx.x == 0 && threadIdx.x < (unsigned)(n - n4 * 4)) {
-    int64_t e = n4 * 4 + threadIdx.x;
-    float pp = p[e], mm = m[e], vv = v[e], gg = g[e];
-    if (e < n_reg) gg = fmaf(l2, pp, gg);
-    adam1(pp, mm, vv, gg, omb1, omb2, alpha, eps);
-    p[e] = pp; m[e] = mm; v[e] = vv;
-  }
+  score_adam_dense_body(p, m, v, g, n4, n, n_reg, l2, alpha, omb1, omb2, eps, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // One group of D/4 lanes per table row; the state byte decides what the row costs (see score_hip.h).

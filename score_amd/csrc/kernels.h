@@ -105,6 +105,12 @@ int score_launch_bn_bwd(int B, int Dh, const float* x, const float* gamma, float
                         float* dgamma, float* dbeta, float* tmp, float* scratch, int64_t scratch_floats,
                         ColsumJobs* cq, hipStream_t s);
 int score_launch_l2_partials(const float* wreg, int64_t n_reg, float* part /* 256 floats */, hipStream_t s);
+// the per-step transforms of the weights in one launch: [Wx_gates | Wx_cand] copies, the folded first attention layer
+// (W1 = null: none), the L2 partial sums
+int score_launch_weight_prep(const float* gk0, const float* ck0, const float* gb0, const float* cb0, const float* gk1,
+                             const float* ck1, const float* gb1, const float* cb1, int I0, int I1, int Imax, int H, float* cat,
+                             int Dk, int NA, const float* W1, float* weff, float* wq, int copies, int64_t copy_stride,
+                             const float* wreg, int64_t n_reg, float* part, hipStream_t s);
 int score_launch_head_out(int B, int NF, const float* f2, const float* w3, const float* b3, const int32_t* label,
                           float* logit, float* y, float* lossb, float* dlogit, float* loss, float lambda,
                           const float* part, int Bglobal, hipStream_t s, const int32_t* id_status = nullptr);

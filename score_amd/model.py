@@ -772,10 +772,12 @@ class SCOREBASE(object):
             if self._tiled_on() and self._row_grads:
                 if next_batch is not None:
                     self._catchup_ahead(next_batch, lr)
-                self._adam_table_tiled(lr)
+                # (the touched rows and the dense variables in one launch where nothing stands between them)
+                if not self._adam_table_tiled(lr, dense=(reg_lambda,)):
+                    self.adam_dense(lr, reg_lambda)
             else:
                 self.adam_table(lr)
-            self.adam_dense(lr, reg_lambda)
+                self.adam_dense(lr, reg_lambda)
             self.adam_advance()
 
     # ------------------------------------------------------------------ time-tiled table optimizer
@@ -888,10 +890,12 @@ class SCOREBASE(object):
         self._ahead = (nxt, side.record_event())
         self._b4_recorded = None
 
-    def _adam_table_tiled(self, lr):
+    def _adam_table_tiled(self, lr, dense=None):
         """ApplyAdam of step self.step + 1 on the rows that have a gradient; every other live row owes it.
         (On the main stream: behind the row-gradient event on the side stream, beside the weight-gradient products,
-        it slowed those by what it saved -- bwd_weight_grads 0.180 -> 0.246 ms, profiles/r02_probes.md.)"""
+        it slowed those by what it saved -- bwd_weight_grads 0.180 -> 0.246 ms, profiles/r02_probes.md.)
+        dense = (reg_lambda,): the flat dense variables' ApplyAdam in the same launch (score_adam_touched_and_dense);
+        returns True if it did that."""
         row_step, ring, T = self._tiled_table()
         cur = self._cur()
         # this step's window slice first: it must not see a row half-way through its first update (state 0 -> 2 -> 1
@@ -902,6 +906,7 @@ class SCOREBASE(object):
             row_step.fill_(int(self.step))
             self._tiled_ready = True
         rl, self._row_list = getattr(self, "_row_list", None), None
+        did_dense = False
         if rl is not None:
             lay, ws = rl          # (the plan's buffers: its side-stream work is behind the event score_backward waited for)
             rows = ws[lay.plan_unique_rows:]
@@ -909,12 +914,20 @@ class SCOREBASE(object):
             _lib.check(self.lib.score_adam_touched_rows(C.byref(T), _ptr(rows), _ptr(meta), int(lay.n_occurrences) + 1,
                                                         int(self.step) + 1, self._alpha(lr), self._stream()),
                        "score_adam_touched_rows")
+        elif dense is not None and not self._use_dev_scalars:
+            _lib.check(self.lib.score_adam_touched_and_dense(
+                C.byref(T), int(self.step) + 1, self._alpha(lr), _ptr(self.w), _ptr(self.w_m), _ptr(self.w_v), _ptr(self.w_g),
+                self.n_w, self.n_reg, float(dense[0]),
+                C.c_void_p(self._id_status.data_ptr() + 4) if self._guard_on else None, self._stream()),
+                "score_adam_touched_and_dense")
+            did_dense = True
         else:
             _lib.check(self.lib.score_adam_touched(C.byref(T), int(self.step) + 1, self._alpha(lr), self._stream()),
                        "score_adam_touched")
         self._row_grads = False
         self._flags_marked = False
         self._adam_dirty = True
+        return did_dense
 
     def _flush_adam(self):
         """Every live row up to self.step: what any reader of table / table_m / table_v other than the training
