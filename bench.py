@@ -322,14 +322,17 @@ def visible_gpus():
     if not os.path.isdir(base):
         return 0                      # no KFD driver: no ROCm device can be opened
     try:
-        n = 0
+        n = readable = 0
         for d in os.listdir(base):
             try:
                 props = dict(line.split()[:2] for line in open(os.path.join(base, d, "properties")) if len(line.split()) >= 2)
             except Exception:
                 continue
+            readable += 1
             if int(props.get("simd_count", "0")) > 0:
                 n += 1
+        if readable == 0:
+            return None               # (nodes exist but none can be read: unknown -- the ranks themselves refuse a missing device)
     except Exception:
         return None
     for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
