@@ -201,6 +201,8 @@ class SCOREBASE(object):
         self._ev_sweep = None
         self._ev_b4 = None           # stage boundary 4 of the backward pass (row scatter done): where the look-ahead catch-up starts
         self._ahead = None           # (DeviceBatch, event): its rows were brought up to date through the step in flight
+        self._early_loss = None      # set for the length of a train() call: the loss copied out right behind the forward pass
+        self._early_loss_state = {"stream": None, "host": None, "event": None}
         self._sweep_st = None        # stream of the window slice when it runs beside the forward pass (adam_sweep_at = "f1")
         self._fwd_stage_event = None
         self._pinned_stream = self._pinned_handle = None
@@ -684,6 +686,18 @@ class SCOREBASE(object):
         lay, ws, st = self._forward(db, reg_lambda, keep_prob, dropout_masks,
                                     gather_event=self._ev_gather if (self.scatter_mode == 0 and not early) else None,
                                     sweep=True, stage_event=fwd_stage)
+        if self._early_loss is not None:
+            # train(): the loss is final here, a whole backward pass and optimizer step before the stream is through -- it is
+            # copied to pinned memory on a stream of its own behind this point, so the caller's read-back (score.py:101-116
+            # returns the loss every step) waits for the forward only and the host goes on queueing
+            el = self._early_loss
+            if el["stream"] is None:
+                el["stream"] = torch.cuda.Stream(device=self.device)
+                el["host"] = torch.zeros((4,), dtype=torch.float32).pin_memory()
+            el["stream"].wait_event(cur.record_event())
+            with torch.cuda.stream(el["stream"]), self._Unpin(self):
+                el["host"].copy_(ws[lay.loss:lay.loss + 4], non_blocking=True)
+                el["event"] = el["stream"].record_event()
         if fwd_stage is not None and self._pending_sweep is not None:
             if self._sweep_st is None:
                 self._sweep_st = torch.cuda.Stream(device=self.device)      # (its own stream: the occurrence sort must not queue behind it)
@@ -1077,8 +1091,24 @@ class SCOREBASE(object):
             self._use_dev_scalars = False
 
     # ------------------------------------------------------------------ reference interface
-    def train(self, sess, batch_data, lr, reg_lambda, keep_prob=0.8, dropout_masks=None):
-        loss = float(self.train_async(batch_data, lr, reg_lambda, keep_prob, dropout_masks).item())
+    def train(self, sess, batch_data, lr, reg_lambda, keep_prob=0.8, dropout_masks=None, next_batch=None):
+        """loss = model.train(sess, batch_data, lr, reg_lambda) (score.py:101-116).  The loss is read back every step, as the
+        reference's sess.run returns it -- from a copy taken right behind the forward pass on a stream of its own, so the
+        read-back does not drain the queue: the backward pass and the optimizer of this step run while the host prepares the
+        next call (every later use of the model is ordered behind them on the stream)."""
+        # (not for captured steps: the copy's stream would be unjoined work inside the capture)
+        self._early_loss = None if self._graph_on else self._early_loss_state
+        self._early_loss_state["event"] = None
+        try:
+            dev_loss = self.train_async(batch_data, lr, reg_lambda, keep_prob, dropout_masks, next_batch)
+        finally:
+            self._early_loss = None
+        ev = self._early_loss_state["event"]
+        if ev is not None:
+            ev.synchronize()
+            loss = float(self._early_loss_state["host"][0])
+        else:                       # (a captured step: the loss comes at the end of the replay)
+            loss = float(dev_loss.item())
         if loss != loss:
             self.check_ids()
         return loss
