@@ -911,7 +911,7 @@ def main():
                                           ("coattn_bwd_kernel_t", "pull_kernel", "pull_fixup_kernel", "pull_long_kernel",
                                            "target_bwd_kernel"), ("embed.hip", "scatter.hip"))
     adam_tr, adam_src = committed_traffic(args.config, "bench_workload",
-                                          ("adam_touched_kernel", "adam_rows_kernel", "adam_kernel"), ("adam_tiled.hip", "head.hip"))
+                                          ("adam_step_kernel", "adam_touched_kernel", "adam_rows_kernel", "adam_kernel"), ("adam_tiled.hip", "head.hip"))
     bench_block = {"kernel": "coattn_fwd_kernel (fused embedding gather + co-attention, both calls, one launch) on the bench "
                              "workload",
                    "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
