@@ -307,7 +307,10 @@ class Heartbeat(object):
                 sys.stderr.write("bench.py heartbeat: rank %d phase=%s ticks=%d last_collective=%s idle=%.0fs\n"
                                  % (self.rank, self.phase, self.count, coll, now - self._t_seen))
                 sys.stderr.flush()
-            if now - self._t_seen > self.stall:
+            # (set-up and reporting are single long host-side stretches -- synthetic batches, table initialisation, on a fresh
+            #  box the first import of torch: three times the patience there)
+            limit = self.stall * (3.0 if self.phase in ("start", "setup", "report", "after") else 1.0)
+            if now - self._t_seen > limit:
                 sys.stderr.write("bench.py: rank %d made no progress for %.0f s in phase '%s' (tick %d), last collective "
                                  "entered: %s -- giving up (exit 3)\n" % (self.rank, now - self._t_seen, self.phase,
                                                                            self.count, coll))
@@ -457,7 +460,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # a collective that never completes must fail within minutes, not at the default 10 (= the driver's whole limit)
         from datetime import timedelta
-        tmo = timedelta(seconds=int(os.environ.get("SCORE_DIST_TIMEOUT_S", "120")))
+        tmo = timedelta(seconds=int(os.environ.get("SCORE_DIST_TIMEOUT_S", "180")))
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world_size, timeout=tmo,
                                     device_id=torch.device("cuda", local_rank))
