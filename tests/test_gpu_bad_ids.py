@@ -181,6 +181,38 @@ def test_async_steps_queued_behind_a_bad_batch_are_not_applied_either(mode):
     assert _same(m, _snapshot(twin))
 
 
+def test_look_ahead_hint_naming_a_bad_batch_changes_nothing():
+    """apply_adam(next_batch=) catches the NEXT batch's rows up one step early: a hinted batch with an id outside the table
+    must neither be dereferenced out of bounds there (the id scan ignores such values) nor change what the raise leaves behind"""
+    cfg = so.Cfg(*CFG, model_type="SCORE")
+    rng = np.random.default_rng(41)
+    m, twin = _model(), _model()
+    for x in (m, twin):
+        x.adam_tiled_min_bytes = 0
+    goods = []
+    for _ in range(4):
+        g = random_batch(rng, cfg, 10)
+        g["length"][:] = cfg.T
+        goods.append(g)
+    bad = {k: v.copy() for k, v in goods[2].items()}
+    bad["item_1hop"][3, 2, 1, 0] = 2 ** 31 - 1
+    bad["user_2hop"][0, 0, 0, 1] = -7
+    dg = [m.device_batch(batch_tuple(g)) for g in goods]
+    dt = [twin.device_batch(batch_tuple(g)) for g in goods]
+    db = m.device_batch(batch_tuple(bad))
+    for i in range(3):
+        nxt = db if i == 2 else dg[i + 1]
+        assert float(m.train_async(dg[i], 1e-3, 1e-4, next_batch=nxt)) == float(twin.train_async(dt[i], 1e-3, 1e-4, next_batch=dt[(i + 1) % 4]))
+    snap = _snapshot(m)
+    with pytest.raises(ValueError) as ei:
+        m.train(None, db, 1e-3, 1e-4)
+    assert "(item_1hop)" in str(ei.value) and "(user_2hop)" in str(ei.value)
+    assert _same(m, snap)
+    for i in (3, 0, 1):
+        assert m.train(None, dg[i], 1e-3, 1e-4) == twin.train(None, dt[i], 1e-3, 1e-4), i
+    assert _same(m, _snapshot(twin))
+
+
 def test_a_flush_with_the_word_set_raises_instead_of_returning_a_stale_table():
     cfg = so.Cfg(*CFG, model_type="SCORE")
     m = _model()
