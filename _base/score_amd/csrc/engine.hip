@@ -993,18 +993,9 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
   EV(4);
   // the remaining weight-gradient products of the pass, then the gradients assembled from them
   if (side) HIPTRY(hipStreamWaitEvent(s, side->join, 0));
-  // The finishers of the dense gradient -- the split-K slab reduce, the folded attention layer's gradient, the column sums: four
-  // small dependent launches, ~40 us of the launch stream at cfg-3 -- have ONE consumer, the dense variables' ApplyAdam.  A
-  // caller that passes score_state_t.grads_done_event gets them on the side stream (idle by now: the launch stream has just
-  // waited for its join) behind the products, and the event recorded behind them: it may run the table's touched-row update,
-  // which needs the row gradients only, on the launch stream meanwhile, and waits for the event before anything reads grad_w.
-  const bool fin_side = st->grads_done_event != nullptr && side != nullptr;
-  hipStream_t fs = fin_side ? side->st : s;
-  G(gemm_queue_flush(&gq, x3 != 0, ws + w.dwslab + slab_used, w.dwslab_floats - slab_used, s, fin_side ? fs : nullptr,
-                     fin_side ? side->fork : nullptr));
+  G(gemm_queue_flush(&gq, x3 != 0, ws + w.dwslab + slab_used, w.dwslab_floats - slab_used, s));
+  if (d.attn) G(score_launch_attn_w1_grad(d.Dk, AT1, ws + w.dweff, ws + w.dwq, gw + P.at_w[1], s));
+  G(colsum_queue_flush(&cq, ws + w.cs_part + w.cs_part_floats / 2, w.cs_part_floats - w.cs_part_floats / 2, s));
   EV(5);
-  if (d.attn) G(score_launch_attn_w1_grad(d.Dk, AT1, ws + w.dweff, ws + w.dwq, gw + P.at_w[1], fs));
-  G(colsum_queue_flush(&cq, ws + w.cs_part + w.cs_part_floats / 2, w.cs_part_floats - w.cs_part_floats / 2, fs));
-  if (fin_side) HIPTRY(hipEventRecord((hipEvent_t)st->grads_done_event, fs));
   return 0;
 }

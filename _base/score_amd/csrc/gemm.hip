@@ -431,8 +431,7 @@ int gemm_queue_add(GemmQueue* q, int M, int N, int K, const float* A, int lda, c
 // C_j = A_j^T . B_j for every queued job: the jobs that qualify for the bf16x3 kernel go out as one grouped
 // launch of 128x128 tiles, the rest as one grouped launch of the 64x64 f32 kernel, K split so that either
 // launch fills the chip a few times over; one more launch reduces all slabs (fixed order: reproducible).
-int gemm_queue_flush(GemmQueue* q, int x3, float* slab, int64_t slab_floats, hipStream_t s, hipStream_t reduce_stream,
-                     hipEvent_t reduce_event) {
+int gemm_queue_flush(GemmQueue* q, int x3, float* slab, int64_t slab_floats, hipStream_t s) {
   if (!q || q->n == 0) return 0;
   if (!slab) return SCORE_E_BADARG;
   GemmGroup g3, gf;
@@ -491,17 +490,8 @@ int gemm_queue_flush(GemmQueue* q, int x3, float* slab, int64_t slab_floats, hip
                        0);
     SCORE_CHECK_LAUNCH();
   }
-  // the slab reduce: on `s`, or -- reduce_stream given -- on that stream behind the products (the caller orders what consumes
-  // the results behind it: score_backward's end-of-pass finishers, engine.hip)
-  hipStream_t rs = s;
-  if (reduce_stream && reduce_event) {
-    hipError_t e = hipEventRecord(reduce_event, s);
-    if (e != hipSuccess) return (int)e;
-    if ((e = hipStreamWaitEvent(reduce_stream, reduce_event, 0)) != hipSuccess) return (int)e;
-    rs = reduce_stream;
-  }
   if (rg.n) {
-    hipLaunchKernelGGL(splitk_reduce_group_kernel, dim3(rblocks), dim3(256), 0, rs, rg);
+    hipLaunchKernelGGL(splitk_reduce_group_kernel, dim3(rblocks), dim3(256), 0, s, rg);
     SCORE_CHECK_LAUNCH();
   }
   q->n = 0;

@@ -23,8 +23,7 @@ struct GemmQueueJob { const float* A; const float* B; float* C; int M, N, K, lda
 struct GemmQueue { int n; GemmQueueJob j[2 * GEMM_GROUP_MAX]; };
 int gemm_queue_add(GemmQueue* q, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
                    int ldc);
-int gemm_queue_flush(GemmQueue* q, int x3, float* slab, int64_t slab_floats, hipStream_t s, hipStream_t reduce_stream = nullptr,
-                     hipEvent_t reduce_event = nullptr);
+int gemm_queue_flush(GemmQueue* q, int x3, float* slab, int64_t slab_floats, hipStream_t s);
 #define COLSUM_MAX_JOBS 24
 #define COLSUM_MAX_PARTS 128
 struct ColsumJob { const float* X; float* out; int M, N, ld, acc, cols, rpb, nparts; int64_t part_off; };

@@ -201,12 +201,6 @@ class SCOREBASE(object):
         self._ev_sweep = None
         self._ev_b4 = None           # stage boundary 4 of the backward pass (row scatter done): where the look-ahead catch-up starts
         self._ahead = None           # (DeviceBatch, event): its rows were brought up to date through the step in flight
-        self._grads_pending = None   # event behind the dense gradient's finishers on the side stream (score_state_t.grads_done_event)
-        self._ev_grads = None
-        # from this many (b, t) rows on, score_backward's end-of-pass finishers run on the side stream under the touched-row
-        # update (cfg-3: ~40 us off the launch stream); below, the step is bound by the host's launch calls and the table's and
-        # the dense variables' updates stay ONE launch behind finishers on the launch stream
-        self.overlap_finishers_min_rows = 8192
         self._early_loss = None      # set for the length of a train() call: the loss copied out right behind the forward pass
         self._early_loss_state = {"stream": None, "host": None, "event": None}
         self._sweep_st = None        # stream of the window slice when it runs beside the forward pass (adam_sweep_at = "f1")
@@ -363,18 +357,6 @@ class SCOREBASE(object):
         self._tbl, self._tiled, self._tiled_ready = t, None, False
 
     @property
-    def w_g(self):
-        """the flat dense gradient of the last backward pass.  Its finishers (slab reduce, column sums) may still be running
-        on the engine's side stream (score_state_t.grads_done_event): whoever reads it through here waits for them first"""
-        self._join_grads()
-        return self._w_g
-
-    def _join_grads(self):
-        ev, self._grads_pending = self._grads_pending, None
-        if ev is not None:
-            self._cur().wait_event(ev)
-
-    @property
     def adam_window(self):
         return self._adam_window
 
@@ -418,7 +400,7 @@ class SCOREBASE(object):
         # four spare floats behind the dense gradient: the sharded path appends its share of the log-loss so that
         # one all-reduce carries both (score_amd/dist.py)
         self._w_g_ext = torch.zeros((self.n_w + 4,), **f32)
-        self._w_g = self._w_g_ext[:self.n_w]
+        self.w_g = self._w_g_ext[:self.n_w]
 
     def _view(self, flat, entry):
         name, off, rows, cols, _, _ = entry
@@ -779,16 +761,8 @@ class SCOREBASE(object):
             if events[4] is None:
                 events[4] = self._ev_b4
             self._b4_recorded = events[4]
-        self._join_grads()                    # (a previous pass's finishers: they wrote the buffer this pass writes)
-        if (self.scatter_mode == 0 and not self._use_dev_scalars and self._tiled_on()
-                and db.B * (db.active_slices or int(self.cfg.max_time_len)) >= self.overlap_finishers_min_rows):
-            if self._ev_grads is None:
-                self._ev_grads = torch.cuda.Event()
-                self._ev_grads.record(cur)              # materialise the hipEvent_t
-            st.grads_done_event = C.c_void_p(self._ev_grads.cuda_event)
-            self._grads_pending = self._ev_grads
         rc = self.lib.score_backward(C.byref(self.cfg), C.byref(st), C.byref(db.struct), float(keep_prob),
-                                     _ptr(self._w_g), _ptr(self.table_g), self._event_array(events),
+                                     _ptr(self.w_g), _ptr(self.table_g), self._event_array(events),
                                      self._stream())
         _lib.check(rc, "score_backward")
         if ev_sweep_start is not None:
@@ -812,14 +786,8 @@ class SCOREBASE(object):
             if self._tiled_on() and self._row_grads:
                 if next_batch is not None:
                     self._catchup_ahead(next_batch, lr)
-                if self._grads_pending is not None:
-                    # the dense gradient's finishers are still running on the side stream: the table's touched rows (row
-                    # gradients only) first, the dense variables behind the finishers' event
-                    self._adam_table_tiled(lr)
-                    self._join_grads()
-                    self.adam_dense(lr, reg_lambda)
-                # (else the touched rows and the dense variables in one launch: nothing stands between them)
-                elif not self._adam_table_tiled(lr, dense=(reg_lambda,)):
+                # (the touched rows and the dense variables in one launch where nothing stands between them)
+                if not self._adam_table_tiled(lr, dense=(reg_lambda,)):
                     self.adam_dense(lr, reg_lambda)
             else:
                 self.adam_table(lr)
@@ -962,7 +930,7 @@ class SCOREBASE(object):
                        "score_adam_touched_rows")
         elif dense is not None and not self._use_dev_scalars:
             _lib.check(self.lib.score_adam_touched_and_dense(
-                C.byref(T), int(self.step) + 1, self._alpha(lr), _ptr(self.w), _ptr(self.w_m), _ptr(self.w_v), _ptr(self._w_g),
+                C.byref(T), int(self.step) + 1, self._alpha(lr), _ptr(self.w), _ptr(self.w_m), _ptr(self.w_v), _ptr(self.w_g),
                 self.n_w, self.n_reg, float(dense[0]),
                 C.c_void_p(self._id_status.data_ptr() + 4) if self._guard_on else None, self._stream()),
                 "score_adam_touched_and_dense")

@@ -402,6 +402,13 @@ typedef struct {
                            to loss[0] / loss[1] and the bits to loss[3], so whoever reads the loss learns of it;
                            score_id_status() is the synchronous query.  Ids of time slices >= active_slices are never
                            dereferenced and not checked.                                                         */
+  void* grads_done_event; /* optional hipEvent_t (score_backward): the pass's last four launches -- slab reduce, folded attention
+                           layer's gradient, column sums: everything that FINISHES grad_w -- then run on the context's side
+                           stream behind the weight-gradient products, and this event is recorded behind them.  grad_table is
+                           complete on `stream` when score_backward returns as before; grad_w only once the event has fired:
+                           the caller runs what needs the row gradients alone (score_adam_touched) on `stream` meanwhile and
+                           makes `stream` wait for the event before score_adam on the dense variables (or anything else that
+                           reads grad_w).  NULL: everything on `stream`, as before.                                   */
 } score_state_t;
 
 /* Synchronous query of a score_state_t.id_status word: copies it to *bits (optional), waits for `stream`, clears the
@@ -478,7 +485,8 @@ int score_forward(const score_config_t* cfg, const score_state_t* st, const scor
  * score_state_t.row_flags).  Must follow score_forward on the same workspace/batch.
  * stage_events: null, or SIX handles: [0] start, [1] after the head, [2] after the temporal
  * attention, [3] after the GRUs, [4] after the co-attention/embedding scatter, [5] after the
- * weight-gradient products (all X^T dY of the pass run here, as grouped launches). */
+ * weight-gradient products (all X^T dY of the pass run here, as grouped launches; with score_state_t.grads_done_event the
+ * event sits behind the products, the finishers that follow them run on the side stream). */
 int score_backward(const score_config_t* cfg, const score_state_t* st, const score_batch_t* batch,
                    float keep_prob, float* grad_w, float* grad_table, void* const* stage_events,
                    void* stream);
