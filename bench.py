@@ -415,6 +415,9 @@ def main():
                     help="do NOT tell apply_adam which batch comes next (SCOREBASE.apply_adam(next_batch=): with the time-tiled "
                          "table optimizer the next batch's rows are brought up to date beside this step's weight-gradient "
                          "products instead of in front of the next forward pass)")
+    ap.add_argument("--set", dest="model_attrs", action="append", default=[], metavar="ATTR=VALUE",
+                    help="set a public attribute of the model before the run (A/B of its placement choices: loss_on_side=0, "
+                         "adam_sweep_at=3, overlap_finishers_min_rows=0 ...); the value is parsed as a Python literal")
     ap.add_argument("--debug-flags", type=int, default=0, help="score_state_t.debug_flags (A/B switches of the launch sequence)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step as one captured hipGraph (SCOREBASE.enable_graph: launch-bound small shapes); "
@@ -502,6 +505,16 @@ def main():
         inner.skip_masked_slices = False
     if args.debug_flags:
         inner.debug_flags = args.debug_flags
+    for kv in args.model_attrs:
+        import ast
+        k, _, v = kv.partition("=")
+        if k.startswith("_") or not hasattr(inner, k):
+            raise SystemExit("bench.py --set: the model has no public attribute %r" % k)
+        try:
+            v = ast.literal_eval(v)
+        except (ValueError, SyntaxError):
+            pass                # a bare word: kept as a string
+        setattr(inner, k, v)
     # every rank trains on its own batches (weak: B each, global B * N; strong: global_batch / N each)
     batches = [model.device_batch(world.batch(B, rank * 1000 + i)) for i in range(args.batches)]
 

@@ -409,6 +409,12 @@ typedef struct {
                            the caller runs what needs the row gradients alone (score_adam_touched) on `stream` meanwhile and
                            makes `stream` wait for the event before score_adam on the dense variables (or anything else that
                            reads grad_w).  NULL: everything on `stream`, as before.                                   */
+  void* loss_done_event;  /* optional hipEvent_t (score_forward): the loss reduction (one workgroup: loss[0..3] from the per-sample
+                           terms and the L2 partial sums) then runs on the context's side stream behind the head, and this event is
+                           recorded behind it -- the head's successor on `stream` (score_backward's first launch) no longer queues
+                           behind a one-block kernel.  loss[] is final once the event has fired; on `stream` it is final behind
+                           score_backward of the same step (which joins the side stream), not behind score_forward alone.  NULL:
+                           on `stream`, as before (evaluation: nothing follows the forward pass).                        */
 } score_state_t;
 
 /* Synchronous query of a score_state_t.id_status word: copies it to *bits (optional), waits for `stream`, clears the

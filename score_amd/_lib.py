@@ -45,7 +45,8 @@ class State(C.Structure):
                 ("workspace_bytes", C.c_int64), ("scatter_mode", C.c_int32), ("global_batch", C.c_int32),
                 ("gemm_mode", C.c_int32), ("debug_flags", C.c_int32), ("row_flags", C.c_void_p),
                 ("gather_done_event", C.c_void_p), ("plan_done_event", C.c_void_p), ("step_scalars", C.c_void_p),
-                ("context", C.c_void_p), ("id_status", C.c_void_p), ("grads_done_event", C.c_void_p)]
+                ("context", C.c_void_p), ("id_status", C.c_void_p), ("grads_done_event", C.c_void_p),
+                ("loss_done_event", C.c_void_p)]
 
 
 class Graph(C.Structure):

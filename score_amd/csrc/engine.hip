@@ -672,7 +672,16 @@ extern "C" int score_forward(const score_config_t* cfg, const score_state_t* st,
                                               st->step_scalars ? &st->step_scalars->drop_seed : nullptr, ws + w.dz2,
                                               (st->debug_flags & 2) ? 1 : 0);
   if (hrc == 0) {
-    G(score_launch_loss_final(B, ws + w.lossb, ws + w.loss, reg_lambda, ws + w.part, Bg, s, st->id_status));    // (dz2 came with the head)
+    // (dz2 came with the head.)  The loss reduction is one workgroup and has no reader inside the step: with
+    // score_state_t.loss_done_event it runs on the side stream, so the backward pass's first launch follows the head directly
+    hipStream_t ls = s;
+    if (st->loss_done_event) {
+      HIPTRY(hipEventRecord(sd->fork, s));
+      HIPTRY(hipStreamWaitEvent(sd->st, sd->fork, 0));
+      ls = sd->st;
+    }
+    G(score_launch_loss_final(B, ws + w.lossb, ws + w.loss, reg_lambda, ws + w.part, Bg, ls, st->id_status));
+    if (st->loss_done_event) HIPTRY(hipEventRecord((hipEvent_t)st->loss_done_event, ls));
   } else if (hrc == SCORE_E_SHAPE) {
     if (st->step_scalars && keep_prob < 1.f) return SCORE_E_SHAPE;   // the layer-by-layer path takes its seed by value
     G(score_launch_bn_fwd(B, d.Dhead, ws + w.head_inp, W + P.bn_g, W + P.bn_b, rs, ws + w.bn, s));
@@ -684,6 +693,7 @@ extern "C" int score_forward(const score_config_t* cfg, const score_state_t* st,
     // fc3, sigmoid, log-loss, l2 (:74-94)
     G(score_launch_head_out(B, FC2, ws + w.f2, W + P.fc_w[2], W + P.fc_b[2], bt->label, ws + w.logit, ws + w.y_pred,
                             ws + w.lossb, ws + w.dlogit, ws + w.loss, reg_lambda, ws + w.part, Bg, s, st->id_status));
+    if (st->loss_done_event) HIPTRY(hipEventRecord((hipEvent_t)st->loss_done_event, s));
   } else {
     return hrc;
   }
