@@ -22,6 +22,7 @@ back to it on its own.
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 import torch
@@ -91,6 +92,7 @@ class TorchDistComm(object):
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self._gloo = dist.get_backend(group) == "gloo"
+        self._list_form = None  # all_to_all_remote: True once the list form with empty own slots has gone through, False if refused
         self.last = None       # ("name", sequence number) of the collective this rank entered last (bench.py's heartbeat)
         self._seq = 0
 
@@ -164,9 +166,24 @@ class TorchDistComm(object):
             self.all_to_all(out, inp, out_splits, in_splits)
             return
         self._note("all_to_all_remote[%s x %d]" % (str(inp.dtype).replace("torch.", ""), int(inp.shape[0]) - int(ins[r].shape[0])))
+        if self._list_form is False:   # (see below)
+            self.all_to_all(out, inp, out_splits, in_splits)
+            return
         outs[r] = out.new_empty((0,) + tuple(out.shape[1:]))
         ins[r] = inp.new_empty((0,) + tuple(inp.shape[1:]))
-        self.dist.all_to_all(outs, ins, group=self.group)
+        try:
+            self.dist.all_to_all(outs, ins, group=self.group)
+            self._list_form = True
+        except (RuntimeError, ValueError, TypeError) as e:
+            # a backend whose list form refuses empty slots says so when it checks its arguments, before anything is
+            # enqueued, and on every rank alike (same shapes of the same call): from then on the own segment rides through
+            # the collective as well (the split form).  Once the list form has worked, an error is an error.
+            if self._list_form:
+                raise
+            self._list_form = False
+            sys.stderr.write("[score_amd.dist] rank %d: all_to_all with empty own slots refused (%s); the own segment goes "
+                             "through the collective from here on\n" % (r, str(e).splitlines()[0][:200]))
+            self.all_to_all(out, inp, out_splits, in_splits)
 
     def all_reduce_sum(self, t):
         self._note("all_reduce[%d]" % t.numel())

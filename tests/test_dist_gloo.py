@@ -114,6 +114,22 @@ def test_ranks_on_the_rccl_code_path(world):
     assert j["own_slot_sizes"] == [[0, 0]]                       # what a rank owns never went through the collective
     assert len(set(j["list_collectives_per_rank"])) == 1 and j["list_collectives_per_rank"][0] >= 6
     assert len({tuple(x) for x in j["last"]}) == 1               # every rank entered the same last collective (same sequence number)
+    assert j["list_form"] == [True] * world
+
+
+def test_a_backend_that_refuses_empty_slots_gets_the_split_form():
+    """TorchDistComm.all_to_all_remote: if the backend's list all_to_all will not take empty tensors (it says so when it checks
+    its arguments, on every rank alike), the own segment goes through the collective instead -- once, with a line on stderr --
+    and the results are the same."""
+    import json
+    import subprocess
+    out = subprocess.run([sys.executable, os.path.join(HERE, "threaded_pg_worker.py"), "3", "refuse"], capture_output=True,
+                         text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    j = json.loads(out.stdout.strip().splitlines()[-1])
+    assert j["ok"] and j["loss_rel_err"] < 1e-5 and j["table_max_err"] < 2e-6 and j["dense_identical_across_ranks"]
+    assert j["list_form"] == [False] * 3 and j["list_collectives_per_rank"] == [1, 1, 1]      # tried once per rank
+    assert out.stderr.count("empty own slots refused") == 3
 
 
 # ---- an id outside the table on ONE rank: rejected on EVERY rank before the step starts (score.py:51-66) -------------

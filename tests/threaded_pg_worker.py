@@ -21,7 +21,7 @@ sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, HERE)
 
 
-def main(world=3):
+def main(world=3, refuse=False):
     import torch.testing._internal.distributed.multi_threaded_pg as mt
     torch._C._distributed_c10d._set_thread_isolation_mode(True)
     mt._install_threaded_pg()
@@ -46,6 +46,8 @@ def main(world=3):
 
             def spy(outs, ins, group=None):          # the own slot of the collective is empty on every rank
                 seen.append((int(outs[r].numel()), int(ins[r].numel()), len(outs)))
+                if refuse:                           # a backend whose list form will not take empty slots (argument check:
+                    raise RuntimeError("all_to_all: empty tensor in slot %d" % r)      # nothing enqueued, every rank alike)
                 return orig(outs, ins, group=group)
             import types
             comm.dist = types.SimpleNamespace(**{k: getattr(comm.dist, k) for k in dir(comm.dist) if not k.startswith("__")})
@@ -56,7 +58,7 @@ def main(world=3):
             losses = [model.train(None, bts[0], 1e-3, 1e-3, keep_prob=1.0, next_batch=bts[1])]
             losses.append(model.train(None, bts[1], 1e-3, 1e-3, keep_prob=1.0))
             out[r] = dict(losses=losses, shard=be.full_table_part(), dense={k: v.copy() for k, v in be.dense.items()},
-                          a2a=seen, last=comm.last)
+                          a2a=seen, last=comm.last, list_form=comm._list_form)
             dist.destroy_process_group()
         except Exception:
             import traceback
@@ -86,9 +88,10 @@ def main(world=3):
                       "dense_identical_across_ranks": bool(dense_same),
                       "own_slot_sizes": sorted({(a, b) for r in range(world) for a, b, _ in out[r]["a2a"]}),
                       "list_collectives_per_rank": [len(out[r]["a2a"]) for r in range(world)],
+                      "list_form": [out[r]["list_form"] for r in range(world)],
                       "last": [list(out[r]["last"]) for r in range(world)]}))
     return 0
 
 
 if __name__ == "__main__":
-    sys.exit(main(int(sys.argv[1]) if len(sys.argv) > 1 else 3))
+    sys.exit(main(int(sys.argv[1]) if len(sys.argv) > 1 else 3, refuse=len(sys.argv) > 2 and sys.argv[2] == "refuse"))
