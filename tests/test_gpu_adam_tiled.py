@@ -399,3 +399,35 @@ def test_look_ahead_catchup_of_the_next_batch_is_bitwise_the_same():
             assert same_state(plain, ahead), i
     assert same_state(plain, ahead)
     assert ahead._ahead is None or ahead._ahead[0] is not None
+
+
+def test_side_stream_finishers_and_loss_do_not_change_a_bit():
+    """score_state_t.grads_done_event (the dense gradient's end-of-pass finishers on the engine's side stream, under the table's
+    touched-row update) and .loss_done_event (the loss reduction there, beside the backward pass's first launches) only MOVE
+    launches: with both forced on at a small shape (they engage from overlap_finishers_min_rows (b, t) rows on), losses --
+    train_async's device scalar and train()'s early read-back --, gradients and optimizer state equal the run with both off,
+    bit for bit; so do an evaluation in between and a forward_backward whose gradients the caller reads."""
+    cfg = so.Cfg(3000, 16, 16, 4, 3, 2, 3, "SCORE")
+    off, on = make(cfg, 5), make(cfg, 5)
+    off.overlap_finishers_min_rows = 10 ** 9
+    on.overlap_finishers_min_rows = 0
+    assert on.loss_on_side and off.loss_on_side
+    bs = batches(cfg, 16, 5, seed=21, hot_rows=150)
+    d_off, d_on = [off.device_batch(b) for b in bs], [on.device_batch(b) for b in bs]
+    for i in range(14):
+        bi = (3 * i) % 5
+        if i % 3 == 2:          # the reference's call: the loss comes back every step (train()'s early read-back)
+            assert off.train(None, d_off[bi], 1e-2, 1e-4) == on.train(None, d_on[bi], 1e-2, 1e-4), i
+        else:
+            assert float(off.train_async(d_off[bi], 1e-2, 1e-4)) == float(on.train_async(d_on[bi], 1e-2, 1e-4)), i
+        if i >= 3:
+            assert on._tiled_on() and on._ev_grads is not None and on._ev_loss is not None
+            assert off._ev_grads is None and off._ev_loss is None
+        if i == 6:
+            assert off.eval(None, d_off[1], 1e-4)[0] == on.eval(None, d_on[1], 1e-4)[0]
+        if i == 9:              # gradients read by the caller: w_g joins the finishers first
+            lo, wo = off.forward_backward(d_off[2], 1e-4)
+            ln, wn = on.forward_backward(d_on[2], 1e-4)
+            assert torch.equal(off.w_g, on.w_g) and torch.equal(off.dense_table_grad(), on.dense_table_grad())
+            assert float(wo[lo.loss]) == float(wn[ln.loss])
+    assert same_state(off, on)
