@@ -871,6 +871,8 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
       }
     }
     G(gemm_queue_flush(&gq, x3 != 0, ws + w.dwslab, slab_half, side->st));
+    // the folded first attention layer's gradient from the two products just reduced (head.hip): here, off the launch stream
+    if (d.attn) G(score_launch_attn_w1_grad(d.Dk, AT1, ws + w.dweff, ws + w.dwq, gw + P.at_w[1], side->st));
     // the bias / bn1 gradients known so far (column sums of matrices that are final by now), same place
     if (q_on_side) G(colsum_queue_flush(&cq, ws + w.cs_part, w.cs_part_floats / 2, side->st));
     HIPTRY(hipEventRecord(side->join, side->st));
@@ -1003,18 +1005,22 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
   EV(4);
   // the remaining weight-gradient products of the pass, then the gradients assembled from them
   if (side) HIPTRY(hipStreamWaitEvent(s, side->join, 0));
-  // The finishers of the dense gradient -- the split-K slab reduce, the folded attention layer's gradient, the column sums: four
-  // small dependent launches, ~40 us of the launch stream at cfg-3 -- have ONE consumer, the dense variables' ApplyAdam.  A
-  // caller that passes score_state_t.grads_done_event gets them on the side stream (idle by now: the launch stream has just
-  // waited for its join) behind the products, and the event recorded behind them: it may run the table's touched-row update,
-  // which needs the row gradients only, on the launch stream meanwhile, and waits for the event before anything reads grad_w.
+  // The finishers of the dense gradient -- the split-K slab reduce and the column sums: TWO small launches behind the products
+  // (score_launch_finish; four dependent ones before round 4, the folded attention layer's gradient among them -- that one now
+  // follows the side stream's products, above) -- have ONE consumer, the dense variables' ApplyAdam.  A caller that passes
+  // score_state_t.grads_done_event gets them on the side stream (idle by now: the launch stream has just waited for its join)
+  // behind the products, and the event recorded behind them: it may run the table's touched-row update, which needs the row
+  // gradients only, on the launch stream meanwhile, and waits for the event before anything reads grad_w.
   const bool fin_side = st->grads_done_event != nullptr && side != nullptr;
   hipStream_t fs = fin_side ? side->st : s;
-  G(gemm_queue_flush(&gq, x3 != 0, ws + w.dwslab + slab_used, w.dwslab_floats - slab_used, s, fin_side ? fs : nullptr,
-                     fin_side ? side->fork : nullptr));
+  ReduceGroup rg;
+  G(gemm_queue_flush(&gq, x3 != 0, ws + w.dwslab + slab_used, w.dwslab_floats - slab_used, s, &rg));
   EV(5);
-  if (d.attn) G(score_launch_attn_w1_grad(d.Dk, AT1, ws + w.dweff, ws + w.dwq, gw + P.at_w[1], fs));
-  G(colsum_queue_flush(&cq, ws + w.cs_part + w.cs_part_floats / 2, w.cs_part_floats - w.cs_part_floats / 2, fs));
+  if (fin_side) {
+    HIPTRY(hipEventRecord(side->fork, s));
+    HIPTRY(hipStreamWaitEvent(fs, side->fork, 0));
+  }
+  G(score_launch_finish(&rg, &cq, ws + w.cs_part + w.cs_part_floats / 2, w.cs_part_floats - w.cs_part_floats / 2, fs));
   if (fin_side) HIPTRY(hipEventRecord((hipEvent_t)st->grads_done_event, fs));
   return 0;
 }

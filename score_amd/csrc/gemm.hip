@@ -217,14 +217,12 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slab, int nsplit,
 }
 
 // every split-K slab set of a flushed queue in one launch: C = sum_z slab[z]  (slab order)
-struct ReduceJob { const float* slab; float* C; int ns, M, N, ldc, first_block, pad; };
-struct ReduceGroup { int n; int pad; ReduceJob j[2 * GEMM_GROUP_MAX]; };
-__global__ void splitk_reduce_group_kernel(const ReduceGroup g) {
+__device__ __forceinline__ void splitk_reduce_group_body(const ReduceGroup& g, int blk) {
   int ji = 0;
-  while (ji + 1 < g.n && (int)blockIdx.x >= g.j[ji + 1].first_block) ++ji;
+  while (ji + 1 < g.n && blk >= g.j[ji + 1].first_block) ++ji;
   const ReduceJob& job = g.j[ji];
   const int64_t n = (int64_t)job.M * job.N;
-  const int64_t i = (int64_t)((int)blockIdx.x - job.first_block) * blockDim.x + threadIdx.x;
+  const int64_t i = (int64_t)(blk - job.first_block) * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int row = (int)(i / job.N), col = (int)(i - (int64_t)row * job.N);
   float s = 0.f;
@@ -239,6 +237,7 @@ __global__ void splitk_reduce_group_kernel(const ReduceGroup g) {
   for (; z < job.ns; ++z) s += job.slab[(int64_t)z * n + i];
   job.C[(int64_t)row * job.ldc + col] = s;
 }
+__global__ void splitk_reduce_group_kernel(const ReduceGroup g) { splitk_reduce_group_body(g, (int)blockIdx.x); }
 
 static void fill_prob(GemmProb* p, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
                       int ldc, int k_chunk, float* slab, int gx, int gy, int gz) {
@@ -431,8 +430,8 @@ int gemm_queue_add(GemmQueue* q, int M, int N, int K, const float* A, int lda, c
 // C_j = A_j^T . B_j for every queued job: the jobs that qualify for the bf16x3 kernel go out as one grouped
 // launch of 128x128 tiles, the rest as one grouped launch of the 64x64 f32 kernel, K split so that either
 // launch fills the chip a few times over; one more launch reduces all slabs (fixed order: reproducible).
-int gemm_queue_flush(GemmQueue* q, int x3, float* slab, int64_t slab_floats, hipStream_t s, hipStream_t reduce_stream,
-                     hipEvent_t reduce_event) {
+int gemm_queue_flush(GemmQueue* q, int x3, float* slab, int64_t slab_floats, hipStream_t s, ReduceGroup* defer) {
+  if (defer) defer->n = defer->blocks = 0;
   if (!q || q->n == 0) return 0;
   if (!slab) return SCORE_E_BADARG;
   GemmGroup g3, gf;
@@ -491,17 +490,11 @@ int gemm_queue_flush(GemmQueue* q, int x3, float* slab, int64_t slab_floats, hip
                        0);
     SCORE_CHECK_LAUNCH();
   }
-  // the slab reduce: on `s`, or -- reduce_stream given -- on that stream behind the products (the caller orders what consumes
-  // the results behind it: score_backward's end-of-pass finishers, engine.hip)
-  hipStream_t rs = s;
-  if (reduce_stream && reduce_event) {
-    hipError_t e = hipEventRecord(reduce_event, s);
-    if (e != hipSuccess) return (int)e;
-    if ((e = hipStreamWaitEvent(reduce_stream, reduce_event, 0)) != hipSuccess) return (int)e;
-    rs = reduce_stream;
-  }
-  if (rg.n) {
-    hipLaunchKernelGGL(splitk_reduce_group_kernel, dim3(rblocks), dim3(256), 0, rs, rg);
+  rg.blocks = rblocks;
+  if (defer) {
+    *defer = rg;                // (the caller launches it: score_launch_finish)
+  } else if (rg.n) {
+    hipLaunchKernelGGL(splitk_reduce_group_kernel, dim3(rblocks), dim3(256), 0, s, rg);
     SCORE_CHECK_LAUNCH();
   }
   q->n = 0;
@@ -585,9 +578,9 @@ __global__ __launch_bounds__(256) void colsum_multi_stage1(const ColsumJobs jobs
     part[j.part_off + (int64_t)blockIdx.y * j.N + n] = t;
   }
 }
-__global__ void colsum_multi_stage2(const ColsumJobs jobs, const float* __restrict__ part) {
-  const ColsumJob& j = jobs.job[blockIdx.y];
-  int n = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void colsum_multi_stage2_body(const ColsumJobs& jobs, const float* __restrict__ part, int job, int bx) {
+  const ColsumJob& j = jobs.job[job];
+  int n = bx * blockDim.x + threadIdx.x;
   if (n >= j.N) return;
   const float* p0 = part + j.part_off + n;
   float s = 0.f;
@@ -601,6 +594,20 @@ __global__ void colsum_multi_stage2(const ColsumJobs jobs, const float* __restri
   }
   for (; p < j.nparts; ++p) s += p0[(int64_t)p * j.N];
   j.out[n] = j.acc ? j.out[n] + s : s;
+}
+__global__ void colsum_multi_stage2(const ColsumJobs jobs, const float* __restrict__ part) {
+  colsum_multi_stage2_body(jobs, part, (int)blockIdx.y, (int)blockIdx.x);
+}
+// workgroups [0, rg.blocks): the split-K slab reduce; the rest, gx2 per job: the column sums' second stage
+__global__ __launch_bounds__(256) void finish_kernel(const ReduceGroup rg, const ColsumJobs jobs, const float* __restrict__ part,
+                                                     int gx2) {
+  const int blk = (int)blockIdx.x;
+  if (blk < rg.blocks) {
+    splitk_reduce_group_body(rg, blk);
+    return;
+  }
+  const int b = blk - rg.blocks;
+  colsum_multi_stage2_body(jobs, part, b / gx2, b % gx2);
 }
 
 int colsum_queue_add(ColsumJobs* q, const float* X, int M, int N, int ld, float* out, int acc) {
@@ -618,6 +625,32 @@ int colsum_queue_add(ColsumJobs* q, const float* X, int M, int N, int ld, float*
   j.rpb = rpb; j.nparts = nparts;
   j.part_off = q->part_used;
   q->part_used += (int64_t)nparts * N;
+  return 0;
+}
+
+int score_launch_finish(const ReduceGroup* rg, ColsumJobs* q, float* part, int64_t part_floats, hipStream_t s) {
+  ReduceGroup none;
+  none.n = none.blocks = 0;
+  if (!rg) rg = &none;
+  if (!q || q->n == 0) {
+    if (rg->n) {
+      hipLaunchKernelGGL(splitk_reduce_group_kernel, dim3(rg->blocks), dim3(256), 0, s, *rg);
+      SCORE_CHECK_LAUNCH();
+    }
+    return 0;
+  }
+  if (q->part_used > part_floats) return SCORE_E_WORKSPACE;
+  int gx = 1, gx2 = 1;
+  for (int i = 0; i < q->n; ++i) {
+    gx = max(gx, (q->job[i].N + q->job[i].cols - 1) / q->job[i].cols);
+    gx2 = max(gx2, (q->job[i].N + 255) / 256);
+  }
+  hipLaunchKernelGGL(colsum_multi_stage1, dim3(gx, COLSUM_MAX_PARTS, q->n), dim3(256), 0, s, *q, part);
+  SCORE_CHECK_LAUNCH();
+  hipLaunchKernelGGL(finish_kernel, dim3(rg->blocks + gx2 * q->n), dim3(256), 0, s, *rg, *q, part, gx2);
+  SCORE_CHECK_LAUNCH();
+  q->n = 0;
+  q->part_used = 0;
   return 0;
 }
 

@@ -23,8 +23,12 @@ struct GemmQueueJob { const float* A; const float* B; float* C; int M, N, K, lda
 struct GemmQueue { int n; GemmQueueJob j[2 * GEMM_GROUP_MAX]; };
 int gemm_queue_add(GemmQueue* q, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
                    int ldc);
-int gemm_queue_flush(GemmQueue* q, int x3, float* slab, int64_t slab_floats, hipStream_t s, hipStream_t reduce_stream = nullptr,
-                     hipEvent_t reduce_event = nullptr);
+// every split-K slab set of a flushed queue: C = sum_z slab[z]  (slab order); blocks = workgroups of 256 its reduce needs
+struct ReduceJob { const float* slab; float* C; int ns, M, N, ldc, first_block, pad; };
+struct ReduceGroup { int n; int blocks; ReduceJob j[2 * GEMM_GROUP_MAX]; };
+// defer == nullptr: the slab reduce follows the products on `s`.  defer given: the products only; *defer describes the reduce
+// the caller still owes (score_launch_finish, behind the products)
+int gemm_queue_flush(GemmQueue* q, int x3, float* slab, int64_t slab_floats, hipStream_t s, ReduceGroup* defer = nullptr);
 #define COLSUM_MAX_JOBS 24
 #define COLSUM_MAX_PARTS 128
 struct ColsumJob { const float* X; float* out; int M, N, ld, acc, cols, rpb, nparts; int64_t part_off; };
@@ -33,6 +37,10 @@ struct ColsumJobs { ColsumJob job[COLSUM_MAX_JOBS]; int n; int64_t part_used; };
 // The queued X matrices must stay untouched until the flush.
 int colsum_queue_add(ColsumJobs* q, const float* X, int M, int N, int ld, float* out, int acc);
 int colsum_queue_flush(ColsumJobs* q, float* part, int64_t part_floats, hipStream_t s);
+// the end of a backward pass in TWO launches instead of four: the queued column sums' first stage, then ONE launch that is
+// the deferred split-K slab reduce of gemm_queue_flush (rg, may be empty) AND the column sums' second stage -- the two are
+// independent of each other, each workgroup does what its index says.  Same arithmetic, same order as the separate launches.
+int score_launch_finish(const ReduceGroup* rg, ColsumJobs* q, float* part, int64_t part_floats, hipStream_t s);
 int score_launch_colsum(const float* X, int M, int N, int ld, float* out, int accumulate,
                         float* scratch, int64_t scratch_floats, hipStream_t s);
 // embed.hip

@@ -246,9 +246,7 @@ template <int MODE>
 __global__ __launch_bounds__(256) void pull_kernel(const PullArgs a, const uint32_t* __restrict__ keys,
                                                    const uint32_t* __restrict__ vals, int64_t n, int WS,
                                                    float* __restrict__ out, float* __restrict__ pfirst,
-                                                   float* __restrict__ plast, int* __restrict__ long_count) {
-  // the long-chain counter pull_fixup_kernel (next launch) appends to: cleared here instead of by a memset launch
-  if (blockIdx.x == 0 && threadIdx.x < 4) long_count[threadIdx.x] = 0;
+                                                   float* __restrict__ plast) {
   const int LPR = a.LPRp;                                // lanes per group (power of two >= D/4)
   const int gpb = blockDim.x / LPR;                      // groups per block
   const int64_t w = (int64_t)blockIdx.x * gpb + threadIdx.x / LPR;
@@ -348,63 +346,56 @@ __device__ __forceinline__ int64_t run_end(const uint32_t* __restrict__ keys, in
 }
 
 // A run that starts in window w and continues to the right: total = plast[w] + pfirst[w+1] + ...
-// (window order, so the sum is reproducible).  Chains longer than LONG_CHAIN windows (the hot
-// categorical rows: thousands of windows) are queued for pull_long_kernel.
+// (window order, so the sum is reproducible).  Chains longer than LONG_CHAIN windows (the hot categorical rows:
+// thousands of windows) are taken by the WHOLE workgroup afterwards: its groups sum contiguous sub-ranges of the chain,
+// then the partial sums are added in group order (fixed partition => reproducible).  (Until round 4 those chains were
+// queued for a third launch, one workgroup per chain there as here: 6 - 11 us and a dependent launch on the step's chain.)
 #define LONG_CHAIN 16
 __global__ __launch_bounds__(256) void pull_fixup_kernel(const PullArgs a, const uint32_t* __restrict__ keys,
                                                          int64_t n, int WS, float* __restrict__ out,
                                                          const float* __restrict__ pfirst,
-                                                         const float* __restrict__ plast,
-                                                         int* __restrict__ long_count, int2* __restrict__ long_list) {
+                                                         const float* __restrict__ plast) {
+  extern __shared__ float sh[];              // [groups][D]: a long chain's partial sums
+  __shared__ int2 s_long[256];               // (window, L) of the long chains that start in this workgroup's windows
+  __shared__ int s_nlong;
   const int LPR = a.LPRp;
   const int gpb = blockDim.x / LPR;
-  const int64_t w = (int64_t)blockIdx.x * gpb + threadIdx.x / LPR;
-  const int ch4 = (threadIdx.x % LPR) * 4;
-  const int64_t start = w * WS;
-  if (start >= n || ch4 >= a.D) return;
-  const int64_t end = start + WS < n ? start + WS : n;
-  const uint32_t lastkey = keys[end - 1];
-  if ((lastkey == 0 && a.zero_is_dummy) || end >= n || keys[end] != lastkey) return;  // not open to the right
-  if (keys[start] == lastkey && start > 0 && keys[start - 1] == lastkey) return;  // did not start here
-  const int64_t re = run_end(keys, end, n, lastkey);
-  const int L = (int)((re - 1) / WS - w);                                 // windows w+1 .. w+L continue the run
-  if (L > LONG_CHAIN) {
-    if (ch4 == 0) {
-      int slot = atomicAdd(long_count, 1);
-      long_list[slot] = make_int2((int)w, L);
-    }
-    return;
-  }
-  float4 tot = ld4(plast + w * a.D + ch4);
-  for (int j = 1; j <= L; ++j) tot = add4(tot, ld4(pfirst + (w + j) * a.D + ch4));
-  store_row(a, out, lastkey, end - 1, ch4, tot);
-}
-
-// one block per long chain: its groups sum contiguous sub-ranges of the chain, then the partial
-// sums are added in group order (fixed partition => reproducible)
-__global__ __launch_bounds__(256) void pull_long_kernel(const PullArgs a, const uint32_t* __restrict__ keys,
-                                                        int WS, float* __restrict__ out,
-                                                        const float* __restrict__ pfirst,
-                                                        const float* __restrict__ plast,
-                                                        const int* __restrict__ long_count,
-                                                        const int2* __restrict__ long_list) {
-  extern __shared__ float sh[];  // [groups][D]
-  const int LPR = a.LPRp;
-  const int ng = blockDim.x / LPR;
   const int g = threadIdx.x / LPR;
+  const int64_t w = (int64_t)blockIdx.x * gpb + g;
   const int ch4 = (threadIdx.x % LPR) * 4;
   const bool lane_ok = ch4 < a.D;
-  const int count = *long_count;
-  for (int c = blockIdx.x; c < count; c += gridDim.x) {
-    const int2 e = long_list[c];
-    const int64_t w = e.x;
+  if (threadIdx.x == 0) s_nlong = 0;
+  __syncthreads();
+  const int64_t start = w * WS;
+  if (start < n && lane_ok) {
+    const int64_t end = start + WS < n ? start + WS : n;
+    const uint32_t lastkey = keys[end - 1];
+    const bool open_right = !((lastkey == 0 && a.zero_is_dummy) || end >= n || keys[end] != lastkey);
+    const bool starts_here = !(keys[start] == lastkey && start > 0 && keys[start - 1] == lastkey);
+    if (open_right && starts_here) {
+      const int64_t re = run_end(keys, end, n, lastkey);
+      const int L = (int)((re - 1) / WS - w);                               // windows w+1 .. w+L continue the run
+      if (L > LONG_CHAIN) {
+        if (ch4 == 0) s_long[atomicAdd(&s_nlong, 1)] = make_int2(g, L);     // (the order of the list changes no sum)
+      } else {
+        float4 tot = ld4(plast + w * a.D + ch4);
+        for (int j = 1; j <= L; ++j) tot = add4(tot, ld4(pfirst + (w + j) * a.D + ch4));
+        store_row(a, out, lastkey, end - 1, ch4, tot);
+      }
+    }
+  }
+  __syncthreads();
+  const int count = s_nlong;
+  for (int c = 0; c < count; ++c) {
+    const int2 e = s_long[c];
+    const int64_t wl = (int64_t)blockIdx.x * gpb + e.x;
     const int L = e.y;
-    const int chunk = (L + ng - 1) / ng;
+    const int chunk = (L + gpb - 1) / gpb;
     const int j0 = 1 + g * chunk, j1 = min(L, (g + 1) * chunk);
     float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
     if (lane_ok) {
-      // eight partial sums: eight loads in flight per trip (one dependent add chain made this kernel wait a
-      // full memory latency per window); fixed association, so still reproducible
+      // eight partial sums: eight loads in flight per trip (one dependent add chain waits a full memory latency per
+      // window); fixed association, so still reproducible
       float4 t8[8];
 #pragma unroll
       for (int q = 0; q < 8; ++q) t8[q] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -412,20 +403,20 @@ __global__ __launch_bounds__(256) void pull_long_kernel(const PullArgs a, const 
       for (; j + 7 <= j1; j += 8) {
         float4 v[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = ld4(pfirst + (w + j + q) * a.D + ch4);
+        for (int q = 0; q < 8; ++q) v[q] = ld4(pfirst + (wl + j + q) * a.D + ch4);
 #pragma unroll
         for (int q = 0; q < 8; ++q) t8[q] = add4(t8[q], v[q]);
       }
-      for (; j <= j1; ++j) t8[0] = add4(t8[0], ld4(pfirst + (w + j) * a.D + ch4));
+      for (; j <= j1; ++j) t8[0] = add4(t8[0], ld4(pfirst + (wl + j) * a.D + ch4));
       tot = add4(add4(add4(t8[0], t8[1]), add4(t8[2], t8[3])), add4(add4(t8[4], t8[5]), add4(t8[6], t8[7])));
+      st4(sh + g * a.D + ch4, tot);
     }
-    if (lane_ok) st4(sh + g * a.D + ch4, tot);
     __syncthreads();
     if (g == 0 && lane_ok) {
-      float4 t = ld4(plast + w * a.D + ch4);
-      for (int q = 0; q < ng; ++q) t = add4(t, ld4(sh + q * a.D + ch4));
-      const uint32_t key = keys[(w + 1) * (int64_t)WS - 1];
-      store_row(a, out, key, (w + 1) * (int64_t)WS - 1, ch4, t);
+      float4 t = ld4(plast + wl * a.D + ch4);
+      for (int q = 0; q < gpb; ++q) t = add4(t, ld4(sh + q * a.D + ch4));
+      const uint32_t key = keys[(wl + 1) * (int64_t)WS - 1];
+      store_row(a, out, key, (wl + 1) * (int64_t)WS - 1, ch4, t);
     }
     __syncthreads();
   }
@@ -443,26 +434,21 @@ int score_launch_pull(PullArgs& a, const uint32_t* keys, const uint32_t* vals, i
   if (LPR > 64) return SCORE_E_SHAPE;
   a.LPRp = LPR;
   int64_t nw = cdiv64(n, WS);
-  // partials: pfirst [nw][D] | plast [nw][D] | long-chain counter (4 floats) | long list [nw] int2
-  if (2 * nw * a.D + 4 + 2 * nw > partial_floats) return SCORE_E_WORKSPACE;
+  // partials: pfirst [nw][D] | plast [nw][D]
+  if (2 * nw * a.D > partial_floats) return SCORE_E_WORKSPACE;
   float* pfirst = partials;
   float* plast = partials + nw * a.D;
-  int* long_count = reinterpret_cast<int*>(plast + nw * a.D);
-  int2* long_list = reinterpret_cast<int2*>(long_count + 4);
   int gpb = 256 / LPR;
   unsigned blocks = (unsigned)cdiv64(nw, gpb);
   // contribution form: owner-side row sum (descriptors are source slots), constant coefficients, or the
   // co-attention's per-(unit, k) coefficients
   const int mode = (a.G[1] == nullptr && a.ldg[0] == 0) ? 0 : (a.cA[0] ? 2 : 1);
-  if (mode == 0) hipLaunchKernelGGL(pull_kernel<0>, dim3(blocks), dim3(256), 0, s, a, keys, vals, n, WS, out, pfirst, plast, long_count);
-  else if (mode == 1) hipLaunchKernelGGL(pull_kernel<1>, dim3(blocks), dim3(256), 0, s, a, keys, vals, n, WS, out, pfirst, plast, long_count);
-  else hipLaunchKernelGGL(pull_kernel<2>, dim3(blocks), dim3(256), 0, s, a, keys, vals, n, WS, out, pfirst, plast, long_count);
+  if (mode == 0) hipLaunchKernelGGL(pull_kernel<0>, dim3(blocks), dim3(256), 0, s, a, keys, vals, n, WS, out, pfirst, plast);
+  else if (mode == 1) hipLaunchKernelGGL(pull_kernel<1>, dim3(blocks), dim3(256), 0, s, a, keys, vals, n, WS, out, pfirst, plast);
+  else hipLaunchKernelGGL(pull_kernel<2>, dim3(blocks), dim3(256), 0, s, a, keys, vals, n, WS, out, pfirst, plast);
   SCORE_CHECK_LAUNCH();
-  hipLaunchKernelGGL(pull_fixup_kernel, dim3(blocks), dim3(256), 0, s, a, keys, n, WS, out, pfirst, plast,
-                     long_count, long_list);
-  SCORE_CHECK_LAUNCH();
-  hipLaunchKernelGGL(pull_long_kernel, dim3(1024), dim3(256), (size_t)gpb * a.D * sizeof(float), s, a, keys, WS,
-                     out, pfirst, plast, long_count, long_list);
+  hipLaunchKernelGGL(pull_fixup_kernel, dim3(blocks), dim3(256), (size_t)gpb * a.D * sizeof(float), s, a, keys, n, WS, out,
+                     pfirst, plast);
   SCORE_CHECK_LAUNCH();
   return 0;
 }

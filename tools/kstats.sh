@@ -1,5 +1,6 @@
 # per-kernel averages of one bench invocation: tools/kstats.sh <outdir-under-gpurun_out> <bench args...>
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$1; shift
+# KSTATS_TREE=<subdir>: run the bench.py of that source tree (tools/ab_trees.sh) instead of the repo's own
+R=$GRAFT_REPO_ROOT/${KSTATS_TREE:-.}; O=$GRAFT_REPO_ROOT/gpurun_out/$1; shift
 mkdir -p $O; cd /tmp; export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/st -- python3 $R/bench.py --no-cpu-baseline --no-side "$@" > $O/run.log 2>&1
 find $O -name "*.db" -delete
