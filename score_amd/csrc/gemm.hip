@@ -442,7 +442,7 @@ int gemm_queue_flush(GemmQueue* q, int x3, float* slab, int64_t slab_floats, hip
     const GemmQueueJob& j = q->j[i];
     const bool al = (j.lda & 3) == 0 && (j.ldb & 3) == 0 && (reinterpret_cast<uintptr_t>(j.A) & 15) == 0 &&
                     (reinterpret_cast<uintptr_t>(j.B) & 15) == 0 && (j.M & 3) == 0 && (j.N & 3) == 0;
-    fam[i] = (x3 && al && j.M >= 64 && j.N >= 32 && (int64_t)j.M * j.N >= 32768 && j.K >= 4096) ? 1 : 0;
+    fam[i] = (x3 && al && j.M >= 64 && j.N >= 32 && (int64_t)j.M * j.N >= 16384 && j.K >= 4096) ? 1 : 0;
     const int64_t tiles = fam[i] ? (int64_t)((j.M + 127) / 128) * ((j.N + 127) / 128)
                                  : (int64_t)((j.M + 63) / 64) * ((j.N + 63) / 64);
     work[fam[i]] += tiles * j.K;
@@ -452,6 +452,18 @@ int gemm_queue_flush(GemmQueue* q, int x3, float* slab, int64_t slab_floats, hip
   int kc[2];
   kc[1] = (int)align_up64(cdiv64(work[1] > 0 ? work[1] : 1, 512), 32);
   if (kc[1] < 256) kc[1] = 256;
+  // ... and not ONE workgroup more than the 512 that are resident together (every job's share is padded to a multiple of
+  // eight below): a 513th starts a second round of the whole launch -- measured +27 us on a 100-us launch at cfg-3
+  for (int guard = 0; guard < 64; ++guard) {
+    int64_t blocks = 0;
+    for (int i = 0; i < q->n; ++i)
+      if (fam[i]) {
+        const GemmQueueJob& j = q->j[i];
+        blocks += ((int64_t)((j.M + 127) / 128) * ((j.N + 127) / 128) * cdiv64(j.K, kc[1]) + 7) & ~(int64_t)7;
+      }
+    if (blocks <= 512 || kc[1] >= 1 << 20) break;
+    kc[1] += 32;
+  }
   kc[0] = (int)align_up64(cdiv64(work[0] > 0 ? work[0] : 1, 1024), BK_ALIGN);
   if (kc[0] < 128) kc[0] = 128;
   ReduceGroup rg;
