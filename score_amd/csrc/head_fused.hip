@@ -804,7 +804,7 @@ __global__ __launch_bounds__(64 * HF_NW) void head_bwd_fused_kernel(const HeadBw
           const int i = lq * 4 + r, row = b0 + i;
           const float q = acc[r] / a.keep;
           const float v = (row < a.B && y[r] > 0.f) ? q : 0.f;      // relu (+ dropout) of fc1, as the GEMM epilogue had it
-          if (row < a.B) a.dz1[(int64_t)row * N1 + col] = v;
+          if (row < a.B && blockIdx.y == 0) a.dz1[(int64_t)row * N1 + col] = v;
           z1s[i * LD1 + col] = v;
         }
       }
@@ -812,7 +812,11 @@ __global__ __launch_bounds__(64 * HF_NW) void head_bwd_fused_kernel(const HeadBw
   }
   __syncthreads();
   // fc1 backward + bn1 backward: tiles wave, wave + 8, ... of ceil(Dh / 16); B[k][n] = W1[n][k], streamed one tile ahead
-  const int nt = (a.Dh + 15) >> 4;
+  // (gridDim.y workgroups share a row tile's column tiles -- each has computed dz1 for itself: at 1024 samples the 64 row
+  //  tiles alone left three quarters of the chip idle for 27 us of the launch stream; four shares: the same sums, 15 us)
+  const int nt_all = (a.Dh + 15) >> 4;
+  const int per = (nt_all + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int t0 = (int)blockIdx.y * per, nt = min(nt_all, t0 + per);
   float4 av[HB_K1Q / 4];
 #pragma unroll
   for (int s4 = 0; s4 < HB_K1Q / 4; ++s4) av[s4] = *reinterpret_cast<const float4*>(z1s + lc * LD1 + lq * HB_K1Q + 4 * s4);
@@ -827,9 +831,9 @@ __global__ __launch_bounds__(64 * HF_NW) void head_bwd_fused_kernel(const HeadBw
       dst[s4] = ld4(k + 3 < N1 ? wrow + 4 * s4 : a.W1);
     }
   };
-  if (wave < nt) fetch(bw[0], wave);
+  if (t0 + wave < nt) fetch(bw[0], t0 + wave);
   int cur = 0;
-  for (int tile = wave; tile < nt; tile += HF_NW, cur ^= 1) {
+  for (int tile = t0 + wave; tile < nt; tile += HF_NW, cur ^= 1) {
     if (tile + HF_NW < nt) {
       if (cur == 0) fetch(bw[1], tile + HF_NW); else fetch(bw[0], tile + HF_NW);
     }
@@ -1021,7 +1025,10 @@ int score_launch_head_bwd_fused(int B, int Dh, int N1, int N2, const float* dz2,
   HeadBwdArgs a;
   a.B = B; a.Dh = Dh; a.dz2 = dz2; a.W2 = W2; a.f1 = f1; a.keep = keep; a.W1 = W1; a.x = x; a.gamma = gamma; a.rs = rs;
   a.dz1 = dz1; a.dbn = dbn; a.dhead = dhead; a.tmp = tmp;
-  hipLaunchKernelGGL(head_bwd_fused_kernel, dim3((B + HF_ROWS - 1) / HF_ROWS), dim3(64 * HF_NW), 0, s, a);
+  // few row tiles and many column tiles of d bn1: the column tiles dealt to up to four workgroups per row tile
+  const int mt = (B + HF_ROWS - 1) / HF_ROWS, ntile = (Dh + 15) >> 4;
+  const int ny = (mt <= 128 && ntile >= 4 * HF_NW) ? (mt <= 64 ? 4 : 2) : 1;
+  hipLaunchKernelGGL(head_bwd_fused_kernel, dim3(mt, ny), dim3(64 * HF_NW), 0, s, a);
   SCORE_CHECK_LAUNCH();
   return 0;
 }
