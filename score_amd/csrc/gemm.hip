@@ -454,15 +454,15 @@ int gemm_queue_flush(GemmQueue* q, int x3, float* slab, int64_t slab_floats, hip
   if (kc[1] < 256) kc[1] = 256;
   // ... and not ONE workgroup more than the 512 that are resident together (every job's share is padded to a multiple of
   // eight below): a 513th starts a second round of the whole launch -- measured +27 us on a 100-us launch at cfg-3
-  for (int guard = 0; guard < 64; ++guard) {
+  for (int guard = 0; guard < 256; ++guard) {
     int64_t blocks = 0;
     for (int i = 0; i < q->n; ++i)
       if (fam[i]) {
         const GemmQueueJob& j = q->j[i];
         blocks += ((int64_t)((j.M + 127) / 128) * ((j.N + 127) / 128) * cdiv64(j.K, kc[1]) + 7) & ~(int64_t)7;
       }
-    if (blocks <= 512 || kc[1] >= 1 << 20) break;
-    kc[1] += 32;
+    if (blocks <= 512 || kc[1] >= 1 << 24) break;
+    kc[1] += (int)align_up64(kc[1] / 64 > 32 ? kc[1] / 64 : 32, 32);       // (K = 204,800 at cfg-5: steps of 32 would never get there)
   }
   kc[0] = (int)align_up64(cdiv64(work[0] > 0 ? work[0] : 1, 1024), BK_ALIGN);
   if (kc[0] < 128) kc[0] = 128;
