@@ -415,10 +415,6 @@ def main():
                     help="do NOT tell apply_adam which batch comes next (SCOREBASE.apply_adam(next_batch=): with the time-tiled "
                          "table optimizer the next batch's rows are brought up to date beside this step's weight-gradient "
                          "products instead of in front of the next forward pass)")
-    ap.add_argument("--flush-before-warmup", action="store_true",
-                    help="A/B: apply what the table optimizer owes BEFORE the warm-up steps instead of between them and the timed "
-                         "region (the region then starts in the steady state of a long run -- look-ahead primed, caches as a step "
-                         "leaves them -- and also pays what the warm-up steps deferred)")
     ap.add_argument("--set", dest="model_attrs", action="append", default=[], metavar="ATTR=VALUE",
                     help="set a public attribute of the model before the run (A/B of its placement choices: loss_on_side=0, "
                          "adam_sweep_at=3, overlap_finishers_min_rows=0 ...); the value is parsed as a Python literal")
@@ -615,8 +611,6 @@ def main():
     gc.collect()
     gc.freeze()
     beat("warmup")
-    if args.flush_before_warmup:
-        finish_adam()
     run_steps(max(args.warmup - 1, 0))
     if args.warmup > 0 and not graph:
         # the last warm-up step carries stage events like every `every`-th timed step does: the first step that records
@@ -628,8 +622,7 @@ def main():
     # the time-tiled optimizer applies a row's zero-gradient updates late; what the WARM-UP steps still owe is applied here,
     # before the clock starts, as what the timed steps still owe is applied before it stops: the region pays for exactly its
     # own steps (round 4; before, it also paid the warm-up's share of the replay arithmetic)
-    if not args.flush_before_warmup:
-        finish_adam()
+    finish_adam()
     beat("timed")
     barrier()
     t0 = time.perf_counter()
