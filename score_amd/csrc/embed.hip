@@ -686,7 +686,12 @@ int score_launch_target_bwd(float* grad_table, int D, int Fu, int Fi, int B, int
   if (coattn) {
     // dW_t = tgt^T S (call 0 targets the item: query cols Du.., call 1 the user: cols 0..), dbias = sum_b S
     const int Du = Fu * D, Di = Fi * D;
-    if (gq) {   // with the backward pass's other weight-gradient products (query and S stay untouched)
+    if (cq) {   // one output column each: row-weighted column sums with the pass's other column sums (query and S stay
+                // untouched until they run) -- as queued GEMM jobs they alone kept a launch of the f32 GEMM kernel in the end-of-pass
+                // flush at cfg-3
+      SCORE_TRY(colsum_queue_add(cq, query + Du, B, Di, ldq, dW1, 0, S));
+      SCORE_TRY(colsum_queue_add(cq, query, B, Du, ldq, dW2, 0, S + B));
+    } else if (gq) {
       SCORE_TRY(gemm_queue_add(gq, Di, 1, B, query + Du, ldq, S, 1, dW1, 1));
       SCORE_TRY(gemm_queue_add(gq, Du, 1, B, query, ldq, S + B, 1, dW2, 1));
     } else {

@@ -574,12 +574,23 @@ __global__ __launch_bounds__(256) void colsum_multi_stage1(const ColsumJobs jobs
     const float* x = j.X + n;
     int m = m0 + ty;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    for (; m + 3 * nty < m1; m += 4 * nty) {
-      const float v0 = x[(int64_t)m * j.ld], v1 = x[(int64_t)(m + nty) * j.ld];
-      const float v2 = x[(int64_t)(m + 2 * nty) * j.ld], v3 = x[(int64_t)(m + 3 * nty) * j.ld];
-      s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+    if (j.scale) {          // rows weighted by scale[m] (X^T s: the co-attention's target-row weight gradients)
+      const float* sc = j.scale;
+      for (; m + 3 * nty < m1; m += 4 * nty) {
+        const float v0 = x[(int64_t)m * j.ld], v1 = x[(int64_t)(m + nty) * j.ld];
+        const float v2 = x[(int64_t)(m + 2 * nty) * j.ld], v3 = x[(int64_t)(m + 3 * nty) * j.ld];
+        const float c0 = sc[m], c1 = sc[m + nty], c2 = sc[m + 2 * nty], c3 = sc[m + 3 * nty];
+        s0 = fmaf(v0, c0, s0); s1 = fmaf(v1, c1, s1); s2 = fmaf(v2, c2, s2); s3 = fmaf(v3, c3, s3);
+      }
+      for (; m < m1; m += nty) s0 = fmaf(x[(int64_t)m * j.ld], sc[m], s0);
+    } else {
+      for (; m + 3 * nty < m1; m += 4 * nty) {
+        const float v0 = x[(int64_t)m * j.ld], v1 = x[(int64_t)(m + nty) * j.ld];
+        const float v2 = x[(int64_t)(m + 2 * nty) * j.ld], v3 = x[(int64_t)(m + 3 * nty) * j.ld];
+        s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+      }
+      for (; m < m1; m += nty) s0 += x[(int64_t)m * j.ld];
     }
-    for (; m < m1; m += nty) s0 += x[(int64_t)m * j.ld];
     s = (s0 + s1) + (s2 + s3);
   }
   sh[threadIdx.x] = s;
@@ -622,10 +633,10 @@ __global__ __launch_bounds__(256) void finish_kernel(const ReduceGroup rg, const
   colsum_multi_stage2_body(jobs, part, b / gx2, b % gx2);
 }
 
-int colsum_queue_add(ColsumJobs* q, const float* X, int M, int N, int ld, float* out, int acc) {
+int colsum_queue_add(ColsumJobs* q, const float* X, int M, int N, int ld, float* out, int acc, const float* scale) {
   if (q->n >= COLSUM_MAX_JOBS) return SCORE_E_WORKSPACE;
   ColsumJob& j = q->job[q->n++];
-  j.X = X; j.M = M; j.N = N; j.ld = ld; j.out = out; j.acc = acc;
+  j.X = X; j.M = M; j.N = N; j.ld = ld; j.out = out; j.acc = acc; j.scale = scale;
   int cols = 1;
   while (cols < N && cols < 64) cols <<= 1;
   j.cols = cols;

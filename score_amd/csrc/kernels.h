@@ -31,11 +31,12 @@ struct ReduceGroup { int n; int blocks; ReduceJob j[2 * GEMM_GROUP_MAX]; };
 int gemm_queue_flush(GemmQueue* q, int x3, float* slab, int64_t slab_floats, hipStream_t s, ReduceGroup* defer = nullptr);
 #define COLSUM_MAX_JOBS 24
 #define COLSUM_MAX_PARTS 128
-struct ColsumJob { const float* X; float* out; int M, N, ld, acc, cols, rpb, nparts; int64_t part_off; };
+struct ColsumJob { const float* X; float* out; const float* scale; int M, N, ld, acc, cols, rpb, nparts; int64_t part_off; };
 struct ColsumJobs { ColsumJob job[COLSUM_MAX_JOBS]; int n; int64_t part_used; };
 // deferred column sums: queue jobs during a pass, run them all in two launches at its end.
 // The queued X matrices must stay untouched until the flush.
-int colsum_queue_add(ColsumJobs* q, const float* X, int M, int N, int ld, float* out, int acc);
+// scale (optional, [M]): out[n] = sum_m scale[m] * X[m][n] -- a product X^T s with one output column, without a GEMM launch
+int colsum_queue_add(ColsumJobs* q, const float* X, int M, int N, int ld, float* out, int acc, const float* scale = nullptr);
 int colsum_queue_flush(ColsumJobs* q, float* part, int64_t part_floats, hipStream_t s);
 // the end of a backward pass in TWO launches instead of four: the queued column sums' first stage, then ONE launch that is
 // the deferred split-K slab reduce of gemm_queue_flush (rg, may be empty) AND the column sums' second stage -- the two are
