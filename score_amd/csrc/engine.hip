@@ -260,7 +260,7 @@ void build_ws(const Dims& d, int B, WS* w) {
 // score_state_t.context; forked from / joined back into the caller's stream with events.  A caller that passes no
 // context shares ONE process-wide default context per device (created on first use, released by
 // score_context_destroy(NULL)): the only state the library keeps between calls.
-struct SideStream { hipStream_t st; hipEvent_t fork, join, wx; int device; };
+struct SideStream { hipStream_t st; hipEvent_t fork, join, wx; int device; hipStream_t fwd_on; };
 static int side_stream_create(SideStream* sd) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return SCORE_E_BADARG;
@@ -270,7 +270,7 @@ static int side_stream_create(SideStream* sd) {
   if ((e = hipEventCreateWithFlags(&a, hipEventDisableTiming)) != hipSuccess) { hipStreamDestroy(st); return (int)e; }
   if ((e = hipEventCreateWithFlags(&b, hipEventDisableTiming)) != hipSuccess) { hipEventDestroy(a); hipStreamDestroy(st); return (int)e; }
   if ((e = hipEventCreateWithFlags(&c, hipEventDisableTiming)) != hipSuccess) { hipEventDestroy(a); hipEventDestroy(b); hipStreamDestroy(st); return (int)e; }
-  sd->st = st; sd->fork = a; sd->join = b; sd->wx = c; sd->device = dev;
+  sd->st = st; sd->fork = a; sd->join = b; sd->wx = c; sd->device = dev; sd->fwd_on = nullptr;
   return 0;
 }
 static void side_stream_release(SideStream* sd) {
@@ -510,6 +510,7 @@ extern "C" int score_forward(const score_config_t* cfg, const score_state_t* st,
   G(side_stream(st, &sd));
   HIPTRY(hipEventRecord(sd->fork, s));
   HIPTRY(hipStreamWaitEvent(sd->st, sd->fork, 0));
+  sd->fwd_on = s;       // (score_backward on this stream next finds the side stream already behind everything before this pass)
   // what the step derives from the weights alone, in ONE launch off the main stream: the [Wx_gates | Wx_cand] copies for the
   // hoisted GRU input projections, the folded first attention layer (dense_3 on [q, k, q-k, q*k], head.hip) and the L2 norm's
   // partial sums (three launches before round 4: the reference's own batch sizes are bound by the host's launch calls)
@@ -731,8 +732,15 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
   // gradient is queued -- so the fill runs on the side stream, off the chain of dependent launches.
   SideStream* side = nullptr;
   G(side_stream(st, &side));
-  HIPTRY(hipEventRecord(side->fork, s));
-  HIPTRY(hipStreamWaitEvent(side->st, side->fork, 0));
+  // (the fill needs the side stream behind the LAST readers of grad_w -- the previous step's optimizer --, not behind this pass's
+  //  forward: score_forward of this step, on this stream and context, forked the side stream behind them already.  A record between
+  //  the head's forward and backward costs the launch stream a ~6-us bubble; only a caller that skipped the forward pays it.)
+  const bool forked = side->fwd_on == s;
+  side->fwd_on = nullptr;
+  if (!forked) {
+    HIPTRY(hipEventRecord(side->fork, s));
+    HIPTRY(hipStreamWaitEvent(side->st, side->fork, 0));
+  }
   hipError_t he = hipMemsetAsync(gw, 0, P.n_floats * sizeof(float), side->st);
   if (he != hipSuccess) return (int)he;
 
@@ -972,6 +980,9 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
       G(score_coattn_bwd_multi(ca, 2, d.D, B, dWs, ws + w.ca_slab, w.ca_slab_floats, atomic ? 1 : 0, &cq, s));
   }
   if (side && d.attn && st->scatter_mode != 2) HIPTRY(hipStreamWaitEvent(s, side->wx, 0));     // d query comes from the side stream
+  // (the occurrence sort's event, which the row scatter below needs: waited for HERE, next to the wait above -- every wait or record
+  //  between two launches costs the launch stream a bubble of ~6 us, two adjacent ones cost one)
+  if (!atomic && st->plan_done_event) HIPTRY(hipStreamWaitEvent(s, (hipEvent_t)st->plan_done_event, 0));
   G(score_launch_target_bwd(grad_table, d.D, d.Fu, d.Fi, B, T, bt->target_user, bt->target_item,
                             d.attn ? ws + w.dquery : nullptr, d.Dq, ws + w.dhead, d.Dhead, d.off_ti, d.off_tu,
                             ws + w.query, d.coattn ? W + P.ca_w[0] : nullptr, d.coattn ? W + P.ca_w[1] : nullptr,
@@ -980,7 +991,6 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
                             d.coattn ? gw + P.ca_b[1] : nullptr, atomic ? nullptr : ws + w.dtgt, scratch, SF, &cq, &gq,
                             s, st->n_table_rows));
   if (!atomic) {
-    if (st->plan_done_event) HIPTRY(hipStreamWaitEvent(s, (hipEvent_t)st->plan_done_event, 0));
     PullArgs pa;
     memset(&pa, 0, sizeof(pa));
     pa.D = d.D; pa.K = d.K; pa.zero_is_dummy = 1;
