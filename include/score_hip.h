@@ -368,7 +368,7 @@ typedef struct {
                            head's forward in one launch at every batch size; bit 2 = the H = 128 recurrences on the
                            f32-input MFMA kernels instead of the bf16x3 form; bit 3 = the GRU input projections (and
                            their input gradients) on the tiled bf16x3 kernel instead of the whole-N panel form
-                           (csrc/gemm_panel.hip); bit 4 = the input gradients in the panel form only from 64 K rows per side (below: the tiled kernel); bit 6 =
+                           (csrc/gemm_panel.hip); bit 4 = the input gradients in the panel form at every size; bit 6 =
                            build_fc_net layer by layer instead of the fused head kernels; bit 7 = the temporal attention
                            layer by layer instead of its fused kernels (the paths shapes outside the fused kernels'
                            instantiated widths take anyway); bit 5 = the index plan sorts with the library's radix sort at

@@ -448,19 +448,20 @@ extern "C" int score_index_plan(const score_config_t* cfg, const score_state_t* 
 
 // do the two sides' GRU input projections (which = 0) / their input gradients (which = 1) take the panel form?  Same
 // answer in the forward pass (which writes the weight images) and in the backward pass (which uses them).
-// The input gradients: wherever the panel form is allowed (late round 4; debug_flags bit 4: only from 64 K rows per side, the
-// default until then).  The kernel itself is 30 % faster (71 vs 101 us at cfg-3), but a panel workgroup owns its CU (8 waves x
-// 256 registers), and the backward pass has ~350 us of other streams' work to place -- the side stream's query branch and early
-// weight gradients, the optimizer's window slice -- which the tiled kernel lets run beside it and a one-round panel kernel pushes
-// into the co-attention backward and the scatter: in rounds 3 and early 4 that cost what the kernel saved (cfg-3 scatter stage
-// 0.254 -> 0.329 ms).  With the end-of-pass launches merged, the weight-gradient launch capped at one round of workgroups and two
-// sync points off the launch stream (profiles/r04_probes.md 16 - 22) the spill is 18 us against 42 saved: 1.2454 -> 1.2334
-// ms/step at the driver's protocol (5 alternating pairs), 1.2078 -> 1.1879 at 200 steps; the CCMR shape unchanged.
+// The input gradients: from 64 K rows per side (cfg-5), or with debug_flags bit 4.  The kernel itself is 30 % faster there
+// too (71 vs 101 us at cfg-3), but a panel workgroup owns its CU (8 waves x 256 registers), and the backward pass has
+// ~350 us of other streams' work to place -- the side stream's query branch and early weight gradients, the optimizer's
+// window slice -- which the tiled kernel lets run beside it and a one-round panel kernel pushes into the co-attention
+// backward and the scatter (cfg-3: 0.254 -> 0.329 ms), or, with the recurrences' weight gradients moved in front of those
+// (round 3's SCORE_WGRAD_EARLY), into them (1.287 -> 1.285 ms/step; projections only: 1.273; round 4: with the head's and the
+// attention's products folded into the end-of-pass launch, or the side stream joined before the co-attention backward, the
+// same: profiles/r04_probes.md).  At cfg-5's sizes the other
+// streams' work is small beside these products: 20.3 -> 19.8 ms/step with both.
 static bool panel_gemms(const Dims& d, const score_state_t* st, int BT, int which) {
   if (st->gemm_mode != 1 || (st->debug_flags & 8) || d.Is[0] != d.Is[1]) return false;
   const int ns = panel_x_splits(d.H);
   return which == 0 ? ns > 0 && score_gemm_panel_ok(2 * ns, BT, 3 * d.H / ns, d.Is[0], d.I, 3 * d.H, nullptr)
-                    : (!(st->debug_flags & 16) || (int64_t)BT >= 65536) && panel_d_splits(d.Is[0]) > 0 &&
+                    : ((st->debug_flags & 16) || (int64_t)BT >= 65536) && panel_d_splits(d.Is[0]) > 0 &&
                           score_gemm_panel_ok(2 * panel_d_splits(d.Is[0]), BT, d.Is[0] / panel_d_splits(d.Is[0]), 3 * d.H, 3 * d.H, d.I, nullptr);
 }
 

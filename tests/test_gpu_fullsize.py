@@ -127,8 +127,8 @@ def test_one_step_vs_oracle_full_size(cfg3):
 
 def test_panel_and_tiled_projections_agree_full_size(cfg3):
     # csrc/gemm_panel.hip: at this size the GRU input projections of both sides run as ONE launch of 256 whole-N panels
-    # (weights as MFMA-fragment images) and so do their input gradients; score_state_t.debug_flags bit 3 puts both back on the
-    # tiled bf16x3 kernel, bit 4 the input gradients alone (below 64 K rows per side).  Same fp32-accurate products, different summation trees:
+    # (weights as MFMA-fragment images); score_state_t.debug_flags bit 3 puts them back on the tiled bf16x3 kernel, bit 4
+    # moves their input gradients to the panel form as well.  Same fp32-accurate products, different summation trees:
     # predictions and gradients agree to fp32 rounding (the op test bounds each form against fp64).
     w, kw, B, m = cfg3
     b = w.batch(B, 5)
@@ -149,11 +149,9 @@ def test_panel_and_tiled_projections_agree_full_size(cfg3):
         assert np.abs(p1 - p0).max() < 2e-6 and abs(l1 - l0) < 1e-6
         assert float((w1 - w0).abs().max()) <= 2e-5 * float(w0.abs().max())
         assert float((g1 - g0).abs().max()) <= 2e-5 * float(g0.abs().max())
-    # the tiled form differs from the panel form somewhere (the switches did switch), the forward of flags 16 is flags 0's
+    # the tiled form differs from the panel form somewhere (the switch did switch), the forward of flags 16 is flags 0's
     assert not np.array_equal(out[8][0], p0) or not torch.equal(out[8][2], w0)
     assert np.array_equal(out[16][0], p0)
-    assert not torch.equal(out[16][3], g0) or not torch.equal(out[16][2], w0)
-    assert m.gemm_forms(B, 0)[1] == 1          # (the input gradients' panel form is what this size takes)
 
 
 def test_plan_sorts_give_the_same_bits_full_size(cfg3):
