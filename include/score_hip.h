@@ -488,7 +488,8 @@ int score_forward(const score_config_t* cfg, const score_state_t* st, const scor
 /* Backward of the same graph: grad_w [n_floats] (overwritten; WITHOUT the L2
  * term, which score_adam adds) and grad_table [n_table_rows, D] (scatter_mode 1: zeroed by
  * the caller, accumulated into; modes 0/2: the rows of the batch are overwritten, see
- * score_state_t.row_flags).  Must follow score_forward on the same workspace/batch.
+ * score_state_t.row_flags).  Must follow score_forward on the same workspace/batch (and, to reuse its fork of the context's side
+ * stream, on the same stream and context: otherwise the pass records one event more at its start).
  * stage_events: null, or SIX handles: [0] start, [1] after the head, [2] after the temporal
  * attention, [3] after the GRUs, [4] after the co-attention/embedding scatter, [5] after the
  * weight-gradient products (all X^T dY of the pass run here, as grouped launches; with score_state_t.grads_done_event the
