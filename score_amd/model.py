@@ -208,6 +208,7 @@ class SCOREBASE(object):
         # update (cfg-3: ~40 us off the launch stream); below, the step is bound by the host's launch calls and the table's and
         # the dense variables' updates stay ONE launch behind finishers on the launch stream
         self.overlap_finishers_min_rows = 8192
+        self.dense_adam_on_side = True       # (with the finishers overlap) the dense variables' ApplyAdam on the host's side stream
         self.loss_on_side = True            # the loss reduction of a training step on the engine's side stream (score_state_t.loss_done_event)
         self._early_loss = None      # set for the length of a train() call: the loss copied out right behind the forward pass
         self._early_loss_state = {"stream": None, "host": None, "event": None}
@@ -215,6 +216,8 @@ class SCOREBASE(object):
         self._fwd_stage_event = None
         self._pinned_stream = self._pinned_handle = None
         self._row_list = None
+        self._dense_pending = None      # event behind the dense variables' ApplyAdam when it ran on the side stream (apply_adam)
+        self._ev_dense = None
         self.w = torch.zeros((self.n_w,), **f32)
         self._alloc_optimizer()
         self._ws = {}              # (B, slot) -> (layout, buffer), least recently used first
@@ -363,6 +366,41 @@ class SCOREBASE(object):
     def table(self, t):
         self._flush_adam()
         self._tbl, self._tiled, self._tiled_ready = t, None, False
+
+    # the flat dense variables and their Adam slots.  Their ApplyAdam may have run on the side stream (apply_adam: behind the dense
+    # gradient's finishers, beside the table's touched-row update): whoever reads or writes them through here waits for it first
+    @property
+    def w(self):
+        self._join_dense()
+        return self._w
+
+    @w.setter
+    def w(self, t):
+        self._w = t
+
+    @property
+    def w_m(self):
+        self._join_dense()
+        return self._w_m
+
+    @w_m.setter
+    def w_m(self, t):
+        self._w_m = t
+
+    @property
+    def w_v(self):
+        self._join_dense()
+        return self._w_v
+
+    @w_v.setter
+    def w_v(self, t):
+        self._w_v = t
+
+    def _join_dense(self):
+        ev, self._dense_pending = self._dense_pending, None
+        if ev is not None:
+            self._grads_pending = None          # (the update ran behind the finishers: they are through as well)
+            self._cur().wait_event(ev)
 
     @property
     def w_g(self):
@@ -831,10 +869,21 @@ class SCOREBASE(object):
                     self._catchup_ahead(next_batch, lr)
                 if self._grads_pending is not None:
                     # the dense gradient's finishers are still running on the side stream: the table's touched rows (row
-                    # gradients only) first, the dense variables behind the finishers' event
+                    # gradients only) first, the dense variables behind the finishers' event -- on the host's side stream
+                    # (idle by now: the look-ahead catch-up was started at boundary 4), so that the launch stream goes from the
+                    # touched rows straight into the next step; whoever touches the dense variables next waits (self.w)
                     self._adam_table_tiled(lr)
-                    self._join_grads()
-                    self.adam_dense(lr, reg_lambda)
+                    side = self._side if self.dense_adam_on_side else None
+                    if side is not None:
+                        side.wait_event(self._grads_pending)
+                        self.adam_dense(lr, reg_lambda, stream=side)
+                        if self._ev_dense is None:
+                            self._ev_dense = torch.cuda.Event()
+                        self._ev_dense.record(side)
+                        self._dense_pending = self._ev_dense
+                    else:
+                        self._join_grads()
+                        self.adam_dense(lr, reg_lambda)
                 # (else the touched rows and the dense variables in one launch: nothing stands between them)
                 elif not self._adam_table_tiled(lr, dense=(reg_lambda,)):
                     self.adam_dense(lr, reg_lambda)
@@ -1036,8 +1085,15 @@ class SCOREBASE(object):
             self._flags_marked = False
         _lib.check(rc, "score_adam(table)")
 
-    def adam_dense(self, lr, reg_lambda):
-        """ApplyAdam over the flat dense variables (L2 term folded in) on the current stream."""
+    def adam_dense(self, lr, reg_lambda, stream=None):
+        """ApplyAdam over the flat dense variables (L2 term folded in) on the current stream.
+        stream (apply_adam only): a side stream the caller has ordered behind the dense gradient's finishers."""
+        if stream is not None:
+            rc = self.lib.score_adam(_ptr(self._w), _ptr(self._w_m), _ptr(self._w_v), _ptr(self._w_g), self.n_w,
+                                     self.n_reg, float(reg_lambda), self._alpha(lr), ADAM_B1, ADAM_B2, ADAM_EPS,
+                                     self._guard_dense, C.c_void_p(stream.cuda_stream))
+            _lib.check(rc, "score_adam(dense)")
+            return
         if self._use_dev_scalars:
             rc = self.lib.score_adam_dev(_ptr(self.w), _ptr(self.w_m), _ptr(self.w_v), _ptr(self.w_g), self.n_w,
                                          self.n_reg, float(reg_lambda), _ptr(self._scalars), ADAM_B1, ADAM_B2, ADAM_EPS,

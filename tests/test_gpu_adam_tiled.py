@@ -411,7 +411,7 @@ def test_side_stream_finishers_and_loss_do_not_change_a_bit():
     off, on = make(cfg, 5), make(cfg, 5)
     off.overlap_finishers_min_rows = 10 ** 9
     on.overlap_finishers_min_rows = 0
-    assert on.loss_on_side and off.loss_on_side
+    assert on.loss_on_side and off.loss_on_side and on.dense_adam_on_side    # (the dense ApplyAdam then runs on the side stream too)
     bs = batches(cfg, 16, 5, seed=21, hot_rows=150)
     d_off, d_on = [off.device_batch(b) for b in bs], [on.device_batch(b) for b in bs]
     for i in range(14):
