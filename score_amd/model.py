@@ -207,7 +207,7 @@ class SCOREBASE(object):
         # from this many (b, t) rows on, score_backward's end-of-pass finishers run on the side stream under the touched-row
         # update (cfg-3: ~40 us off the launch stream); below, the step is bound by the host's launch calls and the table's and
         # the dense variables' updates stay ONE launch behind finishers on the launch stream
-        self.overlap_finishers_min_rows = 8192
+        self.overlap_finishers_min_rows = 6144       # (the CCMR shape's 7,600 rows gain 1.7 % from it, the Tmall default's 2,200 lose 4 %)
         self.dense_adam_on_side = True       # (with the finishers overlap) the dense variables' ApplyAdam on the host's side stream
         self.loss_on_side = True            # the loss reduction of a training step on the engine's side stream (score_state_t.loss_done_event)
         self._early_loss = None      # set for the length of a train() call: the loss copied out right behind the forward pass
