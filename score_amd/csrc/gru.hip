@@ -866,7 +866,10 @@ int score_gru_bwd_multi(GruArgs& a, int nsides, hipStream_t s) {
     dim3 grid(nsides * ((a.B + RRB - 1) / RRB));
 #define LB(Hv, NWv) hipLaunchKernelGGL((gru_bwd_reg_kernel<Hv, NWv>), grid, dim3(64 * NWv), 0, s, a)
     if (H == 16) LB(16, 4);
-    else if (H == 32) LB(32, 4);
+    else if (H == 32) {     // two waves from 20 slices on: a shorter step, a longer prologue (each wave holds twice the weights) -- the CCMR
+      if (a.T >= 20) LB(32, 2);     // shape (T = 40) 0.5174 -> 0.5064 ms/step, cfg-2 (T = 10) 0.272 -> 0.278; the forward keeps four
+      else LB(32, 4);
+    }
     else if (H == 64) LB(64, 4);
     else if (a.nw8) LB(128, 8);
     else LB(128, 4);
