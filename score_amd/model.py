@@ -1158,6 +1158,8 @@ class SCOREBASE(object):
         key = (db.B, db.active_slices, float(reg_lambda), float(keep_prob), int(self.global_batch), int(self.gemm_mode),
                int(self.debug_flags))
         ent = self._graphs.get(key)
+        self._join_dense()               # (eager steps before: nothing of theirs may be pending on a side stream when a capture begins)
+        self._join_grads()
         self._use_dev_scalars = True
         try:
             self._write_step_scalars(lr)
@@ -1230,6 +1232,7 @@ class SCOREBASE(object):
         call takes them off the step count and the beta powers again.  Parameters, Adam slots, step and beta powers
         are then bit for bit what they were before the offending call.  Callers of train_async / eval_async call
         this at their own sync points."""
+        self._join_dense()        # (the dense variables' update may be on the side stream: it is what counts a suppressed step)
         bits, skipped = [int(x) for x in self._id_status.tolist()]
         if bits:
             self._id_status.zero_()

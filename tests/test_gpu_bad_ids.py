@@ -109,7 +109,7 @@ def _same(m, snap):
         now["step"] == snap["step"] and now["b1"] == snap["b1"] and now["b2"] == snap["b2"]
 
 
-@pytest.mark.parametrize("mode", ["sweep", "tiled", "graph"])
+@pytest.mark.parametrize("mode", ["sweep", "tiled", "overlap", "graph"])
 def test_no_variable_is_updated_by_a_step_that_raises(mode):
     """score.py:51-66 + :101-116: tf.nn.embedding_lookup raises inside sess.run, so train_step's assigns never run -- the
     embedding table, every dense variable, both Adam slots of each and beta1_power / beta2_power are what they were before
@@ -128,14 +128,18 @@ def test_no_variable_is_updated_by_a_step_that_raises(mode):
     bad["target_item"][7, 2] = -9
     m, twin = _model(), _model()
     for x in (m, twin):
-        if mode == "tiled":
+        if mode in ("tiled", "overlap"):
             x.adam_tiled_min_bytes = 0
+        if mode == "overlap":       # the finishers, the loss reduction and the dense ApplyAdam on the side streams (what large batches take)
+            x.overlap_finishers_min_rows = 0
         if mode == "graph":
             x.enable_graph(True)
     for i in range(5):                               # (graph: eager, eager, captured, replays)
         assert m.train(None, goods[i % 3], 1e-3, 1e-4) == twin.train(None, goods[i % 3], 1e-3, 1e-4)
-    if mode == "tiled":
+    if mode in ("tiled", "overlap"):
         assert m._tiled_on() and m._adam_dirty
+    if mode == "overlap":
+        assert m._ev_grads is not None and m._ev_dense is not None
     snap = _snapshot(m)
     with pytest.raises(ValueError) as ei:
         m.train(None, batch_tuple(bad), 1e-3, 1e-4)
@@ -148,7 +152,7 @@ def test_no_variable_is_updated_by_a_step_that_raises(mode):
     assert _same(m, _snapshot(twin))
 
 
-@pytest.mark.parametrize("mode", ["sweep", "tiled"])
+@pytest.mark.parametrize("mode", ["sweep", "tiled", "overlap"])
 def test_async_steps_queued_behind_a_bad_batch_are_not_applied_either(mode):
     """train_async: the host has queued more steps by the time anybody looks.  The word is sticky, so the device applies
     none of them and counts them; check_ids() takes exactly that many off the host's step count."""
@@ -163,8 +167,10 @@ def test_async_steps_queued_behind_a_bad_batch_are_not_applied_either(mode):
     bad["item_2hop"][0, 0, 0, 0] = 2 ** 30
     m, twin = _model(), _model()
     for x in (m, twin):
-        if mode == "tiled":
+        if mode in ("tiled", "overlap"):
             x.adam_tiled_min_bytes = 0
+        if mode == "overlap":
+            x.overlap_finishers_min_rows = 0
     for i in range(3):
         m.train_async(goods[i], 1e-3, 1e-4)
         twin.train_async(goods[i], 1e-3, 1e-4)
