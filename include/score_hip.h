@@ -133,6 +133,11 @@ typedef struct {
 } score_workspace_t;
 
 int score_workspace_layout(const score_config_t* cfg, int32_t B, score_workspace_t* out);
+/* Float offset of an INTERNAL workspace region by name ("gates", "a1", "dxproj", "dtgt", ...: csrc/engine.hip lists them) for
+ * tests and tools that compare two forms of a pass region by region; *second (optional) gets the offset of the second
+ * side / call of a paired region, -1 if the region is single.  Host-only; SCORE_E_BADARG for an unknown name.  Replaces
+ * nothing in the reference (what `sess.run([tensor])` on an intermediate would be, score.py:188-224). */
+int score_workspace_field(const score_config_t* cfg, int32_t B, const char* name, int64_t* offset, int64_t* second);
 
 /* ---- per-op entry points (each is also a stage of score_forward/backward) ---- */
 
@@ -373,8 +378,11 @@ typedef struct {
                            layer by layer instead of its fused kernels (the paths shapes outside the fused kernels'
                            instantiated widths take anyway); bit 5 = the index plan sorts with the library's radix sort at
                            every size, bit 8 = with csrc/sort.hip's at every size (default: by the number of occurrences;
-                           both are stable, the plan is the same bits).  The ONLY switches of the launch sequence: the
-                           library reads no environment variable                                                     */
+                           both are stable, the plan is the same bits); bit 9 (512) = never take the per-sample
+                           whole-model kernels (csrc/persample.h: at H = 32, B <= 512, K <= 10, <= 48 computed slices
+                           SCORE / SCORE_USER / SCORE_ITEM run each pass as ONE kernel, a workgroup per sample), bit 10
+                           (1024) = take them for the forward pass only, bit 11 (2048) = for the backward pass only.
+                           The ONLY switches of the launch sequence: the library reads no environment variable       */
   uint8_t* row_flags;   /* optional [n_table_rows] row state of the dense table optimizer (see
                            score_adam_rows): score_backward (scatter_mode 0) marks every row it
                            writes into grad_table with 2 and leaves all other rows of grad_table

@@ -300,6 +300,21 @@ def forward_literal(cfg, params, batch, keep_prob=1.0, dropout_masks=None):
 # ---------------------------------------------------------------------------
 # Oracle B: collapsed form, torch (autograd gives the gradients)
 # ---------------------------------------------------------------------------
+# Distance of the relu pre-activations of a forward pass from the kink (tests choose seeded inputs away from it: the
+# gradient of a relu network is discontinuous there, and two correct fp32 implementations whose pre-activation of ONE unit
+# differs in the last bit then differ by that unit's whole gradient).  forward() resets it and reports out["relu_margin"].
+_RELU_MARGIN = [float("inf"), None]      # [min |pre-activation| seen, [B, T] bool mask of the slices that count or None]
+
+
+def _note_relu(pre):
+    m = _RELU_MARGIN[1]
+    a = pre.detach().abs()
+    if m is not None and a.dim() >= 2 and tuple(a.shape[:2]) == tuple(m.shape):
+        a = a[m]
+    if a.numel():
+        _RELU_MARGIN[0] = min(_RELU_MARGIN[0], float(a.min()))
+
+
 def _co_attention_collapsed(seq1, seq2, tgt, W, b):
     """Exact collapsed form of score.py:147-167.
 
@@ -314,7 +329,9 @@ def _co_attention_collapsed(seq1, seq2, tgt, W, b):
     Dx = seq1.shape[3]
     wt, w1, w2 = W[:Dx, 0], W[Dx:2 * Dx, 0], W[2 * Dx:, 0]
     c = (tgt * wt).sum(-1) + b[0]                             # [B]
-    r = torch.relu((seq1 * w1).sum(-1) + (seq2 * w2).sum(-1) + c[:, None, None])  # [B,T,K]
+    z = (seq1 * w1).sum(-1) + (seq2 * w2).sum(-1) + c[:, None, None]
+    _note_relu(z)
+    r = torch.relu(z)                                         # [B,T,K]
     p = torch.softmax(r, dim=-1)
     seq1_result = (seq1 * p[..., None]).sum(2)
     seq2_result = seq2.sum(2) / K
@@ -377,6 +394,7 @@ def forward(cfg, P, batch, keep_prob=1.0, dropout_masks=None, reg_lambda=0.0, ti
     length = batch["length"].long()
     mask = torch.arange(c.T)[None, :] < length[:, None]       # [B,T] bool
     out = {"target_item": target_item, "target_user": target_user}
+    _RELU_MARGIN[0], _RELU_MARGIN[1] = float("inf"), mask     # (slices past a sample's length reach nothing)
 
     if c.model_type == "RRN":
         user_side, item_side, atten_info = user_1hop.sum(2), item_1hop.sum(2), None
@@ -414,8 +432,12 @@ def forward(cfg, P, batch, keep_prob=1.0, dropout_masks=None, reg_lambda=0.0, ti
         q = query @ P[n[0] + "/kernel"] + P[n[0] + "/bias"]
         qs = q[:, None, :].expand(-1, c.T, -1)
         ainp = torch.cat([qs, key, qs - key, qs * key], -1)
-        a1 = torch.relu(ainp @ P[n[1] + "/kernel"] + P[n[1] + "/bias"])
-        a2 = torch.relu(a1 @ P[n[2] + "/kernel"] + P[n[2] + "/bias"])
+        z1 = ainp @ P[n[1] + "/kernel"] + P[n[1] + "/bias"]
+        _note_relu(z1)
+        a1 = torch.relu(z1)
+        z2 = a1 @ P[n[2] + "/kernel"] + P[n[2] + "/bias"]
+        _note_relu(z2)
+        a2 = torch.relu(z2)
         a3 = (a2 @ P[n[3] + "/kernel"] + P[n[3] + "/bias"])[..., 0]
         s = torch.where(mask, a3, torch.full_like(a3, PAD_SCORE))
         score = torch.softmax(s, dim=-1)                      # [B,T]
@@ -431,10 +453,15 @@ def forward(cfg, P, batch, keep_prob=1.0, dropout_masks=None, reg_lambda=0.0, ti
     out["head_inp"] = inp
     inv = P["bn1/gamma"] * (1.0 / math.sqrt(1.0 + BN_EPS))
     bn1 = inp * inv + P["bn1/beta"]
-    fc1 = torch.relu(bn1 @ P["fc1/kernel"] + P["fc1/bias"])
+    _RELU_MARGIN[1] = None
+    zf1 = bn1 @ P["fc1/kernel"] + P["fc1/bias"]
+    _note_relu(zf1)
+    fc1 = torch.relu(zf1)
     if dropout_masks is not None:
         fc1 = fc1 * dropout_masks[0].to(dt) / keep_prob
-    fc2 = torch.relu(fc1 @ P["fc2/kernel"] + P["fc2/bias"])
+    zf2 = fc1 @ P["fc2/kernel"] + P["fc2/bias"]
+    _note_relu(zf2)
+    fc2 = torch.relu(zf2)
     if dropout_masks is not None:
         fc2 = fc2 * dropout_masks[1].to(dt) / keep_prob
     logit = (fc2 @ P["fc3/kernel"] + P["fc3/bias"]).reshape(-1)
@@ -444,7 +471,7 @@ def forward(cfg, P, batch, keep_prob=1.0, dropout_masks=None, reg_lambda=0.0, ti
                 - (1 - lab) * torch.log(1 - y + LOGLOSS_EPS)).mean()
     l2 = sum((P[name] ** 2).sum() * 0.5 for name, _, _, reg in param_spec(c) if reg)
     out.update(logit=logit, y_pred=y, log_loss=log_loss, l2=l2,
-               loss=log_loss + reg_lambda * l2)
+               loss=log_loss + reg_lambda * l2, relu_margin=_RELU_MARGIN[0])
     return out
 
 

@@ -87,6 +87,7 @@ _SIGS = {
     "score_param_layout": [C.POINTER(Config), C.POINTER(ParamEntry), C.c_int32, C.POINTER(C.c_int64),
                            C.POINTER(C.c_int64)],
     "score_workspace_layout": [C.POINTER(Config), C.c_int32, C.POINTER(Workspace)],
+    "score_workspace_field": [C.POINTER(Config), C.c_int32, C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
     "score_gather_fwd": [c_f, C.c_int64, C.c_int32, c_i, C.c_int64, c_f, C.c_void_p],
     "score_coattn_fwd": [c_f, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_i, c_i,
                          c_f, c_f, c_f, c_f, C.c_int32, c_f, C.c_int32, c_f, C.c_int32, c_f, C.c_int32,
@@ -204,6 +205,14 @@ def workspace_layout(cfg, B):
     ws = Workspace()
     check(lib.score_workspace_layout(C.byref(cfg), int(B), C.byref(ws)), "score_workspace_layout")
     return ws
+
+
+def workspace_field(cfg, B, name):
+    """(offset, offset of the second side / call or -1) of an internal workspace region, in floats"""
+    lib = load()
+    a, b = C.c_int64(0), C.c_int64(-1)
+    check(lib.score_workspace_field(C.byref(cfg), int(B), name.encode(), C.byref(a), C.byref(b)), "score_workspace_field")
+    return a.value, b.value
 
 
 _listpack = None

@@ -9,6 +9,7 @@
 #include <new>
 #include "common.h"
 #include "kernels.h"
+#include "persample.h"
 
 namespace {
 
@@ -146,6 +147,7 @@ struct WS {
   int64_t uid, unique_rows, meta, remap[6];
   int64_t ca_slab, ca_slab_floats, cs_part, cs_part_floats, wxcat;
   int64_t pimg_x[2], pimg_d[2];      // weight fragment images of the panel GEMMs (gemm_panel.hip): projection, input gradient
+  int64_t psimg;                     // weight images of the per-sample whole-model kernels (persample.h)
   int64_t scratch_floats, total;
 };
 
@@ -154,6 +156,17 @@ struct WS {
 static int panel_x_splits(int H) { return 3 * H <= 512 ? 1 : ((3 * H) % 32 == 0 && 3 * H <= 1024 ? 2 : 0); }
 // ... and the input gradients' I output columns likewise (cfg-5, Tmall-shaped: 896)
 static int panel_d_splits(int I) { return I <= 512 ? 1 : (I % 32 == 0 && I <= 1024 ? 2 : 0); }
+
+// the per-sample whole-model kernels (persample.h: SCORE / SCORE_USER / SCORE_ITEM at H = 32) read their weights as images
+static int64_t ps_image_region_floats(const Dims& d) {
+  if (d.H != 32 || !d.coattn || !d.attn) return 0;
+  PsShape s;
+  memset(&s, 0, sizeof(s));
+  s.H = d.H; s.I = d.I; s.Dk = d.Dk; s.Dhead = d.Dhead;
+  PsImages im;
+  ps_plan_images(s, &im);
+  return im.total;
+}
 
 void build_ws(const Dims& d, int B, WS* w) {
   int64_t cur = 0;
@@ -208,6 +221,7 @@ void build_ws(const Dims& d, int B, WS* w) {
     const int nd = panel_d_splits(d.Is[sd]);
     w->pimg_d[sd] = take(nd ? nd * score_gemm_panel_image_floats(d.Is[sd] / nd, 3 * d.H) : 0);
   }
+  w->psimg = take(ps_image_region_floats(d));
   w->dgstage = take((int64_t)B * d.Dhead);
   w->scratch2 = take(w->scratch_floats);           // split-K scratch of the side stream's products
   // scratch of the recurrences without a register-resident kernel: MFMA-fragment weight copies (H = 256) or the
@@ -391,6 +405,35 @@ extern "C" int score_workspace_layout(const score_config_t* cfg, int32_t B, scor
   return 0;
 }
 
+// float offset of an internal workspace region by name (tests / tools compare the forms of a pass region by region);
+// per-side / per-call regions: the first one (the second follows at the same distance as in score_workspace_t's pairs)
+extern "C" int score_workspace_field(const score_config_t* cfg, int32_t B, const char* name, int64_t* offset, int64_t* second) {
+  Dims d;
+  SCORE_TRY(make_dims(cfg, &d));
+  if (B <= 0 || !name || !offset) return SCORE_E_BADARG;
+  WS w;
+  build_ws(d, B, &w);
+  struct { const char* n; int64_t a, b; } tab[] = {
+      {"xside", w.xside[0], w.xside[1]}, {"info", w.info, -1}, {"rsave", w.rsave[0], w.rsave[1]}, {"query", w.query, -1},
+      {"head_inp", w.head_inp, -1}, {"att_score", w.att_score, -1}, {"logit", w.logit, -1}, {"y_pred", w.y_pred, -1},
+      {"gru_out", w.gru_out[0], w.gru_out[1]}, {"gru_final", w.gru_final[0], w.gru_final[1]}, {"xproj", w.xproj[0], w.xproj[1]},
+      {"gates", w.gates[0], w.gates[1]}, {"q", w.q, -1}, {"ainp", w.ainp, -1}, {"a1", w.a1, -1}, {"a2", w.a2, -1},
+      {"bn", w.bn, -1}, {"f1", w.f1, -1}, {"f2", w.f2, -1}, {"lossb", w.lossb, -1}, {"dlogit", w.dlogit, -1},
+      {"dz2", w.dz2, -1}, {"dz1", w.dz1, -1}, {"dbn", w.dbn, -1}, {"dhead", w.dhead, -1}, {"dgstage", w.dgstage, -1},
+      {"ds", w.ds, -1}, {"da2", w.da2, -1}, {"da1", w.da1, -1}, {"adzsum", w.adzsum, -1}, {"dq", w.dq, -1},
+      {"dquery", w.dquery, -1}, {"dgru", w.dgru[0], w.dgru[1]}, {"dinfo", w.dinfo, -1}, {"dxproj", w.dxproj[0], w.dxproj[1]},
+      {"rh", w.rh[0], w.rh[1]}, {"hprev", w.hprev[0], w.hprev[1]}, {"dxside", w.dxside[0], w.dxside[1]},
+      {"dzsum", w.dzsum[0], w.dzsum[1]}, {"pcoef", w.pcoef[0], w.pcoef[1]}, {"dzcoef", w.dzcoef[0], w.dzcoef[1]},
+      {"dtgt", w.dtgt, -1}, {"S", w.S, -1}, {"ca_slab", w.ca_slab, -1}, {"psimg", w.psimg, -1}};
+  for (auto& e : tab)
+    if (strcmp(e.n, name) == 0) {
+      *offset = e.a;
+      if (second) *second = e.b;
+      return 0;
+    }
+  return SCORE_E_BADARG;
+}
+
 extern "C" int score_index_plan(const score_config_t* cfg, const score_state_t* st, const score_batch_t* bt,
                                 int32_t n_shards, int32_t dedup, void* stream) {
   Dims d;
@@ -478,6 +521,234 @@ extern "C" int score_gemm_forms(const score_config_t* cfg, const score_state_t* 
   return 0;
 }
 
+// ---------------------------------------------------------------- per-sample whole-model path (persample.h)
+// The reference's own shapes (train_score.py:15-16, 285-372: D = 16, H = 32, B = 100 / 200) are bound by launch latency,
+// not by bytes or flops: score_forward / score_backward then run ONE kernel each (a workgroup per sample) plus the
+// weight-gradient products and the row scatter.  debug_flags bit 9 (512): never; bit 10 (1024): the forward pass only;
+// bit 11 (2048): the backward pass only (A/B and parity tests compare the forms).
+namespace {
+struct PsPlan { PsShape s; PsImages im; };
+
+bool ps_path(const Dims& d, const score_state_t* st, const score_batch_t* bt, int TA, PsPlan* pp) {
+  if ((st->debug_flags & 512) || st->scatter_mode == 1) return false;
+  if (!d.coattn || !d.attn) return false;                     // SCORE, SCORE_USER, SCORE_ITEM
+  const int Bg = st->global_batch > 0 ? st->global_batch : bt->B;
+  if (ps_plan_shape(bt->B, TA, d.T, d.K, d.D, d.Fu, d.Fi, d.H, d.NI, d.Dk, d.Dhead, d.off_u, d.off_i, d.off_ti, d.off_tu, Bg,
+                    &pp->s) != 0)
+    return false;
+  ps_plan_images(pp->s, &pp->im);
+  return true;
+}
+
+// the step's weight images, the L2 partial sums and (optionally) a cleared dense-gradient buffer: one launch
+int ps_prep(const Dims& d, const Params& P, const WS& w, const PsPlan& pp, const score_state_t* st, float* zero, int64_t zero_floats,
+            hipStream_t s) {
+  const float* W = st->w;
+  float* img = st->workspace + w.psimg;
+  const int H = d.H, I = d.I, Dk = d.Dk, Dh = d.Dhead;
+  PsPrepArgs pa;
+  memset(&pa, 0, sizeof(pa));
+  int n = 0;
+  auto job = [&](const float* Wp, const float* W2, int64_t off, int K, int N, int ld, int kind, int trans, int aux) {
+    PsImgJob& j = pa.job[n++];
+    j.W = Wp; j.W2 = W2; j.img = img + off; j.K = K; j.N = N; j.ld = ld; j.kind = kind; j.trans = trans; j.aux = aux;
+  };
+  for (int sd = 0; sd < 2; ++sd) job(W + P.gk[sd], W + P.ck[sd], pp.im.wx[sd], I, 3 * H, 0, PS_SRC_WXCAT, 0, H);
+  job(W + P.at_w[0], nullptr, pp.im.q2, I, Dk, Dk, PS_SRC_PLAIN, 0, 0);
+  job(W + P.at_w[1], nullptr, pp.im.wq, Dk, AT1, AT1, PS_SRC_WQ, 0, Dk);
+  job(W + P.at_w[1], nullptr, pp.im.weff, 2 * Dk, AT1, AT1, PS_SRC_WEFF, 0, Dk);
+  job(W + P.at_w[2], nullptr, pp.im.w4, AT1, AT2, AT2, PS_SRC_PLAIN, 0, 0);
+  job(W + P.fc_w[0], nullptr, pp.im.fc1, Dh, FC1, FC1, PS_SRC_PLAIN, 0, 0);
+  job(W + P.fc_w[1], nullptr, pp.im.fc2, FC1, FC2, FC2, PS_SRC_PLAIN, 0, 0);
+  job(W + P.fc_w[1], nullptr, pp.im.fc2t, FC2, FC1, FC2, PS_SRC_PLAIN, 1, 0);
+  job(W + P.fc_w[0], nullptr, pp.im.fc1t, FC1, Dh, FC1, PS_SRC_PLAIN, 1, 0);
+  job(W + P.at_w[2], nullptr, pp.im.w4t, AT2, AT1, AT2, PS_SRC_PLAIN, 1, 0);
+  job(W + P.at_w[1], nullptr, pp.im.wefft, AT1, 2 * Dk, AT1, PS_SRC_WEFF, 1, Dk);
+  job(W + P.at_w[1], nullptr, pp.im.wqt, AT1, Dk, AT1, PS_SRC_WQ, 1, Dk);
+  job(W + P.at_w[0], nullptr, pp.im.q2t, Dk, I, Dk, PS_SRC_PLAIN, 1, 0);
+  for (int sd = 0; sd < 2; ++sd) job(W + P.gk[sd], W + P.ck[sd], pp.im.wxt[sd], 3 * H, I, 0, PS_SRC_WXCAT, 1, H);
+  pa.njobs = n;
+  pa.wreg = W; pa.n_reg = P.n_reg; pa.part = st->workspace + w.part;
+  pa.zero = zero; pa.zero_floats = zero_floats;
+  return score_launch_ps_prep(pa, s);
+}
+
+int forward_ps(const Dims& d, const Params& P, const WS& w, const PsPlan& pp, const score_state_t* st, const score_batch_t* bt,
+               float reg_lambda, float keep_prob, const uint8_t* mask0, const uint8_t* mask1, uint64_t seed,
+               void* const* stage_events, hipStream_t s) {
+  float* ws = st->workspace;
+  const int B = bt->B;
+  G(ps_prep(d, P, w, pp, st, nullptr, 0, s));
+  if (st->debug_flags & 1024) {      // (the layer-by-layer backward pass that follows reads the concatenated / folded copies)
+    const float* W = st->w;
+    const int64_t weff_stride = align_up64(2 * (int64_t)d.Dk * AT1 + 48, 4);
+    G(score_launch_weight_prep(W + P.gk[0], W + P.ck[0], W + P.gb[0], W + P.cb[0], W + P.gk[1], W + P.ck[1], W + P.gb[1],
+                               W + P.cb[1], d.Is[0], d.Is[1], d.I, d.H, ws + w.wxcat, d.Dk, AT1, W + P.at_w[1], ws + w.weff,
+                               ws + w.wq, SCORE_WEFF_COPIES, weff_stride, W, P.n_reg, ws + w.part, s));
+  }
+  EV(0);
+  PsFwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.s = pp.s; a.im = pp.im; a.img = ws + w.psimg;
+  a.idx1[0] = bt->user_1hop; a.idx2[0] = bt->item_2hop; a.idx1[1] = bt->user_2hop; a.idx2[1] = bt->item_1hop;
+  a.tu = bt->target_user; a.ti = bt->target_item; a.label = bt->label; a.length = bt->length;
+  a.table = st->table; a.n_rows = (uint32_t)(st->n_table_rows < 0x80000000ll ? st->n_table_rows : 0x80000000ll);
+  a.id_status = st->id_status; a.W = st->w;
+  for (int c = 0; c < 2; ++c) {
+    a.ca_w[c] = P.ca_w[c]; a.ca_b[c] = P.ca_b[c]; a.gk[c] = P.gk[c]; a.gb[c] = P.gb[c]; a.ck[c] = P.ck[c]; a.cb[c] = P.cb[c];
+    a.xside[c] = ws + w.xside[c]; a.rsave[c] = ws + w.rsave[c]; a.gates[c] = ws + w.gates[c]; a.gru_out[c] = ws + w.gru_out[c];
+    a.gru_final[c] = ws + w.gru_final[c];
+  }
+  for (int i = 0; i < 4; ++i) a.at_b[i] = P.at_b[i];
+  a.at_w5 = P.at_w[3]; a.bn_g = P.bn_g; a.bn_b = P.bn_b;
+  for (int i = 0; i < 3; ++i) a.fc_b[i] = P.fc_b[i];
+  a.fc_w3 = P.fc_w[2];
+  a.query = ws + w.query; a.head_inp = ws + w.head_inp; a.info = ws + w.info; a.q = ws + w.q; a.ainp = ws + w.ainp;
+  a.a1 = ws + w.a1; a.a2 = ws + w.a2; a.att_score = ws + w.att_score; a.bn = ws + w.bn; a.f1 = ws + w.f1; a.f2 = ws + w.f2;
+  a.logit = ws + w.logit; a.y = ws + w.y_pred; a.lossb = ws + w.lossb; a.dlogit = ws + w.dlogit; a.dz2 = ws + w.dz2;
+  a.keep = keep_prob; a.rs = (float)(1.0 / sqrt(1.0 + 1e-3)); a.drop = keep_prob < 1.f ? 1 : 0;
+  a.mask0 = mask0; a.mask1 = mask1; a.seed0 = seed; a.seed1 = seed ^ 0x5DEECE66Dull;
+  a.seed_dev = st->step_scalars ? &st->step_scalars->drop_seed : nullptr;
+  G(score_launch_ps_fwd(a, s));
+  if (st->gather_done_event) HIPTRY(hipEventRecord((hipEvent_t)st->gather_done_event, s));
+  EV(1); EV(2); EV(3);
+  const int Bg = st->global_batch > 0 ? st->global_batch : B;
+  hipStream_t ls = s;
+  SideStream* sd = nullptr;
+  if (st->loss_done_event) {
+    G(side_stream(st, &sd));
+    HIPTRY(hipEventRecord(sd->fork, s));
+    HIPTRY(hipStreamWaitEvent(sd->st, sd->fork, 0));
+    ls = sd->st;
+  }
+  G(score_launch_loss_final(B, ws + w.lossb, ws + w.loss, reg_lambda, ws + w.part, Bg, ls, st->id_status));
+  if (st->loss_done_event) HIPTRY(hipEventRecord((hipEvent_t)st->loss_done_event, ls));
+  EV(4);
+  return 0;
+}
+
+int backward_ps(const Dims& d, const Params& P, const WS& w, const PsPlan& pp, const score_state_t* st, const score_batch_t* bt,
+                float keep_prob, float* gw, float* grad_table, void* const* stage_events, hipStream_t s) {
+  float* ws = st->workspace;
+  const float* W = st->w;
+  const int B = bt->B, T = pp.s.A, H = d.H, BT = B * T;
+  const int x3 = st->gemm_mode == 1 ? GF_X3 : 0;
+  SideStream* side = nullptr;
+  G(side_stream(st, &side));
+  side->fwd_on = nullptr;
+  if (st->debug_flags & 2048) {      // (after a layer-by-layer forward pass: the images are not there yet; clears gw too)
+    G(ps_prep(d, P, w, pp, st, gw, P.n_floats, s));
+  } else {
+    HIPTRY(hipMemsetAsync(gw, 0, P.n_floats * sizeof(float), s));
+  }
+  EV(0);
+  PsBwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.s = pp.s; a.im = pp.im; a.img = ws + w.psimg;
+  a.idx1[0] = bt->user_1hop; a.idx2[0] = bt->item_2hop; a.idx1[1] = bt->user_2hop; a.idx2[1] = bt->item_1hop;
+  a.length = bt->length; a.table = st->table;
+  a.n_rows = (uint32_t)(st->n_table_rows < 0x80000000ll ? st->n_table_rows : 0x80000000ll);
+  a.W = W;
+  for (int c = 0; c < 2; ++c) {
+    a.ca_w[c] = P.ca_w[c]; a.gk[c] = P.gk[c]; a.ck[c] = P.ck[c];
+    a.rsave[c] = ws + w.rsave[c]; a.gates[c] = ws + w.gates[c]; a.gru_out[c] = ws + w.gru_out[c];
+    a.dxproj[c] = ws + w.dxproj[c]; a.rh[c] = ws + w.rh[c]; a.hprev[c] = ws + w.hprev[c]; a.dxside[c] = ws + w.dxside[c];
+    a.pcoef[c] = ws + w.pcoef[c]; a.dzcoef[c] = ws + w.dzcoef[c];
+  }
+  a.at_w5 = P.at_w[3]; a.bn_g = P.bn_g;
+  a.query = ws + w.query; a.head_inp = ws + w.head_inp; a.info = ws + w.info; a.q = ws + w.q; a.ainp = ws + w.ainp;
+  a.a1 = ws + w.a1; a.a2 = ws + w.a2; a.att_score = ws + w.att_score; a.f1 = ws + w.f1; a.dz2 = ws + w.dz2;
+  a.dz1 = ws + w.dz1; a.dbn = ws + w.dbn; a.dgstage = ws + w.dgstage; a.ds = ws + w.ds; a.da2 = ws + w.da2; a.da1 = ws + w.da1;
+  a.adzsum = ws + w.adzsum; a.dq = ws + w.dq; a.dtgt = ws + w.dtgt; a.S = ws + w.S;
+  a.caslab[0] = ws + w.ca_slab; a.caslab[1] = ws + w.ca_slab + (int64_t)B * 2 * d.Di;
+  a.keep = keep_prob; a.rs = (float)(1.0 / sqrt(1.0 + 1e-3));
+  if ((int64_t)B * 2 * (d.Di + d.Du) > w.ca_slab_floats) return SCORE_E_WORKSPACE;
+  G(score_launch_ps_bwd(a, s));
+  EV(1); EV(2); EV(3);
+
+  // every weight gradient X^T dY and column sum of the pass, from what the kernel left in the workspace
+  ColsumJobs cq;
+  cq.n = 0; cq.part_used = 0;
+  GemmQueue gq;
+  gq.n = 0;
+  G(gemm_queue_add(&gq, FC2, 1, B, ws + w.f2, FC2, ws + w.dlogit, 1, gw + P.fc_w[2], 1));
+  G(colsum_queue_add(&cq, ws + w.dlogit, B, 1, 1, gw + P.fc_b[2], 0));
+  G(gemm_queue_add(&gq, FC1, FC2, B, ws + w.f1, FC1, ws + w.dz2, FC2, gw + P.fc_w[1], FC2));
+  G(colsum_queue_add(&cq, ws + w.dz2, B, FC2, FC2, gw + P.fc_b[1], 0));
+  G(gemm_queue_add(&gq, d.Dhead, FC1, B, ws + w.bn, d.Dhead, ws + w.dz1, FC1, gw + P.fc_w[0], FC1));
+  G(colsum_queue_add(&cq, ws + w.dz1, B, FC1, FC1, gw + P.fc_b[0], 0));
+  G(colsum_queue_add(&cq, ws + w.dgstage, B, d.Dhead, d.Dhead, gw + P.bn_g, 0));
+  G(colsum_queue_add(&cq, ws + w.dbn, B, d.Dhead, d.Dhead, gw + P.bn_b, 0));
+  G(gemm_queue_add(&gq, AT2, 1, BT, ws + w.a2, AT2, ws + w.ds, 1, gw + P.at_w[3], 1));
+  G(colsum_queue_add(&cq, ws + w.ds, BT, 1, 1, gw + P.at_b[3], 0));
+  G(gemm_queue_add(&gq, AT1, AT2, BT, ws + w.a1, AT1, ws + w.da2, AT2, gw + P.at_w[2], AT2));
+  G(colsum_queue_add(&cq, ws + w.da2, BT, AT2, AT2, gw + P.at_b[2], 0));
+  G(gemm_queue_add(&gq, 2 * d.Dk, AT1, BT, ws + w.ainp, 2 * d.Dk, ws + w.da1, AT1, ws + w.dweff, AT1));
+  G(colsum_queue_add(&cq, ws + w.da1, BT, AT1, AT1, gw + P.at_b[1], 0));
+  G(gemm_queue_add(&gq, d.Dk, AT1, B, ws + w.q, d.Dk, ws + w.adzsum, AT1, ws + w.dwq, AT1));
+  G(gemm_queue_add(&gq, d.Dq, d.Dk, B, ws + w.query, d.Dq, ws + w.dq, d.Dk, gw + P.at_w[0], d.Dk));
+  G(colsum_queue_add(&cq, ws + w.dq, B, d.Dk, d.Dk, gw + P.at_b[0], 0));
+  for (int sd = 0; sd < 2; ++sd) {
+    float* dxp = ws + w.dxproj[sd];
+    G(gemm_queue_add(&gq, d.I, 2 * H, BT, ws + w.xside[sd], d.I, dxp, 3 * H, gw + P.gk[sd], 2 * H));
+    G(gemm_queue_add(&gq, d.I, H, BT, ws + w.xside[sd], d.I, dxp + 2 * H, 3 * H, gw + P.ck[sd], H));
+    G(gemm_queue_add(&gq, H, 2 * H, BT, ws + w.hprev[sd], H, dxp, 3 * H, gw + P.gk[sd] + (int64_t)d.I * 2 * H, 2 * H));
+    G(gemm_queue_add(&gq, H, H, BT, ws + w.rh[sd], H, dxp + 2 * H, 3 * H, gw + P.ck[sd] + (int64_t)d.I * H, H));
+    G(colsum_queue_add(&cq, dxp, BT, 2 * H, 3 * H, gw + P.gb[sd], 0));
+    G(colsum_queue_add(&cq, dxp + 2 * H, BT, H, 3 * H, gw + P.cb[sd], 0));
+  }
+  // the co-attention denses: [w_t | w_1 | w_2] -- w_t from the target rows weighted by S, w_1 | w_2 from the per-sample slabs
+  G(colsum_queue_add(&cq, a.caslab[0], B, 2 * d.Di, 2 * d.Di, gw + P.ca_w[0] + d.Di, 1));
+  G(colsum_queue_add(&cq, a.caslab[1], B, 2 * d.Du, 2 * d.Du, gw + P.ca_w[1] + d.Du, 1));
+  G(colsum_queue_add(&cq, ws + w.query + d.Du, B, d.Di, d.Dq, gw + P.ca_w[0], 0, ws + w.S));
+  G(colsum_queue_add(&cq, ws + w.query, B, d.Du, d.Dq, gw + P.ca_w[1], 0, ws + w.S + B));
+  G(colsum_queue_add(&cq, ws + w.S, B, 1, 1, gw + P.ca_b[0], 0));
+  G(colsum_queue_add(&cq, ws + w.S + B, B, 1, 1, gw + P.ca_b[1], 0));
+
+  // ---- embedding rows (score.py:51-66): the sorted pull-form scatter
+  if (st->plan_done_event) HIPTRY(hipStreamWaitEvent(s, (hipEvent_t)st->plan_done_event, 0));
+  {
+    PullArgs pa;
+    memset(&pa, 0, sizeof(pa));
+    pa.D = d.D; pa.K = d.K; pa.zero_is_dummy = 1;
+    pa.flags = st->scatter_mode == 0 ? st->row_flags : nullptr;
+    pa.uid = st->scatter_mode == 2 ? reinterpret_cast<const uint32_t*>(ws + w.uid) : nullptr;
+    const float invK = 1.0f / (float)d.K;
+    const float* Gm[6] = {ws + w.dxside[0], ws + w.dxside[1], ws + w.dxside[0], ws + w.dxside[1], ws + w.dtgt, ws + w.dtgt};
+    const int ldg[6] = {d.I, d.I, d.I, d.I, d.Dq, d.Dq};
+    const int gcol[6] = {0, d.Du, d.Di, 0, 0, d.Du};
+    for (int g = 0; g < 6; ++g) { pa.G[g] = Gm[g]; pa.ldg[g] = ldg[g]; pa.gcol[g] = gcol[g]; pa.constA[g] = 1.0f; }
+    pa.cA[0] = ws + w.pcoef[0]; pa.cA[2] = ws + w.pcoef[1];
+    pa.constA[1] = invK; pa.constA[3] = invK;
+    pa.cB[0] = pa.cB[1] = ws + w.dzcoef[0]; pa.cB[2] = pa.cB[3] = ws + w.dzcoef[1];
+    pa.Wv[0] = W + P.ca_w[0] + d.Di; pa.Wv[1] = W + P.ca_w[0] + 2 * d.Di;
+    pa.Wv[2] = W + P.ca_w[1] + d.Du; pa.Wv[3] = W + P.ca_w[1] + 2 * d.Du;
+    const int64_t n_occ = (int64_t)B * (2 * (int64_t)T * d.K * (d.Fu + d.Fi) + d.Fu + d.Fi);
+    G(score_launch_pull(pa, reinterpret_cast<uint32_t*>(ws + w.keys_out), reinterpret_cast<uint32_t*>(ws + w.vals_out), n_occ + 1,
+                        grad_table, ws + w.partials, w.partial_floats, s));
+  }
+  EV(4);
+  // ---- the weight-gradient products in one grouped flush, then the finishers
+  const bool fin_side = st->grads_done_event != nullptr;
+  hipStream_t fs = fin_side ? side->st : s;
+  ReduceGroup rg;
+  G(gemm_queue_flush(&gq, x3 != 0, ws + w.dwslab, w.dwslab_floats, s, &rg));
+  EV(5);
+  if (fin_side) {
+    HIPTRY(hipEventRecord(side->fork, s));
+    HIPTRY(hipStreamWaitEvent(fs, side->fork, 0));
+  }
+  G(score_launch_finish(&rg, &cq, ws + w.cs_part, w.cs_part_floats, fs));
+  G(score_launch_attn_w1_grad(d.Dk, AT1, ws + w.dweff, ws + w.dwq, gw + P.at_w[1], fs));
+  if (fin_side) HIPTRY(hipEventRecord((hipEvent_t)st->grads_done_event, fs));
+  if (!fin_side && st->loss_done_event) {     // (the forward pass put its loss reduction on the side stream: final on `stream` behind this pass)
+    HIPTRY(hipEventRecord(side->join, side->st));
+    HIPTRY(hipStreamWaitEvent(s, side->join, 0));
+  }
+  return 0;
+}
+}  // namespace
+
 extern "C" int score_forward(const score_config_t* cfg, const score_state_t* st, const score_batch_t* bt,
                              float reg_lambda, float keep_prob, const uint8_t* drop_mask0,
                              const uint8_t* drop_mask1, uint64_t drop_seed, void* const* stage_events,
@@ -496,6 +767,11 @@ extern "C" int score_forward(const score_config_t* cfg, const score_state_t* st,
   build_ws(d, B, &w);
   if (w.total * 4 > st->workspace_bytes) return SCORE_E_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
+  {
+    PsPlan pp;       // the reference's own shapes: the whole pass as one kernel per sample (persample.h)
+    if (!(st->debug_flags & 2048) && ps_path(d, st, bt, T, &pp))
+      return forward_ps(d, P, w, pp, st, bt, reg_lambda, keep_prob, drop_mask0, drop_mask1, drop_seed, stage_events, s);
+  }
   float* ws = st->workspace;
   const float* W = st->w;
   float* scratch = ws + w.scratch;
@@ -716,6 +992,11 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
   build_ws(d, B, &w);
   if (w.total * 4 > st->workspace_bytes) return SCORE_E_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
+  {
+    PsPlan pp;
+    if (!(st->debug_flags & 1024) && ps_path(d, st, bt, T, &pp))
+      return backward_ps(d, P, w, pp, st, bt, keep_prob, gw, grad_table, stage_events, s);
+  }
   float* ws = st->workspace;
   const float* W = st->w;
   float* scratch = ws + w.scratch;

@@ -192,6 +192,7 @@ def test_fused_attention_and_head_widths_vs_oracle(H, K, B, T):
     P = so.init_params(cfg, 4)
     b = random_batch(rng, cfg, B)
     m = make_model(cfg, P)
+    m.debug_flags = 512          # (H = 32, B <= 512 would take the per-sample kernels instead: tests/test_gpu_persample.py)
     om = so.OracleModel(cfg.N, cfg.D, cfg.H, cfg.T, cfg.K, cfg.Fu, cfg.Fi, "SCORE", params={k: v.copy() for k, v in P.items()})
     m.forward_backward(batch_tuple(b), 0.0, 1.0)
     g = m.get_grads()
@@ -255,6 +256,7 @@ def test_fused_and_layerwise_paths_agree():
     P = so.init_params(cfg, 3)
     b = random_batch(rng, cfg, 80)
     m = make_model(cfg, P)
+    m.debug_flags = 512          # (both runs on the layer-by-layer pass: the per-sample kernels have neither switch)
     lay, ws = m.forward_backward(batch_tuple(b), 1e-4, 1.0)
     torch.cuda.synchronize()
     y0 = ws[lay.y_pred:lay.y_pred + 80].clone()
@@ -263,7 +265,7 @@ def test_fused_and_layerwise_paths_agree():
     # score_state_t.debug_flags bits 6 / 7: the head / the temporal attention layer by layer (rounds 1 - 3 switched these
     # through the environment, which the library reads ONCE per process: set after the first call it compared the fused
     # path with itself)
-    m.debug_flags = 64 | 128
+    m.debug_flags = 512 | 64 | 128
     lay, ws = m.forward_backward(batch_tuple(b), 1e-4, 1.0)
     torch.cuda.synchronize()
     y1 = ws[lay.y_pred:lay.y_pred + 80].clone()
