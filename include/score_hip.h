@@ -438,6 +438,11 @@ int score_id_status(int32_t* id_status, int32_t* bits, int32_t clear, void* stre
 int score_gemm_forms(const score_config_t* cfg, const score_state_t* st, int32_t B, int32_t active_slices,
                      int32_t* x_form, int32_t* dx_form);
 
+/* 1 if score_forward / score_backward run a batch of B samples with `active_slices` computed time slices (0 = all T) as the
+ * per-sample whole-model kernels (csrc/persample.h) under st->scatter_mode / st->debug_flags, 0 if layer by layer.  Host-only:
+ * callers use it to place their own side-stream work (score_amd/model.py), tests to assert the form they compare. */
+int score_persample_form(const score_config_t* cfg, const score_state_t* st, int32_t B, int32_t active_slices);
+
 /* Index plan of a batch (depends on the indices only; run it before score_backward, on
  * any stream ordered before it).  Radix-sorts all R*B row uses by (owner shard, row).
  * n_shards > 1 (table row-sharded, owner = row % n_shards) or dedup != 0 additionally

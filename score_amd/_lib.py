@@ -134,6 +134,7 @@ _SIGS = {
     "score_auc_logloss": [c_f, c_i, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p],
     "score_auc_scratch_bytes": [C.c_int64],
     "score_ranking_quality": [c_f, c_i, C.c_int64, C.c_int32, c_f, c_i, c_f, C.c_int64, C.c_void_p],
+    "score_persample_form": [C.POINTER(Config), C.POINTER(State), C.c_int32, C.c_int32],
     "score_gemm_forms": [C.POINTER(Config), C.POINTER(State), C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)],
     "score_forward": [C.POINTER(Config), C.POINTER(State), C.POINTER(Batch), C.c_float, C.c_float, C.c_void_p,
                       C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p), C.c_void_p],

@@ -636,10 +636,19 @@ int backward_ps(const Dims& d, const Params& P, const WS& w, const PsPlan& pp, c
   SideStream* side = nullptr;
   G(side_stream(st, &side));
   side->fwd_on = nullptr;
+  // With score_state_t.grads_done_event everything that FINISHES grad_w -- the weight-gradient products, the column sums, the
+  // slab reduce -- runs on the context's side stream behind the backward kernel, beside the row scatter on `stream`: at these
+  // shapes every dependent launch costs the chain ~5 us whatever it computes, so the chain holds the scatter only
+  const bool fin_side = st->grads_done_event != nullptr;
+  hipStream_t fs = fin_side ? side->st : s;
   if (st->debug_flags & 2048) {      // (after a layer-by-layer forward pass: the images are not there yet; clears gw too)
     G(ps_prep(d, P, w, pp, st, gw, P.n_floats, s));
   } else {
-    HIPTRY(hipMemsetAsync(gw, 0, P.n_floats * sizeof(float), s));
+    if (fin_side) {                  // (behind the previous readers of grad_w: they precede this pass on `stream`)
+      HIPTRY(hipEventRecord(side->fork, s));
+      HIPTRY(hipStreamWaitEvent(fs, side->fork, 0));
+    }
+    HIPTRY(hipMemsetAsync(gw, 0, P.n_floats * sizeof(float), fs));
   }
   EV(0);
   PsBwdArgs a;
@@ -664,6 +673,10 @@ int backward_ps(const Dims& d, const Params& P, const WS& w, const PsPlan& pp, c
   a.keep = keep_prob; a.rs = (float)(1.0 / sqrt(1.0 + 1e-3));
   if ((int64_t)B * 2 * (d.Di + d.Du) > w.ca_slab_floats) return SCORE_E_WORKSPACE;
   G(score_launch_ps_bwd(a, s));
+  if (fin_side) {
+    HIPTRY(hipEventRecord(side->wx, s));
+    HIPTRY(hipStreamWaitEvent(fs, side->wx, 0));
+  }
   EV(1); EV(2); EV(3);
 
   // every weight gradient X^T dY and column sum of the pass, from what the kernel left in the workspace
@@ -705,6 +718,14 @@ int backward_ps(const Dims& d, const Params& P, const WS& w, const PsPlan& pp, c
   G(colsum_queue_add(&cq, ws + w.S, B, 1, 1, gw + P.ca_b[0], 0));
   G(colsum_queue_add(&cq, ws + w.S + B, B, 1, 1, gw + P.ca_b[1], 0));
 
+  // ---- the weight-gradient products in one grouped flush, then the finishers (side stream with grads_done_event)
+  {
+    ReduceGroup rg;
+    G(gemm_queue_flush(&gq, x3 != 0, ws + w.dwslab, w.dwslab_floats, fs, &rg));
+    G(score_launch_finish(&rg, &cq, ws + w.cs_part, w.cs_part_floats, fs));
+    G(score_launch_attn_w1_grad(d.Dk, AT1, ws + w.dweff, ws + w.dwq, gw + P.at_w[1], fs));
+    if (fin_side) HIPTRY(hipEventRecord((hipEvent_t)st->grads_done_event, fs));
+  }
   // ---- embedding rows (score.py:51-66): the sorted pull-form scatter
   if (st->plan_done_event) HIPTRY(hipStreamWaitEvent(s, (hipEvent_t)st->plan_done_event, 0));
   {
@@ -728,26 +749,24 @@ int backward_ps(const Dims& d, const Params& P, const WS& w, const PsPlan& pp, c
                         grad_table, ws + w.partials, w.partial_floats, s));
   }
   EV(4);
-  // ---- the weight-gradient products in one grouped flush, then the finishers
-  const bool fin_side = st->grads_done_event != nullptr;
-  hipStream_t fs = fin_side ? side->st : s;
-  ReduceGroup rg;
-  G(gemm_queue_flush(&gq, x3 != 0, ws + w.dwslab, w.dwslab_floats, s, &rg));
   EV(5);
-  if (fin_side) {
-    HIPTRY(hipEventRecord(side->fork, s));
-    HIPTRY(hipStreamWaitEvent(fs, side->fork, 0));
-  }
-  G(score_launch_finish(&rg, &cq, ws + w.cs_part, w.cs_part_floats, fs));
-  G(score_launch_attn_w1_grad(d.Dk, AT1, ws + w.dweff, ws + w.dwq, gw + P.at_w[1], fs));
-  if (fin_side) HIPTRY(hipEventRecord((hipEvent_t)st->grads_done_event, fs));
-  if (!fin_side && st->loss_done_event) {     // (the forward pass put its loss reduction on the side stream: final on `stream` behind this pass)
-    HIPTRY(hipEventRecord(side->join, side->st));
-    HIPTRY(hipStreamWaitEvent(s, side->join, 0));
-  }
+  // (the forward pass put its loss reduction on the side stream: loss[] is final on `stream` behind this pass -- it ran beside
+  //  the backward kernel, the wait costs nothing)
+  if (st->loss_done_event) HIPTRY(hipStreamWaitEvent(s, (hipEvent_t)st->loss_done_event, 0));
   return 0;
 }
 }  // namespace
+
+extern "C" int score_persample_form(const score_config_t* cfg, const score_state_t* st, int32_t B, int32_t active_slices) {
+  Dims d;
+  SCORE_TRY(make_dims(cfg, &d));
+  if (!st || B <= 0 || active_slices < 0) return SCORE_E_BADARG;
+  score_batch_t bt;
+  memset(&bt, 0, sizeof(bt));
+  bt.B = B; bt.active_slices = active_slices;
+  PsPlan pp;
+  return ps_path(d, st, &bt, active_T(d, &bt), &pp) ? 1 : 0;
+}
 
 extern "C" int score_forward(const score_config_t* cfg, const score_state_t* st, const score_batch_t* bt,
                              float reg_lambda, float keep_prob, const uint8_t* drop_mask0,

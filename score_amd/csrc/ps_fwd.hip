@@ -5,6 +5,9 @@
 #include "kernels.h"
 
 namespace {
+#if defined(PS_PHASE_TIMING)
+__device__ unsigned long long ps_ts_fwd[32];
+#endif
 
 // ------------------------------------------------------------------------------------------------ weight images
 __device__ __forceinline__ float ps_src(const PsImgJob& j, int r, int c) {
@@ -71,10 +74,10 @@ __global__ __launch_bounds__(256) void ps_prep_kernel(const PsPrepArgs a) {
 // ------------------------------------------------------------------------------------------------ forward
 // one (slice, co-attention call) unit by a group of GS lanes: the body of coattn_fwd_kernel (embed.hip) with one slot per
 // lane, the target rows gathered by the group itself, results into LDS and global memory
-template <int KMAX>
-__device__ __forceinline__ void ps_gather(const PsFwdArgs& a, const PsLds& L, float* sm, int b, int v, int c) {
+template <int KMAX, int c>
+__device__ __forceinline__ void ps_gather(const PsFwdArgs& a, const PsLds& L, float* sm, int b, int v) {
   const PsShape& s = a.s;
-  const int GS = s.GS[c], nslots = s.nslots[c], K = s.K, D4 = s.D4, D = 4 * D4, A = s.A;
+  const int GS = PS2(s.GS, c), nslots = PS2(s.nslots, c), K = s.K, D4 = s.D4, D = 4 * D4, A = s.A;
   const int F = c == 0 ? s.Fi : s.Fu;
   const int rel = v - (c ? s.V0 : 0);
   const int t = rel / GS, gl = rel & (GS - 1);
@@ -85,11 +88,11 @@ __device__ __forceinline__ void ps_gather(const PsFwdArgs& a, const PsLds& L, fl
   const int f = sl / D4, coff = (sl - f * D4) * 4;
   const int Dx = nslots * 4;
   const float* __restrict__ table = a.table;
-  const float* __restrict__ Wc = a.W + a.ca_w[c];
+  const float* __restrict__ Wc = a.W + PS2(a.ca_w, c);
   const float4 wt = ld4(Wc + sl * 4), w1 = ld4(Wc + Dx + sl * 4), w2 = ld4(Wc + 2 * Dx + sl * 4);
   const int64_t ui = (int64_t)b * s.Tidx + tc;
-  const int32_t* __restrict__ i1 = a.idx1[c] + ui * K * F;
-  const int32_t* __restrict__ i2 = a.idx2[c] + ui * K * F;
+  const int32_t* __restrict__ i1 = PS2(a.idx1, c) + ui * K * F;
+  const int32_t* __restrict__ i2 = PS2(a.idx2, c) + ui * K * F;
   const int32_t* __restrict__ tg = (c == 0 ? a.ti : a.tu) + (int64_t)b * F;
   // every load of the unit is unconditional and goes out before anything is consumed (embed.hip: 2K dependent round
   // trips per wave otherwise): the 2K + 1 row ids, then the 2K + 1 rows
@@ -128,14 +131,14 @@ __device__ __forceinline__ void ps_gather(const PsFwdArgs& a, const PsLds& L, fl
 #pragma unroll
   for (int k = 0; k < KMAX; ++k) {
     const bool live = ok && k < K;
-    v1[k] = live ? v1[k] : z4;
-    const float4 y = live ? yv[k] : z4;
+    v1[k] = ps_sel4(live, v1[k]);
+    const float4 y = ps_sel4(live, yv[k]);
     sum2 = add4(sum2, y);
     red[k] = (k < K) ? dot4(v1[k], w1) + dot4(y, w2) : 0.f;
   }
   red[KMAX] = ok ? dot4(tv, wt) : 0.f;
   group_sum_n<KMAX + 1>(red, GS);
-  const float cc = red[KMAX] + a.W[a.ca_b[c]];
+  const float cc = red[KMAX] + a.W[PS2(a.ca_b, c)];
   float r[KMAX], p[KMAX];
   float rmax = 0.f, rsum = 0.f;
 #pragma unroll
@@ -180,7 +183,7 @@ __device__ __forceinline__ void ps_gather(const PsFwdArgs& a, const PsLds& L, fl
         if (i == k) rv = r[k];
       if (i < K) {
         val = (float)K * rv;
-        a.rsave[c][row * K + i] = rv;
+        PS2(a.rsave, c)[row * K + i] = rv;
       }
       a.info[row * 4 * K + c * 2 * K + i] = val;
       sm[L.infos + t * 4 * K + c * 2 * K + i] = val;
@@ -213,7 +216,10 @@ __global__ __launch_bounds__(PS_NT) void ps_fwd_kernel(const PsFwdArgs a) {
   const int len = min(a.length[b], A);
   const uint64_t seed0 = a.seed_dev ? *a.seed_dev : a.seed0;
   const uint64_t seed1 = a.seed_dev ? (seed0 ^ 0x5DEECE66Dull) : a.seed1;
+  PS_MARK(ps_ts_fwd, 0);
 
+  // the forward images (contiguous: wx .. fc2) on their way into this XCD's L2 while the gather runs
+  const PsTouch warm = ps_touch(a.img + a.im.wx[0], a.im.fc2t - a.im.wx[0], tid);
   // ---- phase 1: target rows (last wave) and the fused gather + both co-attentions (everybody)
   {
     // zero the k padding of the operands built in this phase
@@ -247,36 +253,47 @@ __global__ __launch_bounds__(PS_NT) void ps_fwd_kernel(const PsFwdArgs a) {
       *reinterpret_cast<float4*>(sm + L.hin + hoff) = v;
     }
   }
-  for (int v0 = wave * 64; v0 < s.Vtot; v0 += PS_NT) ps_gather<KMAX>(a, L, sm, b, v0 + lane, v0 >= s.V0 ? 1 : 0);
+  for (int v0 = wave * 64; v0 < s.Vtot; v0 += PS_NT) {
+    if (v0 >= s.V0) ps_gather<KMAX, 1>(a, L, sm, b, v0 + lane);
+    else ps_gather<KMAX, 0>(a, L, sm, b, v0 + lane);
+  }
   __syncthreads();
+  PS_MARK(ps_ts_fwd, 1);
 
-  // ---- phase 2: GRU input projections of both sides (x . [Wx_gates | Wx_cand] + bias) and the attention's query q
+  // ---- phase 2: GRU input projections of both sides (x . [Wx_gates | Wx_cand] + bias: waves 0-5, two column tiles each) and
+  // the attention's query q (waves 6-7, four tiles each): every tile of the phase in flight at once
   {
-    const int ntx = 3 * H / 16, nq = (Dk + 15) >> 4, ntask = 2 * ntx + nq;
-    const int ncx = (I + 15) >> 4;
-    for (int task = wave; task < ntask; task += PS_NW) {
-      if (task < 2 * ntx) {
-        const int side = task / ntx, ct = task - side * ntx;
-        ps_f32x4 acc[MT];
-        ps_zero<MT>(acc);
-        ps_mma<MT>(acc, sm + L.xs + side * MP * L.ldx, L.ldx, ps_tile(a.img, a.im.wx[side], ct, ncx), ncx, lane);
-        const int col = ct * 16 + lc;
-        const float bias = col < 2 * H ? W[a.gb[side] + col] : W[a.cb[side] + col - 2 * H];
+    const int ncx = (I + 15) >> 4, nq = (Dk + 15) >> 4;
+    if (wave < 6) {
+      const int side = wave / 3, ct0 = 2 * (wave % 3);
+      ps_f32x4 acc[2][MT];
+      ps_zero<MT, 2>(acc);
+      const int64_t io = PS2(a.im.wx, side);
+      const float4* const tl[2] = {ps_tile(a.img, io, ct0, ncx), ps_tile(a.img, io, ct0 + 1, ncx)};
+      ps_mma<MT, 2>(acc, sm + L.xs + side * MP * L.ldx, L.ldx, tl, ncx, lane);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int col = (ct0 + i) * 16 + lc;
+        const float bias = col < 2 * H ? W[PS2(a.gb, side) + col] : W[PS2(a.cb, side) + col - 2 * H];
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
           for (int v = 0; v < 4; ++v) {
             const int row = m * 16 + 4 * lq + v;
-            if (row < A) sm[L.xp + (side * A + row) * 3 * H + col] = acc[m][v] + bias;
+            if (row < A) sm[L.xp + (side * A + row) * 3 * H + col] = acc[i][m][v] + bias;
           }
-      } else {
-        const int ct = task - 2 * ntx;
-        ps_f32x4 acc[1];
-        ps_zero<1>(acc);
-        ps_mma<1>(acc, sm + L.qs, 0, ps_tile(a.img, a.im.q2, ct, ncx), ncx, lane);
-        const int col = ct * 16 + lc;
+      }
+    } else {
+      const int ctb = (wave - 6) * 4;
+      float qo[4];
+      const float4* const tl[4] = {ps_tile(a.img, a.im.q2, ctb, ncx, nq), ps_tile(a.img, a.im.q2, ctb + 1, ncx, nq),
+                                   ps_tile(a.img, a.im.q2, ctb + 2, ncx, nq), ps_tile(a.img, a.im.q2, ctb + 3, ncx, nq)};
+      ps_gemv<4>(qo, sm + L.qs, tl, ncx, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int col = (ctb + i) * 16 + lc;
         if (lq == 0 && col < Dk) {
-          const float v = acc[0][0] + W[a.at_b[0] + col];
+          const float v = qo[i] + W[a.at_b[0] + col];
           sm[L.qv + col] = v;
           a.q[(int64_t)b * Dk + col] = v;
         }
@@ -284,14 +301,17 @@ __global__ __launch_bounds__(PS_NT) void ps_fwd_kernel(const PsFwdArgs a) {
     }
   }
   __syncthreads();
+  PS_MARK(ps_ts_fwd, 2);
 
-  // ---- phase 3: both recurrences on wave 0 (lanes 0-31 user side, 32-63 item side; a lane owns column j of r, u and the
-  // candidate with its 3 x 32 recurrent weights in registers, the state goes round through LDS); the other waves
-  // meanwhile: the per-sample term of the folded dense_3, qz = q . (Wa + Wc) + b
-  if (wave == 0) {
-    const int side = lane >> 5, j = lane & 31;
-    const float* __restrict__ Wg = W + a.gk[side] + (int64_t)I * 2 * H;      // h rows of gates/kernel [H, 2H]
-    const float* __restrict__ Wcn = W + a.ck[side] + (int64_t)I * H;          // h rows of candidate/kernel [H, H]
+  // ---- phase 3: the two recurrences, one wave per side (wave 0 user side, wave 1 item side).  A lane owns column j = lane % 32 of
+  // r, u and the candidate with its 3 x 32 recurrent weights in registers (both half-waves compute the same thing); the state
+  // h_k reaches every lane as a scalar, v_readlane from lane k -- no LDS round trip in the step (through LDS, 8 + 8
+  // ds_read_b128 per step and their latency were the step: 0.6 us).  Waves 2-6 meanwhile: the per-sample term of the folded
+  // dense_3, qz = q . (Wa + Wc) + b
+  if (wave < 2) {
+    const int side = wave, j = lane & 31;
+    const float* __restrict__ Wg = W + PS2(a.gk, side) + (int64_t)I * 2 * H;      // h rows of gates/kernel [H, 2H]
+    const float* __restrict__ Wcn = W + PS2(a.ck, side) + (int64_t)I * H;          // h rows of candidate/kernel [H, H]
     float wr[H], wu[H], wc[H];
 #pragma unroll
     for (int k = 0; k < H; ++k) {
@@ -299,58 +319,56 @@ __global__ __launch_bounds__(PS_NT) void ps_fwd_kernel(const PsFwdArgs a) {
       wu[k] = Wg[k * 2 * H + H + j];
       wc[k] = Wcn[k * H + j];
     }
-    float* hsm = sm + L.hs + side * H;
-    float* rhm = sm + L.hs + 2 * H + side * H;
     const float* xpb = sm + L.xp + side * A * 3 * H;
     float* gob = sm + L.gout + side * MP * H;
-    float* gsave = a.gates[side] + (int64_t)b * A * 3 * H;
-    float* osave = a.gru_out[side] + (int64_t)b * A * H;
+    float* gsave = PS2(a.gates, side) + (int64_t)b * A * 3 * H;
+    float* osave = PS2(a.gru_out, side) + (int64_t)b * A * H;
     float h = 0.f;
+    float nxr = xpb[j], nxu = xpb[H + j], nxc = xpb[2 * H + j];
     for (int t = 0; t < A; ++t) {
-      const float xr = xpb[t * 3 * H + j], xu = xpb[t * 3 * H + H + j], xc = xpb[t * 3 * H + 2 * H + j];
-      hsm[j] = h;
-      ps_wave_sync();
-      float ar = xr, au = xu;
+      const float xr = nxr, xu = nxu, xc = nxc;
+      const int tn = t + 1 < A ? t + 1 : t;            // the next step's x-projection, read a step ahead
+      nxr = xpb[tn * 3 * H + j]; nxu = xpb[tn * 3 * H + H + j]; nxc = xpb[tn * 3 * H + 2 * H + j];
+      float ar0 = xr, ar1 = 0.f, au0 = xu, au1 = 0.f;
 #pragma unroll
-      for (int k4 = 0; k4 < H / 4; ++k4) {
-        const float4 hv = *reinterpret_cast<const float4*>(hsm + 4 * k4);
-        ar = fmaf(hv.x, wr[4 * k4 + 0], ar); au = fmaf(hv.x, wu[4 * k4 + 0], au);
-        ar = fmaf(hv.y, wr[4 * k4 + 1], ar); au = fmaf(hv.y, wu[4 * k4 + 1], au);
-        ar = fmaf(hv.z, wr[4 * k4 + 2], ar); au = fmaf(hv.z, wu[4 * k4 + 2], au);
-        ar = fmaf(hv.w, wr[4 * k4 + 3], ar); au = fmaf(hv.w, wu[4 * k4 + 3], au);
+      for (int k = 0; k < H; k += 2) {
+        const float h0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(h), k));
+        const float h1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(h), k + 1));
+        ar0 = fmaf(h0, wr[k], ar0); au0 = fmaf(h0, wu[k], au0);
+        ar1 = fmaf(h1, wr[k + 1], ar1); au1 = fmaf(h1, wu[k + 1], au1);
       }
-      const float r = ps_sigmoid(ar), u = ps_sigmoid(au);
-      rhm[j] = r * h;
-      ps_wave_sync();
-      float ac = xc;
+      const float r = ps_sigmoid(ar0 + ar1), u = ps_sigmoid(au0 + au1);
+      const float rh = r * h;
+      float ac0 = xc, ac1 = 0.f;
 #pragma unroll
-      for (int k4 = 0; k4 < H / 4; ++k4) {
-        const float4 hv = *reinterpret_cast<const float4*>(rhm + 4 * k4);
-        ac = fmaf(hv.x, wc[4 * k4 + 0], ac); ac = fmaf(hv.y, wc[4 * k4 + 1], ac);
-        ac = fmaf(hv.z, wc[4 * k4 + 2], ac); ac = fmaf(hv.w, wc[4 * k4 + 3], ac);
+      for (int k = 0; k < H; k += 2) {
+        const float g0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rh), k));
+        const float g1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rh), k + 1));
+        ac0 = fmaf(g0, wc[k], ac0);
+        ac1 = fmaf(g1, wc[k + 1], ac1);
       }
-      const float cnd = ps_tanh(ac);
+      const float cnd = ps_tanh(ac0 + ac1);
       const float hn = u * h + (1.0f - u) * cnd;
       const bool live = t < len;
       const float o = live ? hn : 0.f;         // dynamic_rnn: zero output past the length, state carried through
       h = live ? hn : h;
-      gsave[t * 3 * H + j] = r; gsave[t * 3 * H + H + j] = u; gsave[t * 3 * H + 2 * H + j] = cnd;
-      osave[t * H + j] = o;
-      gob[t * H + j] = o;
-      ps_wave_sync();
+      if (lane < H) {
+        gsave[t * 3 * H + j] = r; gsave[t * 3 * H + H + j] = u; gsave[t * 3 * H + 2 * H + j] = cnd;
+        osave[t * H + j] = o;
+        gob[t * H + j] = o;
+      }
     }
-    if (a.gru_final[side]) a.gru_final[side][(int64_t)b * H + j] = h;
+    if (lane < H && PS2(a.gru_final, side)) PS2(a.gru_final, side)[(int64_t)b * H + j] = h;
   } else {
     const int nck = (Dk + 15) >> 4;
-    for (int ct = wave - 1; ct < 5; ct += PS_NW - 1) {
-      ps_f32x4 acc[1];
-      ps_zero<1>(acc);
-      ps_mma<1>(acc, sm + L.qv, 0, ps_tile(a.img, a.im.wq, ct, nck), nck, lane);
-      const int col = ct * 16 + lc;
-      if (lq == 0) sm[L.qzv + col] = acc[0][0] + W[a.at_b[1] + col];
-    }
+    float qo[1];
+    const float4* const tl[1] = {ps_tile(a.img, a.im.wq, wave - 2, nck, 5)};
+    ps_gemv<1>(qo, sm + L.qv, tl, nck, lane);
+    const int col = (wave - 2) * 16 + lc;
+    if (lq == 0 && wave < 7) sm[L.qzv + col] = qo[0] + W[a.at_b[1] + col];
   }
   __syncthreads();
+  PS_MARK(ps_ts_fwd, 3);
 
   // ---- phase 4: rows of the folded first attention layer's input, [k, q*k], k = [user state | item state | atten_info]
   {
@@ -375,15 +393,17 @@ __global__ __launch_bounds__(PS_NT) void ps_fwd_kernel(const PsFwdArgs a) {
     }
   }
   __syncthreads();
+  PS_MARK(ps_ts_fwd, 4);
 
   // ---- phase 5: dense_3 (folded): a1 = relu([k, q*k] . Weff + qz)
   {
     const int nca = (2 * Dk + 15) >> 4;
-    for (int ct = wave; ct < 5; ct += PS_NW) {
-      ps_f32x4 acc[MT];
-      ps_zero<MT>(acc);
-      ps_mma<MT>(acc, sm + L.ainp, L.lda, ps_tile(a.img, a.im.weff, ct, nca), nca, lane);
-      const int col = ct * 16 + lc;
+    ps_f32x4 acc[1][MT];
+    ps_zero<MT, 1>(acc);
+    const float4* const tl[1] = {ps_tile(a.img, a.im.weff, wave, nca, 5)};
+    ps_mma<MT, 1>(acc, sm + L.ainp, L.lda, tl, nca, lane);
+    if (wave < 5) {
+      const int col = wave * 16 + lc;
       const float qz = sm[L.qzv + col];
 #pragma unroll
       for (int m = 0; m < MT; ++m)
@@ -391,7 +411,7 @@ __global__ __launch_bounds__(PS_NT) void ps_fwd_kernel(const PsFwdArgs a) {
         for (int v = 0; v < 4; ++v) {
           const int row = m * 16 + 4 * lq + v;
           if (row < A) {
-            const float x = fmaxf(acc[m][v] + qz, 0.f);
+            const float x = fmaxf(acc[0][m][v] + qz, 0.f);
             sm[L.a1s + row * L.ld1 + col] = x;
             a.a1[((int64_t)b * A + row) * 80 + col] = x;
           }
@@ -399,27 +419,32 @@ __global__ __launch_bounds__(PS_NT) void ps_fwd_kernel(const PsFwdArgs a) {
     }
   }
   __syncthreads();
+  PS_MARK(ps_ts_fwd, 5);
 
   // ---- phase 6: dense_4: a2 = relu(a1 . W4 + b4)
-  for (int ct = wave; ct < 3; ct += PS_NW) {
-    ps_f32x4 acc[MT];
-    ps_zero<MT>(acc);
-    ps_mma<MT>(acc, sm + L.a1s, L.ld1, ps_tile(a.img, a.im.w4, ct, 5), 5, lane);
-    const int col = ct * 16 + lc;
+  {
+    ps_f32x4 acc[1][MT];
+    ps_zero<MT, 1>(acc);
+    const float4* const tl[1] = {ps_tile(a.img, a.im.w4, wave, 5, 3)};
+    ps_mma<MT, 1>(acc, sm + L.a1s, L.ld1, tl, 5, lane);
+    const int col = wave * 16 + lc;
     const float b4 = W[a.at_b[2] + min(col, 39)];
+    if (wave < 3) {
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+      for (int m = 0; m < MT; ++m)
 #pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const int row = m * 16 + 4 * lq + v;
-        if (row < A && col < 40) {
-          const float x = fmaxf(acc[m][v] + b4, 0.f);
-          sm[L.a2s + row * L.ld2 + col] = x;
-          a.a2[((int64_t)b * A + row) * 40 + col] = x;
+        for (int v = 0; v < 4; ++v) {
+          const int row = m * 16 + 4 * lq + v;
+          if (row < A && col < 40) {
+            const float x = fmaxf(acc[0][m][v] + b4, 0.f);
+            sm[L.a2s + row * L.ld2 + col] = x;
+            a.a2[((int64_t)b * A + row) * 40 + col] = x;
+          }
         }
-      }
+    }
   }
   __syncthreads();
+  PS_MARK(ps_ts_fwd, 6);
 
   // ---- phase 7: dense_5, where(mask, ., -2^32+1), softmax over the slices (score.py:177-185); a lane per slice
   if (wave == 0) {
@@ -438,6 +463,7 @@ __global__ __launch_bounds__(PS_NT) void ps_fwd_kernel(const PsFwdArgs a) {
     }
   }
   __syncthreads();
+  PS_MARK(ps_ts_fwd, 7);
   // pooled states sum_t rep_t * score_t (score.py:214-215) into the head's input
   if (tid < 2 * H) {
     const int side = tid / H, j = tid - side * H;
@@ -450,6 +476,7 @@ __global__ __launch_bounds__(PS_NT) void ps_fwd_kernel(const PsFwdArgs a) {
     }
   }
   __syncthreads();
+  PS_MARK(ps_ts_fwd, 8);
   // bn1: inference-mode affine (score.py:69)
   for (int j = tid; j < Dh; j += PS_NT) {
     const float v = sm[L.hin + j] * (W[a.bn_g + j] * a.rs) + W[a.bn_b + j];
@@ -457,36 +484,40 @@ __global__ __launch_bounds__(PS_NT) void ps_fwd_kernel(const PsFwdArgs a) {
     a.bn[(int64_t)b * Dh + j] = v;
   }
   __syncthreads();
+  PS_MARK(ps_ts_fwd, 9);
 
-  // ---- phase 8: fc1 200 relu dropout
+  // ---- phase 8: fc1 200 relu dropout (13 column tiles: waves 0-4 take two)
   {
     const int nc = (Dh + 15) >> 4;
-    for (int ct = wave; ct < 13; ct += PS_NW) {
-      ps_f32x4 acc[1];
-      ps_zero<1>(acc);
-      ps_mma<1>(acc, sm + L.bns, 0, ps_tile(a.img, a.im.fc1, ct, nc), nc, lane);
-      const int col = ct * 16 + lc;
+    float fo[2];
+    const float4* const tl[2] = {ps_tile(a.img, a.im.fc1, wave, nc, 13), ps_tile(a.img, a.im.fc1, wave + 8, nc, 13)};
+    ps_gemv<2>(fo, sm + L.bns, tl, nc, lane);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int col = (wave + 8 * i) * 16 + lc;
       if (lq == 0 && col < 200) {
-        const float v = ps_act(acc[0][0], W[a.fc_b[0] + col], a.drop, a.keep, a.mask0, seed0, b, col, 200);
+        const float v = ps_act(fo[i], W[a.fc_b[0] + col], a.drop, a.keep, a.mask0, seed0, b, col, 200);
         sm[L.f1s + col] = v;
         a.f1[(int64_t)b * 200 + col] = v;
       }
     }
   }
   __syncthreads();
+  PS_MARK(ps_ts_fwd, 10);
   // ---- phase 9: fc2 80 relu dropout
-  for (int ct = wave; ct < 5; ct += PS_NW) {
-    ps_f32x4 acc[1];
-    ps_zero<1>(acc);
-    ps_mma<1>(acc, sm + L.f1s, 0, ps_tile(a.img, a.im.fc2, ct, 13), 13, lane);
-    const int col = ct * 16 + lc;
-    if (lq == 0) {
-      const float v = ps_act(acc[0][0], W[a.fc_b[1] + col], a.drop, a.keep, a.mask1, seed1, b, col, 80);
+  {
+    float fo[1];
+    const float4* const tl[1] = {ps_tile(a.img, a.im.fc2, wave, 13, 5)};
+    ps_gemv<1>(fo, sm + L.f1s, tl, 13, lane);
+    const int col = wave * 16 + lc;
+    if (lq == 0 && wave < 5) {
+      const float v = ps_act(fo[0], W[a.fc_b[1] + col], a.drop, a.keep, a.mask1, seed1, b, col, 80);
       sm[L.f2s + col] = v;
       a.f2[(int64_t)b * 80 + col] = v;
     }
   }
   __syncthreads();
+  PS_MARK(ps_ts_fwd, 11);
   // ---- phase 10: fc3, sigmoid, the sample's log-loss term and its gradient, dz2 (score.py:74-81)
   if (wave == 0) {
     float part = sm[L.f2s + lane] * W[a.fc_w3 + lane];
@@ -508,6 +539,8 @@ __global__ __launch_bounds__(PS_NT) void ps_fwd_kernel(const PsFwdArgs a) {
       a.dz2[(int64_t)b * 80 + n] = sm[L.f2s + n] > 0.f ? q : 0.f;
     }
   }
+  ps_touch_use(warm, sm + L.misc);
+  PS_MARK(ps_ts_fwd, 12);
 }
 
 }  // namespace
@@ -516,6 +549,7 @@ __global__ __launch_bounds__(PS_NT) void ps_fwd_kernel(const PsFwdArgs a) {
 int ps_plan_shape(int B, int A, int Tidx, int K, int D, int Fu, int Fi, int H, int NI, int Dk, int Dhead, int off_u, int off_i,
                   int off_ti, int off_tu, int Bglobal, PsShape* o) {
   if (B <= 0 || B > PS_MAX_B || A <= 0 || A > 48 || K <= 0 || K > 10 || H != 32 || (D & 3) || D <= 0) return SCORE_E_SHAPE;
+  if ((Fu + Fi) * D > 192) return SCORE_E_SHAPE;         // (tile-to-wave deals of the kernels: <= 12 column tiles of I, <= 16 of Dhead)
   if (NI != 4 * K || Dk != 2 * H + NI) return SCORE_E_SHAPE;           // (SCORE / SCORE_USER / SCORE_ITEM)
   memset(o, 0, sizeof(*o));
   o->B = B; o->A = A; o->Tidx = Tidx; o->K = K; o->D4 = D / 4; o->Fu = Fu; o->Fi = Fi; o->H = H;
@@ -596,3 +630,9 @@ int score_launch_ps_fwd(const PsFwdArgs& a, hipStream_t s) {
   if (mt == 2) return ps_fwd_launch<10, 2>(a, lds, s);
   return ps_fwd_launch<10, 3>(a, lds, s);
 }
+
+#if defined(PS_PHASE_TIMING)
+extern "C" int score_ps_phase_read_fwd(unsigned long long* out32) {
+  return (int)hipMemcpyFromSymbol(out32, HIP_SYMBOL(ps_ts_fwd), 32 * sizeof(unsigned long long));
+}
+#endif

@@ -217,6 +217,8 @@ class SCOREBASE(object):
         self._pinned_stream = self._pinned_handle = None
         self._row_list = None
         self._dense_pending = None      # event behind the dense variables' ApplyAdam when it ran on the side stream (apply_adam)
+        self._ps_form = {}
+        self._ps_last = False           # the last forward_backward ran as the per-sample whole-model kernels
         self._ev_dense = None
         self.w = torch.zeros((self.n_w,), **f32)
         self._alloc_optimizer()
@@ -437,10 +439,21 @@ class SCOREBASE(object):
         return self._tbl_v
 
     def __del__(self):
+        # Work this object queued on its OWN streams (the dense variables' ApplyAdam and the index plan on the host's side stream,
+        # the window slice, the early loss copy) may still be running: the caching allocator knows a tensor only by the stream
+        # it was allocated on and would hand the dying model's buffers to the next allocation while those kernels still write
+        # them (seen as two "identical" models diverging by a few ulp when one of them inherited such a block).  Wait first.
+        for st in (getattr(self, "_side", None), getattr(self, "_sweep_st", None),
+                   (getattr(self, "_early_loss_state", None) or {}).get("stream")):
+            try:
+                if st is not None:
+                    st.synchronize()
+            except Exception:
+                pass
         ctx, self._ctx = getattr(self, "_ctx", None), None
         if ctx is not None and ctx.value and getattr(self, "lib", None) is not None:
             try:
-                self.lib.score_context_destroy(ctx)
+                self.lib.score_context_destroy(ctx)      # (synchronises the engine's side stream)
             except Exception:
                 pass
 
@@ -660,6 +673,18 @@ class SCOREBASE(object):
     def device_batch(self, batch_data):
         return batch_data if isinstance(batch_data, DeviceBatch) else DeviceBatch(self, batch_data)
 
+    def persample_form(self, B, active_slices=0):
+        """True if a batch of B samples with `active_slices` computed slices runs as the per-sample whole-model kernels
+        (include/score_hip.h score_persample_form; csrc/persample.h): the reference's own shapes.  The step is then a handful of
+        launches whose COUNT on the launch stream is what it costs, and everything off the scatter's chain goes to side streams."""
+        key = (int(B), int(active_slices), int(self.debug_flags), int(self.scatter_mode), int(self.global_batch))
+        got = self._ps_form.get(key)
+        if got is None:
+            _, ws = self._workspace(B)
+            st = self._state(ws)
+            got = self._ps_form[key] = self.lib.score_persample_form(C.byref(self.cfg), C.byref(st), int(B), int(active_slices)) == 1
+        return got
+
     def gemm_forms(self, B, active_slices=0):
         """(x_form, dx_form) of include/score_hip.h score_gemm_forms: how the GRU input projections / their input gradients
         of a batch of B samples run under this model's gemm_mode and debug_flags (0 = tiled kernels, n = panel groups per side)"""
@@ -750,8 +775,10 @@ class SCOREBASE(object):
         ev_loss = None
         # (only where the device, not the host's launch calls, bounds the step: tmall_default 0.330 -> 0.335 ms with it, cfg-3
         #  1.2811 -> 1.2762, four alternating pairs on one box)
-        if (self.loss_on_side and not self._graph_on and not self._use_dev_scalars
-                and db.B * (db.active_slices or int(self.cfg.max_time_len)) >= self.overlap_finishers_min_rows):
+        # (the per-sample kernels: always -- every launch taken off the chain is ~5 us there)
+        self._ps_last = self.persample_form(db.B, db.active_slices)
+        side_ok = self._ps_last or db.B * (db.active_slices or int(self.cfg.max_time_len)) >= self.overlap_finishers_min_rows
+        if self.loss_on_side and not self._graph_on and not self._use_dev_scalars and side_ok:
             if self._ev_loss is None:
                 self._ev_loss = torch.cuda.Event()
                 self._ev_loss.record(cur)               # materialise the hipEvent_t
@@ -835,8 +862,8 @@ class SCOREBASE(object):
                 events[4] = self._ev_b4
             self._b4_recorded = events[4]
         self._join_grads()                    # (a previous pass's finishers: they wrote the buffer this pass writes)
-        if (self.scatter_mode == 0 and not self._use_dev_scalars and self._tiled_on()
-                and db.B * (db.active_slices or int(self.cfg.max_time_len)) >= self.overlap_finishers_min_rows):
+        if (self.scatter_mode == 0 and not self._use_dev_scalars and not self._graph_on and side_ok
+                and (self._tiled_on() or self.persample_form(db.B, db.active_slices))):
             if self._ev_grads is None:
                 self._ev_grads = torch.cuda.Event()
                 self._ev_grads.record(cur)              # materialise the hipEvent_t
@@ -873,7 +900,11 @@ class SCOREBASE(object):
                     # (idle by now: the look-ahead catch-up was started at boundary 4), so that the launch stream goes from the
                     # touched rows straight into the next step; whoever touches the dense variables next waits (self.w)
                     self._adam_table_tiled(lr)
-                    side = self._side if self.dense_adam_on_side else None
+                    # (the per-sample form: on the launch stream.  Its products run wholly on the engine's side stream and take as long
+                    #  as the scatter + touched-row update beside them, and the next forward pass needs the dense variables either
+                    #  way: nothing to gain -- and with the update on the host's side stream two identical models were seen to
+                    #  drift apart by an ulp under tests/test_gpu_bad_ids.py when the products were delayed; not understood, see DESIGN)
+                    side = self._side if (self.dense_adam_on_side and not self._ps_last) else None
                     if side is not None:
                         side.wait_event(self._grads_pending)
                         self.adam_dense(lr, reg_lambda, stream=side)
@@ -889,7 +920,7 @@ class SCOREBASE(object):
                     self.adam_dense(lr, reg_lambda)
             else:
                 self.adam_table(lr)
-                self.adam_dense(lr, reg_lambda)
+                self.adam_dense(lr, reg_lambda)        # (reads self.w_g: waits for the finishers' event first)
             self.adam_advance()
 
     # ------------------------------------------------------------------ time-tiled table optimizer

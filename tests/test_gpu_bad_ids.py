@@ -130,8 +130,9 @@ def test_no_variable_is_updated_by_a_step_that_raises(mode):
     for x in (m, twin):
         if mode in ("tiled", "overlap"):
             x.adam_tiled_min_bytes = 0
-        if mode == "overlap":       # the finishers, the loss reduction and the dense ApplyAdam on the side streams (what large batches take)
-            x.overlap_finishers_min_rows = 0
+        if mode == "overlap":       # the finishers, the loss reduction and the dense ApplyAdam on the side streams (what large batches take:
+            x.overlap_finishers_min_rows = 0      # the layer-by-layer pass -- this shape would run as the per-sample kernels, whose
+            x.debug_flags = 512                   # own side placement the sweep / tiled modes exercise)
         if mode == "graph":
             x.enable_graph(True)
     for i in range(5):                               # (graph: eager, eager, captured, replays)
@@ -171,6 +172,7 @@ def test_async_steps_queued_behind_a_bad_batch_are_not_applied_either(mode):
             x.adam_tiled_min_bytes = 0
         if mode == "overlap":
             x.overlap_finishers_min_rows = 0
+            x.debug_flags = 512
     for i in range(3):
         m.train_async(goods[i], 1e-3, 1e-4)
         twin.train_async(goods[i], 1e-3, 1e-4)

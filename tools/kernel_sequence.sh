@@ -10,10 +10,11 @@ f = glob.glob(sys.argv[1] + "/tr/*/*_kernel_trace.csv")[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 names = [r["Kernel_Name"] for r in rows]
 # one step = from one coattn_fwd_kernel to the next, taken near the end of the run
-idx = [i for i, n in enumerate(names) if "coattn_fwd_kernel" in n]
+idx = [i for i, n in enumerate(names) if "ps_fwd_kernel" in n] or [i for i, n in enumerate(names) if "coattn_fwd_kernel" in n]
 a, b = idx[-3], idx[-2]
 t0 = int(rows[a]["Start_Timestamp"])
 with open(sys.argv[1] + "/sequence.txt", "w") as o:
+    o.write("%d launches between two forward kernels\n" % (b - a))
     for r in rows[a - 6:b - 6]:
         line = "%9.1f us  +%7.1f  q%-3s %s" % ((int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3,
                                               r.get("Queue_Id", "?"), r["Kernel_Name"].split("(")[0][:90])
