@@ -68,7 +68,7 @@ struct Params {  // float offsets into the flat buffer
   int64_t n_floats, n_reg;
 };
 
-int build_layout(const Dims& d, score_param_entry_t* out, int max_entries, Params* P) {
+int build_layout_raw(const Dims& d, score_param_entry_t* out, int max_entries, Params* P) {
   // TF creation order (score.py:188-224): co_attention denses, GRU cells, attention denses, bn1, fc1-3
   char names[32][64];
   int rows[32], cols[32], reg[32], init[32];
@@ -132,6 +132,35 @@ int build_layout(const Dims& d, score_param_entry_t* out, int max_entries, Param
   return n;
 }
 
+// Every entry point derives the parameter and workspace layouts from the config: a few dozen snprintf's and a page of
+// arithmetic per call, six times per training step -- ~30 us of a host-bound 200-us step at the reference's own shapes.  The last
+// result per thread is kept (a step alternates between one config and one batch size).
+struct LayoutKey { int64_t N; int D, H, T, K, Fu, Fi, mt, B; };
+static inline LayoutKey layout_key(const Dims& d, int B) {
+  LayoutKey k;
+  memset(&k, 0, sizeof(k));            // (padding bytes too: the keys are compared with memcmp)
+  k.N = d.N; k.D = d.D; k.H = d.H; k.T = d.T; k.K = d.K; k.Fu = d.Fu; k.Fi = d.Fi; k.mt = d.mt; k.B = B;
+  return k;
+}
+static inline bool same_key(const LayoutKey& a, const LayoutKey& b) { return memcmp(&a, &b, sizeof(a)) == 0; }
+int build_layout(const Dims& d, score_param_entry_t* out, int max_entries, Params* P) {
+  struct Memo { bool ok; LayoutKey k; Params P; int n; score_param_entry_t ent[32]; };
+  static thread_local Memo memo = {};
+  LayoutKey k = layout_key(d, 0);
+  if (!memo.ok || !same_key(memo.k, k)) {
+    memset(&memo.k, 0, sizeof(memo.k));
+    memo.n = build_layout_raw(d, memo.ent, 32, &memo.P);
+    memo.k = k; memo.ok = memo.n >= 0;
+    if (memo.n < 0) return memo.n;
+  }
+  *P = memo.P;
+  if (out) {
+    if (memo.n > max_entries) return SCORE_E_BADARG;
+    memcpy(out, memo.ent, sizeof(score_param_entry_t) * memo.n);
+  }
+  return memo.n;
+}
+
 // ---------------------------------------------------------------- workspace layout (float offsets)
 struct WS {
   int64_t xside[2], info, rsave[2], query, head_inp, att_score, logit, y_pred, loss;
@@ -168,7 +197,7 @@ static int64_t ps_image_region_floats(const Dims& d) {
   return im.total;
 }
 
-void build_ws(const Dims& d, int B, WS* w) {
+void build_ws_raw(const Dims& d, int B, WS* w) {
   int64_t cur = 0;
   auto take = [&](int64_t n) { int64_t o = cur; cur = align_up64(cur + (n > 0 ? n : 4), 4); return o; };
   const int64_t BT = (int64_t)B * d.T;
@@ -265,6 +294,18 @@ void build_ws(const Dims& d, int B, WS* w) {
   }
   w->partials = take(w->partial_floats);
   w->total = cur;
+}
+
+void build_ws(const Dims& d, int B, WS* w) {
+  struct Memo { bool ok; LayoutKey k; WS w; };
+  static thread_local Memo memo = {};
+  LayoutKey k = layout_key(d, B);
+  if (!memo.ok || !same_key(memo.k, k)) {
+    memset(&memo.k, 0, sizeof(memo.k));
+    build_ws_raw(d, B, &memo.w);
+    memo.k = k; memo.ok = true;
+  }
+  *w = memo.w;
 }
 
 // A second stream for work that is independent of the long narrow kernels of the path: the GRU recurrences
@@ -641,15 +682,10 @@ int backward_ps(const Dims& d, const Params& P, const WS& w, const PsPlan& pp, c
   // shapes every dependent launch costs the chain ~5 us whatever it computes, so the chain holds the scatter only
   const bool fin_side = st->grads_done_event != nullptr;
   hipStream_t fs = fin_side ? side->st : s;
-  if (st->debug_flags & 2048) {      // (after a layer-by-layer forward pass: the images are not there yet; clears gw too)
-    G(ps_prep(d, P, w, pp, st, gw, P.n_floats, s));
-  } else {
-    if (fin_side) {                  // (behind the previous readers of grad_w: they precede this pass on `stream`)
-      HIPTRY(hipEventRecord(side->fork, s));
-      HIPTRY(hipStreamWaitEvent(fs, side->fork, 0));
-    }
-    HIPTRY(hipMemsetAsync(gw, 0, P.n_floats * sizeof(float), fs));
-  }
+  // (no memset of grad_w: every float of it is overwritten by this pass -- each variable of SCORE / SCORE_USER / SCORE_ITEM gets a
+  //  gradient, every product and column sum stores rather than accumulates -- except the alignment padding between the tensors,
+  //  which the backward kernel's first workgroup clears)
+  if (st->debug_flags & 2048) G(ps_prep(d, P, w, pp, st, nullptr, 0, s));      // (after a layer-by-layer forward pass: no images yet)
   EV(0);
   PsBwdArgs a;
   memset(&a, 0, sizeof(a));
@@ -671,6 +707,21 @@ int backward_ps(const Dims& d, const Params& P, const WS& w, const PsPlan& pp, c
   a.adzsum = ws + w.adzsum; a.dq = ws + w.dq; a.dtgt = ws + w.dtgt; a.S = ws + w.S;
   a.caslab[0] = ws + w.ca_slab; a.caslab[1] = ws + w.ca_slab + (int64_t)B * 2 * d.Di;
   a.keep = keep_prob; a.rs = (float)(1.0 / sqrt(1.0 + 1e-3));
+  {
+    score_param_entry_t ent[32];
+    Params Pl;
+    const int ne = build_layout(d, ent, 32, &Pl);
+    if (ne < 0) return ne;
+    a.gw = gw; a.npad = 0;
+    for (int i = 0; i < ne; ++i) {
+      const int64_t end = ent[i].offset + (int64_t)ent[i].rows * (ent[i].cols ? ent[i].cols : 1);
+      const int64_t stop = align_up64(end, 4);
+      if (stop > end) {
+        if (a.npad >= PS_MAX_PADS) return SCORE_E_SHAPE;
+        a.pad_off[a.npad] = (int)end; a.pad_len[a.npad] = (int)(stop - end); ++a.npad;
+      }
+    }
+  }
   if ((int64_t)B * 2 * (d.Di + d.Du) > w.ca_slab_floats) return SCORE_E_WORKSPACE;
   G(score_launch_ps_bwd(a, s));
   if (fin_side) {
@@ -711,8 +762,8 @@ int backward_ps(const Dims& d, const Params& P, const WS& w, const PsPlan& pp, c
     G(colsum_queue_add(&cq, dxp + 2 * H, BT, H, 3 * H, gw + P.cb[sd], 0));
   }
   // the co-attention denses: [w_t | w_1 | w_2] -- w_t from the target rows weighted by S, w_1 | w_2 from the per-sample slabs
-  G(colsum_queue_add(&cq, a.caslab[0], B, 2 * d.Di, 2 * d.Di, gw + P.ca_w[0] + d.Di, 1));
-  G(colsum_queue_add(&cq, a.caslab[1], B, 2 * d.Du, 2 * d.Du, gw + P.ca_w[1] + d.Du, 1));
+  G(colsum_queue_add(&cq, a.caslab[0], B, 2 * d.Di, 2 * d.Di, gw + P.ca_w[0] + d.Di, 0));
+  G(colsum_queue_add(&cq, a.caslab[1], B, 2 * d.Du, 2 * d.Du, gw + P.ca_w[1] + d.Du, 0));
   G(colsum_queue_add(&cq, ws + w.query + d.Du, B, d.Di, d.Dq, gw + P.ca_w[0], 0, ws + w.S));
   G(colsum_queue_add(&cq, ws + w.query, B, d.Du, d.Dq, gw + P.ca_w[1], 0, ws + w.S + B));
   G(colsum_queue_add(&cq, ws + w.S, B, 1, 1, gw + P.ca_b[0], 0));

@@ -18,6 +18,7 @@
 #define PS_NW 8
 #define PS_MAX_B 512       // batch sizes above this take the layer-by-layer path (weights would be streamed B times)
 #define SCORE_PS_MAX_DEVICES 16
+#define PS_MAX_PADS 40
 
 // floats of the image of a [K][N] matrix
 static inline int64_t ps_image_floats(int K, int N) { return (int64_t)((K + 15) / 16) * ((N + 15) / 16) * 256; }
@@ -77,6 +78,9 @@ struct PsBwdArgs {
   float* dxproj[2]; float* rh[2]; float* hprev[2]; float* dxside[2]; float* pcoef[2]; float* dzcoef[2]; float* dtgt;
   float* S; float* caslab[2];            // S [2][B]; co-attention dW1 | dW2 partial of this sample: caslab[c][b][2 Dx]
   float keep, rs;
+  // the alignment padding between the tensors of the flat dense gradient: nothing of the pass writes it, ApplyAdam and the L2
+  // norm run over it -- workgroup 0 clears it (every other float of grad_w is overwritten by the pass: no memset launch)
+  float* gw; int npad; int pad_off[PS_MAX_PADS]; int pad_len[PS_MAX_PADS];
 };
 
 int ps_plan_shape(int B, int A, int Tidx, int K, int D, int Fu, int Fi, int H, int NI, int Dk, int Dhead, int off_u, int off_i,

@@ -133,6 +133,8 @@ __global__ __launch_bounds__(PS_NT) void ps_bwd_kernel(const PsBwdArgs a) {
   const int len = min(a.length[b], A);
   const int64_t bt0 = (int64_t)b * A;
   PS_MARK(ps_ts_bwd, 0);
+  if (b == 0 && a.gw && tid < a.npad)
+    for (int e = 0; e < a.pad_len[tid]; ++e) a.gw[a.pad_off[tid] + e] = 0.f;
 
   // the backward images (contiguous: fc2t .. wxt) on their way into this XCD's L2 meanwhile
   const PsTouch warm = ps_touch(a.img + a.im.fc2t, a.im.total - a.im.fc2t, tid);

@@ -218,6 +218,8 @@ class SCOREBASE(object):
         self._row_list = None
         self._dense_pending = None      # event behind the dense variables' ApplyAdam when it ran on the side stream (apply_adam)
         self._ps_form = {}
+        self._st_cache = {}
+        self._evs = {}
         self._ps_last = False           # the last forward_backward ran as the per-sample whole-model kernels
         self._ev_dense = None
         self.w = torch.zeros((self.n_w,), **f32)
@@ -600,13 +602,28 @@ class SCOREBASE(object):
         return ent
 
     def _state(self, ws):
-        return _lib.State(table=_ptr(self._tbl), n_table_rows=self._tbl.shape[0], w=_ptr(self.w), workspace=_ptr(ws),
-                          workspace_bytes=ws.numel() * 4, scatter_mode=int(self.scatter_mode),
-                          global_batch=int(self.global_batch), gemm_mode=int(self.gemm_mode),
-                          debug_flags=int(self.debug_flags),
-                          row_flags=_ptr(self.table_flags) if self.scatter_mode == 0 else None,
-                          step_scalars=_ptr(self._scalars) if self._use_dev_scalars else None, context=self._ctx,
-                          id_status=_ptr(self._id_status))
+        w = self.w                   # (the property: joins a dense ApplyAdam still running on a side stream)
+        key = (ws.data_ptr(), self._tbl.data_ptr(), w.data_ptr(), self.table_flags.data_ptr())
+        ent = self._st_cache.get(key)
+        if ent is None:
+            if len(self._st_cache) > 16:
+                self._st_cache.clear()
+            ent = self._st_cache[key] = _lib.State(
+                table=_ptr(self._tbl), n_table_rows=self._tbl.shape[0], w=_ptr(w), workspace=_ptr(ws),
+                workspace_bytes=ws.numel() * 4, context=self._ctx, id_status=_ptr(self._id_status))
+        # one struct per (workspace, table, variables), refreshed in place: building it anew was ~8 us of Python per step
+        st = ent
+        st.workspace_bytes = ws.numel() * 4          # (a new workspace may sit where an evicted one of another size did)
+        st.n_table_rows = self._tbl.shape[0]
+        st.scatter_mode = int(self.scatter_mode)
+        st.global_batch = int(self.global_batch)
+        st.gemm_mode = int(self.gemm_mode)
+        st.debug_flags = int(self.debug_flags)
+        st.row_flags = self.table_flags.data_ptr() if self.scatter_mode == 0 else None
+        st.step_scalars = self._scalars.data_ptr() if self._use_dev_scalars else None
+        st.id_status = self._id_status.data_ptr()      # (a caller may have pointed the struct at a status word of its own: dist.py)
+        st.gather_done_event = st.plan_done_event = st.grads_done_event = st.loss_done_event = None
+        return st
 
     @staticmethod
     def _event_array(events):
@@ -625,6 +642,17 @@ class SCOREBASE(object):
         self.fwd_events, self.bwd_events = mk(5), mk(6)
         for e in self.fwd_events + self.bwd_events:
             e.record()          # forces creation of the underlying hipEvent_t
+
+    def _rec(self, name, stream):
+        """record the model's reusable event `name` on `stream` and return it.  One event object per purpose, re-recorded every step
+        (a new torch Event per record is a hipEventCreate / hipEventDestroy pair: five of them per step were ~25 us of a host-bound
+        200-us step).  Safe because every wait on such an event is ISSUED before its next record, and a stream wait binds to the
+        record that is current when it is issued."""
+        ev = self._evs.get(name)
+        if ev is None:
+            ev = self._evs[name] = torch.cuda.Event()
+        ev.record(stream)
+        return ev
 
     def _cur(self):
         """torch.cuda.current_stream(self.device), looked up once per public call: the query costs ~4 us of Python and a
@@ -756,7 +784,7 @@ class SCOREBASE(object):
         # latency-bound gather hardly notices the sort beside it: 1.489 -> 1.476 ms/step)
         early = self.scatter_mode == 0
         if early:
-            ev_start = cur.record_event()
+            ev_start = self._rec("start", cur)
         # time-tiled optimizer: this step's slice of the table (rows nobody in the batch touches: any time between the
         # batch rows' catch-up and the touched-row update will do).  "f1": behind the fused gather, i.e. beside the forward
         # recurrence, which is matrix-bound and fills half the CUs; 1 .. 4: at that stage boundary of the backward pass
@@ -797,7 +825,7 @@ class SCOREBASE(object):
             el["stream"].wait_event(ev_loss if ev_loss is not None else cur.record_event())
             with torch.cuda.stream(el["stream"]), self._Unpin(self):
                 el["host"].copy_(ws[lay.loss:lay.loss + 4], non_blocking=True)
-                el["event"] = el["stream"].record_event()
+                el["event"] = self._rec("early_loss", el["stream"])
         if fwd_stage is not None and self._pending_sweep is not None:
             if self._sweep_st is None:
                 self._sweep_st = torch.cuda.Stream(device=self.device)      # (its own stream: the occurrence sort must not queue behind it)
@@ -820,7 +848,7 @@ class SCOREBASE(object):
                 _lib.check(self.lib.score_index_plan(C.byref(self.cfg), C.byref(st), C.byref(db.struct), 1,
                                                      2 if want_list else 0, self._stream()), "score_index_plan")
                 row_list = (lay, ws) if want_list else None
-                plan_done = self._side.record_event()
+                plan_done = self._rec("plan", self._side)
             st.plan_done_event = C.c_void_p(plan_done.cuda_event)
             self._plan_done = plan_done                  # keep the event alive until the backward has run
         # time-tiled optimizer: where this step's slice of the table starts.  Beside the backward recurrence (stage
@@ -994,7 +1022,7 @@ class SCOREBASE(object):
             # the backward recurrence (inline_sweep: here on the main stream instead -- a row shard's gather, score_amd/dist.py)
             rows, K = self._tbl.shape[0], self.adam_window
             j = (upto + 1) % K
-            self._pending_sweep = (rows * j // K, rows * (j + 1) // K, upto, cur.record_event())
+            self._pending_sweep = (rows * j // K, rows * (j + 1) // K, upto, self._rec("sweep_after", cur))
             if inline_sweep:
                 self._launch_sweep(cur)
 
@@ -1011,7 +1039,7 @@ class SCOREBASE(object):
         _lib.check(self.lib.score_adam_catchup_rows(C.byref(T), lo, hi, upto, C.c_void_p(stream.cuda_stream)),
                    "score_adam_catchup_rows")
         if other:
-            self._ev_sweep = stream.record_event()
+            self._ev_sweep = self._rec("sweep", stream)
 
     _look_ahead = True               # score_backward records its stage boundary 4 for apply_adam(next_batch=)
 
@@ -1030,7 +1058,7 @@ class SCOREBASE(object):
         _lib.check(self.lib.score_adam_catchup_ids_through(C.byref(T), _ptr(nxt.flat), nxt.flat.numel(), int(self.step) + 1,
                                                            self._alpha(lr), C.c_void_p(side.cuda_stream)),
                    "score_adam_catchup_ids_through")
-        self._ahead = (nxt, side.record_event())
+        self._ahead = (nxt, self._rec("ahead", side))
         self._b4_recorded = None
 
     def _adam_table_tiled(self, lr, dense=None):
