@@ -218,6 +218,8 @@ class SCOREBASE(object):
         self._row_list = None
         self._dense_pending = None      # event behind the dense variables' ApplyAdam when it ran on the side stream (apply_adam)
         self._ps_form = {}
+        self._ev_arrays = {}
+        self._alpha_memo = (None, 0.0)
         self._st_cache = {}
         self._evs = {}
         self._ps_last = False           # the last forward_backward ran as the per-sample whole-model kernels
@@ -625,12 +627,18 @@ class SCOREBASE(object):
         st.gather_done_event = st.plan_done_event = st.grads_done_event = st.loss_done_event = None
         return st
 
-    @staticmethod
-    def _event_array(events):
+    def _event_array(self, events):
         """torch.cuda.Events (timing enabled, already recorded once) -> hipEvent_t[], or NULL."""
         if not events:
             return None
-        return (C.c_void_p * len(events))(*[C.c_void_p(e.cuda_event if e is not None else 0) for e in events])
+        key = tuple(id(e) for e in events)
+        ent = self._ev_arrays.get(key)
+        if ent is None or any(a is not b for a, b in zip(ent[1], events)):
+            if len(self._ev_arrays) > 16:
+                self._ev_arrays.clear()
+            arr = (C.c_void_p * len(events))(*[C.c_void_p(e.cuda_event if e is not None else 0) for e in events])
+            ent = self._ev_arrays[key] = (arr, list(events))      # (the list keeps the events alive: ids are not reused meanwhile)
+        return ent[0]
 
     def enable_stage_events(self, on=True):
         """Record stage-boundary events inside score_forward/backward (bench.py's live
@@ -777,6 +785,7 @@ class SCOREBASE(object):
         if self.scatter_mode == 0:
             if self._side is None:
                 self._side = torch.cuda.Stream(device=self.device)
+                self._side_handle = C.c_void_p(self._side.cuda_stream)
                 self._ev_gather = torch.cuda.Event()
                 self._ev_gather.record(cur)          # materialise the hipEvent_t
         # the occurrence sort starts together with the forward (an event recorded here, not between the gather and
@@ -838,17 +847,17 @@ class SCOREBASE(object):
             # (its workspace regions are its own; the previous step's scatter, their last reader, is behind
             # the event the side stream waits for)
             self._side.wait_event(ev_start if early else self._ev_gather)
-            with torch.cuda.stream(self._side), self._Unpin(self):
-                # (dedup = 2: also the list of the batch's unique rows, for score_adam_touched_rows -- the touched-row update
-                #  driven by that list instead of a scan of the table's state bytes.  OFF by default: measured on one box,
-                #  alternating runs (tools/ab_env.sh), the update itself is 8 - 10 us shorter but the three extra plan kernels
-                #  on the side stream cost the input projections / recurrence beside them 16 - 18 us: 1.306 vs 1.298 ms/step.
-                #  model.adam_touched_list = True turns it on.)
-                want_list = self._tiled_on() and bool(self.adam_touched_list)
-                _lib.check(self.lib.score_index_plan(C.byref(self.cfg), C.byref(st), C.byref(db.struct), 1,
-                                                     2 if want_list else 0, self._stream()), "score_index_plan")
-                row_list = (lay, ws) if want_list else None
-                plan_done = self._rec("plan", self._side)
+            # (dedup = 2: also the list of the batch's unique rows, for score_adam_touched_rows -- the touched-row update
+            #  driven by that list instead of a scan of the table's state bytes.  OFF by default: measured on one box,
+            #  alternating runs (tools/ab_env.sh), the update itself is 8 - 10 us shorter but the three extra plan kernels
+            #  on the side stream cost the input projections / recurrence beside them 16 - 18 us: 1.306 vs 1.298 ms/step.
+            #  model.adam_touched_list = True turns it on.)
+            # (the side stream is handed to the call: entering and leaving a `with torch.cuda.stream(...)` block was ~10 us)
+            want_list = self._tiled_on() and bool(self.adam_touched_list)
+            _lib.check(self.lib.score_index_plan(C.byref(self.cfg), C.byref(st), C.byref(db.struct), 1,
+                                                 2 if want_list else 0, self._side_handle), "score_index_plan")
+            row_list = (lay, ws) if want_list else None
+            plan_done = self._rec("plan", self._side)
             st.plan_done_event = C.c_void_p(plan_done.cuda_event)
             self._plan_done = plan_done                  # keep the event alive until the backward has run
         # time-tiled optimizer: where this step's slice of the table starts.  Beside the backward recurrence (stage
@@ -907,8 +916,11 @@ class SCOREBASE(object):
         return lay, ws
 
     def _alpha(self, lr):
-        f = np.float32
-        return float(f(f(lr) * np.sqrt(f(1) - self.beta2_power) / (f(1) - self.beta1_power)))
+        key = (lr, self.step, float(self.beta1_power), float(self.beta2_power))
+        if self._alpha_memo[0] != key:      # (asked for two or three times per step: ~2 us of NumPy scalars each)
+            f = np.float32
+            self._alpha_memo = (key, float(f(f(lr) * np.sqrt(f(1) - self.beta2_power) / (f(1) - self.beta1_power))))
+        return self._alpha_memo[1]
 
     def apply_adam(self, lr, reg_lambda, next_batch=None):
         """tf.train.AdamOptimizer(lr).minimize(loss) update (score.py:96-99): dense over the
