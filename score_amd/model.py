@@ -218,6 +218,9 @@ class SCOREBASE(object):
         self._row_list = None
         self._dense_pending = None      # event behind the dense variables' ApplyAdam when it ran on the side stream (apply_adam)
         self._ps_form = {}
+        self._plan_ready = None          # (batch, event, workspace, active slices) of an index plan launched a step ahead
+        self._st_ahead = None
+        self.plan_ahead = True           # apply_adam(next_batch=) also sorts the next batch's occurrences (side stream, behind the scatter)
         self._ev_arrays = {}
         self._alpha_memo = (None, 0.0)
         self._st_cache = {}
@@ -846,6 +849,18 @@ class SCOREBASE(object):
             # the first half of the backward, and score_backward waits for it just before the row scatter
             # (its workspace regions are its own; the previous step's scatter, their last reader, is behind
             # the event the side stream waits for)
+            want_list = self._tiled_on() and bool(self.adam_touched_list)
+            pr, self._plan_ready = self._plan_ready, None
+            if pr is not None and pr[0] is db and pr[2] == ws.data_ptr() and pr[3] == db.active_slices and not want_list:
+                # apply_adam(next_batch=db) of the previous step has already sorted this batch's occurrences, behind that step's
+                # row scatter (_plan_ahead): since the per-sample kernels, the six launches of the sort (~110 us with their gaps)
+                # are longer than the forward and backward kernels they used to hide under
+                plan_done = pr[1]
+                row_list = None
+                st.plan_done_event = C.c_void_p(plan_done.cuda_event)
+                self._plan_done = plan_done
+                early = None
+        if self.scatter_mode == 0 and early is not None:
             self._side.wait_event(ev_start if early else self._ev_gather)
             # (dedup = 2: also the list of the batch's unique rows, for score_adam_touched_rows -- the touched-row update
             #  driven by that list instead of a scan of the table's state bytes.  OFF by default: measured on one box,
@@ -853,7 +868,6 @@ class SCOREBASE(object):
             #  on the side stream cost the input projections / recurrence beside them 16 - 18 us: 1.306 vs 1.298 ms/step.
             #  model.adam_touched_list = True turns it on.)
             # (the side stream is handed to the call: entering and leaving a `with torch.cuda.stream(...)` block was ~10 us)
-            want_list = self._tiled_on() and bool(self.adam_touched_list)
             _lib.check(self.lib.score_index_plan(C.byref(self.cfg), C.byref(st), C.byref(db.struct), 1,
                                                  2 if want_list else 0, self._side_handle), "score_index_plan")
             row_list = (lay, ws) if want_list else None
@@ -888,7 +902,8 @@ class SCOREBASE(object):
                 events[k] = self._ev_stage
             ev_sweep_start = events[k]
         self._b4_recorded = None
-        if self._look_ahead and self.scatter_mode == 0 and self._tiled_on():
+        self._b4_any = None
+        if self._look_ahead and self.scatter_mode == 0 and (self._tiled_on() or self.plan_ahead):
             # boundary 4 (the row scatter has marked every row that gets this step's gradient): apply_adam(next_batch=)
             # starts the next batch's catch-up there, on the side stream
             if self._ev_b4 is None:
@@ -898,6 +913,7 @@ class SCOREBASE(object):
             if events[4] is None:
                 events[4] = self._ev_b4
             self._b4_recorded = events[4]
+            self._b4_any = events[4]
         self._join_grads()                    # (a previous pass's finishers: they wrote the buffer this pass writes)
         if (self.scatter_mode == 0 and not self._use_dev_scalars and not self._graph_on and side_ok
                 and (self._tiled_on() or self.persample_form(db.B, db.active_slices))):
@@ -934,6 +950,9 @@ class SCOREBASE(object):
             if self._tiled_on() and self._row_grads:
                 if next_batch is not None:
                     self._catchup_ahead(next_batch, lr)
+            if next_batch is not None and self.plan_ahead:
+                self._plan_ahead(next_batch)
+            if self._tiled_on() and self._row_grads:
                 if self._grads_pending is not None:
                     # the dense gradient's finishers are still running on the side stream: the table's touched rows (row
                     # gradients only) first, the dense variables behind the finishers' event -- on the host's side stream
@@ -1072,6 +1091,28 @@ class SCOREBASE(object):
                    "score_adam_catchup_ids_through")
         self._ahead = (nxt, self._rec("ahead", side))
         self._b4_recorded = None
+
+    def _plan_ahead(self, nxt):
+        """The NEXT batch's index plan (the occurrence sort of the row scatter: it depends on the ids only), on the side stream
+        behind THIS step's row scatter -- the last reader of the plan's buffers.  The ids it sees are not reported (the sticky
+        status word guards this step's optimizer kernels, which run meanwhile): the forward pass of the batch reports them."""
+        ev4 = getattr(self, "_b4_any", None)
+        if (not isinstance(nxt, DeviceBatch) or nxt.flat is None or ev4 is None or self._side is None or self.scatter_mode != 0
+                or self._graph_on or self._use_dev_scalars or (self._tiled_on() and self.adam_touched_list)):
+            return
+        lay, ws = self._workspace(nxt.B)
+        st = self._st_ahead
+        if st is None:
+            st = self._st_ahead = _lib.State()
+        st.table = self._tbl.data_ptr(); st.n_table_rows = self._tbl.shape[0]; st.w = self._w.data_ptr()
+        st.workspace = ws.data_ptr(); st.workspace_bytes = ws.numel() * 4
+        st.scatter_mode = 0; st.gemm_mode = int(self.gemm_mode); st.debug_flags = int(self.debug_flags)
+        st.context = self._ctx
+        st.id_status = None
+        self._side.wait_event(ev4)
+        _lib.check(self.lib.score_index_plan(C.byref(self.cfg), C.byref(st), C.byref(nxt.struct), 1, 0, self._side_handle),
+                   "score_index_plan")
+        self._plan_ready = (nxt, self._rec("plan_ahead", self._side), ws.data_ptr(), nxt.active_slices)
 
     def _adam_table_tiled(self, lr, dense=None):
         """ApplyAdam of step self.step + 1 on the rows that have a gradient; every other live row owes it.
