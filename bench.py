@@ -425,6 +425,10 @@ def main():
     ap.add_argument("--gather-probe-only", action="store_true",
                     help="run only the low-duplication gather probe (for rocprofv3 --pmc passes) and print its JSON")
     ap.add_argument("--probe-rows", type=int, default=32_000_000)
+    ap.add_argument("--a2a", choices=["split", "remote"], default=None,
+                    help="form of the row / gradient all-to-all with N > 1 ranks: 'remote' = list form with empty own slots (a rank's own "
+                         "rows never go through RCCL), 'split' = all_to_all_single with the own segment inside.  Default: what the "
+                         "set-up probe finds to round-trip (score_amd/dist.py TorchDistComm.probe_a2a), the same on every rank")
     ap.add_argument("--lr", type=float, default=1e-3)
     ap.add_argument("--reg-lambda", type=float, default=1e-4)
     args = ap.parse_args()
@@ -490,6 +494,8 @@ def main():
 
     if sharded:
         from score_amd.dist import ShardedSCORE
+        if args.a2a:
+            os.environ["SCORE_A2A"] = args.a2a          # (read by the set-up probe of every rank)
         model = ShardedSCORE(seed=1111, **kw)
     else:
         model = SCORE(seed=1111, **kw)
@@ -665,7 +671,12 @@ def main():
         # the stage table: eager steps with every boundary event, right behind the timed region (same state, same batches)
         n_st = max(3 * every, 12)
         events = {i: full_event_set() for i in range(0, n_st, every)}
+        cm_ = getattr(model, "comm", None)
+        if cm_ is not None and hasattr(cm_, "timing"):
+            cm_.timing = True                 # (the per-rank table of the collectives: these steps, not the timed region)
         fb2 = run_steps(n_st, 0, events)
+        if cm_ is not None and hasattr(cm_, "timing"):
+            cm_.timing = False
         fb = fb2 if fb is None else fb
         torch.cuda.synchronize()
     else:
@@ -681,6 +692,14 @@ def main():
         dist.all_gather(got, mine)
         dt_ranks = [float(t.item()) for t in got]
         dt = max(dt_ranks)
+    coll_table = None
+    if dist is not None and hasattr(getattr(model, "comm", None), "timing_summary"):
+        mine_t = {k: {kk: round(vv, 4) for kk, vv in v.items()} for k, v in model.comm.timing_summary().items()}
+        if ranks_seen > 1:
+            coll_table = [None] * ranks_seen
+            dist.all_gather_object(coll_table, mine_t)
+        else:
+            coll_table = [mine_t]
     if sharded:
         loss = float((fb[0][1] + args.reg_lambda * fb[0][2]).item())
     else:
@@ -986,7 +1005,13 @@ def main():
                                  % (n_sync, dt_sync / n_sync * 1e3, sync_losses[-1]),
         "ms_per_step_ranks": {"min": min(dt_ranks) / args.steps * 1e3, "max": max(dt_ranks) / args.steps * 1e3},
         "rccl_ranks": ranks_seen if (dist is not None and backend == "nccl") else 0,
-        "dist": ({"backend": backend, "world_size": ranks_seen} if dist is not None else None),
+        "dist": ({"backend": backend, "world_size": ranks_seen, "a2a_probe": getattr(getattr(model, "comm", None), "a2a_probe", None),
+                  "collectives_ms": coll_table,
+                  "collectives_what": "per rank, averaged over the timed steps, a pair of HIP events around each data-path collective on "
+                                      "the stream it is issued on: a2a_row_requests (int32 ids), a2a_rows (fp32 rows back), a2a_row_grads "
+                                      "(fp32 row gradients to the owners), all_reduce (flat dense gradient + the loss slot) -- what the "
+                                      "first multi-GPU curve is read against DESIGN section 5's prediction with"}
+                 if dist is not None else None),
         "higher_is_better": True,
         "scaling": "strong" if strong else "weak",
         "vs_baseline": None,

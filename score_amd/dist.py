@@ -82,6 +82,13 @@ def _concurrent_stream(device, candidates=8, cycles=1500000):
     return best
 
 
+def _a2a(cm, out, inp, out_splits, in_splits, tag):
+    """the remote-only all-to-all where the communicator has one (TorchDistComm: tagged for bench.py's per-rank table)"""
+    if isinstance(cm, TorchDistComm):
+        return cm.all_to_all_remote(out, inp, out_splits, in_splits, tag=tag)
+    return getattr(cm, "all_to_all_remote", cm.all_to_all)(out, inp, out_splits, in_splits)
+
+
 class TorchDistComm(object):
     """torch.distributed collectives (nccl == RCCL on ROCm; gloo for the CPU tests)."""
 
@@ -92,9 +99,93 @@ class TorchDistComm(object):
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self._gloo = dist.get_backend(group) == "gloo"
-        self._list_form = None  # all_to_all_remote: True once the list form with empty own slots has gone through, False if refused
+        # all_to_all_remote's form: "remote" = the list form with EMPTY tensors in the own slot (what a rank owns never goes through
+        # the collective), "split" = all_to_all_single with the own segment inside.  Decided ONCE, at set-up, identically on every
+        # rank (probe_a2a): never by catching an error in the hot path, where a rank-local or asynchronous failure would flip one
+        # rank only and the ranks' collectives would stop matching.  SCORE_A2A=split|remote (bench.py --a2a) forces one.
+        self._list_form = None
+        self.a2a_probe = None   # what the probe found (bench.py prints it)
         self.last = None       # ("name", sequence number) of the collective this rank entered last (bench.py's heartbeat)
         self._seq = 0
+        # bench.py --gpus N: a pair of timing events around every data-path collective of the timed steps, on the stream the
+        # collective is issued on -- the per-rank table the first multi-GPU curve is read against
+        self.timing = False
+        self._timed = []
+
+    def _timed_call(self, tag, tensor, fn):
+        if not self.timing or tensor.device.type != "cuda":
+            return fn()
+        st = torch.cuda.current_stream(tensor.device)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        r = fn()
+        e1.record(st)
+        self._timed.append((tag, e0, e1, int(tensor.numel()) * tensor.element_size()))
+        return r
+
+    def timing_summary(self):
+        """{tag: {"calls", "ms_avg", "ms_max", "bytes_avg"}} of the collectives timed so far (synchronises)"""
+        out = {}
+        for tag, e0, e1, nbytes in self._timed:
+            e1.synchronize()
+            ms = e0.elapsed_time(e1)
+            d = out.setdefault(tag, {"calls": 0, "ms_sum": 0.0, "ms_max": 0.0, "bytes_sum": 0})
+            d["calls"] += 1; d["ms_sum"] += ms; d["ms_max"] = max(d["ms_max"], ms); d["bytes_sum"] += nbytes
+        self._timed = []
+        return {k: {"calls": v["calls"], "ms_avg": v["ms_sum"] / v["calls"], "ms_max": v["ms_max"],
+                    "bytes_avg": v["bytes_sum"] / v["calls"]} for k, v in out.items()}
+
+    def probe_a2a(self, device, force=None):
+        """Run both all-to-all forms on tiny tensors, compare what arrives with what every rank must receive, and settle on one
+        form for the whole run -- the same one on every rank (the verdicts are all-reduced).  One line on stderr from rank 0.
+        force: "split" / "remote" (or SCORE_A2A): take that form without asking (still checked, a mismatch raises)."""
+        force = force or os.environ.get("SCORE_A2A") or None
+        if force not in (None, "split", "remote"):
+            raise ValueError("all-to-all form must be 'split' or 'remote', got %r" % (force,))
+        if self.world == 1 or self._gloo:
+            self._list_form = None if self.world == 1 else True
+            self.a2a_probe = {"form": "none (one rank)" if self.world == 1 else "pairwise (gloo)", "forced": force}
+            return self.a2a_probe
+        G, r = self.world, self.rank
+        per = 3                                       # rows per peer; row values name (source, destination, row)
+        inp = torch.tensor([[1000.0 * r + 10.0 * p + i for i in range(per)] for p in range(G)], dtype=torch.float32,
+                           device=device).reshape(G * per, 1)
+        want = torch.tensor([[1000.0 * p + 10.0 * r + i for i in range(per)] for p in range(G)], dtype=torch.float32,
+                            device=device).reshape(G * per, 1)
+        splits = [per] * G
+        verdict = {}
+        for form in ("remote", "split"):
+            ok = 1.0
+            out = torch.full_like(inp, -1.0)
+            try:
+                if form == "split":
+                    self.dist.all_to_all_single(out, inp, splits, splits, group=self.group)
+                else:
+                    outs, ins = list(out.split(splits, 0)), list(inp.split(splits, 0))
+                    outs[r].copy_(ins[r])
+                    outs[r] = out.new_empty((0, 1))
+                    ins[r] = inp.new_empty((0, 1))
+                    self.dist.all_to_all(outs, ins, group=self.group)
+                if torch.device(device).type == "cuda":
+                    torch.cuda.synchronize(device)
+                ok = 1.0 if torch.equal(out, want) else 0.0
+            except (RuntimeError, ValueError, TypeError) as e:      # (an argument check: before anything is enqueued)
+                ok = 0.0
+                verdict[form + "_error"] = str(e).splitlines()[0][:160]
+            flag = torch.tensor([ok], dtype=torch.float32, device=device)
+            self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN, group=self.group)     # every rank, or nobody
+            verdict[form] = bool(flag.item() == 1.0)
+        if force is not None and not verdict[force]:
+            raise RuntimeError("all-to-all form %r was asked for and does not round-trip on this backend: %r" % (force, verdict))
+        form = force or ("remote" if verdict["remote"] else "split")
+        if not verdict[form]:
+            raise RuntimeError("neither all-to-all form round-trips on this backend: %r" % (verdict,))
+        self._list_form = form == "remote"
+        verdict.update(form=form, forced=force)
+        self.a2a_probe = verdict
+        if r == 0:
+            sys.stderr.write("[score_amd.dist] all-to-all probe over %d ranks: %r\n" % (G, verdict))
+        return verdict
 
     def _note(self, name):
         self._seq += 1
@@ -151,7 +242,10 @@ class TorchDistComm(object):
         for r in reqs:
             r.wait()
 
-    def all_to_all_remote(self, out, inp, out_splits, in_splits):
+    def all_to_all_remote(self, out, inp, out_splits, in_splits, tag="a2a"):
+        return self._timed_call(tag, inp, lambda: self._all_to_all_remote(out, inp, out_splits, in_splits))
+
+    def _all_to_all_remote(self, out, inp, out_splits, in_splits):
         """all_to_all of the segments that belong to OTHER ranks only; this rank's own segment is a device-side copy (or,
         for callers that pass out / inp whose own segments are the same memory, nothing).  What a rank owns never goes
         through RCCL: one rank = no collective at all, G ranks = (G - 1) / G of the bytes in the collective's kernels."""
@@ -166,26 +260,19 @@ class TorchDistComm(object):
             self.all_to_all(out, inp, out_splits, in_splits)
             return
         self._note("all_to_all_remote[%s x %d]" % (str(inp.dtype).replace("torch.", ""), int(inp.shape[0]) - int(ins[r].shape[0])))
-        if self._list_form is False:   # (see below)
+        if self._list_form is None:    # (nobody ran the set-up probe: ShardedSCORE does; a bare communicator settles it here)
+            self.probe_a2a(inp.device)
+        if not self._list_form:
             self.all_to_all(out, inp, out_splits, in_splits)
             return
         outs[r] = out.new_empty((0,) + tuple(out.shape[1:]))
         ins[r] = inp.new_empty((0,) + tuple(inp.shape[1:]))
-        try:
-            self.dist.all_to_all(outs, ins, group=self.group)
-            self._list_form = True
-        except (RuntimeError, ValueError, TypeError) as e:
-            # a backend whose list form refuses empty slots says so when it checks its arguments, before anything is
-            # enqueued, and on every rank alike (same shapes of the same call): from then on the own segment rides through
-            # the collective as well (the split form).  Once the list form has worked, an error is an error.
-            if self._list_form:
-                raise
-            self._list_form = False
-            sys.stderr.write("[score_amd.dist] rank %d: all_to_all with empty own slots refused (%s); the own segment goes "
-                             "through the collective from here on\n" % (r, str(e).splitlines()[0][:200]))
-            self.all_to_all(out, inp, out_splits, in_splits)
+        self.dist.all_to_all(outs, ins, group=self.group)
 
-    def all_reduce_sum(self, t):
+    def all_reduce_sum(self, t, tag="all_reduce"):
+        return self._timed_call(tag, t, lambda: self._all_reduce_sum(t))
+
+    def _all_reduce_sum(self, t):
         self._note("all_reduce[%d]" % t.numel())
         if self._gloo and t.device.type != "cpu":
             h = t.cpu()
@@ -501,6 +588,9 @@ class ShardedSCORE(object):
             # initialisation costs tens of ms and would otherwise land inside a training step
             for cm in {id(c): c for c in (self.comm, self.comm.index_comm())}.values():
                 cm.exchange_counts([0] * self.world, self.device)
+        if hasattr(self.comm, "probe_a2a"):
+            # which all-to-all form this backend round-trips: settled here, once, the same on every rank
+            self.comm.probe_a2a(self.device)
         if self.device.type == "cuda" and hasattr(self.backend, "dense_grad_with_loss"):
             # the gradient-exchange stream (and its start-up probe, a handful of device-wide waits): here, not
             # inside the first training step
@@ -546,7 +636,7 @@ class ShardedSCORE(object):
             req = plan["unique_rows"]           # (the one owner is this rank: its request list IS the plan's unique rows)
         else:
             req = torch.empty((sum(recv),), dtype=torch.int32, device=self.device)
-            getattr(cm, "all_to_all_remote", cm.all_to_all)(req, plan["unique_rows"], recv, send)
+            _a2a(cm, req, plan["unique_rows"], recv, send, "a2a_row_requests")
         plan.update(send=send, recv=recv, req=req, global_B=sum(sizes), bad_by_rank=[e >> 32 for e in extras])
         if hasattr(self.backend, "note_requests"):
             self.backend.note_requests(sum(recv))
@@ -565,7 +655,7 @@ class ShardedSCORE(object):
         if self.world == 1:
             return rows                         # (gathered in the plan's unique-row order: it IS the mini-table)
         mini = torch.empty((plan["U"], self.D), dtype=torch.float32, device=self.device)
-        getattr(cm, "all_to_all_remote", cm.all_to_all)(mini, rows, plan["send"], plan["recv"])
+        _a2a(cm, mini, rows, plan["send"], plan["recv"], "a2a_rows")
         return mini
 
     def prefetch(self, batch_data):
@@ -692,7 +782,7 @@ class ShardedSCORE(object):
             self._gside.wait_event(ev)
             with torch.cuda.stream(self._gside):
                 if self.world > 1:
-                    getattr(cm, "all_to_all_remote", cm.all_to_all)(grads_in, mini_g, plan["recv"], plan["send"])
+                    _a2a(cm, grads_in, mini_g, plan["recv"], plan["send"], "a2a_row_grads")
                 mini_g.record_stream(self._gside)
                 be.accumulate(plan["req"], grads_in, plan["recv"])
                 if pipelined:
@@ -726,7 +816,7 @@ class ShardedSCORE(object):
             grads_in = mini_g
         else:
             grads_in = torch.empty((plan["req"].numel(), self.D), dtype=torch.float32, device=self.device)
-            getattr(cm, "all_to_all_remote", cm.all_to_all)(grads_in, mini_g, plan["recv"], plan["send"])
+            _a2a(cm, grads_in, mini_g, plan["recv"], plan["send"], "a2a_row_grads")
         cm.all_reduce_sum(be.dense_grad())
         be.accumulate(plan["req"], grads_in, plan["recv"])
         loss = fw["loss"].clone()          # [loss, log_loss (local share of the global mean), l2]

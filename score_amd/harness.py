@@ -197,7 +197,10 @@ def train_loop(model, train_batches, vali_batches, lr, reg_lambda, train_batch_s
         it = iter(pairs)
         if n_steps is not None:
             for i in range(n_steps):
-                p = next(it)
+                p = next(it, None)
+                if p is None:        # a loader whose __len__ overstates what it yields: say so here, on this rank, instead of
+                    raise RuntimeError("train_loop: the loader of rank %d ended after %d of the %d batches its len() promised "
+                                       "(the other ranks are inside that step's collectives: they time out)" % (comm.rank, i, n_steps))
                 yield (p[0], p[1] if i + 1 < n_steps else None)
             return
         while True:
@@ -252,6 +255,12 @@ def train_loop(model, train_batches, vali_batches, lr, reg_lambda, train_batch_s
                         early_stop = True
                     if (vali_mrrs[-1] - vali_mrrs[-2]) <= 0.001 and (vali_mrrs[-2] - vali_mrrs[-3]) <= 0.001:
                         early_stop = True
+        # the tail of an epoch after its last evaluation was never looked at: a batch with an id outside the table there would
+        # leave the sticky status word set and every later optimizer step suppressed without anybody hearing of it
+        if use_async and hasattr(model, "check_ids"):
+            model.check_ids()
+    if hasattr(model, "check_ids"):
+        model.check_ids()
     index = int(np.argmax(vali_mrrs))
     curves.update(best_index=index, best_mrr=vali_mrrs[index], steps=step, saved_at_steps=saves,
                   eval_iter_num=eval_iter_num, early_stopped=early_stop)

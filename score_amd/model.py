@@ -218,6 +218,7 @@ class SCOREBASE(object):
         self._row_list = None
         self._dense_pending = None      # event behind the dense variables' ApplyAdam when it ran on the side stream (apply_adam)
         self._ps_form = {}
+        self._train_stream = None        # the stream the last forward_backward ran on (who else must wait for side-stream updates)
         self._plan_ready = None          # (batch, event, workspace, active slices) of an index plan launched a step ahead
         self._st_ahead = None
         self.plan_ahead = True           # apply_adam(next_batch=) also sorts the next batch's occurrences (side stream, behind the scatter)
@@ -409,7 +410,13 @@ class SCOREBASE(object):
         ev, self._dense_pending = self._dense_pending, None
         if ev is not None:
             self._grads_pending = None          # (the update ran behind the finishers: they are through as well)
-            self._cur().wait_event(ev)
+            cur = self._cur()
+            cur.wait_event(ev)
+            # (touched from inside a `with torch.cuda.stream(x)` block of the caller: x waits above, and so must the stream the
+            #  training sequence runs on -- its next forward pass reads the variables too, and the pending event is gone by then)
+            own = self._train_stream
+            if own is not None and own.cuda_stream != cur.cuda_stream:
+                own.wait_event(ev)
 
     @property
     def w_g(self):
@@ -421,7 +428,11 @@ class SCOREBASE(object):
     def _join_grads(self):
         ev, self._grads_pending = self._grads_pending, None
         if ev is not None:
-            self._cur().wait_event(ev)
+            cur = self._cur()
+            cur.wait_event(ev)
+            own = self._train_stream
+            if own is not None and own.cuda_stream != cur.cuda_stream:
+                own.wait_event(ev)
 
     @property
     def adam_window(self):
@@ -785,6 +796,7 @@ class SCOREBASE(object):
         db = self.device_batch(batch_data)
         plan_done = None
         cur = self._cur()
+        self._train_stream = cur
         if self.scatter_mode == 0:
             if self._side is None:
                 self._side = torch.cuda.Stream(device=self.device)
@@ -1393,6 +1405,11 @@ class SCOREBASE(object):
 
     def save(self, sess, path):
         """All global variables incl. the Adam slots, under the TF variable names."""
+        if self._guard_on:
+            # an id outside the table fed through train_async / eval_async and never checked: the optimizer has applied nothing
+            # since, while the host's step count and beta powers went on -- such a checkpoint would hold global_step / beta
+            # powers ahead of the variables.  Raises (and takes the suppressed steps off the count) instead of writing it.
+            self.check_ids()
         blob = {"emb_mtx": self._table_host()}
         for e in self.entries:
             blob[e[0]] = self._view(self.w, e).cpu().numpy().copy()

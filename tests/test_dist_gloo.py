@@ -118,9 +118,9 @@ def test_ranks_on_the_rccl_code_path(world):
 
 
 def test_a_backend_that_refuses_empty_slots_gets_the_split_form():
-    """TorchDistComm.all_to_all_remote: if the backend's list all_to_all will not take empty tensors (it says so when it checks
-    its arguments, on every rank alike), the own segment goes through the collective instead -- once, with a line on stderr --
-    and the results are the same."""
+    """TorchDistComm.probe_a2a (run by ShardedSCORE at set-up): if the backend's list all_to_all will not take empty tensors, every
+    rank settles on the split form -- the verdict is all-reduced, nothing is decided by catching an error inside a training step --
+    with one line on stderr from rank 0, and the results are the same."""
     import json
     import subprocess
     out = subprocess.run([sys.executable, os.path.join(HERE, "threaded_pg_worker.py"), "3", "refuse"], capture_output=True,
@@ -128,8 +128,8 @@ def test_a_backend_that_refuses_empty_slots_gets_the_split_form():
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     j = json.loads(out.stdout.strip().splitlines()[-1])
     assert j["ok"] and j["loss_rel_err"] < 1e-5 and j["table_max_err"] < 2e-6 and j["dense_identical_across_ranks"]
-    assert j["list_form"] == [False] * 3 and j["list_collectives_per_rank"] == [1, 1, 1]      # tried once per rank
-    assert out.stderr.count("empty own slots refused") == 3
+    assert j["list_form"] == [False] * 3 and j["list_collectives_per_rank"] == [1, 1, 1]      # tried once per rank: the set-up probe
+    assert out.stderr.count("all-to-all probe over 3 ranks") == 1 and "'remote': False" in out.stderr and "'form': 'split'" in out.stderr
 
 
 # ---- an id outside the table on ONE rank: rejected on EVERY rank before the step starts (score.py:51-66) -------------

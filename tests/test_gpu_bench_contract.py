@@ -87,7 +87,11 @@ def test_gpus_n_starts_its_own_ranks():
     if torch.cuda.device_count() < 2:
         assert out.returncode == 2 and "2 GPU" not in out.stdout and "GPU(s) visible" in out.stderr, out.stderr[-500:]
     j = _run("--gpus", "2", "--steps", "4", "--warmup", "1", "--config", "cfg2", SCORE_BENCH_DEVICE="0", SCORE_DIST_BACKEND="gloo")
-    assert j["n_gpus"] == 2 and j["dist"] == {"backend": "gloo", "world_size": 2} and j["rccl_ranks"] == 0
+    assert j["n_gpus"] == 2 and j["dist"]["backend"] == "gloo" and j["dist"]["world_size"] == 2 and j["rccl_ranks"] == 0
+    # the all-to-all form was settled at set-up, and every rank reports its collectives
+    assert "gloo" in j["dist"]["a2a_probe"]["form"] and len(j["dist"]["collectives_ms"]) == 2
+    for t in j["dist"]["collectives_ms"]:
+        assert {"a2a_row_requests", "a2a_rows", "a2a_row_grads", "all_reduce"} <= set(t) and t["a2a_rows"]["calls"] > 0
     assert j["cpu_baseline"] is None and j["ms_per_step_ranks"]["min"] <= j["ms_per_step_ranks"]["max"] == j["ms_per_step"]
     assert abs(j["value"] - 2 * 256 / (j["ms_per_step"] * 1e-3)) < 1e-6 * j["value"]
 
