@@ -381,7 +381,10 @@ typedef struct {
                            both are stable, the plan is the same bits); bit 9 (512) = never take the per-sample
                            whole-model kernels (csrc/persample.h: at H = 32, B <= 512, K <= 10, <= 48 computed slices
                            SCORE / SCORE_USER / SCORE_ITEM run each pass as ONE kernel, a workgroup per sample), bit 10
-                           (1024) = take them for the forward pass only, bit 11 (2048) = for the backward pass only.
+                           (1024) = take them for the forward pass only, bit 11 (2048) = for the backward pass only;
+                           bit 12 (4096) = NO second stream: everything score_forward / score_backward would fork onto
+                           the context's side stream runs on `stream`, in launch order (same results bit for bit; what
+                           a suspected stream race is compared against -- score_amd.model inlines its own streams too).
                            The ONLY switches of the launch sequence: the library reads no environment variable       */
   uint8_t* row_flags;   /* optional [n_table_rows] row state of the dense table optimizer (see
                            score_adam_rows): score_backward (scatter_mode 0) marks every row it
@@ -506,7 +509,11 @@ int score_forward(const score_config_t* cfg, const score_state_t* st, const scor
  * stage_events: null, or SIX handles: [0] start, [1] after the head, [2] after the temporal
  * attention, [3] after the GRUs, [4] after the co-attention/embedding scatter, [5] after the
  * weight-gradient products (all X^T dY of the pass run here, as grouped launches; with score_state_t.grads_done_event the
- * event sits behind the products, the finishers that follow them run on the side stream). */
+ * event sits behind the products, the finishers that follow them run on the side stream).
+ * grad_w between the two calls: score_backward's zero fill / first writers of grad_w run on the context's side stream, forked
+ * where score_forward of the same step began -- i.e. they may execute any time after score_forward was CALLED.  Nothing may
+ * read or write grad_w on `stream` (or anywhere else) between score_forward and the completion of score_backward of the same
+ * step; the previous step's readers (the optimizer) must be on `stream` before score_forward, or joined into it.            */
 int score_backward(const score_config_t* cfg, const score_state_t* st, const score_batch_t* batch,
                    float keep_prob, float* grad_w, float* grad_table, void* const* stage_events,
                    void* stream);

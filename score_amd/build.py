@@ -25,6 +25,9 @@ def _stale(target, deps):
 
 def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    # the product library never carries a timing probe's stripped kernel (csrc/common.h: those switches need SCORE_PROBE_BUILD)
+    if any("SCORE_PROBE_BUILD" in f for f in FLAGS) or "SCORE_PROBE_BUILD" in os.environ.get("HIPCC_COMPILE_FLAGS_APPEND", ""):
+        raise RuntimeError("score_amd.build: -DSCORE_PROBE_BUILD is for tools/*_probe.py only, never for libscore_hip.so")
     os.makedirs(LIBDIR, exist_ok=True)
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)

@@ -6,6 +6,20 @@
 
 #define SCORE_WAVE 64
 
+// Timing probes (tools/*_probe.py) compile single kernels with one ingredient stripped -- no loads, no matrix
+// instruction, no stores: WRONG results by design.  Such a switch only compiles with -DSCORE_PROBE_BUILD beside it, which
+// score_amd/build.py refuses to pass: the product library cannot carry one by accident.
+#if (defined(X3_PROBE_NOLOADA) || defined(X3_PROBE_NOLOADB) || defined(X3_PROBE_NOSPLIT) || defined(X3_PROBE_NOLDSW) ||      \
+     defined(X3_PROBE_NOLDSR) || defined(X3_PROBE_NOMFMA) || defined(X3_PROBE_NOSTORE) || defined(PANEL_PROBE_NOMFMA) ||      \
+     defined(PANEL_PROBE_NOALOAD) || defined(PANEL_PROBE_NOASTORE) || defined(PANEL_PROBE_NOBLOAD) ||                         \
+     defined(PANEL_PROBE_NOREAD) || defined(PANEL_PROBE_NOCSTORE) || defined(GRP_NOMFMA) || defined(GRP_NOSTORE) ||           \
+     defined(GRP_NOXLOAD) || defined(GSP_NOMFMA) || defined(GSP_NOBLOAD) || defined(GSP_NOSTORE) || defined(GSP_NOXLOAD) ||   \
+     defined(XGP_NOMFMA) || defined(XGP_NOSTORE) || defined(XGP_NOXLOAD) || defined(AFP_NOPRELOAD) || defined(AFP_NOMFMA) ||  \
+     defined(AFP_NOEPI) || defined(AFP_NOBUILD) || defined(AFP_NOTAIL) || defined(AFP_NOINP)) &&                              \
+    !defined(SCORE_PROBE_BUILD)
+#error "a wrong-by-design probe switch needs -DSCORE_PROBE_BUILD (tools/*_probe.py pass it; score_amd/build.py never does)"
+#endif
+
 #define SCORE_CHECK_LAUNCH()                      \
   do {                                            \
     hipError_t e__ = hipGetLastError();           \

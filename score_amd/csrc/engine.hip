@@ -348,6 +348,19 @@ static int side_stream(const score_state_t* st, SideStream** out) {
   *out = &sd;
   return 0;
 }
+// debug_flags bit 12 (4096): no second stream at all -- everything the passes would fork runs on the caller's stream, in
+// launch order (the context's events are still recorded and waited for: on one stream those are no-ops).  What a
+// suspected stream race is compared against.
+static int side_stream(const score_state_t* st, hipStream_t s, SideStream** out) {
+  SideStream* real = nullptr;
+  SCORE_TRY(side_stream(st, &real));
+  if (!st || !(st->debug_flags & 4096)) { *out = real; return 0; }
+  static thread_local SideStream inl;
+  const hipStream_t was = inl.fwd_on;
+  inl = *real; inl.st = s; inl.fwd_on = was;
+  *out = &inl;
+  return 0;
+}
 // A/B switches of the launch sequence: score_state_t.debug_flags only (round 4: the environment switches of rounds 1 - 3 --
 // SCORE_WGRAD_SIDE / _EARLY, SCORE_PANEL_DX, SCORE_GEMM_TILED, SCORE_GRU_STEPWISE, SCORE_GRU_BIAS_COLSUM, SCORE_HEAD_UNFUSED,
 // SCORE_ATTN_*_UNFUSED -- were decided A/Bs or duplicates of a flag bit, and a process-wide switch read once cannot be
@@ -657,7 +670,7 @@ int forward_ps(const Dims& d, const Params& P, const WS& w, const PsPlan& pp, co
   hipStream_t ls = s;
   SideStream* sd = nullptr;
   if (st->loss_done_event) {
-    G(side_stream(st, &sd));
+    G(side_stream(st, s, &sd));
     HIPTRY(hipEventRecord(sd->fork, s));
     HIPTRY(hipStreamWaitEvent(sd->st, sd->fork, 0));
     ls = sd->st;
@@ -675,7 +688,7 @@ int backward_ps(const Dims& d, const Params& P, const WS& w, const PsPlan& pp, c
   const int B = bt->B, T = pp.s.A, H = d.H, BT = B * T;
   const int x3 = st->gemm_mode == 1 ? GF_X3 : 0;
   SideStream* side = nullptr;
-  G(side_stream(st, &side));
+  G(side_stream(st, s, &side));
   side->fwd_on = nullptr;
   // With score_state_t.grads_done_event everything that FINISHES grad_w -- the weight-gradient products, the column sums, the
   // slab reduce -- runs on the context's side stream behind the backward kernel, beside the row scatter on `stream`: at these
@@ -853,7 +866,7 @@ extern "C" int score_forward(const score_config_t* cfg, const score_state_t* st,
   // side stream: the L2 norm of the weights (needs no batch), then the attention's query branch (target rows and
   // weights only) -- beside the gather and the GRUs
   SideStream* sd = nullptr;
-  G(side_stream(st, &sd));
+  G(side_stream(st, s, &sd));
   HIPTRY(hipEventRecord(sd->fork, s));
   HIPTRY(hipStreamWaitEvent(sd->st, sd->fork, 0));
   sd->fwd_on = s;       // (score_backward on this stream next finds the side stream already behind everything before this pass)
@@ -1082,7 +1095,7 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
   // none).  Nothing on the main stream writes it before the side stream's join below -- every weight / bias
   // gradient is queued -- so the fill runs on the side stream, off the chain of dependent launches.
   SideStream* side = nullptr;
-  G(side_stream(st, &side));
+  G(side_stream(st, s, &side));
   // (the fill needs the side stream behind the LAST readers of grad_w -- the previous step's optimizer --, not behind this pass's
   //  forward: score_forward of this step, on this stream and context, forked the side stream behind them already.  A record between
   //  the head's forward and backward costs the launch stream a ~6-us bubble; only a caller that skipped the forward pays it.)

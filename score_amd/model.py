@@ -227,6 +227,7 @@ class SCOREBASE(object):
         self._st_cache = {}
         self._evs = {}
         self._ps_last = False           # the last forward_backward ran as the per-sample whole-model kernels
+        self._inline_on = False         # debug_flags bit 12 was set at the last forward_backward: every stream below IS the launch stream
         self._ev_dense = None
         self.w = torch.zeros((self.n_w,), **f32)
         self._alloc_optimizer()
@@ -797,9 +798,18 @@ class SCOREBASE(object):
         plan_done = None
         cur = self._cur()
         self._train_stream = cur
+        # debug_flags bit 12 (4096, score_hip.h): NO second stream anywhere -- the engine's forks, the index plan, the window
+        # slice, the look-ahead, the dense ApplyAdam and the early loss copy all run on the launch stream, in launch order
+        # (tests/test_gpu_model.py compares the overlap modes with it bit for bit; the first thing to try on a suspected race)
+        inline = bool(int(self.debug_flags) & 4096)
+        if inline != self._inline_on or (inline and self._side is not None and self._side.cuda_stream != cur.cuda_stream):
+            torch.cuda.synchronize(self.device)
+            self._side = self._sweep_st = self._early_loss_state["stream"] = None
+            self._plan_ready = None
+            self._inline_on = inline
         if self.scatter_mode == 0:
             if self._side is None:
-                self._side = torch.cuda.Stream(device=self.device)
+                self._side = cur if inline else torch.cuda.Stream(device=self.device)
                 self._side_handle = C.c_void_p(self._side.cuda_stream)
                 self._ev_gather = torch.cuda.Event()
                 self._ev_gather.record(cur)          # materialise the hipEvent_t
@@ -844,7 +854,8 @@ class SCOREBASE(object):
             # returns the loss every step) waits for the forward only and the host goes on queueing
             el = self._early_loss
             if el["stream"] is None:
-                el["stream"] = torch.cuda.Stream(device=self.device)
+                el["stream"] = cur if inline else torch.cuda.Stream(device=self.device)
+            if el["host"] is None:
                 el["host"] = torch.zeros((4,), dtype=torch.float32).pin_memory()
             el["stream"].wait_event(ev_loss if ev_loss is not None else cur.record_event())
             with torch.cuda.stream(el["stream"]), self._Unpin(self):
@@ -852,7 +863,7 @@ class SCOREBASE(object):
                 el["event"] = self._rec("early_loss", el["stream"])
         if fwd_stage is not None and self._pending_sweep is not None:
             if self._sweep_st is None:
-                self._sweep_st = torch.cuda.Stream(device=self.device)      # (its own stream: the occurrence sort must not queue behind it)
+                self._sweep_st = cur if inline else torch.cuda.Stream(device=self.device)      # (its own stream: the occurrence sort must not queue behind it)
             self._sweep_st.wait_event(self._fwd_stage_event)
             self._launch_sweep(self._sweep_st)
         if self.scatter_mode == 0:

@@ -67,3 +67,21 @@ def test_model_requires_gpu():
     from score_amd.model import SCORE
     with pytest.raises(RuntimeError):
         SCORE(100, 4, 8, 3, 2, 3, 4)
+
+
+def test_stripped_probe_kernels_cannot_reach_the_product_build():
+    """the timing probes' wrong-by-design switches (no loads / no matrix instruction / no stores) stop the preprocessor
+    unless -DSCORE_PROBE_BUILD is beside them, and build.py refuses that flag"""
+    import subprocess
+    from score_amd import build as b
+    src = os.path.join(b.CSRC, "gru.hip")
+    cmd = ["/opt/rocm/bin/hipcc"] + b.FLAGS + ["-E", "-DGRP_NOMFMA", src, "-o", os.devnull]
+    out = subprocess.run(cmd, capture_output=True, text=True)
+    assert out.returncode != 0 and "SCORE_PROBE_BUILD" in out.stderr
+    saved = list(b.FLAGS)
+    try:
+        b.FLAGS.append("-DSCORE_PROBE_BUILD")
+        with pytest.raises(RuntimeError):
+            b.build()
+    finally:
+        b.FLAGS[:] = saved

@@ -431,3 +431,54 @@ def test_side_stream_finishers_and_loss_do_not_change_a_bit():
             assert torch.equal(off.w_g, on.w_g) and torch.equal(off.dense_table_grad(), on.dense_table_grad())
             assert float(wo[lo.loss]) == float(wn[ln.loss])
     assert same_state(off, on)
+
+
+@pytest.mark.parametrize("mode", ["persample", "layered", "finishers", "slice_f1", "slice_plan", "sweep"])
+def test_everything_inline_on_the_launch_stream_equals_every_overlap_mode(mode):
+    """debug_flags bit 12 (4096, score_hip.h): NO second stream anywhere -- the engine's forks, the index plan (and the one
+    sorted a step ahead), the window slice, the look-ahead catch-up, the dense ApplyAdam and the early loss copy all run on
+    the launch stream in launch order.  Every overlap mode only MOVES launches: losses, predictions and the whole optimizer
+    state equal the inline run's bit for bit, hints right or wrong, with evaluations and table reads in between."""
+    H = 32 if mode in ("persample", "layered") else 16
+    cfg = so.Cfg(3000, 16, H, 5, 3, 2, 3, "SCORE")
+    window = 0 if mode == "sweep" else 5
+    a, b = make(cfg, window), make(cfg, window)
+    for m in (a, b):
+        if mode == "layered":
+            m.debug_flags = 512
+        if mode == "finishers":
+            m.overlap_finishers_min_rows = 0
+        if mode == "slice_f1":
+            m.adam_sweep_at = "f1"
+        if mode == "slice_plan":
+            m.adam_sweep_at = "plan"
+    b.debug_flags |= 4096
+    assert a.persample_form(8, 5) == (mode == "persample") and b.persample_form(8, 5) == (mode == "persample")
+    bs = batches(cfg, 16, 8, seed=33, hot_rows=150)
+    da, db_ = [a.device_batch(x) for x in bs[:6]], [b.device_batch(x) for x in bs[:6]]
+    order = [0, 1, 2, 3, 4, 5, 0, 2, 4, 1, 3, 5, 5, 0, 1, 1, 2, 3, 4, 0]
+    for i, bi in enumerate(order):
+        nxt = order[i + 1] if i + 1 < len(order) else 0
+        hint = None if i % 5 == 4 else (nxt + 1) % 6 if i % 7 == 3 else nxt
+        ha, hb = (None, None) if hint is None else (da[hint], db_[hint])
+        if i % 3 == 2:
+            la, lb = a.train(None, da[bi], 1e-2, 1e-4, keep_prob=0.8, next_batch=ha), b.train(None, db_[bi], 1e-2, 1e-4, keep_prob=0.8, next_batch=hb)
+        else:
+            la = float(a.train_async(da[bi], 1e-2, 1e-4, keep_prob=0.8, next_batch=ha))
+            lb = float(b.train_async(db_[bi], 1e-2, 1e-4, keep_prob=0.8, next_batch=hb))
+        assert la == lb, (mode, i, la, lb)
+        cur = torch.cuda.current_stream().cuda_stream
+        assert b._side is None or b._side.cuda_stream == cur
+        assert b._sweep_st is None or b._sweep_st.cuda_stream == cur
+        if i == 8:
+            assert a.eval(None, da[4], 1e-4)[0] == b.eval(None, db_[4], 1e-4)[0]
+        if i == 13:
+            assert same_state(a, b), (mode, i)
+    assert same_state(a, b), mode
+    if mode != "sweep":
+        assert a._side is not None and a._side.cuda_stream != torch.cuda.current_stream().cuda_stream
+    # the switch can be thrown on a live model: the next steps of `a`, now inline, still track `b`
+    a.debug_flags |= 4096
+    for bi in (2, 4, 1):
+        assert float(a.train_async(da[bi], 1e-2, 1e-4, keep_prob=0.8)) == float(b.train_async(db_[bi], 1e-2, 1e-4, keep_prob=0.8))
+    assert same_state(a, b), mode

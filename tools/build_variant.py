@@ -11,6 +11,9 @@ from score_amd import build as b      # noqa: E402
 
 
 def build_variant(name, sources, flags):
+    # variants keep results right (timing marks, alternative instruction choices); the stripped kernels of the *_probe.py
+    # tools are single-kernel builds of their own and never link into a whole library
+    assert not any("SCORE_PROBE_BUILD" in f for f in flags), "stripped kernels do not go into a loadable libscore_hip"
     b.build()
     objdir = os.path.join(b.HERE, "build", name)
     os.makedirs(objdir, exist_ok=True)

@@ -19,7 +19,7 @@ dout, dxproj, rh, hprev = r(2, B * T, H), torch.zeros(2, B * T, 3 * H, device="c
 P = lambda t: C.c_void_p(t.data_ptr())
 for name, defs in variants:
     so = os.path.join(tmp, "probe_%s.so" % name)
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-DSCORE_PROBE_BUILD",
                            "-Wno-pass-failed", "-I" + os.path.join(root, "include"), "-I" + os.path.join(root, "score_amd", "csrc")] + defs +
                           [os.path.join(root, "tools", "gru_reg_wrap.hip"), "-o", so])
     lib = C.CDLL(so)

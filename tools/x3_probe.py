@@ -27,7 +27,7 @@ tmp = tempfile.mkdtemp()
 libs = {}
 for name, defs in variants:
     so = os.path.join(tmp, "probe_%s.so" % name)
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-DSCORE_PROBE_BUILD",
                            "-I" + os.path.join(root, "include"), "-I" + os.path.join(root, "score_amd", "csrc")] + defs +
                           [os.path.join(root, "tools", "x3_probe_wrap.hip"), "-o", so])
     libs[name] = C.CDLL(so)

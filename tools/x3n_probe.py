@@ -8,7 +8,7 @@ sys.path.insert(0, root)
 from score_amd import _lib
 lib = _lib.load()
 so = os.path.join(tempfile.mkdtemp(), "x3n.so")
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-result",
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-DSCORE_PROBE_BUILD", "-Wno-unused-result",
                        "-I" + os.path.join(root, "include"), "-I" + os.path.join(root, "score_amd", "csrc")] +
                       [a for a in sys.argv[1:] if a.startswith("-D")] + [os.path.join(root, "tools", "x3n", "x3n_probe.hip"), "-o", so])
 x = C.CDLL(so)
