@@ -202,6 +202,29 @@ class TemporalGraph(object):
         off, nbr = c["off%d" % hop], c["nbr%d" % hop]
         return nbr[off[e * self.S + t]:off[e * self.S + t + 1]]
 
+    # ---- one file per graph (what a db_name of the reference resolves to, see GraphLoader) ---------------
+    def save(self, path):
+        """The graph as ONE .npz file: the CSR arrays of both sides, the feature rows, the 2-hop degree lists if kept."""
+        a = {"dims": np.asarray([self.U, self.I, self.S], dtype=np.int64), "user_rows": self.user_rows, "item_rows": self.item_rows}
+        for side, c in (("u", self.user_csr), ("i", self.item_csr)):
+            for k in ("off1", "nbr1", "off2", "nbr2"):
+                a["%s_%s" % (side, k)] = np.asarray(c[k])
+        if self.user_degrees is not None and self.item_degrees is not None:
+            a["u_deg2"], a["i_deg2"] = np.asarray(self.user_degrees, dtype=np.int32), np.asarray(self.item_degrees, dtype=np.int32)
+        with open(path, "wb") as f:
+            np.savez(f, **a)
+        return path
+
+    @classmethod
+    def load(cls, path):
+        with np.load(path) as z:
+            U, I, S = [int(x) for x in z["dims"]]
+            side = lambda p: {k: z["%s_%s" % (p, k)] for k in ("off1", "nbr1", "off2", "nbr2")}
+            g = cls(U, I, S, side("u"), side("i"), z["user_rows"], z["item_rows"])
+            if "u_deg2" in z.files:
+                g.user_degrees, g.item_degrees = z["u_deg2"], z["i_deg2"]
+        return g
+
     # ---- device residency -------------------------------------------------------------
     def to_device(self, device=None, mode="rs"):
         """mode: GraphHandler's 2-hop sampling mode -- 'rs' uniform (what train_score.py uses for all three data sets),
@@ -253,9 +276,10 @@ class _AssembledBatch(DeviceBatch):
 
 
 class DeviceGraphLoader(object):
-    """Iterator with the constructor shape of GraphLoader (graph_loader.py:279-281); yields device
-    batches accepted by SCORE.train / SCORE.eval.  `target_lines`: iterable of 'uid,pos_iid,neg...'
-    strings or of (uid, [iids]) pairs (gen_target.py's target_<t>.txt format)."""
+    """Iterator over device batches accepted by SCORE.train / SCORE.eval, from a TemporalGraph object and target lines in
+    memory (`target_lines`: iterable of 'uid,pos_iid,neg...' strings or of (uid, [iids]) pairs -- gen_target.py's
+    target_<t>.txt format).  NOT the reference's constructor: `GraphLoader` below has that one (graph_loader.py:279-281)
+    and resolves its arguments to this class."""
 
     def __init__(self, graph, batch_size, target_lines, start_time, pred_time, neg_sample_num,
                  max_time_len, obj_per_time_slice, seed=1111):
@@ -308,3 +332,66 @@ class DeviceGraphLoader(object):
         self._batch_no += 1
         length = self.pred_time - self.start_time
         return _AssembledBatch(tens, B, length if 0 < length < T else 0, flat)
+
+
+# ---- the reference's call site (train_score.py:150, 222) ---------------------------------------------------------------
+_GRAPHS = {}
+
+
+def register_graph(db_name, graph):
+    """What `db_name` (graph_handler_params[1]: the MongoDB database graph_storage.py filled, e.g. 'tmall_2hop') stands for
+    here: a TemporalGraph, or the path of a file written by TemporalGraph.save (read on first use).  The documents'
+    content -- per (entity, slice) a 1-hop list and a sampled 2-hop list, graph_storage.py:78-246 -- is what
+    TemporalGraph.from_log builds; the database itself is out of scope (storage engine)."""
+    _GRAPHS[str(db_name)] = graph
+
+
+def resolve_graph(db_name):
+    g = _GRAPHS.get(str(db_name))
+    if g is None:
+        raise KeyError("no graph registered for db_name %r (score_amd.graph.register_graph(db_name, TemporalGraph | file))" % (db_name,))
+    if not isinstance(g, TemporalGraph):
+        g = TemporalGraph.load(g)
+        _GRAPHS[str(db_name)] = g
+    return g
+
+
+class GraphLoader(DeviceGraphLoader):
+    """GraphLoader(graph_handler_params, batch_size, target_file, start_time, pred_time, worker_n, neg_sample_num)
+    -- the reference's constructor, argument for argument (graph_loader.py:279-281; graph_handler_params as GraphHandler
+    takes them, :41-55: [time_slice_num, db_name, obj_per_time_slice, user_num, item_num, start_time, user_per_collection,
+    item_per_collection, mode, user_feat_dict_file, item_feat_dict_file, user_fnum, item_fnum]), so train_score.py:150, 222
+    swap by import as the model does.  Yields the same 8 tensors per batch (:383), on the device.
+
+    db_name -> a registered TemporalGraph (register_graph); target_file is read as the reference reads it (:293-294);
+    history length = time_slice_num - start_time - 1 (:252-254).  worker_n / max_q_size / wait_time are accepted and unused:
+    a batch is ONE kernel launch, there are no loader processes to size.  user_per_collection / item_per_collection (the
+    sharding of the Mongo collections) and the two feat-dict files (the graph carries the feature rows) are unused too.
+    Errors: ValueError where the reference prints and exits (batch size not a multiple of 1 + neg_sample_num, :289-291; a
+    mode other than 'is' / 'rs', :248) or where the graph contradicts the parameters."""
+
+    def __init__(self, graph_handler_params, batch_size, target_file, start_time, pred_time, worker_n, neg_sample_num,
+                 max_q_size=10, wait_time=0.01, seed=1111):
+        (time_slice_num, db_name, obj_per_time_slice, user_num, item_num, gh_start_time, _upc, _ipc, mode, _uf, _if,
+         user_fnum, item_fnum) = graph_handler_params
+        g = resolve_graph(db_name)
+        if (g.U, g.I, g.Fu, g.Fi) != (int(user_num), int(item_num), int(user_fnum), int(item_fnum)):
+            raise ValueError("graph %r has (users, items, user_fnum, item_fnum) = %r, graph_handler_params say %r"
+                             % (db_name, (g.U, g.I, g.Fu, g.Fi), (user_num, item_num, user_fnum, item_fnum)))
+        if int(gh_start_time) != int(start_time):
+            raise ValueError("GraphHandler start_time %r != GraphLoader start_time %r (one value in train_score.py)"
+                             % (gh_start_time, start_time))
+        if int(time_slice_num) > g.S or int(pred_time) > g.S:
+            raise ValueError("the graph holds %d time slices, asked for %r (pred_time %r)" % (g.S, time_slice_num, pred_time))
+        if g._dev is None or getattr(g, "mode", None) != mode:
+            g.to_device(mode=mode)
+        with open(target_file, "r") as f:
+            lines = f.readlines()
+        self.worker_n, self.max_q_size, self.wait_time = worker_n, max_q_size, wait_time
+        super(GraphLoader, self).__init__(g, batch_size, lines, int(start_time), int(pred_time), int(neg_sample_num),
+                                          int(time_slice_num) - int(gh_start_time) - 1, int(obj_per_time_slice), seed=seed)
+        self.num_of_batch = len(self)           # (:295-297)
+
+    def stop(self):
+        """graph_loader.py:399-402 ends its processes here; nothing to end"""
+        return None

@@ -433,7 +433,7 @@ def test_side_stream_finishers_and_loss_do_not_change_a_bit():
     assert same_state(off, on)
 
 
-@pytest.mark.parametrize("mode", ["persample", "layered", "finishers", "slice_f1", "slice_plan", "sweep"])
+@pytest.mark.parametrize("mode", ["persample", "layered", "finishers", "slice_f1", "slice_plan", "sweep", "wide", "wide_finishers"])
 def test_everything_inline_on_the_launch_stream_equals_every_overlap_mode(mode):
     """debug_flags bit 12 (4096, score_hip.h): NO second stream anywhere -- the engine's forks, the index plan (and the one
     sorted a step ahead), the window slice, the look-ahead catch-up, the dense ApplyAdam and the early loss copy all run on
@@ -441,12 +441,14 @@ def test_everything_inline_on_the_launch_stream_equals_every_overlap_mode(mode):
     state equal the inline run's bit for bit, hints right or wrong, with evaluations and table reads in between."""
     H = 32 if mode in ("persample", "layered") else 16
     cfg = so.Cfg(3000, 16, H, 5, 3, 2, 3, "SCORE")
+    if mode.startswith("wide"):          # a third shape: D = 64 / H = 128 (the bf16x3 products and register-resident recurrences of cfg-3)
+        cfg = so.Cfg(5000, 64, 128, 5, 3, 3, 4, "SCORE")
     window = 0 if mode == "sweep" else 5
     a, b = make(cfg, window), make(cfg, window)
     for m in (a, b):
         if mode == "layered":
             m.debug_flags = 512
-        if mode == "finishers":
+        if mode in ("finishers", "wide_finishers"):
             m.overlap_finishers_min_rows = 0
         if mode == "slice_f1":
             m.adam_sweep_at = "f1"

@@ -167,3 +167,52 @@ def test_degree_weighted_2hop_sampling_mode_is(tag):
     g.to_device(mode="rs")
     b = next(DeviceGraphLoader(g, len(lines), lines, st, pred, 0, T, K, seed=1000))
     assert np.array_equal(b.tensors[0].cpu().numpy(), first[0])
+
+
+@pytest.mark.parametrize("tag", ["f34", "f12"])
+def test_graphloader_with_the_references_constructor(tag, tmp_path):
+    """GraphLoader(graph_handler_params, batch_size, target_file, start_time, pred_time, worker_n, neg_sample_num) --
+    train_score.py:150, 222's call, argument for argument -- over a graph FILE registered under the db_name: the 1-hop tensors
+    and target rows equal the reference loader's batches of g4 exactly, and every tensor equals what DeviceGraphLoader yields
+    from the same graph object and lines (same seed)."""
+    from score_amd.graph import DeviceGraphLoader, GraphLoader, TemporalGraph, register_graph, resolve_graph
+    g, (U, I, S, K, Fu, Fi, st) = build(tag)
+    register_graph("g4_%s_2hop" % tag, g.save(str(tmp_path / "graph.npz")))
+    params = [S, "g4_%s_2hop" % tag, K, U, I, st, 1000, 1000, "rs", None, None, Fu, Fi]
+    pred_time = S - 3
+    p = "%s_p%d/" % (tag, pred_time)
+    uids, iids = Z[p + "uids"].tolist(), Z[p + "iids"].tolist()
+    target = tmp_path / "target.txt"
+    target.write_text("".join("%d,%d\n" % (u, i) for u, i in zip(uids, iids)))
+    loader = GraphLoader(params, len(uids), str(target), st, pred_time, 8, 0)
+    assert isinstance(resolve_graph("g4_%s_2hop" % tag), TemporalGraph) and loader.num_of_batch == 1
+    b = next(loader)
+    got = [t.cpu().numpy() for t in b.tensors]
+    assert np.array_equal(got[0], Z[p + "user_1hop"]) and np.array_equal(got[2], Z[p + "item_1hop"])
+    assert np.array_equal(got[4], Z[tag + "/user_feat"][np.asarray(uids) - 1])
+    assert np.array_equal(got[5], Z[tag + "/item_feat"][np.asarray(iids) - U - 1])
+    assert got[7].tolist() == [pred_time - st] * len(uids)
+    with pytest.raises(StopIteration):
+        next(loader)
+    loader.stop()
+    # 1 + 1 candidates per line, three lines a batch, a short last batch: the same batches as the object-level loader
+    rng = np.random.default_rng(3)
+    lines = ["%d,%d,%d\n" % (rng.integers(1, U + 1), rng.integers(U + 1, U + I + 1), rng.integers(U + 1, U + I + 1)) for _ in range(7)]
+    target.write_text("".join(lines))
+    a = GraphLoader(params, 6, str(target), st, S - 2, 8, 1, seed=5)
+    d = DeviceGraphLoader(g, 6, lines, st, S - 2, 1, S - 1 - st, K, seed=5)
+    assert len(a) == len(d) == 3
+    n = 0
+    for x, y in zip(a, d):
+        assert x.B == y.B and x.active_slices == y.active_slices and all(torch.equal(s, t) for s, t in zip(x.tensors, y.tensors))
+        n += 1
+    assert n == 3
+    # where the reference prints and exits, or the parameters contradict the graph
+    with pytest.raises(ValueError):
+        GraphLoader(params, 5, str(target), st, S - 2, 8, 1)
+    with pytest.raises(ValueError):
+        GraphLoader(params[:3] + [U + 1] + params[4:], 6, str(target), st, S - 2, 8, 1)
+    with pytest.raises(ValueError):
+        GraphLoader(params[:8] + ["xx"] + params[9:], 6, str(target), st, S - 2, 8, 1)
+    with pytest.raises(KeyError):
+        GraphLoader(params[:1] + ["nobody_2hop"] + params[2:], 6, str(target), st, S - 2, 8, 1)

@@ -198,3 +198,26 @@ def test_sort_based_build_equals_the_list_build():
         over = (np.diff(a.user_csr["off1"]) > m1).sum() + (np.diff(a.item_csr["off1"]) > m1).sum()
         capped = (np.diff(a.user_csr["off2"]) == m2).sum() + (np.diff(a.item_csr["off2"]) == m2).sum()
         assert seed == 4 or (over > 0 and capped > 0)            # the random paths were really taken
+
+
+def test_graph_file_round_trip(tmp_path):
+    """TemporalGraph.save / load: what a db_name of the reference's graph_handler_params resolves to (graph.register_graph)"""
+    from score_amd.graph import TemporalGraph, register_graph, resolve_graph
+    rng = np.random.default_rng(4)
+    n, U, I, S = 400, 12, 20, 5
+    uid, iid, t = rng.integers(1, U + 1, n), rng.integers(U + 1, U + I + 1, n), rng.integers(0, S, n)
+    urows = np.concatenate([np.arange(1, U + 1)[:, None], rng.integers(40, 50, (U, 1))], 1).astype(np.int32)
+    irows = np.concatenate([np.arange(U + 1, U + I + 1)[:, None], rng.integers(50, 60, (I, 2))], 1).astype(np.int32)
+    g = TemporalGraph.from_log(uid, iid, t, U, I, S, urows, irows, max_1hop=4, max_2hop=6, seed=2)
+    h = TemporalGraph.load(g.save(str(tmp_path / "g.npz")))
+    assert (h.U, h.I, h.S, h.Fu, h.Fi) == (g.U, g.I, g.S, g.Fu, g.Fi)
+    for a, b in ((g.user_csr, h.user_csr), (g.item_csr, h.item_csr)):
+        assert all(np.array_equal(a[k], b[k]) for k in ("off1", "nbr1", "off2", "nbr2"))
+    assert np.array_equal(g.user_rows, h.user_rows) and np.array_equal(g.item_rows, h.item_rows)
+    assert (g.user_degrees is None) == (h.user_degrees is None)
+    if g.user_degrees is not None:
+        assert np.array_equal(g.user_degrees, h.user_degrees) and np.array_equal(g.item_degrees, h.item_degrees)
+    register_graph("t_2hop", str(tmp_path / "g.npz"))
+    assert resolve_graph("t_2hop").U == U and resolve_graph("t_2hop") is resolve_graph("t_2hop")
+    with pytest.raises(KeyError):
+        resolve_graph("missing_2hop")
