@@ -563,6 +563,13 @@ def main():
                 # with a next batch the step is pipelined: the optimizer runs inside (apply_adam below is then a no-op)
                 fb = model.forward_backward(batches[i % len(batches)], args.reg_lambda, 0.8, None, nxt,
                                             lr=args.lr if args.pipeline else None)
+            elif events is None or i not in events:
+                # the model's own one-call step (score.py:101-116 is one sess.run): forward_backward + apply_adam inside -- and, in the
+                # steady state of the per-sample form, one call into the library for the whole step (score_train_step)
+                nb = batches[(i + 1) % len(batches)] if look_ahead else None
+                last_loss[0] = model.train_async(batches[i % len(batches)], args.lr, args.reg_lambda, 0.8, None, nb)
+                fb = inner._workspace(batches[i % len(batches)].B) if hasattr(batches[i % len(batches)], "B") else fb
+                continue
             else:
                 fb = model.forward_backward(batches[i % len(batches)], args.reg_lambda, 0.8)
             if e_a0 is not None:

@@ -42,6 +42,12 @@ typedef void* score_context_t;
 int score_context_create(score_context_t* ctx);
 /* ctx == NULL: release the process-wide default contexts.  Synchronises the context's stream first. */
 int score_context_destroy(score_context_t ctx);
+/* A context also owns a few words of device memory for the launches that run dependent phases with a barrier across their
+ * workgroups instead of a launch boundary (round 5: the index plan's sort in one launch; csrc/common.h score_grid_sync;
+ * opt-in, score_state_t.debug_flags bit 13).  The wait at such a barrier is bounded: *errors = how many of them have EVER timed
+ * out in this context (0 unless a grid was not co-resident for ~0.2 s; results of that launch are then wrong).  Synchronous
+ * (one small device-to-host copy); ctx == NULL: the current device's default context.                                        */
+int score_context_sync_errors(score_context_t ctx, int32_t* errors);
 
 /* The scalars of a training step that change from step to step, kept in DEVICE memory so that a captured step
  * (hipGraph: small shapes are launch-bound, ~60 launches of a few microseconds each) can be replayed with new
@@ -384,7 +390,11 @@ typedef struct {
                            (1024) = take them for the forward pass only, bit 11 (2048) = for the backward pass only;
                            bit 12 (4096) = NO second stream: everything score_forward / score_backward would fork onto
                            the context's side stream runs on `stream`, in launch order (same results bit for bit; what
-                           a suspected stream race is compared against -- score_amd.model inlines its own streams too).
+                           a suspected stream race is compared against -- score_amd.model inlines its own streams too);
+                           bit 13 (8192) = the index plan's sort as ONE launch with barriers across its workgroups between
+                           the phases (score_grid_sync; up to 524 K occurrences) instead of six launches: same bits, one
+                           launch call for the host -- and slower on the device (the barriers' agent-scope fences write
+                           back / invalidate every XCD's L2 under the kernels running beside it): off by default.
                            The ONLY switches of the launch sequence: the library reads no environment variable       */
   uint8_t* row_flags;   /* optional [n_table_rows] row state of the dense table optimizer (see
                            score_adam_rows): score_backward (scatter_mode 0) marks every row it
@@ -425,7 +435,13 @@ typedef struct {
                            recorded behind it -- the head's successor on `stream` (score_backward's first launch) no longer queues
                            behind a one-block kernel.  loss[] is final once the event has fired; on `stream` it is final behind
                            score_backward of the same step (which joins the side stream), not behind score_forward alone.  NULL:
-                           on `stream`, as before (evaluation: nothing follows the forward pass).                        */
+                           on `stream`, as before (evaluation: nothing follows the forward pass).
+                           (The per-sample whole-model forward kernel reduces the loss itself -- its last workgroup to finish
+                           does it, round 5 -- so there the event is simply recorded on `stream` behind that kernel.)      */
+  float* loss_host;       /* optional: four floats of PINNED HOST memory mapped into the device (hipHostMalloc): the per-sample
+                           forward kernel also stores loss[0..3] there (system scope), so a caller that returns the loss every
+                           step (score.py:101-116) reads it after waiting for an event recorded behind score_forward -- no copy,
+                           no extra stream.  Ignored by the layer-by-layer pass (score_persample_form tells which runs).   */
 } score_state_t;
 
 /* Synchronous query of a score_state_t.id_status word: copies it to *bits (optional), waits for `stream`, clears the
@@ -517,6 +533,61 @@ int score_forward(const score_config_t* cfg, const score_state_t* st, const scor
 int score_backward(const score_config_t* cfg, const score_state_t* st, const score_batch_t* batch,
                    float keep_prob, float* grad_w, float* grad_table, void* const* stage_events,
                    void* stream);
+
+/* ---- one training step in one call (csrc/step.hip) -----------------------------------------------------------------------
+ * The steady-state step of model.train (score.py:101-116) for a caller that runs the time-tiled table optimizer with the
+ * look-ahead (score_adam_catchup_ids_through) and sorts the next batch's index plan a step ahead: exactly
+ *   wait(ev_ahead), wait(ev_sweep)                                   [stream]   if wait_ahead / wait_sweep
+ *   score_forward(..., loss_done_event = ev_loss, loss_host)         [stream]
+ *   score_backward(plan_done_event = ev_plan, grads_done_event = ev_grads, stage events 2 / 4 = ev_stage2 / ev_b4)   [stream]
+ *   wait(ev_stage2); score_adam_catchup_rows(slice); record(ev_sweep)                       [side_stream]   if slice_hi > slice_lo
+ *   wait(ev_b4); score_adam_catchup_ids_through(next ids, step, alpha); record(ev_ahead);
+ *                score_index_plan(next batch -> next_workspace); record(ev_plan)            [side_stream]   if next_batch
+ *   wait(ev_grads); score_adam_touched_and_dense(step, alpha, l2 = reg_lambda)              [stream]
+ * -- the same entry points with the same arguments a caller would use one by one (the events are the caller's, re-used from
+ * call to call: every wait above is issued before the same call re-records its event).  PRECONDITIONS the caller guarantees:
+ * the batch's rows are up to date through step - 1 (the previous call named this batch as next_batch, or the caller ran
+ * score_adam_catchup_ids), ev_plan is recorded behind THIS batch's index plan in st->workspace, no row is in state 2.
+ * What it saves is host time between the calls (the reference's own batch sizes are bound by it), nothing on the device. */
+typedef struct {
+  const score_adam_table_t* table;                       /* the embedding table's optimizer state (g = grad_table of the passes) */
+  float* w; float* w_m; float* w_v; float* w_g;          /* flat dense variables, their Adam slots and gradient [n_w]           */
+  int64_t n_w, n_reg;
+  int32_t* skipped;                                      /* optional score_guard_t.skipped                                      */
+  float reg_lambda, keep_prob, alpha;
+  uint32_t step;                                         /* the optimizer step being applied (1-based)                          */
+  uint64_t drop_seed;
+  int64_t slice_lo, slice_hi; uint32_t slice_upto;       /* the window slice of this step (score_adam_catchup_rows)             */
+  int32_t wait_ahead, wait_sweep;
+  const score_batch_t* next_batch; const int32_t* next_ids; int64_t n_next_ids;      /* optional: the batch the NEXT call trains on */
+  float* next_workspace; int64_t next_workspace_bytes;
+  float* loss_host;                                      /* optional, see score_state_t.loss_host                               */
+  void* side_stream;
+  void* ev_ahead; void* ev_sweep; void* ev_plan; void* ev_stage2; void* ev_b4; void* ev_grads; void* ev_loss;   /* hipEvent_t */
+} score_train_step_t;
+int score_train_step(const score_config_t* cfg, const score_state_t* st, const score_batch_t* batch, const score_train_step_t* p,
+                     void* stream);
+
+/* ---- launches issued by a second host thread (csrc/async.hip) ----------------------------------------------------------
+ * At the reference's own batch sizes the step is bound by the ONE host thread that queues it; these hand the calls that start
+ * side-stream work -- the next batch's index plan, the look-ahead catch-up of its rows, the optimizer's window slice -- to a
+ * worker thread of the library (one per process, started on first use).  Each takes the arguments of the call it stands for (by
+ * value: the structs may be reused at once), then: the stream, up to three hipEvent_t the stream waits for first
+ * (hipStreamWaitEvent), an optional hipEvent_t recorded behind the work, and a ticket.
+ * THE CALLER'S DUTY: score_async_wait(ticket) before anything waits for, re-records or destroys an event the job names, frees a
+ * buffer it uses, or synchronises the device expecting the job's work to be part of it -- it returns once the worker has
+ * ISSUED the job (not executed: that is what the events are for), with the job's error code if it failed (the first failure
+ * since the last wait; the record event is recorded even then).  ticket 0 = everything submitted so far.
+ * Not for use inside a stream capture. */
+int score_async_index_plan(const score_config_t* cfg, const score_state_t* st, const score_batch_t* batch, int32_t n_shards,
+                           int32_t dedup, void* stream, void* const* wait_events, int32_t n_wait, void* record_event,
+                           uint64_t* ticket);
+int score_async_adam_catchup_ids_through(const score_adam_table_t* t, const int32_t* ids, int64_t n_ids, uint32_t step,
+                                         float alpha, void* stream, void* const* wait_events, int32_t n_wait,
+                                         void* record_event, uint64_t* ticket);
+int score_async_adam_catchup_rows(const score_adam_table_t* t, int64_t row_begin, int64_t row_end, uint32_t upto, void* stream,
+                                  void* const* wait_events, int32_t n_wait, void* record_event, uint64_t* ticket);
+int score_async_wait(uint64_t ticket);
 
 /* ---- "next" row f1: batch assembly on the device -------------------------------------- */
 

@@ -46,7 +46,7 @@ class State(C.Structure):
                 ("gemm_mode", C.c_int32), ("debug_flags", C.c_int32), ("row_flags", C.c_void_p),
                 ("gather_done_event", C.c_void_p), ("plan_done_event", C.c_void_p), ("step_scalars", C.c_void_p),
                 ("context", C.c_void_p), ("id_status", C.c_void_p), ("grads_done_event", C.c_void_p),
-                ("loss_done_event", C.c_void_p)]
+                ("loss_done_event", C.c_void_p), ("loss_host", C.c_void_p)]
 
 
 class Graph(C.Structure):
@@ -67,6 +67,18 @@ class AdamTable(C.Structure):
                 ("D", C.c_int32), ("reserved", C.c_int32), ("row_flags", C.c_void_p), ("row_step", C.c_void_p),
                 ("alpha_ring", C.c_void_p), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
                 ("reserved2", C.c_int32), ("id_status", C.c_void_p), ("skipped_steps", C.c_void_p)]
+
+
+class TrainStep(C.Structure):
+    """score_train_step_t"""
+    _fields_ = [("table", C.c_void_p), ("w", C.c_void_p), ("w_m", C.c_void_p), ("w_v", C.c_void_p), ("w_g", C.c_void_p),
+                ("n_w", C.c_int64), ("n_reg", C.c_int64), ("skipped", C.c_void_p), ("reg_lambda", C.c_float),
+                ("keep_prob", C.c_float), ("alpha", C.c_float), ("step", C.c_uint32), ("drop_seed", C.c_uint64),
+                ("slice_lo", C.c_int64), ("slice_hi", C.c_int64), ("slice_upto", C.c_uint32), ("wait_ahead", C.c_int32),
+                ("wait_sweep", C.c_int32), ("next_batch", C.c_void_p), ("next_ids", C.c_void_p), ("n_next_ids", C.c_int64),
+                ("next_workspace", C.c_void_p), ("next_workspace_bytes", C.c_int64), ("loss_host", C.c_void_p),
+                ("side_stream", C.c_void_p), ("ev_ahead", C.c_void_p), ("ev_sweep", C.c_void_p), ("ev_plan", C.c_void_p),
+                ("ev_stage2", C.c_void_p), ("ev_b4", C.c_void_p), ("ev_grads", C.c_void_p), ("ev_loss", C.c_void_p)]
 
 
 class Guard(C.Structure):
@@ -135,6 +147,15 @@ _SIGS = {
     "score_auc_scratch_bytes": [C.c_int64],
     "score_ranking_quality": [c_f, c_i, C.c_int64, C.c_int32, c_f, c_i, c_f, C.c_int64, C.c_void_p],
     "score_persample_form": [C.POINTER(Config), C.POINTER(State), C.c_int32, C.c_int32],
+    "score_context_sync_errors": [C.c_void_p, C.POINTER(C.c_int32)],
+    "score_async_index_plan": [C.POINTER(Config), C.POINTER(State), C.POINTER(Batch), C.c_int32, C.c_int32, C.c_void_p,
+                               C.POINTER(C.c_void_p), C.c_int32, C.c_void_p, C.POINTER(C.c_uint64)],
+    "score_async_adam_catchup_ids_through": [C.POINTER(AdamTable), C.c_void_p, C.c_int64, C.c_uint32, C.c_float, C.c_void_p,
+                                             C.POINTER(C.c_void_p), C.c_int32, C.c_void_p, C.POINTER(C.c_uint64)],
+    "score_async_adam_catchup_rows": [C.POINTER(AdamTable), C.c_int64, C.c_int64, C.c_uint32, C.c_void_p,
+                                      C.POINTER(C.c_void_p), C.c_int32, C.c_void_p, C.POINTER(C.c_uint64)],
+    "score_async_wait": [C.c_uint64],
+    "score_train_step": [C.POINTER(Config), C.POINTER(State), C.POINTER(Batch), C.POINTER(TrainStep), C.c_void_p],
     "score_gemm_forms": [C.POINTER(Config), C.POINTER(State), C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)],
     "score_forward": [C.POINTER(Config), C.POINTER(State), C.POINTER(Batch), C.c_float, C.c_float, C.c_void_p,
                       C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p), C.c_void_p],

@@ -28,6 +28,23 @@ struct TiledArgs {
 };
 __device__ __forceinline__ bool tiled_guarded(const TiledArgs& a) { return a.guard && *a.guard; }
 
+// Publishing a row's ApplyAdam of step `upto` (state 2 -> 1) while OTHER kernels run beside this one (round 5: the window
+// slice and the look-ahead catch-up of the next batch's rows on the side stream no longer wait for / hold up the touched-row
+// update): those kernels take a row for lagging when they read state 1 and row_step < upto, and must never see the new state
+// with the old count (they would replay step `upto` on a row that already has it, with a zero gradient).  The count is
+// written first, through to memory (agent scope), and the state byte only when that store has been acknowledged; readers
+// load the count past their caches (tiled_row_step): a fresh state 1 then always comes with the fresh count, a stale state
+// byte reads 2 (the row looks busy: skipped).  Concurrent kernels have no kernel boundary between them to make plain
+// loads coherent across the XCDs' L2s.
+__device__ __forceinline__ void tiled_publish_applied(const TiledArgs& a, int64_t row, uint32_t upto) {
+  __hip_atomic_store(&a.step[row], upto, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  a.flags[row] = 1;
+}
+__device__ __forceinline__ uint32_t tiled_row_step(const TiledArgs& a, int64_t row) {
+  return __hip_atomic_load(&a.step[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __device__ __forceinline__ int tiled_lane() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
 // Sub-group `sg` of the wave takes the sg-th set bit of `mask` (a lane index), and the first `nper` set bits
@@ -56,6 +73,7 @@ template <int MODE>
 __device__ __forceinline__ void tiled_rows(const TiledArgs& a, uint64_t mask, int my_row, uint32_t my_old, uint32_t upto,
                                            float alpha_now, float areg, int lane) {
   const int nper = SCORE_WAVE / a.LPR, sg = lane / a.LPR, ch4 = (lane % a.LPR) * 4;
+  int64_t pend = -1;            // MODE 0: row whose count is on its way to memory; its state byte follows (tiled_publish_applied)
   while (mask) {
     const int src = tiled_pick(mask, sg, nper);
     const int srcl = src < 0 ? 0 : src;
@@ -74,8 +92,14 @@ __device__ __forceinline__ void tiled_rows(const TiledArgs& a, uint64_t mask, in
         score_adam1(p.y, m.y, v.y, g.y, a.omb1, a.omb2, alpha_now, a.eps);
         score_adam1(p.z, m.z, v.z, g.z, a.omb1, a.omb2, alpha_now, a.eps);
         score_adam1(p.w, m.w, v.w, g.w, a.omb1, a.omb2, alpha_now, a.eps);
+        // (the previous trip's rows: this trip's loads have returned, so -- memory operations of a wave complete in order --
+        //  has the count's store; the wait below is free)
+        if (pend >= 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); a.flags[pend] = 1; pend = -1; }
         st4(a.p + e, p); st4(a.m + e, m); st4(a.v + e, v);
-        if (ch4 == 0) { a.flags[row] = 1; a.step[row] = upto; }
+        if (ch4 == 0) {
+          __hip_atomic_store(&a.step[row], upto, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          pend = row;
+        }
       }
     } else {
       const uint32_t smin = (uint32_t)__builtin_amdgcn_readfirstlane((int)tiled_wave_min(on ? old : upto));
@@ -100,6 +124,27 @@ __device__ __forceinline__ void tiled_rows(const TiledArgs& a, uint64_t mask, in
       }
     }
   }
+  if (MODE == 0 && pend >= 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); a.flags[pend] = 1; }
+}
+
+// The scans of the state bytes: SCAN_V consecutive rows' bytes per lane in one load (bytes beyond n_rows read as 0).
+// SCAN_V = 4 where the rows are narrow (D <= 32: the reference's own eb_dim 16 -- a batch touches 0.1 % of the rows and the
+// scan itself is the kernel: 5.4 M rows, 7,600 hits, 35 us with a byte per lane); 1 where they are wide (cfg-3: 12 % of the rows
+// hit, the row traffic is the kernel, and four times fewer waves each working through four times the hits was 2x SLOWER).
+template <int SCAN_V>
+__device__ __forceinline__ uint32_t tiled_load_states(const uint8_t* __restrict__ flags, int64_t r0, int64_t n_rows) {
+  if (SCAN_V == 1) return r0 < n_rows ? (uint32_t)flags[r0] : 0u;
+  if (r0 + SCAN_V <= n_rows && (reinterpret_cast<uintptr_t>(flags + r0) & 3) == 0)      // (r0 is a multiple of SCAN_V: aligned whenever the array is)
+    return *reinterpret_cast<const uint32_t*>(flags + r0);
+  uint32_t f = 0;
+  for (int j = 0; j < SCAN_V; ++j)
+    if (r0 + j < n_rows) f |= (uint32_t)flags[r0 + j] << (8 * j);
+  return f;
+}
+// does any byte of f equal `state` (1 .. 3)?
+__device__ __forceinline__ bool tiled_has_state(uint32_t f, uint32_t state) {
+  const uint32_t x = f ^ (state * 0x01010101u);
+  return ((x - 0x01010101u) & ~x & 0x80808080u) != 0u;
 }
 
 // rows whose state byte is 2: the step's ApplyAdam from their gradient.  One lane per row scans the state bytes.
@@ -123,6 +168,7 @@ __device__ __forceinline__ uint32_t tiled_applied(const TiledArgs& a, uint32_t s
   return step - 1 > sk ? step - 1 - sk : 0u;
 }
 // `drop` (score_adam_unmark) or a set guard word: nothing is applied (tiled_unmark_row).  Virtual block blk of nblk.
+template <int SCAN_V>
 __device__ __forceinline__ void adam_touched_body(const TiledArgs& a, uint32_t step, float alpha, int drop, int blk, int nblk) {
   const int lane = tiled_lane();
   const int64_t stride = (int64_t)nblk * blockDim.x;
@@ -133,16 +179,22 @@ __device__ __forceinline__ void adam_touched_body(const TiledArgs& a, uint32_t s
     return;
   }
   if (blk == 0 && threadIdx.x == 0) a.ring[step % SCORE_ADAM_RING] = alpha;
-  for (int64_t base = ((int64_t)blk * blockDim.x + threadIdx.x) - lane; base < a.n_rows; base += stride) {
-    const int64_t r = base + lane;
-    const bool hit = r < a.n_rows && a.flags[r] == 2;
-    const uint64_t mask = __ballot(hit);
-    tiled_rows<0>(a, mask, (int)r, 0u, step, alpha, 0.f, lane);
+  // SCAN_V state bytes per lane and trip (round 5: one byte per lane made the scan of a 5.4 M-row table 35 us for 7,600 hits)
+  for (int64_t base = (((int64_t)blk * blockDim.x + threadIdx.x) - lane) * SCAN_V; base < a.n_rows; base += stride * SCAN_V) {
+    const int64_t r0 = base + (int64_t)lane * SCAN_V;
+    const uint32_t f = tiled_load_states<SCAN_V>(a.flags, r0, a.n_rows);
+    if (!__ballot(tiled_has_state(f, 2u))) continue;
+#pragma unroll
+    for (int j = 0; j < SCAN_V; ++j) {
+      const uint64_t mask = __ballot(((f >> (8 * j)) & 0xFFu) == 2u);
+      if (mask) tiled_rows<0>(a, mask, (int)(r0 + j), 0u, step, alpha, 0.f, lane);
+    }
   }
 }
 // rows whose state byte is 2: the step's ApplyAdam from their gradient.  One lane per row scans the state bytes.
+template <int SCAN_V>
 __global__ __launch_bounds__(256) void adam_touched_kernel(const TiledArgs a, uint32_t step, float alpha, int drop) {
-  adam_touched_body(a, step, alpha, drop, (int)blockIdx.x, (int)gridDim.x);
+  adam_touched_body<SCAN_V>(a, step, alpha, drop, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // The step's whole ApplyAdam in ONE launch (round 4): blocks [0, nb_t) the touched rows of the table, blocks [nb_t, nb_t + nb_d)
@@ -150,10 +202,11 @@ __global__ __launch_bounds__(256) void adam_touched_kernel(const TiledArgs a, ui
 // memory and were two dependent launches at the end of every step.  The guard is the table's (score_adam_table_t.id_status):
 // set, neither half applies anything and the dense half counts the suppressed step.
 struct DenseAdamArgs { float* p; float* m; float* v; const float* g; int64_t n4, n, n_reg; float l2; int32_t* skipped; };
+template <int SCAN_V>
 __global__ __launch_bounds__(256) void adam_step_kernel(const TiledArgs a, uint32_t step, float alpha, const DenseAdamArgs d,
                                                         int nb_t, int nb_d) {
   if ((int)blockIdx.x < nb_t) {
-    adam_touched_body(a, step, alpha, 0, (int)blockIdx.x, nb_t);
+    adam_touched_body<SCAN_V>(a, step, alpha, 0, (int)blockIdx.x, nb_t);
     return;
   }
   if (tiled_guarded(a)) {
@@ -206,7 +259,7 @@ __global__ __launch_bounds__(256) void adam_touched_rows_kernel(const TiledArgs 
       score_adam1(p[u].z, m[u].z, v[u].z, g[u].z, a.omb1, a.omb2, alpha, a.eps);
       score_adam1(p[u].w, m[u].w, v[u].w, g[u].w, a.omb1, a.omb2, alpha, a.eps);
       st4(a.p + e, p[u]); st4(a.m + e, m[u]); st4(a.v + e, v[u]);
-      if (ch4 == 0) { a.flags[row[u]] = 1; a.step[row[u]] = step; }
+      if (ch4 == 0) tiled_publish_applied(a, row[u], step);
     }
   }
 }
@@ -224,7 +277,7 @@ __global__ __launch_bounds__(256) void adam_catchup_rows_kernel(const TiledArgs 
     uint32_t old = upto;
     bool hit = false;
     if (r < row_end && a.flags[r] == 1) {
-      old = a.step[r];
+      old = tiled_row_step(a, r);
       hit = old < upto;
     }
     const uint64_t mask = __ballot(hit);
@@ -247,10 +300,11 @@ __global__ __launch_bounds__(256) void adam_mark_ids_kernel(const TiledArgs a, c
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     const int row = ids[i];
-    if (row >= 0 && (int64_t)row < a.n_rows && a.flags[row] == 1 && a.step[row] < upto) a.flags[row] = 3;
+    if (row >= 0 && (int64_t)row < a.n_rows && a.flags[row] == 1 && tiled_row_step(a, row) < upto) a.flags[row] = 3;
   }
 }
 // second half: the rows in state 3 are replayed up to `upto` and return to state 1 (the scan of score_adam_touched)
+template <int SCAN_V>
 __global__ __launch_bounds__(256) void adam_catchup_marked_kernel(const TiledArgs a, uint32_t upto) {
   if (tiled_guarded(a)) {                   // (the word was raised between the two halves: the marks go, nothing is replayed)
     for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < a.n_rows; r += (int64_t)gridDim.x * blockDim.x)
@@ -260,12 +314,18 @@ __global__ __launch_bounds__(256) void adam_catchup_marked_kernel(const TiledArg
   const int lane = tiled_lane();
   const float areg = a.ring[(upto - (uint32_t)lane) % SCORE_ADAM_RING];
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t base = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) - lane; base < a.n_rows; base += stride) {
-    const int64_t r = base + lane;
-    const bool hit = r < a.n_rows && a.flags[r] == 3;
-    const uint32_t old = hit ? a.step[r] : upto;
-    const uint64_t mask = __ballot(hit);
-    tiled_rows<2>(a, mask, (int)r, old, upto, 0.f, areg, lane);
+  for (int64_t base = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) - lane) * SCAN_V; base < a.n_rows; base += stride * SCAN_V) {
+    const int64_t r0 = base + (int64_t)lane * SCAN_V;
+    const uint32_t f = tiled_load_states<SCAN_V>(a.flags, r0, a.n_rows);
+    if (!__ballot(tiled_has_state(f, 3u))) continue;
+#pragma unroll
+    for (int j = 0; j < SCAN_V; ++j) {
+      const bool hit = ((f >> (8 * j)) & 0xFFu) == 3u;
+      const uint64_t mask = __ballot(hit);
+      if (!mask) continue;
+      const uint32_t old = hit ? a.step[r0 + j] : upto;
+      tiled_rows<2>(a, mask, (int)(r0 + j), old, upto, 0.f, areg, lane);
+    }
   }
 }
 
@@ -288,6 +348,11 @@ static int tiled_args(const score_adam_table_t* t, TiledArgs* a, bool need_g) {
   a->skipped = t->skipped_steps;
   return 0;
 }
+static int tiled_scan_v(const TiledArgs& a) { return a.D <= 32 ? 4 : 1; }
+static int tiled_scan_blocks(const TiledArgs& a) {      // SCAN_V rows per thread
+  const int64_t want = cdiv64(a.n_rows, 256 * tiled_scan_v(a));
+  return (int)(want < 1 ? 1 : want < 32768 ? want : 32768);
+}
 static int tiled_blocks(int64_t n) {
   const int64_t want = cdiv64(n, 256);
   return (int)(want < 1 ? 1 : want < 32768 ? want : 32768);
@@ -297,7 +362,8 @@ extern "C" int score_adam_touched(const score_adam_table_t* t, uint32_t step, fl
   TiledArgs a;
   SCORE_TRY(tiled_args(t, &a, true));
   if (step == 0) return SCORE_E_BADARG;
-  hipLaunchKernelGGL(adam_touched_kernel, dim3(tiled_blocks(a.n_rows)), dim3(256), 0, (hipStream_t)stream, a, step, alpha, 0);
+  if (tiled_scan_v(a) == 4) hipLaunchKernelGGL(adam_touched_kernel<4>, dim3(tiled_scan_blocks(a)), dim3(256), 0, (hipStream_t)stream, a, step, alpha, 0);
+  else hipLaunchKernelGGL(adam_touched_kernel<1>, dim3(tiled_scan_blocks(a)), dim3(256), 0, (hipStream_t)stream, a, step, alpha, 0);
   SCORE_CHECK_LAUNCH();
   return 0;
 }
@@ -312,10 +378,11 @@ extern "C" int score_adam_touched_and_dense(const score_adam_table_t* t, uint32_
     return SCORE_E_SHAPE;
   DenseAdamArgs d;
   d.p = p; d.m = m; d.v = v; d.g = g; d.n4 = n / 4; d.n = n; d.n_reg = n_reg; d.l2 = l2; d.skipped = skipped;
-  const int nb_t = tiled_blocks(a.n_rows);
+  const int nb_t = tiled_scan_blocks(a);
   const int64_t want = cdiv64(d.n4 > 0 ? d.n4 : 1, 256);
   const int nb_d = (int)(want < 8192 ? want : 8192);
-  hipLaunchKernelGGL(adam_step_kernel, dim3(nb_t + nb_d), dim3(256), 0, (hipStream_t)stream, a, step, alpha, d, nb_t, nb_d);
+  if (tiled_scan_v(a) == 4) hipLaunchKernelGGL(adam_step_kernel<4>, dim3(nb_t + nb_d), dim3(256), 0, (hipStream_t)stream, a, step, alpha, d, nb_t, nb_d);
+  else hipLaunchKernelGGL(adam_step_kernel<1>, dim3(nb_t + nb_d), dim3(256), 0, (hipStream_t)stream, a, step, alpha, d, nb_t, nb_d);
   SCORE_CHECK_LAUNCH();
   return 0;
 }
@@ -323,7 +390,7 @@ extern "C" int score_adam_touched_and_dense(const score_adam_table_t* t, uint32_
 extern "C" int score_adam_unmark(const score_adam_table_t* t, uint32_t upto, void* stream) {
   TiledArgs a;
   SCORE_TRY(tiled_args(t, &a, false));
-  hipLaunchKernelGGL(adam_touched_kernel, dim3(tiled_blocks(a.n_rows)), dim3(256), 0, (hipStream_t)stream, a, upto + 1, 0.f, 1);
+  hipLaunchKernelGGL(adam_touched_kernel<1>, dim3(tiled_blocks(a.n_rows)), dim3(256), 0, (hipStream_t)stream, a, upto + 1, 0.f, 1);
   SCORE_CHECK_LAUNCH();
   return 0;
 }
@@ -364,7 +431,8 @@ extern "C" int score_adam_catchup_ids(const score_adam_table_t* t, const int32_t
   hipLaunchKernelGGL(adam_mark_ids_kernel, dim3(tiled_blocks(cdiv64(n_ids, 4))), dim3(256), 0, (hipStream_t)stream, a, ids,
                      n_ids, upto, 0, 0.f);
   SCORE_CHECK_LAUNCH();
-  hipLaunchKernelGGL(adam_catchup_marked_kernel, dim3(tiled_blocks(a.n_rows)), dim3(256), 0, (hipStream_t)stream, a, upto);
+  if (tiled_scan_v(a) == 4) hipLaunchKernelGGL(adam_catchup_marked_kernel<4>, dim3(tiled_scan_blocks(a)), dim3(256), 0, (hipStream_t)stream, a, upto);
+  else hipLaunchKernelGGL(adam_catchup_marked_kernel<1>, dim3(tiled_scan_blocks(a)), dim3(256), 0, (hipStream_t)stream, a, upto);
   SCORE_CHECK_LAUNCH();
   return 0;
 }
@@ -378,7 +446,8 @@ extern "C" int score_adam_catchup_ids_through(const score_adam_table_t* t, const
   hipLaunchKernelGGL(adam_mark_ids_kernel, dim3(tiled_blocks(cdiv64(n_ids, 4))), dim3(256), 0, (hipStream_t)stream, a, ids,
                      n_ids, step, 1, alpha);
   SCORE_CHECK_LAUNCH();
-  hipLaunchKernelGGL(adam_catchup_marked_kernel, dim3(tiled_blocks(a.n_rows)), dim3(256), 0, (hipStream_t)stream, a, step);
+  if (tiled_scan_v(a) == 4) hipLaunchKernelGGL(adam_catchup_marked_kernel<4>, dim3(tiled_scan_blocks(a)), dim3(256), 0, (hipStream_t)stream, a, step);
+  else hipLaunchKernelGGL(adam_catchup_marked_kernel<1>, dim3(tiled_scan_blocks(a)), dim3(256), 0, (hipStream_t)stream, a, step);
   SCORE_CHECK_LAUNCH();
   return 0;
 }

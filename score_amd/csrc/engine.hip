@@ -218,7 +218,7 @@ void build_ws_raw(const Dims& d, int B, WS* w) {
   w->a1 = take(BT * AT1); w->a2 = take(BT * AT2);
   w->bn = take((int64_t)B * d.Dhead);
   w->f1 = take((int64_t)B * FC1); w->f2 = take((int64_t)B * FC2);
-  w->lossb = take(B); w->dlogit = take(B); w->part = take(256);
+  w->lossb = take(B); w->dlogit = take(B); w->part = take(256 + 4);      // (+ one word: the per-sample forward kernel's count of finished workgroups)
   w->dz2 = take((int64_t)B * FC2); w->dz1 = take((int64_t)B * FC1);
   w->dbn = take((int64_t)B * d.Dhead); w->dhead = take((int64_t)B * d.Dhead);
   w->ds = take(BT); w->da2 = take(BT * AT2); w->da1 = take(BT * AT1);
@@ -315,7 +315,17 @@ void build_ws(const Dims& d, int B, WS* w) {
 // score_state_t.context; forked from / joined back into the caller's stream with events.  A caller that passes no
 // context shares ONE process-wide default context per device (created on first use, released by
 // score_context_destroy(NULL)): the only state the library keeps between calls.
-struct SideStream { hipStream_t st; hipEvent_t fork, join, wx; int device; hipStream_t fwd_on; };
+// sync: SCORE_SYNC_SLOTS x 4 zeroed words of device memory for score_grid_sync (common.h), handed out in rotation to the launches
+// that fuse dependent phases (a slot is free again long before its turn comes round: a context is driven by one host thread)
+#define SCORE_SYNC_SLOTS 32
+struct SideStream { hipStream_t st; hipEvent_t fork, join, wx; int device; hipStream_t fwd_on; unsigned int* sync; unsigned int sync_next; };
+static unsigned int* sync_slot(SideStream* sd, const score_state_t* st) {
+  // bit 13 OPTS IN: measured (profiles/r05_probes.md), the one-launch sort takes 162 us against ~110 us for the six launches with
+  // their gaps, and its agent-scope fences (an L2 write-back + invalidate per barrier and workgroup, on every XCD) slow the
+  // kernels running beside it -- the per-sample forward 35 -> 50 us, the backward 38 -> 47 us: the step got 25 % slower.
+  if (!sd || !sd->sync || !st || !(st->debug_flags & 8192)) return nullptr;
+  return sd->sync + 4 * (sd->sync_next++ % SCORE_SYNC_SLOTS);
+}
 static int side_stream_create(SideStream* sd) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return SCORE_E_BADARG;
@@ -326,6 +336,12 @@ static int side_stream_create(SideStream* sd) {
   if ((e = hipEventCreateWithFlags(&b, hipEventDisableTiming)) != hipSuccess) { hipEventDestroy(a); hipStreamDestroy(st); return (int)e; }
   if ((e = hipEventCreateWithFlags(&c, hipEventDisableTiming)) != hipSuccess) { hipEventDestroy(a); hipEventDestroy(b); hipStreamDestroy(st); return (int)e; }
   sd->st = st; sd->fork = a; sd->join = b; sd->wx = c; sd->device = dev; sd->fwd_on = nullptr;
+  sd->sync = nullptr; sd->sync_next = 0;
+  void* sy = nullptr;
+  if (hipMalloc(&sy, SCORE_SYNC_SLOTS * 16) == hipSuccess) {
+    if (hipMemset(sy, 0, SCORE_SYNC_SLOTS * 16) == hipSuccess) sd->sync = static_cast<unsigned int*>(sy);
+    else hipFree(sy);
+  }
   return 0;
 }
 static void side_stream_release(SideStream* sd) {
@@ -333,6 +349,8 @@ static void side_stream_release(SideStream* sd) {
   hipStreamSynchronize(sd->st);
   hipEventDestroy(sd->fork); hipEventDestroy(sd->join); hipEventDestroy(sd->wx);
   hipStreamDestroy(sd->st);
+  if (sd->sync) hipFree(sd->sync);
+  sd->sync = nullptr;
   sd->st = nullptr;
 }
 #define SCORE_MAX_DEVICES 16
@@ -415,6 +433,22 @@ extern "C" int score_context_destroy(void* ctx) {
   }
   std::lock_guard<std::mutex> lock(g_default_mu);
   for (int i = 0; i < SCORE_MAX_DEVICES; ++i) side_stream_release(&g_default_ctx[i]);
+  return 0;
+}
+
+extern "C" int score_context_sync_errors(void* ctx, int32_t* errors) {
+  if (!errors) return SCORE_E_BADARG;
+  SideStream* sd = reinterpret_cast<SideStream*>(ctx);
+  if (!sd) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SCORE_MAX_DEVICES) return SCORE_E_BADARG;
+    sd = &g_default_ctx[dev];
+  }
+  *errors = 0;
+  if (!sd->sync) return 0;
+  unsigned int host[SCORE_SYNC_SLOTS * 4];
+  HIPTRY(hipMemcpy(host, sd->sync, sizeof(host), hipMemcpyDeviceToHost));
+  for (int i = 0; i < SCORE_SYNC_SLOTS; ++i) *errors += host[4 * i + 2] ? 1 : 0;
   return 0;
 }
 
@@ -527,8 +561,11 @@ extern "C" int score_index_plan(const score_config_t* cfg, const score_state_t* 
   uint32_t* vals_in = reinterpret_cast<uint32_t*>(ws + w.vals_in);
   uint32_t* keys_out = reinterpret_cast<uint32_t*>(ws + w.keys_out);
   uint32_t* vals_out = reinterpret_cast<uint32_t*>(ws + w.vals_out);
+  SideStream* ctx = nullptr;
+  G(side_stream(st, &ctx));
   G(score_launch_plan(pf, key_bits, keys_in, vals_in, keys_out, vals_out, ws + w.sort_temp,
-                      (size_t)w.sort_temp_bytes, s, (st->debug_flags & 32) ? 1 : (st->debug_flags & 256) ? 2 : 0));
+                      (size_t)w.sort_temp_bytes, s, (st->debug_flags & 32) ? 1 : (st->debug_flags & 256) ? 2 : 0,
+                      sync_slot(ctx, st)));
   if (n_shards > 1 || dedup) {
     PlanRemapArgs ra;
     memset(&ra, 0, sizeof(ra));
@@ -663,20 +700,15 @@ int forward_ps(const Dims& d, const Params& P, const WS& w, const PsPlan& pp, co
   a.keep = keep_prob; a.rs = (float)(1.0 / sqrt(1.0 + 1e-3)); a.drop = keep_prob < 1.f ? 1 : 0;
   a.mask0 = mask0; a.mask1 = mask1; a.seed0 = seed; a.seed1 = seed ^ 0x5DEECE66Dull;
   a.seed_dev = st->step_scalars ? &st->step_scalars->drop_seed : nullptr;
+  const int Bg = st->global_batch > 0 ? st->global_batch : B;
+  a.loss = ws + w.loss; a.loss_host = st->loss_host; a.part = ws + w.part;
+  a.done = reinterpret_cast<unsigned int*>(ws + w.part) + 256;
+  a.lambda = reg_lambda; a.inv_bglobal = 1.0f / (float)Bg;
   G(score_launch_ps_fwd(a, s));
   if (st->gather_done_event) HIPTRY(hipEventRecord((hipEvent_t)st->gather_done_event, s));
   EV(1); EV(2); EV(3);
-  const int Bg = st->global_batch > 0 ? st->global_batch : B;
-  hipStream_t ls = s;
-  SideStream* sd = nullptr;
-  if (st->loss_done_event) {
-    G(side_stream(st, s, &sd));
-    HIPTRY(hipEventRecord(sd->fork, s));
-    HIPTRY(hipStreamWaitEvent(sd->st, sd->fork, 0));
-    ls = sd->st;
-  }
-  G(score_launch_loss_final(B, ws + w.lossb, ws + w.loss, reg_lambda, ws + w.part, Bg, ls, st->id_status));
-  if (st->loss_done_event) HIPTRY(hipEventRecord((hipEvent_t)st->loss_done_event, ls));
+  // (the loss: reduced by the kernel's last workgroup -- until round 5 a one-workgroup launch on the side stream)
+  if (st->loss_done_event) HIPTRY(hipEventRecord((hipEvent_t)st->loss_done_event, s));
   EV(4);
   return 0;
 }

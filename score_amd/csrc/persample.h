@@ -33,7 +33,7 @@ struct PsImgJob { const float* W; const float* W2; float* img; int K, N, ld, kin
 #define PS_MAX_IMG 16
 struct PsPrepArgs {
   PsImgJob job[PS_MAX_IMG]; int njobs, img_blocks;
-  const float* wreg; int64_t n_reg; float* part;        // L2 partial sums (256 blocks)
+  const float* wreg; int64_t n_reg; float* part;        // L2 partial sums (256 blocks); part[256] (a word) <- 0: PsFwdArgs.done
   float* zero; int64_t zero_floats; int zero_blocks;    // dense gradient buffer cleared for the backward pass
 };
 
@@ -60,6 +60,10 @@ struct PsFwdArgs {
   float* gru_final[2]; float* q; float* ainp; float* a1; float* a2; float* att_score; float* bn; float* f1; float* f2;
   float* logit; float* y; float* lossb; float* dlogit; float* dz2;
   float keep, rs; int drop; const uint8_t* mask0; const uint8_t* mask1; uint64_t seed0, seed1; const uint64_t* seed_dev;
+  // the loss of the step (score.py:74-81, 91-94), reduced by the LAST workgroup to finish (round 5: it was a one-workgroup launch
+  // of its own on the side stream -- a launch, a fork and two event calls per step): `done` counts finished workgroups (zeroed by
+  // ps_prep_kernel), part = the 256 partial sums of squares of the regularised range, loss_host = optional pinned host copy
+  float* loss; float* loss_host; const float* part; unsigned int* done; float lambda, inv_bglobal;
 };
 
 struct PsBwdArgs {

@@ -61,7 +61,10 @@ __global__ __launch_bounds__(256) void ps_prep_kernel(const PsPrepArgs a) {
       if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
       __syncthreads();
     }
-    if (threadIdx.x == 0) a.part[b2] = sh[0];
+    if (threadIdx.x == 0) {
+      a.part[b2] = sh[0];
+      if (b2 == 0) reinterpret_cast<unsigned int*>(a.part)[PS_L2_PARTS] = 0u;       // the forward kernel's count of finished workgroups
+    }
     return;
   }
   // the dense gradient starts from zero (the backward pass accumulates some of its pieces)
@@ -531,16 +534,58 @@ __global__ __launch_bounds__(PS_NT) void ps_fwd_kernel(const PsFwdArgs a) {
     if (lane == 0) {
       a.logit[b] = z;
       a.y[b] = p;
-      a.lossb[b] = -lab * logf(p + eps) - (1.0f - lab) * logf(1.0f - p + eps);
       a.dlogit[b] = dl;
+      // the sample's term goes through to memory (agent scope) and is acknowledged BEFORE this workgroup counts itself done:
+      // whoever counts last then reads every term past its caches -- no cache-wide fence (a workgroup-count of L2 write-backs
+      // at the end of every step slows whatever runs beside this kernel)
+      __hip_atomic_store(&a.lossb[b], -lab * logf(p + eps) - (1.0f - lab) * logf(1.0f - p + eps), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
     }
     for (int n = lane; n < 80; n += 64) {
       const float q = dl * W[a.fc_w3 + n] / a.keep;
       a.dz2[(int64_t)b * 80 + n] = sm[L.f2s + n] > 0.f ? q : 0.f;
     }
+    if (lane == 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned int t = __hip_atomic_fetch_add(a.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      reinterpret_cast<volatile int*>(sm + L.misc)[0] = (t == (unsigned int)s.B - 1u) ? 1 : 0;
+    }
   }
-  ps_touch_use(warm, sm + L.misc);
+  ps_touch_use(warm, sm + L.misc + 4);
   PS_MARK(ps_ts_fwd, 12);
+  __syncthreads();
+  if (reinterpret_cast<volatile int*>(sm + L.misc)[0] == 0) return;
+  // ---- the last workgroup: loss[1] = sum_b lossb / Bglobal, loss[2] = 0.5 * sum(parts), loss[0] = loss[1] + lambda * loss[2] -- the
+  // sums of loss_final_kernel (head.hip), thread for thread, so the layer-by-layer pass gives the same bits
+  {
+    float* sh = sm;                  // (every phase is behind the barrier above: any region will do)
+    float* sp = sh + 256;
+    if (tid < 256) {
+      float acc = 0.f;
+      for (int i = tid; i < s.B; i += 256) acc += __hip_atomic_load(&a.lossb[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      sh[tid] = acc;
+      sp[tid] = a.part[tid];
+    }
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (tid < o) { sh[tid] += sh[tid + o]; sp[tid] += sp[tid + o]; }
+      __syncthreads();
+    }
+    if (tid == 0) {
+      float l1 = sh[0] * a.inv_bglobal;
+      const float l2 = 0.5f * sp[0];
+      float l0 = l1 + a.lambda * l2;
+      const int32_t bad = a.id_status ? __hip_atomic_load(a.id_status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+      if (bad) l0 = l1 = __int_as_float(0x7fc00000);
+      a.loss[0] = l0; a.loss[1] = l1; a.loss[2] = l2; a.loss[3] = (float)bad;
+      if (a.loss_host) {
+        __hip_atomic_store(&a.loss_host[1], l1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&a.loss_host[2], l2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&a.loss_host[3], (float)bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&a.loss_host[0], l0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  }
 }
 
 }  // namespace

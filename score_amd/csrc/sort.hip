@@ -117,14 +117,13 @@ __device__ __forceinline__ void plan_fill_one(const PlanFillArgs& a, int64_t i, 
 }
 
 // keys / vals of the tile written, and the tile's histogram of the FIRST pass's digit
-__global__ __launch_bounds__(THREADS) void plan_fill_hist_kernel(PlanFillArgs a, int64_t n, uint32_t* __restrict__ keys,
-                                                                 uint32_t* __restrict__ vals, int dbits,
-                                                                 uint32_t* __restrict__ M) {
-  extern __shared__ uint32_t hist[];
+__device__ __forceinline__ void plan_fill_hist_tile(const PlanFillArgs& a, int64_t n, uint32_t* __restrict__ keys,
+                                                    uint32_t* __restrict__ vals, int dbits, uint32_t* __restrict__ M,
+                                                    int tile, uint32_t* hist) {
   const int nbins = 1 << dbits, tid = threadIdx.x;
   for (int d = tid; d < nbins; d += THREADS) hist[d] = 0;
   __syncthreads();
-  const int64_t base = (int64_t)blockIdx.x * TILE;
+  const int64_t base = (int64_t)tile * TILE;
   const int lane = tid & 63;
 #pragma unroll 4
   for (int j = 0; j < EPT; ++j) {
@@ -138,17 +137,22 @@ __global__ __launch_bounds__(THREADS) void plan_fill_hist_kernel(PlanFillArgs a,
     hist_add(hist, key & (uint32_t)(nbins - 1), i < n, lane);
   }
   __syncthreads();
-  uint32_t* row = M + (int64_t)blockIdx.x * nbins;
+  uint32_t* row = M + (int64_t)tile * nbins;
   for (int d = tid; d < nbins; d += THREADS) row[d] = hist[d];
 }
-
-__global__ __launch_bounds__(THREADS) void sort_hist_kernel(const uint32_t* __restrict__ keys, int64_t n, int shift, int dbits,
-                                                            uint32_t* __restrict__ M) {
+__global__ __launch_bounds__(THREADS) void plan_fill_hist_kernel(PlanFillArgs a, int64_t n, uint32_t* __restrict__ keys,
+                                                                 uint32_t* __restrict__ vals, int dbits,
+                                                                 uint32_t* __restrict__ M) {
   extern __shared__ uint32_t hist[];
+  plan_fill_hist_tile(a, n, keys, vals, dbits, M, (int)blockIdx.x, hist);
+}
+
+__device__ __forceinline__ void sort_hist_tile(const uint32_t* __restrict__ keys, int64_t n, int shift, int dbits,
+                                               uint32_t* __restrict__ M, int tile, uint32_t* hist) {
   const int nbins = 1 << dbits, tid = threadIdx.x;
   for (int d = tid; d < nbins; d += THREADS) hist[d] = 0;
   __syncthreads();
-  const int64_t base = (int64_t)blockIdx.x * TILE;
+  const int64_t base = (int64_t)tile * TILE;
   uint32_t k[EPT];
 #pragma unroll
   for (int j = 0; j < EPT; ++j) {
@@ -159,8 +163,13 @@ __global__ __launch_bounds__(THREADS) void sort_hist_kernel(const uint32_t* __re
   for (int j = 0; j < EPT; ++j)
     hist_add(hist, (k[j] >> shift) & (uint32_t)(nbins - 1), base + j * THREADS + tid < n, tid & 63);
   __syncthreads();
-  uint32_t* row = M + (int64_t)blockIdx.x * nbins;
+  uint32_t* row = M + (int64_t)tile * nbins;
   for (int d = tid; d < nbins; d += THREADS) row[d] = hist[d];
+}
+__global__ __launch_bounds__(THREADS) void sort_hist_kernel(const uint32_t* __restrict__ keys, int64_t n, int shift, int dbits,
+                                                            uint32_t* __restrict__ M) {
+  extern __shared__ uint32_t hist[];
+  sort_hist_tile(keys, n, shift, dbits, M, (int)blockIdx.x, hist);
 }
 
 // per bin: M[tile][bin] <- number of keys with that digit in EARLIER tiles; tot[bin] <- in all tiles.
@@ -210,11 +219,10 @@ __global__ __launch_bounds__(CS_WAVES * 64) void sort_colscan_kernel(uint32_t* _
 // LDS of the scatter kernel, in 32-bit words: cnt u16[nbins][8] | dpre u16[nbins] | adj i32[nbins] | ex u32[TILE] | sc[16]
 __host__ __device__ constexpr int scatter_lds_bytes(int nbins) { return nbins * 16 + nbins * 2 + nbins * 4 + TILE * 4 + 64; }
 
-__global__ __launch_bounds__(THREADS) void sort_scatter_kernel(const uint32_t* __restrict__ kin, const uint32_t* __restrict__ vin,
-                                                               uint32_t* __restrict__ kout, uint32_t* __restrict__ vout,
-                                                               int64_t n, int shift, int dbits, const uint32_t* __restrict__ M,
-                                                               const uint32_t* __restrict__ tot) {
-  extern __shared__ uint32_t smem[];
+__device__ __forceinline__ void sort_scatter_tile(const uint32_t* __restrict__ kin, const uint32_t* __restrict__ vin,
+                                                  uint32_t* __restrict__ kout, uint32_t* __restrict__ vout, int64_t n, int shift,
+                                                  int dbits, const uint32_t* __restrict__ M, const uint32_t* __restrict__ tot,
+                                                  int tile, uint32_t* smem) {
   const int nbins = 1 << dbits;
   const uint32_t mask = (uint32_t)(nbins - 1);
   uint16_t* cnt = reinterpret_cast<uint16_t*>(smem);           // [d][wave]: count, later the exclusive prefix over waves
@@ -223,8 +231,9 @@ __global__ __launch_bounds__(THREADS) void sort_scatter_kernel(const uint32_t* _
   uint32_t* ex = reinterpret_cast<uint32_t*>(adj + nbins);
   uint32_t* sc = ex + TILE;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int64_t base = (int64_t)blockIdx.x * TILE;
+  const int64_t base = (int64_t)tile * TILE;
   const int ntile = (int)min((int64_t)TILE, n - base);
+  __syncthreads();                       // (the fused kernel: a previous phase of this workgroup may still read the LDS)
   for (int i = tid; i < nbins * WAVES / 2; i += THREADS) smem[i] = 0;
   uint32_t key[EPT], val[EPT], pos[EPT];
 #pragma unroll
@@ -279,7 +288,7 @@ __global__ __launch_bounds__(THREADS) void sort_scatter_kernel(const uint32_t* _
   }
   uint32_t lo = block_excl_scan(ls, sc, tid);
   uint32_t go = block_excl_scan(gs, sc, tid);
-  const uint32_t* Mrow = M + (int64_t)blockIdx.x * nbins;
+  const uint32_t* Mrow = M + (int64_t)tile * nbins;
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
     if (q < dpt && has) {
@@ -322,6 +331,59 @@ __global__ __launch_bounds__(THREADS) void sort_scatter_kernel(const uint32_t* _
   for (int j = 0; j < EPT; ++j) {
     const int i = j * THREADS + tid;
     if (i < ntile) vout[dest[j]] = ex[i];
+  }
+}
+__global__ __launch_bounds__(THREADS) void sort_scatter_kernel(const uint32_t* __restrict__ kin, const uint32_t* __restrict__ vin,
+                                                               uint32_t* __restrict__ kout, uint32_t* __restrict__ vout,
+                                                               int64_t n, int shift, int dbits, const uint32_t* __restrict__ M,
+                                                               const uint32_t* __restrict__ tot) {
+  extern __shared__ uint32_t smem[];
+  sort_scatter_tile(kin, vin, kout, vout, n, shift, dbits, M, tot, (int)blockIdx.x, smem);
+}
+
+// ---------------------------------------------------------------- the whole plan sort in ONE launch (round 5)
+// Up to FUSED_MAX_TILES tiles (524 K occurrences: the reference's own batch sizes at every data set's shape): a workgroup per
+// tile runs fill + histogram, column scan, scatter, histogram, column scan, scatter with score_grid_sync between the phases --
+// the same arithmetic as the six launches (stable: the plan is the same bits), five barriers (~3 us each) instead of five launch
+// boundaries and, what matters at these sizes, ONE launch call of the host instead of six (the step is bound by those).
+constexpr int FUSED_MAX_TILES = 64;
+__device__ __forceinline__ void sort_colscan_all(uint32_t* __restrict__ M, int ntiles, int nbins, uint32_t* __restrict__ tot,
+                                                 int blk, int nblk) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int g = blk * WAVES + w; g * 64 < nbins; g += nblk * WAVES) {        // a wave per 64 bins, a lane per bin, tiles in order
+    uint32_t* col = M + g * 64 + lane;
+    uint32_t run = 0;
+    int t = 0;
+    for (; t + 8 <= ntiles; t += 8) {
+      uint32_t c[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) c[u] = col[(int64_t)(t + u) * nbins];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { col[(int64_t)(t + u) * nbins] = run; run += c[u]; }
+    }
+    for (; t < ntiles; ++t) { const uint32_t c = col[(int64_t)t * nbins]; col[(int64_t)t * nbins] = run; run += c; }
+    tot[g * 64 + lane] = run;
+  }
+}
+struct FusedSort { int npass, dbits[3], shift[3]; };
+__global__ __launch_bounds__(THREADS) void plan_sort_fused_kernel(PlanFillArgs a, int64_t n, uint32_t* k0, uint32_t* v0, uint32_t* k1,
+                                                                  uint32_t* v1, uint32_t* M, uint32_t* tot, FusedSort sh,
+                                                                  unsigned int* bar) {
+  extern __shared__ uint32_t smem[];
+  const int tile = (int)blockIdx.x, ntiles = (int)gridDim.x;
+  plan_fill_hist_tile(a, n, k0, v0, sh.dbits[0], M, tile, smem);
+  for (int p = 0; p < sh.npass; ++p) {
+    if (p > 0) {
+      __syncthreads();
+      sort_hist_tile(k0, n, sh.shift[p], sh.dbits[p], M, tile, smem);
+    }
+    score_grid_sync(bar, (unsigned)ntiles);
+    sort_colscan_all(M, ntiles, 1 << sh.dbits[p], tot, tile, ntiles);
+    score_grid_sync(bar, (unsigned)ntiles);
+    sort_scatter_tile(k0, v0, k1, v1, n, sh.shift[p], sh.dbits[p], M, tot, tile, smem);
+    if (p + 1 < sh.npass) score_grid_sync(bar, (unsigned)ntiles);          // (every tile of the pass written before anybody reads one)
+    uint32_t* t = k0; k0 = k1; k1 = t;
+    t = v0; v0 = v1; v1 = t;
   }
 }
 
@@ -395,7 +457,7 @@ size_t score_sort_temp_bytes(int64_t n) {
 // keys_out / vals_out <- the occurrences of the batch sorted by (owner, row), equal keys in occurrence order (stable).
 // keys_in / vals_in are scratch (they hold an intermediate pass afterwards).
 int score_launch_plan_own(const PlanFillArgs& a, int key_bits, uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys_out,
-                      uint32_t* vals_out, void* temp, size_t temp_bytes, hipStream_t s) {
+                      uint32_t* vals_out, void* temp, size_t temp_bytes, hipStream_t s, unsigned int* sync) {
   const int64_t n = a.off[6] + 1;   // + sentinel
   if (n >= (1ll << 31)) return SCORE_E_SHAPE;
   if (score_sort_temp_bytes(n) > temp_bytes) return SCORE_E_WORKSPACE;
@@ -408,6 +470,19 @@ int score_launch_plan_own(const PlanFillArgs& a, int key_bits, uint32_t* keys_in
   uint32_t* v0 = (sh.npass & 1) ? vals_in : vals_out;
   uint32_t* k1 = (sh.npass & 1) ? keys_out : keys_in;
   uint32_t* v1 = (sh.npass & 1) ? vals_out : vals_in;
+  if (sync && ntiles <= FUSED_MAX_TILES) {
+    FusedSort fs;
+    fs.npass = sh.npass;
+    int lds = 0;
+    for (int p = 0; p < 3; ++p) {
+      fs.dbits[p] = p < sh.npass ? sh.dbits[p] : 0; fs.shift[p] = p < sh.npass ? sh.shift[p] : 0;
+      if (p < sh.npass && scatter_lds_bytes(1 << sh.dbits[p]) > lds) lds = scatter_lds_bytes(1 << sh.dbits[p]);
+    }
+    SCORE_TRY(set_lds((const void*)plan_sort_fused_kernel, lds));
+    hipLaunchKernelGGL(plan_sort_fused_kernel, dim3(ntiles), dim3(THREADS), lds, s, a, n, k0, v0, k1, v1, M, tot, fs, sync);
+    SCORE_CHECK_LAUNCH();
+    return 0;
+  }
   hipLaunchKernelGGL(plan_fill_hist_kernel, dim3(ntiles), dim3(THREADS), (1 << sh.dbits[0]) * 4, s, a, n, k0, v0, sh.dbits[0], M);
   SCORE_CHECK_LAUNCH();
   return run_passes(sh, k0, v0, k1, v1, n, M, tot, true, s);

@@ -1,0 +1,68 @@
+// One training step in ONE call of the host (round 5).
+//
+// model.train (score.py:101-116) is one sess.run per step in the reference; here it is a forward pass, a backward pass, the
+// optimizer's three pieces and the next batch's index plan, on three streams tied by a dozen events.  Queued call by call from
+// Python, the bookkeeping between the calls (which event, which stream, what is pending) costs as much host time as the calls
+// themselves at the reference's own batch sizes (tools/host_calls.py: ~85 us of "python + torch" against ~110 us inside the
+// library for a step whose dependent device work is ~150 us).  score_train_step makes the steady-state sequence here, from a
+// struct the caller fills once and touches up per step.  It is the SAME sequence of the same entry points with the same
+// arguments on the same streams as score_amd/model.py's call-by-call path (which remains: first steps, evaluation in between,
+// stage events, wrong hints -- anything not steady state), so the two are interchangeable step by step, bit for bit
+// (tests/test_gpu_persample.py).
+#include "common.h"
+
+#define HIPTRY_(expr)                                  \
+  do {                                                 \
+    hipError_t e__ = (expr);                           \
+    if (e__ != hipSuccess) return (int)e__;            \
+  } while (0)
+
+extern "C" int score_train_step(const score_config_t* cfg, const score_state_t* st_in, const score_batch_t* batch,
+                                const score_train_step_t* p, void* stream) {
+  if (!cfg || !st_in || !batch || !p || !p->table || !p->w || !p->w_m || !p->w_v || !p->w_g || !p->side_stream ||
+      !p->ev_stage2 || !p->ev_b4 || !p->ev_grads || !p->ev_sweep || !p->ev_plan || !p->ev_ahead)
+    return SCORE_E_BADARG;
+  hipStream_t s = (hipStream_t)stream, side = (hipStream_t)p->side_stream;
+  score_state_t st = *st_in;
+  // (1) what the previous step left running on the side stream on rows this batch reads: the look-ahead catch-up of exactly these
+  //     rows, the window slice
+  if (p->wait_ahead) HIPTRY_(hipStreamWaitEvent(s, (hipEvent_t)p->ev_ahead, 0));
+  if (p->wait_sweep) HIPTRY_(hipStreamWaitEvent(s, (hipEvent_t)p->ev_sweep, 0));
+  // (2) forward
+  st.gather_done_event = nullptr;
+  st.loss_done_event = p->ev_loss;
+  st.loss_host = p->loss_host;
+  st.plan_done_event = nullptr;
+  st.grads_done_event = nullptr;
+  SCORE_TRY(score_forward(cfg, &st, batch, p->reg_lambda, p->keep_prob, nullptr, nullptr, p->drop_seed, nullptr, stream));
+  // (3) backward: the row scatter behind this batch's index plan (sorted by the previous call), the dense gradient's finishers on
+  //     the context's side stream
+  st.plan_done_event = p->ev_plan;
+  st.grads_done_event = p->ev_grads;
+  void* ev[6] = {nullptr, nullptr, p->ev_stage2, nullptr, p->ev_b4, nullptr};
+  SCORE_TRY(score_backward(cfg, &st, batch, p->keep_prob, p->w_g, const_cast<float*>(p->table->g), ev, stream));
+  // (4) side stream: this step's slice of the table (rows nobody in the batch touches), from stage boundary 2 of the pass
+  if (p->slice_hi > p->slice_lo) {
+    HIPTRY_(hipStreamWaitEvent(side, (hipEvent_t)p->ev_stage2, 0));
+    SCORE_TRY(score_adam_catchup_rows(p->table, p->slice_lo, p->slice_hi, p->slice_upto, p->side_stream));
+    HIPTRY_(hipEventRecord((hipEvent_t)p->ev_sweep, side));
+  }
+  // (5) side stream, behind the row scatter: the NEXT batch's rows brought up to date through this step, then its index plan
+  if (p->next_batch) {
+    HIPTRY_(hipStreamWaitEvent(side, (hipEvent_t)p->ev_b4, 0));
+    SCORE_TRY(score_adam_catchup_ids_through(p->table, p->next_ids, p->n_next_ids, p->step, p->alpha, p->side_stream));
+    HIPTRY_(hipEventRecord((hipEvent_t)p->ev_ahead, side));
+    score_state_t sp = *st_in;
+    sp.workspace = p->next_workspace; sp.workspace_bytes = p->next_workspace_bytes;
+    sp.id_status = nullptr;        // (the ids are reported by the forward pass of that batch: the word guards THIS step's optimizer)
+    sp.gather_done_event = sp.plan_done_event = sp.grads_done_event = sp.loss_done_event = nullptr;
+    sp.loss_host = nullptr;
+    SCORE_TRY(score_index_plan(cfg, &sp, p->next_batch, 1, 0, p->side_stream));
+    HIPTRY_(hipEventRecord((hipEvent_t)p->ev_plan, side));
+  }
+  // (6) the step's ApplyAdam: rows with a gradient and the dense variables in one launch, behind the finishers
+  HIPTRY_(hipStreamWaitEvent(s, (hipEvent_t)p->ev_grads, 0));
+  SCORE_TRY(score_adam_touched_and_dense(p->table, p->step, p->alpha, p->w, p->w_m, p->w_v, p->w_g, p->n_w, p->n_reg, p->reg_lambda,
+                                         p->skipped, stream));
+  return 0;
+}

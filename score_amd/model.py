@@ -228,6 +228,17 @@ class SCOREBASE(object):
         self._evs = {}
         self._ps_last = False           # the last forward_backward ran as the per-sample whole-model kernels
         self._inline_on = False         # debug_flags bit 12 was set at the last forward_backward: every stream below IS the launch stream
+        self.fast_step = True           # train / train_async: the steady-state step of the per-sample form as one library call (_train_step_fast)
+        self._step_args = self._step_T = None
+        # the launches that start side-stream work (next batch's index plan, look-ahead catch-up, window slice) are made by the
+        # library's worker thread (csrc/async.hip) while this thread queues the step's chain -- the per-sample form only (the step is
+        # bound by this thread's launch calls there: tools/host_calls.py)
+        # OFF by default: measured, the step takes the same time with it (tmall_default 0.2073 vs 0.2054 ms, cfg-2 0.1675 vs 0.1671,
+        # taobao_default 0.2178 vs 0.2174) -- the HIP runtime serialises the two threads' calls: the 30 us of launch calls the worker
+        # takes over come back as slower event / launch calls on this thread (tools/host_calls.py: "python + torch" 75 -> 240 us)
+        self.launch_worker = os.environ.get("SCORE_LAUNCH_WORKER", "0") == "1"
+        self._sweep_ticket = 0
+        self._evh_cache = {}
         self._ev_dense = None
         self.w = torch.zeros((self.n_w,), **f32)
         self._alloc_optimizer()
@@ -462,6 +473,11 @@ class SCOREBASE(object):
         # the window slice, the early loss copy) may still be running: the caching allocator knows a tensor only by the stream
         # it was allocated on and would hand the dying model's buffers to the next allocation while those kernels still write
         # them (seen as two "identical" models diverging by a few ulp when one of them inherited such a block).  Wait first.
+        try:
+            if getattr(self, "lib", None) is not None:
+                self.lib.score_async_wait(C.c_uint64(0))      # (launches the worker thread still owes: issued before the streams are drained)
+        except Exception:
+            pass
         for st in (getattr(self, "_side", None), getattr(self, "_sweep_st", None),
                    (getattr(self, "_early_loss_state", None) or {}).get("stream")):
             try:
@@ -612,6 +628,7 @@ class SCOREBASE(object):
             # pulls memory from under a step; the device-wide wait keeps the allocator from handing the block to a
             # new tensor while kernels enqueued on other streams still use it (evictions are rare: a new batch size).
             while len(self._ws) >= self.max_workspaces:
+                self.lib.score_async_wait(C.c_uint64(0))
                 torch.cuda.synchronize(self.device)
                 self._ws.pop(next(iter(self._ws)))
             ent = (lay, buf)
@@ -639,7 +656,7 @@ class SCOREBASE(object):
         st.row_flags = self.table_flags.data_ptr() if self.scatter_mode == 0 else None
         st.step_scalars = self._scalars.data_ptr() if self._use_dev_scalars else None
         st.id_status = self._id_status.data_ptr()      # (a caller may have pointed the struct at a status word of its own: dist.py)
-        st.gather_done_event = st.plan_done_event = st.grads_done_event = st.loss_done_event = None
+        st.gather_done_event = st.plan_done_event = st.grads_done_event = st.loss_done_event = st.loss_host = None
         return st
 
     def _event_array(self, events):
@@ -724,6 +741,34 @@ class SCOREBASE(object):
     def device_batch(self, batch_data):
         return batch_data if isinstance(batch_data, DeviceBatch) else DeviceBatch(self, batch_data)
 
+    def sync_errors(self):
+        """how many in-launch barriers of this model's context have ever timed out (score_context_sync_errors; 0)"""
+        n = C.c_int32(0)
+        _lib.check(self.lib.score_context_sync_errors(self._ctx, C.byref(n)), "score_context_sync_errors")
+        return int(n.value)
+
+    def _async_on(self):
+        return (self.launch_worker and self._ps_last and not self._inline_on and not self._graph_on and not self._use_dev_scalars)
+
+    def _async_wait(self, ticket):
+        """the worker thread has ISSUED the job (score_hip.h: before anything waits for / re-records an event the job names)"""
+        if ticket:
+            _lib.check(self.lib.score_async_wait(C.c_uint64(ticket)), "score_async_wait")
+
+    def _evh(self, name):
+        """an event for the worker thread to record: (torch event, handle); recorded once here so that the handle exists"""
+        e = self._evh_cache.get(name)
+        if e is None:
+            ev = torch.cuda.Event()
+            ev.record(self._cur())
+            e = self._evh_cache[name] = (ev, C.c_void_p(ev.cuda_event))
+        return e
+
+    @staticmethod
+    def _ev_list(*events):
+        hs = [C.c_void_p(e.cuda_event) for e in events if e is not None]
+        return (C.c_void_p * max(len(hs), 1))(*hs), len(hs)
+
     def persample_form(self, B, active_slices=0):
         """True if a batch of B samples with `active_slices` computed slices runs as the per-sample whole-model kernels
         (include/score_hip.h score_persample_form; csrc/persample.h): the reference's own shapes.  The step is then a handful of
@@ -761,6 +806,14 @@ class SCOREBASE(object):
         st = self._state(ws)
         if loss_event is not None:
             st.loss_done_event = C.c_void_p(loss_event.cuda_event)
+        st.loss_host = None
+        if self._early_loss is not None and self._ps_last and loss_event is not None:
+            # train() on the per-sample form: the forward kernel's last workgroup stores the loss into pinned host memory itself
+            # (score_state_t.loss_host); the caller reads it behind loss_event -- no copy, no stream of its own
+            el = self._early_loss
+            if el["host"] is None:
+                el["host"] = torch.zeros((4,), dtype=torch.float32).pin_memory()
+            st.loss_host = el["host"].data_ptr()
         if self._tiled_on():
             self._catchup(db, sweep)
         else:
@@ -803,6 +856,7 @@ class SCOREBASE(object):
         # (tests/test_gpu_model.py compares the overlap modes with it bit for bit; the first thing to try on a suspected race)
         inline = bool(int(self.debug_flags) & 4096)
         if inline != self._inline_on or (inline and self._side is not None and self._side.cuda_stream != cur.cuda_stream):
+            self.lib.score_async_wait(C.c_uint64(0))
             torch.cuda.synchronize(self.device)
             self._side = self._sweep_st = self._early_loss_state["stream"] = None
             self._plan_ready = None
@@ -848,7 +902,9 @@ class SCOREBASE(object):
         lay, ws, st = self._forward(db, reg_lambda, keep_prob, dropout_masks,
                                     gather_event=self._ev_gather if (self.scatter_mode == 0 and not early) else None,
                                     sweep=True, stage_event=fwd_stage, loss_event=ev_loss)
-        if self._early_loss is not None:
+        if self._early_loss is not None and st.loss_host:
+            self._early_loss["event"] = ev_loss
+        elif self._early_loss is not None:
             # train(): the loss is final here, a whole backward pass and optimizer step before the stream is through -- it is
             # copied to pinned memory on a stream of its own behind this point, so the caller's read-back (score.py:101-116
             # returns the loss every step) waits for the forward only and the host goes on queueing
@@ -874,12 +930,15 @@ class SCOREBASE(object):
             # the event the side stream waits for)
             want_list = self._tiled_on() and bool(self.adam_touched_list)
             pr, self._plan_ready = self._plan_ready, None
+            if pr is not None and not (pr[0] is db and pr[2] == ws.data_ptr() and pr[3] == db.active_slices and not want_list):
+                self._async_wait(pr[4])            # (a plan nobody uses: still issued before its events and buffers move on)
             if pr is not None and pr[0] is db and pr[2] == ws.data_ptr() and pr[3] == db.active_slices and not want_list:
                 # apply_adam(next_batch=db) of the previous step has already sorted this batch's occurrences, behind that step's
                 # row scatter (_plan_ahead): since the per-sample kernels, the six launches of the sort (~110 us with their gaps)
                 # are longer than the forward and backward kernels they used to hide under
                 plan_done = pr[1]
                 row_list = None
+                self._async_wait(pr[4])            # (the worker has made the record call the backward pass's wait binds to)
                 st.plan_done_event = C.c_void_p(plan_done.cuda_event)
                 self._plan_done = plan_done
                 early = None
@@ -950,8 +1009,7 @@ class SCOREBASE(object):
                                      self._stream())
         _lib.check(rc, "score_backward")
         if ev_sweep_start is not None:
-            self._side.wait_event(ev_sweep_start)
-            self._launch_sweep(self._side)
+            self._launch_sweep(self._side, behind=ev_sweep_start)
         return lay, ws
 
     def _alpha(self, lr):
@@ -973,7 +1031,9 @@ class SCOREBASE(object):
             if self._tiled_on() and self._row_grads:
                 if next_batch is not None:
                     self._catchup_ahead(next_batch, lr)
-            if next_batch is not None and self.plan_ahead:
+            # (the per-sample form only: at cfg-3 the library's sort of 2.9 M occurrences behind the scatter -- instead of beside the
+            #  next forward pass's recurrences, which leave half the chip idle -- cost 1.19 -> 1.31 ms/step, two alternating pairs)
+            if next_batch is not None and self.plan_ahead and self._ps_last:
                 self._plan_ahead(next_batch)
             if self._tiled_on() and self._row_grads:
                 if self._grads_pending is not None:
@@ -981,6 +1041,14 @@ class SCOREBASE(object):
                     # gradients only) first, the dense variables behind the finishers' event -- on the host's side stream
                     # (idle by now: the look-ahead catch-up was started at boundary 4), so that the launch stream goes from the
                     # touched rows straight into the next step; whoever touches the dense variables next waits (self.w)
+                    if self._ps_last:
+                        # (the per-sample form: ONE launch for the touched rows and the dense variables, behind the finishers' event --
+                        #  they end before the row scatter does, tools/kernel_sequence.sh)
+                        self._join_grads()
+                        if not self._adam_table_tiled(lr, dense=(reg_lambda,)):
+                            self.adam_dense(lr, reg_lambda)
+                        self.adam_advance()
+                        return
                     self._adam_table_tiled(lr)
                     # (the per-sample form: on the launch stream.  Its products run wholly on the engine's side stream and take as long
                     #  as the scatter + touched-row update beside them, and the next forward pass needs the dense variables either
@@ -1029,9 +1097,12 @@ class SCOREBASE(object):
 
     def _join_sweep(self, cur):
         if self._ev_sweep is not None:
+            self._async_wait(self._sweep_ticket)
+            self._sweep_ticket = 0
             cur.wait_event(self._ev_sweep)
             self._ev_sweep = None
         if self._ahead is not None:          # (a look-ahead catch-up replays rows on the side stream: nothing else may meanwhile)
+            self._async_wait(self._ahead[2])
             cur.wait_event(self._ahead[1])
 
     def _catchup(self, db, sweep):
@@ -1039,6 +1110,7 @@ class SCOREBASE(object):
         training step the window's slice of the table follows on its own stream, beside the step."""
         ah, self._ahead = self._ahead, None
         if ah is not None:
+            self._async_wait(ah[2])
             self._cur().wait_event(ah[1])
             if ah[0] is db and db.flat is not None:
                 # apply_adam(next_batch=db) of the previous step has brought these rows up to date through that step
@@ -1080,7 +1152,8 @@ class SCOREBASE(object):
             if inline_sweep:
                 self._launch_sweep(cur)
 
-    def _launch_sweep(self, stream):
+    def _launch_sweep(self, stream, behind=None):
+        """behind: an event the slice also has to wait for (the stage boundary it starts at)"""
         if self._pending_sweep is None:
             return
         lo, hi, upto, after = self._pending_sweep
@@ -1088,6 +1161,16 @@ class SCOREBASE(object):
         _, _, T = self._tiled
         cur = self._cur()
         other = stream.cuda_stream != cur.cuda_stream       # (current_stream() returns a new wrapper object every call)
+        if other and self._async_on():
+            ev, evh = self._evh("sweep_w")
+            waits, nw = self._ev_list(behind, after)
+            tk = C.c_uint64(0)
+            _lib.check(self.lib.score_async_adam_catchup_rows(C.byref(T), lo, hi, upto, C.c_void_p(stream.cuda_stream), waits, nw,
+                                                              evh, C.byref(tk)), "score_async_adam_catchup_rows")
+            self._ev_sweep, self._sweep_ticket = ev, int(tk.value)
+            return
+        if behind is not None:
+            stream.wait_event(behind)
         if other:
             stream.wait_event(after)
         _lib.check(self.lib.score_adam_catchup_rows(C.byref(T), lo, hi, upto, C.c_void_p(stream.cuda_stream)),
@@ -1104,15 +1187,27 @@ class SCOREBASE(object):
             return
         _, _, T = self._tiled
         side = self._side
-        side.wait_event(ev4)
-        if self._ev_sweep is not None:       # (a window slice on a stream of its own: behind it)
-            side.wait_event(self._ev_sweep)
         # (the side stream has run this step's window slice before -- it was started at boundary 2 --, so the two replays
         #  never meet on a row; rows in state 2 are skipped here and updated by score_adam_touched on the main stream)
+        if self._async_on():
+            # (a window slice on a stream of its own: behind it -- the worker makes that event's record call before this job's wait)
+            ev, evh = self._evh("ahead_w")
+            waits, nw = self._ev_list(ev4, self._ev_sweep)
+            tk = C.c_uint64(0)
+            _lib.check(self.lib.score_async_adam_catchup_ids_through(C.byref(T), _ptr(nxt.flat), nxt.flat.numel(), int(self.step) + 1,
+                                                                     self._alpha(lr), C.c_void_p(side.cuda_stream), waits, nw, evh,
+                                                                     C.byref(tk)), "score_async_adam_catchup_ids_through")
+            self._ahead = (nxt, ev, int(tk.value))
+            self._b4_recorded = None
+            return
+        side.wait_event(ev4)
+        if self._ev_sweep is not None:       # (a window slice on a stream of its own: behind it)
+            self._async_wait(self._sweep_ticket)
+            side.wait_event(self._ev_sweep)
         _lib.check(self.lib.score_adam_catchup_ids_through(C.byref(T), _ptr(nxt.flat), nxt.flat.numel(), int(self.step) + 1,
                                                            self._alpha(lr), C.c_void_p(side.cuda_stream)),
                    "score_adam_catchup_ids_through")
-        self._ahead = (nxt, self._rec("ahead", side))
+        self._ahead = (nxt, self._rec("ahead", side), 0)
         self._b4_recorded = None
 
     def _plan_ahead(self, nxt):
@@ -1132,10 +1227,18 @@ class SCOREBASE(object):
         st.scatter_mode = 0; st.gemm_mode = int(self.gemm_mode); st.debug_flags = int(self.debug_flags)
         st.context = self._ctx
         st.id_status = None
+        if self._async_on():
+            ev, evh = self._evh("plan_w")
+            waits, nw = self._ev_list(ev4)
+            tk = C.c_uint64(0)
+            _lib.check(self.lib.score_async_index_plan(C.byref(self.cfg), C.byref(st), C.byref(nxt.struct), 1, 0, self._side_handle,
+                                                       waits, nw, evh, C.byref(tk)), "score_async_index_plan")
+            self._plan_ready = (nxt, ev, ws.data_ptr(), nxt.active_slices, int(tk.value))
+            return
         self._side.wait_event(ev4)
         _lib.check(self.lib.score_index_plan(C.byref(self.cfg), C.byref(st), C.byref(nxt.struct), 1, 0, self._side_handle),
                    "score_index_plan")
-        self._plan_ready = (nxt, self._rec("plan_ahead", self._side), ws.data_ptr(), nxt.active_slices)
+        self._plan_ready = (nxt, self._rec("plan_ahead", self._side), ws.data_ptr(), nxt.active_slices, 0)
 
     def _adam_table_tiled(self, lr, dense=None):
         """ApplyAdam of step self.step + 1 on the rows that have a gradient; every other live row owes it.
@@ -1145,10 +1248,12 @@ class SCOREBASE(object):
         returns True if it did that."""
         row_step, ring, T = self._tiled_table()
         cur = self._cur()
-        # this step's window slice first: it must not see a row half-way through its first update (state 0 -> 2 -> 1
-        # with row_step still unset); it finished long ago (it runs beside the forward)
-        self._join_sweep(cur)
+        # (round 5: NOT behind this step's window slice or the look-ahead catch-up any more -- they run on the side stream, on rows
+        #  this update does not touch, and the kernels publish / read a row's step count so that neither can take a row of this
+        #  batch for a lagging one (csrc/adam_tiled.hip tiled_publish_applied).  At the CCMR shape the launch stream stood ~95 us
+        #  per step waiting for slice -> mark -> catch-up in front of this launch.  The next forward pass still waits for both.)
         if not self._tiled_ready:
+            self._join_sweep(cur)
             # (only reached with no row lagging: _flush_adam ran, or nothing tiled has happened yet)
             row_step.fill_(int(self.step))
             self._tiled_ready = True
@@ -1245,10 +1350,119 @@ class SCOREBASE(object):
         self.beta2_power = np.float32(self.beta2_power * np.float32(ADAM_B2))
         self.step += 1
 
+    def _ensure_ev(self, attr):
+        ev = getattr(self, attr)
+        if ev is None:
+            ev = torch.cuda.Event()
+            ev.record(self._cur())              # materialise the hipEvent_t
+            setattr(self, attr, ev)
+        return ev
+
+    def _train_step_fast(self, db, lr, reg_lambda, keep_prob, nxt):
+        """The steady-state step of the per-sample form as ONE call into the library (score_train_step, csrc/step.hip): the same
+        entry points with the same arguments on the same streams and events as forward_backward + apply_adam below make one by
+        one -- what is saved is this interpreter's share of the step (tools/host_calls.py: ~85 of ~190 us at the Tmall default
+        shape, which is bound by the host).  Returns None when the step is not that steady state (first steps, another batch than
+        the one announced, stage events, an evaluation in between, ...): the caller then takes the call-by-call path, and the two
+        can alternate step by step (tests/test_gpu_persample.py)."""
+        if (not self.fast_step or self._graph_on or self._use_dev_scalars or self.scatter_mode != 0 or self.fwd_events or self.bwd_events
+                or self.catchup_events or int(self.debug_flags) or str(self.adam_sweep_at) != "2" or self.adam_touched_list
+                or self._tiled is None or not self._tiled_ready or not self._adam_dirty or self._flags_marked or self._row_grads
+                or self._pending_sweep is not None or self._side is None or not isinstance(db, DeviceBatch) or db.flat is None
+                or not self._look_ahead or not self._tiled_on() or self._async_on()):
+            return None
+        ah, pr = self._ahead, self._plan_ready
+        if ah is None or ah[0] is not db or pr is None or pr[0] is not db or pr[3] != db.active_slices:
+            return None
+        if nxt is not None and (not isinstance(nxt, DeviceBatch) or nxt.flat is None or not self.plan_ahead):
+            return None
+        if not self.persample_form(db.B, db.active_slices):
+            return None
+        lay, ws = self._workspace(db.B)
+        if pr[2] != ws.data_ptr():
+            return None
+        cur = self._cur()
+        if self._inline_on or (self._train_stream is not None and self._train_stream.cuda_stream != cur.cuda_stream):
+            return None
+        self._join_dense()
+        self._join_grads()
+        st = self._state(ws)
+        row_step, ring, T = self._tiled
+        p = self._step_args
+        if p is None:
+            p = self._step_args = _lib.TrainStep()
+            p.table = C.addressof(T)
+            p.n_w, p.n_reg = self.n_w, self.n_reg
+            p.skipped = self._id_status.data_ptr() + 4 if self._guard_on else None
+            p.side_stream = self._side.cuda_stream
+            p.ev_stage2 = self._ensure_ev("_ev_stage").cuda_event
+            p.ev_b4 = self._ensure_ev("_ev_b4").cuda_event
+            p.ev_grads = self._ensure_ev("_ev_grads").cuda_event
+            p.ev_loss = self._ensure_ev("_ev_loss").cuda_event
+            self._step_T = T
+        elif self._step_T is not T:
+            p.table = C.addressof(T)
+            self._step_T = T
+        p.w, p.w_m, p.w_v, p.w_g = self._w.data_ptr(), self._w_m.data_ptr(), self._w_v.data_ptr(), self._w_g.data_ptr()
+        ev_sweep = self._ev_sweep
+        p.wait_sweep = 1 if ev_sweep is not None else 0
+        if ev_sweep is None:
+            ev_sweep = self._evs.get("sweep") or self._rec("sweep", cur)
+        p.ev_sweep = ev_sweep.cuda_event
+        p.wait_ahead = 1
+        p.ev_ahead = ah[1].cuda_event
+        p.ev_plan = pr[1].cuda_event
+        p.reg_lambda, p.keep_prob, p.alpha = float(reg_lambda), float(keep_prob), self._alpha(lr)
+        upto = int(self.step)
+        p.step = upto + 1
+        p.drop_seed = (self._drop_seed * 0x9E3779B1 + upto * 0x85EBCA77) & 0xFFFFFFFFFFFFFFFF
+        rows, K = self._tbl.shape[0], self.adam_window
+        j = (upto + 1) % K
+        p.slice_lo, p.slice_hi, p.slice_upto = rows * j // K, rows * (j + 1) // K, upto
+        if nxt is not None:
+            lay2, ws2 = self._workspace(nxt.B)
+            p.next_batch, p.next_ids, p.n_next_ids = C.addressof(nxt.struct), nxt.flat.data_ptr(), nxt.flat.numel()
+            p.next_workspace, p.next_workspace_bytes = ws2.data_ptr(), ws2.numel() * 4
+        else:
+            p.next_batch = None
+        el = self._early_loss
+        if el is not None:
+            if el["host"] is None:
+                el["host"] = torch.zeros((4,), dtype=torch.float32).pin_memory()
+            p.loss_host = el["host"].data_ptr()
+            el["event"] = self._ev_loss
+        else:
+            p.loss_host = None
+        self._ahead = None
+        self._plan_ready = None
+        _lib.check(self.lib.score_train_step(C.byref(self.cfg), C.byref(st), C.byref(db.struct), C.byref(p), self._stream()),
+                   "score_train_step")
+        # the bookkeeping forward_backward + apply_adam leave behind
+        self._ps_last, self._train_stream = True, cur
+        self._keep = (None, None)
+        self._ev_sweep = ev_sweep if p.slice_hi > p.slice_lo else None
+        self._sweep_ticket = 0
+        self._plan_done = pr[1]
+        self._b4_recorded, self._b4_any = None, self._ev_b4
+        self._grads_pending = None
+        self._row_grads = self._flags_marked = False
+        self._adam_dirty = True
+        self._row_list = None
+        if nxt is not None:
+            self._ahead = (nxt, ah[1], 0)
+            self._plan_ready = (nxt, pr[1], ws2.data_ptr(), nxt.active_slices, 0)
+        self.adam_advance()
+        return ws[lay.loss]
+
     def train_async(self, batch_data, lr, reg_lambda, keep_prob=0.8, dropout_masks=None, next_batch=None):
         """One training step; returns the loss as a 0-d device tensor (no host sync).  next_batch: see apply_adam."""
         if self._graph_on and dropout_masks is None and self.scatter_mode == 0 and not self.fwd_events:
             return self._train_captured(batch_data, lr, reg_lambda, keep_prob)
+        if dropout_masks is None and self._ahead is not None and self._ahead[0] is batch_data:
+            with self._Pin(self):
+                loss = self._train_step_fast(batch_data, lr, reg_lambda, keep_prob, next_batch)
+            if loss is not None:
+                return loss
         with self._Pin(self):
             lay, ws = self.forward_backward(batch_data, reg_lambda, keep_prob, dropout_masks)
             self.apply_adam(lr, reg_lambda, next_batch)
@@ -1310,12 +1524,23 @@ class SCOREBASE(object):
                 static = DeviceBatch.empty(self, db.B, db.active_slices)
                 static.flat.copy_(db.flat)
                 lay, ws = self._workspace(db.B)
+                self.lib.score_async_wait(C.c_uint64(0))       # (no other thread of ours makes a HIP call while the capture runs)
                 torch.cuda.synchronize(self.device)
                 g = torch.cuda.CUDAGraph()
                 step, b1p, b2p = self.step, self.beta1_power, self.beta2_power
-                with torch.cuda.graph(g):
-                    self.forward_backward(static, reg_lambda, keep_prob, None)
-                    self.apply_adam(lr, reg_lambda)
+                # (no cyclic garbage collection inside the capture: another model's __del__ -- it synchronises its streams and
+                #  destroys its context -- is not a legal call while a stream of the device is capturing; seen once as
+                #  hipErrorStreamCaptureInvalidated in a long test session.  torch.cuda.graph collects right before it begins.)
+                import gc
+                gc_on = gc.isenabled()
+                gc.disable()
+                try:
+                    with torch.cuda.graph(g):
+                        self.forward_backward(static, reg_lambda, keep_prob, None)
+                        self.apply_adam(lr, reg_lambda)
+                finally:
+                    if gc_on:
+                        gc.enable()
                 # (capturing executed nothing: undo the host-side bookkeeping of the traced call)
                 self.step, self.beta1_power, self.beta2_power = step, b1p, b2p
                 ent = self._graphs[key] = (g, static, lay, ws)
@@ -1375,6 +1600,7 @@ class SCOREBASE(object):
                 self._rollback_steps(skipped)
             self._pending_sweep = None          # (a window slice scheduled for a step that was not applied)
             if self._ahead is not None:         # (a look-ahead catch-up that the set word suppressed)
+                self._async_wait(self._ahead[2])
                 self._cur().wait_event(self._ahead[1])
                 self._ahead = None
             self._adam_dirty = self._tiled is not None and self._tiled_ready     # (a suppressed flush left rows behind)

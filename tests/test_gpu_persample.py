@@ -132,3 +132,46 @@ def test_bad_ids_are_reported_by_the_fused_gather():
         assert "batch_data[%d]" % i in str(ei.value)
     l = m.train(None, batch_tuple(b), 1e-3, 1e-4, keep_prob=1.0)
     assert np.isfinite(l)
+
+
+def test_one_call_step_equals_the_call_by_call_step():
+    """score_train_step (csrc/step.hip): the steady-state step as ONE library call -- the same entry points, arguments, streams and
+    events as forward_backward + apply_adam make one by one.  Two models, one with fast_step off: the same losses (train()'s
+    read-back and train_async's device scalar), predictions and optimizer state bit for bit, with right hints, a wrong hint, no
+    hint, an evaluation and a table read in between, a batch of another size, and an lr change -- and the fast path did run."""
+    from test_gpu_adam_tiled import make, batches, same_state
+    cfg = so.Cfg(3000, 16, 32, 5, 3, 2, 3, "SCORE")
+    a, b = make(cfg, 5), make(cfg, 5)
+    b.fast_step = False
+    bs = batches(cfg, 6, 8, seed=33, hot_rows=150) + batches(cfg, 2, 5, seed=34, hot_rows=150)
+    da, db_ = [a.device_batch(x) for x in bs], [b.device_batch(x) for x in bs]
+    order = [0, 1, 2, 3, 4, 5, 0, 2, 4, 1, 3, 5, 5, 0, 1, 6, 7, 2, 3, 4, 0, 1, 2, 3, 4, 5, 0, 1]
+    calls = {"n": 0}
+    real = a.lib.score_train_step
+
+    def counting(*args):
+        calls["n"] += 1
+        return real(*args)
+
+    class Lib(object):
+        def __getattr__(self, name):
+            return counting if name == "score_train_step" else getattr(a_lib, name)
+    a_lib, a.lib = a.lib, Lib()
+    for i, bi in enumerate(order):
+        lr = 1e-2 if i < 17 else 3e-3
+        nxt = order[i + 1] if i + 1 < len(order) else 0
+        hint = None if i % 9 == 8 else (nxt + 1) % 6 if i % 7 == 3 else nxt
+        ha, hb = (None, None) if hint is None else (da[hint], db_[hint])
+        if i % 3 == 2:
+            la, lb = a.train(None, da[bi], lr, 1e-4, keep_prob=0.8, next_batch=ha), b.train(None, db_[bi], lr, 1e-4, keep_prob=0.8, next_batch=hb)
+        else:
+            la = float(a.train_async(da[bi], lr, 1e-4, keep_prob=0.8, next_batch=ha))
+            lb = float(b.train_async(db_[bi], lr, 1e-4, keep_prob=0.8, next_batch=hb))
+        assert la == lb, (i, la, lb)
+        if i == 10:
+            assert a.eval(None, da[4], 1e-4)[0] == b.eval(None, db_[4], 1e-4)[0]
+        if i == 20:
+            assert same_state(a, b), i
+    assert same_state(a, b)
+    assert calls["n"] >= 12, calls            # (most steps: every one whose batch was the one announced a step earlier)
+    a.lib = a_lib
