@@ -538,11 +538,11 @@ int score_backward(const score_config_t* cfg, const score_state_t* st, const sco
  * The steady-state step of model.train (score.py:101-116) for a caller that runs the time-tiled table optimizer with the
  * look-ahead (score_adam_catchup_ids_through) and sorts the next batch's index plan a step ahead: exactly
  *   wait(ev_ahead), wait(ev_sweep)                                   [stream]   if wait_ahead / wait_sweep
- *   score_forward(..., loss_done_event = ev_loss, loss_host)         [stream]
- *   score_backward(plan_done_event = ev_plan, grads_done_event = ev_grads, stage events 2 / 4 = ev_stage2 / ev_b4)   [stream]
- *   wait(ev_stage2); score_adam_catchup_rows(slice); record(ev_sweep)                       [side_stream]   if slice_hi > slice_lo
+ *   score_forward(..., loss_host, loss_done_event = ev_loss if loss_host)                   [stream]
+ *   score_backward(plan_done_event = ev_plan, grads_done_event = ev_grads, stage event 4 = ev_b4)   [stream]
  *   wait(ev_b4); score_adam_catchup_ids_through(next ids, step, alpha); record(ev_ahead);
  *                score_index_plan(next batch -> next_workspace); record(ev_plan)            [side_stream]   if next_batch
+ *                score_adam_catchup_rows(slice); record(ev_sweep)                           [side_stream]   if slice_hi > slice_lo
  *   wait(ev_grads); score_adam_touched_and_dense(step, alpha, l2 = reg_lambda)              [stream]
  * -- the same entry points with the same arguments a caller would use one by one (the events are the caller's, re-used from
  * call to call: every wait above is issued before the same call re-records its event).  PRECONDITIONS the caller guarantees:

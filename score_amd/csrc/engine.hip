@@ -816,10 +816,15 @@ int backward_ps(const Dims& d, const Params& P, const WS& w, const PsPlan& pp, c
 
   // ---- the weight-gradient products in one grouped flush, then the finishers (side stream with grads_done_event)
   {
+    // (round 5: TWO launches -- products + column sums' first stage, then slab reduce + second stage + the folded attention
+    //  layer's gradient -- where there were four in a row: they stand between the backward kernel and the dense ApplyAdam)
     ReduceGroup rg;
-    G(gemm_queue_flush(&gq, x3 != 0, ws + w.dwslab, w.dwslab_floats, fs, &rg));
-    G(score_launch_finish(&rg, &cq, ws + w.cs_part, w.cs_part_floats, fs));
-    G(score_launch_attn_w1_grad(d.Dk, AT1, ws + w.dweff, ws + w.dwq, gw + P.at_w[1], fs));
+    int cs_done = 0;
+    G(gemm_queue_flush(&gq, x3 != 0, ws + w.dwslab, w.dwslab_floats, fs, &rg, &cq, ws + w.cs_part, w.cs_part_floats, &cs_done));
+    W1Fold wf;
+    memset(&wf, 0, sizeof(wf));
+    wf.Dk = d.Dk; wf.NA = AT1; wf.dweff = ws + w.dweff; wf.dwq = ws + w.dwq; wf.gW1 = gw + P.at_w[1];
+    G(score_launch_finish(&rg, &cq, ws + w.cs_part, w.cs_part_floats, fs, cs_done, &wf));
     if (fin_side) HIPTRY(hipEventRecord((hipEvent_t)st->grads_done_event, fs));
   }
   // ---- embedding rows (score.py:51-66): the sorted pull-form scatter

@@ -5,6 +5,7 @@
 // slab reduce.  Large products are routed to gemm_bf16x3.hip when the caller allows it.  Also here: the
 // deferred multi-job column sum (bias gradients, slab reductions), the grouped launches and the deferred
 // weight-gradient queue.
+#include <cstring>
 #include "common.h"
 #include "kernels.h"
 
@@ -46,10 +47,10 @@ __device__ __forceinline__ float epilogue(float v, int row, int col, int N, cons
 // TRANS 2: A[K,M] (lda) , B[K,N] (ldb)  -> C = A^T . B
 // Block = 2x2 waves, each wave a (32*WM) x (32*WN) tile => block tile (64*WM) x (64*WN).
 template <int TRANS, int WM, int WN, int BK>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmGroup grp, const float* __restrict__ bias, int flags,
-                                                       float keep, const uint8_t* __restrict__ mask, uint64_t seed) {
+__device__ __forceinline__ void gemm_f32_body(const GemmGroup& grp, int blk, const float* __restrict__ bias, int flags,
+                                              float keep, const uint8_t* __restrict__ mask, uint64_t seed) {
   // this workgroup's problem and its index inside it (kernels.h: GemmGroup)
-  int pi = 0, local = (int)blockIdx.x;
+  int pi = 0, local = blk;
   while (pi + 1 < grp.n && local >= ((grp.p[pi].nblocks + 7) & ~7)) { local -= (grp.p[pi].nblocks + 7) & ~7; ++pi; }
   const GemmProb& pr = grp.p[pi];
   if (local >= pr.nblocks) return;
@@ -192,6 +193,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmGroup grp, cons
         }
       }
     }
+}
+template <int TRANS, int WM, int WN, int BK>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmGroup grp, const float* __restrict__ bias, int flags,
+                                                       float keep, const uint8_t* __restrict__ mask, uint64_t seed) {
+  gemm_f32_body<TRANS, WM, WN, BK>(grp, (int)blockIdx.x, bias, flags, keep, mask, seed);
 }
 
 __global__ void splitk_reduce_kernel(const float* __restrict__ slab, int nsplit, int M, int N,
@@ -430,7 +436,10 @@ int gemm_queue_add(GemmQueue* q, int M, int N, int K, const float* A, int lda, c
 // C_j = A_j^T . B_j for every queued job: the jobs that qualify for the bf16x3 kernel go out as one grouped
 // launch of 128x128 tiles, the rest as one grouped launch of the 64x64 f32 kernel, K split so that either
 // launch fills the chip a few times over; one more launch reduces all slabs (fixed order: reproducible).
-int gemm_queue_flush(GemmQueue* q, int x3, float* slab, int64_t slab_floats, hipStream_t s, ReduceGroup* defer) {
+__global__ void gemm_colsum_kernel(const GemmGroup grp, const ColsumJobs jobs, float* __restrict__ part, int gemm_blocks, int gx);
+int gemm_queue_flush(GemmQueue* q, int x3, float* slab, int64_t slab_floats, hipStream_t s, ReduceGroup* defer,
+                     const ColsumJobs* with_colsums, float* cs_part, int64_t cs_part_floats, int* colsums_done) {
+  if (colsums_done) *colsums_done = 0;
   if (defer) defer->n = defer->blocks = 0;
   if (!q || q->n == 0) return 0;
   if (!slab) return SCORE_E_BADARG;
@@ -497,7 +506,16 @@ int gemm_queue_flush(GemmQueue* q, int x3, float* slab, int64_t slab_floats, hip
     ++g.n;
   }
   if (g3.n) SCORE_TRY(score_launch_gemm_bf16x3(2, 2, g3, nullptr, 0, 1.f, nullptr, 0, s));
-  if (gf.n) {
+  if (gf.n && with_colsums && with_colsums->n > 0 && cs_part && with_colsums->part_used <= cs_part_floats) {
+    int gx = 1;
+    for (int i = 0; i < with_colsums->n; ++i)
+      gx = max(gx, (with_colsums->job[i].N + with_colsums->job[i].cols - 1) / with_colsums->job[i].cols);
+    const int64_t cs_blocks = (int64_t)gx * COLSUM_MAX_PARTS * with_colsums->n;
+    hipLaunchKernelGGL(gemm_colsum_kernel, dim3((unsigned)(gf.total_blocks + cs_blocks)), dim3(256), 0, s, gf, *with_colsums, cs_part,
+                       gf.total_blocks, gx);
+    SCORE_CHECK_LAUNCH();
+    if (colsums_done) *colsums_done = 1;
+  } else if (gf.n) {
     hipLaunchKernelGGL((gemm_f32_kernel<2, 1, 1, 16>), dim3(gf.total_blocks), dim3(256), 0, s, gf, nullptr, 0, 1.f, nullptr,
                        0);
     SCORE_CHECK_LAUNCH();
@@ -560,14 +578,14 @@ int score_launch_colsum(const float* X, int M, int N, int ld, float* out, int ac
 }
 
 // ---- many column sums in two launches (bias gradients and slab reductions of one backward pass)
-__global__ __launch_bounds__(256) void colsum_multi_stage1(const ColsumJobs jobs, float* __restrict__ part) {
+__device__ __forceinline__ void colsum_multi_stage1_body(const ColsumJobs& jobs, float* __restrict__ part, int bx, int by, int bz) {
   __shared__ float sh[256];
-  const ColsumJob& j = jobs.job[blockIdx.z];
+  const ColsumJob& j = jobs.job[bz];
   const int cols = j.cols, nty = 256 / cols;
-  if ((int)blockIdx.y >= j.nparts || (int)blockIdx.x * cols >= j.N) return;
+  if (by >= j.nparts || bx * cols >= j.N) return;
   const int tx = threadIdx.x % cols, ty = threadIdx.x / cols;
-  const int n = blockIdx.x * cols + tx;
-  const int m0 = blockIdx.y * j.rpb, m1 = min(j.M, m0 + j.rpb);
+  const int n = bx * cols + tx;
+  const int m0 = by * j.rpb, m1 = min(j.M, m0 + j.rpb);
   float s = 0.f;
   if (n < j.N) {
     // four rows in flight per thread; the order of the adds is fixed by (rpb, nty): reproducible
@@ -598,8 +616,25 @@ __global__ __launch_bounds__(256) void colsum_multi_stage1(const ColsumJobs jobs
   if (ty == 0 && n < j.N) {
     float t = 0.f;
     for (int r = 0; r < nty; ++r) t += sh[r * cols + tx];
-    part[j.part_off + (int64_t)blockIdx.y * j.N + n] = t;
+    part[j.part_off + (int64_t)by * j.N + n] = t;
   }
+}
+__global__ __launch_bounds__(256) void colsum_multi_stage1(const ColsumJobs jobs, float* __restrict__ part) {
+  colsum_multi_stage1_body(jobs, part, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
+}
+// The grouped f32 weight-gradient products AND the column sums' first stage in ONE launch (round 5, the per-sample form): both
+// read what the backward kernel left, neither reads the other -- as two launches on one stream they ran one after the other
+// (16 + 17 us at the Tmall default shape, in front of the dense variables' ApplyAdam).  Workgroups [0, gemm_blocks): the
+// products (gemm_f32_kernel<2, 1, 1, 16>'s body), the rest: colsum_multi_stage1's (bx fastest, then part, then job).
+__global__ __launch_bounds__(256) void gemm_colsum_kernel(const GemmGroup grp, const ColsumJobs jobs, float* __restrict__ part,
+                                                          int gemm_blocks, int gx) {
+  const int blk = (int)blockIdx.x;
+  if (blk < gemm_blocks) {
+    gemm_f32_body<2, 1, 1, 16>(grp, blk, nullptr, 0, 1.f, nullptr, 0);
+    return;
+  }
+  const int b = blk - gemm_blocks;
+  colsum_multi_stage1_body(jobs, part, b % gx, (b / gx) % COLSUM_MAX_PARTS, b / (gx * COLSUM_MAX_PARTS));
 }
 __device__ __forceinline__ void colsum_multi_stage2_body(const ColsumJobs& jobs, const float* __restrict__ part, int job, int bx) {
   const ColsumJob& j = jobs.job[job];
@@ -622,15 +657,37 @@ __global__ void colsum_multi_stage2(const ColsumJobs jobs, const float* __restri
   colsum_multi_stage2_body(jobs, part, (int)blockIdx.y, (int)blockIdx.x);
 }
 // workgroups [0, rg.blocks): the split-K slab reduce; the rest, gx2 per job: the column sums' second stage
+// one element of a product from its split-K slabs, in slab order (splitk_reduce_group_body's sum), or from C where K was not split
+__device__ __forceinline__ float w1_piece(const float* __restrict__ slab, int ns, int64_t n, const float* __restrict__ C, int64_t i) {
+  if (ns <= 1) return C[i];
+  float s = 0.f;
+  for (int z = 0; z < ns; ++z) s += slab[(int64_t)z * n + i];
+  return s;
+}
 __global__ __launch_bounds__(256) void finish_kernel(const ReduceGroup rg, const ColsumJobs jobs, const float* __restrict__ part,
-                                                     int gx2) {
+                                                     int gx2, int cs_blocks, const W1Fold w1) {
   const int blk = (int)blockIdx.x;
   if (blk < rg.blocks) {
     splitk_reduce_group_body(rg, blk);
     return;
   }
   const int b = blk - rg.blocks;
-  colsum_multi_stage2_body(jobs, part, b / gx2, b % gx2);
+  if (b < cs_blocks) {
+    colsum_multi_stage2_body(jobs, part, b / gx2, b % gx2);
+    return;
+  }
+  // the folded first attention layer's gradient (head.hip attn_w1_grad_kernel: dWa = dWq, dWb = dWeff_k, dWc = dWq - dWeff_k,
+  // dWd = dWeff_qk) straight from the two products' slabs -- it was a launch of its own behind this one
+  const int64_t n = (int64_t)w1.Dk * w1.NA;
+  const int64_t i = (int64_t)(b - cs_blocks) * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float dq = w1_piece(w1.slab_q, w1.ns_q, n, w1.dwq, i);
+  const float dk = w1_piece(w1.slab_e, w1.ns_e, 2 * n, w1.dweff, i);
+  const float dqk = w1_piece(w1.slab_e, w1.ns_e, 2 * n, w1.dweff, n + i);
+  w1.gW1[i] = dq;
+  w1.gW1[n + i] = dk;
+  w1.gW1[2 * n + i] = dq - dk;
+  w1.gW1[3 * n + i] = dqk;
 }
 
 int colsum_queue_add(ColsumJobs* q, const float* X, int M, int N, int ld, float* out, int acc, const float* scale) {
@@ -651,10 +708,24 @@ int colsum_queue_add(ColsumJobs* q, const float* X, int M, int N, int ld, float*
   return 0;
 }
 
-int score_launch_finish(const ReduceGroup* rg, ColsumJobs* q, float* part, int64_t part_floats, hipStream_t s) {
+int score_launch_finish(const ReduceGroup* rg, ColsumJobs* q, float* part, int64_t part_floats, hipStream_t s, int stage1_done,
+                        const W1Fold* w1) {
   ReduceGroup none;
   none.n = none.blocks = 0;
   if (!rg) rg = &none;
+  W1Fold wf;
+  memset(&wf, 0, sizeof(wf));
+  int w1_blocks = 0;
+  if (w1 && q && q->n > 0) {
+    wf = *w1;
+    for (int i = 0; i < rg->n; ++i) {       // the two products' slab sets (none: K was not split, the product wrote its C)
+      if (rg->j[i].C == w1->dweff) { wf.slab_e = rg->j[i].slab; wf.ns_e = rg->j[i].ns; }
+      if (rg->j[i].C == w1->dwq) { wf.slab_q = rg->j[i].slab; wf.ns_q = rg->j[i].ns; }
+    }
+    w1_blocks = (int)cdiv64((int64_t)w1->Dk * w1->NA, 256);
+  } else if (w1) {
+    return SCORE_E_BADARG;
+  }
   if (!q || q->n == 0) {
     if (rg->n) {
       hipLaunchKernelGGL(splitk_reduce_group_kernel, dim3(rg->blocks), dim3(256), 0, s, *rg);
@@ -668,9 +739,11 @@ int score_launch_finish(const ReduceGroup* rg, ColsumJobs* q, float* part, int64
     gx = max(gx, (q->job[i].N + q->job[i].cols - 1) / q->job[i].cols);
     gx2 = max(gx2, (q->job[i].N + 255) / 256);
   }
-  hipLaunchKernelGGL(colsum_multi_stage1, dim3(gx, COLSUM_MAX_PARTS, q->n), dim3(256), 0, s, *q, part);
-  SCORE_CHECK_LAUNCH();
-  hipLaunchKernelGGL(finish_kernel, dim3(rg->blocks + gx2 * q->n), dim3(256), 0, s, *rg, *q, part, gx2);
+  if (!stage1_done) {
+    hipLaunchKernelGGL(colsum_multi_stage1, dim3(gx, COLSUM_MAX_PARTS, q->n), dim3(256), 0, s, *q, part);
+    SCORE_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(finish_kernel, dim3(rg->blocks + gx2 * q->n + w1_blocks), dim3(256), 0, s, *rg, *q, part, gx2, gx2 * q->n, wf);
   SCORE_CHECK_LAUNCH();
   q->n = 0;
   q->part_used = 0;

@@ -28,7 +28,12 @@ struct ReduceJob { const float* slab; float* C; int ns, M, N, ldc, first_block, 
 struct ReduceGroup { int n; int blocks; ReduceJob j[2 * GEMM_GROUP_MAX]; };
 // defer == nullptr: the slab reduce follows the products on `s`.  defer given: the products only; *defer describes the reduce
 // the caller still owes (score_launch_finish, behind the products)
-int gemm_queue_flush(GemmQueue* q, int x3, float* slab, int64_t slab_floats, hipStream_t s, ReduceGroup* defer = nullptr);
+// with_colsums (+ cs_part): the queued column sums' FIRST stage runs in the same launch as the f32 products (*colsums_done = 1 if
+// it did: score_launch_finish(..., stage1_done) then starts at the second stage)
+struct ColsumJobs;
+int gemm_queue_flush(GemmQueue* q, int x3, float* slab, int64_t slab_floats, hipStream_t s, ReduceGroup* defer = nullptr,
+                     const ColsumJobs* with_colsums = nullptr, float* cs_part = nullptr, int64_t cs_part_floats = 0,
+                     int* colsums_done = nullptr);
 #define COLSUM_MAX_JOBS 24
 #define COLSUM_MAX_PARTS 128
 struct ColsumJob { const float* X; float* out; const float* scale; int M, N, ld, acc, cols, rpb, nparts; int64_t part_off; };
@@ -41,7 +46,11 @@ int colsum_queue_flush(ColsumJobs* q, float* part, int64_t part_floats, hipStrea
 // the end of a backward pass in TWO launches instead of four: the queued column sums' first stage, then ONE launch that is
 // the deferred split-K slab reduce of gemm_queue_flush (rg, may be empty) AND the column sums' second stage -- the two are
 // independent of each other, each workgroup does what its index says.  Same arithmetic, same order as the separate launches.
-int score_launch_finish(const ReduceGroup* rg, ColsumJobs* q, float* part, int64_t part_floats, hipStream_t s);
+// w1: the folded first attention layer's gradient computed by the same launch from the dweff / dwq products' slabs
+// (instead of score_launch_attn_w1_grad behind it); stage1_done: see gemm_queue_flush
+struct W1Fold { int Dk, NA; const float* dweff; const float* dwq; float* gW1; const float* slab_e; const float* slab_q; int ns_e, ns_q; };
+int score_launch_finish(const ReduceGroup* rg, ColsumJobs* q, float* part, int64_t part_floats, hipStream_t s, int stage1_done = 0,
+                        const W1Fold* w1 = nullptr);
 int score_launch_colsum(const float* X, int M, int N, int ld, float* out, int accumulate,
                         float* scratch, int64_t scratch_floats, hipStream_t s);
 // embed.hip

@@ -20,7 +20,7 @@
 extern "C" int score_train_step(const score_config_t* cfg, const score_state_t* st_in, const score_batch_t* batch,
                                 const score_train_step_t* p, void* stream) {
   if (!cfg || !st_in || !batch || !p || !p->table || !p->w || !p->w_m || !p->w_v || !p->w_g || !p->side_stream ||
-      !p->ev_stage2 || !p->ev_b4 || !p->ev_grads || !p->ev_sweep || !p->ev_plan || !p->ev_ahead)
+      !p->ev_b4 || !p->ev_grads || !p->ev_sweep || !p->ev_plan || !p->ev_ahead)
     return SCORE_E_BADARG;
   hipStream_t s = (hipStream_t)stream, side = (hipStream_t)p->side_stream;
   score_state_t st = *st_in;
@@ -28,9 +28,9 @@ extern "C" int score_train_step(const score_config_t* cfg, const score_state_t* 
   //     rows, the window slice
   if (p->wait_ahead) HIPTRY_(hipStreamWaitEvent(s, (hipEvent_t)p->ev_ahead, 0));
   if (p->wait_sweep) HIPTRY_(hipStreamWaitEvent(s, (hipEvent_t)p->ev_sweep, 0));
-  // (2) forward
+  // (2) forward (ev_loss: only somebody who reads the loss from the host needs an event behind the forward kernel)
   st.gather_done_event = nullptr;
-  st.loss_done_event = p->ev_loss;
+  st.loss_done_event = p->loss_host ? p->ev_loss : nullptr;
   st.loss_host = p->loss_host;
   st.plan_done_event = nullptr;
   st.grads_done_event = nullptr;
@@ -39,17 +39,11 @@ extern "C" int score_train_step(const score_config_t* cfg, const score_state_t* 
   //     the context's side stream
   st.plan_done_event = p->ev_plan;
   st.grads_done_event = p->ev_grads;
-  void* ev[6] = {nullptr, nullptr, p->ev_stage2, nullptr, p->ev_b4, nullptr};
+  void* ev[6] = {nullptr, nullptr, nullptr, nullptr, p->ev_b4, nullptr};
   SCORE_TRY(score_backward(cfg, &st, batch, p->keep_prob, p->w_g, const_cast<float*>(p->table->g), ev, stream));
-  // (4) side stream: this step's slice of the table (rows nobody in the batch touches), from stage boundary 2 of the pass
-  if (p->slice_hi > p->slice_lo) {
-    HIPTRY_(hipStreamWaitEvent(side, (hipEvent_t)p->ev_stage2, 0));
-    SCORE_TRY(score_adam_catchup_rows(p->table, p->slice_lo, p->slice_hi, p->slice_upto, p->side_stream));
-    HIPTRY_(hipEventRecord((hipEvent_t)p->ev_sweep, side));
-  }
-  // (5) side stream, behind the row scatter: the NEXT batch's rows brought up to date through this step, then its index plan
+  // (4) side stream, behind the row scatter: the NEXT batch's rows brought up to date through this step, then its index plan
+  HIPTRY_(hipStreamWaitEvent(side, (hipEvent_t)p->ev_b4, 0));
   if (p->next_batch) {
-    HIPTRY_(hipStreamWaitEvent(side, (hipEvent_t)p->ev_b4, 0));
     SCORE_TRY(score_adam_catchup_ids_through(p->table, p->next_ids, p->n_next_ids, p->step, p->alpha, p->side_stream));
     HIPTRY_(hipEventRecord((hipEvent_t)p->ev_ahead, side));
     score_state_t sp = *st_in;
@@ -59,6 +53,14 @@ extern "C" int score_train_step(const score_config_t* cfg, const score_state_t* 
     sp.loss_host = nullptr;
     SCORE_TRY(score_index_plan(cfg, &sp, p->next_batch, 1, 0, p->side_stream));
     HIPTRY_(hipEventRecord((hipEvent_t)p->ev_plan, side));
+  }
+  // (5) ... and LAST on the side stream this step's slice of the table (rows lagging behind step - 1, none of them this batch's or
+  //     -- any more -- the next one's): nothing of the next step waits for it (its own side-stream work queues behind it, its
+  //     forward pass reads rows the slice skips, its touched-row update publishes counts the slice cannot mistake: adam_tiled.hip);
+  //     ev_sweep is for whoever reads the table otherwise (a flush, an evaluation, the call-by-call path)
+  if (p->slice_hi > p->slice_lo) {
+    SCORE_TRY(score_adam_catchup_rows(p->table, p->slice_lo, p->slice_hi, p->slice_upto, p->side_stream));
+    HIPTRY_(hipEventRecord((hipEvent_t)p->ev_sweep, side));
   }
   // (6) the step's ApplyAdam: rows with a gradient and the dense variables in one launch, behind the finishers
   HIPTRY_(hipStreamWaitEvent(s, (hipEvent_t)p->ev_grads, 0));

@@ -228,6 +228,7 @@ class SCOREBASE(object):
         self._evs = {}
         self._ps_last = False           # the last forward_backward ran as the per-sample whole-model kernels
         self._inline_on = False         # debug_flags bit 12 was set at the last forward_backward: every stream below IS the launch stream
+        self._sweep_on_side = False     # the pending window slice was queued on self._side (by the one-call step)
         self.fast_step = True           # train / train_async: the steady-state step of the per-sample form as one library call (_train_step_fast)
         self._step_args = self._step_T = None
         # the launches that start side-stream work (next batch's index plan, look-ahead catch-up, window slice) are made by the
@@ -1095,8 +1096,13 @@ class SCOREBASE(object):
             self._tiled_ready = False
         return self._tiled
 
-    def _join_sweep(self, cur):
-        if self._ev_sweep is not None:
+    def _join_sweep(self, cur, rows_untouched=False):
+        """rows_untouched: the caller launches nothing that replays rows on `cur` (the batch's rows were caught up a step ahead);
+        a slice the one-call step queued LAST on the side stream then needs no wait: what follows on the side stream queues
+        behind it, the forward pass reads rows it skips, the touched-row update publishes counts it cannot mistake"""
+        if self._ev_sweep is not None and rows_untouched and self._sweep_on_side and str(self.adam_sweep_at) != "f1":
+            pass            # (adam_sweep_at "f1" puts this step's slice on a stream of its own: it would not queue behind that one)
+        elif self._ev_sweep is not None:
             self._async_wait(self._sweep_ticket)
             self._sweep_ticket = 0
             cur.wait_event(self._ev_sweep)
@@ -1123,7 +1129,7 @@ class SCOREBASE(object):
         self._catchup_ids([db.flat] if db.flat is not None else list(db.tensors[:6]), sweep)
 
     def _catchup_ids(self, spans, sweep, inline_sweep=False):
-        """spans: int32 device tensors of row ids (values outside the table are ignored)"""
+        """spans: int32 device tensors of row ids (values outside the table are ignored); [] = the rows are up to date already"""
         ev = self.catchup_events
         _, _, T = self._tiled_table()     # (created here, on the main stream, well before the side stream first uses it)
         if not self._adam_dirty:
@@ -1131,7 +1137,7 @@ class SCOREBASE(object):
                 ev[0].record(); ev[1].record()
             return
         cur = self._cur()
-        self._join_sweep(cur)
+        self._join_sweep(cur, rows_untouched=not spans and not self._flags_marked and not inline_sweep)
         if self._flags_marked:
             self._drop_row_marks()        # (a backward nobody applied left state-2 marks)
         upto = int(self.step)
@@ -1177,6 +1183,7 @@ class SCOREBASE(object):
                    "score_adam_catchup_rows")
         if other:
             self._ev_sweep = self._rec("sweep", stream)
+            self._sweep_on_side = False
 
     _look_ahead = True               # score_backward records its stage boundary 4 for apply_adam(next_batch=)
 
@@ -1404,8 +1411,11 @@ class SCOREBASE(object):
             p.table = C.addressof(T)
             self._step_T = T
         p.w, p.w_m, p.w_v, p.w_g = self._w.data_ptr(), self._w_m.data_ptr(), self._w_v.data_ptr(), self._w_g.data_ptr()
+        # (the previous step's window slice: waited for only if it ran somewhere else than in front of the look-ahead catch-up of
+        #  this batch's rows on the side stream -- i.e. after a call-by-call step with its slice on another stream; the one-call
+        #  step queues its slice LAST on the side stream, and the next one's work there queues behind it)
         ev_sweep = self._ev_sweep
-        p.wait_sweep = 1 if ev_sweep is not None else 0
+        p.wait_sweep = 1 if (ev_sweep is not None and not self._sweep_on_side) else 0
         if ev_sweep is None:
             ev_sweep = self._evs.get("sweep") or self._rec("sweep", cur)
         p.ev_sweep = ev_sweep.cuda_event
@@ -1441,6 +1451,7 @@ class SCOREBASE(object):
         self._ps_last, self._train_stream = True, cur
         self._keep = (None, None)
         self._ev_sweep = ev_sweep if p.slice_hi > p.slice_lo else None
+        self._sweep_on_side = True
         self._sweep_ticket = 0
         self._plan_done = pr[1]
         self._b4_recorded, self._b4_any = None, self._ev_b4
