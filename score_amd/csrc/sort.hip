@@ -222,7 +222,7 @@ __host__ __device__ constexpr int scatter_lds_bytes(int nbins) { return nbins * 
 __device__ __forceinline__ void sort_scatter_tile(const uint32_t* __restrict__ kin, const uint32_t* __restrict__ vin,
                                                   uint32_t* __restrict__ kout, uint32_t* __restrict__ vout, int64_t n, int shift,
                                                   int dbits, const uint32_t* __restrict__ M, const uint32_t* __restrict__ tot,
-                                                  int tile, uint32_t* smem) {
+                                                  int tile, uint32_t* smem, int raw_tiles = 0) {
   const int nbins = 1 << dbits;
   const uint32_t mask = (uint32_t)(nbins - 1);
   uint16_t* cnt = reinterpret_cast<uint16_t*>(smem);           // [d][wave]: count, later the exclusive prefix over waves
@@ -271,30 +271,58 @@ __device__ __forceinline__ void sort_scatter_tile(const uint32_t* __restrict__ k
   // (dpre) and of all tiles (binbase, from the column scan's totals)
   const int dpt = nbins >= THREADS ? nbins / THREADS : 1;          // digits per thread, contiguous
   const bool has = tid * dpt < nbins;
-  uint32_t lt[8], gt[8], ls = 0, gs = 0;
+  // raw_tiles > 0 (small sorts, round 5): M holds the tiles' raw histograms and this workgroup takes its own column prefix
+  // (same digit, earlier tiles) and the bins' totals from them -- raw_tiles x dpt words per thread -- instead of a column-scan
+  // launch in front of every scatter (two of the sort's six launches: the step is bound by the host's launch calls there)
+  uint32_t lt[8], gt[8], mb[8], ls = 0, gs = 0;
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
-    lt[q] = gt[q] = 0;
+    lt[q] = gt[q] = mb[q] = 0;
     if (q < dpt && has) {
       const int d = tid * dpt + q;
       uint32_t run = 0;
 #pragma unroll
       for (int i = 0; i < WAVES; ++i) { const uint32_t c = cnt[d * WAVES + i]; cnt[d * WAVES + i] = (uint16_t)run; run += c; }
       lt[q] = run;
-      gt[q] = tot[d];
+      if (raw_tiles <= 0) {
+        gt[q] = tot[d];
+        mb[q] = M[(int64_t)tile * nbins + d];
+      }
       ls += run;
-      gs += gt[q];
     }
   }
+  if (raw_tiles > 0 && has) {
+    // four tiles' counts of this thread's digits in flight per trip (a load at a time made the scatter 25 -> 44 us)
+    const uint32_t* col = M + tid * dpt;
+    for (int t0 = 0; t0 < raw_tiles; t0 += 4) {
+      uint32_t c[4][8];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t* row = col + (int64_t)(t0 + u < raw_tiles ? t0 + u : 0) * nbins;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) c[u][q] = q < dpt ? row[q] : 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const bool in = t0 + u < raw_tiles, early = t0 + u < tile;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          gt[q] += in ? c[u][q] : 0u;
+          mb[q] += early ? c[u][q] : 0u;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) gs += (q < dpt && has) ? gt[q] : 0u;
   uint32_t lo = block_excl_scan(ls, sc, tid);
   uint32_t go = block_excl_scan(gs, sc, tid);
-  const uint32_t* Mrow = M + (int64_t)tile * nbins;
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
     if (q < dpt && has) {
       const int d = tid * dpt + q;
       dpre[d] = (uint16_t)lo;
-      adj[d] = (int32_t)(go + Mrow[d]) - (int32_t)lo;
+      adj[d] = (int32_t)(go + mb[q]) - (int32_t)lo;
       lo += lt[q];
       go += gt[q];
     }
@@ -336,9 +364,9 @@ __device__ __forceinline__ void sort_scatter_tile(const uint32_t* __restrict__ k
 __global__ __launch_bounds__(THREADS) void sort_scatter_kernel(const uint32_t* __restrict__ kin, const uint32_t* __restrict__ vin,
                                                                uint32_t* __restrict__ kout, uint32_t* __restrict__ vout,
                                                                int64_t n, int shift, int dbits, const uint32_t* __restrict__ M,
-                                                               const uint32_t* __restrict__ tot) {
+                                                               const uint32_t* __restrict__ tot, int raw_tiles) {
   extern __shared__ uint32_t smem[];
-  sort_scatter_tile(kin, vin, kout, vout, n, shift, dbits, M, tot, (int)blockIdx.x, smem);
+  sort_scatter_tile(kin, vin, kout, vout, n, shift, dbits, M, tot, (int)blockIdx.x, smem, raw_tiles);
 }
 
 // ---------------------------------------------------------------- the whole plan sort in ONE launch (round 5)
@@ -419,11 +447,14 @@ int colscan_and_scatter(const uint32_t* kin, const uint32_t* vin, uint32_t* kout
                         uint32_t* M, uint32_t* tot, hipStream_t s) {
   const int nbins = 1 << dbits;
   const int ntiles = (int)cdiv64(n, TILE);
-  hipLaunchKernelGGL(sort_colscan_kernel, dim3((nbins + 63) / 64), dim3(CS_WAVES * 64), 0, s, M, ntiles, nbins, tot);
-  SCORE_CHECK_LAUNCH();
+  const int raw = ntiles <= FUSED_MAX_TILES ? ntiles : 0;       // (up to 64 tiles the scatter scans its own columns: four launches)
+  if (!raw) {
+    hipLaunchKernelGGL(sort_colscan_kernel, dim3((nbins + 63) / 64), dim3(CS_WAVES * 64), 0, s, M, ntiles, nbins, tot);
+    SCORE_CHECK_LAUNCH();
+  }
   const int lds = scatter_lds_bytes(nbins);
   SCORE_TRY(set_lds((const void*)sort_scatter_kernel, lds));
-  hipLaunchKernelGGL(sort_scatter_kernel, dim3(ntiles), dim3(THREADS), lds, s, kin, vin, kout, vout, n, shift, dbits, M, tot);
+  hipLaunchKernelGGL(sort_scatter_kernel, dim3(ntiles), dim3(THREADS), lds, s, kin, vin, kout, vout, n, shift, dbits, M, tot, raw);
   SCORE_CHECK_LAUNCH();
   return 0;
 }

@@ -41,7 +41,12 @@ extern "C" int score_train_step(const score_config_t* cfg, const score_state_t* 
   st.grads_done_event = p->ev_grads;
   void* ev[6] = {nullptr, nullptr, nullptr, nullptr, p->ev_b4, nullptr};
   SCORE_TRY(score_backward(cfg, &st, batch, p->keep_prob, p->w_g, const_cast<float*>(p->table->g), ev, stream));
-  // (4) side stream, behind the row scatter: the NEXT batch's rows brought up to date through this step, then its index plan
+  // (4) the step's ApplyAdam: rows with a gradient and the dense variables in one launch, behind the finishers -- queued BEFORE the
+  //     side stream's work: the next forward pass waits for this launch (through the weight images) longer than for the look-ahead
+  HIPTRY_(hipStreamWaitEvent(s, (hipEvent_t)p->ev_grads, 0));
+  SCORE_TRY(score_adam_touched_and_dense(p->table, p->step, p->alpha, p->w, p->w_m, p->w_v, p->w_g, p->n_w, p->n_reg, p->reg_lambda,
+                                         p->skipped, stream));
+  // (5) side stream, behind the row scatter: the NEXT batch's rows brought up to date through this step, then its index plan
   HIPTRY_(hipStreamWaitEvent(side, (hipEvent_t)p->ev_b4, 0));
   if (p->next_batch) {
     SCORE_TRY(score_adam_catchup_ids_through(p->table, p->next_ids, p->n_next_ids, p->step, p->alpha, p->side_stream));
@@ -54,7 +59,7 @@ extern "C" int score_train_step(const score_config_t* cfg, const score_state_t* 
     SCORE_TRY(score_index_plan(cfg, &sp, p->next_batch, 1, 0, p->side_stream));
     HIPTRY_(hipEventRecord((hipEvent_t)p->ev_plan, side));
   }
-  // (5) ... and LAST on the side stream this step's slice of the table (rows lagging behind step - 1, none of them this batch's or
+  // (6) ... and LAST on the side stream this step's slice of the table (rows lagging behind step - 1, none of them this batch's or
   //     -- any more -- the next one's): nothing of the next step waits for it (its own side-stream work queues behind it, its
   //     forward pass reads rows the slice skips, its touched-row update publishes counts the slice cannot mistake: adam_tiled.hip);
   //     ev_sweep is for whoever reads the table otherwise (a flush, an evaluation, the call-by-call path)
@@ -62,9 +67,5 @@ extern "C" int score_train_step(const score_config_t* cfg, const score_state_t* 
     SCORE_TRY(score_adam_catchup_rows(p->table, p->slice_lo, p->slice_hi, p->slice_upto, p->side_stream));
     HIPTRY_(hipEventRecord((hipEvent_t)p->ev_sweep, side));
   }
-  // (6) the step's ApplyAdam: rows with a gradient and the dense variables in one launch, behind the finishers
-  HIPTRY_(hipStreamWaitEvent(s, (hipEvent_t)p->ev_grads, 0));
-  SCORE_TRY(score_adam_touched_and_dense(p->table, p->step, p->alpha, p->w, p->w_m, p->w_v, p->w_g, p->n_w, p->n_reg, p->reg_lambda,
-                                         p->skipped, stream));
   return 0;
 }
