@@ -41,7 +41,7 @@ sys.path.insert(0, ROOT)
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 matrix peak (MI355X_MICROARCH.md; AMD's headline doubles it with sparsity)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable (float4 copy)
-PROFILE_ROUND = os.environ.get("SCORE_PROFILE_ROUND", "r04")
+PROFILE_ROUND = os.environ.get("SCORE_PROFILE_ROUND", "r05")
 
 
 def alg_bytes_per_sample(T, K, D, Fu, Fi):
