@@ -18,3 +18,10 @@ done
 python3 tools/host_calls.py tmall_default > $O/host_calls_tmall_default.txt 2>&1
 python3 tools/host_calls.py cfg2 > $O/host_calls_cfg2.txt 2>&1
 ls -la $O
+# the per-phase times of the two per-sample kernels (a -DPS_PHASE_TIMING build: python tools/build_variant.py phase ps_fwd.hip,ps_bwd.hip -DPS_PHASE_TIMING)
+if [ -f score_amd/lib/libscore_hip_phase.so ]; then
+  for c in tmall_default cfg2 ccmr_default; do
+    SCORE_HIP_LIB=score_amd/lib/libscore_hip_phase.so python3 tools/ps_phase_probe.py $c > $O/phases_$c.txt 2>&1
+  done
+  SCORE_HIP_LIB=score_amd/lib/libscore_hip_phase.so python3 tools/ps_phase_probe.py tmall_default 8 > $O/phases_tmall_default_b8.txt 2>&1
+fi
