@@ -566,7 +566,9 @@ def main():
             elif events is None or i not in events:
                 # the model's own one-call step (score.py:101-116 is one sess.run): forward_backward + apply_adam inside -- and, in the
                 # steady state of the per-sample form, one call into the library for the whole step (score_train_step)
-                nb = batches[(i + 1) % len(batches)] if look_ahead else None
+                # (no batch is announced behind the last step of a run: none comes, and the look-ahead work queued for it
+                #  would only be waited for by the optimizer's flush that closes the timed region)
+                nb = batches[(i + 1) % len(batches)] if (look_ahead and i + 1 < first + n) else None
                 last_loss[0] = model.train_async(batches[i % len(batches)], args.lr, args.reg_lambda, 0.8, None, nb)
                 fb = inner._workspace(batches[i % len(batches)].B) if hasattr(batches[i % len(batches)], "B") else fb
                 continue
@@ -574,7 +576,7 @@ def main():
                 fb = model.forward_backward(batches[i % len(batches)], args.reg_lambda, 0.8)
             if e_a0 is not None:
                 e_a0.record()
-            if look_ahead:      # the next batch is known (the loader's queue): its rows are caught up beside this step's tail
+            if look_ahead and i + 1 < first + n:      # the next batch is known (the loader's queue): its rows are caught up beside this step's tail
                 model.apply_adam(args.lr, args.reg_lambda, next_batch=batches[(i + 1) % len(batches)])
             else:
                 model.apply_adam(args.lr, args.reg_lambda)

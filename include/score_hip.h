@@ -394,7 +394,9 @@ typedef struct {
                            bit 13 (8192) = the index plan's sort as ONE launch with barriers across its workgroups between
                            the phases (score_grid_sync; up to 524 K occurrences) instead of six launches: same bits, one
                            launch call for the host -- and slower on the device (the barriers' agent-scope fences write
-                           back / invalidate every XCD's L2 under the kernels running beside it): off by default.
+                           back / invalidate every XCD's L2 under the kernels running beside it): off by default;
+                           bit 14 (16384) = (layer-by-layer pass, finishers on the side stream) the column sums' first stage
+                           beside the end-of-pass products instead of behind them (measured 1.2 % slower at cfg-3: off).
                            The ONLY switches of the launch sequence: the library reads no environment variable       */
   uint8_t* row_flags;   /* optional [n_table_rows] row state of the dense table optimizer (see
                            score_adam_rows): score_backward (scatter_mode 0) marks every row it

@@ -1425,13 +1425,24 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
   const bool fin_side = st->grads_done_event != nullptr && side != nullptr;
   hipStream_t fs = fin_side ? side->st : s;
   ReduceGroup rg;
+  // (round 5, debug_flags bit 14, OFF: the column sums' FIRST stage -- it reads what the pass has written by now, nothing of the
+  //  products below -- on the side stream BESIDE the products instead of behind them, where it runs beside the touched-row update
+  //  and takes 52 us instead of 13 while the dense ApplyAdam waits.  Measured, three alternating pairs at cfg-3: 853.0 k samples/s
+  //  with it, 863.9 k without -- what it saves at the step's tail the matrix-bound products lose to it.)
+  int cs_early = 0;
+  if (fin_side && cq.n > 0 && (st->debug_flags & 16384)) {
+    HIPTRY(hipEventRecord(side->fork, s));
+    HIPTRY(hipStreamWaitEvent(fs, side->fork, 0));
+    G(colsum_queue_stage1(&cq, ws + w.cs_part + w.cs_part_floats / 2, w.cs_part_floats - w.cs_part_floats / 2, fs));
+    cs_early = 1;
+  }
   G(gemm_queue_flush(&gq, x3 != 0, ws + w.dwslab + slab_used, w.dwslab_floats - slab_used, s, &rg));
   EV(5);
   if (fin_side) {
     HIPTRY(hipEventRecord(side->fork, s));
     HIPTRY(hipStreamWaitEvent(fs, side->fork, 0));
   }
-  G(score_launch_finish(&rg, &cq, ws + w.cs_part + w.cs_part_floats / 2, w.cs_part_floats - w.cs_part_floats / 2, fs));
+  G(score_launch_finish(&rg, &cq, ws + w.cs_part + w.cs_part_floats / 2, w.cs_part_floats - w.cs_part_floats / 2, fs, cs_early));
   if (fin_side) HIPTRY(hipEventRecord((hipEvent_t)st->grads_done_event, fs));
   return 0;
 }

@@ -750,6 +750,17 @@ int score_launch_finish(const ReduceGroup* rg, ColsumJobs* q, float* part, int64
   return 0;
 }
 
+// the first stage alone (the queue stays: score_launch_finish(..., stage1_done = 1) runs the second stage and empties it)
+int colsum_queue_stage1(const ColsumJobs* q, float* part, int64_t part_floats, hipStream_t s) {
+  if (!q || q->n == 0) return 0;
+  if (q->part_used > part_floats) return SCORE_E_WORKSPACE;
+  int gx = 1;
+  for (int i = 0; i < q->n; ++i) gx = max(gx, (q->job[i].N + q->job[i].cols - 1) / q->job[i].cols);
+  hipLaunchKernelGGL(colsum_multi_stage1, dim3(gx, COLSUM_MAX_PARTS, q->n), dim3(256), 0, s, *q, part);
+  SCORE_CHECK_LAUNCH();
+  return 0;
+}
+
 int colsum_queue_flush(ColsumJobs* q, float* part, int64_t part_floats, hipStream_t s) {
   if (q->n == 0) return 0;
   if (q->part_used > part_floats) return SCORE_E_WORKSPACE;

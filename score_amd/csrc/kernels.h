@@ -48,6 +48,7 @@ int colsum_queue_flush(ColsumJobs* q, float* part, int64_t part_floats, hipStrea
 // independent of each other, each workgroup does what its index says.  Same arithmetic, same order as the separate launches.
 // w1: the folded first attention layer's gradient computed by the same launch from the dweff / dwq products' slabs
 // (instead of score_launch_attn_w1_grad behind it); stage1_done: see gemm_queue_flush
+int colsum_queue_stage1(const ColsumJobs* q, float* part, int64_t part_floats, hipStream_t s);
 struct W1Fold { int Dk, NA; const float* dweff; const float* dwq; float* gW1; const float* slab_e; const float* slab_q; int ns_e, ns_q; };
 int score_launch_finish(const ReduceGroup* rg, ColsumJobs* q, float* part, int64_t part_floats, hipStream_t s, int stage1_done = 0,
                         const W1Fold* w1 = nullptr);
