@@ -282,6 +282,12 @@ int score_adam_rows_dev(float* p, float* m, float* v, const float* g, int64_t n_
 int score_adam_rows(float* p, float* m, float* v, const float* g, int64_t n_rows, int32_t D,
                     uint8_t* row_flags, float alpha, float beta1, float beta2, float eps, const score_guard_t* guard,
                     void* stream);
+/* score_adam_rows on the table and score_adam on the flat dense variables [n] (first n_reg regularised with l2) in ONE launch:
+ * disjoint memory, the same arithmetic per element as the two calls.  guard: ONE counted call (the dense half counts a suppressed
+ * step, neither half applies anything while the word is set). */
+int score_adam_rows_and_dense(float* p, float* m, float* v, const float* g, int64_t n_rows, int32_t D, uint8_t* row_flags,
+                              float* wp, float* wm, float* wv, const float* wg, int64_t n, int64_t n_reg, float l2, float alpha,
+                              float beta1, float beta2, float eps, const score_guard_t* guard, void* stream);
 
 /* ---- time-tiled ApplyAdam over the table ----------------------------------------------------------------------
  * Dense ApplyAdam moves every live row every step, but the update of a row WITHOUT a gradient (m *= b1, v *= b2,

@@ -126,6 +126,8 @@ _SIGS = {
                             C.c_float, C.POINTER(Guard), C.c_void_p],
     "score_adam_rows": [c_f, c_f, c_f, c_f, C.c_int64, C.c_int32, C.c_void_p, C.c_float, C.c_float, C.c_float,
                         C.c_float, C.POINTER(Guard), C.c_void_p],
+    "score_adam_rows_and_dense": [c_f, c_f, c_f, c_f, C.c_int64, C.c_int32, C.c_void_p, c_f, c_f, c_f, c_f, C.c_int64, C.c_int64,
+                                  C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(Guard), C.c_void_p],
     "score_adam_touched": [C.POINTER(AdamTable), C.c_uint32, C.c_float, C.c_void_p],
     "score_adam_touched_and_dense": [C.POINTER(AdamTable), C.c_uint32, C.c_float, c_f, c_f, c_f, c_f, C.c_int64, C.c_int64,
                                      C.c_float, C.c_void_p, C.c_void_p],

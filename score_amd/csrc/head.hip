@@ -659,21 +659,14 @@ __device__ __forceinline__ void adam_st(float* p, const float4& v) {
   st4(p, v);
 #endif
 }
-__global__ __launch_bounds__(256) void adam_rows_kernel(float* __restrict__ p, float* __restrict__ m,
-                                                        float* __restrict__ v, const float* __restrict__ g,
-                                                        int64_t n_rows, int D, int LPR, uint8_t* __restrict__ flags,
-                                                        float alpha, float omb1, float omb2, float eps,
-                                                        const float* __restrict__ alpha_dev,
-                                                        const int32_t* __restrict__ guard, int32_t* __restrict__ skipped) {
-  if (guard && *guard) {                       // score_guard_t (the state bytes stay: the caller clamps them)
-    if (skipped && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(skipped, 1);
-    return;
-  }
-  if (alpha_dev) alpha = *alpha_dev;
+__device__ __forceinline__ void adam_rows_body(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
+                                               const float* __restrict__ g, int64_t n_rows, int D, int LPR,
+                                               uint8_t* __restrict__ flags, float alpha, float omb1, float omb2, float eps,
+                                               int blk, int nblk) {
   const int gpb = blockDim.x / LPR;
   const int ch4 = (threadIdx.x % LPR) * 4;
-  const int64_t stride = (int64_t)gridDim.x * gpb;
-  int64_t row0 = (int64_t)blockIdx.x * gpb + threadIdx.x / LPR;
+  const int64_t stride = (int64_t)nblk * gpb;
+  int64_t row0 = (int64_t)blk * gpb + threadIdx.x / LPR;
   if (ch4 >= D) return;
   for (; row0 < n_rows; row0 += 2 * stride) {
     const int64_t row1 = row0 + stride;
@@ -707,6 +700,40 @@ __global__ __launch_bounds__(256) void adam_rows_kernel(float* __restrict__ p, f
     }
   }
 }
+__global__ __launch_bounds__(256) void adam_rows_kernel(float* __restrict__ p, float* __restrict__ m,
+                                                        float* __restrict__ v, const float* __restrict__ g,
+                                                        int64_t n_rows, int D, int LPR, uint8_t* __restrict__ flags,
+                                                        float alpha, float omb1, float omb2, float eps,
+                                                        const float* __restrict__ alpha_dev,
+                                                        const int32_t* __restrict__ guard, int32_t* __restrict__ skipped) {
+  if (guard && *guard) {                       // score_guard_t (the state bytes stay: the caller clamps them)
+    if (skipped && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(skipped, 1);
+    return;
+  }
+  if (alpha_dev) alpha = *alpha_dev;
+  adam_rows_body(p, m, v, g, n_rows, D, LPR, flags, alpha, omb1, omb2, eps, (int)blockIdx.x, (int)gridDim.x);
+}
+// score_adam_rows on the table AND score_adam on the flat dense variables in ONE launch (round 5: the per-step sweep of a small
+// table -- cfg-2 -- ended in two dependent launches of 11 and 4 us with a launch boundary between them): workgroups [0, nb_r) the
+// rows, the rest the dense variables; disjoint memory, the same arithmetic per element as the two calls.  A set guard word:
+// neither half applies anything, the dense half counts the suppressed step (score_guard_t: ONE counted call per step).
+struct AdamDenseHalf { float* p; float* m; float* v; const float* g; int64_t n4, n, n_reg; float l2; };
+__global__ __launch_bounds__(256) void adam_rows_dense_kernel(float* __restrict__ p, float* __restrict__ m,
+                                                              float* __restrict__ v, const float* __restrict__ g,
+                                                              int64_t n_rows, int D, int LPR, uint8_t* __restrict__ flags,
+                                                              float alpha, float omb1, float omb2, float eps, const AdamDenseHalf d,
+                                                              int nb_r, int nb_d, const int32_t* __restrict__ guard,
+                                                              int32_t* __restrict__ skipped) {
+  if (guard && *guard) {
+    if (skipped && (int)blockIdx.x == nb_r && threadIdx.x == 0) atomicAdd(skipped, 1);
+    return;
+  }
+  if ((int)blockIdx.x < nb_r) {
+    adam_rows_body(p, m, v, g, n_rows, D, LPR, flags, alpha, omb1, omb2, eps, (int)blockIdx.x, nb_r);
+    return;
+  }
+  score_adam_dense_body(d.p, d.m, d.v, d.g, d.n4, d.n, d.n_reg, d.l2, alpha, omb1, omb2, eps, (int)blockIdx.x - nb_r, nb_d);
+}
 
 static int adam_rows_impl(float* p, float* m, float* v, const float* g, int64_t n_rows, int32_t D,
                           uint8_t* row_flags, float alpha, const float* alpha_dev, float beta1, float beta2, float eps,
@@ -731,6 +758,31 @@ extern "C" int score_adam_rows(float* p, float* m, float* v, const float* g, int
                                uint8_t* row_flags, float alpha, float beta1, float beta2, float eps,
                                const score_guard_t* guard, void* stream) {
   return adam_rows_impl(p, m, v, g, n_rows, D, row_flags, alpha, nullptr, beta1, beta2, eps, guard, stream);
+}
+extern "C" int score_adam_rows_and_dense(float* p, float* m, float* v, const float* g, int64_t n_rows, int32_t D,
+                                         uint8_t* row_flags, float* wp, float* wm, float* wv, const float* wg, int64_t n,
+                                         int64_t n_reg, float l2, float alpha, float beta1, float beta2, float eps,
+                                         const score_guard_t* guard, void* stream) {
+  if (!p || !m || !v || !g || !row_flags || n_rows <= 0 || D <= 0 || !wp || !wm || !wv || !wg || n <= 0) return SCORE_E_BADARG;
+  if ((D & 3) || D > 256) return SCORE_E_SHAPE;
+  if ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v) |
+       reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(wp) | reinterpret_cast<uintptr_t>(wm) |
+       reinterpret_cast<uintptr_t>(wv) | reinterpret_cast<uintptr_t>(wg)) & 15)
+    return SCORE_E_SHAPE;
+  int LPR = 1;
+  while (LPR < D / 4) LPR <<= 1;
+  const int gpb = 256 / LPR;
+  const int64_t want_r = cdiv64(n_rows, gpb);
+  const int nb_r = (int)(want_r < 16384 ? want_r : 16384);
+  AdamDenseHalf d;
+  d.p = wp; d.m = wm; d.v = wv; d.g = wg; d.n4 = n / 4; d.n = n; d.n_reg = n_reg; d.l2 = l2;
+  const int64_t want_d = cdiv64(d.n4 > 0 ? d.n4 : 1, 256);
+  const int nb_d = (int)(want_d < 8192 ? want_d : 8192);
+  hipLaunchKernelGGL(adam_rows_dense_kernel, dim3(nb_r + nb_d), dim3(256), 0, (hipStream_t)stream, p, m, v, g, n_rows, D, LPR,
+                     row_flags, alpha, 1.0f - beta1, 1.0f - beta2, eps, d, nb_r, nb_d, guard ? guard->id_status : nullptr,
+                     guard ? guard->skipped : nullptr);
+  SCORE_CHECK_LAUNCH();
+  return 0;
 }
 extern "C" int score_adam_rows_dev(float* p, float* m, float* v, const float* g, int64_t n_rows, int32_t D,
                                    uint8_t* row_flags, const score_step_scalars_t* sc, float beta1, float beta2,

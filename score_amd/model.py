@@ -1029,13 +1029,21 @@ class SCOREBASE(object):
         products, instead of in front of the next forward pass (score_adam_catchup_ids_through).  Same updates, same order
         per row: the same bits.  A different batch next is fine (it is caught up the usual way)."""
         with self._Pin(self):
-            if self._tiled_on() and self._row_grads:
-                if next_batch is not None:
+            # (decided NOW: the first tiled step fills row_step on this stream inside _adam_table_tiled -- a look-ahead queued behind
+            #  the scatter's event on the side stream would not be behind that fill)
+            want_ahead = self._tiled_on() and self._row_grads and next_batch is not None and self._tiled_ready
+
+            def side_work():
+                if want_ahead:
                     self._catchup_ahead(next_batch, lr)
-            # (the per-sample form only: at cfg-3 the library's sort of 2.9 M occurrences behind the scatter -- instead of beside the
-            #  next forward pass's recurrences, which leave half the chip idle -- cost 1.19 -> 1.31 ms/step, two alternating pairs)
-            if next_batch is not None and self.plan_ahead and self._ps_last:
-                self._plan_ahead(next_batch)
+                # (the per-sample form only: at cfg-3 the library's sort of 2.9 M occurrences behind the scatter -- instead of beside the
+                #  next forward pass's recurrences, which leave half the chip idle -- cost 1.19 -> 1.31 ms/step, two alternating pairs)
+                if next_batch is not None and self.plan_ahead and self._ps_last:
+                    self._plan_ahead(next_batch)
+            # the per-sample form queues the optimizer FIRST: the step is bound by this thread's launch calls there, and the next
+            # forward pass waits for the dense variables (through the weight images) longer than for the look-ahead
+            if not self._ps_last:
+                side_work()
             if self._tiled_on() and self._row_grads:
                 if self._grads_pending is not None:
                     # the dense gradient's finishers are still running on the side stream: the table's touched rows (row
@@ -1048,6 +1056,7 @@ class SCOREBASE(object):
                         self._join_grads()
                         if not self._adam_table_tiled(lr, dense=(reg_lambda,)):
                             self.adam_dense(lr, reg_lambda)
+                        side_work()
                         self.adam_advance()
                         return
                     self._adam_table_tiled(lr)
@@ -1069,9 +1078,22 @@ class SCOREBASE(object):
                 # (else the touched rows and the dense variables in one launch: nothing stands between them)
                 elif not self._adam_table_tiled(lr, dense=(reg_lambda,)):
                     self.adam_dense(lr, reg_lambda)
+            elif (self._row_grads and not self._use_dev_scalars and not self._adam_dirty and self._ps_last):
+                # the per-step sweep of a small table (cfg-2) and the dense variables in ONE launch (score_adam_rows_and_dense)
+                self._tiled_ready = False
+                self._join_grads()
+                _lib.check(self.lib.score_adam_rows_and_dense(
+                    _ptr(self._tbl), _ptr(self._tbl_m), _ptr(self._tbl_v), _ptr(self.table_g), self._tbl.shape[0], self._tbl.shape[1],
+                    _ptr(self.table_flags), _ptr(self.w), _ptr(self.w_m), _ptr(self.w_v), _ptr(self._w_g), self.n_w, self.n_reg,
+                    float(reg_lambda), self._alpha(lr), ADAM_B1, ADAM_B2, ADAM_EPS, self._guard_dense, self._stream()),
+                    "score_adam_rows_and_dense")
+                self._row_grads = False
+                self._flags_marked = False
             else:
                 self.adam_table(lr)
                 self.adam_dense(lr, reg_lambda)        # (reads self.w_g: waits for the finishers' event first)
+            if self._ps_last:
+                side_work()
             self.adam_advance()
 
     # ------------------------------------------------------------------ time-tiled table optimizer
