@@ -466,3 +466,37 @@ def test_sort_pairs_is_a_stable_sort(n, key_bits, dist):
     # too little scratch / bad arguments
     assert lib.score_sort_pairs(P(k0), P(v0), P(k1), P(v1), n, key_bits, P(temp), 16, C.byref(where), stream()) == -3
     assert lib.score_sort_pairs(P(k0), P(v0), P(k1), P(v1), n, 33, P(temp), tb, C.byref(where), stream()) == -1
+
+
+def test_rows_and_dense_in_one_launch_equal_the_two_calls():
+    """score_adam_rows_and_dense (the small-table sweep + the dense variables, cfg-2's optimizer) against score_adam_rows followed by
+    score_adam: bit for bit, states 0 / 1 / 2, the regularised range, a tail that is not a multiple of four -- and a set guard
+    word: nothing applied by either half, ONE suppressed step counted"""
+    lib = _lib.load()
+    g_ = torch.Generator(device="cuda").manual_seed(3)
+    R, D, n, n_reg = 1537, 16, 10243, 6001
+    def mk():
+        torch.manual_seed(5)
+        t = lambda *s: torch.randn(*s, device="cuda")
+        return dict(p=t(R, D), m=t(R, D) * 0.1, v=t(R, D).abs() * 0.01, g=t(R, D), wp=t(n + 1), wm=t(n + 1) * 0.1, wv=t(n + 1).abs() * 0.01,
+                    wg=t(n + 1), flags=torch.randint(0, 3, (R,), dtype=torch.uint8, device="cuda", generator=g_.manual_seed(3)))
+    a, b = mk(), mk()
+    assert torch.equal(a["flags"], b["flags"]) and int((a["flags"] == 2).sum()) > 100 and int((a["flags"] == 0).sum()) > 100
+    for step in range(3):
+        al = 1e-3 * (1 + step)
+        _lib.check(lib.score_adam_rows(P(a["p"]), P(a["m"]), P(a["v"]), P(a["g"]), R, D, P(a["flags"]), al, 0.9, 0.999, 1e-8, None, stream()), "rows")
+        _lib.check(lib.score_adam(P(a["wp"]), P(a["wm"]), P(a["wv"]), P(a["wg"]), n, n_reg, 1e-3, al, 0.9, 0.999, 1e-8, None, stream()), "dense")
+        _lib.check(lib.score_adam_rows_and_dense(P(b["p"]), P(b["m"]), P(b["v"]), P(b["g"]), R, D, P(b["flags"]), P(b["wp"]), P(b["wm"]),
+                                                 P(b["wv"]), P(b["wg"]), n, n_reg, 1e-3, al, 0.9, 0.999, 1e-8, None, stream()), "both")
+        torch.cuda.synchronize()
+        for k in a:
+            assert torch.equal(a[k], b[k]), (step, k)
+        for x in (a, b):
+            x["flags"][::3] = 2          # some rows get a gradient again
+    word = torch.tensor([4, 0], dtype=torch.int32, device="cuda")
+    guard = _lib.Guard(id_status=word.data_ptr(), skipped=word.data_ptr() + 4)
+    snap = {k: v.clone() for k, v in b.items()}
+    _lib.check(lib.score_adam_rows_and_dense(P(b["p"]), P(b["m"]), P(b["v"]), P(b["g"]), R, D, P(b["flags"]), P(b["wp"]), P(b["wm"]),
+                                             P(b["wv"]), P(b["wg"]), n, n_reg, 1e-3, 1e-3, 0.9, 0.999, 1e-8, guard, stream()), "guarded")
+    torch.cuda.synchronize()
+    assert all(torch.equal(snap[k], b[k]) for k in b) and word.tolist() == [4, 1]
