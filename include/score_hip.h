@@ -548,10 +548,11 @@ int score_backward(const score_config_t* cfg, const score_state_t* st, const sco
  *   wait(ev_ahead), wait(ev_sweep)                                   [stream]   if wait_ahead / wait_sweep
  *   score_forward(..., loss_host, loss_done_event = ev_loss if loss_host)                   [stream]
  *   score_backward(plan_done_event = ev_plan, grads_done_event = ev_grads, stage event 4 = ev_b4)   [stream]
+ *   wait(ev_grads); score_adam_touched_and_dense(step, alpha, l2 = reg_lambda)              [stream]
  *   wait(ev_b4); score_adam_catchup_ids_through(next ids, step, alpha); record(ev_ahead);
  *                score_index_plan(next batch -> next_workspace); record(ev_plan)            [side_stream]   if next_batch
  *                score_adam_catchup_rows(slice); record(ev_sweep)                           [side_stream]   if slice_hi > slice_lo
- *   wait(ev_grads); score_adam_touched_and_dense(step, alpha, l2 = reg_lambda)              [stream]
+ *   (in this order of CALLS; on the device the side stream's work runs beside the optimizer launch)
  * -- the same entry points with the same arguments a caller would use one by one (the events are the caller's, re-used from
  * call to call: every wait above is issued before the same call re-records its event).  PRECONDITIONS the caller guarantees:
  * the batch's rows are up to date through step - 1 (the previous call named this batch as next_batch, or the caller ran
@@ -571,7 +572,7 @@ typedef struct {
   float* next_workspace; int64_t next_workspace_bytes;
   float* loss_host;                                      /* optional, see score_state_t.loss_host                               */
   void* side_stream;
-  void* ev_ahead; void* ev_sweep; void* ev_plan; void* ev_stage2; void* ev_b4; void* ev_grads; void* ev_loss;   /* hipEvent_t */
+  void* ev_ahead; void* ev_sweep; void* ev_plan; void* ev_stage2 /* unused */; void* ev_b4; void* ev_grads; void* ev_loss;   /* hipEvent_t */
 } score_train_step_t;
 int score_train_step(const score_config_t* cfg, const score_state_t* st, const score_batch_t* batch, const score_train_step_t* p,
                      void* stream);

@@ -1422,17 +1422,18 @@ class SCOREBASE(object):
             p = self._step_args = _lib.TrainStep()
             p.table = C.addressof(T)
             p.n_w, p.n_reg = self.n_w, self.n_reg
-            p.skipped = self._id_status.data_ptr() + 4 if self._guard_on else None
-            p.side_stream = self._side.cuda_stream
-            p.ev_stage2 = self._ensure_ev("_ev_stage").cuda_event
-            p.ev_b4 = self._ensure_ev("_ev_b4").cuda_event
-            p.ev_grads = self._ensure_ev("_ev_grads").cuda_event
-            p.ev_loss = self._ensure_ev("_ev_loss").cuda_event
             self._step_T = T
         elif self._step_T is not T:
             p.table = C.addressof(T)
             self._step_T = T
+        # (handles re-read every call: the side stream is replaced when the inline mode is switched, the buffers by set_params)
         p.w, p.w_m, p.w_v, p.w_g = self._w.data_ptr(), self._w_m.data_ptr(), self._w_v.data_ptr(), self._w_g.data_ptr()
+        p.skipped = self._id_status.data_ptr() + 4 if self._guard_on else None
+        p.side_stream = self._side.cuda_stream
+        p.ev_stage2 = None
+        p.ev_b4 = self._ensure_ev("_ev_b4").cuda_event
+        p.ev_grads = self._ensure_ev("_ev_grads").cuda_event
+        p.ev_loss = self._ensure_ev("_ev_loss").cuda_event
         # (the previous step's window slice: waited for only if it ran somewhere else than in front of the look-ahead catch-up of
         #  this batch's rows on the side stream -- i.e. after a call-by-call step with its slice on another stream; the one-call
         #  step queues its slice LAST on the side stream, and the next one's work there queues behind it)
