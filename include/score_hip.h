@@ -450,6 +450,10 @@ typedef struct {
                            forward kernel also stores loss[0..3] there (system scope), so a caller that returns the loss every
                            step (score.py:101-116) reads it after waiting for an event recorded behind score_forward -- no copy,
                            no extra stream.  Ignored by the layer-by-layer pass (score_persample_form tells which runs).   */
+  float* plan_workspace;  /* optional (score_backward, scatter_mode 0): the batch's index plan lies in THIS buffer -- another
+                           workspace of the same layout, where score_index_plan wrote it -- instead of in `workspace`: a caller
+                           that alternates two buffers for the plans can sort the next batch's plan while this step's scatter
+                           still reads its own (everything else of the step stays in `workspace`).  NULL: in `workspace`.       */
 } score_state_t;
 
 /* Synchronous query of a score_state_t.id_status word: copies it to *bits (optional), waits for `stream`, clears the
@@ -573,6 +577,12 @@ typedef struct {
   float* loss_host;                                      /* optional, see score_state_t.loss_host                               */
   void* side_stream;
   void* ev_ahead; void* ev_sweep; void* ev_plan; void* ev_stage2 /* unused */; void* ev_b4; void* ev_grads; void* ev_loss;   /* hipEvent_t */
+  void* ev_plan_next;     /* optional hipEvent_t.  Given (and next_workspace a DIFFERENT workspace than st->workspace: the caller
+                             alternates two): the next batch's index plan is queued FIRST on the side stream, with no wait, and
+                             this event recorded behind it -- the sort runs beside this step's passes.  NULL: one workspace, the
+                             plan behind this step's scatter, ev_plan re-recorded (the sequence above).                         */
+  void* plan_stream;      /* optional: a third stream for that early plan (it waits for ev_b4's previous record first); NULL: the
+                             side stream -- the look-ahead catch-up then queues behind the sort.                                */
 } score_train_step_t;
 int score_train_step(const score_config_t* cfg, const score_state_t* st, const score_batch_t* batch, const score_train_step_t* p,
                      void* stream);

@@ -46,7 +46,7 @@ class State(C.Structure):
                 ("gemm_mode", C.c_int32), ("debug_flags", C.c_int32), ("row_flags", C.c_void_p),
                 ("gather_done_event", C.c_void_p), ("plan_done_event", C.c_void_p), ("step_scalars", C.c_void_p),
                 ("context", C.c_void_p), ("id_status", C.c_void_p), ("grads_done_event", C.c_void_p),
-                ("loss_done_event", C.c_void_p), ("loss_host", C.c_void_p)]
+                ("loss_done_event", C.c_void_p), ("loss_host", C.c_void_p), ("plan_workspace", C.c_void_p)]
 
 
 class Graph(C.Structure):
@@ -78,7 +78,8 @@ class TrainStep(C.Structure):
                 ("wait_sweep", C.c_int32), ("next_batch", C.c_void_p), ("next_ids", C.c_void_p), ("n_next_ids", C.c_int64),
                 ("next_workspace", C.c_void_p), ("next_workspace_bytes", C.c_int64), ("loss_host", C.c_void_p),
                 ("side_stream", C.c_void_p), ("ev_ahead", C.c_void_p), ("ev_sweep", C.c_void_p), ("ev_plan", C.c_void_p),
-                ("ev_stage2", C.c_void_p), ("ev_b4", C.c_void_p), ("ev_grads", C.c_void_p), ("ev_loss", C.c_void_p)]
+                ("ev_stage2", C.c_void_p), ("ev_b4", C.c_void_p), ("ev_grads", C.c_void_p), ("ev_loss", C.c_void_p),
+                ("ev_plan_next", C.c_void_p), ("plan_stream", C.c_void_p)]
 
 
 class Guard(C.Structure):

@@ -820,7 +820,9 @@ int backward_ps(const Dims& d, const Params& P, const WS& w, const PsPlan& pp, c
     //  layer's gradient -- where there were four in a row: they stand between the backward kernel and the dense ApplyAdam)
     ReduceGroup rg;
     int cs_done = 0;
-    G(gemm_queue_flush(&gq, x3 != 0, ws + w.dwslab, w.dwslab_floats, fs, &rg, &cq, ws + w.cs_part, w.cs_part_floats, &cs_done));
+    // (all products on the f32 kernel here: at the CCMR shape -- 7,600 (b, t) rows -- the bf16x3 family would take four of them as a
+    //  launch of its own IN FRONT of this one, on the chain to the dense ApplyAdam: 0.3582 vs 0.3566 ms, two alternating pairs)
+    G(gemm_queue_flush(&gq, 0, ws + w.dwslab, w.dwslab_floats, fs, &rg, &cq, ws + w.cs_part, w.cs_part_floats, &cs_done));
     W1Fold wf;
     memset(&wf, 0, sizeof(wf));
     wf.Dk = d.Dk; wf.NA = AT1; wf.dweff = ws + w.dweff; wf.dwq = ws + w.dwq; wf.gW1 = gw + P.at_w[1];
@@ -846,7 +848,9 @@ int backward_ps(const Dims& d, const Params& P, const WS& w, const PsPlan& pp, c
     pa.Wv[0] = W + P.ca_w[0] + d.Di; pa.Wv[1] = W + P.ca_w[0] + 2 * d.Di;
     pa.Wv[2] = W + P.ca_w[1] + d.Du; pa.Wv[3] = W + P.ca_w[1] + 2 * d.Du;
     const int64_t n_occ = (int64_t)B * (2 * (int64_t)T * d.K * (d.Fu + d.Fi) + d.Fu + d.Fi);
-    G(score_launch_pull(pa, reinterpret_cast<uint32_t*>(ws + w.keys_out), reinterpret_cast<uint32_t*>(ws + w.vals_out), n_occ + 1,
+    // (score_state_t.plan_workspace: the plan of this batch sorted into ANOTHER workspace of the same layout, a step ahead)
+    float* pw = st->plan_workspace ? st->plan_workspace : ws;
+    G(score_launch_pull(pa, reinterpret_cast<uint32_t*>(pw + w.keys_out), reinterpret_cast<uint32_t*>(pw + w.vals_out), n_occ + 1,
                         grad_table, ws + w.partials, w.partial_floats, s));
   }
   EV(4);
@@ -1358,8 +1362,9 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
   //  profiles/r03_probes.md)
   EV(3);
   const bool atomic = st->scatter_mode == 1;
-  uint32_t* keys_out = reinterpret_cast<uint32_t*>(ws + w.keys_out);
-  uint32_t* vals_out = reinterpret_cast<uint32_t*>(ws + w.vals_out);
+  float* pw_ = (st->plan_workspace && st->scatter_mode == 0) ? st->plan_workspace : ws;      // (see score_state_t.plan_workspace)
+  uint32_t* keys_out = reinterpret_cast<uint32_t*>(pw_ + w.keys_out);
+  uint32_t* vals_out = reinterpret_cast<uint32_t*>(pw_ + w.vals_out);
   {
     CoattnArgs ca;
     memset(&ca, 0, sizeof(ca));

@@ -24,6 +24,25 @@ extern "C" int score_train_step(const score_config_t* cfg, const score_state_t* 
     return SCORE_E_BADARG;
   hipStream_t s = (hipStream_t)stream, side = (hipStream_t)p->side_stream;
   score_state_t st = *st_in;
+  // (0) side stream, FIRST: the NEXT batch's index plan into ITS workspace (next_workspace: not the one this step computes in --
+  //     the caller alternates two).  It depends on the ids only, and nothing of this step touches that workspace, so the sort runs
+  //     beside this step's passes instead of behind its scatter: pull(n) -> look-ahead -> sort(n + 1) -> pull(n + 1) was the
+  //     longest cycle of the step at the Taobao / Tmall default shapes (the sort is ~100 us).  The last readers of that workspace's
+  //     plan (the scatter two steps back) are behind an event this stream waited for a step ago.
+  if (p->next_batch && p->ev_plan_next) {
+    // (on a stream of its own when the caller has one: the look-ahead catch-up below must not queue behind ~100 us of sort;
+    //  ev_b4 still holds the PREVIOUS call's record here -- that step's scatter, the last launch that touched this side of
+    //  the caller's two workspaces but one)
+    hipStream_t ps = p->plan_stream ? (hipStream_t)p->plan_stream : side;
+    if (p->plan_stream) HIPTRY_(hipStreamWaitEvent(ps, (hipEvent_t)p->ev_b4, 0));
+    score_state_t sp = *st_in;
+    sp.workspace = p->next_workspace; sp.workspace_bytes = p->next_workspace_bytes;
+    sp.id_status = nullptr;        // (the ids are reported by the forward pass of that batch: the word guards THIS step's optimizer)
+    sp.gather_done_event = sp.plan_done_event = sp.grads_done_event = sp.loss_done_event = nullptr;
+    sp.loss_host = nullptr; sp.plan_workspace = nullptr;
+    SCORE_TRY(score_index_plan(cfg, &sp, p->next_batch, 1, 0, (void*)ps));
+    HIPTRY_(hipEventRecord((hipEvent_t)p->ev_plan_next, ps));
+  }
   // (1) what the previous step left running on the side stream on rows this batch reads: the look-ahead catch-up of exactly these
   //     rows, the window slice
   if (p->wait_ahead) HIPTRY_(hipStreamWaitEvent(s, (hipEvent_t)p->ev_ahead, 0));
@@ -51,13 +70,15 @@ extern "C" int score_train_step(const score_config_t* cfg, const score_state_t* 
   if (p->next_batch) {
     SCORE_TRY(score_adam_catchup_ids_through(p->table, p->next_ids, p->n_next_ids, p->step, p->alpha, p->side_stream));
     HIPTRY_(hipEventRecord((hipEvent_t)p->ev_ahead, side));
-    score_state_t sp = *st_in;
-    sp.workspace = p->next_workspace; sp.workspace_bytes = p->next_workspace_bytes;
-    sp.id_status = nullptr;        // (the ids are reported by the forward pass of that batch: the word guards THIS step's optimizer)
-    sp.gather_done_event = sp.plan_done_event = sp.grads_done_event = sp.loss_done_event = nullptr;
-    sp.loss_host = nullptr;
-    SCORE_TRY(score_index_plan(cfg, &sp, p->next_batch, 1, 0, p->side_stream));
-    HIPTRY_(hipEventRecord((hipEvent_t)p->ev_plan, side));
+    if (!p->ev_plan_next) {        // (one workspace, one plan event: the plan behind this step's scatter, as before)
+      score_state_t sp = *st_in;
+      sp.workspace = p->next_workspace; sp.workspace_bytes = p->next_workspace_bytes;
+      sp.id_status = nullptr;
+      sp.gather_done_event = sp.plan_done_event = sp.grads_done_event = sp.loss_done_event = nullptr;
+      sp.loss_host = nullptr; sp.plan_workspace = nullptr;
+      SCORE_TRY(score_index_plan(cfg, &sp, p->next_batch, 1, 0, p->side_stream));
+      HIPTRY_(hipEventRecord((hipEvent_t)p->ev_plan, side));
+    }
   }
   // (6) ... and LAST on the side stream this step's slice of the table (rows lagging behind step - 1, none of them this batch's or
   //     -- any more -- the next one's): nothing of the next step waits for it (its own side-stream work queues behind it, its

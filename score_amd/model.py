@@ -229,6 +229,15 @@ class SCOREBASE(object):
         self._ps_last = False           # the last forward_backward ran as the per-sample whole-model kernels
         self._inline_on = False         # debug_flags bit 12 was set at the last forward_backward: every stream below IS the launch stream
         self._sweep_on_side = False     # the pending window slice was queued on self._side (by the one-call step)
+        # the one-call step may alternate two PLAN buffers so that the next batch's sort needs nothing of this step and runs beside
+        # its passes instead of behind its scatter.  Whether that pays depends on which cycle bounds the step -- pull -> look-ahead ->
+        # sort -> pull (Taobao default: 0.2205 -> 0.1912 ms with two buffers) or the launch stream's own chain, which the early sort
+        # then slows (Tmall default 0.1929 -> 0.1996, CCMR 0.3466 -> 0.3566) -- so "auto" times 32 one-call steps each way on the
+        # device (two event pairs, read without blocking) and keeps the faster; True / False force one.
+        self.plan_two_workspaces = "auto"
+        self._two_tune = None
+        self._plan_events = [None, None]
+        self._plan_stream = None
         self.fast_step = True           # train / train_async: the steady-state step of the per-sample form as one library call (_train_step_fast)
         self._step_args = self._step_T = None
         # the launches that start side-stream work (next batch's index plan, look-ahead catch-up, window slice) are made by the
@@ -479,7 +488,7 @@ class SCOREBASE(object):
                 self.lib.score_async_wait(C.c_uint64(0))      # (launches the worker thread still owes: issued before the streams are drained)
         except Exception:
             pass
-        for st in (getattr(self, "_side", None), getattr(self, "_sweep_st", None),
+        for st in (getattr(self, "_side", None), getattr(self, "_sweep_st", None), getattr(self, "_plan_stream", None),
                    (getattr(self, "_early_loss_state", None) or {}).get("stream")):
             try:
                 if st is not None:
@@ -658,6 +667,7 @@ class SCOREBASE(object):
         st.step_scalars = self._scalars.data_ptr() if self._use_dev_scalars else None
         st.id_status = self._id_status.data_ptr()      # (a caller may have pointed the struct at a status word of its own: dist.py)
         st.gather_done_event = st.plan_done_event = st.grads_done_event = st.loss_done_event = st.loss_host = None
+        st.plan_workspace = None
         return st
 
     def _event_array(self, events):
@@ -931,9 +941,13 @@ class SCOREBASE(object):
             # the event the side stream waits for)
             want_list = self._tiled_on() and bool(self.adam_touched_list)
             pr, self._plan_ready = self._plan_ready, None
-            if pr is not None and not (pr[0] is db and pr[2] == ws.data_ptr() and pr[3] == db.active_slices and not want_list):
+            plan_here = pr is not None and pr[0] is db and pr[3] == db.active_slices and not want_list and (
+                pr[2] == ws.data_ptr() or pr[2] == self._plan_buffer(db.B, 1))
+            if pr is not None and not plan_here:
                 self._async_wait(pr[4])            # (a plan nobody uses: still issued before its events and buffers move on)
-            if pr is not None and pr[0] is db and pr[2] == ws.data_ptr() and pr[3] == db.active_slices and not want_list:
+            if plan_here:
+                if pr[2] != ws.data_ptr():
+                    st.plan_workspace = pr[2]      # (sorted into the second plan buffer by the one-call step: score_state_t.plan_workspace)
                 # apply_adam(next_batch=db) of the previous step has already sorted this batch's occurrences, behind that step's
                 # row scatter (_plan_ahead): since the per-sample kernels, the six launches of the sort (~110 us with their gaps)
                 # are longer than the forward and backward kernels they used to hide under
@@ -1379,6 +1393,41 @@ class SCOREBASE(object):
         self.beta2_power = np.float32(self.beta2_power * np.float32(ADAM_B2))
         self.step += 1
 
+    TUNE_SKIP, TUNE_STEPS = 12, 32
+
+    def _two_buffers(self, cur):
+        """plan_two_workspaces, with "auto" resolved by timing: phase 0 = one buffer, phase 1 = two, TUNE_SKIP one-call steps to
+        settle and TUNE_STEPS timed between two events on the launch stream each; then the faster one for good (two buffers only
+        if they win by more than 2 %)."""
+        v = self.plan_two_workspaces
+        if v is True or v is False:
+            return v
+        t = self._two_tune
+        if t is None:
+            t = self._two_tune = {"phase": 0, "n": 0, "ev": [None, None], "ms": [None, None], "choice": None}
+        if t["choice"] is not None:
+            return t["choice"]
+        ph = t["phase"]
+        if ph < 2:
+            if t["n"] == self.TUNE_SKIP:
+                t["ev"][0] = torch.cuda.Event(enable_timing=True); t["ev"][0].record(cur)
+            elif t["n"] == self.TUNE_SKIP + self.TUNE_STEPS:
+                t["ev"][1] = torch.cuda.Event(enable_timing=True); t["ev"][1].record(cur)
+            t["n"] += 1
+            if t["ev"][1] is not None and t["ev"][1].query():
+                t["ms"][ph] = t["ev"][0].elapsed_time(t["ev"][1])
+                t["phase"], t["n"], t["ev"] = ph + 1, 0, [None, None]
+                ph += 1
+        if ph >= 2:
+            t["choice"] = bool(t["ms"][1] < 0.98 * t["ms"][0])
+            return t["choice"]
+        return ph == 1
+
+    def _plan_buffer(self, B, which):
+        """address of plan buffer 0 / 1 of a batch size: the step's workspace, and a second one of the same layout that only ever
+        holds index plans (the one-call step alternates the two: score_state_t.plan_workspace)"""
+        return self._workspace(B, which)[1].data_ptr()
+
     def _ensure_ev(self, attr):
         ev = getattr(self, attr)
         if ev is None:
@@ -1407,8 +1456,12 @@ class SCOREBASE(object):
             return None
         if not self.persample_form(db.B, db.active_slices):
             return None
+        # two plan buffers per batch size (the step's workspace and a second one of the same layout that only ever holds plans),
+        # alternating: the next batch's plan goes into the one this batch's plan is NOT in, so its sort needs nothing of this step
+        # (score_train_step_t.ev_plan_next); everything else of every step stays in the one workspace
         lay, ws = self._workspace(db.B)
-        if pr[2] != ws.data_ptr():
+        slot = 0 if pr[2] == ws.data_ptr() else 1 if pr[2] == self._plan_buffer(db.B, 1) else -1
+        if slot < 0:
             return None
         cur = self._cur()
         if self._inline_on or (self._train_stream is not None and self._train_stream.cuda_stream != cur.cuda_stream):
@@ -1416,6 +1469,7 @@ class SCOREBASE(object):
         self._join_dense()
         self._join_grads()
         st = self._state(ws)
+        st.plan_workspace = pr[2] if slot == 1 else None
         row_step, ring, T = self._tiled
         p = self._step_args
         if p is None:
@@ -1452,12 +1506,26 @@ class SCOREBASE(object):
         rows, K = self._tbl.shape[0], self.adam_window
         j = (upto + 1) % K
         p.slice_lo, p.slice_hi, p.slice_upto = rows * j // K, rows * (j + 1) // K, upto
+        ev_plan_next = None
         if nxt is not None:
-            lay2, ws2 = self._workspace(nxt.B)
+            lay2, ws2 = self._workspace(nxt.B, (1 - slot) if (self._two_buffers(cur) and nxt.B == db.B) else 0)
             p.next_batch, p.next_ids, p.n_next_ids = C.addressof(nxt.struct), nxt.flat.data_ptr(), nxt.flat.numel()
             p.next_workspace, p.next_workspace_bytes = ws2.data_ptr(), ws2.numel() * 4
+            if ws2.data_ptr() != pr[2]:
+                # (an event of its own: this step's scatter still has to wait for THIS batch's plan event)
+                ev_plan_next = self._plan_events[1] if pr[1] is self._plan_events[0] else self._plan_events[0]
+                if ev_plan_next is None:
+                    ev_plan_next = torch.cuda.Event()
+                    ev_plan_next.record(cur)
+                    self._plan_events[0 if self._plan_events[0] is None else 1] = ev_plan_next
+            p.ev_plan_next = ev_plan_next.cuda_event if ev_plan_next is not None else None
+            if ev_plan_next is not None and self._plan_stream is None:
+                self._plan_stream = torch.cuda.Stream(device=self.device)
+            p.plan_stream = self._plan_stream.cuda_stream if ev_plan_next is not None else None
         else:
             p.next_batch = None
+            p.ev_plan_next = None
+            p.plan_stream = None
         el = self._early_loss
         if el is not None:
             if el["host"] is None:
@@ -1484,7 +1552,7 @@ class SCOREBASE(object):
         self._row_list = None
         if nxt is not None:
             self._ahead = (nxt, ah[1], 0)
-            self._plan_ready = (nxt, pr[1], ws2.data_ptr(), nxt.active_slices, 0)
+            self._plan_ready = (nxt, ev_plan_next if ev_plan_next is not None else pr[1], ws2.data_ptr(), nxt.active_slices, 0)
         self.adam_advance()
         return ws[lay.loss]
 

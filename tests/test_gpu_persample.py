@@ -134,7 +134,8 @@ def test_bad_ids_are_reported_by_the_fused_gather():
     assert np.isfinite(l)
 
 
-def test_one_call_step_equals_the_call_by_call_step():
+@pytest.mark.parametrize("two", [False, True, "auto"])
+def test_one_call_step_equals_the_call_by_call_step(two):
     """score_train_step (csrc/step.hip): the steady-state step as ONE library call -- the same entry points, arguments, streams and
     events as forward_backward + apply_adam make one by one.  Two models, one with fast_step off: the same losses (train()'s
     read-back and train_async's device scalar), predictions and optimizer state bit for bit, with right hints, a wrong hint, no
@@ -143,6 +144,10 @@ def test_one_call_step_equals_the_call_by_call_step():
     cfg = so.Cfg(3000, 16, 32, 5, 3, 2, 3, "SCORE")
     a, b = make(cfg, 5), make(cfg, 5)
     b.fast_step = False
+    # (two = True: the next batch's plan alternates between two buffers and is sorted beside the step, score_state_t.plan_workspace;
+    #  "auto": the model times both and keeps one -- with the tuning phases shortened so that this run goes through all of them)
+    a.plan_two_workspaces = two
+    a.TUNE_SKIP, a.TUNE_STEPS = 2, 3
     bs = batches(cfg, 6, 8, seed=33, hot_rows=150) + batches(cfg, 2, 5, seed=34, hot_rows=150)
     da, db_ = [a.device_batch(x) for x in bs], [b.device_batch(x) for x in bs]
     order = [0, 1, 2, 3, 4, 5, 0, 2, 4, 1, 3, 5, 5, 0, 1, 6, 7, 2, 3, 4, 0, 1, 2, 3, 4, 5, 0, 1]
@@ -174,4 +179,9 @@ def test_one_call_step_equals_the_call_by_call_step():
             assert same_state(a, b), i
     assert same_state(a, b)
     assert calls["n"] >= 12, calls            # (most steps: every one whose batch was the one announced a step earlier)
+    if two == "auto":
+        torch.cuda.synchronize()
+        assert a._two_tune is not None and (a._two_tune["choice"] is not None or a._two_tune["phase"] >= 1)
+    if two is True:
+        assert a._plan_stream is not None
     a.lib = a_lib
