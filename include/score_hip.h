@@ -581,6 +581,7 @@ typedef struct {
                              alternates two): the next batch's index plan is queued FIRST on the side stream, with no wait, and
                              this event recorded behind it -- the sort runs beside this step's passes.  NULL: one workspace, the
                              plan behind this step's scatter, ev_plan re-recorded (the sequence above).                         */
+  void* const* fwd_stage_events;   /* optional: score_forward's stage_events (five hipEvent_t or NULL each) -- a caller timing the pass */
   void* plan_stream;      /* optional: a third stream for that early plan (it waits for ev_b4's previous record first); NULL: the
                              side stream -- the look-ahead catch-up then queues behind the sort.                                */
 } score_train_step_t;

@@ -79,7 +79,7 @@ class TrainStep(C.Structure):
                 ("next_workspace", C.c_void_p), ("next_workspace_bytes", C.c_int64), ("loss_host", C.c_void_p),
                 ("side_stream", C.c_void_p), ("ev_ahead", C.c_void_p), ("ev_sweep", C.c_void_p), ("ev_plan", C.c_void_p),
                 ("ev_stage2", C.c_void_p), ("ev_b4", C.c_void_p), ("ev_grads", C.c_void_p), ("ev_loss", C.c_void_p),
-                ("ev_plan_next", C.c_void_p), ("plan_stream", C.c_void_p)]
+                ("ev_plan_next", C.c_void_p), ("fwd_stage_events", C.c_void_p), ("plan_stream", C.c_void_p)]
 
 
 class Guard(C.Structure):

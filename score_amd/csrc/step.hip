@@ -53,7 +53,7 @@ extern "C" int score_train_step(const score_config_t* cfg, const score_state_t* 
   st.loss_host = p->loss_host;
   st.plan_done_event = nullptr;
   st.grads_done_event = nullptr;
-  SCORE_TRY(score_forward(cfg, &st, batch, p->reg_lambda, p->keep_prob, nullptr, nullptr, p->drop_seed, nullptr, stream));
+  SCORE_TRY(score_forward(cfg, &st, batch, p->reg_lambda, p->keep_prob, nullptr, nullptr, p->drop_seed, p->fwd_stage_events, stream));
   // (3) backward: the row scatter behind this batch's index plan (sorted by the previous call), the dense gradient's finishers on
   //     the context's side stream
   st.plan_done_event = p->ev_plan;

@@ -1443,7 +1443,7 @@ class SCOREBASE(object):
         shape, which is bound by the host).  Returns None when the step is not that steady state (first steps, another batch than
         the one announced, stage events, an evaluation in between, ...): the caller then takes the call-by-call path, and the two
         can alternate step by step (tests/test_gpu_persample.py)."""
-        if (not self.fast_step or self._graph_on or self._use_dev_scalars or self.scatter_mode != 0 or self.fwd_events or self.bwd_events
+        if (not self.fast_step or self._graph_on or self._use_dev_scalars or self.scatter_mode != 0 or self.bwd_events
                 or self.catchup_events or int(self.debug_flags) or str(self.adam_sweep_at) != "2" or self.adam_touched_list
                 or self._tiled is None or not self._tiled_ready or not self._adam_dirty or self._flags_marked or self._row_grads
                 or self._pending_sweep is not None or self._side is None or not isinstance(db, DeviceBatch) or db.flat is None
@@ -1488,6 +1488,8 @@ class SCOREBASE(object):
         p.ev_b4 = self._ensure_ev("_ev_b4").cuda_event
         p.ev_grads = self._ensure_ev("_ev_grads").cuda_event
         p.ev_loss = self._ensure_ev("_ev_loss").cuda_event
+        fe = self._event_array(self.fwd_events) if self.fwd_events else None      # (a caller timing the forward pass: bench.py's roofline)
+        p.fwd_stage_events = C.cast(fe, C.c_void_p) if fe is not None else None
         # (the previous step's window slice: waited for only if it ran somewhere else than in front of the look-ahead catch-up of
         #  this batch's rows on the side stream -- i.e. after a call-by-call step with its slice on another stream; the one-call
         #  step queues its slice LAST on the side stream, and the next one's work there queues behind it)
