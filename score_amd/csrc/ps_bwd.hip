@@ -50,8 +50,7 @@ __device__ __forceinline__ void ps_coattn_bwd(const PsBwdArgs& a, const PsLds& L
     v1[k] = ld4(table + (int64_t)ra[k] * D + coff);
     yv[k] = ld4(table + (int64_t)rb[k] * D + coff);
   }
-  const int col1 = c == 0 ? 0 : s.Di, col2 = c == 0 ? s.Du : 0;
-  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int col1 = c == 0 ? 0 : s.Di;
   const float4 g1 = ps_sel4(ok, *reinterpret_cast<const float4*>(sm + L.b_dxs + (0 * A + tc) * I + col1 + sl * 4));
   float dp[KMAX];
 #pragma unroll

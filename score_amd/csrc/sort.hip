@@ -34,8 +34,6 @@ namespace {
 
 constexpr int TILE = 8192, THREADS = 512, WAVES = 8, EPT = 16, PER_WAVE = TILE / WAVES;   // EPT rounds of 64 keys per wave
 
-__device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
-
 // exclusive prefix of x over the 512 threads of the block (all of them call); sc: 16 words of LDS
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t x, uint32_t* sc, int tid) {
   const int lane = tid & 63, w = tid >> 6;

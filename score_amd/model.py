@@ -232,7 +232,7 @@ class SCOREBASE(object):
         # the one-call step may alternate two PLAN buffers so that the next batch's sort needs nothing of this step and runs beside
         # its passes instead of behind its scatter.  Whether that pays depends on which cycle bounds the step -- pull -> look-ahead ->
         # sort -> pull (Taobao default: 0.2205 -> 0.1912 ms with two buffers) or the launch stream's own chain, which the early sort
-        # then slows (Tmall default 0.1929 -> 0.1996, CCMR 0.3466 -> 0.3566) -- so "auto" times 32 one-call steps each way on the
+        # then slows (Tmall default 0.1929 -> 0.1996, CCMR 0.3466 -> 0.3566) -- so "auto" times 64 one-call steps each way on the
         # device (two event pairs, read without blocking) and keeps the faster; True / False force one.
         self.plan_two_workspaces = "auto"
         self._two_tune = None
@@ -1393,7 +1393,7 @@ class SCOREBASE(object):
         self.beta2_power = np.float32(self.beta2_power * np.float32(ADAM_B2))
         self.step += 1
 
-    TUNE_SKIP, TUNE_STEPS = 12, 32
+    TUNE_SKIP, TUNE_STEPS = 16, 64
 
     def _two_buffers(self, cur):
         """plan_two_workspaces, with "auto" resolved by timing: phase 0 = one buffer, phase 1 = two, TUNE_SKIP one-call steps to
