@@ -588,6 +588,13 @@ typedef struct {
 int score_train_step(const score_config_t* cfg, const score_state_t* st, const score_batch_t* batch, const score_train_step_t* p,
                      void* stream);
 
+/* sizeof of every struct above in the header's order (score_step_scalars_t, score_config_t, score_param_entry_t, score_batch_t,
+ * score_workspace_t, score_guard_t, score_adam_table_t, score_state_t, score_train_step_t, score_graph_t, score_batch_out_t), then
+ * offsetof(score_state_t, plan_workspace), offsetof(score_train_step_t, plan_stream), offsetof(score_adam_table_t, skipped_steps):
+ * a binding in another language checks its own structures against these before its first call.  Returns how many values it
+ * wrote (out needs room for at least that many: SCORE_E_BADARG otherwise).  Host only. */
+int score_abi_struct_sizes(int64_t* out, int32_t n);
+
 /* ---- launches issued by a second host thread (csrc/async.hip) ----------------------------------------------------------
  * At the reference's own batch sizes the step is bound by the ONE host thread that queues it; these hand the calls that start
  * side-stream work -- the next batch's index plan, the look-ahead catch-up of its rows, the optimizer's window slice -- to a

@@ -158,6 +158,7 @@ _SIGS = {
     "score_async_adam_catchup_rows": [C.POINTER(AdamTable), C.c_int64, C.c_int64, C.c_uint32, C.c_void_p,
                                       C.POINTER(C.c_void_p), C.c_int32, C.c_void_p, C.POINTER(C.c_uint64)],
     "score_async_wait": [C.c_uint64],
+    "score_abi_struct_sizes": [C.POINTER(C.c_int64), C.c_int32],
     "score_train_step": [C.POINTER(Config), C.POINTER(State), C.POINTER(Batch), C.POINTER(TrainStep), C.c_void_p],
     "score_gemm_forms": [C.POINTER(Config), C.POINTER(State), C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)],
     "score_forward": [C.POINTER(Config), C.POINTER(State), C.POINTER(Batch), C.c_float, C.c_float, C.c_void_p,

@@ -9,6 +9,7 @@
 // arguments on the same streams as score_amd/model.py's call-by-call path (which remains: first steps, evaluation in between,
 // stage events, wrong hints -- anything not steady state), so the two are interchangeable step by step, bit for bit
 // (tests/test_gpu_persample.py).
+#include <cstddef>
 #include "common.h"
 
 #define HIPTRY_(expr)                                  \
@@ -89,4 +90,19 @@ extern "C" int score_train_step(const score_config_t* cfg, const score_state_t* 
     HIPTRY_(hipEventRecord((hipEvent_t)p->ev_sweep, side));
   }
   return 0;
+}
+
+// sizeof / a late field's offset of every struct of include/score_hip.h, in the header's order: what a binding written in another
+// language (score_amd/_lib.py's ctypes structures) checks itself against before the first call (tests/test_abi.py)
+extern "C" int score_abi_struct_sizes(int64_t* out, int32_t n) {
+  const int64_t v[] = {(int64_t)sizeof(score_step_scalars_t), (int64_t)sizeof(score_config_t), (int64_t)sizeof(score_param_entry_t),
+                       (int64_t)sizeof(score_batch_t), (int64_t)sizeof(score_workspace_t), (int64_t)sizeof(score_guard_t),
+                       (int64_t)sizeof(score_adam_table_t), (int64_t)sizeof(score_state_t), (int64_t)sizeof(score_train_step_t),
+                       (int64_t)sizeof(score_graph_t), (int64_t)sizeof(score_batch_out_t),
+                       (int64_t)offsetof(score_state_t, plan_workspace), (int64_t)offsetof(score_train_step_t, plan_stream),
+                       (int64_t)offsetof(score_adam_table_t, skipped_steps)};
+  const int32_t have = (int32_t)(sizeof(v) / sizeof(v[0]));
+  if (!out || n < have) return SCORE_E_BADARG;
+  for (int32_t i = 0; i < have; ++i) out[i] = v[i];
+  return have;
 }

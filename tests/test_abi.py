@@ -85,3 +85,24 @@ def test_stripped_probe_kernels_cannot_reach_the_product_build():
             b.build()
     finally:
         b.FLAGS[:] = saved
+
+
+def test_ctypes_structures_match_the_headers_layout():
+    """every ctypes.Structure of score_amd/_lib.py against sizeof / late-field offsets of the C struct it stands for
+    (score_abi_struct_sizes, host only): a field added on one side only shows here, not as a wrong pointer on the GPU"""
+    import ctypes as C
+    lib = _lib.load()
+    out = (C.c_int64 * 32)()
+    n = lib.score_abi_struct_sizes(out, 32)
+    assert n == 14
+    got = list(out)[:n]
+    want = [None, C.sizeof(_lib.Config), C.sizeof(_lib.ParamEntry), C.sizeof(_lib.Batch), C.sizeof(_lib.Workspace), C.sizeof(_lib.Guard),
+            C.sizeof(_lib.AdamTable), C.sizeof(_lib.State), C.sizeof(_lib.TrainStep), C.sizeof(_lib.Graph), C.sizeof(_lib.BatchOut),
+            _lib.State.plan_workspace.offset, _lib.TrainStep.plan_stream.offset, _lib.AdamTable.skipped_steps.offset]
+    names = ["score_step_scalars_t", "score_config_t", "score_param_entry_t", "score_batch_t", "score_workspace_t", "score_guard_t",
+             "score_adam_table_t", "score_state_t", "score_train_step_t", "score_graph_t", "score_batch_out_t",
+             "offsetof(score_state_t, plan_workspace)", "offsetof(score_train_step_t, plan_stream)",
+             "offsetof(score_adam_table_t, skipped_steps)"]
+    for k, (g, w) in enumerate(zip(got, want)):
+        assert w is None or g == w, (names[k], g, w)
+    assert lib.score_abi_struct_sizes(out, 3) == -1
