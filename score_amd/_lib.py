@@ -46,7 +46,8 @@ class State(C.Structure):
                 ("gemm_mode", C.c_int32), ("debug_flags", C.c_int32), ("row_flags", C.c_void_p),
                 ("gather_done_event", C.c_void_p), ("plan_done_event", C.c_void_p), ("step_scalars", C.c_void_p),
                 ("context", C.c_void_p), ("id_status", C.c_void_p), ("grads_done_event", C.c_void_p),
-                ("loss_done_event", C.c_void_p), ("loss_host", C.c_void_p), ("plan_workspace", C.c_void_p)]
+                ("loss_done_event", C.c_void_p), ("loss_host", C.c_void_p), ("plan_workspace", C.c_void_p),
+                ("images_ready", C.c_int32), ("reserved3", C.c_int32)]
 
 
 class Graph(C.Structure):
@@ -79,7 +80,8 @@ class TrainStep(C.Structure):
                 ("next_workspace", C.c_void_p), ("next_workspace_bytes", C.c_int64), ("loss_host", C.c_void_p),
                 ("side_stream", C.c_void_p), ("ev_ahead", C.c_void_p), ("ev_sweep", C.c_void_p), ("ev_plan", C.c_void_p),
                 ("ev_stage2", C.c_void_p), ("ev_b4", C.c_void_p), ("ev_grads", C.c_void_p), ("ev_loss", C.c_void_p),
-                ("ev_plan_next", C.c_void_p), ("fwd_stage_events", C.c_void_p), ("plan_stream", C.c_void_p)]
+                ("ev_plan_next", C.c_void_p), ("fwd_stage_events", C.c_void_p), ("dense_stream", C.c_void_p),
+                ("ev_prep", C.c_void_p), ("wait_prep", C.c_int32), ("prep_next", C.c_int32), ("plan_stream", C.c_void_p)]
 
 
 class Guard(C.Structure):
@@ -159,6 +161,8 @@ _SIGS = {
                                       C.POINTER(C.c_void_p), C.c_int32, C.c_void_p, C.POINTER(C.c_uint64)],
     "score_async_wait": [C.c_uint64],
     "score_abi_struct_sizes": [C.POINTER(C.c_int64), C.c_int32],
+    "score_persample_prep": [C.POINTER(Config), C.POINTER(State), C.c_int32, C.c_int32, C.c_void_p],
+    "score_context_stream": [C.c_void_p, C.POINTER(C.c_void_p)],
     "score_train_step": [C.POINTER(Config), C.POINTER(State), C.POINTER(Batch), C.POINTER(TrainStep), C.c_void_p],
     "score_gemm_forms": [C.POINTER(Config), C.POINTER(State), C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)],
     "score_forward": [C.POINTER(Config), C.POINTER(State), C.POINTER(Batch), C.c_float, C.c_float, C.c_void_p,

@@ -436,6 +436,17 @@ extern "C" int score_context_destroy(void* ctx) {
   return 0;
 }
 
+extern "C" int score_context_stream(void* ctx, void** stream) {
+  if (!stream) return SCORE_E_BADARG;
+  score_state_t st;
+  memset(&st, 0, sizeof(st));
+  st.context = ctx;
+  SideStream* sd = nullptr;
+  SCORE_TRY(side_stream(&st, &sd));
+  *stream = (void*)sd->st;
+  return 0;
+}
+
 extern "C" int score_context_sync_errors(void* ctx, int32_t* errors) {
   if (!errors) return SCORE_E_BADARG;
   SideStream* sd = reinterpret_cast<SideStream*>(ctx);
@@ -669,7 +680,7 @@ int forward_ps(const Dims& d, const Params& P, const WS& w, const PsPlan& pp, co
                void* const* stage_events, hipStream_t s) {
   float* ws = st->workspace;
   const int B = bt->B;
-  G(ps_prep(d, P, w, pp, st, nullptr, 0, s));
+  if (!st->images_ready) G(ps_prep(d, P, w, pp, st, nullptr, 0, s));      // (else score_persample_prep ran behind the last ApplyAdam)
   if (st->debug_flags & 1024) {      // (the layer-by-layer backward pass that follows reads the concatenated / folded copies)
     const float* W = st->w;
     const int64_t weff_stride = align_up64(2 * (int64_t)d.Dk * AT1 + 48, 4);
@@ -871,6 +882,23 @@ extern "C" int score_persample_form(const score_config_t* cfg, const score_state
   bt.B = B; bt.active_slices = active_slices;
   PsPlan pp;
   return ps_path(d, st, &bt, active_T(d, &bt), &pp) ? 1 : 0;
+}
+
+extern "C" int score_persample_prep(const score_config_t* cfg, const score_state_t* st, int32_t B, int32_t active_slices, void* stream) {
+  Dims d;
+  SCORE_TRY(make_dims(cfg, &d));
+  if (!st || !st->w || !st->workspace || B <= 0 || active_slices < 0) return SCORE_E_BADARG;
+  Params P;
+  build_layout(d, nullptr, 0, &P);
+  WS w;
+  build_ws(d, B, &w);
+  if (w.total * 4 > st->workspace_bytes) return SCORE_E_WORKSPACE;
+  score_batch_t bt;
+  memset(&bt, 0, sizeof(bt));
+  bt.B = B; bt.active_slices = active_slices;
+  PsPlan pp;
+  if ((st->debug_flags & 2048) || !ps_path(d, st, &bt, active_T(d, &bt), &pp)) return SCORE_E_SHAPE;
+  return ps_prep(d, P, w, pp, st, nullptr, 0, (hipStream_t)stream);
 }
 
 extern "C" int score_forward(const score_config_t* cfg, const score_state_t* st, const score_batch_t* bt,

@@ -238,6 +238,16 @@ class SCOREBASE(object):
         self._two_tune = None
         self._plan_events = [None, None]
         self._plan_stream = None
+        # the one-call step can end with the dense variables' ApplyAdam and the NEXT step's weight images on the engine's side stream
+        # (behind the finishers and the scatter) instead of on the launch stream: score_train_step_t.dense_stream.  OFF: the launch
+        # stream's chain loses ~15 us, the host gains a launch and three event calls, and the step is bound by the host here: Tmall
+        # default 0.1971 vs 0.1943 ms, Taobao default 0.1946 vs 0.1947 (one box, 2,000 steps).  (Behind the SCATTER: pull_kernel reads
+        # the co-attention weights.  The dense update on a side stream behind the finishers alone races with it -- which is what the
+        # ulp drift of two identical models was, earlier this round, when that update ran on the model's side stream.)
+        self.dense_and_images_on_side = False
+        self._images_ready = None       # (workspace, step): score_persample_prep ran for it behind the last ApplyAdam
+        self._ctx_stream = None
+        self._ev_prep = None
         self.fast_step = True           # train / train_async: the steady-state step of the per-sample form as one library call (_train_step_fast)
         self._step_args = self._step_T = None
         # the launches that start side-stream work (next batch's index plan, look-ahead catch-up, window slice) are made by the
@@ -404,6 +414,7 @@ class SCOREBASE(object):
     @property
     def w(self):
         self._join_dense()
+        self._images_ready = None        # (whoever holds the tensor may write it: the weight images of the one-call step go stale)
         return self._w
 
     @w.setter
@@ -645,8 +656,9 @@ class SCOREBASE(object):
         self._ws[key] = ent          # most recently used last
         return ent
 
-    def _state(self, ws):
-        w = self.w                   # (the property: joins a dense ApplyAdam still running on a side stream)
+    def _state(self, ws, joined=True):
+        # (the property: joins a dense ApplyAdam still running on a side stream; joined = False: the caller orders the streams itself)
+        w = self.w if joined else self._w
         key = (ws.data_ptr(), self._tbl.data_ptr(), w.data_ptr(), self.table_flags.data_ptr())
         ent = self._st_cache.get(key)
         if ent is None:
@@ -668,6 +680,7 @@ class SCOREBASE(object):
         st.id_status = self._id_status.data_ptr()      # (a caller may have pointed the struct at a status word of its own: dist.py)
         st.gather_done_event = st.plan_done_event = st.grads_done_event = st.loss_done_event = st.loss_host = None
         st.plan_workspace = None
+        st.images_ready = 0
         return st
 
     def _event_array(self, events):
@@ -1074,10 +1087,10 @@ class SCOREBASE(object):
                         self.adam_advance()
                         return
                     self._adam_table_tiled(lr)
-                    # (the per-sample form: on the launch stream.  Its products run wholly on the engine's side stream and take as long
-                    #  as the scatter + touched-row update beside them, and the next forward pass needs the dense variables either
-                    #  way: nothing to gain -- and with the update on the host's side stream two identical models were seen to
-                    #  drift apart by an ulp under tests/test_gpu_bad_ids.py when the products were delayed; not understood, see DESIGN)
+                    # (the per-sample form: on the launch stream.  There the finishers are forked right behind the backward KERNEL, i.e.
+                    #  in front of the row scatter -- and pull_kernel reads the co-attention weights: a dense update behind the
+                    #  finishers' event alone, on another stream, races with it.  That was the ulp drift of two identical models under
+                    #  tests/test_gpu_bad_ids.py earlier in round 5.  The layer-by-layer pass forks its finishers behind the scatter.)
                     side = self._side if (self.dense_adam_on_side and not self._ps_last) else None
                     if side is not None:
                         side.wait_event(self._grads_pending)
@@ -1466,9 +1479,15 @@ class SCOREBASE(object):
         cur = self._cur()
         if self._inline_on or (self._train_stream is not None and self._train_stream.cuda_stream != cur.cuda_stream):
             return None
-        self._join_dense()
+        # the previous one-call step left the dense ApplyAdam + this step's weight images on the engine's side stream: waited for
+        # inside the call (wait_prep) instead of here
+        imr = self._images_ready
+        wait_prep = (imr is not None and imr == (ws.data_ptr(), int(self.step)) and self._dense_pending is not None
+                     and self._dense_pending is self._ev_prep)
+        if not wait_prep:
+            self._join_dense()
         self._join_grads()
-        st = self._state(ws)
+        st = self._state(ws, joined=not wait_prep)
         st.plan_workspace = pr[2] if slot == 1 else None
         row_step, ring, T = self._tiled
         p = self._step_args
@@ -1488,6 +1507,20 @@ class SCOREBASE(object):
         p.ev_b4 = self._ensure_ev("_ev_b4").cuda_event
         p.ev_grads = self._ensure_ev("_ev_grads").cuda_event
         p.ev_loss = self._ensure_ev("_ev_loss").cuda_event
+        side_dense = bool(self.dense_and_images_on_side)
+        if side_dense:
+            if self._ctx_stream is None:
+                h = C.c_void_p(0)
+                _lib.check(self.lib.score_context_stream(self._ctx, C.byref(h)), "score_context_stream")
+                self._ctx_stream = h.value
+            p.dense_stream = self._ctx_stream
+            p.ev_prep = self._ensure_ev("_ev_prep").cuda_event
+            p.prep_next = 1 if (nxt is not None and nxt.B == db.B and nxt.active_slices == db.active_slices) else 0
+        else:
+            p.dense_stream = None
+            p.ev_prep = self._ev_prep.cuda_event if self._ev_prep is not None else None
+            p.prep_next = 0
+        p.wait_prep = 1 if wait_prep else 0
         fe = self._event_array(self.fwd_events) if self.fwd_events else None      # (a caller timing the forward pass: bench.py's roofline)
         p.fwd_stage_events = C.cast(fe, C.c_void_p) if fe is not None else None
         # (the previous step's window slice: waited for only if it ran somewhere else than in front of the look-ahead catch-up of
@@ -1548,10 +1581,19 @@ class SCOREBASE(object):
         self._sweep_ticket = 0
         self._plan_done = pr[1]
         self._b4_recorded, self._b4_any = None, self._ev_b4
-        self._grads_pending = None
         self._row_grads = self._flags_marked = False
         self._adam_dirty = True
         self._row_list = None
+        if side_dense:
+            # (the dense variables are being updated on the engine's side stream: whoever touches them next waits -- self.w)
+            self._grads_pending = None
+            self._dense_pending = self._ev_prep
+            self._images_ready = (ws.data_ptr(), int(self.step) + 1) if p.prep_next else None
+        else:
+            self._grads_pending = None
+            self._images_ready = None
+            if wait_prep:
+                self._dense_pending = None
         if nxt is not None:
             self._ahead = (nxt, ah[1], 0)
             self._plan_ready = (nxt, ev_plan_next if ev_plan_next is not None else pr[1], ws2.data_ptr(), nxt.active_slices, 0)
