@@ -97,8 +97,12 @@ __device__ __forceinline__ void tiled_rows(const TiledArgs& a, uint64_t mask, in
         if (pend >= 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); a.flags[pend] = 1; pend = -1; }
         st4(a.p + e, p); st4(a.m + e, m); st4(a.v + e, v);
         if (ch4 == 0) {
+#if defined(TILED_PROBE_PLAIN_PUBLISH)      // timing probe (tools/build_variant.py): count and state byte as two plain stores, as before round 5
+          a.step[row] = upto; a.flags[row] = 1;
+#else
           __hip_atomic_store(&a.step[row], upto, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           pend = row;
+#endif
         }
       }
     } else {
@@ -128,9 +132,7 @@ __device__ __forceinline__ void tiled_rows(const TiledArgs& a, uint64_t mask, in
 }
 
 // The scans of the state bytes: SCAN_V consecutive rows' bytes per lane in one load (bytes beyond n_rows read as 0).
-// SCAN_V = 4 where the rows are narrow (D <= 32: the reference's own eb_dim 16 -- a batch touches 0.1 % of the rows and the
-// scan itself is the kernel: 5.4 M rows, 7,600 hits, 35 us with a byte per lane); 1 where they are wide (cfg-3: 12 % of the rows
-// hit, the row traffic is the kernel, and four times fewer waves each working through four times the hits was 2x SLOWER).
+// (SCAN_V: state bytes per lane and trip; 1 is what runs -- see tiled_scan_v)
 template <int SCAN_V>
 __device__ __forceinline__ uint32_t tiled_load_states(const uint8_t* __restrict__ flags, int64_t r0, int64_t n_rows) {
   if (SCAN_V == 1) return r0 < n_rows ? (uint32_t)flags[r0] : 0u;
@@ -179,7 +181,7 @@ __device__ __forceinline__ void adam_touched_body(const TiledArgs& a, uint32_t s
     return;
   }
   if (blk == 0 && threadIdx.x == 0) a.ring[step % SCORE_ADAM_RING] = alpha;
-  // SCAN_V state bytes per lane and trip (round 5: one byte per lane made the scan of a 5.4 M-row table 35 us for 7,600 hits)
+  // SCAN_V state bytes per lane and trip
   for (int64_t base = (((int64_t)blk * blockDim.x + threadIdx.x) - lane) * SCAN_V; base < a.n_rows; base += stride * SCAN_V) {
     const int64_t r0 = base + (int64_t)lane * SCAN_V;
     const uint32_t f = tiled_load_states<SCAN_V>(a.flags, r0, a.n_rows);
@@ -353,7 +355,19 @@ static int tiled_args(const score_adam_table_t* t, TiledArgs* a, bool need_g) {
   a->skipped = t->skipped_steps;
   return 0;
 }
+// State bytes per lane (SCAN_V): ONE -- except narrow rows in a table of more than 3 M rows, where a dword of four pays.  Measured
+// inside the step, where the rows are cold (alone on warm rows, tools/adam_touched_probe.py, the two tie): with four a wave owns
+// 256 rows, meets several hits and works through them one dependent memory round trip after the other -- Tmall default
+// (1.5 M rows) 15.4 us (1) vs 27.4 us (4) for the step's ApplyAdam launch, cfg-3 (D = 64) 0.069 vs 0.153 ms -- but over the 5 M-row
+// tables the 84 K single-byte waves of the two scans cost more than that: CCMR default 0.3540 (1) vs 0.3479 ms/step (4), Taobao
+// default 0.2261 vs 0.2205 (two alternating pairs each, tools/build_variant.py variants).
+#if defined(TILED_PROBE_SCAN4)          // timing probes: force one or the other
 static int tiled_scan_v(const TiledArgs& a) { return a.D <= 32 ? 4 : 1; }
+#elif defined(TILED_PROBE_SCAN1)
+static int tiled_scan_v(const TiledArgs& a) { (void)a; return 1; }
+#else
+static int tiled_scan_v(const TiledArgs& a) { return (a.D <= 32 && a.n_rows > 3000000) ? 4 : 1; }
+#endif
 static int tiled_scan_blocks(const TiledArgs& a) {      // SCAN_V rows per thread
   const int64_t want = cdiv64(a.n_rows, 256 * tiled_scan_v(a));
   return (int)(want < 1 ? 1 : want < 32768 ? want : 32768);
