@@ -249,7 +249,8 @@ class SCOREBASE(object):
         self._ctx_stream = None
         self._ev_prep = None
         self.fast_step = True           # train / train_async: the steady-state step of the per-sample form as one library call (_train_step_fast)
-        self._step_args = self._step_T = None
+        self._step_args = self._step_T = self._step_side = None
+        self._pb_cache = {}
         # the launches that start side-stream work (next batch's index plan, look-ahead catch-up, window slice) are made by the
         # library's worker thread (csrc/async.hip) while this thread queues the step's chain -- the per-sample form only (the step is
         # bound by this thread's launch calls there: tools/host_calls.py)
@@ -642,6 +643,7 @@ class SCOREBASE(object):
         key = (B, slot)
         ent = self._ws.pop(key, None)
         if ent is None:
+            self._pb_cache = {}
             lay = _lib.workspace_layout(self.cfg, B)
             buf = torch.empty((lay.total_bytes // 4,), dtype=torch.float32, device=self.device)
             # least-recently-used eviction, one entry at a time.  Whoever still needs an evicted buffer (an index
@@ -1439,7 +1441,11 @@ class SCOREBASE(object):
     def _plan_buffer(self, B, which):
         """address of plan buffer 0 / 1 of a batch size: the step's workspace, and a second one of the same layout that only ever
         holds index plans (the one-call step alternates the two: score_state_t.plan_workspace)"""
-        return self._workspace(B, which)[1].data_ptr()
+        e = self._pb_cache.get(B)
+        if e is None:         # (emptied by _workspace whenever a workspace is created or evicted)
+            w0, w1 = self._workspace(B, 0)[1].data_ptr(), self._workspace(B, 1)[1].data_ptr()
+            e = self._pb_cache[B] = (w0, w1)
+        return e[which]
 
     def _ensure_ev(self, attr):
         ev = getattr(self, attr)
@@ -1473,7 +1479,7 @@ class SCOREBASE(object):
         # alternating: the next batch's plan goes into the one this batch's plan is NOT in, so its sort needs nothing of this step
         # (score_train_step_t.ev_plan_next); everything else of every step stays in the one workspace
         lay, ws = self._workspace(db.B)
-        slot = 0 if pr[2] == ws.data_ptr() else 1 if pr[2] == self._plan_buffer(db.B, 1) else -1
+        slot = 0 if pr[2] == self._plan_buffer(db.B, 0) else 1 if pr[2] == self._plan_buffer(db.B, 1) else -1
         if slot < 0:
             return None
         cur = self._cur()
@@ -1499,14 +1505,17 @@ class SCOREBASE(object):
         elif self._step_T is not T:
             p.table = C.addressof(T)
             self._step_T = T
-        # (handles re-read every call: the side stream is replaced when the inline mode is switched, the buffers by set_params)
+        # (the buffers re-read every call: set_params replaces them; the side stream when it has been replaced -- the inline mode
+        #  switched on and off --; the events are created once and never replaced)
         p.w, p.w_m, p.w_v, p.w_g = self._w.data_ptr(), self._w_m.data_ptr(), self._w_v.data_ptr(), self._w_g.data_ptr()
-        p.skipped = self._id_status.data_ptr() + 4 if self._guard_on else None
-        p.side_stream = self._side.cuda_stream
-        p.ev_stage2 = None
-        p.ev_b4 = self._ensure_ev("_ev_b4").cuda_event
-        p.ev_grads = self._ensure_ev("_ev_grads").cuda_event
-        p.ev_loss = self._ensure_ev("_ev_loss").cuda_event
+        if self._step_side is not self._side:
+            self._step_side = self._side
+            p.skipped = self._id_status.data_ptr() + 4 if self._guard_on else None
+            p.side_stream = self._side.cuda_stream
+            p.ev_stage2 = None
+            p.ev_b4 = self._ensure_ev("_ev_b4").cuda_event
+            p.ev_grads = self._ensure_ev("_ev_grads").cuda_event
+            p.ev_loss = self._ensure_ev("_ev_loss").cuda_event
         side_dense = bool(self.dense_and_images_on_side)
         if side_dense:
             if self._ctx_stream is None:
