@@ -217,3 +217,39 @@ def test_dense_update_and_next_images_on_the_engines_side_stream():
             P = a.get_params()
             a.set_params(P); b.set_params(P)
     assert same_state(a, b) and used >= 8
+
+
+@pytest.mark.parametrize("two", [True, False])
+def test_six_hundred_one_call_steps_stay_bit_identical(two):
+    """a soak for the orderings the one-call step relies on -- the touched-row update beside the look-ahead and the window slice
+    (publish protocol), the next plan sorted beside the step into the other buffer, the loss from pinned host memory --: 600 steps
+    against the call-by-call twin at a shape with ~40 K live rows, hot rows shared by consecutive batches, a short window (rows lag,
+    the slice is busy), state compared every 100 steps"""
+    from test_gpu_adam_tiled import make, batches, same_state
+    cfg = so.Cfg(40000, 16, 32, 6, 5, 2, 3, "SCORE")
+    a, b = make(cfg, 4), make(cfg, 4)
+    b.fast_step = False
+    a.plan_two_workspaces = two
+    bs = batches(cfg, 24, 48, seed=77, hot_rows=3000)
+    da, db_ = [a.device_batch(x) for x in bs], [b.device_batch(x) for x in bs]
+    rng = np.random.default_rng(5)
+    order = rng.integers(0, len(bs), 601).tolist()
+    for i in range(600):
+        bi, nx = order[i], order[i + 1]
+        if i % 50 == 49:
+            la = a.train(None, da[bi], 3e-3, 1e-4, keep_prob=0.8, next_batch=da[nx])
+            lb = b.train(None, db_[bi], 3e-3, 1e-4, keep_prob=0.8, next_batch=db_[nx])
+        else:
+            la = a.train_async(da[bi], 3e-3, 1e-4, keep_prob=0.8, next_batch=da[nx])
+            lb = b.train_async(db_[bi], 3e-3, 1e-4, keep_prob=0.8, next_batch=db_[nx])
+            if i % 10 == 9:
+                la, lb = float(la), float(lb)
+            else:
+                la = lb = 0.0
+        assert la == lb, (i, la, lb)
+        if i % 100 == 99:
+            assert same_state(a, b), i
+    assert same_state(a, b)
+    assert a.sync_errors() == 0
+    assert a._step_args is not None and b._step_args is None and a._tiled_on()       # (the one-call step did run, on the time-tiled optimizer)
+    assert (a._plan_stream is not None) == bool(two)
