@@ -488,3 +488,28 @@ def test_everything_inline_on_the_launch_stream_equals_every_overlap_mode(mode):
     for bi in (2, 4, 1):
         assert float(a.train_async(da[bi], 1e-2, 1e-4, keep_prob=0.8)) == float(b.train_async(db_[bi], 1e-2, 1e-4, keep_prob=0.8))
     assert same_state(a, b), mode
+
+
+def test_three_hundred_overlapped_steps_equal_the_inline_run_at_a_wide_shape():
+    """a soak for the layer-by-layer pass's overlap (D = 64, H = 128: cfg-3's kernels): the touched-row update beside the window
+    slice and the look-ahead catch-up (publish protocol, round 5), finishers and dense ApplyAdam on side streams -- 300 steps
+    with look-ahead hints against a twin with everything inline on the launch stream (debug_flags bit 12): the same bits"""
+    cfg = so.Cfg(60000, 64, 128, 6, 4, 3, 4, "SCORE")
+    a, b = make(cfg, 6), make(cfg, 6)
+    for m in (a, b):
+        m.overlap_finishers_min_rows = 0
+    b.debug_flags |= 4096
+    bs = batches(cfg, 16, 96, seed=91, hot_rows=5000)
+    da, db_ = [a.device_batch(x) for x in bs], [b.device_batch(x) for x in bs]
+    rng = np.random.default_rng(9)
+    order = rng.integers(0, len(bs), 301).tolist()
+    for i in range(300):
+        bi, nx = order[i], order[i + 1]
+        la = a.train_async(da[bi], 3e-3, 1e-4, keep_prob=0.8, next_batch=da[nx])
+        lb = b.train_async(db_[bi], 3e-3, 1e-4, keep_prob=0.8, next_batch=db_[nx])
+        if i % 10 == 9:
+            assert float(la) == float(lb), i
+        if i % 100 == 99:
+            assert same_state(a, b), i
+    assert same_state(a, b)
+    assert a._side is not None and a._side.cuda_stream != torch.cuda.current_stream().cuda_stream and a._ev_grads is not None
