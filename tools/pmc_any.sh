@@ -17,7 +17,8 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 acc = collections.defaultdict(list)
 for r in rows:
     if sys.argv[2] in r['Kernel_Name']:
-        acc[(r['Kernel_Name'].split('(')[0][:40], r['Counter_Name'])].append(float(r['Counter_Value']))
+        name = r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '')
+        acc[(name.split('(')[0][:40], r['Counter_Name'])].append(float(r['Counter_Value']))
 for k, v in sorted(acc.items()):
     print(k[0], k[1], 'n=%d' % len(v), 'mean=%.6g' % (sum(v) / len(v)))
 PY
