@@ -1017,7 +1017,7 @@ def main():
         "rccl_ranks": ranks_seen if (dist is not None and backend == "nccl") else 0,
         "dist": ({"backend": backend, "world_size": ranks_seen, "a2a_probe": getattr(getattr(model, "comm", None), "a2a_probe", None),
                   "collectives_ms": coll_table,
-                  "collectives_what": "per rank, averaged over the timed steps, a pair of HIP events around each data-path collective on "
+                  "collectives_what": "per rank, averaged over the dozen stage-table steps right behind the timed region (not inside it: the events cost host time), a pair of HIP events around each data-path collective on "
                                       "the stream it is issued on: a2a_row_requests (int32 ids), a2a_rows (fp32 rows back), a2a_row_grads "
                                       "(fp32 row gradients to the owners), all_reduce (flat dense gradient + the loss slot) -- what the "
                                       "first multi-GPU curve is read against DESIGN section 5's prediction with"}
