@@ -41,7 +41,7 @@ sys.path.insert(0, ROOT)
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 matrix peak (MI355X_MICROARCH.md; AMD's headline doubles it with sparsity)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable (float4 copy)
-PROFILE_ROUND = os.environ.get("SCORE_PROFILE_ROUND", "r05")
+PROFILE_ROUND = os.environ.get("SCORE_PROFILE_ROUND", "r06")
 
 
 def alg_bytes_per_sample(T, K, D, Fu, Fi):
@@ -318,6 +318,57 @@ class Heartbeat(object):
                 os._exit(3)
 
 
+def small_shape_leg(config, lr, reg_lambda, steps=300, warmup=50, n_batches=8):
+    """One short leg of `model.train_async` on another shape of the path (the reference's own B = 200 / D = 16 / H = 32 shape,
+    train_score.py:15-16,371-372, and BASELINE.json configs[1]): a model of its own, every table row live, device-resident
+    batches with the next one announced (as the headline does), `warmup` untimed steps, `steps` timed between two
+    synchronisations with the optimizer's flush inside.  host_us_per_step: this thread's time in the enqueueing loop alone (the
+    step is bound by it at these shapes); p50: one HIP event per step over a stretch right behind the timed one."""
+    from score_amd.synth import make_world
+    from score_amd.model import SCORE
+    world, kw = make_world(config)
+    B = kw.pop("batch")
+    model = SCORE(seed=1111, **kw)
+    model.table_flags.fill_(1)
+    batches = [model.device_batch(world.batch(B, i)) for i in range(n_batches)]
+
+    def run(n, marks=None):
+        for i in range(n):
+            if marks is not None:
+                marks[i].record()
+            nb = batches[(i + 1) % n_batches] if i + 1 < n else None
+            model.train_async(batches[i % n_batches], lr, reg_lambda, 0.8, None, nb)
+        if marks is not None:
+            marks[n].record()
+    run(warmup)
+    model._flush_adam()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(steps)
+    t_host = time.perf_counter() - t0
+    model._flush_adam()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    n_p = min(steps, 100)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(n_p + 1)]
+    run(n_p, marks)
+    torch.cuda.synchronize()
+    per = [marks[i].elapsed_time(marks[i + 1]) for i in range(n_p)]
+    launches = None
+    try:            # the launch count of one step of this shape: first line of the committed kernel sequence of this round
+        with open(os.path.join(ROOT, "profiles", "%s_%s_sequence.txt" % (PROFILE_ROUND, config))) as f:
+            launches = int(f.readline().split()[0])
+    except (OSError, ValueError, IndexError):
+        pass
+    out = {"samples_per_s": round(B * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 5),
+           "ms_p50": round(float(np.median(per)), 5), "host_us_per_step": round(t_host / steps * 1e6, 1),
+           "launches_per_step": launches, "B": B, "steps": steps, "warmup": warmup,
+           "form": "per-sample" if model.persample_form(B, batches[0].active_slices) else "layered"}
+    del model, batches
+    torch.cuda.empty_cache()
+    return out
+
+
 def visible_gpus():
     """GPUs this process could use, counted WITHOUT touching the HIP runtime: the KFD topology in sysfs (a node with
     simd_count > 0 is a GPU), narrowed by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES when set.  0 without a KFD driver; None if the topology cannot be read."""
@@ -429,6 +480,8 @@ def main():
                     help="form of the row / gradient all-to-all with N > 1 ranks: 'remote' = list form with empty own slots (a rank's own "
                          "rows never go through RCCL), 'split' = all_to_all_single with the own segment inside.  Default: what the "
                          "set-up probe finds to round-trip (score_amd/dist.py TorchDistComm.probe_a2a), the same on every rank")
+    ap.add_argument("--no-small-shapes", action="store_true",
+                    help="skip the two short legs on cfg-2 and the reference's Tmall-default shape (`small_shapes`, the LAST key of the line)")
     ap.add_argument("--lr", type=float, default=1e-3)
     ap.add_argument("--reg-lambda", type=float, default=1e-4)
     args = ap.parse_args()
@@ -1070,10 +1123,22 @@ def main():
         "stages_ms": stages,
     }
     out.update(side)
+    small = None
     if world_size == 1 and not args.no_cpu_baseline:
         params = model.get_params()
         del model, batches, inner
         torch.cuda.empty_cache()
+        if do_side and not args.no_small_shapes:
+            # before the CPU legs (their threads would compete with this thread's launch calls), printed behind them
+            small = {}
+            for c in ("cfg2", "tmall_default"):
+                try:
+                    small[c] = small_shape_leg(c, args.lr, args.reg_lambda)
+                except Exception as e:          # an optional leg never takes the headline down
+                    small[c] = {"error": repr(e)[:200]}
+            small["what"] = ("model.train_async, device-resident batches, next batch announced, every row live; ms_per_step = wall "
+                             "incl. optimizer flush; host_us = enqueue loop only; launches from profiles/%s_<config>_sequence.txt"
+                             % PROFILE_ROUND)
         out["cpu_baseline"] = cpu_baseline(kw, world.batch(B, 1000), params)
         if do_side:
             # the literal materialised-tile form at the reference's own Tmall-default shape (BASELINE.md section 3;
@@ -1093,6 +1158,9 @@ def main():
         hb.stop()
     if dist is not None:
         dist.destroy_process_group()
+    if small is not None:
+        # LAST key of the line: the driver's record keeps the line's last 2,000 characters
+        out["small_shapes"] = small
     # RCCL prints its version banner through C stdio: flush it first so the JSON is the LAST line
     try:
         import ctypes

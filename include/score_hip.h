@@ -17,7 +17,7 @@
  *     score_state_t.context and destroys; calls with DIFFERENT contexts are re-entrant across streams and
  *     host threads.  A NULL context selects one process-wide default context per device (created on
  *     first use under a mutex, released by score_context_destroy(NULL)): calls sharing it must not
- *     overlap in time.  The SCORE_* A/B environment switches are read once, at the first call;
+ *     overlap in time.  The library reads no environment variable (A/B switches: score_state_t.debug_flags);
  *   - all arithmetic is fp32, all indices int32 (score.py:21-30 placeholders);
  *   - table row 0 is the dummy node and must be all-zero in `table`
  *     (score.py:44-47 emb_mtx * mask): kernels rely on it and never update it.
@@ -42,13 +42,6 @@ typedef void* score_context_t;
 int score_context_create(score_context_t* ctx);
 /* ctx == NULL: release the process-wide default contexts.  Synchronises the context's stream first. */
 int score_context_destroy(score_context_t ctx);
-/* A context also owns a few words of device memory for the launches that run dependent phases with a barrier across their
- * workgroups instead of a launch boundary (round 5: the index plan's sort in one launch; csrc/common.h score_grid_sync;
- * opt-in, score_state_t.debug_flags bit 13).  The wait at such a barrier is bounded: *errors = how many of them have EVER timed
- * out in this context (0 unless a grid was not co-resident for ~0.2 s; results of that launch are then wrong).  Synchronous
- * (one small device-to-host copy); ctx == NULL: the current device's default context.                                        */
-int score_context_sync_errors(score_context_t ctx, int32_t* errors);
-
 /* The scalars of a training step that change from step to step, kept in DEVICE memory so that a captured step
  * (hipGraph: small shapes are launch-bound, ~60 launches of a few microseconds each) can be replayed with new
  * values: ApplyAdam's alpha = lr * sqrt(1 - beta2^t) / (1 - beta1^t) (score.py:96-99) and the seed of the
@@ -397,12 +390,9 @@ typedef struct {
                            bit 12 (4096) = NO second stream: everything score_forward / score_backward would fork onto
                            the context's side stream runs on `stream`, in launch order (same results bit for bit; what
                            a suspected stream race is compared against -- score_amd.model inlines its own streams too);
-                           bit 13 (8192) = the index plan's sort as ONE launch with barriers across its workgroups between
-                           the phases (score_grid_sync; up to 524 K occurrences) instead of six launches: same bits, one
-                           launch call for the host -- and slower on the device (the barriers' agent-scope fences write
-                           back / invalidate every XCD's L2 under the kernels running beside it): off by default;
-                           bit 14 (16384) = (layer-by-layer pass, finishers on the side stream) the column sums' first stage
-                           beside the end-of-pass products instead of behind them (measured 1.2 % slower at cfg-3: off).
+                           bit 14 (16384) = (layer-by-layer pass) the recurrences' weight-gradient products at the END of the
+                           launch stream's chain, behind the row scatter (the round-5 placement), instead of on the side stream
+                           beside the co-attention backward and the scatter (round 6; same bits).  Bit 13 is unused.
                            The ONLY switches of the launch sequence: the library reads no environment variable       */
   uint8_t* row_flags;   /* optional [n_table_rows] row state of the dense table optimizer (see
                            score_adam_rows): score_backward (scatter_mode 0) marks every row it
@@ -615,27 +605,6 @@ int score_context_stream(score_context_t ctx, void** stream);
  * a binding in another language checks its own structures against these before its first call.  Returns how many values it
  * wrote (out needs room for at least that many: SCORE_E_BADARG otherwise).  Host only. */
 int score_abi_struct_sizes(int64_t* out, int32_t n);
-
-/* ---- launches issued by a second host thread (csrc/async.hip) ----------------------------------------------------------
- * At the reference's own batch sizes the step is bound by the ONE host thread that queues it; these hand the calls that start
- * side-stream work -- the next batch's index plan, the look-ahead catch-up of its rows, the optimizer's window slice -- to a
- * worker thread of the library (one per process, started on first use).  Each takes the arguments of the call it stands for (by
- * value: the structs may be reused at once), then: the stream, up to three hipEvent_t the stream waits for first
- * (hipStreamWaitEvent), an optional hipEvent_t recorded behind the work, and a ticket.
- * THE CALLER'S DUTY: score_async_wait(ticket) before anything waits for, re-records or destroys an event the job names, frees a
- * buffer it uses, or synchronises the device expecting the job's work to be part of it -- it returns once the worker has
- * ISSUED the job (not executed: that is what the events are for), with the job's error code if it failed (the first failure
- * since the last wait; the record event is recorded even then).  ticket 0 = everything submitted so far.
- * Not for use inside a stream capture. */
-int score_async_index_plan(const score_config_t* cfg, const score_state_t* st, const score_batch_t* batch, int32_t n_shards,
-                           int32_t dedup, void* stream, void* const* wait_events, int32_t n_wait, void* record_event,
-                           uint64_t* ticket);
-int score_async_adam_catchup_ids_through(const score_adam_table_t* t, const int32_t* ids, int64_t n_ids, uint32_t step,
-                                         float alpha, void* stream, void* const* wait_events, int32_t n_wait,
-                                         void* record_event, uint64_t* ticket);
-int score_async_adam_catchup_rows(const score_adam_table_t* t, int64_t row_begin, int64_t row_end, uint32_t upto, void* stream,
-                                  void* const* wait_events, int32_t n_wait, void* record_event, uint64_t* ticket);
-int score_async_wait(uint64_t ticket);
 
 /* ---- "next" row f1: batch assembly on the device -------------------------------------- */
 

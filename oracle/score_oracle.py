@@ -303,16 +303,24 @@ def forward_literal(cfg, params, batch, keep_prob=1.0, dropout_masks=None):
 # Distance of the relu pre-activations of a forward pass from the kink (tests choose seeded inputs away from it: the
 # gradient of a relu network is discontinuous there, and two correct fp32 implementations whose pre-activation of ONE unit
 # differs in the last bit then differ by that unit's whole gradient).  forward() resets it and reports out["relu_margin"].
-_RELU_MARGIN = [float("inf"), None]      # [min |pre-activation| seen, [B, T] bool mask of the slices that count or None]
+# out["relu_margin_per_sample"]: the same minimum per sample [B] -- every relu unit of the graph belongs to ONE sample (nothing
+# crosses the batch: batch_normalization runs in inference mode, score.py:69), so a test that wants arbitrary inputs drops the
+# samples whose margin is below its threshold and compares the rest (tests/helpers.py away_from_relu_kinks).
+_RELU_MARGIN = [float("inf"), None, None]      # [min |pre-activation| seen, [B, T] bool mask of the slices that count or None, per-sample minima [B] or None]
 
 
 def _note_relu(pre):
     m = _RELU_MARGIN[1]
     a = pre.detach().abs()
+    B = a.shape[0] if a.dim() >= 1 else 0
     if m is not None and a.dim() >= 2 and tuple(a.shape[:2]) == tuple(m.shape):
-        a = a[m]
+        big = torch.full_like(a, float("inf"))
+        a = torch.where(m.reshape(m.shape + (1,) * (a.dim() - 2)), a, big)
     if a.numel():
         _RELU_MARGIN[0] = min(_RELU_MARGIN[0], float(a.min()))
+        per = a.reshape(B, -1).min(dim=1).values.to(torch.float64)
+        ps = _RELU_MARGIN[2]
+        _RELU_MARGIN[2] = per if (ps is None or ps.shape != per.shape) else torch.minimum(ps, per)
 
 
 def _co_attention_collapsed(seq1, seq2, tgt, W, b):
@@ -394,7 +402,7 @@ def forward(cfg, P, batch, keep_prob=1.0, dropout_masks=None, reg_lambda=0.0, ti
     length = batch["length"].long()
     mask = torch.arange(c.T)[None, :] < length[:, None]       # [B,T] bool
     out = {"target_item": target_item, "target_user": target_user}
-    _RELU_MARGIN[0], _RELU_MARGIN[1] = float("inf"), mask     # (slices past a sample's length reach nothing)
+    _RELU_MARGIN[0], _RELU_MARGIN[1], _RELU_MARGIN[2] = float("inf"), mask, None     # (slices past a sample's length reach nothing)
 
     if c.model_type == "RRN":
         user_side, item_side, atten_info = user_1hop.sum(2), item_1hop.sum(2), None
@@ -471,7 +479,8 @@ def forward(cfg, P, batch, keep_prob=1.0, dropout_masks=None, reg_lambda=0.0, ti
                 - (1 - lab) * torch.log(1 - y + LOGLOSS_EPS)).mean()
     l2 = sum((P[name] ** 2).sum() * 0.5 for name, _, _, reg in param_spec(c) if reg)
     out.update(logit=logit, y_pred=y, log_loss=log_loss, l2=l2,
-               loss=log_loss + reg_lambda * l2, relu_margin=_RELU_MARGIN[0])
+               loss=log_loss + reg_lambda * l2, relu_margin=_RELU_MARGIN[0],
+               relu_margin_per_sample=(_RELU_MARGIN[2].numpy() if _RELU_MARGIN[2] is not None else None))
     return out
 
 

@@ -152,14 +152,6 @@ _SIGS = {
     "score_auc_scratch_bytes": [C.c_int64],
     "score_ranking_quality": [c_f, c_i, C.c_int64, C.c_int32, c_f, c_i, c_f, C.c_int64, C.c_void_p],
     "score_persample_form": [C.POINTER(Config), C.POINTER(State), C.c_int32, C.c_int32],
-    "score_context_sync_errors": [C.c_void_p, C.POINTER(C.c_int32)],
-    "score_async_index_plan": [C.POINTER(Config), C.POINTER(State), C.POINTER(Batch), C.c_int32, C.c_int32, C.c_void_p,
-                               C.POINTER(C.c_void_p), C.c_int32, C.c_void_p, C.POINTER(C.c_uint64)],
-    "score_async_adam_catchup_ids_through": [C.POINTER(AdamTable), C.c_void_p, C.c_int64, C.c_uint32, C.c_float, C.c_void_p,
-                                             C.POINTER(C.c_void_p), C.c_int32, C.c_void_p, C.POINTER(C.c_uint64)],
-    "score_async_adam_catchup_rows": [C.POINTER(AdamTable), C.c_int64, C.c_int64, C.c_uint32, C.c_void_p,
-                                      C.POINTER(C.c_void_p), C.c_int32, C.c_void_p, C.POINTER(C.c_uint64)],
-    "score_async_wait": [C.c_uint64],
     "score_abi_struct_sizes": [C.POINTER(C.c_int64), C.c_int32],
     "score_persample_prep": [C.POINTER(Config), C.POINTER(State), C.c_int32, C.c_int32, C.c_void_p],
     "score_context_stream": [C.c_void_p, C.POINTER(C.c_void_p)],

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libscore_hip.so")
-SOURCES = ["embed.hip", "gemm.hip", "gemm_bf16x3.hip", "gemm_panel.hip", "gru.hip", "gru_x3.hip", "gru_stream.hip", "head.hip", "head_fused.hip", "adam_tiled.hip", "scatter.hip", "sort.hip", "loader.hip", "ps_fwd.hip", "ps_bwd.hip", "async.hip", "step.hip", "engine.hip"]
+SOURCES = ["embed.hip", "gemm.hip", "gemm_bf16x3.hip", "gemm_panel.hip", "gru.hip", "gru_x3.hip", "gru_stream.hip", "head.hip", "head_fused.hip", "adam_tiled.hip", "scatter.hip", "sort.hip", "loader.hip", "ps_fwd.hip", "ps_bwd.hip", "step.hip", "engine.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result",
          "-Wno-pass-failed", "-munsafe-fp-atomics"]
 

@@ -20,39 +20,6 @@
 #error "a wrong-by-design probe switch needs -DSCORE_PROBE_BUILD (tools/*_probe.py pass it; score_amd/build.py never does)"
 #endif
 
-// ---- a barrier across the workgroups of ONE launch (round 5) --------------------------------------------------------
-// At the reference's own batch sizes a step is a chain of dependent 5 - 25 us kernels, each costing the host a ~4.5 us
-// launch call and the stream a ~5 us boundary; phases that only need "every workgroup is done with the previous phase"
-// run as one launch with this between them.  bar: 4 words of device memory, ZERO when first used and never written by
-// anything else -- {arrivals, generation, error, -} -- self-resetting, so launches that use the same words one after the
-// other need no reset.  The caller keeps the grid small enough to be co-resident (<= ~1 workgroup per CU of a kernel that
-// fits several per CU): a workgroup that is not running cannot arrive.  Other kernels sharing the chip only delay
-// arrival (they end without waiting for anything here).  The wait is BOUNDED (~0.2 s of the 100 MHz clock): on a timeout
-// the error word is raised (score_context_sync_errors) and the workgroup goes on -- wrong results, never a hung queue.
-// Writes before the barrier by any workgroup are visible to every workgroup behind it (agent-scope fences both sides).
-__device__ __forceinline__ void score_grid_sync(unsigned int* bar, unsigned int nblocks) {
-  __threadfence();
-  __syncthreads();
-  if (threadIdx.x == 0 && nblocks > 1) {
-    const unsigned int gen = __hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (__hip_atomic_fetch_add(&bar[0], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == nblocks - 1) {
-      __hip_atomic_store(&bar[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_fetch_add(&bar[1], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-      const unsigned long long t0 = wall_clock64();
-      while (__hip_atomic_load(&bar[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == gen) {
-        __builtin_amdgcn_s_sleep(1);
-        if (wall_clock64() - t0 > 20000000ull) {
-          __hip_atomic_fetch_or(&bar[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          break;
-        }
-      }
-    }
-  }
-  __syncthreads();
-  __threadfence();
-}
-
 #define SCORE_CHECK_LAUNCH()                      \
   do {                                            \
     hipError_t e__ = hipGetLastError();           \

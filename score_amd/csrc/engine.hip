@@ -315,17 +315,7 @@ void build_ws(const Dims& d, int B, WS* w) {
 // score_state_t.context; forked from / joined back into the caller's stream with events.  A caller that passes no
 // context shares ONE process-wide default context per device (created on first use, released by
 // score_context_destroy(NULL)): the only state the library keeps between calls.
-// sync: SCORE_SYNC_SLOTS x 4 zeroed words of device memory for score_grid_sync (common.h), handed out in rotation to the launches
-// that fuse dependent phases (a slot is free again long before its turn comes round: a context is driven by one host thread)
-#define SCORE_SYNC_SLOTS 32
-struct SideStream { hipStream_t st; hipEvent_t fork, join, wx; int device; hipStream_t fwd_on; unsigned int* sync; unsigned int sync_next; };
-static unsigned int* sync_slot(SideStream* sd, const score_state_t* st) {
-  // bit 13 OPTS IN: measured (profiles/r05_probes.md), the one-launch sort takes 162 us against ~110 us for the six launches with
-  // their gaps, and its agent-scope fences (an L2 write-back + invalidate per barrier and workgroup, on every XCD) slow the
-  // kernels running beside it -- the per-sample forward 35 -> 50 us, the backward 38 -> 47 us: the step got 25 % slower.
-  if (!sd || !sd->sync || !st || !(st->debug_flags & 8192)) return nullptr;
-  return sd->sync + 4 * (sd->sync_next++ % SCORE_SYNC_SLOTS);
-}
+struct SideStream { hipStream_t st; hipEvent_t fork, join, wx; int device; hipStream_t fwd_on; };
 static int side_stream_create(SideStream* sd) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return SCORE_E_BADARG;
@@ -336,12 +326,6 @@ static int side_stream_create(SideStream* sd) {
   if ((e = hipEventCreateWithFlags(&b, hipEventDisableTiming)) != hipSuccess) { hipEventDestroy(a); hipStreamDestroy(st); return (int)e; }
   if ((e = hipEventCreateWithFlags(&c, hipEventDisableTiming)) != hipSuccess) { hipEventDestroy(a); hipEventDestroy(b); hipStreamDestroy(st); return (int)e; }
   sd->st = st; sd->fork = a; sd->join = b; sd->wx = c; sd->device = dev; sd->fwd_on = nullptr;
-  sd->sync = nullptr; sd->sync_next = 0;
-  void* sy = nullptr;
-  if (hipMalloc(&sy, SCORE_SYNC_SLOTS * 16) == hipSuccess) {
-    if (hipMemset(sy, 0, SCORE_SYNC_SLOTS * 16) == hipSuccess) sd->sync = static_cast<unsigned int*>(sy);
-    else hipFree(sy);
-  }
   return 0;
 }
 static void side_stream_release(SideStream* sd) {
@@ -349,8 +333,6 @@ static void side_stream_release(SideStream* sd) {
   hipStreamSynchronize(sd->st);
   hipEventDestroy(sd->fork); hipEventDestroy(sd->join); hipEventDestroy(sd->wx);
   hipStreamDestroy(sd->st);
-  if (sd->sync) hipFree(sd->sync);
-  sd->sync = nullptr;
   sd->st = nullptr;
 }
 #define SCORE_MAX_DEVICES 16
@@ -444,22 +426,6 @@ extern "C" int score_context_stream(void* ctx, void** stream) {
   SideStream* sd = nullptr;
   SCORE_TRY(side_stream(&st, &sd));
   *stream = (void*)sd->st;
-  return 0;
-}
-
-extern "C" int score_context_sync_errors(void* ctx, int32_t* errors) {
-  if (!errors) return SCORE_E_BADARG;
-  SideStream* sd = reinterpret_cast<SideStream*>(ctx);
-  if (!sd) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SCORE_MAX_DEVICES) return SCORE_E_BADARG;
-    sd = &g_default_ctx[dev];
-  }
-  *errors = 0;
-  if (!sd->sync) return 0;
-  unsigned int host[SCORE_SYNC_SLOTS * 4];
-  HIPTRY(hipMemcpy(host, sd->sync, sizeof(host), hipMemcpyDeviceToHost));
-  for (int i = 0; i < SCORE_SYNC_SLOTS; ++i) *errors += host[4 * i + 2] ? 1 : 0;
   return 0;
 }
 
@@ -572,11 +538,8 @@ extern "C" int score_index_plan(const score_config_t* cfg, const score_state_t* 
   uint32_t* vals_in = reinterpret_cast<uint32_t*>(ws + w.vals_in);
   uint32_t* keys_out = reinterpret_cast<uint32_t*>(ws + w.keys_out);
   uint32_t* vals_out = reinterpret_cast<uint32_t*>(ws + w.vals_out);
-  SideStream* ctx = nullptr;
-  G(side_stream(st, &ctx));
   G(score_launch_plan(pf, key_bits, keys_in, vals_in, keys_out, vals_out, ws + w.sort_temp,
-                      (size_t)w.sort_temp_bytes, s, (st->debug_flags & 32) ? 1 : (st->debug_flags & 256) ? 2 : 0,
-                      sync_slot(ctx, st)));
+                      (size_t)w.sort_temp_bytes, s, (st->debug_flags & 32) ? 1 : (st->debug_flags & 256) ? 2 : 0));
   if (n_shards > 1 || dedup) {
     PlanRemapArgs ra;
     memset(&ra, 0, sizeof(ra));
@@ -1385,9 +1348,24 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
 
   // ---- co-attention + embedding rows (score.py:147-167, 196-201, 51-66)
   const int64_t slab_used = slab_half;
-  // (round 3 measured the recurrences' weight-gradient products HERE instead of at the end of the pass, on the main stream
-  //  and on the side stream beside the co-attention backward and the scatter: each moves the cost somewhere else,
-  //  profiles/r03_probes.md)
+  // The recurrences' weight-gradient products (X^T dY: eight products, K = B*T) need what the backward recurrence has written and
+  // nothing else, and nothing inside the pass reads them.  Round 6: issued HERE on the side stream -- behind the head's / attention's
+  // products, which end about where the input-gradient product below does -- so the matrix-bound launch runs beside the co-attention
+  // backward and the row scatter, which are bound by memory latency / bandwidth and were alone on the chip for ~250 us at cfg-3
+  // (profiles/r05_cfg3_sequence.txt), instead of at the END of the launch stream's chain in front of the table's touched-row update
+  // (125 us there beside the look-ahead catch-up; 65 us alone).  The join recorded behind them is the one the launch stream waits
+  // for behind the scatter (below), so whatever the caller queues next on the launch stream is also behind their last read of the
+  // workspace.  debug_flags bit 14 (16384): the round-5 placement (A/B).  The sharded path keeps that placement too: its caller
+  // runs the gradient exchange on streams of its own beside the scatter (score_amd/dist.py).
+  ReduceGroup rg;
+  rg.n = rg.blocks = 0;
+  const bool products_early = side != nullptr && st->scatter_mode != 2 && !(st->debug_flags & 16384) && gq.n > 0;
+  if (products_early) {
+    HIPTRY(hipEventRecord(side->fork, s));
+    HIPTRY(hipStreamWaitEvent(side->st, side->fork, 0));
+    G(gemm_queue_flush(&gq, x3 != 0, ws + w.dwslab + slab_used, w.dwslab_floats - slab_used, side->st, &rg));
+    HIPTRY(hipEventRecord(side->join, side->st));
+  }
   EV(3);
   const bool atomic = st->scatter_mode == 1;
   float* pw_ = (st->plan_workspace && st->scatter_mode == 0) ? st->plan_workspace : ws;      // (see score_state_t.plan_workspace)
@@ -1457,25 +1435,13 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
   // gradients only, on the launch stream meanwhile, and waits for the event before anything reads grad_w.
   const bool fin_side = st->grads_done_event != nullptr && side != nullptr;
   hipStream_t fs = fin_side ? side->st : s;
-  ReduceGroup rg;
-  // (round 5, debug_flags bit 14, OFF: the column sums' FIRST stage -- it reads what the pass has written by now, nothing of the
-  //  products below -- on the side stream BESIDE the products instead of behind them, where it runs beside the touched-row update
-  //  and takes 52 us instead of 13 while the dense ApplyAdam waits.  Measured, three alternating pairs at cfg-3: 853.0 k samples/s
-  //  with it, 863.9 k without -- what it saves at the step's tail the matrix-bound products lose to it.)
-  int cs_early = 0;
-  if (fin_side && cq.n > 0 && (st->debug_flags & 16384)) {
-    HIPTRY(hipEventRecord(side->fork, s));
-    HIPTRY(hipStreamWaitEvent(fs, side->fork, 0));
-    G(colsum_queue_stage1(&cq, ws + w.cs_part + w.cs_part_floats / 2, w.cs_part_floats - w.cs_part_floats / 2, fs));
-    cs_early = 1;
-  }
-  G(gemm_queue_flush(&gq, x3 != 0, ws + w.dwslab + slab_used, w.dwslab_floats - slab_used, s, &rg));
+  if (!products_early) G(gemm_queue_flush(&gq, x3 != 0, ws + w.dwslab + slab_used, w.dwslab_floats - slab_used, s, &rg));
   EV(5);
   if (fin_side) {
     HIPTRY(hipEventRecord(side->fork, s));
     HIPTRY(hipStreamWaitEvent(fs, side->fork, 0));
   }
-  G(score_launch_finish(&rg, &cq, ws + w.cs_part + w.cs_part_floats / 2, w.cs_part_floats - w.cs_part_floats / 2, fs, cs_early));
+  G(score_launch_finish(&rg, &cq, ws + w.cs_part + w.cs_part_floats / 2, w.cs_part_floats - w.cs_part_floats / 2, fs, 0));
   if (fin_side) HIPTRY(hipEventRecord((hipEvent_t)st->grads_done_event, fs));
   return 0;
 }

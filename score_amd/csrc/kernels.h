@@ -188,12 +188,10 @@ int score_launch_plan_unique(const PlanRemapArgs& ra, const uint32_t* keys, cons
 int score_scan_temp_bytes(int64_t n, size_t* bytes);
 int score_plan_temp_bytes(int64_t n, int end_bit, size_t* bytes);
 int score_launch_plan(const PlanFillArgs& a, int key_bits, uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys_out,
-                      uint32_t* vals_out, void* temp, size_t temp_bytes, hipStream_t s, int which = 0,
-                      unsigned int* sync = nullptr);
-// sort.hip: the stable radix sort of the plan (small batches) and its scratch.  sync: four zero-initialised words for
-// score_grid_sync (common.h) -- with them, up to 524 K occurrences are sorted by ONE launch instead of six
+                      uint32_t* vals_out, void* temp, size_t temp_bytes, hipStream_t s, int which = 0);
+// sort.hip: the stable radix sort of the plan (small batches) and its scratch
 int score_launch_plan_own(const PlanFillArgs& a, int key_bits, uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys_out,
-                          uint32_t* vals_out, void* temp, size_t temp_bytes, hipStream_t s, unsigned int* sync = nullptr);
+                          uint32_t* vals_out, void* temp, size_t temp_bytes, hipStream_t s);
 size_t score_sort_temp_bytes(int64_t n);
 int score_pull_window(int64_t n);
 int score_launch_pull(PullArgs& a, const uint32_t* keys, const uint32_t* vals, int64_t n, float* out,

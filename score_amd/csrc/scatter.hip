@@ -77,10 +77,10 @@ int score_plan_temp_bytes(int64_t n, int end_bit, size_t* bytes) {
 // Both sorts are stable: the plan is the same bits either way.
 #define SCORE_OWN_SORT_MAX_N (1 << 21)
 int score_launch_plan(const PlanFillArgs& a, int key_bits, uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys_out,
-                      uint32_t* vals_out, void* temp, size_t temp_bytes, hipStream_t s, int which, unsigned int* sync) {
+                      uint32_t* vals_out, void* temp, size_t temp_bytes, hipStream_t s, int which) {
   int64_t n = a.off[6] + 1;   // + sentinel
   if (which == 2 || (which == 0 && n < SCORE_OWN_SORT_MAX_N))
-    return score_launch_plan_own(a, key_bits, keys_in, vals_in, keys_out, vals_out, temp, temp_bytes, s, sync);
+    return score_launch_plan_own(a, key_bits, keys_in, vals_in, keys_out, vals_out, temp, temp_bytes, s);
   hipLaunchKernelGGL(plan_fill_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, s, a, keys_in, vals_in);
   SCORE_CHECK_LAUNCH();
   size_t need = 0;

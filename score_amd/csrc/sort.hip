@@ -367,52 +367,8 @@ __global__ __launch_bounds__(THREADS) void sort_scatter_kernel(const uint32_t* _
   sort_scatter_tile(kin, vin, kout, vout, n, shift, dbits, M, tot, (int)blockIdx.x, smem, raw_tiles);
 }
 
-// ---------------------------------------------------------------- the whole plan sort in ONE launch (round 5)
-// Up to FUSED_MAX_TILES tiles (524 K occurrences: the reference's own batch sizes at every data set's shape): a workgroup per
-// tile runs fill + histogram, column scan, scatter, histogram, column scan, scatter with score_grid_sync between the phases --
-// the same arithmetic as the six launches (stable: the plan is the same bits), five barriers (~3 us each) instead of five launch
-// boundaries and, what matters at these sizes, ONE launch call of the host instead of six (the step is bound by those).
+// (up to FUSED_MAX_TILES tiles the scatter kernel scans its own histogram columns: four launches instead of six)
 constexpr int FUSED_MAX_TILES = 64;
-__device__ __forceinline__ void sort_colscan_all(uint32_t* __restrict__ M, int ntiles, int nbins, uint32_t* __restrict__ tot,
-                                                 int blk, int nblk) {
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  for (int g = blk * WAVES + w; g * 64 < nbins; g += nblk * WAVES) {        // a wave per 64 bins, a lane per bin, tiles in order
-    uint32_t* col = M + g * 64 + lane;
-    uint32_t run = 0;
-    int t = 0;
-    for (; t + 8 <= ntiles; t += 8) {
-      uint32_t c[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) c[u] = col[(int64_t)(t + u) * nbins];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) { col[(int64_t)(t + u) * nbins] = run; run += c[u]; }
-    }
-    for (; t < ntiles; ++t) { const uint32_t c = col[(int64_t)t * nbins]; col[(int64_t)t * nbins] = run; run += c; }
-    tot[g * 64 + lane] = run;
-  }
-}
-struct FusedSort { int npass, dbits[3], shift[3]; };
-__global__ __launch_bounds__(THREADS) void plan_sort_fused_kernel(PlanFillArgs a, int64_t n, uint32_t* k0, uint32_t* v0, uint32_t* k1,
-                                                                  uint32_t* v1, uint32_t* M, uint32_t* tot, FusedSort sh,
-                                                                  unsigned int* bar) {
-  extern __shared__ uint32_t smem[];
-  const int tile = (int)blockIdx.x, ntiles = (int)gridDim.x;
-  plan_fill_hist_tile(a, n, k0, v0, sh.dbits[0], M, tile, smem);
-  for (int p = 0; p < sh.npass; ++p) {
-    if (p > 0) {
-      __syncthreads();
-      sort_hist_tile(k0, n, sh.shift[p], sh.dbits[p], M, tile, smem);
-    }
-    score_grid_sync(bar, (unsigned)ntiles);
-    sort_colscan_all(M, ntiles, 1 << sh.dbits[p], tot, tile, ntiles);
-    score_grid_sync(bar, (unsigned)ntiles);
-    sort_scatter_tile(k0, v0, k1, v1, n, sh.shift[p], sh.dbits[p], M, tot, tile, smem);
-    if (p + 1 < sh.npass) score_grid_sync(bar, (unsigned)ntiles);          // (every tile of the pass written before anybody reads one)
-    uint32_t* t = k0; k0 = k1; k1 = t;
-    t = v0; v0 = v1; v1 = t;
-  }
-}
-
 struct SortShape { int npass, dbits[3], shift[3]; };
 SortShape sort_shape(int key_bits) {
   SortShape s;
@@ -486,7 +442,7 @@ size_t score_sort_temp_bytes(int64_t n) {
 // keys_out / vals_out <- the occurrences of the batch sorted by (owner, row), equal keys in occurrence order (stable).
 // keys_in / vals_in are scratch (they hold an intermediate pass afterwards).
 int score_launch_plan_own(const PlanFillArgs& a, int key_bits, uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys_out,
-                      uint32_t* vals_out, void* temp, size_t temp_bytes, hipStream_t s, unsigned int* sync) {
+                      uint32_t* vals_out, void* temp, size_t temp_bytes, hipStream_t s) {
   const int64_t n = a.off[6] + 1;   // + sentinel
   if (n >= (1ll << 31)) return SCORE_E_SHAPE;
   if (score_sort_temp_bytes(n) > temp_bytes) return SCORE_E_WORKSPACE;
@@ -499,19 +455,6 @@ int score_launch_plan_own(const PlanFillArgs& a, int key_bits, uint32_t* keys_in
   uint32_t* v0 = (sh.npass & 1) ? vals_in : vals_out;
   uint32_t* k1 = (sh.npass & 1) ? keys_out : keys_in;
   uint32_t* v1 = (sh.npass & 1) ? vals_out : vals_in;
-  if (sync && ntiles <= FUSED_MAX_TILES) {
-    FusedSort fs;
-    fs.npass = sh.npass;
-    int lds = 0;
-    for (int p = 0; p < 3; ++p) {
-      fs.dbits[p] = p < sh.npass ? sh.dbits[p] : 0; fs.shift[p] = p < sh.npass ? sh.shift[p] : 0;
-      if (p < sh.npass && scatter_lds_bytes(1 << sh.dbits[p]) > lds) lds = scatter_lds_bytes(1 << sh.dbits[p]);
-    }
-    SCORE_TRY(set_lds((const void*)plan_sort_fused_kernel, lds));
-    hipLaunchKernelGGL(plan_sort_fused_kernel, dim3(ntiles), dim3(THREADS), lds, s, a, n, k0, v0, k1, v1, M, tot, fs, sync);
-    SCORE_CHECK_LAUNCH();
-    return 0;
-  }
   hipLaunchKernelGGL(plan_fill_hist_kernel, dim3(ntiles), dim3(THREADS), (1 << sh.dbits[0]) * 4, s, a, n, k0, v0, sh.dbits[0], M);
   SCORE_CHECK_LAUNCH();
   return run_passes(sh, k0, v0, k1, v1, n, M, tot, true, s);

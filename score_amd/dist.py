@@ -23,6 +23,7 @@ back to it on its own.
 import ctypes as C
 import os
 import sys
+import threading
 
 import numpy as np
 import torch
@@ -36,6 +37,15 @@ if not torch.cuda.is_initialized():
 
 from . import _lib
 from .model import SCOREBASE, DeviceBatch, _ptr, ADAM_B1, ADAM_B2, ADAM_EPS
+
+
+def _a2a_probe_hung(rank, world, timeout_s):
+    """probe_a2a's watchdog: the list-form all-to-all (or the verdict's all-reduce behind it) has not returned"""
+    sys.stderr.write("[score_amd.dist] rank %d of %d: the list-form all-to-all probe (empty own slots) has not returned after %.0f s; "
+                     "start the job with SCORE_A2A=split (bench.py --a2a split) to use all_to_all_single only\n"
+                     % (rank, world, timeout_s))
+    sys.stderr.flush()
+    os._exit(3)
 
 
 def _to_host(t):
@@ -135,10 +145,15 @@ class TorchDistComm(object):
         return {k: {"calls": v["calls"], "ms_avg": v["ms_sum"] / v["calls"], "ms_max": v["ms_max"],
                     "bytes_avg": v["bytes_sum"] / v["calls"]} for k, v in out.items()}
 
-    def probe_a2a(self, device, force=None):
-        """Run both all-to-all forms on tiny tensors, compare what arrives with what every rank must receive, and settle on one
-        form for the whole run -- the same one on every rank (the verdicts are all-reduced).  One line on stderr from rank 0.
-        force: "split" / "remote" (or SCORE_A2A): take that form without asking (still checked, a mismatch raises)."""
+    def probe_a2a(self, device, force=None, timeout_s=None):
+        """Settle on ONE all-to-all form for the whole run -- the same one on every rank -- by running it on tiny tensors and
+        comparing what arrives with what every rank must receive (the verdicts are all-reduced).  One line on stderr from rank 0.
+        force: "split" / "remote" (or SCORE_A2A): ONLY that form is run (a form nobody asked for is never entered: a hang of the
+        list form on one rank must not be able to take a `--a2a split` job down at set-up); a mismatch raises.
+        Not forced: "split" (all_to_all_single, the plain RCCL path) is probed first; the list form with empty own slots -- the
+        preferred one, a rank's own rows stay out of the collective -- is then probed under a watchdog: if it has not returned
+        after timeout_s (SCORE_A2A_PROBE_TIMEOUT, default 60 s) the rank says so on stderr, names the switch that avoids it
+        and exits 3 (a collective that never completes cannot be abandoned inside the process)."""
         force = force or os.environ.get("SCORE_A2A") or None
         if force not in (None, "split", "remote"):
             raise ValueError("all-to-all form must be 'split' or 'remote', got %r" % (force,))
@@ -146,6 +161,8 @@ class TorchDistComm(object):
             self._list_form = None if self.world == 1 else True
             self.a2a_probe = {"form": "none (one rank)" if self.world == 1 else "pairwise (gloo)", "forced": force}
             return self.a2a_probe
+        if timeout_s is None:
+            timeout_s = float(os.environ.get("SCORE_A2A_PROBE_TIMEOUT", "60"))
         G, r = self.world, self.rank
         per = 3                                       # rows per peer; row values name (source, destination, row)
         inp = torch.tensor([[1000.0 * r + 10.0 * p + i for i in range(per)] for p in range(G)], dtype=torch.float32,
@@ -154,9 +171,14 @@ class TorchDistComm(object):
                             device=device).reshape(G * per, 1)
         splits = [per] * G
         verdict = {}
-        for form in ("remote", "split"):
+        for form in ((force,) if force is not None else ("split", "remote")):
             ok = 1.0
             out = torch.full_like(inp, -1.0)
+            dog = None
+            if form == "remote" and force is None and timeout_s > 0:
+                dog = threading.Timer(timeout_s, _a2a_probe_hung, args=(r, G, timeout_s))
+                dog.daemon = True
+                dog.start()
             try:
                 if form == "split":
                     self.dist.all_to_all_single(out, inp, splits, splits, group=self.group)
@@ -175,6 +197,8 @@ class TorchDistComm(object):
             flag = torch.tensor([ok], dtype=torch.float32, device=device)
             self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN, group=self.group)     # every rank, or nobody
             verdict[form] = bool(flag.item() == 1.0)
+            if dog is not None:
+                dog.cancel()
         if force is not None and not verdict[force]:
             raise RuntimeError("all-to-all form %r was asked for and does not round-trip on this backend: %r" % (force, verdict))
         form = force or ("remote" if verdict["remote"] else "split")

@@ -251,15 +251,6 @@ class SCOREBASE(object):
         self.fast_step = True           # train / train_async: the steady-state step of the per-sample form as one library call (_train_step_fast)
         self._step_args = self._step_T = self._step_side = None
         self._pb_cache = {}
-        # the launches that start side-stream work (next batch's index plan, look-ahead catch-up, window slice) are made by the
-        # library's worker thread (csrc/async.hip) while this thread queues the step's chain -- the per-sample form only (the step is
-        # bound by this thread's launch calls there: tools/host_calls.py)
-        # OFF by default: measured, the step takes the same time with it (tmall_default 0.2073 vs 0.2054 ms, cfg-2 0.1675 vs 0.1671,
-        # taobao_default 0.2178 vs 0.2174) -- the HIP runtime serialises the two threads' calls: the 30 us of launch calls the worker
-        # takes over come back as slower event / launch calls on this thread (tools/host_calls.py: "python + torch" 75 -> 240 us)
-        self.launch_worker = os.environ.get("SCORE_LAUNCH_WORKER", "0") == "1"
-        self._sweep_ticket = 0
-        self._evh_cache = {}
         self._ev_dense = None
         self.w = torch.zeros((self.n_w,), **f32)
         self._alloc_optimizer()
@@ -495,11 +486,6 @@ class SCOREBASE(object):
         # the window slice, the early loss copy) may still be running: the caching allocator knows a tensor only by the stream
         # it was allocated on and would hand the dying model's buffers to the next allocation while those kernels still write
         # them (seen as two "identical" models diverging by a few ulp when one of them inherited such a block).  Wait first.
-        try:
-            if getattr(self, "lib", None) is not None:
-                self.lib.score_async_wait(C.c_uint64(0))      # (launches the worker thread still owes: issued before the streams are drained)
-        except Exception:
-            pass
         for st in (getattr(self, "_side", None), getattr(self, "_sweep_st", None), getattr(self, "_plan_stream", None),
                    (getattr(self, "_early_loss_state", None) or {}).get("stream")):
             try:
@@ -651,7 +637,6 @@ class SCOREBASE(object):
             # pulls memory from under a step; the device-wide wait keeps the allocator from handing the block to a
             # new tensor while kernels enqueued on other streams still use it (evictions are rare: a new batch size).
             while len(self._ws) >= self.max_workspaces:
-                self.lib.score_async_wait(C.c_uint64(0))
                 torch.cuda.synchronize(self.device)
                 self._ws.pop(next(iter(self._ws)))
             ent = (lay, buf)
@@ -767,34 +752,6 @@ class SCOREBASE(object):
     def device_batch(self, batch_data):
         return batch_data if isinstance(batch_data, DeviceBatch) else DeviceBatch(self, batch_data)
 
-    def sync_errors(self):
-        """how many in-launch barriers of this model's context have ever timed out (score_context_sync_errors; 0)"""
-        n = C.c_int32(0)
-        _lib.check(self.lib.score_context_sync_errors(self._ctx, C.byref(n)), "score_context_sync_errors")
-        return int(n.value)
-
-    def _async_on(self):
-        return (self.launch_worker and self._ps_last and not self._inline_on and not self._graph_on and not self._use_dev_scalars)
-
-    def _async_wait(self, ticket):
-        """the worker thread has ISSUED the job (score_hip.h: before anything waits for / re-records an event the job names)"""
-        if ticket:
-            _lib.check(self.lib.score_async_wait(C.c_uint64(ticket)), "score_async_wait")
-
-    def _evh(self, name):
-        """an event for the worker thread to record: (torch event, handle); recorded once here so that the handle exists"""
-        e = self._evh_cache.get(name)
-        if e is None:
-            ev = torch.cuda.Event()
-            ev.record(self._cur())
-            e = self._evh_cache[name] = (ev, C.c_void_p(ev.cuda_event))
-        return e
-
-    @staticmethod
-    def _ev_list(*events):
-        hs = [C.c_void_p(e.cuda_event) for e in events if e is not None]
-        return (C.c_void_p * max(len(hs), 1))(*hs), len(hs)
-
     def persample_form(self, B, active_slices=0):
         """True if a batch of B samples with `active_slices` computed slices runs as the per-sample whole-model kernels
         (include/score_hip.h score_persample_form; csrc/persample.h): the reference's own shapes.  The step is then a handful of
@@ -882,7 +839,6 @@ class SCOREBASE(object):
         # (tests/test_gpu_model.py compares the overlap modes with it bit for bit; the first thing to try on a suspected race)
         inline = bool(int(self.debug_flags) & 4096)
         if inline != self._inline_on or (inline and self._side is not None and self._side.cuda_stream != cur.cuda_stream):
-            self.lib.score_async_wait(C.c_uint64(0))
             torch.cuda.synchronize(self.device)
             self._side = self._sweep_st = self._early_loss_state["stream"] = None
             self._plan_ready = None
@@ -958,8 +914,6 @@ class SCOREBASE(object):
             pr, self._plan_ready = self._plan_ready, None
             plan_here = pr is not None and pr[0] is db and pr[3] == db.active_slices and not want_list and (
                 pr[2] == ws.data_ptr() or pr[2] == self._plan_buffer(db.B, 1))
-            if pr is not None and not plan_here:
-                self._async_wait(pr[4])            # (a plan nobody uses: still issued before its events and buffers move on)
             if plan_here:
                 if pr[2] != ws.data_ptr():
                     st.plan_workspace = pr[2]      # (sorted into the second plan buffer by the one-call step: score_state_t.plan_workspace)
@@ -968,7 +922,6 @@ class SCOREBASE(object):
                 # are longer than the forward and backward kernels they used to hide under
                 plan_done = pr[1]
                 row_list = None
-                self._async_wait(pr[4])            # (the worker has made the record call the backward pass's wait binds to)
                 st.plan_done_event = C.c_void_p(plan_done.cuda_event)
                 self._plan_done = plan_done
                 early = None
@@ -1154,12 +1107,9 @@ class SCOREBASE(object):
         if self._ev_sweep is not None and rows_untouched and self._sweep_on_side and str(self.adam_sweep_at) != "f1":
             pass            # (adam_sweep_at "f1" puts this step's slice on a stream of its own: it would not queue behind that one)
         elif self._ev_sweep is not None:
-            self._async_wait(self._sweep_ticket)
-            self._sweep_ticket = 0
             cur.wait_event(self._ev_sweep)
             self._ev_sweep = None
         if self._ahead is not None:          # (a look-ahead catch-up replays rows on the side stream: nothing else may meanwhile)
-            self._async_wait(self._ahead[2])
             cur.wait_event(self._ahead[1])
 
     def _catchup(self, db, sweep):
@@ -1167,7 +1117,6 @@ class SCOREBASE(object):
         training step the window's slice of the table follows on its own stream, beside the step."""
         ah, self._ahead = self._ahead, None
         if ah is not None:
-            self._async_wait(ah[2])
             self._cur().wait_event(ah[1])
             if ah[0] is db and db.flat is not None:
                 # apply_adam(next_batch=db) of the previous step has brought these rows up to date through that step
@@ -1218,14 +1167,6 @@ class SCOREBASE(object):
         _, _, T = self._tiled
         cur = self._cur()
         other = stream.cuda_stream != cur.cuda_stream       # (current_stream() returns a new wrapper object every call)
-        if other and self._async_on():
-            ev, evh = self._evh("sweep_w")
-            waits, nw = self._ev_list(behind, after)
-            tk = C.c_uint64(0)
-            _lib.check(self.lib.score_async_adam_catchup_rows(C.byref(T), lo, hi, upto, C.c_void_p(stream.cuda_stream), waits, nw,
-                                                              evh, C.byref(tk)), "score_async_adam_catchup_rows")
-            self._ev_sweep, self._sweep_ticket = ev, int(tk.value)
-            return
         if behind is not None:
             stream.wait_event(behind)
         if other:
@@ -1247,20 +1188,8 @@ class SCOREBASE(object):
         side = self._side
         # (the side stream has run this step's window slice before -- it was started at boundary 2 --, so the two replays
         #  never meet on a row; rows in state 2 are skipped here and updated by score_adam_touched on the main stream)
-        if self._async_on():
-            # (a window slice on a stream of its own: behind it -- the worker makes that event's record call before this job's wait)
-            ev, evh = self._evh("ahead_w")
-            waits, nw = self._ev_list(ev4, self._ev_sweep)
-            tk = C.c_uint64(0)
-            _lib.check(self.lib.score_async_adam_catchup_ids_through(C.byref(T), _ptr(nxt.flat), nxt.flat.numel(), int(self.step) + 1,
-                                                                     self._alpha(lr), C.c_void_p(side.cuda_stream), waits, nw, evh,
-                                                                     C.byref(tk)), "score_async_adam_catchup_ids_through")
-            self._ahead = (nxt, ev, int(tk.value))
-            self._b4_recorded = None
-            return
         side.wait_event(ev4)
         if self._ev_sweep is not None:       # (a window slice on a stream of its own: behind it)
-            self._async_wait(self._sweep_ticket)
             side.wait_event(self._ev_sweep)
         _lib.check(self.lib.score_adam_catchup_ids_through(C.byref(T), _ptr(nxt.flat), nxt.flat.numel(), int(self.step) + 1,
                                                            self._alpha(lr), C.c_void_p(side.cuda_stream)),
@@ -1285,14 +1214,6 @@ class SCOREBASE(object):
         st.scatter_mode = 0; st.gemm_mode = int(self.gemm_mode); st.debug_flags = int(self.debug_flags)
         st.context = self._ctx
         st.id_status = None
-        if self._async_on():
-            ev, evh = self._evh("plan_w")
-            waits, nw = self._ev_list(ev4)
-            tk = C.c_uint64(0)
-            _lib.check(self.lib.score_async_index_plan(C.byref(self.cfg), C.byref(st), C.byref(nxt.struct), 1, 0, self._side_handle,
-                                                       waits, nw, evh, C.byref(tk)), "score_async_index_plan")
-            self._plan_ready = (nxt, ev, ws.data_ptr(), nxt.active_slices, int(tk.value))
-            return
         self._side.wait_event(ev4)
         _lib.check(self.lib.score_index_plan(C.byref(self.cfg), C.byref(st), C.byref(nxt.struct), 1, 0, self._side_handle),
                    "score_index_plan")
@@ -1466,7 +1387,7 @@ class SCOREBASE(object):
                 or self.catchup_events or int(self.debug_flags) or str(self.adam_sweep_at) != "2" or self.adam_touched_list
                 or self._tiled is None or not self._tiled_ready or not self._adam_dirty or self._flags_marked or self._row_grads
                 or self._pending_sweep is not None or self._side is None or not isinstance(db, DeviceBatch) or db.flat is None
-                or not self._look_ahead or not self._tiled_on() or self._async_on()):
+                or not self._look_ahead or not self._tiled_on()):
             return None
         ah, pr = self._ahead, self._plan_ready
         if ah is None or ah[0] is not db or pr is None or pr[0] is not db or pr[3] != db.active_slices:
@@ -1587,7 +1508,6 @@ class SCOREBASE(object):
         self._keep = (None, None)
         self._ev_sweep = ev_sweep if p.slice_hi > p.slice_lo else None
         self._sweep_on_side = True
-        self._sweep_ticket = 0
         self._plan_done = pr[1]
         self._b4_recorded, self._b4_any = None, self._ev_b4
         self._row_grads = self._flags_marked = False
@@ -1679,7 +1599,6 @@ class SCOREBASE(object):
                 static = DeviceBatch.empty(self, db.B, db.active_slices)
                 static.flat.copy_(db.flat)
                 lay, ws = self._workspace(db.B)
-                self.lib.score_async_wait(C.c_uint64(0))       # (no other thread of ours makes a HIP call while the capture runs)
                 torch.cuda.synchronize(self.device)
                 g = torch.cuda.CUDAGraph()
                 step, b1p, b2p = self.step, self.beta1_power, self.beta2_power
@@ -1755,7 +1674,6 @@ class SCOREBASE(object):
                 self._rollback_steps(skipped)
             self._pending_sweep = None          # (a window slice scheduled for a step that was not applied)
             if self._ahead is not None:         # (a look-ahead catch-up that the set word suppressed)
-                self._async_wait(self._ahead[2])
                 self._cur().wait_event(self._ahead[1])
                 self._ahead = None
             self._adam_dirty = self._tiled is not None and self._tiled_ready     # (a suppressed flush left rows behind)

@@ -132,6 +132,21 @@ def test_a_backend_that_refuses_empty_slots_gets_the_split_form():
     assert out.stderr.count("all-to-all probe over 3 ranks") == 1 and "'remote': False" in out.stderr and "'form': 'split'" in out.stderr
 
 
+def test_a_forced_form_is_the_only_one_the_probe_enters():
+    """with SCORE_A2A=split / bench.py --a2a split the set-up probe runs all_to_all_single ONLY -- a list-form
+    all_to_all that hangs or fails on one rank cannot take such a job down at set-up.  Here the list form raises whenever it is
+    entered ("refuse") and the spy counts its calls: none, on any rank, and the run's results are the same."""
+    import json
+    import subprocess
+    out = subprocess.run([sys.executable, os.path.join(HERE, "threaded_pg_worker.py"), "3", "refuse_force_split"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    j = json.loads(out.stdout.strip().splitlines()[-1])
+    assert j["ok"] and j["loss_rel_err"] < 1e-5 and j["table_max_err"] < 2e-6 and j["dense_identical_across_ranks"]
+    assert j["list_form"] == [False] * 3 and j["list_collectives_per_rank"] == [0, 0, 0]
+    assert "'forced': 'split'" in out.stderr and "'remote'" not in out.stderr
+
+
 # ---- an id outside the table on ONE rank: rejected on EVERY rank before the step starts (score.py:51-66) -------------
 def _badid_worker(rank, world, port, out_dir):
     sys.path.insert(0, ROOT)

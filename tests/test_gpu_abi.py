@@ -113,9 +113,8 @@ def test_stream_copy_helper_copies_exactly():
     assert lib.score_stream_copy(None, C.c_void_p(src.data_ptr()), 8, st) == -1
 
 
-def test_step_and_async_entry_points_reject_missing_arguments():
-    """score_train_step / score_async_*: null structs, a struct without its events or streams -> SCORE_E_BADARG before anything is
-    queued; score_async_wait(0) with nothing submitted returns at once"""
+def test_step_entry_point_rejects_missing_arguments():
+    """score_train_step: null structs, a struct without its events or streams -> SCORE_E_BADARG before anything is queued"""
     import ctypes as C
     from score_amd import _lib
     lib = _lib.load()
@@ -123,10 +122,3 @@ def test_step_and_async_entry_points_reject_missing_arguments():
     assert lib.score_train_step(None, C.byref(st), C.byref(bt), C.byref(p), None) == -1
     assert lib.score_train_step(C.byref(cfg), C.byref(st), C.byref(bt), None, None) == -1
     assert lib.score_train_step(C.byref(cfg), C.byref(st), C.byref(bt), C.byref(p), None) == -1      # (no table, no events)
-    tk = C.c_uint64(0)
-    assert lib.score_async_index_plan(None, C.byref(st), C.byref(bt), 1, 0, None, None, 0, None, C.byref(tk)) == -1
-    assert lib.score_async_index_plan(C.byref(cfg), C.byref(st), C.byref(bt), 1, 0, None, None, 4, None, C.byref(tk)) == -1
-    assert lib.score_async_adam_catchup_rows(None, 0, 1, 1, None, None, 0, None, C.byref(tk)) == -1
-    assert lib.score_async_wait(C.c_uint64(0)) == 0
-    n = C.c_int32(-1)
-    assert lib.score_context_sync_errors(None, C.byref(n)) == 0 and n.value == 0

@@ -433,14 +433,14 @@ def test_side_stream_finishers_and_loss_do_not_change_a_bit():
     assert same_state(off, on)
 
 
-@pytest.mark.parametrize("mode", ["persample", "persample_worker", "layered", "finishers", "slice_f1", "slice_plan", "sweep", "wide",
+@pytest.mark.parametrize("mode", ["persample", "layered", "finishers", "slice_f1", "slice_plan", "sweep", "wide",
                                   "wide_finishers"])
 def test_everything_inline_on_the_launch_stream_equals_every_overlap_mode(mode):
     """debug_flags bit 12 (4096, score_hip.h): NO second stream anywhere -- the engine's forks, the index plan (and the one
     sorted a step ahead), the window slice, the look-ahead catch-up, the dense ApplyAdam and the early loss copy all run on
     the launch stream in launch order.  Every overlap mode only MOVES launches: losses, predictions and the whole optimizer
     state equal the inline run's bit for bit, hints right or wrong, with evaluations and table reads in between."""
-    H = 32 if mode in ("persample", "persample_worker", "layered") else 16
+    H = 32 if mode in ("persample", "layered") else 16
     cfg = so.Cfg(3000, 16, H, 5, 3, 2, 3, "SCORE")
     if mode.startswith("wide"):          # a third shape: D = 64 / H = 128 (the bf16x3 products and register-resident recurrences of cfg-3)
         cfg = so.Cfg(5000, 64, 128, 5, 3, 3, 4, "SCORE")
@@ -456,9 +456,7 @@ def test_everything_inline_on_the_launch_stream_equals_every_overlap_mode(mode):
         if mode == "slice_plan":
             m.adam_sweep_at = "plan"
     b.debug_flags |= 4096
-    if mode == "persample_worker":      # the side-stream launches of the step made by the library's worker thread (csrc/async.hip)
-        a.launch_worker = True
-    ps = mode in ("persample", "persample_worker")
+    ps = mode == "persample"
     assert a.persample_form(8, 5) == ps and b.persample_form(8, 5) == ps
     bs = batches(cfg, 16, 8, seed=33, hot_rows=150)
     da, db_ = [a.device_batch(x) for x in bs[:6]], [b.device_batch(x) for x in bs[:6]]

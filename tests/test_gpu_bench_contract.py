@@ -44,6 +44,13 @@ def test_default_line_carries_the_contract():
     assert ing["device_assembly_samples_per_s"] > 0 and ing["nested_python_lists_samples_per_s"] > 0
     assert j["cpu_baseline_literal_tile"]["value"] > 0 and "materialised" in j["cpu_baseline_literal_tile"]["sample"]
     assert set(j["stages_ms"]) >= {"fwd_gather_coattn", "bwd_coattn_scatter", "adam_table_and_dense"}
+    # the small shapes ride in the default line, as its LAST key (the driver keeps the line's last 2,000 characters)
+    assert list(j)[-1] == "small_shapes"
+    for c in ("cfg2", "tmall_default"):
+        leg = j["small_shapes"][c]
+        assert set(leg) >= {"samples_per_s", "ms_per_step", "ms_p50", "host_us_per_step", "launches_per_step", "B", "steps", "warmup", "form"}, leg
+        assert leg["samples_per_s"] > 0 and leg["form"] == "per-sample" and abs(leg["samples_per_s"] - leg["B"] / (leg["ms_per_step"] * 1e-3)) < 1e-3 * leg["samples_per_s"]
+    assert len(json.dumps(j["small_shapes"])) < 1500
 
 
 def test_cfg3_line_carries_the_panel_gemm_block():

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from oracle import score_oracle as so
-from helpers import batch_tuple, random_batch
+from helpers import away_from_relu_kinks, batch_tuple, random_batch
 from test_gpu_model import make_model, close, LOGIT_TOL
 
 pytestmark = pytest.mark.gpu
@@ -19,13 +19,13 @@ SHAPES = [(3000, 16, 32, 11, 10, 3, 4, 200, 9), (3000, 16, 32, 8, 10, 1, 2, 100,
           (800, 4, 32, 3, 2, 3, 4, 3, 3)]
 
 
-# Batch seeds whose oracle forward pass keeps every relu pre-activation (co-attention, dense_3 / dense_4, fc1 / fc2: 10^5 units
-# and more per batch) at least 1e-5 away from the kink (found with oracle.forward's "relu_margin").  A relu network's
-# gradient is discontinuous there: two correct fp32 passes whose pre-activation of ONE unit differs in the last bit differ
-# by that unit's whole gradient (seen at seed 17: one fc1 unit of one sample, 3 % of the largest table-row gradient).
-SEEDS = {("SCORE", 0): 51, ("SCORE", 1): 36, ("SCORE", 2): 22, ("SCORE", 3): 65, ("SCORE", 4): 17, ("SCORE", 5): 31,
-         ("SCORE", 6): 17, ("SCORE_USER", 1): 29, ("SCORE_USER", 2): 37, ("SCORE_USER", 4): 19, ("SCORE_USER", 6): 17,
-         ("SCORE_ITEM", 1): 19, ("SCORE_ITEM", 2): 37, ("SCORE_ITEM", 4): 19, ("SCORE_ITEM", 6): 18}
+# Arbitrary batch seeds (until round 5 this test ran on hand-picked seeds whose oracle forward pass kept every
+# relu pre-activation -- co-attention, dense_3 / dense_4, fc1 / fc2: 10^5 units and more per batch -- at least 1e-5 away from the
+# kink).  A relu network's gradient is discontinuous there: two correct fp32 passes whose pre-activation of ONE unit differs in
+# the last bit differ by that unit's whole gradient (seen at seed 17 of one shape: one fc1 unit of one sample, 3 % of the largest
+# table-row gradient).  helpers.away_from_relu_kinks drops the SAMPLES that own such a unit (every unit belongs to one sample,
+# nothing crosses the batch) and the rest of the batch is compared -- on any seed.
+ARBITRARY_SEEDS = (17, 101, 2024, 7, 555)
 
 
 def _batch(cfg, B, maxlen, seed):
@@ -47,15 +47,12 @@ def _run(m, b, flags, lam=1e-4, keep=1.0, masks=None):
     return out
 
 
-@pytest.mark.parametrize("shape", SHAPES)
-@pytest.mark.parametrize("mt", ["SCORE", "SCORE_USER", "SCORE_ITEM"])
-def test_forms_agree_and_match_the_oracle(shape, mt):
+def _forms_and_oracle(shape, mt, seed, adam_steps=2):
     N, D, H, T, K, Fu, Fi, B, maxlen = shape
-    if mt != "SCORE" and B > 100:
-        pytest.skip("the ablations' head wiring is covered at the smaller batches")
     cfg = so.Cfg(N, D, H, T, K, Fu, Fi, mt)
     P = so.init_params(cfg, 5)
-    b = _batch(cfg, B, maxlen, SEEDS[(mt, SHAPES.index(shape))])
+    b_all = _batch(cfg, B, maxlen, seed)
+    b, _, keep = away_from_relu_kinks(cfg, P, b_all)
     m = make_model(cfg, P)
     ref = _run(m, b, 512)
     for flags in (0, 1024, 2048):
@@ -67,23 +64,41 @@ def test_forms_agree_and_match_the_oracle(shape, mt):
             assert ok, (flags, e[0], err)
         ok, err = close(got[3].cpu().numpy(), ref[3].cpu().numpy(), rtol=3e-5, atol=3e-8)
         assert ok, (flags, "emb_mtx", err)
-    # ... and the fused form against the oracle: gradients, then two TF-Adam steps and the predictions
+    # ... and the fused form against the oracle: gradients, then TF-Adam steps and the predictions
     m.forward_backward(batch_tuple(b), 0.0, 1.0)
     g = m.get_grads()
     oo, go = so.loss_and_grads(cfg, P, b, 0.0)
-    assert oo["relu_margin"] > 1e-5, oo["relu_margin"]        # (the seed keeps the batch away from the relu kinks, see SEEDS)
+    assert oo["relu_margin"] >= 1e-5, oo["relu_margin"]        # (what away_from_relu_kinks left)
     for k in go:
         ok, err = close(g[k].reshape(np.asarray(go[k]).shape), go[k], rtol=2e-4, atol=2e-6)
-        assert ok, (k, err)
+        assert ok, (k, err, seed, len(keep))
     assert np.all(g["emb_mtx"][0] == 0)
+    if not adam_steps:
+        return
     om = so.OracleModel(cfg.N, cfg.D, cfg.H, cfg.T, cfg.K, cfg.Fu, cfg.Fi, mt, params={k: v.copy() for k, v in P.items()})
-    for _ in range(2):
+    for _ in range(adam_steps):
         lg = m.train(None, batch_tuple(b), 1e-3, 1e-4, keep_prob=1.0)
         lo = om.train(None, batch_tuple(b), 1e-3, 1e-4, keep_prob=1.0)
         assert abs(lg - lo) < 2e-5 * max(1.0, abs(lo))
-    pg, _, _ = m.eval(None, batch_tuple(b), 1e-4)
-    po, _, _ = om.eval(None, batch_tuple(b), 1e-4)
+    # (the predictions on the WHOLE batch: a forward pass is continuous at the kinks)
+    pg, _, _ = m.eval(None, batch_tuple(b_all), 1e-4)
+    po, _, _ = om.eval(None, batch_tuple(b_all), 1e-4)
     assert np.abs(np.asarray(pg) - np.asarray(po)).max() < LOGIT_TOL
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("mt", ["SCORE", "SCORE_USER", "SCORE_ITEM"])
+def test_forms_agree_and_match_the_oracle(shape, mt):
+    if mt != "SCORE" and shape[7] > 100:
+        pytest.skip("the ablations' head wiring is covered at the smaller batches")
+    _forms_and_oracle(shape, mt, 1000 + 37 * SHAPES.index(shape) + len(mt))
+
+
+@pytest.mark.parametrize("seed", ARBITRARY_SEEDS)
+def test_forms_match_the_oracle_on_arbitrary_seeds(seed):
+    """the reference's Tmall shape (B = 200: ~2 * 10^5 relu units per batch) and the odd-width shape, five seeds nobody chose"""
+    _forms_and_oracle(SHAPES[0], "SCORE", seed, adam_steps=0)
+    _forms_and_oracle(SHAPES[4], "SCORE", seed, adam_steps=1)
 
 
 def test_the_switch_switches_and_dropout_is_the_same_mask():
@@ -250,6 +265,5 @@ def test_six_hundred_one_call_steps_stay_bit_identical(two):
         if i % 100 == 99:
             assert same_state(a, b), i
     assert same_state(a, b)
-    assert a.sync_errors() == 0
     assert a._step_args is not None and b._step_args is None and a._tiled_on()       # (the one-call step did run, on the time-tiled optimizer)
     assert (a._plan_stream is not None) == bool(two)

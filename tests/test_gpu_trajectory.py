@@ -115,10 +115,14 @@ def test_two_virtual_ranks_follow_one_device_for_120_steps(pipeline):
     assert abs(roc_auc_score(labels, pg) - roc_auc_score(labels, pr)) < 5e-4
 
 
-def test_cfg2_exact_shape_one_step_vs_oracle():
+@pytest.mark.parametrize("seed", [7, 1, 2, 3, 4])
+def test_cfg2_exact_shape_one_step_vs_oracle(seed):
     """BASELINE.json configs[1] at its own shape and batch size (U = 100 K, I = 50 K, T = 10, K = 5, D = 16, H = 32, B = 256):
-    gradients, two TF-Adam steps and the predictions against the oracle (smoke() runs the shape at B = 64)"""
+    gradients, two TF-Adam steps and the predictions against the oracle (smoke() runs the shape at B = 64).  Arbitrary batches
+    (until round 5: the one batch whose relu pre-activations all kept 1e-5 from the kink): the first 256
+    samples of two loader batches that own no relu unit within 1e-5 of its kink (helpers.away_from_relu_kinks)"""
     from score_amd.synth import make_world
+    from helpers import away_from_relu_kinks
     from test_gpu_model import make_model, close, LOGIT_TOL
     world, kw = make_world("cfg2")
     B = kw.pop("batch")
@@ -126,8 +130,12 @@ def test_cfg2_exact_shape_one_step_vs_oracle():
     cfg = so.Cfg(kw["feature_size"], kw["eb_dim"], kw["hidden_size"], kw["max_time_len"], kw["obj_per_time_slice"],
                  kw["user_fnum"], kw["item_fnum"], "SCORE")
     P = so.init_params(cfg, 11)
-    b = dict(zip(NAMES, world.batch(B, 7)))        # (batch 7: every relu pre-activation of the pass >= 1e-5 from the kink, see
-    m = make_model(cfg, P)                          #  tests/test_gpu_persample.py SEEDS -- found with oracle.forward's "relu_margin")
+    pool = [dict(zip(NAMES, world.batch(B, s_))) for s_ in (seed, seed + 100)]
+    pool = {k: np.concatenate([np.asarray(p_[k]) for p_ in pool]) for k in NAMES}
+    b, _, keep = away_from_relu_kinks(cfg, P, pool)
+    assert keep.size >= B
+    b = {k: np.ascontiguousarray(v[:B]) for k, v in b.items()}
+    m = make_model(cfg, P)
     assert m.persample_form(B, 8)            # (the per-sample whole-model kernels: csrc/persample.h)
     m.forward_backward(batch_tuple(b), 0.0, 1.0)
     g = m.get_grads()
@@ -139,6 +147,9 @@ def test_cfg2_exact_shape_one_step_vs_oracle():
             a, o = a[rows], o[rows]
         ok, err = close(a, o, rtol=3e-4, atol=2e-6)
         assert ok, (k, err, oo["relu_margin"])
+    assert oo["relu_margin"] >= 1e-5
+    if seed != 7:
+        return                                     # (the optimizer steps and the AUC on one batch: the others add nothing to them)
     om = so.OracleModel(cfg.N, cfg.D, cfg.H, cfg.T, cfg.K, cfg.Fu, cfg.Fi, "SCORE", params={k: v.copy() for k, v in P.items()})
     for _ in range(2):
         lg = m.train(None, batch_tuple(b), 1e-3, 1e-4, keep_prob=1.0)

@@ -139,3 +139,25 @@ def test_tiled_torch_form_equals_collapsed_form_and_gradients():
     assert np.abs(oa["y_pred"].detach().numpy() - ob["y_pred"].detach().numpy()).max() < 1e-12
     for k in ga:
         assert np.abs(ga[k] - gb[k]).max() < 1e-10, k
+
+
+def test_relu_margin_per_sample_and_dropping_samples():
+    """oracle.forward's relu_margin_per_sample: its minimum is relu_margin, a sample's value does not depend on the rest of the
+    batch (nothing crosses the batch), and helpers.away_from_relu_kinks leaves a batch whose margin is at least the threshold --
+    what lets the GPU parity tests run on arbitrary seeds."""
+    import torch
+    from helpers import away_from_relu_kinks, random_batch
+    cfg = so.Cfg(300, 8, 32, 5, 4, 3, 4, "SCORE")
+    P = so.init_params(cfg, 4)
+    b = random_batch(np.random.default_rng(3), cfg, 64)
+    with torch.no_grad():
+        out = so.forward(cfg, so.to_torch_params(P), so.to_torch_batch(b))
+    per = np.asarray(out["relu_margin_per_sample"])
+    assert per.shape == (64,) and abs(per.min() - out["relu_margin"]) < 1e-12
+    thr = 0.5 * float(np.sort(per)[4] + np.sort(per)[5])       # a threshold that drops exactly the five closest samples
+    bb, _, keep = away_from_relu_kinks(cfg, P, b, thr=thr)
+    assert keep.size == 59 and np.array_equal(keep, np.nonzero(per >= thr)[0])
+    with torch.no_grad():
+        out2 = so.forward(cfg, so.to_torch_params(P), so.to_torch_batch(bb))
+    assert out2["relu_margin"] >= thr
+    np.testing.assert_allclose(np.asarray(out2["relu_margin_per_sample"]), per[keep], rtol=1e-5, atol=1e-9)

@@ -21,7 +21,7 @@ sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, HERE)
 
 
-def main(world=3, refuse=False):
+def main(world=3, refuse=False, force=None):
     import torch.testing._internal.distributed.multi_threaded_pg as mt
     torch._C._distributed_c10d._set_thread_isolation_mode(True)
     mt._install_threaded_pg()
@@ -29,6 +29,8 @@ def main(world=3, refuse=False):
     from score_amd.dist import ShardedSCORE, TorchDistComm
     from cpu_backend import CpuBackend
     from helpers import random_batch, batch_tuple, NAMES
+    if force:
+        os.environ["SCORE_A2A"] = force           # (what bench.py --a2a sets: only that form may ever be entered)
     cfg_args = (203, 4, 8, 3, 3, 3, 4)            # odd N: the last shards are padded
     cfg = so.Cfg(*cfg_args, model_type="SCORE")
     params = so.init_params(cfg, 5)
@@ -94,4 +96,6 @@ def main(world=3, refuse=False):
 
 
 if __name__ == "__main__":
-    sys.exit(main(int(sys.argv[1]) if len(sys.argv) > 1 else 3, refuse=len(sys.argv) > 2 and sys.argv[2] == "refuse"))
+    mode = sys.argv[2] if len(sys.argv) > 2 else ""
+    sys.exit(main(int(sys.argv[1]) if len(sys.argv) > 1 else 3, refuse=mode in ("refuse", "refuse_force_split"),
+                  force="split" if mode.endswith("force_split") else None))
