@@ -444,9 +444,7 @@ typedef struct {
                            workspace of the same layout, where score_index_plan wrote it -- instead of in `workspace`: a caller
                            that alternates two buffers for the plans can sort the next batch's plan while this step's scatter
                            still reads its own (everything else of the step stays in `workspace`).  NULL: in `workspace`.       */
-  int32_t images_ready;   /* score_forward, per-sample form: non-zero = the weight images, the L2 partial sums and the zeroed
-                           workgroup count in `workspace` are those of the CURRENT st->w already (score_persample_prep ran on
-                           them and nothing has written st->w since): the pass does not rebuild them.  0: it does, first thing. */
+  int32_t reserved4;
   int32_t reserved3;
 } score_state_t;
 
@@ -576,28 +574,11 @@ typedef struct {
                              this event recorded behind it -- the sort runs beside this step's passes.  NULL: one workspace, the
                              plan behind this step's scatter, ev_plan re-recorded (the sequence above).                         */
   void* const* fwd_stage_events;   /* optional: score_forward's stage_events (five hipEvent_t or NULL each) -- a caller timing the pass */
-  void* dense_stream;     /* optional (with ev_prep): the context's side stream (score_context_stream).  Given: the step ends
-                             differently -- score_adam_touched alone on `stream`, with NO wait for the dense gradient's finishers,
-                             and on dense_stream behind them: wait(ev_b4) (the scatter reads the co-attention weights), score_adam
-                             on the dense variables, score_persample_prep for the next call if prep_next, record(ev_prep).  The
-                             next call waits for ev_prep (wait_prep) and passes images_ready.  The launch stream's chain loses
-                             the dense update, the weight images and a launch boundary.                                        */
-  void* ev_prep; int32_t wait_prep, prep_next;
   void* plan_stream;      /* optional: a third stream for that early plan (it waits for ev_b4's previous record first); NULL: the
                              side stream -- the look-ahead catch-up then queues behind the sort.                                */
 } score_train_step_t;
 int score_train_step(const score_config_t* cfg, const score_state_t* st, const score_batch_t* batch, const score_train_step_t* p,
                      void* stream);
-
-/* What the per-sample forward pass derives from the dense variables alone -- the weight images, the 256 partial sums of the L2
- * norm, the zeroed count of finished workgroups -- for a batch of B samples with `active_slices` computed slices, into
- * st->workspace on `stream`: score_forward's first launch at these shapes, callable on its own so that it can run right behind
- * the dense variables' ApplyAdam of the previous step, off the launch stream (score_state_t.images_ready then skips it in
- * score_forward).  SCORE_E_SHAPE if the batch would not take the per-sample form (score_persample_form). */
-int score_persample_prep(const score_config_t* cfg, const score_state_t* st, int32_t B, int32_t active_slices, void* stream);
-/* The side stream of a context (ctx NULL: the current device's default context): for a caller that queues work of its own behind
- * what score_backward left there (the dense gradient's finishers with score_state_t.grads_done_event). */
-int score_context_stream(score_context_t ctx, void** stream);
 
 /* sizeof of every struct above in the header's order (score_step_scalars_t, score_config_t, score_param_entry_t, score_batch_t,
  * score_workspace_t, score_guard_t, score_adam_table_t, score_state_t, score_train_step_t, score_graph_t, score_batch_out_t), then

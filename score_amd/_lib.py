@@ -47,7 +47,7 @@ class State(C.Structure):
                 ("gather_done_event", C.c_void_p), ("plan_done_event", C.c_void_p), ("step_scalars", C.c_void_p),
                 ("context", C.c_void_p), ("id_status", C.c_void_p), ("grads_done_event", C.c_void_p),
                 ("loss_done_event", C.c_void_p), ("loss_host", C.c_void_p), ("plan_workspace", C.c_void_p),
-                ("images_ready", C.c_int32), ("reserved3", C.c_int32)]
+                ("reserved4", C.c_int32), ("reserved3", C.c_int32)]
 
 
 class Graph(C.Structure):
@@ -80,8 +80,7 @@ class TrainStep(C.Structure):
                 ("next_workspace", C.c_void_p), ("next_workspace_bytes", C.c_int64), ("loss_host", C.c_void_p),
                 ("side_stream", C.c_void_p), ("ev_ahead", C.c_void_p), ("ev_sweep", C.c_void_p), ("ev_plan", C.c_void_p),
                 ("ev_stage2", C.c_void_p), ("ev_b4", C.c_void_p), ("ev_grads", C.c_void_p), ("ev_loss", C.c_void_p),
-                ("ev_plan_next", C.c_void_p), ("fwd_stage_events", C.c_void_p), ("dense_stream", C.c_void_p),
-                ("ev_prep", C.c_void_p), ("wait_prep", C.c_int32), ("prep_next", C.c_int32), ("plan_stream", C.c_void_p)]
+                ("ev_plan_next", C.c_void_p), ("fwd_stage_events", C.c_void_p), ("plan_stream", C.c_void_p)]
 
 
 class Guard(C.Structure):
@@ -153,8 +152,6 @@ _SIGS = {
     "score_ranking_quality": [c_f, c_i, C.c_int64, C.c_int32, c_f, c_i, c_f, C.c_int64, C.c_void_p],
     "score_persample_form": [C.POINTER(Config), C.POINTER(State), C.c_int32, C.c_int32],
     "score_abi_struct_sizes": [C.POINTER(C.c_int64), C.c_int32],
-    "score_persample_prep": [C.POINTER(Config), C.POINTER(State), C.c_int32, C.c_int32, C.c_void_p],
-    "score_context_stream": [C.c_void_p, C.POINTER(C.c_void_p)],
     "score_train_step": [C.POINTER(Config), C.POINTER(State), C.POINTER(Batch), C.POINTER(TrainStep), C.c_void_p],
     "score_gemm_forms": [C.POINTER(Config), C.POINTER(State), C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)],
     "score_forward": [C.POINTER(Config), C.POINTER(State), C.POINTER(Batch), C.c_float, C.c_float, C.c_void_p,

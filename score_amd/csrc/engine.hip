@@ -418,17 +418,6 @@ extern "C" int score_context_destroy(void* ctx) {
   return 0;
 }
 
-extern "C" int score_context_stream(void* ctx, void** stream) {
-  if (!stream) return SCORE_E_BADARG;
-  score_state_t st;
-  memset(&st, 0, sizeof(st));
-  st.context = ctx;
-  SideStream* sd = nullptr;
-  SCORE_TRY(side_stream(&st, &sd));
-  *stream = (void*)sd->st;
-  return 0;
-}
-
 extern "C" int score_id_status(int32_t* id_status, int32_t* bits, int32_t clear, void* stream) {
   if (!id_status) return SCORE_E_BADARG;
   hipStream_t s = (hipStream_t)stream;
@@ -643,7 +632,7 @@ int forward_ps(const Dims& d, const Params& P, const WS& w, const PsPlan& pp, co
                void* const* stage_events, hipStream_t s) {
   float* ws = st->workspace;
   const int B = bt->B;
-  if (!st->images_ready) G(ps_prep(d, P, w, pp, st, nullptr, 0, s));      // (else score_persample_prep ran behind the last ApplyAdam)
+  G(ps_prep(d, P, w, pp, st, nullptr, 0, s));
   if (st->debug_flags & 1024) {      // (the layer-by-layer backward pass that follows reads the concatenated / folded copies)
     const float* W = st->w;
     const int64_t weff_stride = align_up64(2 * (int64_t)d.Dk * AT1 + 48, 4);
@@ -845,23 +834,6 @@ extern "C" int score_persample_form(const score_config_t* cfg, const score_state
   bt.B = B; bt.active_slices = active_slices;
   PsPlan pp;
   return ps_path(d, st, &bt, active_T(d, &bt), &pp) ? 1 : 0;
-}
-
-extern "C" int score_persample_prep(const score_config_t* cfg, const score_state_t* st, int32_t B, int32_t active_slices, void* stream) {
-  Dims d;
-  SCORE_TRY(make_dims(cfg, &d));
-  if (!st || !st->w || !st->workspace || B <= 0 || active_slices < 0) return SCORE_E_BADARG;
-  Params P;
-  build_layout(d, nullptr, 0, &P);
-  WS w;
-  build_ws(d, B, &w);
-  if (w.total * 4 > st->workspace_bytes) return SCORE_E_WORKSPACE;
-  score_batch_t bt;
-  memset(&bt, 0, sizeof(bt));
-  bt.B = B; bt.active_slices = active_slices;
-  PsPlan pp;
-  if ((st->debug_flags & 2048) || !ps_path(d, st, &bt, active_T(d, &bt), &pp)) return SCORE_E_SHAPE;
-  return ps_prep(d, P, w, pp, st, nullptr, 0, (hipStream_t)stream);
 }
 
 extern "C" int score_forward(const score_config_t* cfg, const score_state_t* st, const score_batch_t* bt,
@@ -1360,6 +1332,14 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
   ReduceGroup rg;
   rg.n = rg.blocks = 0;
   const bool products_early = side != nullptr && st->scatter_mode != 2 && !(st->debug_flags & 16384) && gq.n > 0;
+  // ... and with them the finishers of the dense gradient (slab reduce, column sums), when the caller takes them on the side stream
+  // (score_state_t.grads_done_event): forked behind target_bwd_kernel, the last launch that feeds them, instead of behind the row
+  // scatter -- they ran beside the table's touched-row update, 58 + 28 us there against 20 + 12 alone, with the dense ApplyAdam and
+  // through it the next forward pass waiting for them
+  const bool fin_side = st->grads_done_event != nullptr && side != nullptr;
+  const bool fin_early = products_early && fin_side;
+  // (the fork HERE, behind the input-gradient product, and not one launch later beside the waits in front of target_bwd_kernel,
+  //  where it would cost the launch stream no packet of its own: 872 k vs 884 k samples/s, profiles/r06_probes.md)
   if (products_early) {
     HIPTRY(hipEventRecord(side->fork, s));
     HIPTRY(hipStreamWaitEvent(side->st, side->fork, 0));
@@ -1402,6 +1382,13 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
                             d.coattn ? gw + P.ca_b[0] : nullptr, d.coattn ? gw + P.ca_w[1] : nullptr,
                             d.coattn ? gw + P.ca_b[1] : nullptr, atomic ? nullptr : ws + w.dtgt, scratch, SF, &cq, &gq,
                             s, st->n_table_rows));
+  if (fin_early) {
+    HIPTRY(hipEventRecord(side->fork, s));
+    HIPTRY(hipStreamWaitEvent(side->st, side->fork, 0));
+    G(score_launch_finish(&rg, &cq, ws + w.cs_part + w.cs_part_floats / 2, w.cs_part_floats - w.cs_part_floats / 2, side->st, 0));
+    HIPTRY(hipEventRecord((hipEvent_t)st->grads_done_event, side->st));
+    HIPTRY(hipEventRecord(side->join, side->st));      // (what the launch stream waits for behind the scatter, below)
+  }
   if (!atomic) {
     PullArgs pa;
     memset(&pa, 0, sizeof(pa));
@@ -1433,10 +1420,10 @@ extern "C" int score_backward(const score_config_t* cfg, const score_state_t* st
   // score_state_t.grads_done_event gets them on the side stream (idle by now: the launch stream has just waited for its join)
   // behind the products, and the event recorded behind them: it may run the table's touched-row update, which needs the row
   // gradients only, on the launch stream meanwhile, and waits for the event before anything reads grad_w.
-  const bool fin_side = st->grads_done_event != nullptr && side != nullptr;
   hipStream_t fs = fin_side ? side->st : s;
   if (!products_early) G(gemm_queue_flush(&gq, x3 != 0, ws + w.dwslab + slab_used, w.dwslab_floats - slab_used, s, &rg));
   EV(5);
+  if (fin_early) return 0;
   if (fin_side) {
     HIPTRY(hipEventRecord(side->fork, s));
     HIPTRY(hipStreamWaitEvent(fs, side->fork, 0));

@@ -48,9 +48,6 @@ extern "C" int score_train_step(const score_config_t* cfg, const score_state_t* 
   //     rows, the window slice
   if (p->wait_ahead) HIPTRY_(hipStreamWaitEvent(s, (hipEvent_t)p->ev_ahead, 0));
   if (p->wait_sweep) HIPTRY_(hipStreamWaitEvent(s, (hipEvent_t)p->ev_sweep, 0));
-  // (the previous call's dense ApplyAdam + weight images on the context's side stream: score_train_step_t.dense_stream)
-  if (p->wait_prep && p->ev_prep) HIPTRY_(hipStreamWaitEvent(s, (hipEvent_t)p->ev_prep, 0));
-  st.images_ready = (p->wait_prep && p->ev_prep) ? 1 : 0;
   // (2) forward (ev_loss: only somebody who reads the loss from the host needs an event behind the forward kernel)
   st.gather_done_event = nullptr;
   st.loss_done_event = p->loss_host ? p->ev_loss : nullptr;
@@ -66,19 +63,7 @@ extern "C" int score_train_step(const score_config_t* cfg, const score_state_t* 
   SCORE_TRY(score_backward(cfg, &st, batch, p->keep_prob, p->w_g, const_cast<float*>(p->table->g), ev, stream));
   // (4) the step's ApplyAdam: rows with a gradient and the dense variables in one launch, behind the finishers -- queued BEFORE the
   //     side stream's work: the next forward pass waits for this launch (through the weight images) longer than for the look-ahead
-  if (p->dense_stream && p->ev_prep) {
-    // rows with a gradient on the launch stream, NOT behind the finishers; the dense variables behind them on the context's side
-    // stream -- and behind the scatter, which reads the co-attention weights (ev_b4) -- then the next call's weight images
-    SCORE_TRY(score_adam_touched(p->table, p->step, p->alpha, stream));
-    hipStream_t ds = (hipStream_t)p->dense_stream;
-    HIPTRY_(hipStreamWaitEvent(ds, (hipEvent_t)p->ev_b4, 0));
-    score_guard_t guard;
-    guard.id_status = p->table->id_status; guard.skipped = p->skipped;
-    SCORE_TRY(score_adam(p->w, p->w_m, p->w_v, p->w_g, p->n_w, p->n_reg, p->reg_lambda, p->alpha, p->table->beta1, p->table->beta2,
-                         p->table->eps, guard.id_status ? &guard : nullptr, p->dense_stream));
-    if (p->prep_next) SCORE_TRY(score_persample_prep(cfg, st_in, batch->B, batch->active_slices, p->dense_stream));
-    HIPTRY_(hipEventRecord((hipEvent_t)p->ev_prep, ds));
-  } else {
+  {
     HIPTRY_(hipStreamWaitEvent(s, (hipEvent_t)p->ev_grads, 0));
     SCORE_TRY(score_adam_touched_and_dense(p->table, p->step, p->alpha, p->w, p->w_m, p->w_v, p->w_g, p->n_w, p->n_reg, p->reg_lambda,
                                            p->skipped, stream));

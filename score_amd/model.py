@@ -238,16 +238,7 @@ class SCOREBASE(object):
         self._two_tune = None
         self._plan_events = [None, None]
         self._plan_stream = None
-        # the one-call step can end with the dense variables' ApplyAdam and the NEXT step's weight images on the engine's side stream
-        # (behind the finishers and the scatter) instead of on the launch stream: score_train_step_t.dense_stream.  OFF: the launch
-        # stream's chain loses ~15 us, the host gains a launch and three event calls, and the step is bound by the host here: Tmall
-        # default 0.1971 vs 0.1943 ms, Taobao default 0.1946 vs 0.1947 (one box, 2,000 steps).  (Behind the SCATTER: pull_kernel reads
-        # the co-attention weights.  The dense update on a side stream behind the finishers alone races with it -- which is what the
-        # ulp drift of two identical models was, earlier this round, when that update ran on the model's side stream.)
-        self.dense_and_images_on_side = False
-        self._images_ready = None       # (workspace, step): score_persample_prep ran for it behind the last ApplyAdam
-        self._ctx_stream = None
-        self._ev_prep = None
+        self._fin_early = False
         self.fast_step = True           # train / train_async: the steady-state step of the per-sample form as one library call (_train_step_fast)
         self._step_args = self._step_T = self._step_side = None
         self._pb_cache = {}
@@ -293,10 +284,14 @@ class SCOREBASE(object):
         # (threads: the walk is one cache miss per boxed int, so it scales with cores until the memory system is busy --
         #  cfg-3 batch on the GPU box's host: 8.9 ms with 1 thread, 2.5 with 4, 1.6 with 8, 1.35 with 16)
         # where the time-tiled optimizer's window slice starts: "2" (stage boundary 2 of the backward pass, beside the
-        # recurrence: the measured best), "1" / "3" / "4", "plan" (behind the occurrence sort), "f1" (behind the fused gather,
-        # on a stream of its own); the touched-row update from the plan's unique-row list instead of a state-byte scan
+        # recurrence), "1" / "3" / "4", "plan" (behind the occurrence sort), "f1" (behind the fused gather, on a stream of its
+        # own); "auto": "2" for the per-sample form (what its one-call step queues) and "plan" for the layer-by-layer pass --
+        # since round 6 moved the recurrences' weight-gradient products beside the scatter, the backward pass has no slack
+        # left for a 100-us HBM-bound scan beside its input-gradient product (cfg-3, one box, interleaved: plan 892 - 895 k
+        # samples/s, "2" 884 - 888 k, "1" 874 - 886 k, "3" 858 - 864 k, "4" 854 - 861 k, "f1" 850 k: profiles/r06_probes.md);
+        # the touched-row update from the plan's unique-row list instead of a state-byte scan
         # (measured +8 us net: off).  Both change WHERE work runs, never a result (tests/test_gpu_adam_tiled.py)
-        self.adam_sweep_at = "2"
+        self.adam_sweep_at = "auto"
         self.adam_touched_list = False
         self.feed_threads = int(os.environ.get("SCORE_FEED_THREADS", str(max(1, min(16, _usable_cpus())))))
         self._stage, self._stage_lock = {}, threading.Lock()
@@ -406,7 +401,6 @@ class SCOREBASE(object):
     @property
     def w(self):
         self._join_dense()
-        self._images_ready = None        # (whoever holds the tensor may write it: the weight images of the one-call step go stale)
         return self._w
 
     @w.setter
@@ -667,7 +661,6 @@ class SCOREBASE(object):
         st.id_status = self._id_status.data_ptr()      # (a caller may have pointed the struct at a status word of its own: dist.py)
         st.gather_done_event = st.plan_done_event = st.grads_done_event = st.loss_done_event = st.loss_host = None
         st.plan_workspace = None
-        st.images_ready = 0
         return st
 
     def _event_array(self, events):
@@ -858,9 +851,10 @@ class SCOREBASE(object):
         # time-tiled optimizer: this step's slice of the table (rows nobody in the batch touches: any time between the
         # batch rows' catch-up and the touched-row update will do).  "f1": behind the fused gather, i.e. beside the forward
         # recurrence, which is matrix-bound and fills half the CUs; 1 .. 4: at that stage boundary of the backward pass
+        self._ps_last = self.persample_form(db.B, db.active_slices)
         sweep_at = str(self.adam_sweep_at)
         if sweep_at not in ("plan", "f1", "1", "2", "3", "4"):
-            sweep_at = "2"                  # (an unknown value must not leave the window slice unlaunched)
+            sweep_at = "2" if self._ps_last else "plan"      # ("auto"; an unknown value must not leave the window slice unlaunched)
         fwd_stage = None
         if sweep_at == "f1" and self._tiled_on():
             if self._ev_stage is None:
@@ -874,7 +868,6 @@ class SCOREBASE(object):
         # (only where the device, not the host's launch calls, bounds the step: tmall_default 0.330 -> 0.335 ms with it, cfg-3
         #  1.2811 -> 1.2762, four alternating pairs on one box)
         # (the per-sample kernels: always -- every launch taken off the chain is ~5 us there)
-        self._ps_last = self.persample_form(db.B, db.active_slices)
         side_ok = self._ps_last or db.B * (db.active_slices or int(self.cfg.max_time_len)) >= self.overlap_finishers_min_rows
         if self.loss_on_side and not self._graph_on and not self._use_dev_scalars and side_ok:
             if self._ev_loss is None:
@@ -987,6 +980,11 @@ class SCOREBASE(object):
                 self._ev_grads.record(cur)              # materialise the hipEvent_t
             st.grads_done_event = C.c_void_p(self._ev_grads.cuda_event)
             self._grads_pending = self._ev_grads
+            # (score_backward then forks the finishers in FRONT of the row scatter, csrc/engine.hip "fin_early": the dense variables'
+            #  update may not follow them on another stream any more -- the scatter reads the co-attention weights)
+            self._fin_early = not self._ps_last and not (int(self.debug_flags) & 16384)
+        else:
+            self._fin_early = False
         rc = self.lib.score_backward(C.byref(self.cfg), C.byref(st), C.byref(db.struct), float(keep_prob),
                                      _ptr(self._w_g), _ptr(self.table_g), self._event_array(events),
                                      self._stream())
@@ -1039,6 +1037,14 @@ class SCOREBASE(object):
                         if not self._adam_table_tiled(lr, dense=(reg_lambda,)):
                             self.adam_dense(lr, reg_lambda)
                         side_work()
+                        self.adam_advance()
+                        return
+                    if self._fin_early:
+                        # round 6: the finishers ran beside the scatter and are through by now -- the touched rows and the dense
+                        # variables in ONE launch on the launch stream, behind the scatter (no stream hop in front of the next pass)
+                        self._join_grads()
+                        if not self._adam_table_tiled(lr, dense=(reg_lambda,)):
+                            self.adam_dense(lr, reg_lambda)
                         self.adam_advance()
                         return
                     self._adam_table_tiled(lr)
@@ -1384,7 +1390,7 @@ class SCOREBASE(object):
         the one announced, stage events, an evaluation in between, ...): the caller then takes the call-by-call path, and the two
         can alternate step by step (tests/test_gpu_persample.py)."""
         if (not self.fast_step or self._graph_on or self._use_dev_scalars or self.scatter_mode != 0 or self.bwd_events
-                or self.catchup_events or int(self.debug_flags) or str(self.adam_sweep_at) != "2" or self.adam_touched_list
+                or self.catchup_events or int(self.debug_flags) or str(self.adam_sweep_at) not in ("2", "auto") or self.adam_touched_list
                 or self._tiled is None or not self._tiled_ready or not self._adam_dirty or self._flags_marked or self._row_grads
                 or self._pending_sweep is not None or self._side is None or not isinstance(db, DeviceBatch) or db.flat is None
                 or not self._look_ahead or not self._tiled_on()):
@@ -1406,15 +1412,9 @@ class SCOREBASE(object):
         cur = self._cur()
         if self._inline_on or (self._train_stream is not None and self._train_stream.cuda_stream != cur.cuda_stream):
             return None
-        # the previous one-call step left the dense ApplyAdam + this step's weight images on the engine's side stream: waited for
-        # inside the call (wait_prep) instead of here
-        imr = self._images_ready
-        wait_prep = (imr is not None and imr == (ws.data_ptr(), int(self.step)) and self._dense_pending is not None
-                     and self._dense_pending is self._ev_prep)
-        if not wait_prep:
-            self._join_dense()
+        self._join_dense()
         self._join_grads()
-        st = self._state(ws, joined=not wait_prep)
+        st = self._state(ws)
         st.plan_workspace = pr[2] if slot == 1 else None
         row_step, ring, T = self._tiled
         p = self._step_args
@@ -1437,20 +1437,6 @@ class SCOREBASE(object):
             p.ev_b4 = self._ensure_ev("_ev_b4").cuda_event
             p.ev_grads = self._ensure_ev("_ev_grads").cuda_event
             p.ev_loss = self._ensure_ev("_ev_loss").cuda_event
-        side_dense = bool(self.dense_and_images_on_side)
-        if side_dense:
-            if self._ctx_stream is None:
-                h = C.c_void_p(0)
-                _lib.check(self.lib.score_context_stream(self._ctx, C.byref(h)), "score_context_stream")
-                self._ctx_stream = h.value
-            p.dense_stream = self._ctx_stream
-            p.ev_prep = self._ensure_ev("_ev_prep").cuda_event
-            p.prep_next = 1 if (nxt is not None and nxt.B == db.B and nxt.active_slices == db.active_slices) else 0
-        else:
-            p.dense_stream = None
-            p.ev_prep = self._ev_prep.cuda_event if self._ev_prep is not None else None
-            p.prep_next = 0
-        p.wait_prep = 1 if wait_prep else 0
         fe = self._event_array(self.fwd_events) if self.fwd_events else None      # (a caller timing the forward pass: bench.py's roofline)
         p.fwd_stage_events = C.cast(fe, C.c_void_p) if fe is not None else None
         # (the previous step's window slice: waited for only if it ran somewhere else than in front of the look-ahead catch-up of
@@ -1513,16 +1499,7 @@ class SCOREBASE(object):
         self._row_grads = self._flags_marked = False
         self._adam_dirty = True
         self._row_list = None
-        if side_dense:
-            # (the dense variables are being updated on the engine's side stream: whoever touches them next waits -- self.w)
-            self._grads_pending = None
-            self._dense_pending = self._ev_prep
-            self._images_ready = (ws.data_ptr(), int(self.step) + 1) if p.prep_next else None
-        else:
-            self._grads_pending = None
-            self._images_ready = None
-            if wait_prep:
-                self._dense_pending = None
+        self._grads_pending = None
         if nxt is not None:
             self._ahead = (nxt, ah[1], 0)
             self._plan_ready = (nxt, ev_plan_next if ev_plan_next is not None else pr[1], ws2.data_ptr(), nxt.active_slices, 0)

@@ -349,7 +349,7 @@ def test_row_list_and_state_scan_forms_of_the_touched_update_agree():
     assert same_state(a, b)
 
 
-@pytest.mark.parametrize("where", ["f1", "plan", "4"])
+@pytest.mark.parametrize("where", ["f1", "plan", "4", "2"])
 def test_window_slice_placement_does_not_change_the_tables(where):
     """model.adam_sweep_at: the step's window slice beside the forward recurrence on its own stream (f1), behind the
     occurrence sort (plan) or at the last stage boundary of the backward pass (4) instead of boundary 2 -- rows nobody in the
@@ -433,7 +433,7 @@ def test_side_stream_finishers_and_loss_do_not_change_a_bit():
     assert same_state(off, on)
 
 
-@pytest.mark.parametrize("mode", ["persample", "layered", "finishers", "slice_f1", "slice_plan", "sweep", "wide",
+@pytest.mark.parametrize("mode", ["persample", "layered", "finishers", "slice_f1", "slice_plan", "slice_2", "sweep", "wide",
                                   "wide_finishers"])
 def test_everything_inline_on_the_launch_stream_equals_every_overlap_mode(mode):
     """debug_flags bit 12 (4096, score_hip.h): NO second stream anywhere -- the engine's forks, the index plan (and the one
@@ -455,6 +455,8 @@ def test_everything_inline_on_the_launch_stream_equals_every_overlap_mode(mode):
             m.adam_sweep_at = "f1"
         if mode == "slice_plan":
             m.adam_sweep_at = "plan"
+        if mode == "slice_2":             # (the per-sample form's placement, here on the layer-by-layer pass: "auto" gives that one "plan")
+            m.adam_sweep_at = "2"
     b.debug_flags |= 4096
     ps = mode == "persample"
     assert a.persample_form(8, 5) == ps and b.persample_form(8, 5) == ps

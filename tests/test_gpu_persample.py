@@ -202,38 +202,6 @@ def test_one_call_step_equals_the_call_by_call_step(two):
     a.lib = a_lib
 
 
-def test_dense_update_and_next_images_on_the_engines_side_stream():
-    """score_train_step_t.dense_stream (model.dense_and_images_on_side): the one-call step with the dense variables' ApplyAdam and
-    the next step's weight images behind the finishers AND the scatter on the engine's side stream, the next call waiting for them
-    (images_ready) -- against the call-by-call step: the same bits, with a wrong hint, an evaluation, a weights read and a
-    set_params in between (each of which must invalidate the prepared images)"""
-    from test_gpu_adam_tiled import make, batches, same_state
-    cfg = so.Cfg(3000, 16, 32, 5, 3, 2, 3, "SCORE")
-    a, b = make(cfg, 5), make(cfg, 5)
-    b.fast_step = False
-    a.dense_and_images_on_side = True
-    bs = batches(cfg, 6, 8, seed=35, hot_rows=150)
-    da, db_ = [a.device_batch(x) for x in bs], [b.device_batch(x) for x in bs]
-    order = [0, 1, 2, 3, 4, 5, 0, 2, 4, 1, 3, 5, 5, 0, 1, 2, 3, 4, 0, 1, 2, 3, 4, 5]
-    used = 0
-    for i, bi in enumerate(order):
-        nxt = order[i + 1] if i + 1 < len(order) else 0
-        hint = (nxt + 1) % 6 if i == 6 else nxt
-        la = float(a.train_async(da[bi], 1e-2, 1e-4, keep_prob=0.8, next_batch=da[hint]))
-        lb = float(b.train_async(db_[bi], 1e-2, 1e-4, keep_prob=0.8, next_batch=db_[hint]))
-        assert la == lb, (i, la, lb)
-        used += a._images_ready is not None
-        if i == 9:
-            assert a.eval(None, da[4], 1e-4)[0] == b.eval(None, db_[4], 1e-4)[0]
-            assert a._images_ready is None
-        if i == 13:
-            assert torch.equal(a.w, b.w) and a._images_ready is None        # (reading the variables: the prepared images are dropped)
-        if i == 16:
-            P = a.get_params()
-            a.set_params(P); b.set_params(P)
-    assert same_state(a, b) and used >= 8
-
-
 @pytest.mark.parametrize("two", [True, False])
 def test_six_hundred_one_call_steps_stay_bit_identical(two):
     """a soak for the orderings the one-call step relies on -- the touched-row update beside the look-ahead and the window slice

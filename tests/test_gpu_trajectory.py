@@ -16,7 +16,7 @@ from test_gpu_cfg1 import pipeline, _loader      # noqa: F401  (module fixture: 
 
 pytestmark = pytest.mark.gpu
 
-STEPS, EVAL_EVERY, BATCH = 120, 30, 32
+STEPS, EVAL_EVERY, BATCH = 120, 60, 32      # (validation at steps 0, 60 and 120: each is 43 oracle passes of 100 candidates)
 
 
 def _sample_batches(pipeline):
