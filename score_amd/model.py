@@ -231,11 +231,9 @@ class SCOREBASE(object):
         self._sweep_on_side = False     # the pending window slice was queued on self._side (by the one-call step)
         # the one-call step may alternate two PLAN buffers so that the next batch's sort needs nothing of this step and runs beside
         # its passes instead of behind its scatter.  Whether that pays depends on which cycle bounds the step -- pull -> look-ahead ->
-        # sort -> pull (Taobao default: 0.2205 -> 0.1912 ms with two buffers) or the launch stream's own chain, which the early sort
-        # then slows (Tmall default 0.1929 -> 0.1996, CCMR 0.3466 -> 0.3566) -- so "auto" times 64 one-call steps each way on the
-        # device (two event pairs, read without blocking) and keeps the faster; True / False force one.
+        # sort -> pull or the launch stream's own chain, which the early sort then slows: "auto" decides by the number of
+        # occurrences per batch (_two_buffers, TWO_BUFFERS_BELOW: a rule, the same on every run and rank); True / False force one.
         self.plan_two_workspaces = "auto"
-        self._two_tune = None
         self._plan_events = [None, None]
         self._plan_stream = None
         self._fin_early = False
@@ -1335,35 +1333,23 @@ class SCOREBASE(object):
         self.beta2_power = np.float32(self.beta2_power * np.float32(ADAM_B2))
         self.step += 1
 
-    TUNE_SKIP, TUNE_STEPS = 16, 64
+    # "auto" = two alternating plan buffers below this many occurrences per batch.  With two, the next batch's sort (~100 us) runs
+    # beside this step's passes instead of behind its scatter: at few occurrences per batch that sort is the longest cycle of the
+    # step, at many the launch stream's chain is and the early sort only slows the kernels on it.  One box, interleaved, 2,000
+    # steps, one / two buffers (profiles/r06_probes.md): Taobao default (96.6 K occurrences) 0.2183 / 0.2200 vs 0.1932 / 0.1928 ms,
+    # cfg-2 (181 K) 0.1637 / 0.1639 vs 0.1643 / 0.1635, Tmall default (309 K) 0.1891 / 0.1880 vs 0.1927 / 0.1913, CCMR default
+    # (961 K) 0.3451 / 0.3504 vs 0.3584 / 0.3562.  (Until round 5 "auto" TIMED both inside the first ~160 steps of a run: the
+    # choice could differ from run to run and rank to rank, and the tuning fell into short measurements.)
+    TWO_BUFFERS_BELOW = 150000
 
-    def _two_buffers(self, cur):
-        """plan_two_workspaces, with "auto" resolved by timing: phase 0 = one buffer, phase 1 = two, TUNE_SKIP one-call steps to
-        settle and TUNE_STEPS timed between two events on the launch stream each; then the faster one for good (two buffers only
-        if they win by more than 2 %)."""
+    def _two_buffers(self, nxt):
         v = self.plan_two_workspaces
         if v is True or v is False:
             return v
-        t = self._two_tune
-        if t is None:
-            t = self._two_tune = {"phase": 0, "n": 0, "ev": [None, None], "ms": [None, None], "choice": None}
-        if t["choice"] is not None:
-            return t["choice"]
-        ph = t["phase"]
-        if ph < 2:
-            if t["n"] == self.TUNE_SKIP:
-                t["ev"][0] = torch.cuda.Event(enable_timing=True); t["ev"][0].record(cur)
-            elif t["n"] == self.TUNE_SKIP + self.TUNE_STEPS:
-                t["ev"][1] = torch.cuda.Event(enable_timing=True); t["ev"][1].record(cur)
-            t["n"] += 1
-            if t["ev"][1] is not None and t["ev"][1].query():
-                t["ms"][ph] = t["ev"][0].elapsed_time(t["ev"][1])
-                t["phase"], t["n"], t["ev"] = ph + 1, 0, [None, None]
-                ph += 1
-        if ph >= 2:
-            t["choice"] = bool(t["ms"][1] < 0.98 * t["ms"][0])
-            return t["choice"]
-        return ph == 1
+        c = self.cfg
+        slices = int(nxt.active_slices) or int(c.max_time_len)
+        f = int(c.user_fnum) + int(c.item_fnum)
+        return int(nxt.B) * (2 * slices * int(c.obj_per_time_slice) * f + f) < self.TWO_BUFFERS_BELOW
 
     def _plan_buffer(self, B, which):
         """address of plan buffer 0 / 1 of a batch size: the step's workspace, and a second one of the same layout that only ever
@@ -1459,7 +1445,7 @@ class SCOREBASE(object):
         p.slice_lo, p.slice_hi, p.slice_upto = rows * j // K, rows * (j + 1) // K, upto
         ev_plan_next = None
         if nxt is not None:
-            lay2, ws2 = self._workspace(nxt.B, (1 - slot) if (self._two_buffers(cur) and nxt.B == db.B) else 0)
+            lay2, ws2 = self._workspace(nxt.B, (1 - slot) if (self._two_buffers(nxt) and nxt.B == db.B) else 0)
             p.next_batch, p.next_ids, p.n_next_ids = C.addressof(nxt.struct), nxt.flat.data_ptr(), nxt.flat.numel()
             p.next_workspace, p.next_workspace_bytes = ws2.data_ptr(), ws2.numel() * 4
             if ws2.data_ptr() != pr[2]:

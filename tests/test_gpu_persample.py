@@ -160,9 +160,8 @@ def test_one_call_step_equals_the_call_by_call_step(two):
     a, b = make(cfg, 5), make(cfg, 5)
     b.fast_step = False
     # (two = True: the next batch's plan alternates between two buffers and is sorted beside the step, score_state_t.plan_workspace;
-    #  "auto": the model times both and keeps one -- with the tuning phases shortened so that this run goes through all of them)
+    #  "auto": by the number of occurrences per batch -- these small batches get two)
     a.plan_two_workspaces = two
-    a.TUNE_SKIP, a.TUNE_STEPS = 2, 3
     bs = batches(cfg, 6, 8, seed=33, hot_rows=150) + batches(cfg, 2, 5, seed=34, hot_rows=150)
     da, db_ = [a.device_batch(x) for x in bs], [b.device_batch(x) for x in bs]
     order = [0, 1, 2, 3, 4, 5, 0, 2, 4, 1, 3, 5, 5, 0, 1, 6, 7, 2, 3, 4, 0, 1, 2, 3, 4, 5, 0, 1]
@@ -195,8 +194,9 @@ def test_one_call_step_equals_the_call_by_call_step(two):
     assert same_state(a, b)
     assert calls["n"] >= 12, calls            # (most steps: every one whose batch was the one announced a step earlier)
     if two == "auto":
-        torch.cuda.synchronize()
-        assert a._two_tune is not None and (a._two_tune["choice"] is not None or a._two_tune["phase"] >= 1)
+        assert a._two_buffers(da[0]) is True and a._plan_stream is not None
+        a.TWO_BUFFERS_BELOW = 10
+        assert a._two_buffers(da[0]) is False
     if two is True:
         assert a._plan_stream is not None
     a.lib = a_lib
