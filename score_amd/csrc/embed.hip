@@ -162,9 +162,22 @@ __global__ __launch_bounds__(256) void coattn_fwd_kernel(const CoattnArgs a) {
 
   // c = w_t . target + bias (constant over t and i), then r_i = relu(part_i + c)
   float cpart = 0.f;
+  if (cc.tidx) {
+    // (round 6: straight from the table by the target's ids -- the copy that target_fwd_kernel gathers for the head and the query
+    //  branch is the same bits, and reading it put that launch and a stream boundary in front of this kernel, the first of the
+    //  step's chain; an id outside the table is the dummy row here as there, and reported there)
 #pragma unroll
-  for (int j = 0; j < SPL; ++j)
-    if (ok[j]) cpart += dot4(ld4(cc.tgt + (int64_t)b_idx * cc.ldt + (gl + j * GS) * 4), ld4(W + (gl + j * GS) * 4));
+    for (int j = 0; j < SPL; ++j) {
+      uint32_t tr = (uint32_t)cc.tidx[(int64_t)b_idx * F + f[j]];
+      tr = tr >= NR ? 0u : tr;
+      const float4 tv = ld4(table + (int64_t)tr * D + coff[j]);
+      if (ok[j]) cpart += dot4(tv, ld4(W + (gl + j * GS) * 4));
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < SPL; ++j)
+      if (ok[j]) cpart += dot4(ld4(cc.tgt + (int64_t)b_idx * cc.ldt + (gl + j * GS) * 4), ld4(W + (gl + j * GS) * 4));
+  }
   float red[KMAX + 1];          // the K partial scores and the target term: reduced across the group together
 #pragma unroll
   for (int k = 0; k < KMAX; ++k) red[k] = (k < K) ? part[k] : 0.f;

@@ -864,16 +864,19 @@ extern "C" int score_forward(const score_config_t* cfg, const score_state_t* st,
   float* scratch = ws + w.scratch;
   const int x3 = st->gemm_mode == 1 ? GF_X3 : 0;
 
-  // target rows -> query [tu | ti] and head_inp [.., ti, tu]      (score.py:62-66, 210, 217)
-  G(score_launch_target_fwd(st->table, d.D, d.Fu, d.Fi, B, bt->target_user, bt->target_item, ws + w.query, d.Dq,
-                            ws + w.head_inp, d.Dhead, d.off_ti, d.off_tu, s, st->n_table_rows, st->id_status));
-  // side stream: the L2 norm of the weights (needs no batch), then the attention's query branch (target rows and
+  // side stream: the target rows, the L2 norm of the weights (needs no batch), then the attention's query branch (target rows and
   // weights only) -- beside the gather and the GRUs
   SideStream* sd = nullptr;
   G(side_stream(st, s, &sd));
   HIPTRY(hipEventRecord(sd->fork, s));
   HIPTRY(hipStreamWaitEvent(sd->st, sd->fork, 0));
   sd->fwd_on = s;       // (score_backward on this stream next finds the side stream already behind everything before this pass)
+  // target rows -> query [tu | ti] and head_inp [.., ti, tu]      (score.py:62-66, 210, 217).  On the side stream since round 6:
+  // its readers on `stream` -- the attention, the head -- are behind the side stream's join anyway, and the fused gather, which
+  // was the third, reads the target rows from the table itself (CoattnCall.tidx): the step's chain starts with the gather
+  // (four interleaved pairs at cfg-3: 886.5 k vs 881.3 k samples/s)
+  G(score_launch_target_fwd(st->table, d.D, d.Fu, d.Fi, B, bt->target_user, bt->target_item, ws + w.query, d.Dq,
+                            ws + w.head_inp, d.Dhead, d.off_ti, d.off_tu, sd->st, st->n_table_rows, st->id_status));
   // what the step derives from the weights alone, in ONE launch off the main stream: the [Wx_gates | Wx_cand] copies for the
   // hoisted GRU input projections, the folded first attention layer (dense_3 on [q, k, q-k, q*k], head.hip) and the L2 norm's
   // partial sums (three launches before round 4: the reference's own batch sizes are bound by the host's launch calls)
@@ -929,12 +932,12 @@ extern "C" int score_forward(const score_config_t* cfg, const score_state_t* st,
     ca.c[0].bit1 = 0; ca.c[0].bit2 = 3; ca.c[1].bit1 = 1; ca.c[1].bit2 = 2;      // positions in the feed tuple (graph_loader.py:383)
     const int ldi = 4 * d.K;
     CoattnCall& c0 = ca.c[0];
-    c0.idx1 = bt->user_1hop; c0.idx2 = bt->item_2hop; c0.tgt = ws + w.query + d.Du; c0.ldt = d.Dq;
+    c0.idx1 = bt->user_1hop; c0.idx2 = bt->item_2hop; c0.tgt = ws + w.query + d.Du; c0.ldt = d.Dq; c0.tidx = bt->target_item;
     c0.W = d.coattn ? W + P.ca_w[0] : nullptr; c0.bias = d.coattn ? W + P.ca_b[0] : nullptr;
     c0.out1 = ws + w.xside[0]; c0.ld1 = d.I; c0.out2 = ws + w.xside[1] + d.Du; c0.ld2 = d.I;
     c0.info = ws + w.info; c0.ldi = ldi; c0.rsave = ws + w.rsave[0]; c0.F = d.Fi;
     CoattnCall& c1 = ca.c[1];
-    c1.idx1 = bt->user_2hop; c1.idx2 = bt->item_1hop; c1.tgt = ws + w.query; c1.ldt = d.Dq;
+    c1.idx1 = bt->user_2hop; c1.idx2 = bt->item_1hop; c1.tgt = ws + w.query; c1.ldt = d.Dq; c1.tidx = bt->target_user;
     c1.W = d.coattn ? W + P.ca_w[1] : nullptr; c1.bias = d.coattn ? W + P.ca_b[1] : nullptr;
     c1.out1 = ws + w.xside[0] + d.Di; c1.ld1 = d.I; c1.out2 = ws + w.xside[1]; c1.ld2 = d.I;
     c1.info = ws + w.info + 2 * d.K; c1.ldi = ldi; c1.rsave = ws + w.rsave[1]; c1.F = d.Fu;

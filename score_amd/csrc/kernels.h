@@ -58,6 +58,8 @@ int score_launch_colsum(const float* X, int M, int N, int ld, float* out, int ac
 struct CoattnCall {
   const int32_t* idx1; const int32_t* idx2;
   const float* tgt; int ldt;
+  const int32_t* tidx;                        // forward, optional: the target's ids [B, F] -- the target rows are then read from
+                                              // the table (the same bits as a gathered copy in tgt, which is not read)
   const float* W; const float* bias;
   float* out1; int ld1; float* out2; int ld2;
   float* info; int ldi; float* rsave;
