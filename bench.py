@@ -318,7 +318,7 @@ class Heartbeat(object):
                 os._exit(3)
 
 
-def small_shape_leg(config, lr, reg_lambda, steps=300, warmup=50, n_batches=8):
+def small_shape_leg(config, lr, reg_lambda, steps=1000, warmup=100, n_batches=8):
     """One short leg of `model.train_async` on another shape of the path (the reference's own B = 200 / D = 16 / H = 32 shape,
     train_score.py:15-16,371-372, and BASELINE.json configs[1]): a model of its own, every table row live, device-resident
     batches with the next one announced (as the headline does), `warmup` untimed steps, `steps` timed between two
@@ -331,6 +331,11 @@ def small_shape_leg(config, lr, reg_lambda, steps=300, warmup=50, n_batches=8):
     model = SCORE(seed=1111, **kw)
     model.table_flags.fill_(1)
     batches = [model.device_batch(world.batch(B, i)) for i in range(n_batches)]
+    # (as the headline does before its warm-up: what the process has alive by now -- the headline's model is gone, its garbage is
+    #  not -- goes to the permanent generation, so that no generation-2 pass of the collector lands in a host-bound timed loop)
+    import gc
+    gc.collect()
+    gc.freeze()
 
     def run(n, marks=None):
         for i in range(n):

@@ -427,7 +427,10 @@ typedef struct {
                            complete on `stream` when score_backward returns as before; grad_w only once the event has fired:
                            the caller runs what needs the row gradients alone (score_adam_touched) on `stream` meanwhile and
                            makes `stream` wait for the event before score_adam on the dense variables (or anything else that
-                           reads grad_w).  NULL: everything on `stream`, as before.                                   */
+                           reads grad_w).  Round 6: the finishers are forked in FRONT of the row scatter (beside it), so the
+                           event says nothing about the scatter -- which reads the co-attention weights: the dense variables
+                           may only be updated behind the event AND behind `stream`'s own launches of the pass (i.e. on `stream`,
+                           or on a stream that also waits for stage boundary 4).  NULL: everything on `stream`, as before. */
   void* loss_done_event;  /* optional hipEvent_t (score_forward): the loss reduction (one workgroup: loss[0..3] from the per-sample
                            terms and the L2 partial sums) then runs on the context's side stream behind the head, and this event is
                            recorded behind it -- the head's successor on `stream` (score_backward's first launch) no longer queues
