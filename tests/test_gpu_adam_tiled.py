@@ -513,3 +513,67 @@ def test_three_hundred_overlapped_steps_equal_the_inline_run_at_a_wide_shape():
             assert same_state(a, b), i
     assert same_state(a, b)
     assert a._side is not None and a._side.cuda_stream != torch.cuda.current_stream().cuda_stream and a._ev_grads is not None
+
+
+@pytest.mark.parametrize("D,n_rows", [(64, 150000), (16, 400000)])
+def test_touched_rows_update_beside_the_look_ahead_on_another_stream(D, n_rows):
+    """score_adam_touched on one stream while score_adam_catchup_ids_through (the look-ahead catch-up of the next
+    batch's rows) and score_adam_catchup_rows (the window slice) run on another -- overlapping id sets, which is how the step runs
+    them since round 5 (csrc/adam_tiled.hip tiled_publish_applied: a row's count is published before its state byte).  Every
+    (row, step) update must be applied exactly once whatever the interleaving: after each round the table equals a twin's on
+    which the three calls ran one after the other on ONE stream, bit for bit, and every live row's count is what it must be.
+    Sixty rounds on sizes whose kernels take tens of microseconds each, so that they do run side by side."""
+    from score_amd import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda")
+    gen = torch.Generator(device=dev).manual_seed(D + n_rows)
+    P = lambda t: C.c_void_p(t.data_ptr())
+    main = torch.cuda.current_stream()
+    other = torch.cuda.Stream()
+
+    def fresh():
+        blk = torch.randn(4, n_rows, D, device=dev, generator=torch.Generator(device=dev).manual_seed(7)) * 0.1
+        blk[1].abs_().mul_(0.01); blk[2].abs_().mul_(0.001)          # live moments everywhere: every row owes every step
+        flags = torch.ones(n_rows, dtype=torch.uint8, device=dev)
+        row_step = torch.zeros(n_rows, dtype=torch.int32, device=dev)
+        ring = torch.zeros(_lib.ADAM_RING + 1, dtype=torch.float32, device=dev)
+        T = _lib.AdamTable(p=P(blk[0]), m=P(blk[1]), v=P(blk[2]), g=P(blk[3]), n_rows=n_rows, D=D, row_flags=P(flags),
+                           row_step=P(row_step), alpha_ring=P(ring), beta1=0.9, beta2=0.999, eps=1e-8)
+        return blk, flags, row_step, ring, T
+    a, b = fresh(), fresh()
+    window = 6
+    ids_now = torch.randint(1, n_rows, (n_rows // 6,), device=dev, generator=gen, dtype=torch.int32)
+    for m_ in (a, b):
+        assert lib.score_adam_catchup_ids(C.byref(m_[4]), P(ids_now), ids_now.numel(), 0, C.c_void_p(main.cuda_stream)) == 0
+    for step in range(1, 61):
+        alpha = 1e-2 / (1.0 + 0.01 * step)
+        # the next batch overlaps this one by about a third; both draw from a hot set now and then
+        hot = (step % 3 == 0)
+        ids_next = torch.randint(1, n_rows // (8 if hot else 1), (n_rows // 6,), device=dev, generator=gen, dtype=torch.int32)
+        ids_next[: ids_next.numel() // 3] = ids_now[: ids_next.numel() // 3]
+        rows = ids_now.long().unique()
+        grads = torch.randn(rows.numel(), D, device=dev, generator=gen)
+        lo, hi = n_rows * (step % window) // window, n_rows * (step % window + 1) // window
+        for m_ in (a, b):
+            m_[0][3][rows] = grads
+            m_[1][rows] = 2                          # what the row scatter leaves: the gradient and the state-2 mark
+        torch.cuda.synchronize()
+        # twin b: one stream, one after the other
+        sb = C.c_void_p(main.cuda_stream)
+        assert lib.score_adam_catchup_rows(C.byref(b[4]), lo, hi, step - 1, sb) == 0
+        assert lib.score_adam_catchup_ids_through(C.byref(b[4]), P(ids_next), ids_next.numel(), step, alpha, sb) == 0
+        assert lib.score_adam_touched(C.byref(b[4]), step, alpha, sb) == 0
+        # a: the touched rows on the launch stream, slice + look-ahead beside them on another
+        other.wait_stream(main)
+        so_ = C.c_void_p(other.cuda_stream)
+        assert lib.score_adam_catchup_rows(C.byref(a[4]), lo, hi, step - 1, so_) == 0
+        assert lib.score_adam_touched(C.byref(a[4]), step, alpha, sb) == 0
+        assert lib.score_adam_catchup_ids_through(C.byref(a[4]), P(ids_next), ids_next.numel(), step, alpha, so_) == 0
+        main.wait_stream(other)
+        torch.cuda.synchronize()
+        assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]), step                   # state bytes, counts
+        assert torch.equal(a[0][:3], b[0][:3]), step                                         # p, m, v
+        nxt = ids_next.long().unique()
+        assert bool((a[2][nxt] == step).all()) and bool((a[2][rows] == step).all()) and not bool((a[1] == 2).any())
+        ids_now = ids_next
+    assert int(a[3][_lib.ADAM_RING].view(torch.int32).item()) == 0
