@@ -485,12 +485,19 @@ def main():
                     help="form of the row / gradient all-to-all with N > 1 ranks: 'remote' = list form with empty own slots (a rank's own "
                          "rows never go through RCCL), 'split' = all_to_all_single with the own segment inside.  Default: what the "
                          "set-up probe finds to round-trip (score_amd/dist.py TorchDistComm.probe_a2a), the same on every rank")
+    ap.add_argument("--small-shape-leg", default=None, metavar="CONFIG",
+                    help="(internal) run ONE small-shape leg on CONFIG in this process and print its JSON: the default run starts "
+                         "one child process per leg")
     ap.add_argument("--no-small-shapes", action="store_true",
                     help="skip the two short legs on cfg-2 and the reference's Tmall-default shape (`small_shapes`, the LAST key of the line)")
     ap.add_argument("--lr", type=float, default=1e-3)
     ap.add_argument("--reg-lambda", type=float, default=1e-4)
     args = ap.parse_args()
 
+    if args.small_shape_leg:
+        torch.cuda.set_device(int(os.environ.get("SCORE_BENCH_DEVICE", "0")))
+        print(json.dumps(small_shape_leg(args.small_shape_leg, args.lr, args.reg_lambda)), flush=True)
+        return
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # called as plain `python bench.py --gpus N`: start the N ranks ourselves.  Nothing above this line has touched
         # the GPU (no torch.cuda call that initialises HIP, no _lib.load()): the ranks are CHILD processes of
@@ -1135,15 +1142,23 @@ def main():
         torch.cuda.empty_cache()
         if do_side and not args.no_small_shapes:
             # before the CPU legs (their threads would compete with this thread's launch calls), printed behind them
+            # each leg in a CHILD process of its own (started, not exec'ed: this process keeps the GPU): in this one the headline's
+            # streams are still alive and the new model's four streams land on hardware queues they share with them -- two streams
+            # on one queue serialise (round 6: Tmall default 0.205 ms here against 0.189 in a fresh process on the same box)
+            import subprocess
             small = {}
             for c in ("cfg2", "tmall_default"):
                 try:
-                    small[c] = small_shape_leg(c, args.lr, args.reg_lambda)
+                    cp = subprocess.run([sys.executable, os.path.abspath(__file__), "--small-shape-leg", c, "--lr", str(args.lr),
+                                         "--reg-lambda", str(args.reg_lambda)], capture_output=True, text=True, timeout=300,
+                                        cwd=ROOT)
+                    lines = [l for l in cp.stdout.strip().splitlines() if l.strip().startswith("{")]
+                    small[c] = json.loads(lines[-1]) if (cp.returncode == 0 and lines) else {"error": (cp.stderr or "no output")[-200:]}
                 except Exception as e:          # an optional leg never takes the headline down
                     small[c] = {"error": repr(e)[:200]}
-            small["what"] = ("model.train_async, device-resident batches, next batch announced, every row live; ms_per_step = wall "
-                             "incl. optimizer flush; host_us = enqueue loop only; launches from profiles/%s_<config>_sequence.txt"
-                             % PROFILE_ROUND)
+            small["what"] = ("model.train_async in a fresh process per leg, device-resident batches, next batch announced, every row "
+                             "live; ms_per_step = wall incl. optimizer flush; host_us = enqueue loop only; launches from "
+                             "profiles/%s_<config>_sequence.txt" % PROFILE_ROUND)
         out["cpu_baseline"] = cpu_baseline(kw, world.batch(B, 1000), params)
         if do_side:
             # the literal materialised-tile form at the reference's own Tmall-default shape (BASELINE.md section 3;
