@@ -42,6 +42,19 @@ typedef void* score_context_t;
 int score_context_create(score_context_t* ctx);
 /* ctx == NULL: release the process-wide default contexts.  Synchronises the context's stream first. */
 int score_context_destroy(score_context_t ctx);
+/* Events for stream-to-stream ordering ONLY (round 6): hipEventDisableTiming | hipEventDisableSystemFence -- recording one does
+ * not write back / invalidate the caches at system scope, which an event made for the host's eyes does on every record (a dozen
+ * records per training step sit between dependent kernels of the launch stream).  What they order is device work on device
+ * memory; a host thread that wants to READ results behind such an event must use an ordinary event (or synchronise the stream).
+ * The context's own fork / join events are of this kind.  score_event_record / score_stream_wait_event take any hipEvent_t.
+ * Replaces nothing in the reference. */
+int score_event_create(void** event);
+int score_event_destroy(void* event);
+int score_event_record(void* event, void* stream);
+int score_stream_wait_event(void* stream, void* event);
+int score_event_query(void* event);          /* 0 = reached, 1 = not yet, else an error */
+int score_event_synchronize(void* event);
+
 /* The scalars of a training step that change from step to step, kept in DEVICE memory so that a captured step
  * (hipGraph: small shapes are launch-bound, ~60 launches of a few microseconds each) can be replayed with new
  * values: ApplyAdam's alpha = lr * sqrt(1 - beta2^t) / (1 - beta1^t) (score.py:96-99) and the seed of the

@@ -151,6 +151,12 @@ _SIGS = {
     "score_auc_scratch_bytes": [C.c_int64],
     "score_ranking_quality": [c_f, c_i, C.c_int64, C.c_int32, c_f, c_i, c_f, C.c_int64, C.c_void_p],
     "score_persample_form": [C.POINTER(Config), C.POINTER(State), C.c_int32, C.c_int32],
+    "score_event_create": [C.POINTER(C.c_void_p)],
+    "score_event_destroy": [C.c_void_p],
+    "score_event_record": [C.c_void_p, C.c_void_p],
+    "score_stream_wait_event": [C.c_void_p, C.c_void_p],
+    "score_event_query": [C.c_void_p],
+    "score_event_synchronize": [C.c_void_p],
     "score_abi_struct_sizes": [C.POINTER(C.c_int64), C.c_int32],
     "score_train_step": [C.POINTER(Config), C.POINTER(State), C.POINTER(Batch), C.POINTER(TrainStep), C.c_void_p],
     "score_gemm_forms": [C.POINTER(Config), C.POINTER(State), C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)],
@@ -162,6 +168,47 @@ _SIGS = {
 
 EXPORTS = tuple(_SIGS)
 _lib = None
+
+
+class DevEvent(object):
+    """An event that orders DEVICE work only (score_event_create: no system-scope fence at a record), with the methods of
+    torch.cuda.Event the host code uses -- record(stream), wait(stream) (what torch.cuda.Stream.wait_event(event) calls),
+    query(), synchronize() -- and `.cuda_event`, the hipEvent_t handed to the library.  Not for a host thread that wants to READ
+    what was computed in front of it (torch.cuda.Event for that)."""
+    __slots__ = ("cuda_event", "_lib")
+
+    def __init__(self):
+        lib = load()
+        h = C.c_void_p(0)
+        check(lib.score_event_create(C.byref(h)), "score_event_create")
+        self.cuda_event = h.value
+        self._lib = lib
+
+    def record(self, stream=None):
+        import torch
+        s = stream if stream is not None else torch.cuda.current_stream()
+        check(self._lib.score_event_record(self.cuda_event, s.cuda_stream), "score_event_record")
+
+    def wait(self, stream=None):
+        import torch
+        s = stream if stream is not None else torch.cuda.current_stream()
+        check(self._lib.score_stream_wait_event(s.cuda_stream, self.cuda_event), "score_stream_wait_event")
+
+    def query(self):
+        rc = self._lib.score_event_query(self.cuda_event)
+        if rc not in (0, 1):
+            check(rc, "score_event_query")
+        return rc == 0
+
+    def synchronize(self):
+        check(self._lib.score_event_synchronize(self.cuda_event), "score_event_synchronize")
+
+    def __del__(self):
+        try:
+            if self.cuda_event:
+                self._lib.score_event_destroy(self.cuda_event)
+        except Exception:
+            pass
 
 
 class ScoreHipError(RuntimeError):

@@ -316,15 +316,50 @@ void build_ws(const Dims& d, int B, WS* w) {
 // context shares ONE process-wide default context per device (created on first use, released by
 // score_context_destroy(NULL)): the only state the library keeps between calls.
 struct SideStream { hipStream_t st; hipEvent_t fork, join, wx; int device; hipStream_t fwd_on; };
+#define HIPTRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return (int)e_; } while (0)
+// events that order device work only (include/score_hip.h score_event_create)
+#define SCORE_DEVICE_EVENT_FLAGS (hipEventDisableTiming | hipEventDisableSystemFence)
+extern "C" int score_event_create(void** event) {
+  if (!event) return SCORE_E_BADARG;
+  hipEvent_t e;
+  HIPTRY(hipEventCreateWithFlags(&e, SCORE_DEVICE_EVENT_FLAGS));
+  *event = (void*)e;
+  return 0;
+}
+extern "C" int score_event_destroy(void* event) {
+  if (!event) return SCORE_E_BADARG;
+  HIPTRY(hipEventDestroy((hipEvent_t)event));
+  return 0;
+}
+extern "C" int score_event_record(void* event, void* stream) {
+  if (!event) return SCORE_E_BADARG;
+  HIPTRY(hipEventRecord((hipEvent_t)event, (hipStream_t)stream));
+  return 0;
+}
+extern "C" int score_stream_wait_event(void* stream, void* event) {
+  if (!event) return SCORE_E_BADARG;
+  HIPTRY(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0));
+  return 0;
+}
+extern "C" int score_event_query(void* event) {
+  if (!event) return SCORE_E_BADARG;
+  const hipError_t e = hipEventQuery((hipEvent_t)event);
+  return e == hipSuccess ? 0 : e == hipErrorNotReady ? 1 : (int)e;
+}
+extern "C" int score_event_synchronize(void* event) {
+  if (!event) return SCORE_E_BADARG;
+  HIPTRY(hipEventSynchronize((hipEvent_t)event));
+  return 0;
+}
 static int side_stream_create(SideStream* sd) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return SCORE_E_BADARG;
   hipStream_t st; hipEvent_t a, b, c;
   hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
   if (e != hipSuccess) return (int)e;
-  if ((e = hipEventCreateWithFlags(&a, hipEventDisableTiming)) != hipSuccess) { hipStreamDestroy(st); return (int)e; }
-  if ((e = hipEventCreateWithFlags(&b, hipEventDisableTiming)) != hipSuccess) { hipEventDestroy(a); hipStreamDestroy(st); return (int)e; }
-  if ((e = hipEventCreateWithFlags(&c, hipEventDisableTiming)) != hipSuccess) { hipEventDestroy(a); hipEventDestroy(b); hipStreamDestroy(st); return (int)e; }
+  if ((e = hipEventCreateWithFlags(&a, SCORE_DEVICE_EVENT_FLAGS)) != hipSuccess) { hipStreamDestroy(st); return (int)e; }
+  if ((e = hipEventCreateWithFlags(&b, SCORE_DEVICE_EVENT_FLAGS)) != hipSuccess) { hipEventDestroy(a); hipStreamDestroy(st); return (int)e; }
+  if ((e = hipEventCreateWithFlags(&c, SCORE_DEVICE_EVENT_FLAGS)) != hipSuccess) { hipEventDestroy(a); hipEventDestroy(b); hipStreamDestroy(st); return (int)e; }
   sd->st = st; sd->fork = a; sd->join = b; sd->wx = c; sd->device = dev; sd->fwd_on = nullptr;
   return 0;
 }
@@ -373,7 +408,6 @@ static inline Flags flags_of(const score_state_t* st) {
   f.gru_stepwise = (st->debug_flags & 1) != 0;
   return f;
 }
-#define HIPTRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return (int)e_; } while (0)
 
 #define G(call) SCORE_TRY(call)
 // every GEMM of the path goes through here: ORs in the caller's product mode (score_state_t.gemm_mode)

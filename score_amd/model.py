@@ -237,6 +237,7 @@ class SCOREBASE(object):
         self._plan_events = [None, None]
         self._plan_stream = None
         self._fin_early = False
+        self._ev_loss_dev = None
         self.fast_step = True           # train / train_async: the steady-state step of the per-sample form as one library call (_train_step_fast)
         self._step_args = self._step_T = self._step_side = None
         self._pb_cache = {}
@@ -692,9 +693,19 @@ class SCOREBASE(object):
         record that is current when it is issued."""
         ev = self._evs.get(name)
         if ev is None:
-            ev = self._evs[name] = torch.cuda.Event()
+            # (stream-to-stream ordering only: an event without the system-scope fence of torch.cuda.Event -- _lib.DevEvent; the
+            #  one event the HOST reads results behind, the early loss copy's, stays an ordinary one)
+            ev = self._evs[name] = self._ev_new(host=name in self._HOST_READ_EVENTS)
         ev.record(stream)
         return ev
+
+    _HOST_READ_EVENTS = ("early_loss",)
+    device_events = True            # False: torch.cuda.Event everywhere (the A/B of profiles/r06_probes.md section 9)
+
+    def _ev_new(self, host=False):
+        """an event for stream-to-stream ordering (_lib.DevEvent: no system-scope fence at its records), or -- host=True: the host
+        reads results behind it -- an ordinary torch.cuda.Event"""
+        return torch.cuda.Event() if (host or not self.device_events) else _lib.DevEvent()
 
     def _cur(self):
         """torch.cuda.current_stream(self.device), looked up once per public call: the query costs ~4 us of Python and a
@@ -838,7 +849,7 @@ class SCOREBASE(object):
             if self._side is None:
                 self._side = cur if inline else torch.cuda.Stream(device=self.device)
                 self._side_handle = C.c_void_p(self._side.cuda_stream)
-                self._ev_gather = torch.cuda.Event()
+                self._ev_gather = self._ev_new()
                 self._ev_gather.record(cur)          # materialise the hipEvent_t
         # the occurrence sort starts together with the forward (an event recorded here, not between the gather and
         # the input projections: a record between two launches costs ~5 us of bubble on the main stream, and the
@@ -856,7 +867,7 @@ class SCOREBASE(object):
         fwd_stage = None
         if sweep_at == "f1" and self._tiled_on():
             if self._ev_stage is None:
-                self._ev_stage = torch.cuda.Event()
+                self._ev_stage = self._ev_new()
                 self._ev_stage.record(cur)              # materialise the hipEvent_t
             fwd_stage = (1, self._ev_stage)
         # the loss reduction (one workgroup, no reader inside the step) on the engine's side stream: score_backward's first
@@ -868,10 +879,20 @@ class SCOREBASE(object):
         # (the per-sample kernels: always -- every launch taken off the chain is ~5 us there)
         side_ok = self._ps_last or db.B * (db.active_slices or int(self.cfg.max_time_len)) >= self.overlap_finishers_min_rows
         if self.loss_on_side and not self._graph_on and not self._use_dev_scalars and side_ok:
-            if self._ev_loss is None:
-                self._ev_loss = torch.cuda.Event()
-                self._ev_loss.record(cur)               # materialise the hipEvent_t
-            ev_loss = self._ev_loss
+            # (train() reads the loss on the host behind this event -- from pinned memory the per-sample kernel wrote, or through a
+            #  copy on another stream that only waits for it: an ordinary event then, with its system-scope release; train_async:
+            #  it only orders streams, and a device event does)
+            host_reads = self._early_loss is not None
+            if host_reads:
+                if self._ev_loss is None:
+                    self._ev_loss = torch.cuda.Event()
+                    self._ev_loss.record(cur)               # materialise the hipEvent_t
+                ev_loss = self._ev_loss
+            else:
+                if self._ev_loss_dev is None:
+                    self._ev_loss_dev = self._ev_new()
+                    self._ev_loss_dev.record(cur)
+                ev_loss = self._ev_loss_dev
         lay, ws, st = self._forward(db, reg_lambda, keep_prob, dropout_masks,
                                     gather_event=self._ev_gather if (self.scatter_mode == 0 and not early) else None,
                                     sweep=True, stage_event=fwd_stage, loss_event=ev_loss)
@@ -950,7 +971,7 @@ class SCOREBASE(object):
         if sweep_at in ("1", "2", "3", "4"):
             # the slice starts at a stage boundary of the backward pass (score_backward records the event there)
             if self._ev_stage is None:
-                self._ev_stage = torch.cuda.Event()
+                self._ev_stage = self._ev_new()
                 self._ev_stage.record(cur)              # materialise the hipEvent_t
             events = list(events) if events else [None] * 6
             k = int(sweep_at)
@@ -963,7 +984,7 @@ class SCOREBASE(object):
             # boundary 4 (the row scatter has marked every row that gets this step's gradient): apply_adam(next_batch=)
             # starts the next batch's catch-up there, on the side stream
             if self._ev_b4 is None:
-                self._ev_b4 = torch.cuda.Event()
+                self._ev_b4 = self._ev_new()
                 self._ev_b4.record(cur)
             events = list(events) if events else [None] * 6
             if events[4] is None:
@@ -974,7 +995,7 @@ class SCOREBASE(object):
         if (self.scatter_mode == 0 and not self._use_dev_scalars and not self._graph_on and side_ok
                 and (self._tiled_on() or self.persample_form(db.B, db.active_slices))):
             if self._ev_grads is None:
-                self._ev_grads = torch.cuda.Event()
+                self._ev_grads = self._ev_new()
                 self._ev_grads.record(cur)              # materialise the hipEvent_t
             st.grads_done_event = C.c_void_p(self._ev_grads.cuda_event)
             self._grads_pending = self._ev_grads
@@ -1055,7 +1076,7 @@ class SCOREBASE(object):
                         side.wait_event(self._grads_pending)
                         self.adam_dense(lr, reg_lambda, stream=side)
                         if self._ev_dense is None:
-                            self._ev_dense = torch.cuda.Event()
+                            self._ev_dense = self._ev_new()
                         self._ev_dense.record(side)
                         self._dense_pending = self._ev_dense
                     else:
@@ -1363,7 +1384,7 @@ class SCOREBASE(object):
     def _ensure_ev(self, attr):
         ev = getattr(self, attr)
         if ev is None:
-            ev = torch.cuda.Event()
+            ev = self._ev_new(host=attr == "_ev_loss")       # (the host reads the loss behind _ev_loss)
             ev.record(self._cur())              # materialise the hipEvent_t
             setattr(self, attr, ev)
         return ev
@@ -1452,7 +1473,7 @@ class SCOREBASE(object):
                 # (an event of its own: this step's scatter still has to wait for THIS batch's plan event)
                 ev_plan_next = self._plan_events[1] if pr[1] is self._plan_events[0] else self._plan_events[0]
                 if ev_plan_next is None:
-                    ev_plan_next = torch.cuda.Event()
+                    ev_plan_next = self._ev_new()
                     ev_plan_next.record(cur)
                     self._plan_events[0 if self._plan_events[0] is None else 1] = ev_plan_next
             p.ev_plan_next = ev_plan_next.cuda_event if ev_plan_next is not None else None

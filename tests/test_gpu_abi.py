@@ -122,3 +122,31 @@ def test_step_entry_point_rejects_missing_arguments():
     assert lib.score_train_step(None, C.byref(st), C.byref(bt), C.byref(p), None) == -1
     assert lib.score_train_step(C.byref(cfg), C.byref(st), C.byref(bt), None, None) == -1
     assert lib.score_train_step(C.byref(cfg), C.byref(st), C.byref(bt), C.byref(p), None) == -1      # (no table, no events)
+
+
+def test_device_only_events_order_streams():
+    """score_event_create / _record / score_stream_wait_event / _query / _synchronize (round 6: events without the system-scope
+    fence, for stream-to-stream ordering) through _lib.DevEvent -- the duck type torch.cuda.Stream.wait_event accepts: a consumer
+    stream that waits for the event sees what the producer stream wrote in front of the record, every time"""
+    from score_amd import _lib
+    dev = torch.device("cuda")
+    a, b = torch.cuda.Stream(), torch.cuda.Stream()
+    ev = _lib.DevEvent()
+    x = torch.zeros(1 << 22, device=dev)
+    y = torch.zeros_like(x)
+    for i in range(1, 41):
+        with torch.cuda.stream(a):
+            x.fill_(float(i))
+            ev.record(a)
+        b.wait_event(ev)                       # (torch calls ev.wait(b))
+        with torch.cuda.stream(b):
+            y.copy_(x)
+        a.wait_stream(b)                       # (the next fill must not overtake the copy)
+    torch.cuda.synchronize()
+    assert float(y.min()) == 40.0 and float(y.max()) == 40.0
+    ev.record()
+    ev.synchronize()
+    assert ev.query()
+    lib = _lib.load()
+    assert lib.score_event_create(None) == -1 and lib.score_event_record(None, None) == -1
+    assert lib.score_stream_wait_event(None, None) == -1 and lib.score_event_query(None) == -1
