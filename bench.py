@@ -481,10 +481,11 @@ def main():
     ap.add_argument("--gather-probe-only", action="store_true",
                     help="run only the low-duplication gather probe (for rocprofv3 --pmc passes) and print its JSON")
     ap.add_argument("--probe-rows", type=int, default=32_000_000)
-    ap.add_argument("--a2a", choices=["split", "remote"], default=None,
+    ap.add_argument("--a2a", choices=["split", "remote", "probe"], default=None,
                     help="form of the row / gradient all-to-all with N > 1 ranks: 'remote' = list form with empty own slots (a rank's own "
-                         "rows never go through RCCL), 'split' = all_to_all_single with the own segment inside.  Default: what the "
-                         "set-up probe finds to round-trip (score_amd/dist.py TorchDistComm.probe_a2a), the same on every rank")
+                         "rows never go through RCCL), 'split' = all_to_all_single with the own segment inside (the default: the plain RCCL "
+                         "path), 'probe' = try both at set-up and take the list form if it round-trips on every rank "
+                         "(score_amd/dist.py TorchDistComm.probe_a2a)")
     ap.add_argument("--small-shape-leg", default=None, metavar="CONFIG",
                     help="(internal) run ONE small-shape leg on CONFIG in this process and print its JSON: the default run starts "
                          "one child process per leg")

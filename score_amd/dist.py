@@ -112,7 +112,7 @@ class TorchDistComm(object):
         # all_to_all_remote's form: "remote" = the list form with EMPTY tensors in the own slot (what a rank owns never goes through
         # the collective), "split" = all_to_all_single with the own segment inside.  Decided ONCE, at set-up, identically on every
         # rank (probe_a2a): never by catching an error in the hot path, where a rank-local or asynchronous failure would flip one
-        # rank only and the ranks' collectives would stop matching.  SCORE_A2A=split|remote (bench.py --a2a) forces one.
+        # rank only and the ranks' collectives would stop matching.  "split" unless SCORE_A2A=remote|probe (bench.py --a2a) asks otherwise.
         self._list_form = None
         self.a2a_probe = None   # what the probe found (bench.py prints it)
         self.last = None       # ("name", sequence number) of the collective this rank entered last (bench.py's heartbeat)
@@ -148,15 +148,22 @@ class TorchDistComm(object):
     def probe_a2a(self, device, force=None, timeout_s=None):
         """Settle on ONE all-to-all form for the whole run -- the same one on every rank -- by running it on tiny tensors and
         comparing what arrives with what every rank must receive (the verdicts are all-reduced).  One line on stderr from rank 0.
-        force: "split" / "remote" (or SCORE_A2A): ONLY that form is run (a form nobody asked for is never entered: a hang of the
-        list form on one rank must not be able to take a `--a2a split` job down at set-up); a mismatch raises.
-        Not forced: "split" (all_to_all_single, the plain RCCL path) is probed first; the list form with empty own slots -- the
-        preferred one, a rank's own rows stay out of the collective -- is then probed under a watchdog: if it has not returned
-        after timeout_s (SCORE_A2A_PROBE_TIMEOUT, default 60 s) the rank says so on stderr, names the switch that avoids it
-        and exits 3 (a collective that never completes cannot be abandoned inside the process)."""
+        A form nobody asked for is never entered (a hang of the list form on one rank must not be able to take a job down at
+        set-up), so:
+          not forced      "split" only: all_to_all_single, the plain RCCL path.  A rank's own segment rides through the collective
+                          as a local copy -- 1 / G of a few MB per step, nothing a first multi-GPU run should risk a hang for.
+          "remote"        (force or SCORE_A2A) ONLY the list form with empty own slots (a rank's own rows stay out of the
+                          collective); a mismatch raises.
+          "split"         the default, said explicitly.
+          "probe"         "split" first, then the list form under a watchdog: if it has not returned after timeout_s
+                          (SCORE_A2A_PROBE_TIMEOUT, default 60 s) the rank says so on stderr, names the switch that avoids it and
+                          exits 3 (a collective that never completes cannot be abandoned inside the process); the list form is
+                          taken when it round-trips on every rank, "split" otherwise."""
         force = force or os.environ.get("SCORE_A2A") or None
-        if force not in (None, "split", "remote"):
-            raise ValueError("all-to-all form must be 'split' or 'remote', got %r" % (force,))
+        if force not in (None, "split", "remote", "probe"):
+            raise ValueError("all-to-all form must be 'split', 'remote' or 'probe', got %r" % (force,))
+        asked, both = force, force == "probe"
+        force = None if both else (force or "split")
         if self.world == 1 or self._gloo:
             self._list_form = None if self.world == 1 else True
             self.a2a_probe = {"form": "none (one rank)" if self.world == 1 else "pairwise (gloo)", "forced": force}
@@ -171,11 +178,11 @@ class TorchDistComm(object):
                             device=device).reshape(G * per, 1)
         splits = [per] * G
         verdict = {}
-        for form in ((force,) if force is not None else ("split", "remote")):
+        for form in (("split", "remote") if both else (force,)):
             ok = 1.0
             out = torch.full_like(inp, -1.0)
             dog = None
-            if form == "remote" and force is None and timeout_s > 0:
+            if form == "remote" and both and timeout_s > 0:
                 dog = threading.Timer(timeout_s, _a2a_probe_hung, args=(r, G, timeout_s))
                 dog.daemon = True
                 dog.start()
@@ -205,7 +212,7 @@ class TorchDistComm(object):
         if not verdict[form]:
             raise RuntimeError("neither all-to-all form round-trips on this backend: %r" % (verdict,))
         self._list_form = form == "remote"
-        verdict.update(form=form, forced=force)
+        verdict.update(form=form, forced=asked)
         self.a2a_probe = verdict
         if r == 0:
             sys.stderr.write("[score_amd.dist] all-to-all probe over %d ranks: %r\n" % (G, verdict))

@@ -98,32 +98,37 @@ def test_two_rank_sharded_training_matches_single_model(tmp_path, model_type):
 
 
 # ---- the branch RCCL takes, with three and four ranks (threads of one process: torch's "threaded" process group) ---------
-@pytest.mark.parametrize("world", [3, 4])
-def test_ranks_on_the_rccl_code_path(world):
-    """score_amd/dist.py under a backend that is not gloo: all_to_all_single for the counts, all_to_all_remote = the own
-    segment copied locally + ONE list all_to_all with empty own slots, all_reduce.  No multi-GPU node has been available to any
-    round; tests/threaded_pg_worker.py runs that branch's index arithmetic with `world` ranks of unequal batch sizes (oracle
-    backend) against one oracle model on the concatenated batch."""
+@pytest.mark.parametrize("world,mode", [(3, ""), (4, ""), (3, "force_remote"), (4, "force_remote")])
+def test_ranks_on_the_rccl_code_path(world, mode):
+    """score_amd/dist.py under a backend that is not gloo: all_to_all_single for the counts, the rows and the row gradients
+    (nothing asked: the split form), or -- SCORE_A2A=remote -- all_to_all_remote = the own segment copied locally + ONE list
+    all_to_all with empty own slots; all_reduce.  No multi-GPU node has been available to any round; tests/threaded_pg_worker.py
+    runs that branch's index arithmetic with `world` ranks of unequal batch sizes (oracle backend) against one oracle model on
+    the concatenated batch."""
     import json
     import subprocess
-    out = subprocess.run([sys.executable, os.path.join(HERE, "threaded_pg_worker.py"), str(world)], capture_output=True,
+    out = subprocess.run([sys.executable, os.path.join(HERE, "threaded_pg_worker.py"), str(world), mode], capture_output=True,
                          text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     j = json.loads(out.stdout.strip().splitlines()[-1])
     assert j["ok"] and j["loss_rel_err"] < 1e-5 and j["table_max_err"] < 2e-6 and j["dense_identical_across_ranks"]
-    assert j["own_slot_sizes"] == [[0, 0]]                       # what a rank owns never went through the collective
-    assert len(set(j["list_collectives_per_rank"])) == 1 and j["list_collectives_per_rank"][0] >= 6
     assert len({tuple(x) for x in j["last"]}) == 1               # every rank entered the same last collective (same sequence number)
-    assert j["list_form"] == [True] * world
+    if mode == "force_remote":
+        assert j["own_slot_sizes"] == [[0, 0]]                   # what a rank owns never went through the collective
+        assert len(set(j["list_collectives_per_rank"])) == 1 and j["list_collectives_per_rank"][0] >= 6
+        assert j["list_form"] == [True] * world and "'forced': 'remote'" in out.stderr and "'split'" not in out.stderr
+    else:                                                        # nothing asked: the list form is never entered, not even to probe it
+        assert j["list_form"] == [False] * world and j["list_collectives_per_rank"] == [0] * world
+        assert "'form': 'split'" in out.stderr and "'forced': None" in out.stderr and "'remote'" not in out.stderr
 
 
 def test_a_backend_that_refuses_empty_slots_gets_the_split_form():
-    """TorchDistComm.probe_a2a (run by ShardedSCORE at set-up): if the backend's list all_to_all will not take empty tensors, every
-    rank settles on the split form -- the verdict is all-reduced, nothing is decided by catching an error inside a training step --
-    with one line on stderr from rank 0, and the results are the same."""
+    """TorchDistComm.probe_a2a with SCORE_A2A=probe (run by ShardedSCORE at set-up): both forms are tried; if the backend's list
+    all_to_all will not take empty tensors, every rank settles on the split form -- the verdict is all-reduced, nothing is decided
+    by catching an error inside a training step -- with one line on stderr from rank 0, and the results are the same."""
     import json
     import subprocess
-    out = subprocess.run([sys.executable, os.path.join(HERE, "threaded_pg_worker.py"), "3", "refuse"], capture_output=True,
+    out = subprocess.run([sys.executable, os.path.join(HERE, "threaded_pg_worker.py"), "3", "refuse_probe"], capture_output=True,
                          text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     j = json.loads(out.stdout.strip().splitlines()[-1])
@@ -132,19 +137,20 @@ def test_a_backend_that_refuses_empty_slots_gets_the_split_form():
     assert out.stderr.count("all-to-all probe over 3 ranks") == 1 and "'remote': False" in out.stderr and "'form': 'split'" in out.stderr
 
 
-def test_a_forced_form_is_the_only_one_the_probe_enters():
-    """with SCORE_A2A=split / bench.py --a2a split the set-up probe runs all_to_all_single ONLY -- a list-form
-    all_to_all that hangs or fails on one rank cannot take such a job down at set-up.  Here the list form raises whenever it is
-    entered ("refuse") and the spy counts its calls: none, on any rank, and the run's results are the same."""
+@pytest.mark.parametrize("mode", ["refuse", "refuse_force_split"])
+def test_a_form_nobody_asked_for_is_never_entered(mode):
+    """with nothing asked, or SCORE_A2A=split / bench.py --a2a split, the set-up probe runs all_to_all_single
+    ONLY -- a list-form all_to_all that hangs or fails on one rank cannot take such a job down at set-up.  Here the list form
+    raises whenever it is entered ("refuse") and the spy counts its calls: none, on any rank, and the run's results are the same."""
     import json
     import subprocess
-    out = subprocess.run([sys.executable, os.path.join(HERE, "threaded_pg_worker.py"), "3", "refuse_force_split"],
+    out = subprocess.run([sys.executable, os.path.join(HERE, "threaded_pg_worker.py"), "3", mode],
                          capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     j = json.loads(out.stdout.strip().splitlines()[-1])
     assert j["ok"] and j["loss_rel_err"] < 1e-5 and j["table_max_err"] < 2e-6 and j["dense_identical_across_ranks"]
     assert j["list_form"] == [False] * 3 and j["list_collectives_per_rank"] == [0, 0, 0]
-    assert "'forced': 'split'" in out.stderr and "'remote'" not in out.stderr
+    assert ("'forced': 'split'" if mode.endswith("split") else "'forced': None") in out.stderr and "'remote'" not in out.stderr
 
 
 # ---- an id outside the table on ONE rank: rejected on EVERY rank before the step starts (score.py:51-66) -------------

@@ -30,7 +30,9 @@ def main(world=3, refuse=False, force=None):
     from cpu_backend import CpuBackend
     from helpers import random_batch, batch_tuple, NAMES
     if force:
-        os.environ["SCORE_A2A"] = force           # (what bench.py --a2a sets: only that form may ever be entered)
+        os.environ["SCORE_A2A"] = force           # (what bench.py --a2a sets)
+    else:
+        os.environ.pop("SCORE_A2A", None)
     cfg_args = (203, 4, 8, 3, 3, 3, 4)            # odd N: the last shards are padded
     cfg = so.Cfg(*cfg_args, model_type="SCORE")
     params = so.init_params(cfg, 5)
@@ -97,5 +99,8 @@ def main(world=3, refuse=False, force=None):
 
 if __name__ == "__main__":
     mode = sys.argv[2] if len(sys.argv) > 2 else ""
-    sys.exit(main(int(sys.argv[1]) if len(sys.argv) > 1 else 3, refuse=mode in ("refuse", "refuse_force_split"),
-                  force="split" if mode.endswith("force_split") else None))
+    # modes: "" (nothing asked: the split form), "force_remote", "refuse_probe" (SCORE_A2A=probe, the list form raises),
+    # "refuse" (nothing asked, the list form raises if entered), "refuse_force_split"
+    sys.exit(main(int(sys.argv[1]) if len(sys.argv) > 1 else 3, refuse=mode.startswith("refuse"),
+                  force="split" if mode.endswith("force_split") else "remote" if mode.endswith("force_remote")
+                  else "probe" if mode.endswith("probe") else None))
