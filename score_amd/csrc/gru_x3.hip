@@ -22,6 +22,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int XH = 128, XNW = 8, XRB = 16;
+#ifndef XG_PREFETCH
+#define XG_PREFETCH 3        // steps of look-ahead of the forward kernel's L2 prefetch (0: none); 3: +0.7 % at cfg-3, five pairs
+#endif
 constexpr int XKS = XH / 32;          // k-steps of 32
 constexpr int XLD = XH + 8;           // bf16 per LDS row of a [16][H] plane
 constexpr int XLD2 = 2 * XH + 8;      //                      a [16][2H] plane
@@ -166,12 +169,27 @@ __global__ __launch_bounds__(64 * XNW) void gru_fwd_x3_kernel(const GruArgs a) {
     for (int r = 0; r < 4; ++r) x[g][r] = ldg(sd.xproj, u3, rb3[r]);
   };
   fetch_x(0, 0); fetch_x(1, 0); fetch_x(2, 0);
+#if XG_PREFETCH
+  // The x-projection rows of step t + XG_PREFETCH pulled towards the L2 a few steps ahead of the loads above: ONE load per wave and
+  // step whose lanes each touch one 128-B line (16 samples x 12 lines per step and workgroup = 24 lines per wave), its value
+  // folded into a word nobody reads.  The loads above run one step ahead -- enough alone on the chip with warm caches (50 us), not
+  // from HBM (66 us with the caches flushed, 54 with this) and not beside the occurrence sort on the other stream
+  // (tools/gru_contention_probe.py).  The backward kernel's twin measured slower (profiles/r06_probes.md section 11).
+  const int pfl = min(lane, 23), pfL = wave * 24 + pfl;
+  const uint32_t pfoff = (uint32_t)(((int64_t)min(b0 + pfL / 12, a.B - 1) * T * 3 * H) * 4 + (pfL % 12) * 128);
+  float pfv = 0.f;
+  uint32_t pfsink = 0;
+#endif
   const int aoff = lc * XLD + 8 * lq;
   // The first step is peeled: at the loop header the compiler's s_waitcnt placement merges the state of the
   // prologue (loads with nothing behind them) with the back edge's (loads with the step's sixteen stores behind
   // them) and keeps the stricter count, so every step waited for the previous step's stores to be acknowledged.
   auto step = [&](const int t) {
     const int64_t u3 = (int64_t)t * 3 * H * 4;
+#if XG_PREFETCH
+    pfsink ^= __float_as_uint(pfv);
+    pfv = ldg(sd.xproj, (int64_t)min(t + XG_PREFETCH, T - 1) * 3 * H * 4, pfoff);
+#endif
     // gates = sigmoid(xproj[:, :2H] + h . Wg)
     f32x4 ar = {0.f, 0.f, 0.f, 0.f}, au = {0.f, 0.f, 0.f, 0.f};
     {
@@ -228,6 +246,9 @@ __global__ __launch_bounds__(64 * XNW) void gru_fwd_x3_kernel(const GruArgs a) {
   };
   step(0);
   for (int t = 1; t < T; ++t) step(t);
+#if XG_PREFETCH
+  asm volatile("" : : "v"(pfsink ^ __float_as_uint(pfv)));     // (keeps the prefetch loads alive: an empty statement that "reads" them)
+#endif
   if (sd.final_state) {
 #pragma unroll
     for (int r = 0; r < 4; ++r)
