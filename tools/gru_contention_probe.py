@@ -15,7 +15,7 @@ out, gates = torch.zeros(2, B * T, H, device="cuda"), torch.zeros(2, B * T, 3 * 
 dout, dxproj, rh, hprev = r(2, B * T, H), torch.zeros(2, B * T, 3 * H, device="cuda"), torch.zeros(2, B * T, H, device="cuda"), torch.zeros(2, B * T, H, device="cuda")
 P = lambda t: C.c_void_p(t.data_ptr())
 libs = {}
-VARIANTS = [("full", []), ("noxload", ["-DXGP_NOXLOAD"]), ("nostore", ["-DXGP_NOSTORE"]), ("nomem", ["-DXGP_NOSTORE", "-DXGP_NOXLOAD"])] + [("pf%d" % k, ["-DXG_PREFETCH=%d" % k]) for k in (2, 3, 4, 6)] + [("glds%d" % k, ["-DXG_GLDS=%d" % k]) for k in (2, 3, 4)]
+VARIANTS = [("full", []), ("noxload", ["-DXGP_NOXLOAD"]), ("nostore", ["-DXGP_NOSTORE"]), ("nomem", ["-DXGP_NOSTORE", "-DXGP_NOXLOAD"])] + [("pf%d" % k, ["-DXG_PREFETCH=%d" % k]) for k in (0, 2, 4, 6)]
 if len(sys.argv) > 1:
     VARIANTS = [v for v in VARIANTS if v[0] in sys.argv[1:]]
 for name, defs in VARIANTS:
