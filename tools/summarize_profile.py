@@ -18,7 +18,8 @@ import sys
 
 
 def stats(src, out):
-    f = glob.glob(src + "/*/*_kernel_stats.csv")[0]
+    import os
+    f = max(glob.glob(src + "/*/*_kernel_stats.csv"), key=os.path.getmtime)      # (a re-used output directory keeps older processes' files)
     rows = list(csv.DictReader(open(f)))
     with open(out, "w") as o:
         w = csv.writer(o)
@@ -29,7 +30,8 @@ def stats(src, out):
 
 
 def _per_kernel(d, counter):
-    f = glob.glob(d + "/*/*_counter_collection.csv")[0]
+    import os
+    f = max(glob.glob(d + "/*/*_counter_collection.csv"), key=os.path.getmtime)
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == counter:
