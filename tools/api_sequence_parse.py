@@ -16,9 +16,9 @@ rows = []
 for r in api:
     n = opname(r)
     d = disp.get(r["correlation_id"]["internal"])
-    k = ksym.get(d["dispatch_info"]["kernel_id"], "?").split("(")[0][-50:] if d else ""
+    k = ksym.get(d["dispatch_info"]["kernel_id"], "?").replace("(anonymous namespace)::", "").split("(")[0][-50:] if d else ""
     rows.append((n, r.get("stream_id", {}).get("handle"), k, r))
-idx = [i for i, x in enumerate(rows) if "coattn_fwd_kernel" in x[2]]
+idx = [i for i, x in enumerate(rows) if "ps_fwd_kernel" in x[2]] or [i for i, x in enumerate(rows) if "coattn_fwd_kernel" in x[2]]
 pick = int(sys.argv[2]) if len(sys.argv) > 2 else len(idx) // 2
 a, b = idx[pick], idx[pick + 1]
 # start the listing behind the previous step's last launch
